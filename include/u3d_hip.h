@@ -1,0 +1,164 @@
+/*
+ * libu3d_hip.so — C ABI of the MI355X-native Uni3DETR detection hot path.
+ *
+ * Every entry point: plain device pointers + explicit sizes + a hipStream_t; returns 0 or a negative
+ * U3D_ERR_* code (u3d_strerror); never throws, never allocates device memory, never synchronises the
+ * stream, keeps no global mutable state.  The caller (the ctypes host layer in uni3detr_amd/native.py,
+ * or any other FFI) owns every buffer.  Citations `ref:` are paths under the reference repository
+ * (zhenyuw16/Uni3DETR) naming the Python call site / upstream op each function replaces.
+ *
+ * Target: gfx950 only.
+ */
+#ifndef U3D_HIP_H_
+#define U3D_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* u3d_stream;   /* == hipStream_t */
+
+enum {
+  U3D_OK = 0,
+  U3D_ERR_ARG = -1,        /* bad argument (null pointer, size out of range)        */
+  U3D_ERR_UNSUPPORTED = -2,/* shape / dtype combination not compiled in              */
+  U3D_ERR_LAUNCH = -3,     /* hipGetLastError() != hipSuccess after a launch         */
+  U3D_ERR_WORKSPACE = -4   /* workspace too small                                    */
+};
+
+enum { U3D_F32 = 0, U3D_BF16 = 1 };
+
+int32_t u3d_version(void);
+const char* u3d_strerror(int32_t code);
+
+/* ------------------------------------------------------------------------------------------------
+ * Occupancy lattice ("BitGrid").  One 64-bit word per 4x4x4 block of cells, bit = (z&3)*16+(y&3)*4+(x&3),
+ * word = ((b*bz + z/4)*by + y/4)*bx + x/4 with bz=ceil(dz/4) etc.  `prefix` = exclusive popcount scan
+ * (nwords+1 entries).  The rank of a set bit is the row index of that voxel at this sparse level.
+ * Replaces the hash-table indice-pair builder of spconv (ref: models/pts_encoder/sparse_encoder_hd.py:9-12,
+ * upstream ext.get_indice_pairs_*).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct u3d_bitgrid {
+  void* words;      /* uint64 [nwords]   */
+  void* prefix;     /* uint32 [nwords+1] */
+  int32_t batch, dz, dy, dx;
+} u3d_bitgrid;
+
+int64_t u3d_bitgrid_nwords(int32_t batch, int32_t dz, int32_t dy, int32_t dx);
+
+/* words must be zeroed by the caller (hipMemsetAsync) before marking. coors: int32 [n,4] (b,z,y,x);
+ * rows with b < 0 are ignored. */
+int32_t u3d_bitgrid_mark(const u3d_bitgrid* g, const int32_t* coors, int32_t n, u3d_stream s);
+
+/* Mark every output site of a strided sparse conv whose window touches an active input:
+ * o = (i + pad - kappa) / stride when divisible and inside `g` (ref: SURVEY.md App. A4 active-set rule;
+ * sparse_encoder_hd.py:181-192).  n_dev: device int32 count of valid rows in `in_coors` (<= n_cap). */
+int32_t u3d_bitgrid_mark_strided(const u3d_bitgrid* g, const int32_t* in_coors, const int32_t* n_dev,
+                                 int32_t n_cap, const int32_t ksize[3], const int32_t stride[3],
+                                 const int32_t pad[3], u3d_stream s);
+
+/* prefix[] from words[]; scratch: uint32 [u3d_bitgrid_scan_scratch(nwords)] ; total count lands in
+ * prefix[nwords] (device). */
+int64_t u3d_bitgrid_scan_scratch(int64_t nwords);
+int32_t u3d_bitgrid_scan(const u3d_bitgrid* g, void* scratch, u3d_stream s);
+
+/* rank[i] = row index of coors[i] in g (or -1). */
+int32_t u3d_bitgrid_rank(const u3d_bitgrid* g, const int32_t* coors, int32_t n, int32_t* rank, u3d_stream s);
+
+/* Enumerate occupied cells in rank order: coors_out int32 [count,4] (b,z,y,x); cap = rows available. */
+int32_t u3d_bitgrid_coords(const u3d_bitgrid* g, int32_t* coors_out, int32_t cap, u3d_stream s);
+
+/* Neighbour table ("rulebook") nbr[kappa][ld] int32, kappa = (kz*k1 + ky)*k2 + kx, -1 = no partner.
+ *   mode 0 (gather/forward): partner of query q at kappa = target cell  q*stride - pad + kappa
+ *       (SubMConv3d: stride 1, pad (k-1)/2, target == query grid; SparseConv3d forward: query = output sites).
+ *   mode 1 (transposed/dgrad): partner = (q + pad - kappa)/stride when divisible (query = input sites,
+ *       target = output grid).
+ * n_dev: device count of valid query rows; rows >= *n_dev get -1.  ld >= n_cap.
+ * Replaces upstream indice_pairs (ref: SURVEY.md §8a a-4; sparse_encoder_hd.py:195-199 builds them per conv). */
+int32_t u3d_nbr_table(const u3d_bitgrid* target, const int32_t* q_coors, const int32_t* n_dev, int32_t n_cap,
+                      const int32_t ksize[3], const int32_t stride[3], const int32_t pad[3], int32_t mode,
+                      int32_t* nbr, int32_t ld, u3d_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Hard voxelization + mean VFE (ref: models/detectors/uni3detr.py:148-149; upstream mmcv Voxelization
+ * hard mode + HardSimpleVFE).  Sequential semantics reproduced exactly: voxels in
+ * first-appearance point order, first `max_points` points per voxel in point order, at most `max_voxels`
+ * voxels per scene.
+ *   points      f32 [n_total, nfeat], scenes concatenated; scene_off int32 [B+1] (device)
+ *   voxel_size/pc_range: host arrays (x,y,z) / (x0,y0,z0,x1,y1,z1)
+ *   outputs (capacity B*max_voxels rows, scene-major, compacted):
+ *     voxels  f32 [cap, max_points, nfeat] or NULL, coors int32 [cap,4] (b,z,y,x), num_points int32 [cap],
+ *     mean    f32 [cap, nfeat] or NULL (sum of kept points / count),
+ *     voxel_off int32 [B+1] device (row offsets per scene; voxel_off[B] = total)
+ *   workspace: u3d_voxelize_hard_workspace(n_total, B) bytes, caller-zeroing NOT required.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t u3d_voxelize_hard_workspace(int32_t n_total, int32_t batch, int32_t max_pts_per_scene);
+int32_t u3d_voxelize_hard(const float* points, const int32_t* scene_off, int32_t batch, int32_t n_total,
+                          int32_t max_pts_per_scene, int32_t nfeat, const float voxel_size[3],
+                          const float pc_range[6], int32_t max_points, int32_t max_voxels,
+                          float* voxels, int32_t* coors, int32_t* num_points, float* mean,
+                          int32_t* voxel_off, void* workspace, int64_t workspace_bytes, u3d_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sparse convolution as output-stationary implicit GEMM over the neighbour table
+ *   out[m,:] = sum_kappa  in[nbr[kappa][m], :] @ W[kappa]        (W: [K, Cin, Cout], K = 27 or 1)
+ * Covers SubMConv3d, SparseConv3d forward (nbr mode 0) and both dgrads (nbr mode 1 + transpose_w=1,
+ * which reads W[kappa] as [Cout_of_fwd x Cin_of_fwd]^T).  nbr == NULL means identity (1x1x1 conv).
+ * (ref: sparse_encoder_hd.py:71-104,181-199; upstream ext.indice_conv_forward/backward.)
+ * dtype U3D_F32: exact-f32 MFMA (v_mfma_f32_16x16x4_f32); U3D_BF16: bf16 operands, f32 accumulate.
+ * n_out_dev: device count of valid output rows (<= n_out_cap).
+ * ---------------------------------------------------------------------------------------------- */
+int32_t u3d_spconv_fwd(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,
+                       const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
+                       int32_t transpose_w, int32_t dtype, u3d_stream s);
+
+/* dW[kappa] = sum_m in[nbr[kappa][m],:]^T @ dout[m,:]   (f32 accumulate, dW f32 [K,Cin,Cout], overwritten).
+ * workspace: u3d_spconv_wgrad_workspace() bytes. */
+int64_t u3d_spconv_wgrad_workspace(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol);
+int32_t u3d_spconv_wgrad(const void* in, const void* dout, const int32_t* nbr, int32_t ld, float* dw,
+                         const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
+                         int32_t dtype, void* workspace, int64_t workspace_bytes, u3d_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm1d over sparse rows [n, C] (training statistics) with optional residual add and ReLU
+ * (ref: sparse_encoder_hd.py:40; upstream make_sparse_convmodule / SparseBasicBlock).
+ * stats: sums f64 [2*C] = (sum x, sum x^2), deterministic two-stage reduction.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t u3d_bn_stats_workspace(int32_t n_cap, int32_t c);
+int32_t u3d_bn_stats(const void* x, const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype,
+                     double* sums, void* workspace, int64_t workspace_bytes, u3d_stream s);
+/* y = relu?( (x-mean)*invstd*gamma + beta (+ residual) ); mean/invstd/gamma/beta f32 [C]. */
+int32_t u3d_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, const void* residual, int32_t relu, void* y,
+                     const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, u3d_stream s);
+/* backward: given dy (grad wrt y), y (for relu mask), x: sums f64 [2*C] = (sum g, sum g*xhat) where
+ * g = dy * (y>0 if relu). */
+int32_t u3d_bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                         int32_t relu, const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype,
+                         double* sums, void* workspace, int64_t workspace_bytes, u3d_stream s);
+/* dx = gamma*invstd*( g - sum_g/n - xhat*sum_gx/n ); dres = g (optional, may be NULL). */
+int32_t u3d_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                         const float* gamma, const double* sums, int32_t relu, void* dx, void* dres,
+                         const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, u3d_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * SparseConvTensor.dense() (ref: sparse_encoder_hd.py:133): rows -> channels-last dense volume
+ * dense[b, z, y, x, :] (= a torch channels_last_3d tensor of logical shape [B,C,D,H,W]); caller zeroes it.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t u3d_to_dense(const void* feat, const int32_t* coors, const int32_t* n_dev, int32_t n_cap, int32_t c,
+                     void* dense, int32_t dz, int32_t dy, int32_t dx, int32_t dtype, u3d_stream s);
+int32_t u3d_from_dense(const void* dense, const int32_t* coors, const int32_t* n_dev, int32_t n_cap, int32_t c,
+                       void* feat, int32_t dz, int32_t dy, int32_t dx, int32_t dtype, u3d_stream s);
+
+/* row gather / permutation: out[i,:] = in[idx[i],:] (idx<0 -> zeros). elem_bytes*c must be a multiple of 4 */
+int32_t u3d_gather_rows(const void* in, const int32_t* idx, int32_t n, int32_t row_bytes, void* out, u3d_stream s);
+/* out[idx[i],:] = in[i,:]  (idx<0 skipped; idx must be injective) */
+int32_t u3d_scatter_rows(const void* in, const int32_t* idx, int32_t n, int32_t row_bytes, void* out, u3d_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* U3D_HIP_H_ */

@@ -1,0 +1,253 @@
+"""GPU parity: HIP geometry + sparse conv + BN + dense vs the CPU oracle (oracle/geometry.py).
+Integer results bit-exact (canonical order), fp32 features within 1e-4 relative (MFMA f32 is an exact fma chain;
+the difference to torch-CPU is summation order only)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import geometry as og
+from uni3detr_amd import native as nv
+from uni3detr_amd.synth import room_scene, uniform_scene, SUNRGBD_RANGE, SUNRGBD_VOXEL
+
+pytestmark = pytest.mark.gpu
+
+
+def _scenes(n, npts=20000, kind="room"):
+    return [room_scene(i, npts)[0] if kind == "room" else uniform_scene(i, npts) for i in range(n)]
+
+
+def _upload(points_list, dev):
+    off = np.cumsum([0] + [p.shape[0] for p in points_list]).astype(np.int32)
+    pts = torch.from_numpy(np.concatenate(points_list)).to(dev)
+    return pts, torch.from_numpy(off).to(dev)
+
+
+@pytest.mark.parametrize("kind,npts,max_voxels", [("room", 20000, 16000), ("uniform", 20000, 16000), ("room", 3000, 40000),
+                                                  ("room", 20000, 40000)])
+def test_voxelize_hard_bit_exact(cuda, kind, npts, max_voxels):
+    pl = _scenes(2, npts, kind)
+    # ragged: second scene shorter, with out-of-range and NaN points mixed in
+    pl[1] = pl[1][: npts - 777].copy()
+    pl[1][5, 0] = 100.0
+    pl[1][6, 2] = np.nan
+    pts, off = _upload(pl, cuda)
+    vox, coors, num, mean, voff = nv.voxelize_hard(pts, off, 2, max(p.shape[0] for p in pl), SUNRGBD_VOXEL, SUNRGBD_RANGE, 5,
+                                                  max_voxels)
+    voff = voff.cpu().numpy()
+    rv, rc, rn = og.voxelize_batch(pl, SUNRGBD_VOXEL, SUNRGBD_RANGE, 5, max_voxels)
+    assert voff[-1] == rc.shape[0]
+    n = int(voff[-1])
+    assert np.array_equal(coors[:n].cpu().numpy(), rc)
+    assert np.array_equal(num[:n].cpu().numpy(), rn)
+    assert np.array_equal(vox[:n].cpu().numpy(), rv)          # exact copies of the kept points
+    rm = og.vfe_mean(rv, rn, 4)
+    np.testing.assert_allclose(mean[:n].cpu().numpy(), rm, rtol=1e-6, atol=1e-7)
+
+
+def test_voxelize_empty_scene(cuda):
+    pl = [room_scene(0, 500)[0], np.full((10, 4), 50.0, np.float32)]   # second scene entirely out of range
+    pts, off = _upload(pl, cuda)
+    vox, coors, num, mean, voff = nv.voxelize_hard(pts, off, 2, 500, SUNRGBD_VOXEL, SUNRGBD_RANGE, 5, 16000)
+    voff = voff.cpu().numpy()
+    rv, rc, rn = og.voxelize_batch(pl, SUNRGBD_VOXEL, SUNRGBD_RANGE, 5, 16000)
+    assert voff[2] == voff[1] == rc.shape[0]
+    assert np.array_equal(coors[: voff[2]].cpu().numpy(), rc)
+
+
+def _level0(cuda, batch=2, npts=6000):
+    pl = _scenes(batch, npts)
+    _, rc, _ = og.voxelize_batch(pl, SUNRGBD_VOXEL, SUNRGBD_RANGE, 5, 16000)
+    return rc
+
+
+def test_bitgrid_rank_and_coords(cuda):
+    rc = _level0(cuda)
+    dims = (128, 320, 320)
+    coors = torch.from_numpy(rc).to(cuda)
+    g = nv.BitGrid(2, dims, cuda)
+    g.mark(coors)
+    g.scan()
+    assert int(g.count_dev.item()) == rc.shape[0]
+    rank = g.rank(coors).cpu().numpy()
+    order = og.block_major_order(rc, dims)
+    expect = np.empty_like(order)
+    expect[order] = np.arange(order.shape[0])
+    assert np.array_equal(rank, expect)
+    cc = g.coords(rc.shape[0]).cpu().numpy()
+    assert np.array_equal(cc, rc[order])
+    # a coordinate that is not occupied ranks -1
+    q = torch.tensor([[0, 127, 319, 319], [1, 0, 0, 0], [5, 0, 0, 0]], dtype=torch.int32, device=cuda)
+    r2 = g.rank(q).cpu().numpy()
+    occupied = {tuple(r) for r in rc.tolist()}
+    for row, r in zip(q.cpu().tolist(), r2):
+        assert (r >= 0) == (tuple(row) in occupied)
+
+
+def _canon_table(nbr, q_coors, t_coors):
+    """table of indices -> table of partner coordinates keyed by query coordinate (order independent)."""
+    K = nbr.shape[0]
+    res = {}
+    for i, q in enumerate(map(tuple, q_coors.tolist())):
+        res[q] = tuple(tuple(t_coors[nbr[k, i]].tolist()) if nbr[k, i] >= 0 else None for k in range(K))
+    return res
+
+
+@pytest.mark.parametrize("pad", [(1, 1, 1), (0, 1, 1)])
+def test_rulebook_bit_exact_canonical(cuda, pad):
+    rc = _level0(cuda, 2, 3000)
+    dims = (128, 320, 320)
+    k3, s1, s2, p1 = (3, 3, 3), (1, 1, 1), (2, 2, 2), (1, 1, 1)
+    coors = torch.from_numpy(rc).to(cuda)
+    g0 = nv.BitGrid(2, dims, cuda)
+    g0.mark(coors); g0.scan()
+    n0 = rc.shape[0]
+    c0 = g0.coords(n0)
+    n0_dev = g0.count_dev
+    # SubM table
+    nbr = g0.nbr_table(c0, n0_dev, k3, s1, p1, 0).cpu().numpy()[:, :n0]
+    c0n = c0.cpu().numpy()
+    ref = og.nbr_table(c0n, c0n, dims, k3, s1, p1, 0)
+    assert np.array_equal(nbr, ref)
+    # strided level
+    ro, dims1 = og.strided_out_coords(rc, dims, k3, s2, pad)
+    g1 = nv.BitGrid(2, dims1, cuda)
+    g1.mark_strided(c0, n0_dev, k3, s2, pad); g1.scan()
+    n1 = int(g1.count_dev.item())
+    assert n1 == ro.shape[0]
+    c1 = g1.coords(n1)
+    c1n = c1.cpu().numpy()
+    assert np.array_equal(c1n[np.lexsort((c1n[:, 3], c1n[:, 2], c1n[:, 1], c1n[:, 0]))], ro)   # same active set
+    fwd = g0.nbr_table(c1, g1.count_dev, k3, s2, pad, 0).cpu().numpy()[:, :n1]
+    assert np.array_equal(fwd, og.nbr_table(c1n, c0n, dims, k3, s2, pad, 0))
+    bwd = g1.nbr_table(c0, n0_dev, k3, s2, pad, 1).cpu().numpy()[:, :n0]
+    assert np.array_equal(bwd, og.nbr_table(c0n, c1n, dims1, k3, s2, pad, 1))
+    # pair-set symmetry: (i -> o at kappa) in fwd  <=>  (o -> i at kappa) in bwd
+    ks, os_ = np.nonzero(fwd >= 0)
+    assert np.array_equal(bwd[ks, fwd[ks, os_]], os_)
+    assert (fwd >= 0).sum() == (bwd >= 0).sum()
+
+
+CONV_CASES = [(4, 16, 27), (16, 16, 27), (16, 32, 27), (32, 32, 27), (32, 64, 27), (64, 64, 27), (64, 128, 27),
+              (128, 128, 27), (128, 256, 1)]
+
+
+@pytest.mark.parametrize("cin,cout,kvol", CONV_CASES)
+def test_spconv_fwd_bwd_f32(cuda, cin, cout, kvol):
+    torch.manual_seed(cin * 1000 + cout)
+    rc = _level0(cuda, 2, 2500)
+    dims = (128, 320, 320)
+    k3, s1, p1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    coors = torch.from_numpy(rc).to(cuda)
+    g0 = nv.BitGrid(2, dims, cuda)
+    g0.mark(coors); g0.scan()
+    n = rc.shape[0]
+    c0 = g0.coords(n)
+    nd = g0.count_dev
+    if kvol == 27:
+        nbr = g0.nbr_table(c0, nd, k3, s1, p1, 0)
+        nbr_t = g0.nbr_table(c0, nd, k3, s1, p1, 1)
+        ref_nbr = nbr.cpu().numpy()[:, :n].astype(np.int64)
+    else:
+        nbr = nbr_t = None
+        ref_nbr = np.arange(n, dtype=np.int64)[None]
+    x = torch.randn(n, cin)
+    w = torch.randn(kvol, cin, cout) * (1.0 / np.sqrt(cin * min(kvol, 9)))
+    gy = torch.randn(n, cout)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = og.sparse_conv(xr, wr, ref_nbr)
+    yr.backward(gy)
+    xd, wd, gyd = x.to(cuda), w.to(cuda), gy.to(cuda)
+    y = nv.spconv_fwd(xd, wd, nbr, nd, n, cout)
+    scale = yr.abs().max().item()
+    assert (y.cpu() - yr.detach()).abs().max().item() <= 1e-4 * scale
+    dx = nv.spconv_fwd(gyd, wd, nbr_t, nd, n, cin, transpose_w=True)
+    assert (dx.cpu() - xr.grad).abs().max().item() <= 1e-4 * xr.grad.abs().max().item()
+    dw = nv.spconv_wgrad(xd, gyd, nbr, nd, kvol)
+    assert (dw.cpu() - wr.grad).abs().max().item() <= 1e-4 * wr.grad.abs().max().item()
+
+
+def test_spconv_strided_f32(cuda):
+    torch.manual_seed(7)
+    rc = _level0(cuda, 2, 2500)
+    dims = (128, 320, 320)
+    k3, s2, pad = (3, 3, 3), (2, 2, 2), (1, 1, 1)
+    coors = torch.from_numpy(rc).to(cuda)
+    g0 = nv.BitGrid(2, dims, cuda)
+    g0.mark(coors); g0.scan()
+    n0 = rc.shape[0]
+    c0 = g0.coords(n0)
+    dims1 = og.conv_out_dims(dims, k3, s2, pad)
+    g1 = nv.BitGrid(2, dims1, cuda)
+    g1.mark_strided(c0, g0.count_dev, k3, s2, pad); g1.scan()
+    n1 = int(g1.count_dev.item())
+    c1 = g1.coords(n1)
+    fwd = g0.nbr_table(c1, g1.count_dev, k3, s2, pad, 0)
+    bwd = g1.nbr_table(c0, g0.count_dev, k3, s2, pad, 1)
+    cin, cout = 16, 32
+    x = torch.randn(n0, cin); w = torch.randn(27, cin, cout) * 0.1; gy = torch.randn(n1, cout)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = og.sparse_conv(xr, wr, fwd.cpu().numpy()[:, :n1].astype(np.int64))
+    yr.backward(gy)
+    y = nv.spconv_fwd(x.to(cuda), w.to(cuda), fwd, g1.count_dev, n1, cout)
+    assert (y.cpu() - yr.detach()).abs().max().item() <= 1e-4 * yr.abs().max().item()
+    dx = nv.spconv_fwd(gy.to(cuda), w.to(cuda), bwd, g0.count_dev, n0, cin, transpose_w=True)
+    assert (dx.cpu() - xr.grad).abs().max().item() <= 1e-4 * xr.grad.abs().max().item()
+    dw = nv.spconv_wgrad(x.to(cuda), gy.to(cuda), fwd, g1.count_dev, 27)
+    assert (dw.cpu() - wr.grad).abs().max().item() <= 1e-4 * wr.grad.abs().max().item()
+    # property: equals the dense conv3d restricted to the active output set
+    dense = og.dense_conv_reference(x, c0.cpu().numpy(), dims, w, k3, s2, pad, 2)
+    c1l = c1.cpu().long()
+    sel = dense[c1l[:, 0], :, c1l[:, 1], c1l[:, 2], c1l[:, 3]]
+    assert (y.cpu() - sel).abs().max().item() <= 1e-4 * sel.abs().max().item()
+    mask = torch.zeros_like(dense[:, 0], dtype=torch.bool)
+    mask[c1l[:, 0], c1l[:, 1], c1l[:, 2], c1l[:, 3]] = True
+    assert dense.abs().sum(1)[~mask].max().item() == 0.0     # nothing outside the active set
+
+
+@pytest.mark.parametrize("c,relu,res", [(16, True, False), (64, True, True), (256, True, False), (32, False, False)])
+def test_bn_fwd_bwd(cuda, c, relu, res):
+    torch.manual_seed(c)
+    n = 5000
+    x = torch.randn(n, c) * 2 + 0.5
+    gamma, beta = torch.rand(c) + 0.5, torch.randn(c) * 0.1
+    r = torch.randn(n, c) if res else None
+    gy = torch.randn(n, c)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    yr = og.bn_train(xr, gr, br, 1e-3, rr, relu)
+    yr.backward(gy)
+    nd = torch.tensor([n], dtype=torch.int32, device=cuda)
+    xd = x.to(cuda)
+    sums = nv.bn_stats(xd, nd)
+    mean = (sums[0] / n)
+    var = (sums[1] / n - mean * mean).clamp_min(0)
+    np.testing.assert_allclose(mean.cpu().numpy(), x.double().mean(0).numpy(), rtol=1e-6, atol=1e-7)
+    invstd = (1.0 / torch.sqrt(var + 1e-3)).float()
+    meanf = mean.float()
+    y = nv.bn_apply(xd, meanf, invstd, gamma.to(cuda), beta.to(cuda), r.to(cuda) if res else None, relu, nd)
+    assert (y.cpu() - yr.detach()).abs().max().item() <= 2e-5 * max(1.0, yr.abs().max().item())
+    gyd = gy.to(cuda)
+    bs = nv.bn_bwd_stats(gyd, y, xd, meanf, invstd, relu, nd)
+    dx, dres = nv.bn_bwd_apply(gyd, y, xd, meanf, invstd, gamma.to(cuda), bs, relu, nd, res)
+    assert (dx.cpu() - xr.grad).abs().max().item() <= 5e-5 * max(1.0, xr.grad.abs().max().item())
+    dgamma, dbeta = bs[1].float().cpu(), bs[0].float().cpu()
+    np.testing.assert_allclose(dgamma.numpy(), gr.grad.numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(dbeta.numpy(), br.grad.numpy(), rtol=1e-4, atol=1e-3)
+    if res:
+        assert (dres.cpu() - rr.grad).abs().max().item() <= 1e-6
+
+
+def test_dense_roundtrip(cuda):
+    rc = _level0(cuda, 2, 1500)
+    dims = (15, 40, 40)
+    rng = np.random.default_rng(0)
+    cells = rng.choice(2 * 15 * 40 * 40, 3000, replace=False)
+    co = np.stack([cells // (15 * 1600), cells // 1600 % 15, cells // 40 % 40, cells % 40], 1).astype(np.int32)
+    f = torch.randn(3000, 256)
+    nd = torch.tensor([3000], dtype=torch.int32, device=cuda)
+    vol = nv.to_dense(f.to(cuda), torch.from_numpy(co).to(cuda), nd, 2, dims)
+    ref = og.to_dense(f, co, 2, dims)
+    assert vol.shape == ref.shape and torch.equal(vol.cpu(), ref)
+    back = nv.from_dense(vol.permute(0, 2, 3, 4, 1).contiguous(), torch.from_numpy(co).to(cuda), nd, 3000)
+    assert torch.equal(back.cpu(), f)

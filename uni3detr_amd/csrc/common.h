@@ -1,0 +1,71 @@
+// Shared device/host helpers for libu3d_hip.so (gfx950 / MI355X only).
+// No torch types anywhere below this line: raw device pointers, sizes, hipStream_t.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/u3d_hip.h"
+
+#define U3D_WAVE 64
+
+#define U3D_CHECK_LAUNCH()                                        \
+  do {                                                            \
+    hipError_t e__ = hipGetLastError();                           \
+    if (e__ != hipSuccess) return U3D_ERR_LAUNCH;                 \
+  } while (0)
+
+#define U3D_REQUIRE(cond, code) \
+  do {                          \
+    if (!(cond)) return (code); \
+  } while (0)
+
+static inline int u3d_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------
+// BitGrid: occupancy of a [B, Dz, Dy, Dx] voxel lattice, one 64-bit word per 4x4x4 block.
+// Row id of an occupied cell = prefix[word] + popcount(bits below it) ("block-major rank").
+// The rank order is the internal row order of every sparse level: rows that are close in
+// space are close in memory, so a 64-row tile of the conv kernel gathers from few lines.
+// ---------------------------------------------------------------------------------------
+struct BitGridDev {
+  const unsigned long long* words;
+  const unsigned int* prefix;  // exclusive popcount scan, nwords + 1 entries
+  int B, Dz, Dy, Dx;           // logical extent (cells)
+  int bz, by, bx;              // extent in 4x4x4 blocks
+};
+
+__host__ __device__ inline BitGridDev u3d_make_grid(const u3d_bitgrid* g) {
+  BitGridDev d;
+  d.words = (const unsigned long long*)g->words;
+  d.prefix = (const unsigned int*)g->prefix;
+  d.B = g->batch; d.Dz = g->dz; d.Dy = g->dy; d.Dx = g->dx;
+  d.bz = (g->dz + 3) >> 2; d.by = (g->dy + 3) >> 2; d.bx = (g->dx + 3) >> 2;
+  return d;
+}
+
+__device__ __forceinline__ long long u3d_word_index(const BitGridDev& g, int b, int z, int y, int x) {
+  return (((long long)b * g.bz + (z >> 2)) * g.by + (y >> 2)) * g.bx + (x >> 2);
+}
+__device__ __forceinline__ int u3d_bit_index(int z, int y, int x) {
+  return ((z & 3) << 4) | ((y & 3) << 2) | (x & 3);
+}
+// row id of (b,z,y,x) or -1 when out of range / unoccupied
+__device__ __forceinline__ int u3d_grid_lookup(const BitGridDev& g, int b, int z, int y, int x) {
+  if ((unsigned)z >= (unsigned)g.Dz || (unsigned)y >= (unsigned)g.Dy || (unsigned)x >= (unsigned)g.Dx) return -1;
+  long long w = u3d_word_index(g, b, z, y, x);
+  unsigned long long bits = g.words[w];
+  int bit = u3d_bit_index(z, y, x);
+  if (!((bits >> bit) & 1ull)) return -1;
+  return (int)(g.prefix[w] + __popcll(bits & ((1ull << bit) - 1ull)));
+}
+
+// wave-level helpers (wave = 64 lanes)
+__device__ __forceinline__ float u3d_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double u3d_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

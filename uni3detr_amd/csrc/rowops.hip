@@ -1,0 +1,224 @@
+// Row-wise ops on sparse feature matrices [n, C]: BatchNorm1d statistics / apply / backward,
+// densification.  All HBM-bound streaming kernels: 16-byte accesses, one pass per tensor.
+#include "common.h"
+#include <type_traits>
+
+typedef unsigned short u16;
+__device__ __forceinline__ float ld_elem(const float* p, long long i) { return p[i]; }
+__device__ __forceinline__ float ld_elem(const u16* p, long long i) { return __uint_as_float(((unsigned)p[i]) << 16); }
+__device__ __forceinline__ void st_elem(float* p, long long i, float v) { p[i] = v; }
+__device__ __forceinline__ void st_elem(u16* p, long long i, float v) {
+  unsigned u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) { p[i] = (u16)((u >> 16) | 0x40u); return; }
+  u += 0x7fffu + ((u >> 16) & 1u);
+  p[i] = (u16)(u >> 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// column statistics: each workgroup (256 threads) reduces a slab of rows for all C columns.
+// thread t owns column (t % CW) of row-lane (t / CW), CW = min(C, 256) ; partial sums in f64.
+// stage 1 -> partial[blocks][2][C] (f64), stage 2 -> sums[2][C] in block order (deterministic).
+// MODE 0: (x, x^2).  MODE 1: g = dy*(relu? y>0), (g, g*xhat).
+// ---------------------------------------------------------------------------------------------
+#define ST_ROWS_PER_BLOCK 512
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_col_stats(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+                                                   const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                   const int* __restrict__ n_dev, int n_cap, int c, double* __restrict__ partial) {
+  __shared__ double red[2][256];
+  const int n = min(*n_dev, n_cap);
+  const int cw = c < 256 ? c : 256;          // columns handled concurrently
+  const int rl = 256 / cw;                   // row lanes
+  const int tcol = threadIdx.x % cw, trow = threadIdx.x / cw;
+  const int r0 = blockIdx.x * ST_ROWS_PER_BLOCK;
+  const int r1 = min(n, r0 + ST_ROWS_PER_BLOCK);
+  for (int cb = 0; cb < c; cb += cw) {
+    int col = cb + tcol;
+    double s0 = 0.0, s1 = 0.0;
+    if (col < c && trow < rl) {
+      float mu = 0.f, is = 0.f;
+      if (MODE == 1) { mu = mean[col]; is = invstd[col]; }
+      for (int r = r0 + trow; r < r1; r += rl) {
+        long long o = (long long)r * c + col;
+        if (MODE == 0) {
+          float v = ld_elem(x, o);
+          s0 += (double)v;
+          s1 += (double)v * (double)v;
+        } else {
+          float g = ld_elem(dy, o);
+          if (relu && !(ld_elem(y, o) > 0.f)) g = 0.f;
+          float xh = (ld_elem(x, o) - mu) * is;
+          s0 += (double)g;
+          s1 += (double)g * (double)xh;
+        }
+      }
+    }
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (trow == 0 && col < c) {
+      double a0 = 0.0, a1 = 0.0;
+      for (int j = 0; j < rl; ++j) { a0 += red[0][j * cw + tcol]; a1 += red[1][j * cw + tcol]; }
+      partial[((long long)blockIdx.x * 2 + 0) * c + col] = a0;
+      partial[((long long)blockIdx.x * 2 + 1) * c + col] = a1;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void k_col_stats_final(const double* __restrict__ partial, int nblocks, const int* __restrict__ n_dev, int n_cap,
+                                  int c, double* __restrict__ sums) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * c) return;
+  int n = min(*n_dev, n_cap);
+  int used = (n + ST_ROWS_PER_BLOCK - 1) / ST_ROWS_PER_BLOCK;
+  if (used > nblocks) used = nblocks;
+  int which = i / c, col = i % c;
+  double s = 0.0;
+  for (int b = 0; b < used; ++b) s += partial[((long long)b * 2 + which) * c + col];
+  sums[i] = s;
+}
+
+extern "C" int64_t u3d_bn_stats_workspace(int32_t n_cap, int32_t c) {
+  return (int64_t)u3d_cdiv(n_cap > 0 ? n_cap : 1, ST_ROWS_PER_BLOCK) * 2 * c * 8;
+}
+
+template <int MODE>
+static int run_stats(const void* x, const void* dy, const void* y, const float* mean, const float* invstd, int relu,
+                     const int32_t* n_dev, int n_cap, int c, int dtype, double* sums, void* ws, int64_t ws_bytes, hipStream_t s) {
+  U3D_REQUIRE(x && n_dev && sums && ws && c > 0, U3D_ERR_ARG);
+  if (n_cap <= 0) { hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, s); return U3D_OK; }
+  U3D_REQUIRE(ws_bytes >= u3d_bn_stats_workspace(n_cap, c), U3D_ERR_WORKSPACE);
+  int nb = u3d_cdiv(n_cap, ST_ROWS_PER_BLOCK);
+  if (dtype == U3D_F32)
+    hipLaunchKernelGGL((k_col_stats<float, MODE>), dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, relu, n_dev, n_cap, c, (double*)ws);
+  else if (dtype == U3D_BF16)
+    hipLaunchKernelGGL((k_col_stats<u16, MODE>), dim3(nb), dim3(256), 0, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, relu, n_dev, n_cap, c, (double*)ws);
+  else return U3D_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_col_stats_final, dim3(u3d_cdiv(2 * c, 256)), dim3(256), 0, s, (const double*)ws, nb, n_dev, n_cap, c, sums);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+extern "C" int32_t u3d_bn_stats(const void* x, const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, double* sums,
+                                void* workspace, int64_t workspace_bytes, u3d_stream s) {
+  return run_stats<0>(x, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, dtype, sums, workspace, workspace_bytes, s);
+}
+extern "C" int32_t u3d_bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                                    int32_t relu, const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, double* sums,
+                                    void* workspace, int64_t workspace_bytes, u3d_stream s) {
+  U3D_REQUIRE(dy && mean && invstd && (!relu || y), U3D_ERR_ARG);
+  return run_stats<1>(x, dy, y, mean, invstd, relu, n_dev, n_cap, c, dtype, sums, workspace, workspace_bytes, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = relu?((x-mean)*invstd*gamma + beta (+res))      /     backward apply
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_bn_apply(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                           const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res, int relu,
+                           T* __restrict__ y, const int* __restrict__ n_dev, int n_cap, int c) {
+  long long total = (long long)min(*n_dev, n_cap) * c;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int col = (int)(i % c);
+    float v = (ld_elem(x, i) - mean[col]) * invstd[col] * gamma[col] + beta[col];
+    if (res) v += ld_elem(res, i);
+    if (relu) v = v > 0.f ? v : 0.f;
+    st_elem(y, i, v);
+  }
+}
+
+template <typename T>
+__global__ void k_bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+                               const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                               const double* __restrict__ sums, int relu, T* __restrict__ dx, T* __restrict__ dres,
+                               const int* __restrict__ n_dev, int n_cap, int c) {
+  int n = min(*n_dev, n_cap);
+  long long total = (long long)n * c;
+  double inv_n = n > 0 ? 1.0 / (double)n : 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int col = (int)(i % c);
+    float g = ld_elem(dy, i);
+    if (relu && !(ld_elem(y, i) > 0.f)) g = 0.f;
+    float is = invstd[col];
+    float xh = (ld_elem(x, i) - mean[col]) * is;
+    float mg = (float)(sums[col] * inv_n), mgx = (float)(sums[c + col] * inv_n);
+    st_elem(dx, i, gamma[col] * is * (g - mg - xh * mgx));
+    if (dres) st_elem(dres, i, g);
+  }
+}
+
+static inline int ew_grid(long long total) {
+  long long b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+extern "C" int32_t u3d_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                const void* residual, int32_t relu, void* y, const int32_t* n_dev, int32_t n_cap, int32_t c,
+                                int32_t dtype, u3d_stream s) {
+  U3D_REQUIRE(x && mean && invstd && gamma && beta && y && n_dev && c > 0, U3D_ERR_ARG);
+  if (n_cap <= 0) return U3D_OK;
+  int g = ew_grid((long long)n_cap * c);
+  if (dtype == U3D_F32)
+    hipLaunchKernelGGL(k_bn_apply<float>, dim3(g), dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const float*)residual, relu, (float*)y, n_dev, n_cap, c);
+  else if (dtype == U3D_BF16)
+    hipLaunchKernelGGL(k_bn_apply<u16>, dim3(g), dim3(256), 0, s, (const u16*)x, mean, invstd, gamma, beta, (const u16*)residual, relu, (u16*)y, n_dev, n_cap, c);
+  else return U3D_ERR_UNSUPPORTED;
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+extern "C" int32_t u3d_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                                    const float* gamma, const double* sums, int32_t relu, void* dx, void* dres,
+                                    const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, u3d_stream s) {
+  U3D_REQUIRE(dy && x && mean && invstd && gamma && sums && dx && n_dev && c > 0 && (!relu || y), U3D_ERR_ARG);
+  if (n_cap <= 0) return U3D_OK;
+  int g = ew_grid((long long)n_cap * c);
+  if (dtype == U3D_F32)
+    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(256), 0, s, (const float*)dy, (const float*)y, (const float*)x, mean, invstd, gamma, sums, relu, (float*)dx, (float*)dres, n_dev, n_cap, c);
+  else if (dtype == U3D_BF16)
+    hipLaunchKernelGGL(k_bn_bwd_apply<u16>, dim3(g), dim3(256), 0, s, (const u16*)dy, (const u16*)y, (const u16*)x, mean, invstd, gamma, sums, relu, (u16*)dx, (u16*)dres, n_dev, n_cap, c);
+  else return U3D_ERR_UNSUPPORTED;
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dense() / its adjoint: rows <-> channels-last volume [B, Dz, Dy, Dx, C]
+// ---------------------------------------------------------------------------------------------
+template <bool TO_DENSE>
+__global__ void k_dense_rows(const uint32_t* __restrict__ src, const int4* __restrict__ coors, const int* __restrict__ n_dev,
+                             int n_cap, int row_words, uint32_t* __restrict__ dst, int dz, int dy, int dx) {
+  long long total = (long long)min(*n_dev, n_cap) * row_words;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int r = (int)(t / row_words), w = (int)(t % row_words);
+    int4 c = coors[r];
+    long long cell = (((long long)c.x * dz + c.y) * dy + c.z) * dx + c.w;
+    if (TO_DENSE) dst[cell * row_words + w] = src[t];
+    else dst[t] = src[cell * row_words + w];
+  }
+}
+
+static int run_dense(bool to_dense, const void* a, const int32_t* coors, const int32_t* n_dev, int n_cap, int c, void* b, int dz,
+                     int dy, int dx, int dtype, hipStream_t s) {
+  U3D_REQUIRE(a && coors && n_dev && b && c > 0, U3D_ERR_ARG);
+  int row_bytes = c * (dtype == U3D_BF16 ? 2 : 4);
+  U3D_REQUIRE((row_bytes & 3) == 0, U3D_ERR_UNSUPPORTED);
+  if (n_cap <= 0) return U3D_OK;
+  int rw = row_bytes / 4;
+  int g = ew_grid((long long)n_cap * rw);
+  if (to_dense) hipLaunchKernelGGL(k_dense_rows<true>, dim3(g), dim3(256), 0, s, (const uint32_t*)a, (const int4*)coors, n_dev, n_cap, rw, (uint32_t*)b, dz, dy, dx);
+  else hipLaunchKernelGGL(k_dense_rows<false>, dim3(g), dim3(256), 0, s, (const uint32_t*)a, (const int4*)coors, n_dev, n_cap, rw, (uint32_t*)b, dz, dy, dx);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+extern "C" int32_t u3d_to_dense(const void* feat, const int32_t* coors, const int32_t* n_dev, int32_t n_cap, int32_t c,
+                                void* dense, int32_t dz, int32_t dy, int32_t dx, int32_t dtype, u3d_stream s) {
+  return run_dense(true, feat, coors, n_dev, n_cap, c, dense, dz, dy, dx, dtype, s);
+}
+extern "C" int32_t u3d_from_dense(const void* dense, const int32_t* coors, const int32_t* n_dev, int32_t n_cap, int32_t c,
+                                  void* feat, int32_t dz, int32_t dy, int32_t dx, int32_t dtype, u3d_stream s) {
+  return run_dense(false, dense, coors, n_dev, n_cap, c, feat, dz, dy, dx, dtype, s);
+}

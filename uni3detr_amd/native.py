@@ -1,0 +1,271 @@
+"""ctypes binding of libu3d_hip.so (C ABI declared in include/u3d_hip.h).
+
+PyTorch is used only as the owner of device memory and streams: every call passes raw `data_ptr()`s and the
+current HIP stream.  There is NO CPU fallback: if the library is missing or a call fails, we raise.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libu3d_hip.so")
+
+F32, BF16 = 0, 1
+
+
+class U3DError(RuntimeError):
+    pass
+
+
+class BitGridStruct(C.Structure):
+    _fields_ = [("words", C.c_void_p), ("prefix", C.c_void_p), ("batch", C.c_int32), ("dz", C.c_int32),
+                ("dy", C.c_int32), ("dx", C.c_int32)]
+
+
+_lib = None
+_P = C.c_void_p
+_I = C.c_int32
+_L = C.c_int64
+_I3 = C.c_int32 * 3
+_F3 = C.c_float * 3
+_F6 = C.c_float * 6
+
+_SIGS = {
+    # name: (restype, argtypes)
+    "u3d_version": (_I, []),
+    "u3d_strerror": (C.c_char_p, [_I]),
+    "u3d_bitgrid_nwords": (_L, [_I, _I, _I, _I]),
+    "u3d_bitgrid_mark": (_I, [C.POINTER(BitGridStruct), _P, _I, _P]),
+    "u3d_bitgrid_mark_strided": (_I, [C.POINTER(BitGridStruct), _P, _P, _I, _I3, _I3, _I3, _P]),
+    "u3d_bitgrid_scan_scratch": (_L, [_L]),
+    "u3d_bitgrid_scan": (_I, [C.POINTER(BitGridStruct), _P, _P]),
+    "u3d_bitgrid_rank": (_I, [C.POINTER(BitGridStruct), _P, _I, _P, _P]),
+    "u3d_bitgrid_coords": (_I, [C.POINTER(BitGridStruct), _P, _I, _P]),
+    "u3d_nbr_table": (_I, [C.POINTER(BitGridStruct), _P, _P, _I, _I3, _I3, _I3, _I, _P, _I, _P]),
+    "u3d_voxelize_hard_workspace": (_L, [_I, _I, _I]),
+    "u3d_voxelize_hard": (_I, [_P, _P, _I, _I, _I, _I, _F3, _F6, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "u3d_spconv_fwd": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "u3d_spconv_wgrad_workspace": (_L, [_I, _I, _I, _I]),
+    "u3d_spconv_wgrad": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "u3d_bn_stats_workspace": (_L, [_I, _I]),
+    "u3d_bn_stats": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _P]),
+    "u3d_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
+    "u3d_bn_bwd_stats": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
+    "u3d_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "u3d_to_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
+    "u3d_from_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
+    "u3d_gather_rows": (_I, [_P, _P, _I, _I, _P, _P]),
+    "u3d_scatter_rows": (_I, [_P, _P, _I, _I, _P, _P]),
+}
+
+
+def exported_symbols():
+    """Names every build of the library must export (checked by the CPU test-suite)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise U3DError(f"{LIB_PATH} is missing: run `python -m uni3detr_amd.build` (hipcc, gfx950). "
+                           "There is no CPU/PyTorch fallback for the HIP hot path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)   # AttributeError -> loud failure if a symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise U3DError(f"{what} failed: {lib().u3d_strerror(rc).decode()} ({rc})")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-contiguous tensor required"
+    return C.c_void_p(t.data_ptr())
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise U3DError(f"unsupported dtype {t.dtype}")
+
+
+# --------------------------------------------------------------------------------------------------
+# BitGrid
+# --------------------------------------------------------------------------------------------------
+class BitGrid:
+    """Occupancy lattice of one sparse level (see include/u3d_hip.h)."""
+
+    def __init__(self, batch, dims, device):
+        self.batch, self.dims = int(batch), tuple(int(d) for d in dims)
+        self.nwords = int(lib().u3d_bitgrid_nwords(self.batch, *self.dims))
+        self.words = torch.zeros(self.nwords, dtype=torch.int64, device=device)
+        self.prefix = torch.empty(self.nwords + 1, dtype=torch.int32, device=device)
+        self._scratch = torch.empty(int(lib().u3d_bitgrid_scan_scratch(self.nwords)), dtype=torch.int32, device=device)
+        self.c = BitGridStruct(self.words.data_ptr(), self.prefix.data_ptr(), self.batch, *self.dims)
+
+    def mark(self, coors):
+        _check(lib().u3d_bitgrid_mark(C.byref(self.c), _ptr(coors), coors.shape[0], _stream()), "bitgrid_mark")
+
+    def mark_strided(self, in_coors, n_dev, ksize, stride, pad):
+        _check(lib().u3d_bitgrid_mark_strided(C.byref(self.c), _ptr(in_coors), _ptr(n_dev), in_coors.shape[0],
+                                              _I3(*ksize), _I3(*stride), _I3(*pad), _stream()), "bitgrid_mark_strided")
+
+    def scan(self):
+        _check(lib().u3d_bitgrid_scan(C.byref(self.c), _ptr(self._scratch), _stream()), "bitgrid_scan")
+
+    @property
+    def count_dev(self):
+        """int32 device scalar view: number of occupied cells (valid after scan())."""
+        return self.prefix[self.nwords:]
+
+    def rank(self, coors):
+        out = torch.empty(coors.shape[0], dtype=torch.int32, device=coors.device)
+        _check(lib().u3d_bitgrid_rank(C.byref(self.c), _ptr(coors), coors.shape[0], _ptr(out), _stream()), "bitgrid_rank")
+        return out
+
+    def coords(self, n):
+        out = torch.empty((n, 4), dtype=torch.int32, device=self.words.device)
+        _check(lib().u3d_bitgrid_coords(C.byref(self.c), _ptr(out), n, _stream()), "bitgrid_coords")
+        return out
+
+    def nbr_table(self, q_coors, n_dev, ksize, stride, pad, mode):
+        n = q_coors.shape[0]
+        ld = (n + 127) // 128 * 128
+        kvol = ksize[0] * ksize[1] * ksize[2]
+        nbr = torch.empty((kvol, ld), dtype=torch.int32, device=q_coors.device)
+        _check(lib().u3d_nbr_table(C.byref(self.c), _ptr(q_coors), _ptr(n_dev), n, _I3(*ksize), _I3(*stride), _I3(*pad),
+                                   mode, _ptr(nbr), ld, _stream()), "nbr_table")
+        return nbr
+
+
+# --------------------------------------------------------------------------------------------------
+# voxelization
+# --------------------------------------------------------------------------------------------------
+def voxelize_hard(points, scene_off, batch, max_pts_per_scene, voxel_size, pc_range, max_points, max_voxels,
+                  want_voxels=True, want_mean=True):
+    """points f32 [n_total,F] (scenes concatenated), scene_off int32 [B+1] device.
+    Returns (voxels|None, coors, num_points, mean|None, voxel_off) with capacity B*max_voxels rows."""
+    n_total, nfeat = points.shape
+    cap = batch * max_voxels
+    dev = points.device
+    voxels = torch.empty((cap, max_points, nfeat), dtype=torch.float32, device=dev) if want_voxels else None
+    coors = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    num = torch.empty((cap,), dtype=torch.int32, device=dev)
+    mean = torch.empty((cap, nfeat), dtype=torch.float32, device=dev) if want_mean else None
+    voxel_off = torch.empty((batch + 1,), dtype=torch.int32, device=dev)
+    wsb = int(lib().u3d_voxelize_hard_workspace(n_total, batch, max_pts_per_scene))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _check(lib().u3d_voxelize_hard(_ptr(points), _ptr(scene_off), batch, n_total, max_pts_per_scene, nfeat,
+                                   _F3(*voxel_size), _F6(*pc_range), max_points, max_voxels, _ptr(voxels), _ptr(coors),
+                                   _ptr(num), _ptr(mean), _ptr(voxel_off), _ptr(ws), wsb, _stream()), "voxelize_hard")
+    return voxels, coors, num, mean, voxel_off
+
+
+# --------------------------------------------------------------------------------------------------
+# sparse conv / BN / dense
+# --------------------------------------------------------------------------------------------------
+def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False):
+    """out[m] = sum_k in[nbr[k][m]] @ W[k]; w: [K, Cin_w, Cout_w] contiguous. Returns [n_out, cout]."""
+    kvol = w.shape[0]
+    cin = inp.shape[1]
+    out = torch.empty((n_out, cout), dtype=inp.dtype, device=inp.device)
+    ld = nbr.shape[1] if nbr is not None else 0
+    _check(lib().u3d_spconv_fwd(_ptr(inp), _ptr(w), _ptr(nbr), ld, _ptr(out), _ptr(n_out_dev), n_out, cin, cout, kvol,
+                                1 if transpose_w else 0, dtype_code(inp), _stream()), "spconv_fwd")
+    return out
+
+
+def spconv_wgrad(inp, dout, nbr, n_out_dev, kvol):
+    cin, cout, n_out = inp.shape[1], dout.shape[1], dout.shape[0]
+    dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=inp.device)
+    wsb = int(lib().u3d_spconv_wgrad_workspace(n_out, cin, cout, kvol))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=inp.device)
+    ld = nbr.shape[1] if nbr is not None else 0
+    _check(lib().u3d_spconv_wgrad(_ptr(inp), _ptr(dout), _ptr(nbr), ld, _ptr(dw), _ptr(n_out_dev), n_out, cin, cout, kvol,
+                                  dtype_code(inp), _ptr(ws), wsb, _stream()), "spconv_wgrad")
+    return dw
+
+
+def bn_stats(x, n_dev):
+    n, c = x.shape
+    sums = torch.empty((2, c), dtype=torch.float64, device=x.device)
+    wsb = int(lib().u3d_bn_stats_workspace(n, c))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    _check(lib().u3d_bn_stats(_ptr(x), _ptr(n_dev), n, c, dtype_code(x), _ptr(sums), _ptr(ws), wsb, _stream()), "bn_stats")
+    return sums
+
+
+def bn_apply(x, mean, invstd, gamma, beta, residual, relu, n_dev):
+    n, c = x.shape
+    y = torch.empty_like(x)
+    _check(lib().u3d_bn_apply(_ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(residual), int(relu),
+                              _ptr(y), _ptr(n_dev), n, c, dtype_code(x), _stream()), "bn_apply")
+    return y
+
+
+def bn_bwd_stats(dy, y, x, mean, invstd, relu, n_dev):
+    n, c = x.shape
+    sums = torch.empty((2, c), dtype=torch.float64, device=x.device)
+    wsb = int(lib().u3d_bn_stats_workspace(n, c))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    _check(lib().u3d_bn_bwd_stats(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), int(relu), _ptr(n_dev), n, c,
+                                  dtype_code(x), _ptr(sums), _ptr(ws), wsb, _stream()), "bn_bwd_stats")
+    return sums
+
+
+def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, relu, n_dev, want_dres):
+    n, c = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    _check(lib().u3d_bn_bwd_apply(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums), int(relu),
+                                  _ptr(dx), _ptr(dres), _ptr(n_dev), n, c, dtype_code(x), _stream()), "bn_bwd_apply")
+    return dx, dres
+
+
+def to_dense(feat, coors, n_dev, batch, dims):
+    """-> logical [B, C, D, H, W] tensor in channels_last_3d memory format."""
+    n, c = feat.shape
+    dz, dy, dx = dims
+    vol = torch.zeros((batch, dz, dy, dx, c), dtype=feat.dtype, device=feat.device)
+    _check(lib().u3d_to_dense(_ptr(feat), _ptr(coors), _ptr(n_dev), n, c, _ptr(vol), dz, dy, dx, dtype_code(feat), _stream()),
+           "to_dense")
+    return vol.permute(0, 4, 1, 2, 3)
+
+
+def from_dense(vol_cl, coors, n_dev, n):
+    """vol_cl: contiguous [B, Dz, Dy, Dx, C] -> rows [n, C]."""
+    b, dz, dy, dx, c = vol_cl.shape
+    feat = torch.empty((n, c), dtype=vol_cl.dtype, device=vol_cl.device)
+    _check(lib().u3d_from_dense(_ptr(vol_cl), _ptr(coors), _ptr(n_dev), n, c, _ptr(feat), dz, dy, dx, dtype_code(vol_cl),
+                                _stream()), "from_dense")
+    return feat
+
+
+def gather_rows(inp, idx):
+    n = idx.shape[0]
+    out = torch.empty((n,) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+    row_bytes = inp[0].numel() * inp.element_size()
+    _check(lib().u3d_gather_rows(_ptr(inp), _ptr(idx), n, row_bytes, _ptr(out), _stream()), "gather_rows")
+    return out
+
+
+def scatter_rows(inp, idx, n_out):
+    out = torch.zeros((n_out,) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+    row_bytes = inp[0].numel() * inp.element_size()
+    _check(lib().u3d_scatter_rows(_ptr(inp), _ptr(idx), idx.shape[0], row_bytes, _ptr(out), _stream()), "scatter_rows")
+    return out
