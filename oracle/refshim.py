@@ -1,0 +1,466 @@
+"""ORACLE (test infrastructure; works ONLY where /root/reference exists, i.e. in the build container).
+
+Name-shim that lets the reference's own pure-torch files import and run verbatim on CPU:
+fake `mmcv / mmdet / mmdet3d` packages (registries, BaseModule, identity fp16 decorators) plus small
+stand-ins for the upstream *behaviour* the reference files call.
+Used by oracle/make_golden.py to generate tests/golden/*.npz and by CPU tests that are skipped when the
+reference tree is absent.  Nothing from /root/reference is copied: files are loaded from where they lie.
+"""
+import copy
+import importlib.util
+import math
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import boxes as ob
+
+REF_ROOT = os.environ.get("U3D_REFERENCE", "/root/reference")
+PLUGIN = os.path.join(REF_ROOT, "projects", "mmdet3d_plugin")
+
+
+def available():
+    return os.path.isdir(PLUGIN)
+
+
+# --------------------------------------------------------------------------------------------------
+# registries
+# --------------------------------------------------------------------------------------------------
+class Registry:
+    def __init__(self, name):
+        self.name, self.map = name, {}
+
+    def register_module(self, name=None, force=False, module=None):
+        def deco(cls):
+            self.map[name or cls.__name__] = cls
+            return cls
+        if module is not None:
+            return deco(module)
+        return deco
+
+    def build(self, cfg, **kw):
+        cfg = dict(cfg)
+        t = cfg.pop("type")
+        cls = self.map[t] if isinstance(t, str) else t
+        cfg.update(kw)
+        return cls(**cfg)
+
+
+REG = {n: Registry(n) for n in ["ATTENTION", "TRANSFORMER_LAYER_SEQUENCE", "TRANSFORMER", "DETECTORS", "HEADS", "LOSSES",
+                                "BACKBONES", "NECKS", "BBOX_ASSIGNERS", "BBOX_CODERS", "MATCH_COST", "MIDDLE_ENCODERS",
+                                "TRANSFORMER_LAYER", "FFN", "POSITIONAL_ENCODING"]}
+
+
+def _identity_deco(*a, **k):
+    if len(a) == 1 and callable(a[0]) and not k:
+        return a[0]
+    return lambda f: f
+
+
+class BaseModule(nn.Module):
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self.init_cfg = init_cfg
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def multi_apply(func, *args, **kwargs):
+    from functools import partial
+    pfunc = partial(func, **kwargs) if kwargs else func
+    return tuple(map(list, zip(*map(pfunc, *args))))
+
+
+def reduce_mean(t):
+    return t
+
+
+def bias_init_with_prob(p):
+    return float(-math.log((1 - p) / p))
+
+
+def xavier_init(module, gain=1, bias=0, distribution="normal"):
+    if distribution == "uniform":
+        nn.init.xavier_uniform_(module.weight, gain=gain)
+    else:
+        nn.init.xavier_normal_(module.weight, gain=gain)
+    if getattr(module, "bias", None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def constant_init(module, val, bias=0):
+    nn.init.constant_(module.weight, val)
+    if getattr(module, "bias", None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+# --------------------------------------------------------------------------------------------------
+# mmcv transformer bricks
+# --------------------------------------------------------------------------------------------------
+class MultiheadAttention(BaseModule):
+    def __init__(self, embed_dims, num_heads, attn_drop=0., proj_drop=0., dropout_layer=None, init_cfg=None,
+                 batch_first=False, dropout=None, **kw):
+        super().__init__(init_cfg)
+        if dropout is not None:
+            attn_drop = dropout
+            dropout_layer = dict(type="Dropout", drop_prob=dropout)
+        self.embed_dims, self.num_heads, self.batch_first = embed_dims, num_heads, batch_first
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.dropout_layer = nn.Dropout(dropout_layer["drop_prob"]) if dropout_layer else nn.Identity()
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
+                key_padding_mask=None, **kwargs):
+        if key is None:
+            key = query
+        if value is None:
+            value = key
+        if identity is None:
+            identity = query
+        if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
+            key_pos = query_pos
+        if query_pos is not None:
+            query = query + query_pos
+        if key_pos is not None:
+            key = key + key_pos
+        out = self.attn(query=query, key=key, value=value, attn_mask=attn_mask, key_padding_mask=key_padding_mask)[0]
+        return identity + self.dropout_layer(self.proj_drop(out))
+
+
+class FFN(BaseModule):
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2, act_cfg=dict(type="ReLU", inplace=True),
+                 ffn_drop=0., dropout_layer=None, add_identity=True, init_cfg=None, **kw):
+        super().__init__(init_cfg)
+        layers, c = [], embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(nn.Sequential(nn.Linear(c, feedforward_channels), nn.ReLU(inplace=True), nn.Dropout(ffn_drop)))
+            c = feedforward_channels
+        layers.append(nn.Linear(feedforward_channels, embed_dims))
+        layers.append(nn.Dropout(ffn_drop))
+        self.layers = nn.Sequential(*layers)
+        self.dropout_layer = nn.Identity()
+        self.add_identity = add_identity
+
+    def forward(self, x, identity=None):
+        out = self.layers(x)
+        if not self.add_identity:
+            return self.dropout_layer(out)
+        if identity is None:
+            identity = x
+        return identity + self.dropout_layer(out)
+
+
+class BaseTransformerLayer(BaseModule):
+    def __init__(self, attn_cfgs=None, ffn_cfgs=None, operation_order=None, norm_cfg=dict(type="LN"), init_cfg=None,
+                 batch_first=False, **kw):
+        super().__init__(init_cfg)
+        self.operation_order = operation_order
+        self.pre_norm = operation_order[0] == "norm"
+        n_attn = operation_order.count("self_attn") + operation_order.count("cross_attn")
+        if isinstance(attn_cfgs, dict):
+            attn_cfgs = [copy.deepcopy(attn_cfgs) for _ in range(n_attn)]
+        self.attentions = nn.ModuleList()
+        for cfg in attn_cfgs:
+            cfg = dict(cfg)
+            cfg.setdefault("batch_first", batch_first)
+            self.attentions.append(REG["ATTENTION"].build(cfg))
+        self.embed_dims = self.attentions[0].embed_dims
+        n_ffn = operation_order.count("ffn")
+        if isinstance(ffn_cfgs, dict):
+            ffn_cfgs = [copy.deepcopy(ffn_cfgs) for _ in range(n_ffn)]
+        self.ffns = nn.ModuleList()
+        for cfg in ffn_cfgs:
+            cfg = dict(cfg)
+            cfg.pop("type", None)
+            self.ffns.append(FFN(**cfg))
+        self.norms = nn.ModuleList([nn.LayerNorm(self.embed_dims) for _ in range(operation_order.count("norm"))])
+
+    def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, attn_masks=None,
+                query_key_padding_mask=None, key_padding_mask=None, **kwargs):
+        ni = ai = fi = 0
+        identity = query
+        for op in self.operation_order:
+            if op == "self_attn":
+                tk = tv = query
+                query = self.attentions[ai](query, tk, tv, identity if self.pre_norm else None, query_pos=query_pos,
+                                            key_pos=query_pos, attn_mask=None, key_padding_mask=query_key_padding_mask,
+                                            **kwargs)
+                ai += 1
+                identity = query
+            elif op == "norm":
+                query = self.norms[ni](query)
+                ni += 1
+            elif op == "cross_attn":
+                query = self.attentions[ai](query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
+                                            key_pos=key_pos, attn_mask=None, key_padding_mask=key_padding_mask, **kwargs)
+                ai += 1
+                identity = query
+            elif op == "ffn":
+                query = self.ffns[fi](query, identity if self.pre_norm else None)
+                fi += 1
+        return query
+
+
+class TransformerLayerSequence(BaseModule):
+    def __init__(self, transformerlayers=None, num_layers=None, init_cfg=None):
+        super().__init__(init_cfg)
+        self.num_layers = num_layers
+        self.layers = nn.ModuleList()
+        for _ in range(num_layers):
+            cfg = copy.deepcopy(transformerlayers)
+            cfg.pop("type", None)
+            self.layers.append(BaseTransformerLayer(**cfg))
+        self.embed_dims = self.layers[0].embed_dims
+        self.pre_norm = self.layers[0].pre_norm
+
+
+class MultiScaleDeformableAttention(nn.Module):
+    pass
+
+
+# --------------------------------------------------------------------------------------------------
+# mmdet pieces
+# --------------------------------------------------------------------------------------------------
+class AssignResult:
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+
+class SamplingResult:
+    pass
+
+
+class PseudoSampler:
+    def __init__(self, **kw):
+        pass
+
+    def sample(self, assign_result, bboxes, gt_bboxes, **kw):
+        r = SamplingResult()
+        r.pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+        r.neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
+        r.pos_assigned_gt_inds = assign_result.gt_inds[r.pos_inds] - 1
+        r.pos_gt_bboxes = gt_bboxes[r.pos_assigned_gt_inds] if gt_bboxes.numel() else gt_bboxes.view(-1, gt_bboxes.shape[-1])
+        return r
+
+
+class FocalLossCost:
+    def __init__(self, weight=1., alpha=0.25, gamma=2, eps=1e-12, **kw):
+        self.weight, self.alpha, self.gamma, self.eps = weight, alpha, gamma, eps
+
+    def __call__(self, cls_pred, gt_labels):
+        p = cls_pred.sigmoid()
+        neg = -(1 - p + self.eps).log() * (1 - self.alpha) * p.pow(self.gamma)
+        pos = -(p + self.eps).log() * self.alpha * (1 - p).pow(self.gamma)
+        return (pos[:, gt_labels] - neg[:, gt_labels]) * self.weight
+
+
+def weight_reduce_loss(loss, weight=None, reduction="mean", avg_factor=None):
+    if weight is not None:
+        loss = loss * weight
+    if avg_factor is None:
+        return loss.mean() if reduction == "mean" else (loss.sum() if reduction == "sum" else loss)
+    if reduction == "mean":
+        return loss.sum() / (avg_factor + torch.finfo(torch.float32).eps)
+    if reduction == "none":
+        return loss
+    raise ValueError
+
+
+def weighted_loss(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(pred, target, weight=None, reduction="mean", avg_factor=None, **kw):
+        return weight_reduce_loss(fn(pred, target, **kw), weight, reduction, avg_factor)
+    return wrapper
+
+
+class L1Loss(nn.Module):
+    def __init__(self, reduction="mean", loss_weight=1.0):
+        super().__init__()
+        self.reduction, self.loss_weight = reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        if target.numel() == 0:
+            return pred.sum() * 0
+        loss = weight_reduce_loss(torch.abs(pred - target), weight, reduction_override or self.reduction, avg_factor)
+        return self.loss_weight * loss
+
+
+class DETRHead(BaseModule):
+    """Only what Uni3DETRHead relies on (App. A7): no loss-weight == cost-weight assertion."""
+
+    def __init__(self, num_classes, in_channels, num_query=100, num_reg_fcs=2, transformer=None, sync_cls_avg_factor=False,
+                 positional_encoding=None, loss_cls=None, loss_bbox=None, loss_iou=None, train_cfg=None, test_cfg=None,
+                 init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        self.bg_cls_weight = 0
+        self.sync_cls_avg_factor = sync_cls_avg_factor
+        if train_cfg:
+            self.assigner = REG["BBOX_ASSIGNERS"].build(train_cfg["assigner"])
+            self.sampler = PseudoSampler()
+        self.num_query, self.num_classes, self.in_channels = num_query, num_classes, in_channels
+        self.num_reg_fcs, self.train_cfg, self.test_cfg = num_reg_fcs, train_cfg, test_cfg
+        self.fp16_enabled = False
+        self.loss_cls = REG["LOSSES"].build(loss_cls)
+        self.loss_bbox = REG["LOSSES"].build(loss_bbox)
+        self.loss_iou = REG["LOSSES"].build(loss_iou)
+        self.cls_out_channels = num_classes
+        self.act_cfg = dict(type="ReLU", inplace=True)
+        self.activate = nn.ReLU(inplace=True)
+        self.transformer = REG["TRANSFORMER"].build(transformer)
+        self.embed_dims = self.transformer.embed_dims
+        self._init_layers()
+
+
+class BaseBBoxCoder:
+    pass
+
+
+class BaseAssigner:
+    pass
+
+
+class GTBoxes:
+    """Stand-in for mmdet3d box structures: `.tensor` [G,7] with bottom-centre z, `.gravity_center`."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+    @property
+    def gravity_center(self):
+        t = self.tensor
+        return torch.cat([t[:, :2], t[:, 2:3] + t[:, 5:6] * 0.5], 1)
+
+    def to(self, *a, **k):
+        return GTBoxes(self.tensor.to(*a, **k))
+
+
+def _bbox_overlaps_3d_shim(b1, b2, mode="iou", coordinate="lidar"):
+    # the reference only reads the diagonal (uni3detr_head.py:695): build it without the O(N^2) clipping
+    if b1.shape[0] == b2.shape[0]:
+        return torch.diag_embed(ob.bbox_overlaps_3d_aligned(b1[:, :7], b2[:, :7]))
+    return ob.bbox_overlaps_3d(b1[:, :7], b2[:, :7])
+
+
+# --------------------------------------------------------------------------------------------------
+def _mod(name, **attrs):
+    m = sys.modules.get(name)
+    if m is None:
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+        if "." in name:
+            parent, child = name.rsplit(".", 1)
+            setattr(_mod(parent), child, m)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    return m
+
+
+_installed = False
+
+
+def install():
+    global _installed
+    if _installed:
+        return
+    if not available():
+        raise RuntimeError(f"reference tree not found at {REF_ROOT}")
+    R = REG
+    R["ATTENTION"].map["MultiheadAttention"] = MultiheadAttention
+    R["MATCH_COST"].map["FocalLossCost"] = FocalLossCost
+    R["LOSSES"].map["L1Loss"] = L1Loss
+    _mod("mmcv")
+    _mod("mmcv.cnn", Linear=nn.Linear, Conv2d=nn.Conv2d, xavier_init=xavier_init, constant_init=constant_init,
+         bias_init_with_prob=bias_init_with_prob)
+    _mod("mmcv.cnn.bricks")
+    _mod("mmcv.cnn.bricks.registry", ATTENTION=R["ATTENTION"], TRANSFORMER_LAYER_SEQUENCE=R["TRANSFORMER_LAYER_SEQUENCE"])
+    _mod("mmcv.cnn.bricks.transformer", MultiScaleDeformableAttention=MultiScaleDeformableAttention,
+         TransformerLayerSequence=TransformerLayerSequence,
+         build_transformer_layer_sequence=lambda cfg, **kw: R["TRANSFORMER_LAYER_SEQUENCE"].build(cfg, **kw))
+    _mod("mmcv.runner", force_fp32=_identity_deco, auto_fp16=_identity_deco, BaseModule=BaseModule)
+    _mod("mmcv.runner.base_module", BaseModule=BaseModule)
+    _mod("mmcv.ops", nms3d=None, nms_bev=None, diff_iou_rotated_3d=None)
+    _mod("mmcv.utils")
+    _mod("mmcv.parallel")
+    _mod("mmdet")
+    _mod("mmdet.models", HEADS=R["HEADS"], LOSSES=R["LOSSES"], DETECTORS=R["DETECTORS"], BACKBONES=R["BACKBONES"],
+         NECKS=R["NECKS"])
+    _mod("mmdet.models.utils")
+    _mod("mmdet.models.utils.builder", TRANSFORMER=R["TRANSFORMER"])
+    _mod("mmdet.models.utils.transformer", inverse_sigmoid=inverse_sigmoid)
+    _mod("mmdet.models.builder")
+    _mod("mmdet.models.dense_heads", DETRHead=DETRHead)
+    _mod("mmdet.models.losses")
+    _mod("mmdet.models.losses.utils", weighted_loss=weighted_loss, weight_reduce_loss=weight_reduce_loss)
+    _mod("mmdet.core", multi_apply=multi_apply, reduce_mean=reduce_mean)
+    _mod("mmdet.core.bbox", BaseBBoxCoder=BaseBBoxCoder)
+    _mod("mmdet.core.bbox.builder", BBOX_ASSIGNERS=R["BBOX_ASSIGNERS"], BBOX_CODERS=R["BBOX_CODERS"])
+    _mod("mmdet.core.bbox.assigners", AssignResult=AssignResult, BaseAssigner=BaseAssigner)
+    _mod("mmdet.core.bbox.match_costs", build_match_cost=lambda cfg: R["MATCH_COST"].build(cfg))
+    _mod("mmdet.core.bbox.match_costs.builder", MATCH_COST=R["MATCH_COST"])
+    _mod("mmdet.datasets")
+    _mod("mmdet.datasets.builder")
+    _mod("mmdet3d", __version__="1.0.0rc5")
+    _mod("mmdet3d.core")
+    _mod("mmdet3d.core.bbox", AxisAlignedBboxOverlaps3D=None)
+    _mod("mmdet3d.core.bbox.coders", build_bbox_coder=lambda cfg: R["BBOX_CODERS"].build(cfg))
+    _mod("mmdet3d.core.bbox.iou_calculators")
+    _mod("mmdet3d.core.bbox.iou_calculators.iou3d_calculator", bbox_overlaps_3d=_bbox_overlaps_3d_shim,
+         bbox_overlaps_nearest_3d=ob.bbox_overlaps_nearest_3d)
+    _mod("mmdet3d.models")
+    _mod("mmdet3d.models.builder", build_loss=lambda cfg: R["LOSSES"].build(cfg), MIDDLE_ENCODERS=R["MIDDLE_ENCODERS"])
+    _mod("mmdet3d.models.detectors")
+    _mod("mmdet3d.models.detectors.mvx_two_stage")
+    _mod("mmdet3d.ops")
+    _mod("mmdet3d.ops.spconv", IS_SPCONV2_AVAILABLE=False)
+    for pkg in ["projects", "projects.mmdet3d_plugin", "projects.mmdet3d_plugin.core", "projects.mmdet3d_plugin.core.bbox"]:
+        _mod(pkg)
+    _installed = True
+
+
+def load(rel_path, name=None):
+    """Load one reference file (path relative to projects/mmdet3d_plugin) as module `name`."""
+    install()
+    name = name or "projects.mmdet3d_plugin." + rel_path[:-3].replace("/", ".")
+    if name in sys.modules and getattr(sys.modules[name], "__file__", None):
+        return sys.modules[name]
+    path = os.path.join(PLUGIN, rel_path)
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    if "." in name:
+        parent, child = name.rsplit(".", 1)
+        setattr(_mod(parent), child, m)
+    spec.loader.exec_module(m)
+    return m
+
+
+def load_hot_path():
+    """Import the reference files on the decoder/head/matcher/loss path; returns a namespace of modules."""
+    ns = types.SimpleNamespace()
+    ns.util = load("core/bbox/util.py")
+    ns.match_cost = load("core/bbox/match_costs/match_cost.py")
+    ns.assigner = load("core/bbox/assigners/hungarian_assigner_3d.py")
+    ns.coder = load("core/bbox/coders/nms_free_coder.py")
+    ns.losses = load("models/losses/rdiouloss.py")
+    ns.transformer = load("models/utils/uni3detr_transformer.py")
+    ns.head = load("models/dense_heads/uni3detr_head.py")
+    return ns
+
+
+def sunrgbd_head_cfg():
+    """The pts_bbox_head + train_cfg dicts of projects/configs/uni3detr/uni3detr_sunrgbd.py, read by exec'ing the
+    reference config where it lies (nothing copied)."""
+    cfg_path = os.path.join(REF_ROOT, "projects", "configs", "uni3detr", "uni3detr_sunrgbd.py")
+    g = {}
+    exec(compile(open(cfg_path).read(), cfg_path, "exec"), g)
+    return copy.deepcopy(g["model"])

@@ -1,0 +1,167 @@
+"""CPU: the oracle restatement (oracle/model.py, oracle/boxes.py, oracle/geometry.py) against
+(1) golden vectors generated from the reference's own files (tests/golden/*.npz, oracle/make_golden.py) and
+(2) self-checking properties for the un-vendored upstream ops (parity unpinned there)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes as ob
+from oracle import geometry as og
+from oracle import model as om
+from oracle.weights import seeded_input, seeded_tensor
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load_head_fixture(name="head_train_b2.npz"):
+    z = np.load(os.path.join(G, name), allow_pickle=False)
+    return z
+
+
+def head_state(z_train, seed):
+    sd = {}
+    for k, shp in zip(z_train["sd_names"], z_train["sd_shapes"]):
+        shape = tuple(int(s) for s in str(shp).split(",")) if str(shp) else ()
+        sd["pts_bbox_head." + str(k)] = seeded_tensor(str(k), shape, seed)
+    return sd
+
+
+def head_inputs(B, seed):
+    feats = seeded_input("pts_feats", (B, 256, 15, 40, 40), seed, -0.5, 1.0).clamp_min(0)
+    fps = seeded_input("fpsbpts", (B, 600, 3), seed, 0.0, 1.0)
+    return feats, fps
+
+
+def split_gts(z):
+    gts, labels, o = [], [], 0
+    for n in z["gt_lens"]:
+        gts.append(torch.from_numpy(z["gts"][o:o + n]))
+        labels.append(torch.from_numpy(z["labels"][o:o + n]))
+        o += n
+    return gts, labels
+
+
+def test_small_ops_match_reference():
+    z = np.load(os.path.join(G, "small_ops.npz"))
+    tb = torch.from_numpy(z["boxes"])
+    norm = om.normalize_bbox(tb)
+    np.testing.assert_allclose(norm.numpy(), z["norm"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(om.denormalize_bbox(norm).numpy(), z["denorm"], rtol=1e-5, atol=1e-5)
+    pred = torch.from_numpy(z["pred"])
+    l1 = torch.cdist(pred, norm[:12, :8], p=1) * 0.25
+    np.testing.assert_allclose(l1.numpy(), z["l1cost"], rtol=1e-5, atol=1e-5)
+    iouc = (1 - ob.bbox_overlaps_nearest_3d(om.denormalize_bbox(pred), tb[:12])) * 1.2
+    np.testing.assert_allclose(iouc.numpy(), z["ioucost"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(om.sine_embed(torch.from_numpy(z["pos"])).numpy(), z["sine"], rtol=1e-5, atol=1e-6)
+    il = 1 - ob.bbox_overlaps_nearest_3d(tb[:32], tb[32:], is_aligned=True)
+    np.testing.assert_allclose(il.numpy(), z["iou3d_loss"], rtol=1e-5, atol=1e-6)
+
+
+def test_head_forward_and_loss_match_reference():
+    z = load_head_fixture()
+    cfg = om.sunrgbd_cfg()
+    seed = int(z["seed"])
+    sd = head_state(z, seed)
+    feats, fps = head_inputs(2, seed)
+    feats.requires_grad_(True)
+    cls, box, iou = om.head_forward(sd, "pts_bbox_head.", feats, fps, cfg)
+    for a, k in ((cls, "cls"), (box, "box"), (iou, "iou")):
+        ref = torch.from_numpy(z[k])
+        assert a.shape == ref.shape
+        err = (a.detach() - ref).abs().max().item()
+        assert err <= 1e-3 * max(1.0, ref.abs().max().item()) * 0.1, (k, err)
+    gts, labels = split_gts(z)
+    losses, assigned = om.head_loss(cls, box, iou, gts, labels, cfg)
+    assert np.array_equal(assigned.numpy().astype(np.int16), z["assigned"])
+    for name, val in zip(z["loss_names"], z["loss_values"]):
+        assert abs(float(losses[str(name)]) - val) <= 1e-4 * max(1.0, abs(val)), name
+    sum(losses.values()).backward()
+    np.testing.assert_allclose(feats.grad.reshape(-1)[::997].numpy(), z["feats_grad_sub"], rtol=2e-3, atol=2e-5)
+    assert abs(float(feats.grad.abs().sum()) - float(z["feats_grad_abs_sum"])) <= 1e-3 * float(z["feats_grad_abs_sum"])
+
+
+def test_head_eval_layout_matches_reference():
+    zt = load_head_fixture()
+    z = np.load(os.path.join(G, "head_eval_b1.npz"))
+    cfg = om.sunrgbd_cfg()
+    sd = head_state(zt, int(z["seed"]))
+    feats, fps = head_inputs(1, int(z["seed"]))
+    with torch.no_grad():
+        cls, box, iou = om.head_forward(sd, "pts_bbox_head.", feats, fps, cfg, rand_points=torch.from_numpy(z["rand_points"]))
+    assert cls.shape == (3, 1, 1200, 10)
+    for a, k in ((cls, "cls"), (box, "box"), (iou, "iou")):
+        assert (a - torch.from_numpy(z[k])).abs().max().item() <= 1e-4 * max(1.0, float(np.abs(z[k]).max()))
+
+
+# ---------------------------------------------------------------------------------------------------
+# properties of the un-vendored ops (no reference vectors exist: SURVEY.md §4)
+# ---------------------------------------------------------------------------------------------------
+def test_rotated_iou_axis_aligned_closed_form_and_monte_carlo():
+    rng = np.random.default_rng(0)
+    b1 = torch.tensor([[0.0, 0, 0, 2, 1, 1, 0.0], [0, 0, 0, 2, 1, 1, math.pi / 2], [1, 1, 0.5, 2, 2, 2, 0.3]])
+    b2 = torch.tensor([[0.5, 0.25, 0.5, 2, 1, 1, 0.0], [0, 0, 0, 1, 2, 1, 0.0], [1.2, 0.8, 0.0, 1.5, 2.5, 2, -0.9]])
+    got = ob.bbox_overlaps_3d_aligned(b1, b2)
+    inter0 = 1.5 * 0.75 * 0.5
+    assert abs(got[0].item() - inter0 / (2 + 2 - inter0)) < 1e-6
+    assert abs(got[1].item() - 1.0) < 1e-6        # (2x1 @ 90deg) == (1x2 @ 0deg)
+    # Monte-Carlo for the generic pair
+    pts = rng.uniform(-2, 4, (400000, 3))
+    def inside(b, p):
+        c, s = math.cos(b[6]), math.sin(b[6])
+        dx, dy = p[:, 0] - b[0], p[:, 1] - b[1]
+        lx, ly = dx * c + dy * s, -dx * s + dy * c
+        return (np.abs(lx) <= b[3] / 2) & (np.abs(ly) <= b[4] / 2) & (p[:, 2] >= b[2]) & (p[:, 2] <= b[2] + b[5])
+    i1, i2 = inside(b1[2].numpy(), pts), inside(b2[2].numpy(), pts)
+    mc = (i1 & i2).sum() / max((i1 | i2).sum(), 1)
+    assert abs(got[2].item() - mc) < 0.01
+
+
+def test_sparse_conv_equals_masked_dense_conv():
+    torch.manual_seed(0)
+    rng = np.random.default_rng(1)
+    dims = (8, 12, 12)
+    cells = rng.choice(2 * 8 * 12 * 12, 300, replace=False)
+    co = np.stack([cells // (8 * 144), cells // 144 % 8, cells // 12 % 12, cells % 12], 1).astype(np.int32)
+    x = torch.randn(300, 5)
+    w = torch.randn(27, 5, 7)
+    # SubM: out set == in set
+    y = og.sparse_conv(x, w, og.nbr_table(co, co, dims, (3, 3, 3), (1, 1, 1), (1, 1, 1), 0))
+    dense = og.dense_conv_reference(x, co, dims, w, (3, 3, 3), (1, 1, 1), (1, 1, 1), 2)
+    c = torch.from_numpy(co).long()
+    assert (y - dense[c[:, 0], :, c[:, 1], c[:, 2], c[:, 3]]).abs().max() < 1e-4
+    # strided with asymmetric padding: active set = support of the dense conv of the indicator
+    for pad in [(1, 1, 1), (0, 1, 1)]:
+        oc, od = og.strided_out_coords(co, dims, (3, 3, 3), (2, 2, 2), pad)
+        ys = og.sparse_conv(x, w, og.nbr_table(oc, co, dims, (3, 3, 3), (2, 2, 2), pad, 0))
+        ds = og.dense_conv_reference(x, co, dims, w, (3, 3, 3), (2, 2, 2), pad, 2)
+        assert tuple(ds.shape[2:]) == od
+        o = torch.from_numpy(oc).long()
+        assert (ys - ds[o[:, 0], :, o[:, 1], o[:, 2], o[:, 3]]).abs().max() < 1e-4
+        ind = og.dense_conv_reference(torch.ones(300, 1), co, dims, torch.ones(27, 1, 1), (3, 3, 3), (2, 2, 2), pad, 2)[:, 0] > 0
+        mask = torch.zeros_like(ind)
+        mask[o[:, 0], o[:, 1], o[:, 2], o[:, 3]] = True
+        assert torch.equal(mask, ind)
+
+
+def test_voxelize_semantics_small():
+    pts = np.array([[0.011, 0.0, -1.99, 1], [0.012, 0.001, -1.99, 2], [5.0, 0, 0, 3], [0.03, 0.0, -1.99, 4],
+                    [0.013, 0.002, -1.985, 5]], np.float32)
+    v, c, n = og.voxelize_hard(pts, (0.02,) * 3, (-3.2, -0.2, -2.0, 3.2, 6.2, 0.56), 2, 10)
+    assert c.tolist() == [[0, 10, 160], [0, 10, 161]]
+    assert n.tolist() == [2, 1]                     # third point of voxel 0 dropped (max_points=2), OOR point skipped
+    assert v[0, 1, 3] == 2 and v[1, 0, 3] == 4
+    v, c, n = og.voxelize_hard(pts, (0.02,) * 3, (-3.2, -0.2, -2.0, 3.2, 6.2, 0.56), 2, 1)
+    assert c.shape[0] == 1 and n.tolist() == [2]    # voxel cap: later voxel never created, its point dropped
+
+
+def test_fps_tie_rule_and_coverage():
+    p = np.zeros((10, 3), np.float32)
+    p[:, 0] = [0, 1, 1, 5, 5, 2, 2, 3, 3, 4]
+    idx = om.fps_packed(p.reshape(-1), 10, 3)
+    assert idx[0] == 0 and idx[1] == 3             # two maxima (3 and 4): T = 8, (3%8,3) < (4%8,4)
+    q = np.random.default_rng(0).random((500, 3)).astype(np.float32)
+    idx = om.fps_packed(q.reshape(-1), 500, 50)
+    assert len(set(idx.tolist())) == 50
