@@ -158,6 +158,35 @@ int32_t u3d_gather_rows(const void* in, const int32_t* idx, int32_t n, int32_t r
 /* out[idx[i],:] = in[i,:]  (idx<0 skipped; idx must be injective) */
 int32_t u3d_scatter_rows(const void* in, const int32_t* idx, int32_t n, int32_t row_bytes, void* out, u3d_stream s);
 
+/* ------------------------------------------------------------------------------------------------
+ * D-FPS (ref: models/detectors/uni3detr.py:138,178-187; upstream mmcv PointsSampler / furthest_point_sample,
+ * SURVEY.md App. A5).  nsets independent point sets; point k of set s is the float triple base[set_off[s]+3k..+2]
+ * (the packed-triple view the upstream kernel takes of whatever buffer it is handed).  idx[0]=0; squared-L2 running
+ * minimum; arg-max ties resolved as the upstream 2^k-thread block reduction does: smallest (k mod T, k),
+ * T = min(1024, 2^floor(log2 n)).  out_idx int32 [nsets, m].  temp: f32 [nsets, temp_stride] only needed when
+ * max_n > 20480.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t u3d_fps(const float* base, const int64_t* set_off, const int32_t* set_n, int32_t nsets, int32_t max_n,
+                int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, u3d_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Matching (ref: core/bbox/assigners/hungarian_assigner_3d.py:53-151; match_costs/match_cost.py:19-30,91-97; upstream
+ * FocalLossCost; scipy.optimize.linear_sum_assignment).
+ *   cls f32 [L,B,Q,C] logits, box f32 [L,B,Q,code] codes, gt f32 [sumG,7] gravity-centre boxes, labels int32 [sumG],
+ *   gt_off int32 [B+1] (device).  cost f32 [L*B, gmax, Q] (GT-major) = w_cls*focal + w_reg*L1(8 code dims) +
+ *   w_iou*(1 - nearest-BEV IoU).  u3d_lsa solves one problem per (layer, scene, query group of nq) on one wavefront
+ *   in float64 with scipy's scan order and tie rule; assigned int32 [L,B,Q]: 0 background, else 1-based GT index.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t u3d_match_cost(const float* cls, const float* box, const float* gt, const int32_t* labels,
+                       const int32_t* gt_off, int32_t nlayers, int32_t batch, int32_t nq_total, int32_t ncls,
+                       int32_t code_size, int32_t gmax, float w_cls, float w_reg, float w_iou, float alpha,
+                       float gamma, float* cost, u3d_stream s);
+int32_t u3d_lsa(const float* cost, const int32_t* gt_off, int32_t nlayers, int32_t batch, int32_t nq_total,
+                int32_t nq, int32_t gmax, int32_t* assigned, u3d_stream s);
+
+/* diag(bbox_overlaps_3d(a,b)) for a,b f32 [n,7] (ref: models/dense_heads/uni3detr_head.py:695). */
+int32_t u3d_iou3d_rotated_aligned(const float* a, const float* b, int32_t n, float* out, u3d_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,106 @@
+"""GPU parity: FPS, match cost, device Hungarian, aligned rotated IoU vs the CPU oracle / golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes as ob
+from oracle import geometry as og
+from oracle import model as om
+from uni3detr_amd import native as nv
+from uni3detr_amd.synth import room_scene, SUNRGBD_RANGE, SUNRGBD_VOXEL
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_fps_matches_oracle_packed_and_voxel(cuda):
+    pl = [room_scene(i, 20000 - 3000 * i)[0] for i in range(2)]
+    _, rc, _ = og.voxelize_batch(pl, SUNRGBD_VOXEL, SUNRGBD_RANGE, 5, 16000)
+    sets, offs, ns, o = [], [], [], 0
+    for p in pl:                       # (i) the packed-triple view of the raw [N,4] buffer
+        sets.append(p.reshape(-1)); offs.append(o); ns.append(p.shape[0]); o += p.size
+    for b in range(2):                 # (ii) float-cast integer voxel coords (z,y,x): massive ties
+        vc = rc[rc[:, 0] == b][:, 1:].astype(np.float32)
+        sets.append(vc.reshape(-1)); offs.append(o); ns.append(vc.shape[0]); o += vc.size
+    base = torch.from_numpy(np.concatenate(sets)).to(cuda)
+    idx = nv.fps(base, torch.tensor(offs, dtype=torch.int64, device=cuda), torch.tensor(ns, dtype=torch.int32, device=cuda),
+                 max(ns), 300).cpu().numpy()
+    for s in range(4):
+        ref = om.fps_packed(sets[s], ns[s], 300)
+        assert np.array_equal(idx[s], ref), s
+
+
+def test_fps_large_set_streaming_path(cuda):
+    p = np.random.default_rng(0).random((50000, 3)).astype(np.float32)
+    base = torch.from_numpy(p.reshape(-1)).to(cuda)
+    idx = nv.fps(base, torch.tensor([0], dtype=torch.int64, device=cuda), torch.tensor([50000], dtype=torch.int32, device=cuda),
+                 50000, 64).cpu().numpy()
+    assert np.array_equal(idx[0], om.fps_packed(p.reshape(-1), 50000, 64))
+
+
+def _fixture():
+    z = np.load(os.path.join(G, "head_train_b2.npz"))
+    gts, labels, o = [], [], 0
+    for n in z["gt_lens"]:
+        g = torch.from_numpy(z["gts"][o:o + n])
+        gts.append(torch.cat([g[:, :2], g[:, 2:3] + g[:, 5:6] * 0.5, g[:, 3:]], 1))   # gravity centre
+        labels.append(torch.from_numpy(z["labels"][o:o + n]))
+        o += n
+    return z, gts, labels
+
+
+def test_match_cost_and_assignment_match_reference_golden(cuda):
+    z, gts, labels = _fixture()
+    cfg = om.sunrgbd_cfg()
+    cls, box = torch.from_numpy(z["cls"]), torch.from_numpy(z["box"])
+    L, B, Q, _ = cls.shape
+    gt_off = torch.tensor(np.cumsum([0] + [g.shape[0] for g in gts]), dtype=torch.int32, device=cuda)
+    gmax = max(g.shape[0] for g in gts)
+    cost = nv.match_cost(cls.to(cuda), box.to(cuda), torch.cat(gts).to(cuda), torch.cat(labels).int().to(cuda), gt_off, gmax,
+                         cfg["cost_cls"], cfg["cost_reg"], cfg["cost_iou"])
+    for l in range(L):
+        for b in range(B):
+            ref = om.match_cost(cls[l, b], box[l, b], gts[b], labels[b], cfg)          # [Q,G]
+            got = cost[l * B + b, : gts[b].shape[0]].t().cpu()
+            assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item()) * 0.05
+    asg = nv.lsa(cost, gt_off, L, B, Q, 300, gmax).cpu().numpy()
+    assert np.array_equal(asg.astype(np.int16), z["assigned"])                       # == reference assigner (scipy)
+
+
+def test_lsa_random_and_degenerate_vs_scipy(cuda):
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(3)
+    for G, nq, integer in [(1, 300, False), (7, 300, False), (40, 300, False), (64, 300, True), (300, 300, False), (13, 900, True)]:
+        B = 3
+        c = rng.random((B, G, nq)).astype(np.float32)
+        if integer:
+            c = rng.integers(0, 4, (B, G, nq)).astype(np.float32)                    # massive ties: tie rule must equal scipy's
+        gt_off = torch.tensor([0, G, 2 * G, 3 * G], dtype=torch.int32, device=cuda)
+        asg = nv.lsa(torch.from_numpy(c).to(cuda), gt_off, 1, B, nq, nq, G).cpu().numpy()[0]
+        for b in range(B):
+            r, col = linear_sum_assignment(c[b].T)                                   # scipy on [nq, G] as the reference calls it
+            exp = np.zeros(nq, np.int32)
+            exp[r] = col + 1
+            assert np.array_equal(asg[b], exp), (G, nq, integer, b)
+
+
+def test_lsa_empty_scene(cuda):
+    gt_off = torch.tensor([0, 0, 5], dtype=torch.int32, device=cuda)
+    c = torch.rand(2, 5, 300, device=cuda)
+    asg = nv.lsa(c, gt_off, 1, 2, 300, 300, 5).cpu().numpy()[0]
+    assert asg[0].sum() == 0 and (asg[1] > 0).sum() == 5
+
+
+def test_rotated_iou_aligned(cuda):
+    rng = np.random.default_rng(5)
+    n = 4000
+    a = np.concatenate([rng.uniform(-3, 3, (n, 3)), rng.uniform(0.2, 2.5, (n, 3)), rng.uniform(-4, 4, (n, 1))], 1).astype(np.float32)
+    b = a + np.concatenate([rng.normal(0, 0.4, (n, 3)), rng.normal(0, 0.2, (n, 3)), rng.normal(0, 0.5, (n, 1))], 1).astype(np.float32)
+    b[:, 3:6] = np.abs(b[:, 3:6]) + 0.05
+    b[:10] = 0.0                                   # unmatched rows of the loss: all-zero targets
+    a[10:20, 6] = b[10:20, 6] = 0.0                # axis aligned
+    got = nv.iou3d_rotated_aligned(torch.from_numpy(a).to(cuda), torch.from_numpy(b).to(cuda)).cpu()
+    ref = ob.bbox_overlaps_3d_aligned(torch.from_numpy(a), torch.from_numpy(b))
+    assert (got - ref).abs().max().item() < 2e-4

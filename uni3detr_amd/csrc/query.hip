@@ -1,0 +1,392 @@
+// Query-side kernels: farthest point sampling, match cost, rectangular assignment (one wavefront per
+// problem), aligned rotated 3-D IoU.  Latency-bound work: one launch each for the whole batch, no host syncs.
+#include "common.h"
+#include <math.h>
+
+// ============================================================================================
+// D-FPS (ref: models/detectors/uni3detr.py:138,178-187; upstream mmcv furthest_point_sample).
+// One workgroup (1024 threads x 20 register-resident points) per point set.  Point k of set s = triple base[3k..3k+2] (the upstream
+// kernel's packed-triple view of the buffer).  Start index 0, running min of squared L2, arg-max with the
+// upstream block-reduction tie rule: smallest (k mod T, k), T = min(1024, 2^floor(log2 n)).
+// ============================================================================================
+#define FPS_THREADS 1024
+#define FPS_MAXJ 20   // register-resident points per thread (n <= 20480); larger sets stream min-dist via `temp`
+
+// candidate (d, k) beats (bd, bk): larger distance, or equal distance and smaller (k mod T, k); T is a power of two
+__device__ __forceinline__ bool fps_better(float d, int k, float bd, int bk, unsigned tmask, unsigned n) {
+  if (d != bd) return d > bd;
+  unsigned t1 = ((unsigned)k & tmask) * n + (unsigned)k, t2 = ((unsigned)bk & tmask) * n + (unsigned)bk;
+  return t1 < t2;
+}
+
+template <bool REG>
+__global__ __launch_bounds__(FPS_THREADS) void k_fps(const float* __restrict__ base, const long long* __restrict__ set_off,
+                                                    const int* __restrict__ set_n, int m, int* __restrict__ out_idx,
+                                                    float* __restrict__ temp, long long temp_stride) {
+  constexpr int NW = FPS_THREADS / 64;
+  __shared__ float s_d[NW];
+  __shared__ int s_k[NW];
+  __shared__ float s_cur[3];
+  const int s = blockIdx.x;
+  const float* p = base + set_off[s];
+  const int n = set_n[s];
+  int* out = out_idx + (long long)s * m;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (n <= 0) { for (int j = tid; j < m; j += FPS_THREADS) out[j] = 0; return; }
+  int T = 1;
+  while ((T << 1) <= n && (T << 1) <= 1024) T <<= 1;
+  const unsigned tmask = (unsigned)T - 1u, un = (unsigned)n;
+
+  float px[REG ? FPS_MAXJ : 1], py[REG ? FPS_MAXJ : 1], pz[REG ? FPS_MAXJ : 1], md[REG ? FPS_MAXJ : 1];
+  float* tmp = temp + (long long)s * temp_stride;
+  if (REG) {
+#pragma unroll
+    for (int j = 0; j < FPS_MAXJ; ++j) {
+      int k = tid + j * FPS_THREADS;
+      px[j] = py[j] = pz[j] = 0.f;
+      if (k < n) { px[j] = p[3 * k]; py[j] = p[3 * k + 1]; pz[j] = p[3 * k + 2]; }
+      md[j] = k < n ? 1e10f : -1.f;           // padding never wins (all real distances are >= 0)
+    }
+  } else {
+    for (int k = tid; k < n; k += FPS_THREADS) tmp[k] = 1e10f;
+  }
+  if (tid == 0) { out[0] = 0; s_cur[0] = p[0]; s_cur[1] = p[1]; s_cur[2] = p[2]; }
+  __syncthreads();
+  for (int r = 1; r < m; ++r) {
+    const float cx = s_cur[0], cy = s_cur[1], cz = s_cur[2];
+    float bd = -2.f; int bk = 0x7fffffff;
+    int tl = tid;
+    asm volatile("" : "+v"(tl));      // launder: stops LICM from hoisting 2 x FPS_MAXJ index/tie registers out of the round loop
+    if (REG) {
+#pragma unroll
+      for (int j = 0; j < FPS_MAXJ; ++j) {
+        float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+        float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        float v = fminf(md[j], d);
+        md[j] = v;
+        int k = tl + j * FPS_THREADS;
+        if (fps_better(v, k, bd, bk, tmask, un)) { bd = v; bk = k; }
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound live temporaries: 160 VGPRs hold the points
+      }
+    } else {
+      for (int k = tid; k < n; k += FPS_THREADS) {
+        float dx = p[3 * k] - cx, dy = p[3 * k + 1] - cy, dz = p[3 * k + 2] - cz;
+        float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        float v = fminf(tmp[k], d);
+        tmp[k] = v;
+        if (fps_better(v, k, bd, bk, tmask, un)) { bd = v; bk = k; }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float od = __shfl_xor(bd, o, 64); int ok = __shfl_xor(bk, o, 64);
+      if (fps_better(od, ok, bd, bk, tmask, un)) { bd = od; bk = ok; }
+    }
+    if (lane == 0) { s_d[wid] = bd; s_k[wid] = bk; }
+    __syncthreads();
+    if (wid == 0) {
+      float d2 = lane < NW ? s_d[lane] : -3.f; int k2 = lane < NW ? s_k[lane] : 0x7fffffff;
+#pragma unroll
+      for (int o = NW / 2; o > 0; o >>= 1) {
+        float od = __shfl_xor(d2, o, 64); int ok = __shfl_xor(k2, o, 64);
+        if (fps_better(od, ok, d2, k2, tmask, un)) { d2 = od; k2 = ok; }
+      }
+      if (lane == 0) { out[r] = k2; s_cur[0] = p[3 * k2]; s_cur[1] = p[3 * k2 + 1]; s_cur[2] = p[3 * k2 + 2]; }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int32_t u3d_fps(const float* base, const int64_t* set_off, const int32_t* set_n, int32_t nsets, int32_t max_n,
+                           int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, u3d_stream s) {
+  U3D_REQUIRE(base && set_off && set_n && out_idx && nsets > 0 && m > 0, U3D_ERR_ARG);
+  if (max_n <= FPS_THREADS * FPS_MAXJ) {
+    hipLaunchKernelGGL(k_fps<true>, dim3(nsets), dim3(FPS_THREADS), 0, s, base, (const long long*)set_off, set_n, m, out_idx, temp, (long long)temp_stride);
+  } else {
+    U3D_REQUIRE(temp && temp_stride >= max_n, U3D_ERR_WORKSPACE);
+    hipLaunchKernelGGL(k_fps<false>, dim3(nsets), dim3(FPS_THREADS), 0, s, base, (const long long*)set_off, set_n, m, out_idx, temp, (long long)temp_stride);
+  }
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+// ============================================================================================
+// box code helpers (ref: core/bbox/util.py:8-80)
+// ============================================================================================
+struct Box7 { float x, y, z, dx, dy, dz, yaw; };
+
+__device__ __forceinline__ Box7 denorm_box(const float* c) {
+  Box7 b;
+  b.x = c[0]; b.y = c[1]; b.z = c[4];
+  b.dx = expf(c[3]); b.dy = expf(c[2]); b.dz = expf(c[5]);      // (l, w, h) = exp(code 3, 2, 5)
+  b.yaw = -atan2f(c[6], c[7]) - 1.57079632679489662f;
+  return b;
+}
+__device__ __forceinline__ void norm_box(const float* g, float* c) {
+  float rot = -g[6] - 1.57079632679489662f;
+  c[0] = g[0]; c[1] = g[1]; c[2] = logf(g[4] + 1e-5f); c[3] = logf(g[3] + 1e-5f); c[4] = g[2]; c[5] = logf(g[5] + 1e-5f);
+  c[6] = sinf(rot); c[7] = cosf(rot);
+}
+// nearest-BEV axis-aligned box (mmdet3d nearest_bev)
+__device__ __forceinline__ void nearest_bev(float x, float y, float dx, float dy, float yaw, float* o) {
+  const float PI = 3.14159265358979323846f;
+  float r = yaw - floorf(yaw / PI + 0.5f) * PI;
+  r = fabsf(r);
+  float w = dx, h = dy;
+  if (r > PI / 4) { w = dy; h = dx; }
+  o[0] = x - w / 2; o[1] = y - h / 2; o[2] = x + w / 2; o[3] = y + h / 2;
+}
+__device__ __forceinline__ float iou_aa(const float* a, const float* b) {
+  float a1 = (a[2] - a[0]) * (a[3] - a[1]), a2 = (b[2] - b[0]) * (b[3] - b[1]);
+  float w = fmaxf(fminf(a[2], b[2]) - fmaxf(a[0], b[0]), 0.f), h = fmaxf(fminf(a[3], b[3]) - fmaxf(a[1], b[1]), 0.f);
+  float ov = w * h;
+  return ov / fmaxf(a1 + a2 - ov, 1e-6f);
+}
+
+// ============================================================================================
+// match cost (ref: core/bbox/assigners/hungarian_assigner_3d.py:110-121; match_costs/match_cost.py:19-30,91-97;
+// upstream FocalLossCost).  Output is GT-major: cost[p][g][q], p = (layer*B + b), q over ALL queries of the scene,
+// so that the assignment kernel streams contiguous rows.  gt: gravity-centre boxes [sumG,7]; gt_off [B+1].
+// ============================================================================================
+__global__ void k_match_cost(const float* __restrict__ cls, const float* __restrict__ box, const float* __restrict__ gt,
+                             const int* __restrict__ labels, const int* __restrict__ gt_off, int L, int B, int Q, int C,
+                             int code, int gmax, float w_cls, float w_reg, float w_iou, float alpha, float gamma,
+                             float* __restrict__ cost) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  int p = blockIdx.y;             // layer*B + b
+  int b = p % B;
+  if (q >= Q) return;
+  int g0 = gt_off[b], G = gt_off[b + 1] - g0;
+  if (G <= 0) return;
+  const float* c = cls + ((long long)p * Q + q) * C;
+  const float* bx = box + ((long long)p * Q + q) * code;
+  float code8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) code8[j] = bx[j];
+  Box7 pb = denorm_box(code8);
+  float pbev[4];
+  nearest_bev(pb.x, pb.y, pb.dx, pb.dy, pb.yaw, pbev);
+  for (int g = 0; g < G; ++g) {
+    const float* gb = gt + (long long)(g0 + g) * 7;
+    float logit = c[labels[g0 + g]];
+    float pr = 1.f / (1.f + expf(-logit));
+    float neg = -logf(1.f - pr + 1e-12f) * (1.f - alpha) * powf(pr, gamma);
+    float pos = -logf(pr + 1e-12f) * alpha * powf(1.f - pr, gamma);
+    float ccls = (pos - neg) * w_cls;
+    float gc[8];
+    norm_box(gb, gc);
+    float l1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) l1 += fabsf(code8[j] - gc[j]);
+    float gbev[4];
+    nearest_bev(gb[0], gb[1], gb[3], gb[4], gb[6], gbev);
+    float ciou = (1.f - iou_aa(pbev, gbev)) * w_iou;
+    cost[((long long)p * gmax + g) * Q + q] = ccls + l1 * w_reg + ciou;
+  }
+}
+
+extern "C" int32_t u3d_match_cost(const float* cls, const float* box, const float* gt, const int32_t* labels,
+                                  const int32_t* gt_off, int32_t nlayers, int32_t batch, int32_t nq_total, int32_t ncls,
+                                  int32_t code_size, int32_t gmax, float w_cls, float w_reg, float w_iou, float alpha,
+                                  float gamma, float* cost, u3d_stream s) {
+  U3D_REQUIRE(cls && box && gt && labels && gt_off && cost && code_size >= 8 && gmax > 0, U3D_ERR_ARG);
+  dim3 grid(u3d_cdiv(nq_total, 128), nlayers * batch);
+  hipLaunchKernelGGL(k_match_cost, grid, dim3(128), 0, s, cls, box, gt, labels, gt_off, nlayers, batch, nq_total, ncls,
+                     code_size, gmax, w_cls, w_reg, w_iou, alpha, gamma, cost);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+// ============================================================================================
+// Rectangular linear-sum assignment, one wavefront per problem, float64, all state in LDS — the
+// shortest-augmenting-path algorithm of scipy.optimize.linear_sum_assignment (Crouse 2016) including its scan
+// order over `remaining` and its tie rule (value < lowest, or == lowest and column unassigned), so that the
+// result equals scipy's also on degenerate costs (ref: hungarian_assigner_3d.py:129-139).
+// Problem (p, grp): rows = the G GTs of scene b (scipy transposes when rows > cols), cols = the nq queries of
+// group grp; cost row i = cost[p][i][grp*nq .. +nq].   Output assigned[p][q] = 1-based gt index or 0.
+// ============================================================================================
+__global__ __launch_bounds__(64) void k_lsa(const float* __restrict__ cost, const int* __restrict__ gt_off, int B, int Q,
+                                            int nq, int gmax, int* __restrict__ assigned) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ngrp = Q / nq;
+  const int p = blockIdx.x / ngrp, grp = blockIdx.x % ngrp;
+  const int b = p % B;
+  const int G = gt_off[b + 1] - gt_off[b];
+  const int lane = threadIdx.x;
+  int* asg = assigned + (long long)p * Q + grp * nq;
+  for (int j = lane; j < nq; j += 64) asg[j] = 0;
+  if (G <= 0) return;
+  const int nr = G < gmax ? G : gmax, nc = nq;
+  const float* cm = cost + (long long)p * gmax * Q + grp * nq;   // row i at cm + i*Q
+  double* v = (double*)smem;          // [nc]
+  double* spc = v + nc;               // [nc] shortestPathCosts
+  double* u = spc + nc;               // [gmax]
+  int* row4col = (int*)(u + gmax);    // [nc]
+  int* path = row4col + nc;           // [nc]
+  int* remaining = path + nc;         // [nc]
+  int* SC = remaining + nc;           // [nc]
+  int* col4row = SC + nc;             // [gmax]
+  int* SR = col4row + gmax;           // [gmax]
+  for (int j = lane; j < nc; j += 64) { v[j] = 0.0; row4col[j] = -1; }
+  for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
+  __syncthreads();
+  const double INF = __longlong_as_double(0x7ff0000000000000LL);
+  for (int cur = 0; cur < nr; ++cur) {
+    double minVal = 0.0;
+    int num_remaining = nc;
+    for (int it = lane; it < nc; it += 64) { remaining[it] = nc - it - 1; spc[it] = INF; SC[it] = 0; }
+    for (int i = lane; i < nr; i += 64) SR[i] = 0;
+    __syncthreads();
+    int sink = -1, i = cur;
+    while (sink == -1) {
+      if (lane == 0) SR[i] = 1;
+      const double ui = u[i];
+      const float* crow = cm + (long long)i * Q;
+      double lo = INF; int idx = -1; int lo_un = 0;
+      for (int it = lane; it < num_remaining; it += 64) {
+        int j = remaining[it];
+        double r = minVal + (double)crow[j] - ui - v[j];
+        double sp = spc[j];
+        if (r < sp) { path[j] = i; spc[j] = r; sp = r; }
+        int un = row4col[j] == -1;
+        if (sp < lo || (sp == lo && un)) { lo = sp; idx = it; lo_un = un; }
+      }
+      // combine lanes exactly like one sequential scan over it = 0..num_remaining-1 would: minimal value; among equal
+      // values the LAST unassigned position if any is unassigned, else the FIRST position.
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        double olo = __shfl_xor(lo, o, 64); int oidx = __shfl_xor(idx, o, 64); int oun = __shfl_xor(lo_un, o, 64);
+        bool take = false;
+        if (oidx >= 0) {
+          if (idx < 0 || olo < lo) take = true;
+          else if (olo == lo) {
+            if (oun && lo_un) take = oidx > idx;
+            else if (oun) take = true;
+            else if (!lo_un) take = oidx < idx;
+          }
+        }
+        if (take) { lo = olo; idx = oidx; lo_un = oun; }
+      }
+      minVal = lo;
+      if (idx < 0 || !(minVal < INF)) { sink = -2; break; }   // infeasible (inf / NaN costs): scene stays background
+      int j = remaining[idx];
+      int r4 = row4col[j];
+      __syncthreads();
+      if (lane == 0) { SC[j] = 1; remaining[idx] = remaining[num_remaining - 1]; }
+      --num_remaining;
+      if (r4 == -1) sink = j; else i = r4;
+      __syncthreads();
+    }
+    if (sink < 0) break;
+    if (lane == 0) u[cur] += minVal;
+    for (int r = lane; r < nr; r += 64)
+      if (SR[r] && r != cur) u[r] += minVal - spc[col4row[r]];
+    for (int j = lane; j < nc; j += 64)
+      if (SC[j]) v[j] -= minVal - spc[j];
+    __syncthreads();
+    if (lane == 0) {
+      int j = sink;
+      while (true) {
+        int ii = path[j];
+        row4col[j] = ii;
+        int t = col4row[ii]; col4row[ii] = j; j = t;
+        if (ii == cur) break;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i2 = lane; i2 < nr; i2 += 64) {
+    int j = col4row[i2];
+    if (j >= 0) asg[j] = i2 + 1;
+  }
+}
+
+static inline size_t lsa_lds_bytes(int nq, int gmax) { return (size_t)(2 * nq + gmax) * 8 + (size_t)(4 * nq + 2 * gmax) * 4; }
+
+extern "C" int32_t u3d_lsa(const float* cost, const int32_t* gt_off, int32_t nlayers, int32_t batch, int32_t nq_total,
+                           int32_t nq, int32_t gmax, int32_t* assigned, u3d_stream s) {
+  U3D_REQUIRE(cost && gt_off && assigned && nq > 0 && nq_total % nq == 0 && gmax > 0, U3D_ERR_ARG);
+  U3D_REQUIRE(gmax <= nq, U3D_ERR_UNSUPPORTED);
+  size_t lds = lsa_lds_bytes(nq, gmax);
+  U3D_REQUIRE(lds <= 160 * 1024, U3D_ERR_UNSUPPORTED);
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_lsa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int nproblems = nlayers * batch * (nq_total / nq);
+  hipLaunchKernelGGL(k_lsa, dim3(nproblems), dim3(64), lds, s, cost, gt_off, batch, nq_total, nq, gmax, assigned);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+// ============================================================================================
+// Aligned rotated 3-D IoU: diag(bbox_overlaps_3d(a, b)) without the O(N^2) matrix the reference builds
+// (ref: models/dense_heads/uni3detr_head.py:695; upstream mmdet3d BaseInstance3DBoxes.overlaps + mmcv box_iou_rotated,
+// z is treated as the BOTTOM face, BEV w/h clamped >= 1e-4).  a, b: [n,7] f32.
+// ============================================================================================
+struct P2 { float x, y; };
+
+__device__ int clip_poly(const P2* in, int n, P2 a, P2 b, P2* out) {
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    P2 p = in[i], q = in[(i + 1 == n) ? 0 : i + 1];
+    float sp = (b.x - a.x) * (p.y - a.y) - (b.y - a.y) * (p.x - a.x);
+    float sq = (b.x - a.x) * (q.y - a.y) - (b.y - a.y) * (q.x - a.x);
+    if (sp >= 0.f) out[m++] = p;
+    if ((sp >= 0.f) != (sq >= 0.f)) {
+      float t = sp / (sp - sq);
+      out[m++] = P2{p.x + t * (q.x - p.x), p.y + t * (q.y - p.y)};
+    }
+  }
+  return m;
+}
+
+__device__ void rect_corners(float cx, float cy, float w, float h, float ang, P2* c) {
+  float cs = cosf(ang), sn = sinf(ang);
+  const float sx[4] = {-0.5f, 0.5f, 0.5f, -0.5f}, sy[4] = {-0.5f, -0.5f, 0.5f, 0.5f};
+  for (int i = 0; i < 4; ++i) {
+    float x = sx[i] * w, y = sy[i] * h;
+    c[i] = P2{cx + x * cs - y * sn, cy + x * sn + y * cs};
+  }
+}
+
+__global__ void k_iou3d_rotated_aligned(const float* __restrict__ a, const float* __restrict__ b, int n, float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = a + (long long)i * 7;
+  const float* q = b + (long long)i * 7;
+  float w1 = fmaxf(p[3], 1e-4f), h1 = fmaxf(p[4], 1e-4f), w2 = fmaxf(q[3], 1e-4f), h2 = fmaxf(q[4], 1e-4f);
+  float a1 = w1 * h1, a2 = w2 * h2;
+  float iou2d = 0.f;
+  if (a1 >= 1e-14f && a2 >= 1e-14f) {
+    P2 poly[12], tmp[12], clipper[4];
+    // work relative to the first centre: keeps f32 clipping accurate for far-away boxes
+    rect_corners(0.f, 0.f, w1, h1, p[6], poly);
+    rect_corners(q[0] - p[0], q[1] - p[1], w2, h2, q[6], clipper);
+    int m = 4;
+    for (int e = 0; e < 4 && m > 0; ++e) {
+      m = clip_poly(poly, m, clipper[e], clipper[(e + 1) & 3], tmp);
+      for (int t = 0; t < m; ++t) poly[t] = tmp[t];
+    }
+    float inter = 0.f;
+    if (m >= 3) {
+      for (int t = 0; t < m; ++t) {
+        P2 u = poly[t], v = poly[(t + 1 == m) ? 0 : t + 1];
+        inter += u.x * v.y - v.x * u.y;
+      }
+      inter = fabsf(inter) * 0.5f;
+    }
+    iou2d = inter / (a1 + a2 - inter);
+  }
+  float ov_bev = iou2d * (a1 + a2) / (1.f + iou2d);
+  float top = fminf(p[2] + p[5], q[2] + q[5]), bot = fmaxf(p[2], q[2]);
+  float ov_h = fmaxf(top - bot, 0.f);
+  float ov = ov_bev * ov_h;
+  float v1 = p[3] * p[4] * p[5], v2 = q[3] * q[4] * q[5];
+  out[i] = ov / fmaxf(v1 + v2 - ov, 1e-8f);
+}
+
+extern "C" int32_t u3d_iou3d_rotated_aligned(const float* a, const float* b, int32_t n, float* out, u3d_stream s) {
+  U3D_REQUIRE(a && b && out, U3D_ERR_ARG);
+  if (n <= 0) return U3D_OK;
+  hipLaunchKernelGGL(k_iou3d_rotated_aligned, dim3(u3d_cdiv(n, 128)), dim3(128), 0, s, a, b, n, out);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}

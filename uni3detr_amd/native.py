@@ -55,6 +55,10 @@ _SIGS = {
     "u3d_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "u3d_to_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     "u3d_from_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
+    "u3d_fps": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _L, _P]),
+    "u3d_match_cost": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
+    "u3d_lsa": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "u3d_iou3d_rotated_aligned": (_I, [_P, _P, _I, _P, _P]),
     "u3d_gather_rows": (_I, [_P, _P, _I, _I, _P, _P]),
     "u3d_scatter_rows": (_I, [_P, _P, _I, _I, _P, _P]),
 }
@@ -268,4 +272,44 @@ def scatter_rows(inp, idx, n_out):
     out = torch.zeros((n_out,) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
     row_bytes = inp[0].numel() * inp.element_size()
     _check(lib().u3d_scatter_rows(_ptr(inp), _ptr(idx), idx.shape[0], row_bytes, _ptr(out), _stream()), "scatter_rows")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# query side: FPS, matching, IoU
+# --------------------------------------------------------------------------------------------------
+FPS_REG_MAX = 20480
+
+
+def fps(base, set_off, set_n, max_n, m):
+    """base: f32 device buffer; set_off int64 [S] element offsets; set_n int32 [S]; -> idx int32 [S, m]."""
+    nsets = set_off.shape[0]
+    out = torch.empty((nsets, m), dtype=torch.int32, device=base.device)
+    temp, stride = None, 0
+    if max_n > FPS_REG_MAX:
+        temp = torch.empty((nsets, max_n), dtype=torch.float32, device=base.device)
+        stride = max_n
+    _check(lib().u3d_fps(_ptr(base), _ptr(set_off), _ptr(set_n), nsets, max_n, m, _ptr(out), _ptr(temp), stride, _stream()), "fps")
+    return out
+
+
+def match_cost(cls, box, gt, labels, gt_off, gmax, w_cls, w_reg, w_iou, alpha=0.25, gamma=2.0):
+    """cls [L,B,Q,C], box [L,B,Q,code] f32; gt [sumG,7] gravity-centre; labels int32; -> cost f32 [L*B, gmax, Q]."""
+    L, B, Q, Ccls = cls.shape
+    cost = torch.zeros((L * B, gmax, Q), dtype=torch.float32, device=cls.device)
+    _check(lib().u3d_match_cost(_ptr(cls), _ptr(box), _ptr(gt), _ptr(labels), _ptr(gt_off), L, B, Q, Ccls, box.shape[-1], gmax,
+                                w_cls, w_reg, w_iou, alpha, gamma, _ptr(cost), _stream()), "match_cost")
+    return cost
+
+
+def lsa(cost, gt_off, L, B, Q, nq, gmax):
+    assigned = torch.empty((L, B, Q), dtype=torch.int32, device=cost.device)
+    _check(lib().u3d_lsa(_ptr(cost), _ptr(gt_off), L, B, Q, nq, gmax, _ptr(assigned), _stream()), "lsa")
+    return assigned
+
+
+def iou3d_rotated_aligned(a, b):
+    n = a.shape[0]
+    out = torch.empty((n,), dtype=torch.float32, device=a.device)
+    _check(lib().u3d_iou3d_rotated_aligned(_ptr(a), _ptr(b), n, _ptr(out), _stream()), "iou3d_rotated_aligned")
     return out
