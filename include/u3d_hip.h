@@ -130,6 +130,11 @@ int32_t u3d_spconv_wgrad(const void* in, const void* dout, const int32_t* nbr, i
 int64_t u3d_bn_stats_workspace(int32_t n_cap, int32_t c);
 int32_t u3d_bn_stats(const void* x, const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype,
                      double* sums, void* workspace, int64_t workspace_bytes, u3d_stream s);
+/* sums -> mean, invstd = 1/sqrt(biased var + eps); optional nn.BatchNorm1d running-stat update
+ * (running = (1-m)*running + m*batch, unbiased variance) and num_batches_tracked += 1. */
+int32_t u3d_bn_finalize(const double* sums, const int32_t* n_dev, int32_t n_cap, int32_t c, float eps, float momentum,
+                        float* running_mean, float* running_var, int64_t* num_batches, float* mean, float* invstd,
+                        u3d_stream s);
 /* y = relu?( (x-mean)*invstd*gamma + beta (+ residual) ); mean/invstd/gamma/beta f32 [C]. */
 int32_t u3d_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, const void* residual, int32_t relu, void* y,

@@ -112,6 +112,37 @@ extern "C" int32_t u3d_bn_bwd_stats(const void* dy, const void* y, const void* x
   return run_stats<1>(x, dy, y, mean, invstd, relu, n_dev, n_cap, c, dtype, sums, workspace, workspace_bytes, s);
 }
 
+// sums -> mean / invstd (biased variance) and the running-stat update of nn.BatchNorm1d (unbiased variance), one launch
+__global__ void k_bn_finalize(const double* __restrict__ sums, const int* __restrict__ n_dev, int n_cap, int c, float eps,
+                              float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                              long long* __restrict__ num_batches, float* __restrict__ mean, float* __restrict__ invstd) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int n = min(*n_dev, n_cap);
+  if (i == 0 && num_batches) *num_batches += 1;
+  if (i >= c) return;
+  double nn = n > 0 ? (double)n : 1.0;
+  double mu = sums[i] / nn;
+  double var = sums[c + i] / nn - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[i] = (float)mu;
+  invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    double unbiased = n > 1 ? var * nn / (nn - 1.0) : var;
+    running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * (float)mu;
+    running_var[i] = (1.f - momentum) * running_var[i] + momentum * (float)unbiased;
+  }
+}
+
+extern "C" int32_t u3d_bn_finalize(const double* sums, const int32_t* n_dev, int32_t n_cap, int32_t c, float eps,
+                                   float momentum, float* running_mean, float* running_var, int64_t* num_batches,
+                                   float* mean, float* invstd, u3d_stream s) {
+  U3D_REQUIRE(sums && n_dev && mean && invstd && c > 0 && (!running_mean || running_var), U3D_ERR_ARG);
+  hipLaunchKernelGGL(k_bn_finalize, dim3(u3d_cdiv(c, 256)), dim3(256), 0, s, sums, n_dev, n_cap, c, eps, momentum,
+                     running_mean, running_var, (long long*)num_batches, mean, invstd);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // y = relu?((x-mean)*invstd*gamma + beta (+res))      /     backward apply
 // ---------------------------------------------------------------------------------------------

@@ -50,6 +50,7 @@ _SIGS = {
     "u3d_spconv_wgrad": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "u3d_bn_stats_workspace": (_L, [_I, _I]),
     "u3d_bn_stats": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _P]),
+    "u3d_bn_finalize": (_I, [_P, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     "u3d_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "u3d_bn_bwd_stats": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
     "u3d_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
@@ -212,6 +213,15 @@ def bn_stats(x, n_dev):
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
     _check(lib().u3d_bn_stats(_ptr(x), _ptr(n_dev), n, c, dtype_code(x), _ptr(sums), _ptr(ws), wsb, _stream()), "bn_stats")
     return sums
+
+
+def bn_finalize(sums, n_dev, n_cap, eps, momentum, running_mean=None, running_var=None, num_batches=None):
+    c = sums.shape[1]
+    mean = torch.empty((c,), dtype=torch.float32, device=sums.device)
+    invstd = torch.empty((c,), dtype=torch.float32, device=sums.device)
+    _check(lib().u3d_bn_finalize(_ptr(sums), _ptr(n_dev), n_cap, c, eps, momentum, _ptr(running_mean), _ptr(running_var),
+                                 _ptr(num_batches), _ptr(mean), _ptr(invstd), _stream()), "bn_finalize")
+    return mean, invstd
 
 
 def bn_apply(x, mean, invstd, gamma, beta, residual, relu, n_dev):

@@ -1,0 +1,192 @@
+"""Uni3DETR detector behind the reference's registry name / constructor / method signatures (ref:
+projects/mmdet3d_plugin/models/detectors/uni3detr.py:113-357; upstream MVXTwoStageDetector)."""
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .. import native as nv
+from ..registry import BACKBONES, DETECTORS, HEADS, MIDDLE_ENCODERS, NECKS, VOXEL_ENCODERS
+
+
+class Voxelization(nn.Module):
+    """mmcv.ops.Voxelization configuration holder (hard mode runs on u3d_voxelize_hard)."""
+
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000, deterministic=True):
+        super().__init__()
+        self.voxel_size, self.point_cloud_range = list(voxel_size), list(point_cloud_range)
+        self.max_num_points = max_num_points
+        self.max_voxels = tuple(max_voxels) if isinstance(max_voxels, (tuple, list)) else (max_voxels, max_voxels)
+        self.deterministic = deterministic
+
+
+@VOXEL_ENCODERS.register_module()
+class HardSimpleVFE(nn.Module):
+    def __init__(self, num_features=4):
+        super().__init__()
+        self.num_features = num_features
+        self.fp16_enabled = False
+
+    def forward(self, features, num_points, coors=None):
+        return features[:, :, : self.num_features].sum(dim=1) / num_points.type_as(features).view(-1, 1)
+
+
+@VOXEL_ENCODERS.register_module()
+class DynamicSimpleVFE(nn.Module):
+    def __init__(self, voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1)):
+        super().__init__()
+        self.voxel_size, self.point_cloud_range = voxel_size, point_cloud_range
+
+
+def shift_scale_points(pred_xyz, src_range, dst_range=None):
+    """Affine map of [B,N,3] points from src_range=[min,max] to dst_range (default unit cube) (ref :18-46)."""
+    lo, hi = src_range
+    if dst_range is None:
+        dlo, dhi = torch.zeros_like(lo), torch.ones_like(hi)
+    else:
+        dlo, dhi = dst_range
+    return ((pred_xyz - lo[:, None, :]) * (dhi - dlo)[:, None, :]) / (hi - lo)[:, None, :] + dlo[:, None, :]
+
+
+@DETECTORS.register_module()
+class Uni3DETR(nn.Module):
+    def __init__(self, dynamic_voxelization=False, use_grid_mask=False, pts_voxel_layer=None, pts_voxel_encoder=None,
+                 pts_middle_encoder=None, pts_fusion_layer=None, pts_backbone=None, pts_neck=None, pts_bbox_head=None,
+                 train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        self.pts_voxel_layer = Voxelization(**pts_voxel_layer) if pts_voxel_layer else None
+        self.pts_voxel_encoder = VOXEL_ENCODERS.build(pts_voxel_encoder) if pts_voxel_encoder else None
+        self.pts_middle_encoder = MIDDLE_ENCODERS.build(pts_middle_encoder) if pts_middle_encoder else None
+        self.pts_backbone = BACKBONES.build(pts_backbone) if pts_backbone else None
+        self.pts_neck = NECKS.build(pts_neck) if pts_neck else None
+        if pts_bbox_head:
+            head = dict(pts_bbox_head)
+            head["train_cfg"] = train_cfg["pts"] if train_cfg else None
+            head["test_cfg"] = test_cfg["pts"] if test_cfg and "pts" in test_cfg else None
+            self.pts_bbox_head = HEADS.build(head)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.dynamic_voxelization = dynamic_voxelization
+        if pts_middle_encoder:
+            self.pts_fp16 = hasattr(self.pts_middle_encoder, "fp16_enabled")
+        self.num_fps = pts_bbox_head["num_query"] if pts_bbox_head else 0
+        # upstream furthest_point_sample is handed the raw [1,N,F] buffer and reads it as packed xyz triples
+        # (DESIGN.md "FPS view"); set False to sample on true xyz instead.
+        self.fps_packed_view = True
+        self.amp_dtype = None           # torch.bfloat16 -> throughput mode (sparse encoder bf16 MFMA, dense + decoder autocast)
+
+    with_pts_backbone = property(lambda self: self.pts_backbone is not None)
+    with_pts_neck = property(lambda self: self.pts_neck is not None)
+
+    def init_weights(self):
+        return          # as the reference (ref :140-141): constructor-default init is what training really starts from
+
+    def set_precision(self, mode):
+        assert mode in ("fp32", "bf16")
+        self.amp_dtype = torch.bfloat16 if mode == "bf16" else None
+        if self.pts_middle_encoder is not None:
+            self.pts_middle_encoder.compute_dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+        return self
+
+    # ------------------------------------------------------------------------------------------
+    def voxelize_batch(self, pts):
+        """list of [N_b,F] -> (coors [V,4] int32 (b,z,y,x), mean feats [V,F], voxel_off [B+1] device, points_cat, scene_off)."""
+        B = len(pts)
+        lens = [int(p.shape[0]) for p in pts]
+        cat = torch.cat([p.float() for p in pts]).contiguous() if B > 1 else pts[0].float().contiguous()
+        off = [0]
+        for n in lens:
+            off.append(off[-1] + n)
+        scene_off = torch.tensor(off, dtype=torch.int32, device=cat.device)
+        vl = self.pts_voxel_layer
+        max_voxels = vl.max_voxels[0] if self.training else vl.max_voxels[1]
+        _, coors, num, mean, voxel_off = nv.voxelize_hard(cat, scene_off, B, max(lens), vl.voxel_size, vl.point_cloud_range,
+                                                          vl.max_num_points, max_voxels, want_voxels=False, want_mean=True)
+        total = int(voxel_off[-1].item())          # the one host read the reference also has (ref :153)
+        return coors[:total], mean[:total, : self.pts_voxel_encoder.num_features], voxel_off, cat, scene_off, lens
+
+    def fps_queries(self, cat, scene_off, lens, coors, voxel_off):
+        """2 x D-FPS per scene in ONE launch: raw points and float-cast (z,y,x) voxel coords (ref :178-189)."""
+        B = len(lens)
+        m = self.num_fps
+        F_ = cat.shape[1]
+        dev = cat.device
+        vox = coors[:, 1:].float().contiguous()                                           # [V,3] (z,y,x)
+        if self.fps_packed_view:
+            raw, raw_off = cat.reshape(-1), scene_off[:-1].long() * F_
+        else:
+            raw, raw_off = cat[:, :3].contiguous().reshape(-1), scene_off[:-1].long() * 3
+        base = torch.cat([raw, vox.reshape(-1)])
+        set_off = torch.cat([raw_off, raw.numel() + voxel_off[:-1].long() * 3])
+        set_n = torch.cat([scene_off[1:] - scene_off[:-1], voxel_off[1:] - voxel_off[:-1]]).int()
+        max_n = max(max(lens), int(self.pts_voxel_layer.max_voxels[0 if self.training else 1]))
+        idx = nv.fps(base, set_off.contiguous(), set_n.contiguous(), max_n, m).long()     # [2B, m]
+        p_idx = idx[:B] + scene_off[:-1].long()[:, None]
+        v_idx = idx[B:] + voxel_off[:-1].long()[:, None]
+        a = cat[:, :3][p_idx]                                                             # [B,m,3] xyz
+        b = vox[v_idx][:, :, [2, 1, 0]]                                                   # [B,m,3] (x,y,z) voxel coords
+        a = shift_scale_points(a, [a.min(dim=1)[0], a.max(dim=1)[0]])
+        b = shift_scale_points(b, [b.min(dim=1)[0], b.max(dim=1)[0]])
+        return torch.cat([a, b], 1)
+
+    def extract_pts_feat(self, pts):
+        if self.dynamic_voxelization:
+            raise NotImplementedError("dynamic voxelization (ScanNet configs) is a later row of the hot-path table (DESIGN.md)")
+        coors, feats, voxel_off, cat, scene_off, lens = self.voxelize_batch(pts)
+        x = self.pts_middle_encoder(feats, coors, len(pts))
+        amp = self.amp_dtype
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            if self.with_pts_backbone:
+                x = self.pts_backbone(x)
+            if self.with_pts_neck:
+                x = self.pts_neck(x)
+        fpsbpts = self.fps_queries(cat, scene_off, lens, coors, voxel_off)
+        return x, fpsbpts
+
+    def forward_pts_train(self, pts_feats, gt_bboxes_3d, gt_labels_3d, img_metas, gt_bboxes_ignore=None, fpsbpts=None):
+        amp = self.amp_dtype
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            outs = self.pts_bbox_head(pts_feats, img_metas, fpsbpts)
+        return self.pts_bbox_head.loss(gt_bboxes_3d, gt_labels_3d, outs)
+
+    def forward(self, return_loss=True, **kwargs):
+        return self.forward_train(**kwargs) if return_loss else self.forward_test(**kwargs)
+
+    def forward_train(self, points=None, img_metas=None, gt_bboxes_3d=None, gt_labels_3d=None, gt_labels=None, gt_bboxes=None,
+                      gt_bboxes_ignore=None):
+        pts_feat, fpsbpts = self.extract_pts_feat(points)
+        return dict(self.forward_pts_train(pts_feat, gt_bboxes_3d, gt_labels_3d, img_metas, gt_bboxes_ignore, fpsbpts))
+
+    def forward_test(self, img_metas, points=None, **kwargs):
+        if not isinstance(img_metas, list):
+            raise TypeError(f"img_metas must be a list, but got {type(img_metas)}")
+        if len(img_metas) == 1 or not isinstance(img_metas[0], list):
+            metas = img_metas[0] if isinstance(img_metas[0], list) else img_metas
+            return self.simple_test(metas, points, **kwargs)
+        raise NotImplementedError("test-time augmentation is unfinished in the reference as well (uni3detr.py:318)")
+
+    def simple_test_pts(self, pts_feat, img_metas, rescale=False, fpsbpts=None):
+        outs = self.pts_bbox_head(pts_feat, img_metas, fpsbpts)
+        bbox_list = self.pts_bbox_head.get_bboxes(outs, img_metas, rescale=rescale)
+        return [dict(boxes_3d=b.cpu(), scores_3d=s.cpu(), labels_3d=l.cpu()) for b, s, l in bbox_list]
+
+    @torch.no_grad()
+    def simple_test(self, img_metas, points=None, rescale=False):
+        pts_feat, fpsbpts = self.extract_pts_feat(points)
+        return self.simple_test_pts(pts_feat, img_metas, rescale=rescale, fpsbpts=fpsbpts)
+
+    # ------------------------------------------------------------------------------------------
+    def _parse_losses(self, losses):
+        log_vars = OrderedDict((k, v.mean() if isinstance(v, torch.Tensor) else sum(x.mean() for x in v)) for k, v in losses.items())
+        loss = sum(v for k, v in log_vars.items() if "loss" in k)
+        log_vars["loss"] = loss
+        if dist.is_available() and dist.is_initialized():
+            vals = torch.stack([v.detach() for v in log_vars.values()])
+            dist.all_reduce(vals.div_(dist.get_world_size()))        # one message instead of one per log var
+            log_vars = OrderedDict(zip(log_vars.keys(), vals.unbind()))
+        return loss, log_vars
+
+    def train_step(self, data, optimizer=None):
+        losses = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data["img_metas"]) if data.get("img_metas") else len(data["points"]))

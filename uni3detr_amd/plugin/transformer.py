@@ -1,0 +1,258 @@
+"""Uni3DETRTransformer / Uni3DETRTransformerDecoder / UniCrossAtten behind the reference's registry names
+(ref: projects/mmdet3d_plugin/models/utils/uni3detr_transformer.py:18-360) plus the mmcv bricks the shipped configs name
+(`BaseTransformerLayer`, `MultiheadAttention`, `FFN`).
+
+Execution differs from the reference on purpose: the reference loops over query groups and runs the 3-layer decoder
+once per group; groups never interact, so here all groups of all scenes run together — every linear layer sees
+[B, groups*nq, C] rows and self-attention is block-diagonal over [B*groups, nq] — with identical results.
+Tensors are batch-first internally.  Parameter names are the reference checkpoints' (SURVEY.md Appendix C).
+"""
+import copy
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..registry import ATTENTION, FEEDFORWARD_NETWORK, TRANSFORMER, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+class MLP(nn.Module):
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for i, l in enumerate(self.layers):
+            x = l(x)
+            if i < self.num_layers - 1:
+                x = F.relu(x)
+        return x
+
+
+_SINE_CACHE = {}
+
+
+def get_sine_pos_embed(pos, num_pos_feats=128, temperature=10000, exchange_xy=False):
+    """pos [..., n] in [0,1] -> [..., n*num_pos_feats]: interleaved sin/cos of pos*2pi/T^(2*(i//2)/F) (ref :33-65)."""
+    key = (pos.device, num_pos_feats, temperature)
+    dim_t = _SINE_CACHE.get(key)
+    if dim_t is None:
+        d = torch.arange(num_pos_feats, dtype=torch.float32, device=pos.device)
+        dim_t = temperature ** (2 * torch.div(d, 2, rounding_mode="floor") / num_pos_feats)
+        _SINE_CACHE[key] = dim_t
+    s = pos.float().unsqueeze(-1) * (2 * math.pi) / dim_t                      # [..., n, F]
+    emb = torch.stack((s[..., 0::2].sin(), s[..., 1::2].cos()), dim=-1).flatten(-2)
+    if exchange_xy:
+        emb = torch.cat([emb[..., 1:2, :], emb[..., 0:1, :], emb[..., 2:, :]], dim=-2)
+    return emb.flatten(-2)
+
+
+@ATTENTION.register_module()
+class MultiheadAttention(nn.Module):
+    """mmcv wrapper semantics: q = k = query + query_pos, v = query, residual + dropout (legacy `dropout=` sets both the
+    attention dropout and the residual dropout)."""
+
+    def __init__(self, embed_dims, num_heads, attn_drop=0.0, proj_drop=0.0, dropout_layer=None, init_cfg=None,
+                 batch_first=False, dropout=None, **kwargs):
+        super().__init__()
+        if dropout is not None:
+            attn_drop = dropout
+            dropout_layer = dict(type="Dropout", drop_prob=dropout)
+        self.embed_dims, self.num_heads, self.batch_first = embed_dims, num_heads, batch_first
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop)
+        self.attn_drop = attn_drop
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.dropout_layer = nn.Dropout(dropout_layer["drop_prob"]) if dropout_layer else nn.Identity()
+
+    def forward_grouped(self, x, pos, group):
+        """x, pos: [B, G*group, C]; attention within each group of `group` queries."""
+        B, N, C = x.shape
+        H = self.num_heads
+        qk = (x + pos).reshape(-1, group, C)
+        xv = x.reshape(-1, group, C)
+        w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+        qk_p = F.linear(qk, w[: 2 * C], b[: 2 * C])
+        q, k = qk_p[..., :C], qk_p[..., C:]
+        v = F.linear(xv, w[2 * C:], b[2 * C:])
+        sh = lambda t: t.reshape(-1, group, H, C // H).transpose(1, 2)
+        o = F.scaled_dot_product_attention(sh(q), sh(k), sh(v), dropout_p=self.attn_drop if self.training else 0.0)
+        o = o.transpose(1, 2).reshape(B, N, C)
+        o = self.attn.out_proj(o)
+        return x + self.dropout_layer(self.proj_drop(o))
+
+
+@FEEDFORWARD_NETWORK.register_module()
+class FFN(nn.Module):
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2, act_cfg=dict(type="ReLU", inplace=True),
+                 ffn_drop=0.0, dropout_layer=None, add_identity=True, init_cfg=None, **kwargs):
+        super().__init__()
+        layers, c = [], embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(nn.Sequential(nn.Linear(c, feedforward_channels), nn.ReLU(inplace=True), nn.Dropout(ffn_drop)))
+            c = feedforward_channels
+        layers += [nn.Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop)]
+        self.layers = nn.Sequential(*layers)
+        self.dropout_layer = nn.Dropout(dropout_layer["drop_prob"]) if dropout_layer else nn.Identity()
+        self.add_identity = add_identity
+
+    def forward(self, x, identity=None):
+        out = self.dropout_layer(self.layers(x))
+        if not self.add_identity:
+            return out
+        return (x if identity is None else identity) + out
+
+
+@ATTENTION.register_module()
+class UniCrossAtten(nn.Module):
+    """One trilinear sample of the voxel volume per query, gated by sigmoid(Linear(query+pos)), projected, plus the
+    residual and an encoding of the reference-point logits (ref :216-360)."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_points=1, num_sweeps=1, cam_sweep_feq=12, voxel_range=(0, 0, 0),
+                 im2col_step=64, dropout=0.1, norm_cfg=None, init_cfg=None, batch_first=False, fp16_enabled=False):
+        super().__init__()
+        if embed_dims % num_heads != 0:
+            raise ValueError(f"embed_dims must be divisible by num_heads, but got {embed_dims} and {num_heads}")
+        self.embed_dims, self.num_heads, self.num_points, self.num_sweeps = embed_dims, num_heads, num_points, num_sweeps
+        self.dropout = nn.Dropout(dropout)
+        self.attention_weights = nn.Linear(embed_dims, num_points)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.position_encoder = nn.Sequential(nn.Linear(3, embed_dims), nn.LayerNorm(embed_dims), nn.ReLU(inplace=True),
+                                              nn.Linear(embed_dims, embed_dims), nn.LayerNorm(embed_dims), nn.ReLU(inplace=True))
+        self.batch_first = batch_first
+        self.init_weight()
+        if fp16_enabled:
+            self.fp16_enabled = fp16_enabled
+
+    def init_weight(self):
+        nn.init.constant_(self.attention_weights.weight, 0.0)
+        nn.init.constant_(self.attention_weights.bias, 0.0)
+        nn.init.xavier_uniform_(self.output_proj.weight)
+        nn.init.constant_(self.output_proj.bias, 0.0)
+
+    def forward_bf(self, query, query_pos, value, ref_logits):
+        """query/query_pos [B,N,C]; value [B,C,D,H,W] (or [B,C,H,W]); ref_logits [B,N,3] -> [B,N,C]."""
+        w = self.attention_weights(query + query_pos).sigmoid()                       # [B,N,P]
+        g = (ref_logits.sigmoid() - 0.5) * 2
+        B, N, _ = g.shape
+        if value.dim() == 4:
+            samp = F.grid_sample(value, g[..., :2].reshape(B, 1, N, 2).to(value.dtype), align_corners=False)
+        else:
+            samp = F.grid_sample(value, g.reshape(B, 1, 1, N, 3).to(value.dtype), align_corners=False)
+        samp = samp.reshape(B, value.shape[1], N).transpose(1, 2)                     # [B,N,C]
+        out = self.output_proj(samp.to(query.dtype) * w.sum(-1, keepdim=True))
+        pos_feat = self.position_encoder(ref_logits.to(query.dtype))
+        return self.dropout(out) + query + pos_feat
+
+
+@TRANSFORMER_LAYER.register_module()
+class BaseTransformerLayer(nn.Module):
+    """(self_attn, norm, cross_attn, norm, ffn, norm) post-norm layer; members `attentions`, `ffns`, `norms`."""
+
+    def __init__(self, attn_cfgs=None, ffn_cfgs=None, operation_order=None, norm_cfg=dict(type="LN"), init_cfg=None,
+                 batch_first=False, **kwargs):
+        super().__init__()
+        self.operation_order = tuple(operation_order)
+        n_attn = self.operation_order.count("self_attn") + self.operation_order.count("cross_attn")
+        if isinstance(attn_cfgs, dict):
+            attn_cfgs = [copy.deepcopy(attn_cfgs) for _ in range(n_attn)]
+        assert len(attn_cfgs) == n_attn
+        self.attentions = nn.ModuleList(ATTENTION.build(c) for c in attn_cfgs)
+        self.embed_dims = self.attentions[0].embed_dims
+        n_ffn = self.operation_order.count("ffn")
+        if isinstance(ffn_cfgs, dict):
+            ffn_cfgs = [copy.deepcopy(ffn_cfgs) for _ in range(n_ffn)]
+        self.ffns = nn.ModuleList()
+        for c in ffn_cfgs:
+            c = dict(c)
+            c.setdefault("type", "FFN")
+            self.ffns.append(FEEDFORWARD_NETWORK.build(c))
+        assert norm_cfg["type"] == "LN"
+        self.norms = nn.ModuleList(nn.LayerNorm(self.embed_dims) for _ in range(self.operation_order.count("norm")))
+        self.pre_norm = self.operation_order[0] == "norm"
+        if self.pre_norm:
+            raise NotImplementedError("pre-norm ordering is not used by any shipped Uni3DETR config")
+
+    def forward_bf(self, x, pos, value, ref_logits, group):
+        ai = ni = fi = 0
+        for op in self.operation_order:
+            if op == "self_attn":
+                x = self.attentions[ai].forward_grouped(x, pos, group); ai += 1
+            elif op == "cross_attn":
+                x = self.attentions[ai].forward_bf(x, pos, value, ref_logits); ai += 1
+            elif op == "norm":
+                x = self.norms[ni](x); ni += 1
+            elif op == "ffn":
+                x = self.ffns[fi](x); fi += 1
+        return x
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module()
+class Uni3DETRTransformerDecoder(nn.Module):
+    def __init__(self, transformerlayers=None, num_layers=None, init_cfg=None, return_intermediate=False):
+        super().__init__()
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+        self.layers = nn.ModuleList(TRANSFORMER_LAYER.build(copy.deepcopy(transformerlayers)) for _ in range(num_layers))
+        self.embed_dims = self.layers[0].embed_dims
+        self.d_model = d = 256
+        self.query_scale = MLP(d, d, d, 3)
+        self.ref_point_head = MLP(384, d, d, 3)
+
+    def forward_bf(self, query, ref_logits, value, reg_branches, group):
+        """query [B,N,C], ref_logits [B,N,3] -> (states [L,B,N,C], refs [L,B,N,3] logits after each layer's refinement)."""
+        out = query
+        states, refs = [], []
+        for lid, layer in enumerate(self.layers):
+            raw = self.ref_point_head(get_sine_pos_embed(ref_logits.sigmoid()).to(out.dtype))
+            pos = raw if lid == 0 else self.query_scale(out) * raw
+            out = layer.forward_bf(out, pos, value, ref_logits, group)
+            if reg_branches is not None:
+                tmp = reg_branches[lid](out)
+                assert ref_logits.shape[-1] == 3
+                new_ref = torch.cat([tmp[..., :2] + ref_logits[..., :2], tmp[..., 4:5] + ref_logits[..., 2:3]], -1)
+                ref_logits = new_ref.detach()
+            states.append(out)
+            refs.append(ref_logits)
+        if self.return_intermediate:
+            return torch.stack(states), torch.stack(refs)
+        return out, ref_logits
+
+
+@TRANSFORMER.register_module()
+class Uni3DETRTransformer(nn.Module):
+    def __init__(self, decoder=None, fp16_enabled=False, init_cfg=None, **kwargs):
+        super().__init__()
+        self.decoder = TRANSFORMER_LAYER_SEQUENCE.build(decoder)
+        self.embed_dims = self.decoder.embed_dims
+        self.d_model = 256
+        if fp16_enabled:
+            self.fp16_enabled = fp16_enabled
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, UniCrossAtten):
+                m.init_weight()
+
+    def forward(self, pts_value, query_embed, num_query, reg_branches=None, **kwargs):
+        """pts_value [B,(1,)C,D,H,W]; query_embed [B, G*num_query, 256+3].  Returns the reference's triple:
+        inter_states [L, G*nq, B, C], init_reference [B, G*nq, 3], inter_references [L, B, G*nq, 3] (sigmoid space)."""
+        assert query_embed is not None
+        if pts_value.dim() == 6:
+            pts_value = pts_value.flatten(0, 1) if pts_value.shape[1] == 1 else pts_value[:, 0]
+        ref_logits = query_embed[..., self.d_model:]
+        query = query_embed[..., : self.d_model]
+        states, refs = self.decoder.forward_bf(query, ref_logits, pts_value, reg_branches, num_query)
+        if not self.decoder.return_intermediate:
+            states, refs = states[None], refs[None]
+        return states.permute(0, 2, 1, 3), ref_logits.sigmoid(), refs.sigmoid()

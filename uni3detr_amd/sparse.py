@@ -1,0 +1,175 @@
+"""Host side of the sparse levels: geometry (BitGrid / neighbour tables) and autograd wrappers around the HIP
+sparse-conv / BatchNorm1d / dense() kernels.  Every op calls libu3d_hip.so; nothing here has a torch fallback.
+
+Replaces spconv's SparseConvTensor / indice_key machinery used by the reference encoder
+(ref: models/pts_encoder/sparse_encoder_hd.py:106-138).
+"""
+import torch
+
+from . import native as nv
+
+K3, S1, P1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+
+
+class Level:
+    """One sparse resolution: coordinates in block-major rank order + its SubM tables (built lazily, once per step —
+    the reference rebuilds them for each of its 16 block convs because SparseBasicBlock carries no indice_key)."""
+
+    def __init__(self, grid, coords, n, n_dev):
+        self.grid, self.coords, self.n, self.n_dev = grid, coords, n, n_dev
+        self.dims, self.batch = grid.dims, grid.batch
+        self._subm = None
+
+    def subm_tables(self):
+        if self._subm is None:
+            fwd = self.grid.nbr_table(self.coords, self.n_dev, K3, S1, P1, 0)
+            bwd = self.grid.nbr_table(self.coords, self.n_dev, K3, S1, P1, 1)
+            self._subm = (fwd, bwd)
+        return self._subm
+
+
+class ConvGeom:
+    """Tables of one convolution instance: forward (output-stationary), transposed (input-stationary), sizes."""
+
+    def __init__(self, nbr_fwd, nbr_bwd, n_in, n_in_dev, n_out, n_out_dev):
+        self.nbr_fwd, self.nbr_bwd = nbr_fwd, nbr_bwd
+        self.n_in, self.n_in_dev, self.n_out, self.n_out_dev = n_in, n_in_dev, n_out, n_out_dev
+
+
+def level_from_coors(coors, batch, dims):
+    """coors int32 [N,4] (b,z,y,x), unique.  Returns (Level, rank) with rank[i] = internal row of input row i."""
+    dev = coors.device
+    g = nv.BitGrid(batch, dims, dev)
+    g.mark(coors)
+    g.scan()
+    n = coors.shape[0]
+    rank = g.rank(coors)
+    lvl = Level(g, g.coords(n), n, g.count_dev)
+    return lvl, rank
+
+
+def subm_geom(lvl):
+    fwd, bwd = lvl.subm_tables()
+    return ConvGeom(fwd, bwd, lvl.n, lvl.n_dev, lvl.n, lvl.n_dev)
+
+
+def strided_level(lvl, ksize, stride, pad):
+    """Active output set + tables of a SparseConv3d (ref: sparse_encoder_hd.py:181-192).  One host read of the new
+    row count (the reference's own flow syncs at models/detectors/uni3detr.py:153)."""
+    dims_out = tuple((d + 2 * p - k) // s + 1 for d, k, s, p in zip(lvl.dims, ksize, stride, pad))
+    g = nv.BitGrid(lvl.batch, dims_out, lvl.coords.device)
+    g.mark_strided(lvl.coords, lvl.n_dev, ksize, stride, pad)
+    g.scan()
+    n_out = int(g.count_dev.item())
+    out = Level(g, g.coords(n_out), n_out, g.count_dev)
+    fwd = lvl.grid.nbr_table(out.coords, out.n_dev, ksize, stride, pad, 0)
+    bwd = g.nbr_table(lvl.coords, lvl.n_dev, ksize, stride, pad, 1)
+    return out, ConvGeom(fwd, bwd, lvl.n, lvl.n_dev, n_out, out.n_dev)
+
+
+class _SparseConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, weight, geom):
+        # weight: [kD,kH,kW,Cin,Cout] (mmcv spconv-1.x layout) or [1,1,1,Cin,Cout]
+        w = weight.reshape(-1, weight.shape[-2], weight.shape[-1])
+        wc = w if w.dtype == feats.dtype else w.to(feats.dtype)
+        ctx.geom = geom
+        ctx.save_for_backward(feats, wc)
+        ctx.wshape, ctx.wdtype = weight.shape, weight.dtype
+        nbr = geom.nbr_fwd if w.shape[0] > 1 else None
+        return nv.spconv_fwd(feats, wc.contiguous(), nbr, geom.n_out_dev, geom.n_out, w.shape[2])
+
+    @staticmethod
+    def backward(ctx, dout):
+        feats, wc = ctx.saved_tensors
+        g = ctx.geom
+        dout = dout.contiguous()
+        kvol = wc.shape[0]
+        din = dw = None
+        if ctx.needs_input_grad[0]:
+            nbr = g.nbr_bwd if kvol > 1 else None
+            din = nv.spconv_fwd(dout, wc.contiguous(), nbr, g.n_in_dev, g.n_in, wc.shape[1], transpose_w=True)
+        if ctx.needs_input_grad[1]:
+            nbr = g.nbr_fwd if kvol > 1 else None
+            dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol).reshape(ctx.wshape).to(ctx.wdtype)
+        return din, dw, None
+
+
+def sparse_conv(feats, weight, geom):
+    return _SparseConv.apply(feats, weight, geom)
+
+
+class _BNRows(torch.autograd.Function):
+    """BatchNorm1d over active rows (+ residual) (+ ReLU), training or eval statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, n_dev, bn, relu, training):
+        n = x.shape[0]
+        if training:
+            sums = nv.bn_stats(x, n_dev)
+            mean, invstd = nv.bn_finalize(sums, n_dev, n, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                                          bn.running_mean, bn.running_var, bn.num_batches_tracked)
+        else:
+            mean = bn.running_mean
+            invstd = torch.rsqrt(bn.running_var + bn.eps)
+        g32, b32 = gamma.float(), beta.float()
+        y = nv.bn_apply(x, mean, invstd, g32, b32, residual, relu, n_dev)
+        ctx.save_for_backward(x, y, mean, invstd, g32)
+        ctx.n_dev, ctx.relu, ctx.training, ctx.has_res = n_dev, relu, training, residual is not None
+        ctx.pdtype = gamma.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        sums = nv.bn_bwd_stats(dy, y, x, mean, invstd, ctx.relu, ctx.n_dev)
+        if not ctx.training:
+            # eval statistics are constants: dx = gamma*invstd*g
+            zero = torch.zeros_like(sums)
+            dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, zero, ctx.relu, ctx.n_dev, ctx.has_res)
+        else:
+            dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, ctx.relu, ctx.n_dev, ctx.has_res)
+        dgamma = sums[1].to(ctx.pdtype)
+        dbeta = sums[0].to(ctx.pdtype)
+        return dx, dgamma, dbeta, dres, None, None, None, None
+
+
+def bn_rows(x, bn, n_dev, residual=None, relu=True):
+    return _BNRows.apply(x, bn.weight, bn.bias, residual, n_dev, bn, relu, bn.training)
+
+
+class _ToDense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, lvl):
+        ctx.lvl = lvl
+        return nv.to_dense(feats, lvl.coords, lvl.n_dev, lvl.batch, lvl.dims)
+
+    @staticmethod
+    def backward(ctx, dvol):
+        lvl = ctx.lvl
+        cl = dvol.permute(0, 2, 3, 4, 1).contiguous()      # no copy when dvol is channels_last_3d
+        return nv.from_dense(cl, lvl.coords, lvl.n_dev, lvl.n), None
+
+
+def to_dense(feats, lvl):
+    """rows -> [B,C,D,H,W] (channels_last_3d memory) (ref: sparse_encoder_hd.py:133)."""
+    return _ToDense.apply(feats, lvl)
+
+
+class _PermuteRows(torch.autograd.Function):
+    """out[rank[i]] = in[i] (API row order -> internal block-major order)."""
+
+    @staticmethod
+    def forward(ctx, feats, rank, n_out):
+        ctx.save_for_backward(rank)
+        return nv.scatter_rows(feats.contiguous(), rank, n_out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (rank,) = ctx.saved_tensors
+        return nv.gather_rows(dout.contiguous(), rank), None, None
+
+
+def permute_rows(feats, rank, n_out):
+    return _PermuteRows.apply(feats, rank, n_out)
