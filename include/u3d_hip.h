@@ -82,6 +82,13 @@ int32_t u3d_nbr_table(const u3d_bitgrid* target, const int32_t* q_coors, const i
                       const int32_t ksize[3], const int32_t stride[3], const int32_t pad[3], int32_t mode,
                       int32_t* nbr, int32_t ld, u3d_stream s);
 
+/* Same table for a DENSE lattice (every cell of [batch, dims] is a row; row id = lexicographic (b,z,y,x) index, i.e. the
+ * memory order of a channels-last volume): lets the dense SECOND3D / SECOND3DFPN convolutions run on the same
+ * implicit-GEMM kernels (ref: models/backbones/second_3d.py:52-76, models/necks/second3d_fpn.py:48-104). */
+int32_t u3d_dense_nbr_table(int32_t batch, const int32_t q_dims[3], const int32_t t_dims[3], const int32_t ksize[3],
+                            const int32_t stride[3], const int32_t pad[3], int32_t mode, int32_t* nbr, int32_t ld,
+                            u3d_stream s);
+
 /* ------------------------------------------------------------------------------------------------
  * Hard voxelization + mean VFE (ref: models/detectors/uni3detr.py:148-149; upstream mmcv Voxelization
  * hard mode + HardSimpleVFE).  Sequential semantics reproduced exactly: voxels in

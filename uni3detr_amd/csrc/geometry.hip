@@ -252,6 +252,53 @@ extern "C" int32_t u3d_nbr_table(const u3d_bitgrid* target, const int32_t* q_coo
   return U3D_OK;
 }
 
+// Dense lattice variant: every cell of [B, dims] is a row, row id = lexicographic (b,z,y,x) index (== the memory order of
+// a channels-last volume).  q_dims: lattice of the query rows, t_dims: lattice of the partner rows.
+__global__ void k_dense_nbr_table(int B, int qz, int qy, int qx, int tz, int ty, int tx, Conv3 cv, int mode,
+                                  int* __restrict__ nbr, int ld) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ld) return;
+  int kvol = cv.k[0] * cv.k[1] * cv.k[2];
+  long long nq = (long long)B * qz * qy * qx;
+  if (i >= nq) {
+    for (int k = 0; k < kvol; ++k) nbr[(long long)k * ld + i] = -1;
+    return;
+  }
+  int x = i % qx; int t = i / qx;
+  int y = t % qy; t /= qy;
+  int z = t % qz; int b = t / qz;
+  int k = 0;
+  for (int kz = 0; kz < cv.k[0]; ++kz)
+    for (int ky = 0; ky < cv.k[1]; ++ky)
+      for (int kx = 0; kx < cv.k[2]; ++kx, ++k) {
+        int pz, py, px;
+        bool ok = true;
+        if (mode == 0) {
+          pz = z * cv.s[0] - cv.p[0] + kz; py = y * cv.s[1] - cv.p[1] + ky; px = x * cv.s[2] - cv.p[2] + kx;
+        } else {
+          int uz = z + cv.p[0] - kz, uy = y + cv.p[1] - ky, ux = x + cv.p[2] - kx;
+          ok = uz >= 0 && uy >= 0 && ux >= 0 && uz % cv.s[0] == 0 && uy % cv.s[1] == 0 && ux % cv.s[2] == 0;
+          pz = uz / cv.s[0]; py = uy / cv.s[1]; px = ux / cv.s[2];
+        }
+        ok = ok && (unsigned)pz < (unsigned)tz && (unsigned)py < (unsigned)ty && (unsigned)px < (unsigned)tx;
+        nbr[(long long)k * ld + i] = ok ? (int)((((long long)b * tz + pz) * ty + py) * tx + px) : -1;
+      }
+}
+
+extern "C" int32_t u3d_dense_nbr_table(int32_t batch, const int32_t q_dims[3], const int32_t t_dims[3], const int32_t ksize[3],
+                                       const int32_t stride[3], const int32_t pad[3], int32_t mode, int32_t* nbr, int32_t ld,
+                                       u3d_stream s) {
+  U3D_REQUIRE(nbr && batch > 0 && (mode == 0 || mode == 1), U3D_ERR_ARG);
+  long long nq = (long long)batch * q_dims[0] * q_dims[1] * q_dims[2];
+  U3D_REQUIRE(ld >= nq && nq < 0x7fffffffll, U3D_ERR_ARG);
+  Conv3 cv;
+  for (int i = 0; i < 3; ++i) { cv.k[i] = ksize[i]; cv.s[i] = stride[i]; cv.p[i] = pad[i]; U3D_REQUIRE(stride[i] > 0 && ksize[i] > 0, U3D_ERR_ARG); }
+  hipLaunchKernelGGL(k_dense_nbr_table, dim3(u3d_cdiv(ld, 256)), dim3(256), 0, s, batch, q_dims[0], q_dims[1], q_dims[2],
+                     t_dims[0], t_dims[1], t_dims[2], cv, mode, nbr, ld);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
 // ============================================================================================
 // Row gather / scatter (4-byte granularity, one wave per row segment)
 // ============================================================================================

@@ -43,6 +43,7 @@ _SIGS = {
     "u3d_bitgrid_rank": (_I, [C.POINTER(BitGridStruct), _P, _I, _P, _P]),
     "u3d_bitgrid_coords": (_I, [C.POINTER(BitGridStruct), _P, _I, _P]),
     "u3d_nbr_table": (_I, [C.POINTER(BitGridStruct), _P, _P, _I, _I3, _I3, _I3, _I, _P, _I, _P]),
+    "u3d_dense_nbr_table": (_I, [_I, _I3, _I3, _I3, _I3, _I3, _I, _P, _I, _P]),
     "u3d_voxelize_hard_workspace": (_L, [_I, _I, _I]),
     "u3d_voxelize_hard": (_I, [_P, _P, _I, _I, _I, _I, _F3, _F6, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P]),
     "u3d_spconv_fwd": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -158,6 +159,17 @@ class BitGrid:
         return nbr
 
 
+def dense_nbr_table(batch, q_dims, t_dims, ksize, stride, pad, mode, device):
+    n = batch * q_dims[0] * q_dims[1] * q_dims[2]
+    ld = (n + 127) // 128 * 128
+    kvol = ksize[0] * ksize[1] * ksize[2]
+    nbr = torch.empty((kvol, ld), dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        _check(lib().u3d_dense_nbr_table(batch, _I3(*q_dims), _I3(*t_dims), _I3(*ksize), _I3(*stride), _I3(*pad), mode, _ptr(nbr), ld,
+                                         _stream()), "dense_nbr_table")
+    return nbr
+
+
 # --------------------------------------------------------------------------------------------------
 # voxelization
 # --------------------------------------------------------------------------------------------------
@@ -184,14 +196,53 @@ def voxelize_hard(points, scene_off, batch, max_pts_per_scene, voxel_size, pc_ra
 # --------------------------------------------------------------------------------------------------
 # sparse conv / BN / dense
 # --------------------------------------------------------------------------------------------------
+class KernelTimer:
+    """HIP-event timing of individual launches on the stream they run on (used by bench.py for the roofline block).
+    mode 'census': also counts the valid rulebook pairs P of each call (host sync) to price its algorithmic bytes:
+    N_in*Cin*s + N_out*Cout*s + 8*P + K*Cin*Cout*s."""
+
+    def __init__(self, mode="time"):
+        self.mode, self.calls, self.census = mode, [], []
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, tag, e0, meta=None):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.calls.append((tag, e0, e1))
+        if self.mode == "census":
+            self.census.append((tag, meta))
+
+    def durations_ms(self):
+        torch.cuda.synchronize()
+        return [(t, a.elapsed_time(b)) for t, a, b in self.calls]
+
+
+TIMER = None
+
+
 def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False):
     """out[m] = sum_k in[nbr[k][m]] @ W[k]; w: [K, Cin_w, Cout_w] contiguous. Returns [n_out, cout]."""
     kvol = w.shape[0]
     cin = inp.shape[1]
     out = torch.empty((n_out, cout), dtype=inp.dtype, device=inp.device)
     ld = nbr.shape[1] if nbr is not None else 0
+    t = TIMER
+    e0 = t.begin() if t is not None else None
     _check(lib().u3d_spconv_fwd(_ptr(inp), _ptr(w), _ptr(nbr), ld, _ptr(out), _ptr(n_out_dev), n_out, cin, cout, kvol,
                                 1 if transpose_w else 0, dtype_code(inp), _stream()), "spconv_fwd")
+    if t is not None:
+        meta = None
+        if t.mode == "census":
+            pairs = int((nbr[:, :n_out] >= 0).sum().item()) if nbr is not None else n_out
+            s = inp.element_size()
+            meta = dict(n_in=inp.shape[0], n_out=n_out, cin=cin, cout=cout, kvol=kvol, pairs=pairs,
+                        bytes=inp.shape[0] * cin * s + n_out * cout * s + 8 * pairs + kvol * cin * cout * s,
+                        flops=2 * pairs * cin * cout)
+        t.end("spconv_dgrad" if transpose_w else "spconv_fwd", e0, meta)
     return out
 
 

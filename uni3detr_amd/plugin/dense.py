@@ -1,27 +1,126 @@
-"""SECOND3D backbone and SECOND3DFPN neck (ref: projects/mmdet3d_plugin/models/backbones/second_3d.py:11-114,
-projects/mmdet3d_plugin/models/necks/second3d_fpn.py:11-143).  Dense 3-D convolutions run through PyTorch-ROCm
-(MIOpen) in channels_last_3d; module/parameter names are the reference's (`blocks.{i}.{3j}.weight`, `deblocks.{i}.0.weight`,
-`extra_blocks.{3j}.weight`)."""
+"""SECOND3D backbone and SECOND3DFPN neck behind the reference's registry names and constructors (ref:
+projects/mmdet3d_plugin/models/backbones/second_3d.py:11-114, projects/mmdet3d_plugin/models/necks/second3d_fpn.py:11-143).
+
+Execution is NOT torch/MIOpen convolution (on this stack MIOpen resolves NDHWC 3-D convolutions to naive kernels:
+profiles/r01_a_*): a dense volume is the special case "every cell active" of the sparse levels, so every Conv3d /
+ConvTranspose3d + BatchNorm3d + ReLU here runs on the same HIP implicit-GEMM, weight-gradient and BatchNorm-rows
+kernels as the sparse encoder, over channels-last rows [B*D*H*W, C] with a static neighbour table of the lattice.
+The nn.Conv3d / nn.BatchNorm3d modules are kept as parameter holders so that state_dict names and shapes are the
+reference checkpoints' (`blocks.{i}.{3j}.weight` [Cout,Cin,kd,kh,kw], `deblocks.{i}.0.weight`, `extra_blocks.{3j}.weight`).
+"""
 import numpy as np
 import torch
 from torch import nn
 
+from .. import native as nv
+from .. import sparse as sp
 from ..registry import BACKBONES, NECKS
 
 
 def _conv(cfg, cin, cout, kernel, stride=1, padding=0):
     cfg = dict(cfg)
     t = cfg.pop("type")
-    cls = {"Conv3d": nn.Conv3d, "Conv2d": nn.Conv2d}[t]
-    return cls(cin, cout, kernel, stride=stride, padding=padding, **cfg)
+    if t != "Conv3d":
+        raise NotImplementedError("the HIP dense path implements the Conv3d variant used by every shipped config")
+    if cfg.get("bias", True):
+        raise NotImplementedError("shipped configs build these convolutions with bias=False")
+    return nn.Conv3d(cin, cout, kernel, stride=stride, padding=padding, **cfg)
 
 
 def _norm(cfg, c):
     cfg = dict(cfg)
     t = cfg.pop("type")
-    cls = {"BN3d": nn.BatchNorm3d, "BN2d": nn.BatchNorm2d, "BN": nn.BatchNorm2d}[t]
+    assert t == "BN3d", "shipped configs use BN3d"
     cfg.pop("requires_grad", None)
-    return cls(c, **cfg)
+    return nn.BatchNorm3d(c, **cfg)
+
+
+class Lattice:
+    """Static geometry of dense volumes on one device: neighbour tables keyed by (B, dims, kernel, stride, pad)."""
+
+    _cache = {}
+
+    @classmethod
+    def conv(cls, device, batch, dims_in, ksize, stride, pad):
+        key = ("c", str(device), batch, tuple(dims_in), tuple(ksize), tuple(stride), tuple(pad))
+        g = cls._cache.get(key)
+        if g is None:
+            dims_out = tuple((d + 2 * p - k) // s + 1 for d, k, s, p in zip(dims_in, ksize, stride, pad))
+            n_in = batch * dims_in[0] * dims_in[1] * dims_in[2]
+            n_out = batch * dims_out[0] * dims_out[1] * dims_out[2]
+            one = all(k == 1 for k in ksize) and all(s == 1 for s in stride)
+            fwd = None if one else nv.dense_nbr_table(batch, dims_out, dims_in, ksize, stride, pad, 0, device)
+            bwd = None if one else nv.dense_nbr_table(batch, dims_in, dims_out, ksize, stride, pad, 1, device)
+            n_in_dev = torch.tensor([n_in], dtype=torch.int32, device=device)
+            n_out_dev = torch.tensor([n_out], dtype=torch.int32, device=device)
+            g = (sp.ConvGeom(fwd, bwd, n_in, n_in_dev, n_out, n_out_dev), dims_out)
+            cls._cache[key] = g
+        return g
+
+    @classmethod
+    def upsample_index(cls, device, batch, dims_in, s):
+        """Row map of a (1,s,s)/(1,s,s) transposed conv: output row -> row of Y.view(N_in*s*s, Cout), Y = X @ [W_tap...]."""
+        key = ("u", str(device), batch, tuple(dims_in), s)
+        v = cls._cache.get(key)
+        if v is None:
+            D, H, W = dims_in
+            b = torch.arange(batch, device=device).view(-1, 1, 1, 1)
+            z = torch.arange(D, device=device).view(1, -1, 1, 1)
+            y = torch.arange(H * s, device=device).view(1, 1, -1, 1)
+            x = torch.arange(W * s, device=device).view(1, 1, 1, -1)
+            in_row = ((b * D + z) * H + y // s) * W + x // s
+            tap = (y % s) * s + (x % s)
+            idx = (in_row * (s * s) + tap).reshape(-1).int().contiguous()
+            inv = torch.empty_like(idx)
+            inv[idx.long()] = torch.arange(idx.numel(), device=device, dtype=torch.int32)
+            v = (idx, inv, (D, H * s, W * s))
+            cls._cache[key] = v
+        return v
+
+
+class _GatherBijection(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows, idx, inv):
+        ctx.save_for_backward(inv)
+        return nv.gather_rows(rows.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (inv,) = ctx.saved_tensors
+        return nv.gather_rows(dout.contiguous(), inv), None, None
+
+
+def to_rows(x):
+    """[B,C,D,H,W] (any strides) -> (rows [B*D*H*W, C] contiguous, B, dims); free for channels_last_3d tensors."""
+    B, C, D, H, W = x.shape
+    return x.permute(0, 2, 3, 4, 1).reshape(-1, C), B, (D, H, W)
+
+
+def to_volume(rows, B, dims):
+    """rows -> logical [B,C,D,H,W] view in channels_last_3d memory."""
+    return rows.view(B, *dims, rows.shape[1]).permute(0, 4, 1, 2, 3)
+
+
+def conv_bn_relu(rows, B, dims, conv, bn):
+    ks, st, pd = tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding)
+    geom, dims_out = Lattice.conv(rows.device, B, dims, ks, st, pd)
+    w = conv.weight.permute(2, 3, 4, 1, 0)                 # [Cout,Cin,kd,kh,kw] -> [kd,kh,kw,Cin,Cout]
+    y = sp.sparse_conv(rows, w, geom)
+    return sp.bn_rows(y, bn, geom.n_out_dev, None, True), dims_out
+
+
+def deconv_bn_relu(rows, B, dims, deconv, bn):
+    s = deconv.stride[1]
+    assert tuple(deconv.kernel_size) == (1, s, s) and tuple(deconv.stride) == (1, s, s), "non-overlapping (1,s,s) upsampling only"
+    cin, cout = deconv.weight.shape[0], deconv.weight.shape[1]
+    n_in = rows.shape[0]
+    geom, _ = Lattice.conv(rows.device, B, dims, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    w = deconv.weight.permute(0, 2, 3, 4, 1).reshape(1, 1, 1, cin, s * s * cout)     # columns = (tap, cout)
+    y = sp.sparse_conv(rows, w, geom).view(n_in * s * s, cout)
+    idx, inv, dims_out = Lattice.upsample_index(rows.device, B, dims, s)
+    y = _GatherBijection.apply(y, idx, inv)
+    n_dev = Lattice.conv(rows.device, B, dims_out, (1, 1, 1), (1, 1, 1), (0, 0, 0))[0].n_out_dev
+    return sp.bn_rows(y, bn, n_dev, None, True), dims_out
 
 
 @BACKBONES.register_module()
@@ -39,8 +138,7 @@ class SECOND3D(nn.Module):
         blocks = []
         for i, n in enumerate(layer_nums):
             s = layer_strides[i]
-            stride = (1, s, s) if len(padding) == 3 else (s, s)
-            layers = [_conv(conv_cfg, in_filters[i], out_channels[i], kernel, stride, padding), _norm(norm_cfg, out_channels[i]),
+            layers = [_conv(conv_cfg, in_filters[i], out_channels[i], kernel, (1, s, s), padding), _norm(norm_cfg, out_channels[i]),
                       nn.ReLU(inplace=True)]
             for _ in range(n):
                 layers += [_conv(conv_cfg, out_channels[i], out_channels[i], kernel, 1, padding), _norm(norm_cfg, out_channels[i]),
@@ -48,19 +146,23 @@ class SECOND3D(nn.Module):
             blocks.append(nn.Sequential(*layers))
         self.blocks = nn.ModuleList(blocks)
 
+    @staticmethod
+    def _run_block(blk, rows, B, dims):
+        mods = list(blk)
+        for j in range(0, len(mods), 3):
+            rows, dims = conv_bn_relu(rows, B, dims, mods[j], mods[j + 1])
+        return rows, dims
+
     def forward(self, x):
+        rows, B, dims = to_rows(x)
         outs = []
-        batch = x.shape[0]
-        if self.kernel_type == "Conv2d":
-            x = x.transpose(1, 2).flatten(0, 1)
         for blk in self.blocks:
             if self.is_cascade:
-                x = blk(x)
-                outs.append(x)
+                rows, dims = self._run_block(blk, rows, B, dims)
+                outs.append(to_volume(rows, B, dims))
             else:
-                outs.append(blk(x))
-        if self.kernel_type == "Conv2d":
-            outs = [o.reshape(batch, -1, *o.shape[-3:]).transpose(1, 2) for o in outs]
+                r, d = self._run_block(blk, rows, B, dims)
+                outs.append(to_volume(r, B, d))
         return tuple(outs)
 
 
@@ -74,21 +176,17 @@ class SECOND3DFPN(nn.Module):
         assert len(out_channels) == len(upsample_strides) == len(in_channels)
         self.in_channels, self.out_channels = in_channels, out_channels
         self.fp16_enabled = False
-        self.use_for_distill = use_for_distill
-        up3d = "3d" in upsample_cfg["type"]
+        if use_for_distill:
+            raise NotImplementedError("use_for_distill is not used by any shipped Uni3DETR config")
+        assert upsample_cfg["type"] == "deconv3d" and not upsample_cfg.get("bias", True)
         deblocks = []
         for i, oc in enumerate(out_channels):
             s = upsample_strides[i]
             if s > 1 or (s == 1 and not use_conv_for_no_stride):
-                cfg = dict(upsample_cfg)
-                cfg.pop("type")
-                k = (1, s, s) if up3d else (s, s)
-                up = (nn.ConvTranspose3d if up3d else nn.ConvTranspose2d)(in_channels[i], oc, k, stride=k, **cfg)
+                up = nn.ConvTranspose3d(in_channels[i], oc, (1, s, s), stride=(1, s, s), bias=False)
             else:
                 s2 = int(np.round(1 / s))
-                c3d = "3d" in conv_cfg["type"]
-                k = (1, s2, s2) if c3d else (s2, s2)
-                up = _conv(conv_cfg, in_channels[i], oc, k, k)
+                up = _conv(conv_cfg, in_channels[i], oc, (1, s2, s2), (1, s2, s2))
             deblocks.append(nn.Sequential(up, _norm(norm_cfg, oc), nn.ReLU(inplace=True)))
         self.deblocks = nn.ModuleList(deblocks)
         self.extra_conv = extra_conv
@@ -96,29 +194,28 @@ class SECOND3DFPN(nn.Module):
             extra = dict(extra_conv)
             self.layer_num = extra.pop("num_conv")
             kernel = tuple(extra.pop("kernel")) if "kernel" in extra else (3, 3, 3)
+            if "sep_kernel" in extra:
+                raise NotImplementedError("sep_kernel is not used by any shipped Uni3DETR config")
             padding = tuple((k - 1) // 2 for k in kernel)
-            sep_kernel = tuple(extra.pop("sep_kernel")) if "sep_kernel" in extra else None
             layers = []
             for _ in range(self.layer_num):
-                layers.append(_conv(extra, out_channels[-1], out_channels[-1], kernel, 1, padding))
-                if sep_kernel:
-                    layers.append(_conv(extra, out_channels[-1], out_channels[-1], sep_kernel, 1, tuple((k - 1) // 2 for k in sep_kernel)))
-                layers += [_norm(norm_cfg, out_channels[-1]), nn.ReLU(inplace=True)]
+                layers += [_conv(extra, out_channels[-1], out_channels[-1], kernel, 1, padding), _norm(norm_cfg, out_channels[-1]),
+                           nn.ReLU(inplace=True)]
             self.extra_blocks = nn.Sequential(*layers)
 
     def forward(self, x):
         assert len(x) == len(self.in_channels)
-        ups = [d(x[i]) for i, d in enumerate(self.deblocks)]
-        out = ups[0]
-        for u in ups[1:]:
-            out = out + u
+        out, odims, B = None, None, None
+        for i, d in enumerate(self.deblocks):
+            rows, B, dims = to_rows(x[i])
+            if isinstance(d[0], nn.ConvTranspose3d):
+                r, dd = deconv_bn_relu(rows, B, dims, d[0], d[1])
+            else:
+                r, dd = conv_bn_relu(rows, B, dims, d[0], d[1])
+            assert odims is None or odims == dd, "FPN levels must land on one lattice"
+            out, odims = (r if out is None else out + r), dd
         if self.extra_conv is not None:
-            if self.use_for_distill:
-                final, before = out, []
-                for i in range(self.layer_num):
-                    mid = self.extra_blocks[i * 3:(i + 1) * 3 - 1](final)
-                    before.append(mid.clone())
-                    final = self.extra_blocks[(i + 1) * 3 - 1](mid)
-                return {"final": final, "before_relu": before}
-            out = self.extra_blocks(out)
-        return out
+            mods = list(self.extra_blocks)
+            for j in range(0, len(mods), 3):
+                out, odims = conv_bn_relu(out, B, odims, mods[j], mods[j + 1])
+        return to_volume(out, B, odims)
