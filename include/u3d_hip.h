@@ -196,6 +196,15 @@ int32_t u3d_match_cost(const float* cls, const float* box, const float* gt, cons
 int32_t u3d_lsa(const float* cost, const int32_t* gt_off, int32_t nlayers, int32_t batch, int32_t nq_total,
                 int32_t nq, int32_t gmax, int32_t* assigned, u3d_stream s);
 
+/* Trilinear sampling of a channels-last volume at query points = UniCrossAtten's F.grid_sample (mode bilinear, zeros padding,
+ * align_corners=False; ref: models/utils/uni3detr_transformer.py:342-345).  value: rows [batch*dz*dy*dx, c] (f32|bf16),
+ * grid f32 [batch,nq,3] (x,y,z) in [-1,1], out [batch,nq,c].  Backward: dvalue f32 [rows,c] accumulated with atomics
+ * (caller zeroes; may be NULL), dgrid f32 [batch,nq,3] (may be NULL). */
+int32_t u3d_trilinear_fwd(const void* value, const float* grid, int32_t batch, int32_t nq, int32_t dz, int32_t dy, int32_t dx,
+                          int32_t c, void* out, int32_t dtype, u3d_stream s);
+int32_t u3d_trilinear_bwd(const void* value, const float* grid, const void* dout, int32_t batch, int32_t nq, int32_t dz,
+                          int32_t dy, int32_t dx, int32_t c, float* dvalue, float* dgrid, int32_t dtype, u3d_stream s);
+
 /* diag(bbox_overlaps_3d(a,b)) for a,b f32 [n,7] (ref: models/dense_heads/uni3detr_head.py:695). */
 int32_t u3d_iou3d_rotated_aligned(const float* a, const float* b, int32_t n, float* out, u3d_stream s);
 

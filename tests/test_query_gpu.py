@@ -104,3 +104,26 @@ def test_rotated_iou_aligned(cuda):
     got = nv.iou3d_rotated_aligned(torch.from_numpy(a).to(cuda), torch.from_numpy(b).to(cuda)).cpu()
     ref = ob.bbox_overlaps_3d_aligned(torch.from_numpy(a), torch.from_numpy(b))
     assert (got - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_trilinear_sampler_matches_grid_sample(cuda, dtype):
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    B, C, D, H, W, N = 2, 256, 15, 40, 40, 900
+    vol = torch.randn(B, C, D, H, W)
+    grid = torch.rand(B, N, 3) * 2.4 - 1.2                       # includes out-of-range samples (zero padding)
+    gy = torch.randn(B, N, C)
+    vr = vol.clone().requires_grad_(True)
+    gr = grid.clone().requires_grad_(True)
+    ref = F.grid_sample(vr, gr.view(B, 1, 1, N, 3), mode="bilinear", padding_mode="zeros", align_corners=False)
+    ref = ref.view(B, C, N).transpose(1, 2)
+    (ref * gy).sum().backward()
+    rows = vol.permute(0, 2, 3, 4, 1).reshape(-1, C).contiguous().to(cuda).to(dtype)
+    out = nv.trilinear_fwd(rows, grid.to(cuda), B, (D, H, W))
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    assert (out.float().cpu() - ref.detach()).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    dv, dg = nv.trilinear_bwd(rows, grid.to(cuda), gy.to(cuda).to(dtype), B, (D, H, W))
+    dvr = vr.grad.permute(0, 2, 3, 4, 1).reshape(-1, C)
+    assert (dv.cpu() - dvr).abs().max().item() <= (1e-4 if dtype == torch.float32 else 5e-2) * max(1.0, dvr.abs().max().item())
+    assert (dg.cpu() - gr.grad).abs().max().item() <= (1e-3 if dtype == torch.float32 else 8e-2) * max(1.0, gr.grad.abs().max().item())

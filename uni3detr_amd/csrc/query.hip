@@ -390,3 +390,112 @@ extern "C" int32_t u3d_iou3d_rotated_aligned(const float* a, const float* b, int
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
+
+// ============================================================================================
+// Trilinear sampling of a channels-last volume at query points — the "cross attention" of UniCrossAtten
+// (ref: models/utils/uni3detr_transformer.py:342-345: F.grid_sample(value [B,C,D,H,W], grid [B,1,1,N,3]),
+// mode bilinear(=trilinear), padding zeros, align_corners=False; grid (x,y,z) in [-1,1] indexes (W,H,D)).
+// value: rows [B*D*H*W, C] (f32 or bf16), grid f32 [B,N,3], out [B,N,C] (value dtype).  One wavefront per query.
+// backward: dvalue f32 [B*D*H*W, C] (+= atomics, caller zeroes), dgrid f32 [B,N,3].
+// ============================================================================================
+struct TriCorner { long long row[8]; float w[8]; float dwx[8], dwy[8], dwz[8]; };
+
+__device__ __forceinline__ void tri_setup(const float* g, int b, int D, int H, int W, TriCorner& tc) {
+  float ix = ((g[0] + 1.f) * W - 1.f) * 0.5f, iy = ((g[1] + 1.f) * H - 1.f) * 0.5f, iz = ((g[2] + 1.f) * D - 1.f) * 0.5f;
+  float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+  int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+  float tx = ix - fx, ty = iy - fy, tz = iz - fz;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+    int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+    float wx = dx ? tx : 1.f - tx, wy = dy ? ty : 1.f - ty, wz = dz ? tz : 1.f - tz;
+    bool ok = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H && (unsigned)z < (unsigned)D;
+    tc.row[c] = ok ? (((long long)b * D + z) * H + y) * W + x : -1;
+    tc.w[c] = wx * wy * wz;
+    tc.dwx[c] = (dx ? 1.f : -1.f) * wy * wz;
+    tc.dwy[c] = (dy ? 1.f : -1.f) * wx * wz;
+    tc.dwz[c] = (dz ? 1.f : -1.f) * wx * wy;
+  }
+}
+
+__device__ __forceinline__ float ld_any(const float* p, long long i) { return p[i]; }
+__device__ __forceinline__ float ld_any(const unsigned short* p, long long i) { return __uint_as_float(((unsigned)p[i]) << 16); }
+__device__ __forceinline__ void st_any(float* p, long long i, float v) { p[i] = v; }
+__device__ __forceinline__ void st_any(unsigned short* p, long long i, float v) {
+  unsigned u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  p[i] = (unsigned short)(u >> 16);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_trilinear_fwd(const T* __restrict__ value, const float* __restrict__ grid, int B, int N,
+                                                       int D, int H, int W, int C, T* __restrict__ out) {
+  int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (q >= B * N) return;
+  int b = q / N;
+  TriCorner tc;
+  tri_setup(grid + (long long)q * 3, b, D, H, W, tc);
+  for (int ch = lane; ch < C; ch += 64) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (tc.row[c] >= 0) acc += tc.w[c] * ld_any(value, tc.row[c] * C + ch);
+    st_any(out, (long long)q * C + ch, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_trilinear_bwd(const T* __restrict__ value, const float* __restrict__ grid,
+                                                       const T* __restrict__ dout, int B, int N, int D, int H, int W, int C,
+                                                       float* __restrict__ dvalue, float* __restrict__ dgrid) {
+  int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (q >= B * N) return;
+  int b = q / N;
+  TriCorner tc;
+  tri_setup(grid + (long long)q * 3, b, D, H, W, tc);
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  for (int ch = lane; ch < C; ch += 64) {
+    float go = ld_any(dout, (long long)q * C + ch);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (tc.row[c] >= 0) {
+        if (dvalue) atomicAdd(&dvalue[tc.row[c] * C + ch], tc.w[c] * go);
+        float v = ld_any(value, tc.row[c] * C + ch) * go;
+        gx += tc.dwx[c] * v; gy += tc.dwy[c] * v; gz += tc.dwz[c] * v;
+      }
+  }
+  if (dgrid) {
+    gx = u3d_wave_sum(gx); gy = u3d_wave_sum(gy); gz = u3d_wave_sum(gz);
+    if (lane == 0) {
+      dgrid[(long long)q * 3 + 0] = gx * W * 0.5f;
+      dgrid[(long long)q * 3 + 1] = gy * H * 0.5f;
+      dgrid[(long long)q * 3 + 2] = gz * D * 0.5f;
+    }
+  }
+}
+
+extern "C" int32_t u3d_trilinear_fwd(const void* value, const float* grid, int32_t batch, int32_t nq, int32_t dz, int32_t dy,
+                                     int32_t dx, int32_t c, void* out, int32_t dtype, u3d_stream s) {
+  U3D_REQUIRE(value && grid && out && batch > 0 && nq > 0 && c > 0, U3D_ERR_ARG);
+  dim3 g(u3d_cdiv((long long)batch * nq, 4));
+  if (dtype == U3D_F32) hipLaunchKernelGGL(k_trilinear_fwd<float>, g, dim3(256), 0, s, (const float*)value, grid, batch, nq, dz, dy, dx, c, (float*)out);
+  else if (dtype == U3D_BF16) hipLaunchKernelGGL(k_trilinear_fwd<unsigned short>, g, dim3(256), 0, s, (const unsigned short*)value, grid, batch, nq, dz, dy, dx, c, (unsigned short*)out);
+  else return U3D_ERR_UNSUPPORTED;
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+extern "C" int32_t u3d_trilinear_bwd(const void* value, const float* grid, const void* dout, int32_t batch, int32_t nq,
+                                     int32_t dz, int32_t dy, int32_t dx, int32_t c, float* dvalue, float* dgrid, int32_t dtype,
+                                     u3d_stream s) {
+  U3D_REQUIRE(value && grid && dout && batch > 0 && nq > 0 && c > 0 && (dvalue || dgrid), U3D_ERR_ARG);
+  dim3 g(u3d_cdiv((long long)batch * nq, 4));
+  if (dtype == U3D_F32) hipLaunchKernelGGL(k_trilinear_bwd<float>, g, dim3(256), 0, s, (const float*)value, grid, (const float*)dout, batch, nq, dz, dy, dx, c, dvalue, dgrid);
+  else if (dtype == U3D_BF16) hipLaunchKernelGGL(k_trilinear_bwd<unsigned short>, g, dim3(256), 0, s, (const unsigned short*)value, grid, (const unsigned short*)dout, batch, nq, dz, dy, dx, c, dvalue, dgrid);
+  else return U3D_ERR_UNSUPPORTED;
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}

@@ -15,21 +15,109 @@ __device__ __forceinline__ void st_elem(u16* p, long long i, float v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// column statistics: each workgroup (256 threads) reduces a slab of rows for all C columns.
-// thread t owns column (t % CW) of row-lane (t / CW), CW = min(C, 256) ; partial sums in f64.
-// stage 1 -> partial[blocks][2][C] (f64), stage 2 -> sums[2][C] in block order (deterministic).
-// MODE 0: (x, x^2).  MODE 1: g = dy*(relu? y>0), (g, g*xhat).
+// column statistics, HBM-streaming: every thread loads 16-byte vectors (4 f32 / 8 bf16 columns of one row); a
+// workgroup (256 threads) owns ST_ROWS rows; per-thread f32 partials over <= ST_ROWS/row_lanes rows, then f64 across
+// row lanes (LDS) -> partial[block][2][C] (f64); stage 2 sums the blocks in order (deterministic).
+// MODE 0: (x, x^2).  MODE 1: g = dy*(relu? y>0), (g, g*xhat).   Requires C % VEC == 0 (else the scalar kernel).
 // ---------------------------------------------------------------------------------------------
 #define ST_ROWS_PER_BLOCK 512
 
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { static constexpr int N = 4; };
+template <> struct VecOf<u16> { static constexpr int N = 8; };
+
+template <typename T>
+__device__ __forceinline__ void load_vec(const T* p, float* out);
+template <>
+__device__ __forceinline__ void load_vec<float>(const float* p, float* out) {
+  float4 v = *(const float4*)p;
+  out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void load_vec<u16>(const u16* p, float* out) {
+  uint4 v = *(const uint4*)p;
+  unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { out[2 * i] = __uint_as_float(w[i] << 16); out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_col_stats_vec(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                       const int* __restrict__ n_dev, int n_cap, int c, double* __restrict__ partial) {
+  constexpr int V = VecOf<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* red = (double*)smem_raw;                 // [2][rl][cw*V] laid out as [which][rowlane][col]
+  const int n = min(*n_dev, n_cap);
+  const int cv = c / V;                            // vectors per row
+  const int cw = cv < 256 ? cv : 256;              // vector-columns handled concurrently
+  const int rl = 256 / cw;                         // row lanes
+  const int tcol = threadIdx.x % cw, trow = threadIdx.x / cw;
+  const int r0 = blockIdx.x * ST_ROWS_PER_BLOCK;
+  const int r1 = min(n, r0 + ST_ROWS_PER_BLOCK);
+  for (int cb = 0; cb < cv; cb += cw) {
+    const int vc = cb + tcol;
+    float s0[V], s1[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+    const bool active = vc < cv && trow < rl;
+    if (active) {
+      float mu[V], is[V];
+      if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { mu[e] = mean[vc * V + e]; is[e] = invstd[vc * V + e]; }
+      }
+      for (int r = r0 + trow; r < r1; r += rl) {
+        const long long o = (long long)r * c + (long long)vc * V;
+        float xv[V];
+        load_vec<T>(x + o, xv);
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) { s0[e] += xv[e]; s1[e] += xv[e] * xv[e]; }
+        } else {
+          float gv[V], yv[V];
+          load_vec<T>(dy + o, gv);
+          if (relu) load_vec<T>(y + o, yv);
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            float g = gv[e];
+            if (relu && !(yv[e] > 0.f)) g = 0.f;
+            s0[e] += g;
+            s1[e] += g * ((xv[e] - mu[e]) * is[e]);
+          }
+        }
+      }
+    }
+    const int ncol = cw * V;
+    if (trow < rl) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        red[(0 * rl + trow) * ncol + tcol * V + e] = (double)s0[e];
+        red[(1 * rl + trow) * ncol + tcol * V + e] = (double)s1[e];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * ncol; i += 256) {
+      int which = i / ncol, col = i % ncol;
+      if (cb * V + col < c) {
+        double a = 0.0;
+        for (int j = 0; j < rl; ++j) a += red[(which * rl + j) * ncol + col];
+        partial[((long long)blockIdx.x * 2 + which) * c + cb * V + col] = a;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// scalar fallback for channel counts that are not a multiple of the vector width
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void k_col_stats(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
                                                    const int* __restrict__ n_dev, int n_cap, int c, double* __restrict__ partial) {
   __shared__ double red[2][256];
   const int n = min(*n_dev, n_cap);
-  const int cw = c < 256 ? c : 256;          // columns handled concurrently
-  const int rl = 256 / cw;                   // row lanes
+  const int cw = c < 256 ? c : 256;
+  const int rl = 256 / cw;
   const int tcol = threadIdx.x % cw, trow = threadIdx.x / cw;
   const int r0 = blockIdx.x * ST_ROWS_PER_BLOCK;
   const int r1 = min(n, r0 + ST_ROWS_PER_BLOCK);
@@ -67,17 +155,20 @@ __global__ __launch_bounds__(256) void k_col_stats(const T* __restrict__ x, cons
   }
 }
 
-__global__ void k_col_stats_final(const double* __restrict__ partial, int nblocks, const int* __restrict__ n_dev, int n_cap,
-                                  int c, double* __restrict__ sums) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// stage 2: 64 threads per output column-value cooperate over the blocks (fixed tree order -> deterministic)
+__global__ __launch_bounds__(256) void k_col_stats_final(const double* __restrict__ partial, int nblocks, const int* __restrict__ n_dev,
+                                                         int n_cap, int c, double* __restrict__ sums) {
+  int i = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per output value
+  int lane = threadIdx.x & 63;
   if (i >= 2 * c) return;
   int n = min(*n_dev, n_cap);
   int used = (n + ST_ROWS_PER_BLOCK - 1) / ST_ROWS_PER_BLOCK;
   if (used > nblocks) used = nblocks;
   int which = i / c, col = i % c;
   double s = 0.0;
-  for (int b = 0; b < used; ++b) s += partial[((long long)b * 2 + which) * c + col];
-  sums[i] = s;
+  for (int b = lane; b < used; b += 64) s += partial[((long long)b * 2 + which) * c + col];
+  s = u3d_wave_sum_d(s);
+  if (lane == 0) sums[i] = s;
 }
 
 extern "C" int64_t u3d_bn_stats_workspace(int32_t n_cap, int32_t c) {
@@ -91,12 +182,24 @@ static int run_stats(const void* x, const void* dy, const void* y, const float* 
   if (n_cap <= 0) { hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, s); return U3D_OK; }
   U3D_REQUIRE(ws_bytes >= u3d_bn_stats_workspace(n_cap, c), U3D_ERR_WORKSPACE);
   int nb = u3d_cdiv(n_cap, ST_ROWS_PER_BLOCK);
-  if (dtype == U3D_F32)
-    hipLaunchKernelGGL((k_col_stats<float, MODE>), dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, relu, n_dev, n_cap, c, (double*)ws);
-  else if (dtype == U3D_BF16)
-    hipLaunchKernelGGL((k_col_stats<u16, MODE>), dim3(nb), dim3(256), 0, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, relu, n_dev, n_cap, c, (double*)ws);
-  else return U3D_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_col_stats_final, dim3(u3d_cdiv(2 * c, 256)), dim3(256), 0, s, (const double*)ws, nb, n_dev, n_cap, c, sums);
+  if (dtype == U3D_F32) {
+    if (c % 4 == 0) {
+      int cw = (c / 4) < 256 ? (c / 4) : 256; int rl = 256 / cw;
+      size_t lds = (size_t)2 * rl * cw * 4 * sizeof(double);
+      hipLaunchKernelGGL((k_col_stats_vec<float, MODE>), dim3(nb), dim3(256), lds, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, relu, n_dev, n_cap, c, (double*)ws);
+    } else {
+      hipLaunchKernelGGL((k_col_stats<float, MODE>), dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, relu, n_dev, n_cap, c, (double*)ws);
+    }
+  } else if (dtype == U3D_BF16) {
+    if (c % 8 == 0) {
+      int cw = (c / 8) < 256 ? (c / 8) : 256; int rl = 256 / cw;
+      size_t lds = (size_t)2 * rl * cw * 8 * sizeof(double);
+      hipLaunchKernelGGL((k_col_stats_vec<u16, MODE>), dim3(nb), dim3(256), lds, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, relu, n_dev, n_cap, c, (double*)ws);
+    } else {
+      hipLaunchKernelGGL((k_col_stats<u16, MODE>), dim3(nb), dim3(256), 0, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, relu, n_dev, n_cap, c, (double*)ws);
+    }
+  } else return U3D_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_col_stats_final, dim3(u3d_cdiv(2 * c, 4)), dim3(256), 0, s, (const double*)ws, nb, n_dev, n_cap, c, sums);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

@@ -60,6 +60,8 @@ _SIGS = {
     "u3d_fps": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _L, _P]),
     "u3d_match_cost": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "u3d_lsa": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "u3d_trilinear_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "u3d_trilinear_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "u3d_iou3d_rotated_aligned": (_I, [_P, _P, _I, _P, _P]),
     "u3d_gather_rows": (_I, [_P, _P, _I, _I, _P, _P]),
     "u3d_scatter_rows": (_I, [_P, _P, _I, _I, _P, _P]),
@@ -374,3 +376,21 @@ def iou3d_rotated_aligned(a, b):
     out = torch.empty((n,), dtype=torch.float32, device=a.device)
     _check(lib().u3d_iou3d_rotated_aligned(_ptr(a), _ptr(b), n, _ptr(out), _stream()), "iou3d_rotated_aligned")
     return out
+
+
+def trilinear_fwd(value_rows, grid, batch, dims):
+    """value_rows [B*D*H*W, C] contiguous; grid f32 [B,N,3] -> [B,N,C]."""
+    nq, c = grid.shape[1], value_rows.shape[1]
+    out = torch.empty((batch, nq, c), dtype=value_rows.dtype, device=value_rows.device)
+    _check(lib().u3d_trilinear_fwd(_ptr(value_rows), _ptr(grid), batch, nq, dims[0], dims[1], dims[2], c, _ptr(out),
+                                   dtype_code(value_rows), _stream()), "trilinear_fwd")
+    return out
+
+
+def trilinear_bwd(value_rows, grid, dout, batch, dims, want_dvalue=True, want_dgrid=True):
+    nq, c = grid.shape[1], value_rows.shape[1]
+    dvalue = torch.zeros(value_rows.shape, dtype=torch.float32, device=value_rows.device) if want_dvalue else None
+    dgrid = torch.empty((batch, nq, 3), dtype=torch.float32, device=value_rows.device) if want_dgrid else None
+    _check(lib().u3d_trilinear_bwd(_ptr(value_rows), _ptr(grid), _ptr(dout), batch, nq, dims[0], dims[1], dims[2], c, _ptr(dvalue),
+                                   _ptr(dgrid), dtype_code(value_rows), _stream()), "trilinear_bwd")
+    return dvalue, dgrid

@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import native as nv
 from ..registry import ATTENTION, FEEDFORWARD_NETWORK, TRANSFORMER, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE
 
 
@@ -110,6 +111,29 @@ class FFN(nn.Module):
         return (x if identity is None else identity) + out
 
 
+class _TrilinearSample(torch.autograd.Function):
+    """F.grid_sample(value [B,C,D,H,W], grid [B,1,1,N,3]) -> [B,N,C] on the HIP sampler (channels-last rows)."""
+
+    @staticmethod
+    def forward(ctx, value, grid):
+        B, C, D, H, W = value.shape
+        rows = value.permute(0, 2, 3, 4, 1).reshape(-1, C)      # no copy for channels_last_3d volumes
+        rows = rows if rows.is_contiguous() else rows.contiguous()
+        g = grid.float().contiguous()
+        ctx.save_for_backward(rows, g)
+        ctx.shape = (B, C, D, H, W)
+        return nv.trilinear_fwd(rows, g, B, (D, H, W))
+
+    @staticmethod
+    def backward(ctx, dout):
+        rows, g = ctx.saved_tensors
+        B, C, D, H, W = ctx.shape
+        dv, dg = nv.trilinear_bwd(rows, g, dout.contiguous().to(rows.dtype), B, (D, H, W), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        if dv is not None:
+            dv = dv.to(rows.dtype).view(B, D, H, W, C).permute(0, 4, 1, 2, 3)
+        return dv, dg
+
+
 @ATTENTION.register_module()
 class UniCrossAtten(nn.Module):
     """One trilinear sample of the voxel volume per query, gated by sigmoid(Linear(query+pos)), projected, plus the
@@ -142,11 +166,9 @@ class UniCrossAtten(nn.Module):
         w = self.attention_weights(query + query_pos).sigmoid()                       # [B,N,P]
         g = (ref_logits.sigmoid() - 0.5) * 2
         B, N, _ = g.shape
-        if value.dim() == 4:
-            samp = F.grid_sample(value, g[..., :2].reshape(B, 1, N, 2).to(value.dtype), align_corners=False)
-        else:
-            samp = F.grid_sample(value, g.reshape(B, 1, 1, N, 3).to(value.dtype), align_corners=False)
-        samp = samp.reshape(B, value.shape[1], N).transpose(1, 2)                     # [B,N,C]
+        if value.dim() != 5:
+            raise NotImplementedError("height-less (BEV) value maps are not used by any shipped Uni3DETR config")
+        samp = _TrilinearSample.apply(value, g)                                       # [B,N,C]
         out = self.output_proj(samp.to(query.dtype) * w.sum(-1, keepdim=True))
         pos_feat = self.position_encoder(ref_logits.to(query.dtype))
         return self.dropout(out) + query + pos_feat
