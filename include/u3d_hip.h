@@ -122,6 +122,17 @@ int32_t u3d_spconv_fwd(const void* in, const void* w, const int32_t* nbr, int32_
                        const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
                        int32_t transpose_w, int32_t dtype, u3d_stream s);
 
+/* Second-generation bf16 kernels (256-row tiles, double-buffered LDS, LDS transpose reads): same contract as
+ * u3d_spconv_fwd / u3d_spconv_wgrad with dtype U3D_BF16; return U3D_ERR_UNSUPPORTED for shapes (cin % 64, cout % 64)
+ * that the first-generation kernels serve. */
+int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,
+                           const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
+                           int32_t transpose_w, u3d_stream s);
+int64_t u3d_igemm_wgrad_bf16_workspace(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol);
+int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const int32_t* nbr, int32_t ld, float* dw,
+                             const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
+                             void* workspace, int64_t workspace_bytes, u3d_stream s);
+
 /* dW[kappa] = sum_m in[nbr[kappa][m],:]^T @ dout[m,:]   (f32 accumulate, dW f32 [K,Cin,Cout], overwritten).
  * workspace: u3d_spconv_wgrad_workspace() bytes. */
 int64_t u3d_spconv_wgrad_workspace(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol);

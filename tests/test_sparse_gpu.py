@@ -251,3 +251,88 @@ def test_dense_roundtrip(cuda):
     assert vol.shape == ref.shape and torch.equal(vol.cpu(), ref)
     back = nv.from_dense(vol.permute(0, 2, 3, 4, 1).contiguous(), torch.from_numpy(co).to(cuda), nd, 3000)
     assert torch.equal(back.cpu(), f)
+
+
+BF16_CASES = [(8, 16, 27), (16, 32, 27), (32, 64, 27), (64, 64, 27), (64, 128, 27), (128, 128, 27), (128, 256, 1), (256, 256, 27),
+              (256, 128, 27), (512, 512, 1), (128, 64, 27)]
+
+
+@pytest.mark.parametrize("v2", [True, False])
+@pytest.mark.parametrize("cin,cout,kvol", BF16_CASES)
+def test_spconv_fwd_bwd_bf16(cuda, cin, cout, kvol, v2):
+    """bf16 operands / f32 accumulation, both kernel generations, against the f32 oracle on bf16-rounded inputs."""
+    torch.manual_seed(cin * 1000 + cout + 7)
+    rc = _level0(cuda, 2, 2500)
+    dims = (128, 320, 320)
+    k3, s1, p1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    coors = torch.from_numpy(rc).to(cuda)
+    g0 = nv.BitGrid(2, dims, cuda)
+    g0.mark(coors); g0.scan()
+    n = rc.shape[0]
+    c0 = g0.coords(n)
+    nd = g0.count_dev
+    if kvol == 27:
+        nbr = g0.nbr_table(c0, nd, k3, s1, p1, 0)
+        nbr_t = g0.nbr_table(c0, nd, k3, s1, p1, 1)
+        ref_nbr = nbr.cpu().numpy()[:, :n].astype(np.int64)
+    else:
+        nbr = nbr_t = None
+        ref_nbr = np.arange(n, dtype=np.int64)[None]
+    x = torch.randn(n, cin).bfloat16().float()
+    w = (torch.randn(kvol, cin, cout) * (1.0 / np.sqrt(cin * min(kvol, 9)))).bfloat16().float()
+    gy = torch.randn(n, cout).bfloat16().float()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = og.sparse_conv(xr, wr, ref_nbr)
+    yr.backward(gy)
+    old = nv.USE_IGEMM_V2
+    nv.USE_IGEMM_V2 = v2
+    try:
+        xd, wd, gyd = x.to(cuda).bfloat16(), w.to(cuda).bfloat16(), gy.to(cuda).bfloat16()
+        y = nv.spconv_fwd(xd, wd, nbr, nd, n, cout)
+        dx = nv.spconv_fwd(gyd, wd, nbr_t, nd, n, cin, transpose_w=True)
+        dw = nv.spconv_wgrad(xd, gyd, nbr, nd, kvol)
+    finally:
+        nv.USE_IGEMM_V2 = old
+    assert (y.float().cpu() - yr.detach()).abs().max().item() <= 1e-2 * yr.abs().max().item()          # bf16 output rounding
+    assert (dx.float().cpu() - xr.grad).abs().max().item() <= 1e-2 * xr.grad.abs().max().item()
+    assert (dw.cpu() - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item()                 # f32 accumulate, f32 output
+
+
+def test_dense_lattice_conv_matches_conv3d(cuda):
+    """A dense volume is the all-active special case: conv on the lattice table == F.conv3d (zero padding), incl. strides."""
+    import torch.nn.functional as F
+    from uni3detr_amd.plugin import dense as dn
+    from uni3detr_amd import sparse as sp
+    torch.manual_seed(3)
+    B, C, D, H, W = 2, 64, 5, 12, 10
+    x = torch.randn(B, C, D, H, W)
+    for (k, s, p, co) in [((1, 3, 3), (1, 1, 1), (0, 1, 1), 64), ((1, 3, 3), (1, 2, 2), (0, 1, 1), 128), ((3, 3, 3), (1, 1, 1), (1, 1, 1), 64),
+                          ((1, 1, 1), (1, 1, 1), (0, 0, 0), 128)]:
+        w = torch.randn(co, C, *k) * 0.05
+        gy = None
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        ref = F.conv3d(xr, wr, None, s, p)
+        gy = torch.randn_like(ref)
+        ref.backward(gy)
+        rows = x.permute(0, 2, 3, 4, 1).reshape(-1, C).contiguous().to(cuda).requires_grad_(True)
+        wd = w.to(cuda).requires_grad_(True)
+        geom, dims_out = dn.Lattice.conv(cuda, B, (D, H, W), k, s, p)
+        y = sp.sparse_conv(rows, wd.permute(2, 3, 4, 1, 0), geom)
+        assert dims_out == tuple(ref.shape[2:])
+        yv = y.view(B, *dims_out, co).permute(0, 4, 1, 2, 3)
+        assert (yv.detach().cpu() - ref.detach()).abs().max().item() <= 1e-4 * ref.abs().max().item()
+        y.backward(gy.permute(0, 2, 3, 4, 1).reshape(-1, co).contiguous().to(cuda))
+        gx = rows.grad.view(B, D, H, W, C).permute(0, 4, 1, 2, 3).cpu()
+        assert (gx - xr.grad).abs().max().item() <= 1e-4 * xr.grad.abs().max().item()
+        assert (wd.grad.cpu() - wr.grad).abs().max().item() <= 1e-4 * wr.grad.abs().max().item()
+    # (1,s,s) transposed conv == ConvTranspose3d
+    for s in (2, 4):
+        dec = torch.nn.ConvTranspose3d(C, 32, (1, s, s), stride=(1, s, s), bias=False)
+        bn = torch.nn.BatchNorm3d(32, eps=1e-3, momentum=0.01)
+        ref = F.relu(bn(dec(x)))
+        dec_d, bn_d = torch.nn.ConvTranspose3d(C, 32, (1, s, s), stride=(1, s, s), bias=False).to(cuda), torch.nn.BatchNorm3d(32, eps=1e-3, momentum=0.01).to(cuda)
+        dec_d.load_state_dict(dec.state_dict())
+        rows = x.permute(0, 2, 3, 4, 1).reshape(-1, C).contiguous().to(cuda)
+        y, dims_out = dn.deconv_bn_relu(rows, B, (D, H, W), dec_d, bn_d)
+        yv = y.view(B, *dims_out, 32).permute(0, 4, 1, 2, 3)
+        assert (yv.detach().cpu() - ref.detach()).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())

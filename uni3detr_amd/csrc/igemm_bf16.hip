@@ -1,0 +1,377 @@
+// bf16 implicit-GEMM convolution kernels, second generation (large tiles, double-buffered LDS, register-staged
+// prefetch, LDS transpose reads).  They serve BOTH the sparse levels and the dense SECOND3D/FPN lattice: the only
+// difference is where the neighbour table comes from.
+//
+//   forward / dgrad :  out[m, n] = sum_kappa sum_k  in[nbr[kappa][m], k] * W[kappa](k, n)
+//   weight gradient :  dW[kappa](ci, co) = sum_m in[nbr[kappa][m], ci] * dout[m, co]
+//
+// MFMA: v_mfma_f32_16x16x32_bf16, f32 accumulation.  Tiles up to 256x256 per workgroup (8 waves) so that the
+// L2->CU traffic per MFMA cycle stays below ~36 B/clk (a 128x128 tile would need ~64 B/clk: DESIGN.md §kernels).
+// Operands whose reduction index is the LDS row (W[k][n] in forward, both operands in wgrad) are fetched with
+// ds_read_b64_tr_b16; rows are padded by 16 elements so that those reads are bank-conflict free.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+#define LDS_PTR(p) ((s16x4 __attribute__((address_space(3)))*)(p))
+
+__device__ __forceinline__ u16 f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+
+// 8 reduction-index values for one MFMA operand, reduction index = LDS row.  tile: row-major, `stride` elements per
+// row; returns values (rows k0 + r(g,e), column c0 + (lane&15)), r(g,e) = e<4 ? 4g+e : 16+4g+(e-4), g = lane>>4.
+__device__ __forceinline__ bf16x8 tr_frag(const u16* tile, int stride, int k0, int c0, int lane) {
+  const int g = lane >> 4, L = lane & 15, j = L >> 2, q = L & 3;
+  const u16* p0 = tile + (k0 + 4 * g + j) * stride + c0 + 4 * q;
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(p0));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(p0 + 16 * stride));
+  s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// 8 reduction-index values, reduction index contiguous in the LDS row: row r0 + (lane&15), elements k0 + kmap(g,e) with the
+// SAME r(g,e) permutation as tr_frag (so a tr operand and a direct operand can be paired in one MFMA).
+__device__ __forceinline__ bf16x8 direct_frag(const u16* tile, int stride, int r0, int k0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const u16* p = tile + (r0 + i) * stride + k0 + 4 * g;
+  s16x4 a = *(const s16x4*)p;
+  s16x4 b = *(const s16x4*)(p + 16);
+  s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// =============================================================================================
+// forward / dgrad
+//   tile BM x BN, BM = WAVES_M*WM*16, BN = WAVES_N*WN*16, BK = 64 reduction elements per stage.
+//   W_KMAJOR = true : global W[kappa][k][n]  (forward; staged row-major [k][n], fetched with transpose reads)
+//   W_KMAJOR = false: global W[kappa][n][k]  (dgrad: the forward weight read transposed; staged [n][k], direct reads)
+// =============================================================================================
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool W_KMAJOR>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* __restrict__ in, const u16* __restrict__ w,
+                                                                      const int* __restrict__ nbr, int ld, u16* __restrict__ out,
+                                                                      const int* __restrict__ n_out_dev, int n_out_cap, int cin,
+                                                                      int cout, int kvol) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, BK = 64;
+  constexpr int LDA = BK + 8;                           // A tile [BM][BK] (k contiguous): 36-dword stride -> conflict-free b64 reads
+  constexpr int LDW = W_KMAJOR ? BN + 16 : BK + 8;      // W tile [BK][BN] (transpose reads: +16) or [BN][BK] (direct: +8)
+  constexpr int A_ELEMS = BM * LDA;
+  constexpr int W_ELEMS = W_KMAJOR ? BK * LDW : BN * LDW;
+  constexpr int A_SEGS = BM * (BK / 8) / NT;            // 16-byte segments per thread per stage
+  constexpr int W_SEGS = BK * BN / 8 / NT;
+  static_assert(BM * (BK / 8) % NT == 0 && BK * BN / 8 % NT == 0, "tile/thread mismatch");
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  constexpr int STAGE_ELEMS = A_ELEMS + W_ELEMS;        // buffer b: A at smem + b*STAGE_ELEMS, W right behind it
+
+  const int n_out = min(*n_out_dev, n_out_cap);
+  const int m0 = blockIdx.x * BM;
+  if (m0 >= n_out) return;
+  const int col0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+  const int kchunks = cin / BK;                         // cin % 64 == 0 (dispatch guarantees)
+  const int nstage = kvol * kchunks;
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-thread segment coordinates (fixed)
+  int a_row[A_SEGS], a_part[A_SEGS];
+#pragma unroll
+  for (int u = 0; u < A_SEGS; ++u) { int sgi = tid + u * NT; a_row[u] = sgi / (BK / 8); a_part[u] = sgi % (BK / 8); }
+
+  uint4 ra[A_SEGS], rw[W_SEGS];
+  int idx_cur[A_SEGS];
+
+  auto load_idx = [&](int kap) {
+#pragma unroll
+    for (int u = 0; u < A_SEGS; ++u) {
+      int m = m0 + a_row[u];
+      idx_cur[u] = (m < n_out) ? (nbr ? nbr[(long long)kap * ld + m] : m) : -1;
+    }
+  };
+  auto issue_loads = [&](int st) {
+    const int kap = st / kchunks, c0 = (st % kchunks) * BK;
+#pragma unroll
+    for (int u = 0; u < A_SEGS; ++u) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (idx_cur[u] >= 0) v = *(const uint4*)(in + (long long)idx_cur[u] * cin + c0 + a_part[u] * 8);
+      ra[u] = v;
+    }
+    const u16* wk = w + (long long)kap * cin * cout;
+#pragma unroll
+    for (int u = 0; u < W_SEGS; ++u) {
+      int sgi = tid + u * NT;
+      if (W_KMAJOR) {
+        int k = sgi / (BN / 8), part = sgi % (BN / 8);
+        int n = col0 + part * 8;
+        rw[u] = (n < cout) ? *(const uint4*)(wk + (long long)(c0 + k) * cout + n) : make_uint4(0, 0, 0, 0);
+      } else {
+        int n = sgi / (BK / 8), part = sgi % (BK / 8);
+        rw[u] = (col0 + n < cout) ? *(const uint4*)(wk + (long long)(col0 + n) * cin + c0 + part * 8) : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto store_lds = [&](int buf) {
+    u16* Ab = smem + buf * STAGE_ELEMS;
+    u16* Wb = Ab + A_ELEMS;
+#pragma unroll
+    for (int u = 0; u < A_SEGS; ++u) *(uint4*)(Ab + a_row[u] * LDA + a_part[u] * 8) = ra[u];
+#pragma unroll
+    for (int u = 0; u < W_SEGS; ++u) {
+      int sgi = tid + u * NT;
+      if (W_KMAJOR) { int k = sgi / (BN / 8), part = sgi % (BN / 8); *(uint4*)(Wb + k * LDW + part * 8) = rw[u]; }
+      else { int n = sgi / (BK / 8), part = sgi % (BK / 8); *(uint4*)(Wb + n * LDW + part * 8) = rw[u]; }
+    }
+  };
+
+  load_idx(0);
+  issue_loads(0);
+  store_lds(0);
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nstage) {
+      if ((st + 1) % kchunks == 0) load_idx((st + 1) / kchunks);
+      issue_loads(st + 1);                              // global loads in flight while this stage computes
+    }
+    const u16* A = smem + buf * STAGE_ELEMS;
+    const u16* W = A + A_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 af[WM];
+#pragma unroll
+      for (int a = 0; a < WM; ++a) af[a] = direct_frag(A, LDA, (wm * WM + a) * 16, ks * 32, lane);
+#pragma unroll
+      for (int b = 0; b < WN; ++b) {
+        bf16x8 bfr = W_KMAJOR ? tr_frag(W, LDW, ks * 32, (wn * WN + b) * 16, lane)
+                              : direct_frag(W, LDW, (wn * WN + b) * 16, ks * 32, lane);
+#pragma unroll
+        for (int a = 0; a < WM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr, acc[a][b], 0, 0, 0);
+      }
+    }
+    if (st + 1 < nstage) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+  // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + r
+  const int li = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int m = m0 + (wm * WM + a) * 16 + g * 4 + r;
+      if (m >= n_out) continue;
+#pragma unroll
+      for (int b = 0; b < WN; ++b) {
+        int col = col0 + (wn * WN + b) * 16 + li;
+        if (col < cout) out[(long long)m * cout + col] = f2bf(acc[a][b][r]);
+      }
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool WK>
+static int launch_igemm_fwd(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev,
+                            int n_out_cap, int cin, int cout, int kvol, hipStream_t s) {
+  constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, BK = 64;
+  constexpr int LDA = BK + 8, LDW = WK ? BN + 16 : BK + 8;
+  constexpr size_t lds = 2 * (size_t)(BM * LDA + (WK ? BK * LDW : BN * LDW)) * 2;
+  auto kern = k_igemm_fwd<WAVES_M, WAVES_N, WM, WN, WK>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev,
+                     n_out_cap, cin, cout, kvol);
+  return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
+}
+
+// returns U3D_ERR_UNSUPPORTED when the shape is better served by the first-generation kernel
+extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,
+                                      const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
+                                      int32_t transpose_w, u3d_stream s) {
+  U3D_REQUIRE(in && w && out && n_out_dev && (nbr || kvol == 1), U3D_ERR_ARG);
+  if (cin % 64 != 0 || cout % 8 != 0 || cout < 64) return U3D_ERR_UNSUPPORTED;
+  if (n_out_cap <= 0) return U3D_OK;
+#define IG_CASE(A, B, C, D)                                                                                                  \
+  return transpose_w ? launch_igemm_fwd<A, B, C, D, false>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s)   \
+                     : launch_igemm_fwd<A, B, C, D, true>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
+  if (cout >= 256 && cout % 256 == 0) { IG_CASE(2, 4, 8, 4) }       // 256 x 256
+  if (cout >= 128 && cout % 128 == 0) { IG_CASE(4, 2, 4, 4) }       // 256 x 128
+  if (cout % 64 == 0) { IG_CASE(4, 1, 4, 4) }                        // 256 x 64
+#undef IG_CASE
+  return U3D_ERR_UNSUPPORTED;
+}
+
+// =============================================================================================
+// weight gradient: workgroup (split, kappa, block) accumulates dW[kappa][ci0:+TM][co0:+TN] over its slice of output rows.
+// stage = 64 output rows: A tile [64][TM] (gathered input rows), D tile [64][TN] (dout rows), both row-major with the
+// reduction index as the LDS row -> both MFMA operands come from transpose reads.
+// =============================================================================================
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_wgrad(const u16* __restrict__ in, const u16* __restrict__ dout,
+                                                                        const int* __restrict__ nbr, int ld, float* __restrict__ partial,
+                                                                        const int* __restrict__ n_out_dev, int n_out_cap, int cin,
+                                                                        int cout, int kvol, int co_blocks) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int TM = WAVES_M * WM * 16, TN = WAVES_N * WN * 16, RK = 64;
+  constexpr int LDA = TM + 16, LDD = TN + 16;
+  constexpr int A_ELEMS = RK * LDA, D_ELEMS = RK * LDD;
+  constexpr int A_SEGS = RK * TM / 8 / NT, D_SEGS = RK * TN / 8 / NT;
+  static_assert(RK * TM / 8 % NT == 0 && RK * TN / 8 % NT == 0, "tile/thread mismatch");
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  constexpr int STAGE_ELEMS = A_ELEMS + D_ELEMS;
+
+  const int n_out = min(*n_out_dev, n_out_cap);
+  const int nsplit = gridDim.x, split = blockIdx.x, kap = blockIdx.y;
+  const int ci0 = (blockIdx.z / co_blocks) * TM, co0 = (blockIdx.z % co_blocks) * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = (n_out + RK - 1) / RK;
+  const int per = (ntiles + nsplit - 1) / nsplit;
+  const int t_begin = split * per, t_end = min(ntiles, t_begin + per);
+
+  uint4 ra[A_SEGS], rd[D_SEGS];
+  auto issue_loads = [&](int t) {
+    const int r0 = t * RK;
+#pragma unroll
+    for (int u = 0; u < A_SEGS; ++u) {
+      int sgi = tid + u * NT;
+      int row = sgi / (TM / 8), part = sgi % (TM / 8);
+      int m = r0 + row;
+      int src = (m < n_out) ? (nbr ? nbr[(long long)kap * ld + m] : m) : -1;
+      int c = ci0 + part * 8;
+      ra[u] = (src >= 0 && c < cin) ? *(const uint4*)(in + (long long)src * cin + c) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < D_SEGS; ++u) {
+      int sgi = tid + u * NT;
+      int row = sgi / (TN / 8), part = sgi % (TN / 8);
+      int m = r0 + row;
+      int c = co0 + part * 8;
+      rd[u] = (m < n_out && c < cout) ? *(const uint4*)(dout + (long long)m * cout + c) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < A_SEGS; ++u) { int sgi = tid + u * NT; *(uint4*)(smem + buf * STAGE_ELEMS + (sgi / (TM / 8)) * LDA + (sgi % (TM / 8)) * 8) = ra[u]; }
+#pragma unroll
+    for (int u = 0; u < D_SEGS; ++u) { int sgi = tid + u * NT; *(uint4*)(smem + buf * STAGE_ELEMS + A_ELEMS + (sgi / (TN / 8)) * LDD + (sgi % (TN / 8)) * 8) = rd[u]; }
+  };
+
+  if (t_begin < t_end) {
+    issue_loads(t_begin);
+    store_lds(0);
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+      const int buf = (t - t_begin) & 1;
+      if (t + 1 < t_end) issue_loads(t + 1);
+      const u16* A = smem + buf * STAGE_ELEMS;
+      const u16* D = A + A_ELEMS;
+#pragma unroll
+      for (int ks = 0; ks < RK / 32; ++ks) {
+        bf16x8 bfr[WN];
+#pragma unroll
+        for (int b = 0; b < WN; ++b) bfr[b] = tr_frag(D, LDD, ks * 32, (wn * WN + b) * 16, lane);
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+          bf16x8 af = tr_frag(A, LDA, ks * 32, (wm * WM + a) * 16, lane);
+#pragma unroll
+          for (int b = 0; b < WN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[b], acc[a][b], 0, 0, 0);
+        }
+      }
+      if (t + 1 < t_end) store_lds(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  float* p = partial + ((long long)split * kvol + kap) * cin * cout;
+  const int li = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int ci = ci0 + (wm * WM + a) * 16 + g * 4 + r;
+        int co = co0 + (wn * WN + b) * 16 + li;
+        if (ci < cin && co < cout) p[(long long)ci * cout + co] = acc[a][b][r];
+      }
+}
+
+__global__ void k_igemm_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, long long n, int nsplit) {
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < nsplit; ++k) s += *(const f32x4*)(partial + (long long)k * n + i);
+  *(f32x4*)(dw + i) = s;
+}
+
+struct WgPlan { int tile; int ci_blocks, co_blocks, nsplit; };
+static WgPlan wgrad_plan(int n_out_cap, int cin, int cout, int kvol) {
+  WgPlan p;
+  int mn = cin < cout ? cin : cout;
+  p.tile = (mn >= 256 && cin % 256 == 0 && cout % 256 == 0) ? 256 : ((mn >= 128 && cin % 128 == 0 && cout % 128 == 0) ? 128 : 64);
+  p.ci_blocks = u3d_cdiv(cin, p.tile);
+  p.co_blocks = u3d_cdiv(cout, p.tile);
+  int ntiles = u3d_cdiv(n_out_cap > 0 ? n_out_cap : 1, 64);
+  int wgs_per_split = kvol * p.ci_blocks * p.co_blocks;
+  int target = (p.tile == 256 ? 256 : 512) / wgs_per_split;
+  if (target < 1) target = 1;
+  int ns = ntiles < target ? ntiles : target;
+  // keep at least 8 stages per split so the prologue is amortised
+  while (ns > 1 && ntiles / ns < 8) --ns;
+  p.nsplit = ns < 1 ? 1 : ns;
+  return p;
+}
+
+extern "C" int64_t u3d_igemm_wgrad_bf16_workspace(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol) {
+  WgPlan p = wgrad_plan(n_out_cap, cin, cout, kvol);
+  return (int64_t)p.nsplit * kvol * cin * cout * 4;
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+static int launch_igemm_wgrad(const void* in, const void* dout, const int32_t* nbr, int ld, float* partial, const int32_t* n_out_dev,
+                              int n_out_cap, int cin, int cout, int kvol, const WgPlan& p, hipStream_t s) {
+  constexpr int TM = WAVES_M * WM * 16, TN = WAVES_N * WN * 16, RK = 64;
+  constexpr size_t lds = 2 * (size_t)(RK * (TM + 16) + RK * (TN + 16)) * 2;
+  auto kern = k_igemm_wgrad<WAVES_M, WAVES_N, WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  dim3 grid(p.nsplit, kvol, p.ci_blocks * p.co_blocks);
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, (const u16*)in, (const u16*)dout, nbr, ld, partial, n_out_dev,
+                     n_out_cap, cin, cout, kvol, p.co_blocks);
+  return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
+}
+
+extern "C" int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const int32_t* nbr, int32_t ld, float* dw,
+                                        const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
+                                        void* workspace, int64_t workspace_bytes, u3d_stream s) {
+  U3D_REQUIRE(in && dout && dw && n_out_dev && workspace && (nbr || kvol == 1), U3D_ERR_ARG);
+  if (cin % 64 != 0 || cout % 64 != 0) return U3D_ERR_UNSUPPORTED;
+  WgPlan p = wgrad_plan(n_out_cap, cin, cout, kvol);
+  long long n = (long long)kvol * cin * cout;
+  U3D_REQUIRE(workspace_bytes >= (int64_t)p.nsplit * n * 4, U3D_ERR_WORKSPACE);
+  int rc;
+  if (p.tile == 256) rc = launch_igemm_wgrad<2, 4, 8, 4>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
+  else if (p.tile == 128) rc = launch_igemm_wgrad<2, 2, 4, 4>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
+  else rc = launch_igemm_wgrad<2, 2, 2, 2>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
+  if (rc != U3D_OK) return rc;
+  hipLaunchKernelGGL(k_igemm_wgrad_reduce, dim3(u3d_cdiv(n / 4, 256)), dim3(256), 0, s, (const float*)workspace, dw, n, p.nsplit);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}

@@ -49,6 +49,9 @@ _SIGS = {
     "u3d_spconv_fwd": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "u3d_spconv_wgrad_workspace": (_L, [_I, _I, _I, _I]),
     "u3d_spconv_wgrad": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "u3d_igemm_fwd_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "u3d_igemm_wgrad_bf16_workspace": (_L, [_I, _I, _I, _I]),
+    "u3d_igemm_wgrad_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
     "u3d_bn_stats_workspace": (_L, [_I, _I]),
     "u3d_bn_stats": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _P]),
     "u3d_bn_finalize": (_I, [_P, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
@@ -224,6 +227,7 @@ class KernelTimer:
 
 
 TIMER = None
+USE_IGEMM_V2 = True
 
 
 def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False):
@@ -234,8 +238,15 @@ def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False):
     ld = nbr.shape[1] if nbr is not None else 0
     t = TIMER
     e0 = t.begin() if t is not None else None
-    _check(lib().u3d_spconv_fwd(_ptr(inp), _ptr(w), _ptr(nbr), ld, _ptr(out), _ptr(n_out_dev), n_out, cin, cout, kvol,
-                                1 if transpose_w else 0, dtype_code(inp), _stream()), "spconv_fwd")
+    rc = -2
+    if inp.dtype == torch.bfloat16 and USE_IGEMM_V2:
+        rc = lib().u3d_igemm_fwd_bf16(_ptr(inp), _ptr(w), _ptr(nbr), ld, _ptr(out), _ptr(n_out_dev), n_out, cin, cout, kvol,
+                                      1 if transpose_w else 0, _stream())
+        if rc not in (0, -2):
+            _check(rc, "igemm_fwd_bf16")
+    if rc == -2:      # shape served by the first-generation kernel (small channel counts, f32)
+        _check(lib().u3d_spconv_fwd(_ptr(inp), _ptr(w), _ptr(nbr), ld, _ptr(out), _ptr(n_out_dev), n_out, cin, cout, kvol,
+                                    1 if transpose_w else 0, dtype_code(inp), _stream()), "spconv_fwd")
     if t is not None:
         meta = None
         if t.mode == "census":
@@ -251,6 +262,13 @@ def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False):
 def spconv_wgrad(inp, dout, nbr, n_out_dev, kvol):
     cin, cout, n_out = inp.shape[1], dout.shape[1], dout.shape[0]
     dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=inp.device)
+    if inp.dtype == torch.bfloat16 and USE_IGEMM_V2 and cin % 64 == 0 and cout % 64 == 0:
+        wsb = int(lib().u3d_igemm_wgrad_bf16_workspace(n_out, cin, cout, kvol))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=inp.device)
+        ld = nbr.shape[1] if nbr is not None else 0
+        _check(lib().u3d_igemm_wgrad_bf16(_ptr(inp), _ptr(dout), _ptr(nbr), ld, _ptr(dw), _ptr(n_out_dev), n_out, cin, cout, kvol,
+                                          _ptr(ws), wsb, _stream()), "igemm_wgrad_bf16")
+        return dw
     wsb = int(lib().u3d_spconv_wgrad_workspace(n_out, cin, cout, kvol))
     ws = torch.empty(wsb, dtype=torch.uint8, device=inp.device)
     ld = nbr.shape[1] if nbr is not None else 0
