@@ -18,6 +18,14 @@ from .bbox import bbox_overlaps_3d_aligned, bbox_overlaps_nearest_3d, denormaliz
 from .transformer import inverse_sigmoid
 
 
+def reduce_mean_(t):
+    """In-place mean over ranks (mmdet `reduce_mean` for a whole vector at once); identity without a process group."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t.div_(dist.get_world_size())
+        dist.all_reduce(t)
+    return t
+
+
 def _clones(m, n):
     return nn.ModuleList(copy.deepcopy(m) for _ in range(n))
 
@@ -162,10 +170,7 @@ class Uni3DETRHead(nn.Module):
         else:
             tgt = box_all.new_zeros((L, B, Q, 7))
             lab = torch.full_like(asg, C)
-        num_pos = w.sum(dim=(1, 2))                                                    # [L]
-        if dist.is_available() and dist.is_initialized():
-            num_pos = num_pos / dist.get_world_size()
-            dist.all_reduce(num_pos)                                                   # one message for all layers (ref: 2 per layer)
+        num_pos = reduce_mean_(w.sum(dim=(1, 2)))                                      # [L]; one message for all layers (ref: 2 per layer)
         cls_avg = num_pos.clamp(min=1) if self.sync_cls_avg_factor else w.sum(dim=(1, 2)).clamp(min=1)
         npos = num_pos.clamp(min=1)
 
