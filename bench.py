@@ -22,6 +22,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks (no 2:1 sparsity)
 
 
 def parse():
@@ -88,8 +89,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("U3D_FORCE_DDP") == "1"      # the env flag exercises the RCCL/DDP path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     import projects.mmdet3d_plugin  # noqa: F401
@@ -104,7 +109,7 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=2e-5, weight_decay=0.0001, fused=True)
     net = model
-    if world > 1:
+    if use_dist:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
                                                         bucket_cap_mb=64, broadcast_buffers=False)
     data = make_batch(rank, args.batch, args.points, dev)
@@ -132,22 +137,22 @@ def main():
     if rank == 0 and not args.no_roofline:
         timer = nv.TIMER = nv.KernelTimer("time")
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
         last = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     nv.TIMER = None
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
-    loss_val = float(last)
+    loss_val = float(last.detach())
 
     if rank == 0:
         scenes = world * args.batch * args.steps
@@ -164,27 +169,58 @@ def main():
             durs = timer.durations_ms()
             per_step = len(census)
             assert len(durs) == per_step * args.steps, (len(durs), per_step, args.steps)
-            tot_ms = sum(d for _, d in durs)
-            tot_bytes = sum(m["bytes"] for _, m in census) * args.steps
-            tot_flops = sum(m["flops"] for _, m in census) * args.steps
-            ach = tot_bytes / (tot_ms * 1e-3) / 1e9
-            # the single heaviest launch of the step, by time
-            per_call = np.array([d for _, d in durs]).reshape(args.steps, per_step).mean(0)
-            j = int(per_call.argmax())
-            mj = census[j][1]
+            per_call = np.array([d for _, d in durs]).reshape(args.steps, per_step).mean(0)          # ms, averaged over the timed steps
+            calls = [dict(m, tag=t, ms=float(per_call[i])) for i, (t, m) in enumerate(census)]
+
+            def agg(sel):
+                c = [x for x in calls if sel(x)]
+                ms = sum(x["ms"] for x in c)
+                by = sum(x["bytes"] for x in c)
+                fl = sum(x["flops"] for x in c)
+                return dict(launches_per_step=len(c), ms_per_step=ms, algorithmic_MB_per_step=by / 1e6,
+                            GBps=(by / (ms * 1e-3) / 1e9) if ms else 0.0, TFLOPs=(fl / (ms * 1e-3) / 1e12) if ms else 0.0)
+
+            # dominant kernel = the conv launch class with the most time; its heaviest single launch is priced
+            j = int(np.argmax([x["ms"] for x in calls]))
+            h = calls[j]
+            ai = h["flops"] / h["bytes"]
+            peak_tf = MFMA_PEAK_TF[out["dtype"]]
+            if ai > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
+                ach, peak, unit, bound = h["flops"] / (h["ms"] * 1e-3) / 1e12, peak_tf, "TFLOP/s", "mfma"
+            else:
+                ach, peak, unit, bound = h["bytes"] / (h["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(out["dtype"], {}).get("heaviest_launch_hbm_bytes")
             out["roofline"] = {
-                "kernel": "k_spconv_fwd (SubMConv3d / SparseConv3d forward + dgrad, all launches of the step)",
-                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                "launches_per_step": per_step, "ms_per_step": tot_ms / args.steps, "algorithmic_MB_per_step": tot_bytes / args.steps / 1e6,
-                "tflops": tot_flops / (tot_ms * 1e-3) / 1e12,
-                "heaviest_launch": {"tag": census[j][0], "ms": float(per_call[j]), "GBps": mj["bytes"] / (per_call[j] * 1e-3) / 1e9,
-                                    "n_out": mj["n_out"], "cin": mj["cin"], "cout": mj["cout"], "pairs": mj["pairs"]},
+                "kernel": ("k_igemm_fwd" if h.get("v2") else "k_spconv_fwd") + f" [{h['tag']}, {h['kind']} lattice, N={h['n_out']}, "
+                          f"Cin={h['cin']}, Cout={h['cout']}, K={h['kvol']}, pairs={h['pairs']}]",
+                "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
+                "launch_ms": h["ms"], "algorithmic_bytes": h["bytes"], "flops": h["flops"], "arithmetic_intensity": ai,
+                "launch_GBps": h["bytes"] / (h["ms"] * 1e-3) / 1e9,
+                "all_conv_launches": agg(lambda x: True),
+                "submconv3d_sparse_fwd": agg(lambda x: x["kind"] == "sparse" and x["tag"] == "spconv_fwd" and x["kvol"] == 27 and x["n_in"] == x["n_out"]),
+                "sparse_encoder_convs": agg(lambda x: x["kind"] == "sparse"),
+                "dense_stack_convs": agg(lambda x: x["kind"] == "dense"),
+                "hbm_peak_GBps": HBM_PEAK_GBS,
             }
+            if os.environ.get("U3D_BENCH_DUMP_CALLS"):
+                json.dump(calls, open(os.environ["U3D_BENCH_DUMP_CALLS"], "w"))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.points)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        result_line = json.dumps(out)
+    else:
+        result_line = None
+    if use_dist:
         dist.destroy_process_group()
+    if result_line is not None:
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)      # RCCL prints banner lines through C stdio: flush them BEFORE the result line
+        except Exception:
+            pass
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

@@ -227,6 +227,7 @@ class KernelTimer:
 
 
 TIMER = None
+CALL_KIND = "sparse"
 USE_IGEMM_V2 = True
 
 
@@ -252,7 +253,7 @@ def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False):
         if t.mode == "census":
             pairs = int((nbr[:, :n_out] >= 0).sum().item()) if nbr is not None else n_out
             s = inp.element_size()
-            meta = dict(n_in=inp.shape[0], n_out=n_out, cin=cin, cout=cout, kvol=kvol, pairs=pairs,
+            meta = dict(kind=CALL_KIND, v2=bool(rc == 0), n_in=inp.shape[0], n_out=n_out, cin=cin, cout=cout, kvol=kvol, pairs=pairs,
                         bytes=inp.shape[0] * cin * s + n_out * cout * s + 8 * pairs + kvol * cin * cout * s,
                         flops=2 * pairs * cin * cout)
         t.end("spconv_dgrad" if transpose_w else "spconv_fwd", e0, meta)
@@ -262,18 +263,32 @@ def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False):
 def spconv_wgrad(inp, dout, nbr, n_out_dev, kvol):
     cin, cout, n_out = inp.shape[1], dout.shape[1], dout.shape[0]
     dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=inp.device)
+    t = TIMER
+    meta = None
+    if t is not None and t.mode == "census":
+        pairs = int((nbr[:, :n_out] >= 0).sum().item()) if nbr is not None else n_out
+        s = inp.element_size()
+        meta = dict(kind=CALL_KIND, v2=bool(inp.dtype == torch.bfloat16 and USE_IGEMM_V2 and cin % 64 == 0 and cout % 64 == 0),
+                    n_in=inp.shape[0], n_out=n_out, cin=cin, cout=cout, kvol=kvol, pairs=pairs,
+                    bytes=inp.shape[0] * cin * s + n_out * cout * s + 8 * pairs + kvol * cin * cout * 4, flops=2 * pairs * cin * cout)
     if inp.dtype == torch.bfloat16 and USE_IGEMM_V2 and cin % 64 == 0 and cout % 64 == 0:
         wsb = int(lib().u3d_igemm_wgrad_bf16_workspace(n_out, cin, cout, kvol))
         ws = torch.empty(wsb, dtype=torch.uint8, device=inp.device)
         ld = nbr.shape[1] if nbr is not None else 0
+        e0 = t.begin() if t is not None else None
         _check(lib().u3d_igemm_wgrad_bf16(_ptr(inp), _ptr(dout), _ptr(nbr), ld, _ptr(dw), _ptr(n_out_dev), n_out, cin, cout, kvol,
                                           _ptr(ws), wsb, _stream()), "igemm_wgrad_bf16")
+        if t is not None:
+            t.end("spconv_wgrad", e0, meta)
         return dw
     wsb = int(lib().u3d_spconv_wgrad_workspace(n_out, cin, cout, kvol))
     ws = torch.empty(wsb, dtype=torch.uint8, device=inp.device)
     ld = nbr.shape[1] if nbr is not None else 0
+    e0 = t.begin() if t is not None else None
     _check(lib().u3d_spconv_wgrad(_ptr(inp), _ptr(dout), _ptr(nbr), ld, _ptr(dw), _ptr(n_out_dev), n_out, cin, cout, kvol,
                                   dtype_code(inp), _ptr(ws), wsb, _stream()), "spconv_wgrad")
+    if t is not None:
+        t.end("spconv_wgrad", e0, meta)
     return dw
 
 

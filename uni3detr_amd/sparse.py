@@ -31,9 +31,10 @@ class Level:
 class ConvGeom:
     """Tables of one convolution instance: forward (output-stationary), transposed (input-stationary), sizes."""
 
-    def __init__(self, nbr_fwd, nbr_bwd, n_in, n_in_dev, n_out, n_out_dev):
+    def __init__(self, nbr_fwd, nbr_bwd, n_in, n_in_dev, n_out, n_out_dev, kind="sparse"):
         self.nbr_fwd, self.nbr_bwd = nbr_fwd, nbr_bwd
         self.n_in, self.n_in_dev, self.n_out, self.n_out_dev = n_in, n_in_dev, n_out, n_out_dev
+        self.kind = kind            # "sparse" (encoder levels) or "dense" (SECOND3D/FPN lattice): bench.py tags timings with it
 
 
 def level_from_coors(coors, batch, dims):
@@ -77,6 +78,7 @@ class _SparseConv(torch.autograd.Function):
         ctx.save_for_backward(feats, wc)
         ctx.wshape, ctx.wdtype = weight.shape, weight.dtype
         nbr = geom.nbr_fwd if w.shape[0] > 1 else None
+        nv.CALL_KIND = geom.kind
         return nv.spconv_fwd(feats, wc.contiguous(), nbr, geom.n_out_dev, geom.n_out, w.shape[2])
 
     @staticmethod
@@ -86,6 +88,7 @@ class _SparseConv(torch.autograd.Function):
         dout = dout.contiguous()
         kvol = wc.shape[0]
         din = dw = None
+        nv.CALL_KIND = g.kind
         if ctx.needs_input_grad[0]:
             nbr = g.nbr_bwd if kvol > 1 else None
             din = nv.spconv_fwd(dout, wc.contiguous(), nbr, g.n_in_dev, g.n_in, wc.shape[1], transpose_w=True)
