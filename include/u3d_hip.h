@@ -45,9 +45,12 @@ typedef struct u3d_bitgrid {
   void* words;      /* uint64 [nwords]   */
   void* prefix;     /* uint32 [nwords+1] */
   int32_t batch, dz, dy, dx;
+  int32_t layout;   /* 0: 4x4x4-block words (rank = block-major order, used by the conv levels);
+                       1: linear, one bit per cell in (b,z,y,x) order (rank = lexicographic = torch.unique(dim=0) order) */
 } u3d_bitgrid;
 
 int64_t u3d_bitgrid_nwords(int32_t batch, int32_t dz, int32_t dy, int32_t dx);
+int64_t u3d_bitgrid_nwords_layout(int32_t batch, int32_t dz, int32_t dy, int32_t dx, int32_t layout);
 
 /* words must be zeroed by the caller (hipMemsetAsync) before marking. coors: int32 [n,4] (b,z,y,x);
  * rows with b < 0 are ignored. */
@@ -108,6 +111,18 @@ int32_t u3d_voxelize_hard(const float* points, const int32_t* scene_off, int32_t
                           const float pc_range[6], int32_t max_points, int32_t max_voxels,
                           float* voxels, int32_t* coors, int32_t* num_points, float* mean,
                           int32_t* voxel_off, void* workspace, int64_t workspace_bytes, u3d_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dynamic voxelization + DynamicSimpleVFE (ref: models/detectors/uni3detr.py:155-171; upstream mmcv Voxelization with
+ * max_num_points=-1 and DynamicScatter(average_points=True)).
+ *   u3d_voxelize_dynamic: per point (b, z, y, x) int32, or (b,-1,-1,-1) when out of range (same floor formula as hard mode).
+ *   u3d_scatter_mean: feats[rank[i], :] = mean of points with that rank (rank < 0 skipped); sums f32 [V,nfeat] and
+ *   counts int32 [V] must be zeroed by the caller; f32 atomics (as the upstream kernel), then an in-place divide.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t u3d_voxelize_dynamic(const float* points, const int32_t* scene_off, int32_t batch, int32_t n_total, int32_t nfeat,
+                             const float voxel_size[3], const float pc_range[6], int32_t* coors, u3d_stream s);
+int32_t u3d_scatter_mean(const float* points, const int32_t* rank, int32_t n_total, int32_t nfeat, float* sums,
+                         int32_t* counts, int32_t n_voxels, u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * Sparse convolution as output-stationary implicit GEMM over the neighbour table

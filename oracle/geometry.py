@@ -66,6 +66,29 @@ def vfe_mean(voxels, num, num_features):
     return (v.sum(1) / torch.from_numpy(num).to(v.dtype).view(-1, 1)).numpy()
 
 
+def voxelize_dynamic(points_list, voxel_size, pc_range):
+    """Dynamic mode (max_num_points=-1): per-point (b,z,y,x) or (b,-1,-1,-1); then DynamicScatter mean:
+    unique rows in lexicographic order + mean of member points (ref uni3detr.py:155-171)."""
+    vs = np.asarray(voxel_size, np.float32)
+    lo = np.asarray(pc_range[:3], np.float32)
+    g = grid_size(voxel_size, pc_range)
+    coors = []
+    for b, p in enumerate(points_list):
+        p = np.asarray(p, np.float32)
+        q = (p[:, :3] - lo) / vs
+        ok = np.all((q >= 0) & (q < g.astype(np.float32)), axis=1)
+        c = np.floor(np.where(ok[:, None], q, 0)).astype(np.int32)[:, ::-1]
+        c = np.where(ok[:, None], c, -1)
+        coors.append(np.concatenate([np.full((p.shape[0], 1), b, np.int32), c], 1))
+    coors = np.concatenate(coors)
+    pts = np.concatenate([np.asarray(p, np.float32) for p in points_list])
+    valid = coors[:, 1] >= 0
+    uniq, inv, cnt = np.unique(coors[valid], axis=0, return_inverse=True, return_counts=True)
+    sums = np.zeros((uniq.shape[0], pts.shape[1]), np.float64)
+    np.add.at(sums, inv.reshape(-1), pts[valid].astype(np.float64))
+    return coors, (sums / cnt[:, None]).astype(np.float32), uniq.astype(np.int32)
+
+
 def voxelize_batch(points_list, voxel_size, pc_range, max_points, max_voxels):
     """MVXTwoStageDetector.voxelize: per scene then concat with leading batch index."""
     vox, coo, num = [], [], []

@@ -83,3 +83,12 @@ def test_head_state_dict_keys_match_reference_checkpoint_names():
         assert k in sd, k
     assert tuple(sd["pts_middle_encoder.encoder_layers.encoder_layer3.2.0.weight"].shape) == (3, 3, 3, 64, 128)
     assert tuple(sd["pts_neck.deblocks.2.0.weight"].shape) == (512, 256, 1, 4, 4)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference configs only exist in the build container")
+@pytest.mark.parametrize("name", ["scannet_large", "kitti_3classes", "nuscenes", "sunrgbd"])
+def test_builtin_variants_equal_shipped_configs(name):
+    import json
+    from uni3detr_amd.configs import variants
+    ref = Config.fromfile(os.path.join(REF_CFG, f"uni3detr_{name}.py")).model
+    assert json.dumps(getattr(variants, name), sort_keys=True, default=list) == json.dumps(ref, sort_keys=True, default=list)

@@ -336,3 +336,24 @@ def test_dense_lattice_conv_matches_conv3d(cuda):
         y, dims_out = dn.deconv_bn_relu(rows, B, (D, H, W), dec_d, bn_d)
         yv = y.view(B, *dims_out, 32).permute(0, 4, 1, 2, 3)
         assert (yv.detach().cpu() - ref.detach()).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_dynamic_voxelize_and_scatter_mean(cuda):
+    from uni3detr_amd.plugin.detector import DynamicSimpleVFE
+    rng = np.random.default_rng(2)
+    rangep = (-6.4, -6.4, -0.1, 6.4, 6.4, 2.46)
+    pl = []
+    for b in range(2):
+        p = room_scene(b, 30000 - 5000 * b)[0].copy()
+        p[:, :2] *= 1.5
+        p[:, 2] += 2.0
+        p[:50] += 100.0                                     # out-of-range points -> -1 rows
+        pl.append(p)
+    pts, off = _upload(pl, cuda)
+    coors = nv.voxelize_dynamic(pts, off, 2, SUNRGBD_VOXEL, rangep)
+    rc, rfeat, rvox = og.voxelize_dynamic(pl, SUNRGBD_VOXEL, rangep)
+    assert np.array_equal(coors.cpu().numpy(), rc)
+    vfe = DynamicSimpleVFE(SUNRGBD_VOXEL, rangep)
+    feats, fcoors = vfe(pts, coors, batch_size=2)
+    assert np.array_equal(fcoors.cpu().numpy(), rvox)                  # lexicographic order == torch.unique(dim=0)
+    np.testing.assert_allclose(feats.cpu().numpy(), rfeat, rtol=1e-5, atol=1e-5)

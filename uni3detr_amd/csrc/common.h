@@ -31,6 +31,7 @@ struct BitGridDev {
   const unsigned int* prefix;  // exclusive popcount scan, nwords + 1 entries
   int B, Dz, Dy, Dx;           // logical extent (cells)
   int bz, by, bx;              // extent in 4x4x4 blocks
+  int linear;                  // 1: one bit per cell in lexicographic (b,z,y,x) order (rank == torch.unique(dim=0) order)
 };
 
 __host__ __device__ inline BitGridDev u3d_make_grid(const u3d_bitgrid* g) {
@@ -39,13 +40,19 @@ __host__ __device__ inline BitGridDev u3d_make_grid(const u3d_bitgrid* g) {
   d.prefix = (const unsigned int*)g->prefix;
   d.B = g->batch; d.Dz = g->dz; d.Dy = g->dy; d.Dx = g->dx;
   d.bz = (g->dz + 3) >> 2; d.by = (g->dy + 3) >> 2; d.bx = (g->dx + 3) >> 2;
+  d.linear = g->layout;
   return d;
 }
 
+__device__ __forceinline__ long long u3d_cell_linear(const BitGridDev& g, int b, int z, int y, int x) {
+  return (((long long)b * g.Dz + z) * g.Dy + y) * g.Dx + x;
+}
 __device__ __forceinline__ long long u3d_word_index(const BitGridDev& g, int b, int z, int y, int x) {
+  if (g.linear) return u3d_cell_linear(g, b, z, y, x) >> 6;
   return (((long long)b * g.bz + (z >> 2)) * g.by + (y >> 2)) * g.bx + (x >> 2);
 }
-__device__ __forceinline__ int u3d_bit_index(int z, int y, int x) {
+__device__ __forceinline__ int u3d_bit_index(const BitGridDev& g, int b, int z, int y, int x) {
+  if (g.linear) return (int)(u3d_cell_linear(g, b, z, y, x) & 63);
   return ((z & 3) << 4) | ((y & 3) << 2) | (x & 3);
 }
 // row id of (b,z,y,x) or -1 when out of range / unoccupied
@@ -53,7 +60,7 @@ __device__ __forceinline__ int u3d_grid_lookup(const BitGridDev& g, int b, int z
   if ((unsigned)z >= (unsigned)g.Dz || (unsigned)y >= (unsigned)g.Dy || (unsigned)x >= (unsigned)g.Dx) return -1;
   long long w = u3d_word_index(g, b, z, y, x);
   unsigned long long bits = g.words[w];
-  int bit = u3d_bit_index(z, y, x);
+  int bit = u3d_bit_index(g, b, z, y, x);
   if (!((bits >> bit) & 1ull)) return -1;
   return (int)(g.prefix[w] + __popcll(bits & ((1ull << bit) - 1ull)));
 }

@@ -8,6 +8,11 @@
 extern "C" int64_t u3d_bitgrid_nwords(int32_t batch, int32_t dz, int32_t dy, int32_t dx) {
   return (int64_t)batch * ((dz + 3) / 4) * ((dy + 3) / 4) * ((dx + 3) / 4);
 }
+extern "C" int64_t u3d_bitgrid_nwords_layout(int32_t batch, int32_t dz, int32_t dy, int32_t dx, int32_t layout) {
+  if (layout == 1) return ((int64_t)batch * dz * dy * dx + 63) / 64;
+  return u3d_bitgrid_nwords(batch, dz, dy, dx);
+}
+static inline long long grid_nwords(const u3d_bitgrid* g) { return u3d_bitgrid_nwords_layout(g->batch, g->dz, g->dy, g->dx, g->layout); }
 
 __global__ void k_bitgrid_mark(BitGridDev g, unsigned long long* words, const int4* __restrict__ coors, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -15,7 +20,7 @@ __global__ void k_bitgrid_mark(BitGridDev g, unsigned long long* words, const in
   int4 c = coors[i];  // (b,z,y,x)
   if (c.x < 0 || c.x >= g.B) return;
   if ((unsigned)c.y >= (unsigned)g.Dz || (unsigned)c.z >= (unsigned)g.Dy || (unsigned)c.w >= (unsigned)g.Dx) return;
-  atomicOr(&words[u3d_word_index(g, c.x, c.y, c.z, c.w)], 1ull << u3d_bit_index(c.y, c.z, c.w));
+  atomicOr(&words[u3d_word_index(g, c.x, c.y, c.z, c.w)], 1ull << u3d_bit_index(g, c.x, c.y, c.z, c.w));
 }
 
 extern "C" int32_t u3d_bitgrid_mark(const u3d_bitgrid* g, const int32_t* coors, int32_t n, u3d_stream s) {
@@ -51,7 +56,7 @@ __global__ void k_bitgrid_mark_strided(BitGridDev g, unsigned long long* words, 
         if (tx < 0 || tx % cv.s[2]) continue;
         int ox = tx / cv.s[2];
         if (ox >= g.Dx) continue;
-        atomicOr(&words[u3d_word_index(g, c.x, oz, oy, ox)], 1ull << u3d_bit_index(oz, oy, ox));
+        atomicOr(&words[u3d_word_index(g, c.x, oz, oy, ox)], 1ull << u3d_bit_index(g, c.x, oz, oy, ox));
       }
     }
   }
@@ -154,7 +159,7 @@ extern "C" int64_t u3d_bitgrid_scan_scratch(int64_t nwords) { return (nwords + S
 
 extern "C" int32_t u3d_bitgrid_scan(const u3d_bitgrid* g, void* scratch, u3d_stream s) {
   U3D_REQUIRE(g && g->words && g->prefix && scratch, U3D_ERR_ARG);
-  long long nwords = u3d_bitgrid_nwords(g->batch, g->dz, g->dy, g->dx);
+  long long nwords = grid_nwords(g);
   int nchunks = (int)((nwords + SCAN_CHUNK - 1) / SCAN_CHUNK);
   unsigned* cs = (unsigned*)scratch;
   hipLaunchKernelGGL(k_scan_chunksum, dim3(nchunks), dim3(SCAN_TPB), 0, s, (const unsigned long long*)g->words, nwords, cs);
@@ -186,6 +191,19 @@ __global__ void k_bitgrid_coords(BitGridDev g, long long nwords, int4* __restric
   unsigned long long bits = g.words[w];
   if (!bits) return;
   unsigned r = g.prefix[w];
+  if (g.linear) {
+    while (bits) {
+      int bit = __ffsll((long long)bits) - 1;
+      bits &= bits - 1;
+      long long t = w * 64 + bit;
+      int x = (int)(t % g.Dx); t /= g.Dx;
+      int y = (int)(t % g.Dy); t /= g.Dy;
+      int z = (int)(t % g.Dz); t /= g.Dz;
+      if ((int)r < cap) out[r] = make_int4((int)t, z, y, x);
+      ++r;
+    }
+    return;
+  }
   long long t = w;
   int bx = (int)(t % g.bx); t /= g.bx;
   int by = (int)(t % g.by); t /= g.by;
@@ -201,7 +219,7 @@ __global__ void k_bitgrid_coords(BitGridDev g, long long nwords, int4* __restric
 
 extern "C" int32_t u3d_bitgrid_coords(const u3d_bitgrid* g, int32_t* coors_out, int32_t cap, u3d_stream s) {
   U3D_REQUIRE(g && g->words && g->prefix && coors_out, U3D_ERR_ARG);
-  long long nwords = u3d_bitgrid_nwords(g->batch, g->dz, g->dy, g->dx);
+  long long nwords = grid_nwords(g);
   hipLaunchKernelGGL(k_bitgrid_coords, dim3(u3d_cdiv(nwords, 256)), dim3(256), 0, s, u3d_make_grid(g), nwords,
                      (int4*)coors_out, cap);
   U3D_CHECK_LAUNCH();
@@ -546,6 +564,70 @@ extern "C" int32_t u3d_voxelize_hard(const float* points, const int32_t* scene_o
                        (const unsigned*)w.keys, (const unsigned*)w.first, (const int*)w.head, (const int*)w.next,
                        (const int*)w.slot_of, (const int*)w.vid, (const int*)voxel_off, voxels, (int4*)coors, num_points, mean);
   }
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+
+// ============================================================================================
+// Dynamic voxelization + scatter-mean (DynamicSimpleVFE)
+// ============================================================================================
+__global__ void k_vox_dynamic(const float* __restrict__ pts, const int* __restrict__ scene_off, int B, int n_total, VoxCfg cfg,
+                              int4* __restrict__ coors) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_total) return;
+  int b = 0;
+  while (b + 1 < B && i >= scene_off[b + 1]) ++b;
+  const float* p = pts + (long long)i * cfg.nfeat;
+  int c[3];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float q = __fdiv_rn(__fsub_rn(p[j], cfg.lo[j]), cfg.vs[j]);
+    bool in = (q >= 0.f) && (q < (float)cfg.grid[j]);
+    c[j] = in ? (int)floorf(q) : 0;
+    ok = ok && in;
+  }
+  coors[i] = ok ? make_int4(b, c[2], c[1], c[0]) : make_int4(b, -1, -1, -1);
+}
+
+extern "C" int32_t u3d_voxelize_dynamic(const float* points, const int32_t* scene_off, int32_t batch, int32_t n_total, int32_t nfeat,
+                                        const float voxel_size[3], const float pc_range[6], int32_t* coors, u3d_stream s) {
+  U3D_REQUIRE(points && scene_off && coors && batch > 0 && nfeat >= 3, U3D_ERR_ARG);
+  if (n_total <= 0) return U3D_OK;
+  VoxCfg cfg;
+  for (int j = 0; j < 3; ++j) {
+    cfg.vs[j] = voxel_size[j];
+    cfg.lo[j] = pc_range[j];
+    cfg.grid[j] = (int)lroundf((pc_range[3 + j] - pc_range[j]) / voxel_size[j]);
+  }
+  cfg.nfeat = nfeat; cfg.max_points = 0; cfg.max_voxels = 0; cfg.hsize = 0;
+  hipLaunchKernelGGL(k_vox_dynamic, dim3(u3d_cdiv(n_total, 256)), dim3(256), 0, s, points, scene_off, batch, n_total, cfg, (int4*)coors);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+__global__ void k_scatter_accum(const float* __restrict__ pts, const int* __restrict__ rank, int n_total, int nfeat,
+                                float* __restrict__ sums, int* __restrict__ counts) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_total) return;
+  int r = rank[i];
+  if (r < 0) return;
+  for (int f = 0; f < nfeat; ++f) atomicAdd(&sums[(long long)r * nfeat + f], pts[(long long)i * nfeat + f]);
+  atomicAdd(&counts[r], 1);
+}
+__global__ void k_scatter_divide(float* __restrict__ sums, const int* __restrict__ counts, int n_voxels, int nfeat) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n_voxels * nfeat) return;
+  int c = counts[t / nfeat];
+  sums[t] = sums[t] / (float)(c > 0 ? c : 1);
+}
+
+extern "C" int32_t u3d_scatter_mean(const float* points, const int32_t* rank, int32_t n_total, int32_t nfeat, float* sums,
+                                    int32_t* counts, int32_t n_voxels, u3d_stream s) {
+  U3D_REQUIRE(points && rank && sums && counts && nfeat > 0, U3D_ERR_ARG);
+  if (n_total > 0) hipLaunchKernelGGL(k_scatter_accum, dim3(u3d_cdiv(n_total, 256)), dim3(256), 0, s, points, rank, n_total, nfeat, sums, counts);
+  if (n_voxels > 0) hipLaunchKernelGGL(k_scatter_divide, dim3(u3d_cdiv((long long)n_voxels * nfeat, 256)), dim3(256), 0, s, sums, counts, n_voxels, nfeat);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

@@ -20,7 +20,7 @@ class U3DError(RuntimeError):
 
 class BitGridStruct(C.Structure):
     _fields_ = [("words", C.c_void_p), ("prefix", C.c_void_p), ("batch", C.c_int32), ("dz", C.c_int32),
-                ("dy", C.c_int32), ("dx", C.c_int32)]
+                ("dy", C.c_int32), ("dx", C.c_int32), ("layout", C.c_int32)]
 
 
 _lib = None
@@ -36,6 +36,9 @@ _SIGS = {
     "u3d_version": (_I, []),
     "u3d_strerror": (C.c_char_p, [_I]),
     "u3d_bitgrid_nwords": (_L, [_I, _I, _I, _I]),
+    "u3d_bitgrid_nwords_layout": (_L, [_I, _I, _I, _I, _I]),
+    "u3d_voxelize_dynamic": (_I, [_P, _P, _I, _I, _I, _F3, _F6, _P, _P]),
+    "u3d_scatter_mean": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "u3d_bitgrid_mark": (_I, [C.POINTER(BitGridStruct), _P, _I, _P]),
     "u3d_bitgrid_mark_strided": (_I, [C.POINTER(BitGridStruct), _P, _P, _I, _I3, _I3, _I3, _P]),
     "u3d_bitgrid_scan_scratch": (_L, [_L]),
@@ -121,13 +124,14 @@ def dtype_code(t):
 class BitGrid:
     """Occupancy lattice of one sparse level (see include/u3d_hip.h)."""
 
-    def __init__(self, batch, dims, device):
+    def __init__(self, batch, dims, device, linear=False):
         self.batch, self.dims = int(batch), tuple(int(d) for d in dims)
-        self.nwords = int(lib().u3d_bitgrid_nwords(self.batch, *self.dims))
+        self.linear = bool(linear)
+        self.nwords = int(lib().u3d_bitgrid_nwords_layout(self.batch, *self.dims, 1 if linear else 0))
         self.words = torch.zeros(self.nwords, dtype=torch.int64, device=device)
         self.prefix = torch.empty(self.nwords + 1, dtype=torch.int32, device=device)
         self._scratch = torch.empty(int(lib().u3d_bitgrid_scan_scratch(self.nwords)), dtype=torch.int32, device=device)
-        self.c = BitGridStruct(self.words.data_ptr(), self.prefix.data_ptr(), self.batch, *self.dims)
+        self.c = BitGridStruct(self.words.data_ptr(), self.prefix.data_ptr(), self.batch, *self.dims, 1 if linear else 0)
 
     def mark(self, coors):
         _check(lib().u3d_bitgrid_mark(C.byref(self.c), _ptr(coors), coors.shape[0], _stream()), "bitgrid_mark")
@@ -196,6 +200,23 @@ def voxelize_hard(points, scene_off, batch, max_pts_per_scene, voxel_size, pc_ra
                                    _F3(*voxel_size), _F6(*pc_range), max_points, max_voxels, _ptr(voxels), _ptr(coors),
                                    _ptr(num), _ptr(mean), _ptr(voxel_off), _ptr(ws), wsb, _stream()), "voxelize_hard")
     return voxels, coors, num, mean, voxel_off
+
+
+def voxelize_dynamic(points, scene_off, batch, voxel_size, pc_range):
+    """-> coors int32 [n_total,4] (b,z,y,x), (b,-1,-1,-1) for out-of-range points."""
+    n_total, nfeat = points.shape
+    coors = torch.empty((n_total, 4), dtype=torch.int32, device=points.device)
+    _check(lib().u3d_voxelize_dynamic(_ptr(points), _ptr(scene_off), batch, n_total, nfeat, _F3(*voxel_size), _F6(*pc_range),
+                                      _ptr(coors), _stream()), "voxelize_dynamic")
+    return coors
+
+
+def scatter_mean(points, rank, n_voxels):
+    n_total, nfeat = points.shape
+    sums = torch.zeros((n_voxels, nfeat), dtype=torch.float32, device=points.device)
+    counts = torch.zeros((n_voxels,), dtype=torch.int32, device=points.device)
+    _check(lib().u3d_scatter_mean(_ptr(points), _ptr(rank), n_total, nfeat, _ptr(sums), _ptr(counts), n_voxels, _stream()), "scatter_mean")
+    return sums, counts
 
 
 # --------------------------------------------------------------------------------------------------

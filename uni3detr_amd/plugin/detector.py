@@ -34,9 +34,32 @@ class HardSimpleVFE(nn.Module):
 
 @VOXEL_ENCODERS.register_module()
 class DynamicSimpleVFE(nn.Module):
+    """mean of the points of every occupied voxel; voxels come out in lexicographic (b,z,y,x) order like upstream's
+    DynamicScatter -> torch.unique(dim=0).  Linear BitGrid rank + f32 atomics on the device."""
+
     def __init__(self, voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1)):
         super().__init__()
-        self.voxel_size, self.point_cloud_range = voxel_size, point_cloud_range
+        self.voxel_size, self.point_cloud_range = list(voxel_size), list(point_cloud_range)
+        self.fp16_enabled = False
+
+    def grid_dims(self):
+        vs, pr = self.voxel_size, self.point_cloud_range
+        gx, gy, gz = (int(round((pr[3 + j] - pr[j]) / vs[j])) for j in range(3))
+        return (gz, gy, gx)
+
+    @torch.no_grad()
+    def forward(self, features, coors, batch_size=None):
+        """features f32 [N,F] (all scenes), coors int32 [N,4] (b,z,y,x) with -1 rows for dropped points."""
+        coors = coors.int().contiguous()
+        if batch_size is None:
+            batch_size = int(coors[-1, 0].item()) + 1
+        g = nv.BitGrid(batch_size, self.grid_dims(), features.device, linear=True)
+        g.mark(coors)
+        g.scan()
+        n_vox = int(g.count_dev.item())
+        rank = g.rank(coors)
+        feats, _ = nv.scatter_mean(features.float().contiguous(), rank, n_vox)
+        return feats, g.coords(n_vox)
 
 
 def shift_scale_points(pred_xyz, src_range, dst_range=None):
@@ -119,7 +142,7 @@ class Uni3DETR(nn.Module):
         base = torch.cat([raw, vox.reshape(-1)])
         set_off = torch.cat([raw_off, raw.numel() + voxel_off[:-1].long() * 3])
         set_n = torch.cat([scene_off[1:] - scene_off[:-1], voxel_off[1:] - voxel_off[:-1]]).int()
-        max_n = max(max(lens), int(self.pts_voxel_layer.max_voxels[0 if self.training else 1]))
+        max_n = max(max(lens), int(self.pts_voxel_layer.max_voxels[0 if self.training else 1]) if not self.dynamic_voxelization else 0)
         idx = nv.fps(base, set_off.contiguous(), set_n.contiguous(), max_n, m).long()     # [2B, m]
         p_idx = idx[:B] + scene_off[:-1].long()[:, None]
         v_idx = idx[B:] + voxel_off[:-1].long()[:, None]
@@ -129,11 +152,28 @@ class Uni3DETR(nn.Module):
         b = shift_scale_points(b, [b.min(dim=1)[0], b.max(dim=1)[0]])
         return torch.cat([a, b], 1)
 
+    def voxelize_dynamic_batch(self, pts):
+        """ref :155-167: per-point coors (-1 rows kept), DynamicSimpleVFE mean per voxel."""
+        B = len(pts)
+        lens = [int(p.shape[0]) for p in pts]
+        cat = torch.cat([p.float() for p in pts]).contiguous() if B > 1 else pts[0].float().contiguous()
+        off = [0]
+        for n in lens:
+            off.append(off[-1] + n)
+        scene_off = torch.tensor(off, dtype=torch.int32, device=cat.device)
+        vl = self.pts_voxel_layer
+        coors = nv.voxelize_dynamic(cat, scene_off, B, vl.voxel_size, vl.point_cloud_range)
+        feats, fcoors = self.pts_voxel_encoder(cat, coors, batch_size=B)
+        return coors, feats, fcoors, cat, scene_off, lens
+
     def extract_pts_feat(self, pts):
         if self.dynamic_voxelization:
-            raise NotImplementedError("dynamic voxelization (ScanNet configs) is a later row of the hot-path table (DESIGN.md)")
-        coors, feats, voxel_off, cat, scene_off, lens = self.voxelize_batch(pts)
-        x = self.pts_middle_encoder(feats, coors, len(pts))
+            coors, feats, fcoors, cat, scene_off, lens = self.voxelize_dynamic_batch(pts)
+            x = self.pts_middle_encoder(feats, fcoors, len(pts))
+            voxel_off = scene_off          # the voxel-coordinate FPS runs over the PER-POINT coors incl. -1 rows (ref :166,:183)
+        else:
+            coors, feats, voxel_off, cat, scene_off, lens = self.voxelize_batch(pts)
+            x = self.pts_middle_encoder(feats, coors, len(pts))
         amp = self.amp_dtype
         with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
             if self.with_pts_backbone:
