@@ -234,6 +234,13 @@ int32_t u3d_trilinear_bwd(const void* value, const float* grid, const void* dout
 /* diag(bbox_overlaps_3d(a,b)) for a,b f32 [n,7] (ref: models/dense_heads/uni3detr_head.py:695). */
 int32_t u3d_iou3d_rotated_aligned(const float* a, const float* b, int32_t n, float* out, u3d_stream s);
 
+/* Class-aware rotated-BEV NMS (ref: models/dense_heads/uni3detr_head.py:849-865 -> mmcv.ops.nms3d applied per class).
+ * boxes f32 [n,7] sorted by descending score, labels int32 [n]; keep uint8 [n] (1 = survives).  A box is suppressed by a
+ * kept earlier box of the same label with BEV rotated IoU > thr (height ignored). */
+int64_t u3d_nms3d_workspace(int32_t n);
+int32_t u3d_nms3d(const float* boxes, const int32_t* labels, int32_t n, float thr, uint8_t* keep, void* workspace,
+                  int64_t workspace_bytes, u3d_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -499,3 +499,70 @@ extern "C" int32_t u3d_trilinear_bwd(const void* value, const float* grid, const
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
+
+// ============================================================================================
+// Class-aware rotated BEV NMS (ref: models/dense_heads/uni3detr_head.py:849-865 -> upstream mmcv.ops.nms3d per class;
+// boxes sorted by score, a box is suppressed by any kept higher-scored box of the same label whose
+// rotated BEV IoU exceeds thr; height ignored).  Input must already be sorted by descending score.
+//   pass 1: mask[i][w] bit j set iff j > i, label equal, iou_bev(i, j) > thr      (n x ceil(n/64) words)
+//   pass 2: one wavefront sweeps i = 0..n-1 (kept rows OR their mask into `removed`), writes keep[i].
+// ============================================================================================
+__device__ float bev_iou_rot(const float* p, const float* q) {
+  float a1 = p[3] * p[4], a2 = q[3] * q[4];
+  if (a1 <= 0.f || a2 <= 0.f) return 0.f;
+  P2 poly[12], tmp[12], clipper[4];
+  rect_corners(0.f, 0.f, p[3], p[4], p[6], poly);
+  rect_corners(q[0] - p[0], q[1] - p[1], q[3], q[4], q[6], clipper);
+  int m = 4;
+  for (int e = 0; e < 4 && m > 0; ++e) {
+    m = clip_poly(poly, m, clipper[e], clipper[(e + 1) & 3], tmp);
+    for (int t = 0; t < m; ++t) poly[t] = tmp[t];
+  }
+  float inter = 0.f;
+  if (m >= 3) {
+    for (int t = 0; t < m; ++t) {
+      P2 u = poly[t], v = poly[(t + 1 == m) ? 0 : t + 1];
+      inter += u.x * v.y - v.x * u.y;
+    }
+    inter = fabsf(inter) * 0.5f;
+  }
+  return inter / fmaxf(a1 + a2 - inter, 1e-8f);
+}
+
+__global__ void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ labels, int n, float thr,
+                           unsigned long long* __restrict__ mask, int nw) {
+  int i = blockIdx.x;
+  int j = blockIdx.y * 64 + threadIdx.x;
+  bool sup = false;
+  if (j < n && j > i && labels[i] == labels[j]) sup = bev_iou_rot(boxes + (long long)i * 7, boxes + (long long)j * 7) > thr;
+  unsigned long long b = __ballot(sup);
+  if (threadIdx.x == 0) mask[(long long)i * nw + blockIdx.y] = b;
+}
+
+__global__ void k_nms_sweep(const unsigned long long* __restrict__ mask, int n, int nw, unsigned char* __restrict__ keep) {
+  extern __shared__ unsigned long long removed[];
+  for (int w = threadIdx.x; w < nw; w += 64) removed[w] = 0ull;
+  __syncthreads();
+  for (int i = 0; i < n; ++i) {
+    bool k = !((removed[i >> 6] >> (i & 63)) & 1ull);
+    if (threadIdx.x == 0) keep[i] = k ? 1 : 0;
+    if (k)
+      for (int w = threadIdx.x; w < nw; w += 64) removed[w] |= mask[(long long)i * nw + w];
+    __syncthreads();
+  }
+}
+
+extern "C" int64_t u3d_nms3d_workspace(int32_t n) { return (int64_t)n * ((n + 63) / 64) * 8; }
+
+extern "C" int32_t u3d_nms3d(const float* boxes, const int32_t* labels, int32_t n, float thr, uint8_t* keep, void* workspace,
+                             int64_t workspace_bytes, u3d_stream s) {
+  U3D_REQUIRE(boxes && labels && keep && workspace, U3D_ERR_ARG);
+  if (n <= 0) return U3D_OK;
+  int nw = (n + 63) / 64;
+  U3D_REQUIRE(workspace_bytes >= u3d_nms3d_workspace(n), U3D_ERR_WORKSPACE);
+  U3D_REQUIRE((size_t)nw * 8 <= 64 * 1024, U3D_ERR_UNSUPPORTED);
+  hipLaunchKernelGGL(k_nms_mask, dim3(n, nw), dim3(64), 0, s, boxes, labels, n, thr, (unsigned long long*)workspace, nw);
+  hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), (size_t)nw * 8, s, (const unsigned long long*)workspace, n, nw, keep);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}

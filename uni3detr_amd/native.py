@@ -68,6 +68,8 @@ _SIGS = {
     "u3d_lsa": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "u3d_trilinear_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "u3d_trilinear_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "u3d_nms3d_workspace": (_L, [_I]),
+    "u3d_nms3d": (_I, [_P, _P, _I, C.c_float, _P, _P, _L, _P]),
     "u3d_iou3d_rotated_aligned": (_I, [_P, _P, _I, _P, _P]),
     "u3d_gather_rows": (_I, [_P, _P, _I, _I, _P, _P]),
     "u3d_scatter_rows": (_I, [_P, _P, _I, _I, _P, _P]),
@@ -448,3 +450,20 @@ def trilinear_bwd(value_rows, grid, dout, batch, dims, want_dvalue=True, want_dg
     _check(lib().u3d_trilinear_bwd(_ptr(value_rows), _ptr(grid), _ptr(dout), batch, nq, dims[0], dims[1], dims[2], c, _ptr(dvalue),
                                    _ptr(dgrid), dtype_code(value_rows), _stream()), "trilinear_bwd")
     return dvalue, dgrid
+
+
+def nms3d_classwise(boxes, scores, labels, thr):
+    """boxes [n,7], scores [n], labels [n] -> indices kept, ordered by (label asc, score desc) like the reference's
+    per-class loop over mmcv.ops.nms3d."""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.long, device=boxes.device)
+    order = torch.argsort(scores, descending=True, stable=True)
+    b = boxes[order, :7].float().contiguous()
+    l = labels[order].int().contiguous()
+    keep = torch.empty((n,), dtype=torch.uint8, device=boxes.device)
+    wsb = int(lib().u3d_nms3d_workspace(n))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=boxes.device)
+    _check(lib().u3d_nms3d(_ptr(b), _ptr(l), n, float(thr), _ptr(keep), _ptr(ws), wsb, _stream()), "nms3d")
+    kept = order[keep.bool()]
+    return kept[torch.argsort(labels[kept], stable=True)]

@@ -199,12 +199,62 @@ class Uni3DETRHead(nn.Module):
         self._last_assigned = asg
         return out
 
+    def soft_nms(self, boxes, scores, gaussian_sigma=0.3, prune_threshold=1e-3):
+        """Gaussian soft-NMS with rotated 3-D IoU (ref :796-823); sequential by nature, host loop over the HIP IoU kernel."""
+        boxes, scores = boxes.clone(), scores.clone()
+        idxs = torch.arange(scores.numel(), device=boxes.device)
+        out_i, out_s = [], []
+        while scores.numel() > 0:
+            top = int(torch.argmax(scores))
+            out_i.append(int(idxs[top]))
+            out_s.append(float(scores[top]))
+            ious = bbox_overlaps_3d_aligned(boxes[top:top + 1].expand_as(boxes).contiguous(), boxes)
+            scores = scores * torch.exp(-ious.pow(2) / gaussian_sigma)
+            keep = scores > prune_threshold
+            keep[top] = False
+            boxes, scores, idxs = boxes[keep], scores[keep], idxs[keep]
+        return torch.tensor(out_i, device=boxes.device, dtype=torch.long), torch.tensor(out_s, device=boxes.device)
+
     def get_bboxes(self, preds_dicts, img_metas, rescale=False):
-        """Decode + (optional) NMS: inference tail, SURVEY.md §8f-1 — decode on device; NMS is a later row."""
+        """Decode + post-processing on the device (ref :827-918).  Returns [[boxes [n,7] bottom-centre, scores, labels], ...]."""
+        from .. import native as nv
         preds = self.bbox_coder.decode(preds_dicts)
+        pp = self.post_processing
         ret = []
         for p in preds:
             boxes = p["bboxes"].clone()
             boxes[:, 2] = boxes[:, 2] - boxes[:, 5] * 0.5          # gravity centre -> bottom centre (ref :842)
-            ret.append([boxes, p["scores"], p["labels"]])
+            scores, labels = p["scores"], p["labels"]
+            if pp is not None:
+                if pp["type"] == "nms":
+                    keep = nv.nms3d_classwise(boxes, scores, labels, pp["nms_thr"])
+                    boxes, scores, labels = boxes[keep], scores[keep], labels[keep]
+                elif pp["type"] == "soft_nms":
+                    bs, ss, ls = [], [], []
+                    for j in range(self.num_classes):
+                        ind = labels == j
+                        if int(ind.sum()) == 0:
+                            continue
+                        ki, sc = self.soft_nms(boxes[ind][:, :7], scores[ind], pp["gaussian_sigma"], pp["prune_threshold"])
+                        bs.append(boxes[ind][ki]); ss.append(sc); ls.append(torch.full_like(ki, j))
+                    boxes = torch.cat(bs) if bs else boxes[:0]
+                    scores = torch.cat(ss) if ss else scores[:0]
+                    labels = torch.cat(ls) if ls else labels[:0]
+                elif pp["type"] == "box_merging":
+                    raise NotImplementedError("KITTI 'box_merging' post-processing is CPU/shapely code outside the hot path "
+                                              "(SURVEY.md §2.1 row 16); use type='nms'")
+                else:
+                    raise NotImplementedError(pp["type"] + " not implemented.")
+                if "score_thr" in pp:
+                    thr = pp["score_thr"]
+                    if isinstance(thr, (list, tuple)):
+                        assert len(thr) == self.num_classes
+                        ind = scores > scores.new_tensor(list(thr))[labels]
+                    else:
+                        ind = scores > thr
+                    boxes, scores, labels = boxes[ind], scores[ind], labels[ind]
+                if "num_thr" in pp:
+                    ind = torch.argsort(-scores)[: pp["num_thr"]]
+                    boxes, scores, labels = boxes[ind], scores[ind], labels[ind]
+            ret.append([boxes, scores, labels])
         return ret
