@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     return ap.parse_args()
 
 
@@ -83,19 +84,26 @@ def cpu_baseline(npts):
 
 def main():
     args = parse()
+    import faulthandler
+    # watchdog: a hung collective / kernel must not burn the whole GPU slot — dump all stacks and exit
+    faulthandler.dump_traceback_later(int(os.environ.get("U3D_WATCHDOG_S", "900")), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1 or os.environ.get("U3D_FORCE_DDP") == "1"      # the env flag exercises the RCCL/DDP path on one GPU
-    if use_dist:
+    use_dist = world > 1 or os.environ.get("U3D_FORCE_DDP") == "1"      # the env flag exercises the RCCL path on one GPU
+
+    def init_pg():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
+
+    if use_dist and args.no_graph:
+        init_pg()
 
     import projects.mmdet3d_plugin  # noqa: F401
     from uni3detr_amd import native as nv
@@ -106,36 +114,21 @@ def main():
     torch.manual_seed(1234)
     model = build_model(MODEL_CFG).to(dev).train()      # constructor-default init == what the shipped flow trains from
     model.set_precision(args.precision)
-    params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=2e-5, weight_decay=0.0001, fused=True)
-    net = model
-    if use_dist:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
-                                                        bucket_cap_mb=64, broadcast_buffers=False)
+    from uni3detr_amd.trainer import TrainStep
     data = make_batch(rank, args.batch, args.points, dev)
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        losses = net(return_loss=True, **data)
-        loss, _ = model._parse_losses(losses)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 10.0, foreach=True)
-        opt.step()
-        return loss
-
+    ts = TrainStep(model, data["points"], data["gt_bboxes_3d"], data["gt_labels_3d"], graph=not args.no_graph)
+    caps = None
+    if not args.no_graph:
+        snap = ts.snapshot()
+        counts, caps = ts.capture()                     # exact-size step -> capacities -> static-shape warm-up -> 3 hipGraphs
+        ts.restore(snap)                                # capture/warm-up iterations do not count as training
+        if use_dist:
+            init_pg()                                   # process group only AFTER the captures (see TrainStep.enable_dist)
+    if use_dist:
+        ts.enable_dist()
+    step = ts.step
     for _ in range(args.warmup):
         step()
-    # ---- roofline census (untimed): pairs / algorithmic bytes of every sparse-conv launch of one step
-    census = None
-    if rank == 0 and not args.no_roofline:
-        nv.TIMER = nv.KernelTimer("census")
-        step()
-        torch.cuda.synchronize()
-        census = nv.TIMER.census
-        nv.TIMER = None
-    timer = None
-    if rank == 0 and not args.no_roofline:
-        timer = nv.TIMER = nv.KernelTimer("time")
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -147,7 +140,23 @@ def main():
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    nv.TIMER = None
+    if not args.no_graph:
+        ts.check_capacities()
+    # ---- roofline: per-launch HIP-event timing needs individually launched kernels, so it runs on eager instrumented steps
+    #      of the same workload right after the timed region (census pass prices each launch, timing pass measures it)
+    census, timer = None, None
+    ROOF_STEPS = 3
+    if rank == 0 and not args.no_roofline:
+        ts.dist_on = False                               # instrumented steps are local to rank 0: no collectives
+        nv.TIMER = nv.KernelTimer("census")
+        ts.eager_step()
+        torch.cuda.synchronize()
+        census = nv.TIMER.census
+        timer = nv.TIMER = nv.KernelTimer("time")
+        for _ in range(ROOF_STEPS):
+            ts.eager_step()
+        torch.cuda.synchronize()
+        nv.TIMER = None
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -163,13 +172,15 @@ def main():
             "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "uni3detr_sunrgbd.py (BASELINE configs[1]): train step fwd+loss+bwd+clip+AdamW, "
                                    f"{args.batch} scenes/GPU x {args.points} pts, 300 queries x 3 groups, random-init weights",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss_val},
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss_val,
+                       "launch_mode": "eager" if args.no_graph else "hipGraph x3 (fwd+match | loss+bwd | clip+AdamW), static-shape sparse levels",
+                       "sparse_level_capacities": caps},
         }
         if timer is not None and census:
             durs = timer.durations_ms()
             per_step = len(census)
-            assert len(durs) == per_step * args.steps, (len(durs), per_step, args.steps)
-            per_call = np.array([d for _, d in durs]).reshape(args.steps, per_step).mean(0)          # ms, averaged over the timed steps
+            assert len(durs) == per_step * ROOF_STEPS, (len(durs), per_step, ROOF_STEPS)
+            per_call = np.array([d for _, d in durs]).reshape(ROOF_STEPS, per_step).mean(0)          # ms, averaged over the instrumented steps
             calls = [dict(m, tag=t, ms=float(per_call[i])) for i, (t, m) in enumerate(census)]
 
             def agg(sel):

@@ -509,6 +509,10 @@ __global__ void k_vox_write(const float* __restrict__ pts, const int* __restrict
   }
 }
 
+__global__ void k_fill_u32(unsigned* __restrict__ p, long long n, unsigned v) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
 static inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 struct VoxWs { unsigned* keys; unsigned* first; int* head; int* vid; int* next; int* slot_of; int* scene_cnt; int hsize; int64_t bytes; };
@@ -550,8 +554,12 @@ extern "C" int32_t u3d_voxelize_hard(const float* points, const int32_t* scene_o
   }
   U3D_REQUIRE((long long)cfg.grid[0] * cfg.grid[1] * cfg.grid[2] < 0xFFFFFFFFll, U3D_ERR_ARG);
   cfg.nfeat = nfeat; cfg.max_points = max_points; cfg.max_voxels = max_voxels; cfg.hsize = w.hsize;
-  hipError_t e = hipMemsetAsync(w.keys, 0xFF, (size_t)batch * w.hsize * 4 * 4, s);
-  if (e != hipSuccess) return U3D_ERR_LAUNCH;
+  {  // keys / first / head / vid tables <- 0xFFFFFFFF.  A kernel, not hipMemsetAsync: memset nodes of re-launched HIP graphs
+     // that share a memory pool were observed to leave the tables stale (list cycles -> hang) on ROCm 7.2.
+    long long nfill = (long long)batch * w.hsize * 4;
+    int blocks = (int)((nfill + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, s, w.keys, nfill, 0xFFFFFFFFu);
+  }
   if (n_total > 0) {
     hipLaunchKernelGGL(k_vox_insert, dim3(u3d_cdiv(n_total, 256)), dim3(256), 0, s, points, scene_off, batch, n_total, cfg,
                        w.keys, w.first, w.head, w.next, w.slot_of);

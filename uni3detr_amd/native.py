@@ -156,7 +156,7 @@ class BitGrid:
         return out
 
     def coords(self, n):
-        out = torch.empty((n, 4), dtype=torch.int32, device=self.words.device)
+        out = torch.full((n, 4), -1, dtype=torch.int32, device=self.words.device)
         _check(lib().u3d_bitgrid_coords(C.byref(self.c), _ptr(out), n, _stream()), "bitgrid_coords")
         return out
 
@@ -192,9 +192,9 @@ def voxelize_hard(points, scene_off, batch, max_pts_per_scene, voxel_size, pc_ra
     cap = batch * max_voxels
     dev = points.device
     voxels = torch.empty((cap, max_points, nfeat), dtype=torch.float32, device=dev) if want_voxels else None
-    coors = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-    num = torch.empty((cap,), dtype=torch.int32, device=dev)
-    mean = torch.empty((cap, nfeat), dtype=torch.float32, device=dev) if want_mean else None
+    coors = torch.full((cap, 4), -1, dtype=torch.int32, device=dev)     # rows past the voxel count stay (-1,..): inert everywhere
+    num = torch.zeros((cap,), dtype=torch.int32, device=dev)
+    mean = torch.zeros((cap, nfeat), dtype=torch.float32, device=dev) if want_mean else None
     voxel_off = torch.empty((batch + 1,), dtype=torch.int32, device=dev)
     wsb = int(lib().u3d_voxelize_hard_workspace(n_total, batch, max_pts_per_scene))
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)

@@ -32,7 +32,7 @@ def nearest_bev(boxes):
     yaw = boxes[..., 6]
     r = (yaw - torch.floor(yaw / math.pi + 0.5) * math.pi).abs()
     swap = (r > math.pi / 4).unsqueeze(-1)
-    wh = torch.where(swap, boxes[..., [4, 3]], boxes[..., [3, 4]])
+    wh = torch.where(swap, boxes[..., 3:5].flip(-1), boxes[..., 3:5])
     c = boxes[..., :2]
     return torch.cat([c - wh / 2, c + wh / 2], dim=-1)
 

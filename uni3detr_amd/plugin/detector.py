@@ -97,6 +97,7 @@ class Uni3DETR(nn.Module):
         # (DESIGN.md "FPS view"); set False to sample on true xyz instead.
         self.fps_packed_view = True
         self.amp_dtype = None           # torch.bfloat16 -> throughput mode (sparse encoder bf16 MFMA, dense + decoder autocast)
+        self.static_shapes = False      # True: capacity-sized tensors + device-side counts, no host reads (hipGraph capturable)
 
     with_pts_backbone = property(lambda self: self.pts_backbone is not None)
     with_pts_neck = property(lambda self: self.pts_neck is not None)
@@ -112,20 +113,40 @@ class Uni3DETR(nn.Module):
         return self
 
     # ------------------------------------------------------------------------------------------
-    def voxelize_batch(self, pts):
-        """list of [N_b,F] -> (coors [V,4] int32 (b,z,y,x), mean feats [V,F], voxel_off [B+1] device, points_cat, scene_off)."""
+    def _concat_points(self, pts):
+        """list of [N_b,F] tensors, or a pre-packed dict(cat [sumN,F] f32, scene_off int32 [B+1] device, lens [B] ints)."""
+        if isinstance(pts, dict):
+            return pts["cat"], pts["scene_off"], list(pts["lens"])
         B = len(pts)
         lens = [int(p.shape[0]) for p in pts]
         cat = torch.cat([p.float() for p in pts]).contiguous() if B > 1 else pts[0].float().contiguous()
         off = [0]
         for n in lens:
             off.append(off[-1] + n)
-        scene_off = torch.tensor(off, dtype=torch.int32, device=cat.device)
+        return cat, torch.tensor(off, dtype=torch.int32, device=cat.device), lens
+
+    @staticmethod
+    def _pack_points(pts):
+        """Pre-pack a batch once (static input buffers for hipGraph replay)."""
+        lens = [int(p.shape[0]) for p in pts]
+        cat = torch.cat([p.float() for p in pts]).contiguous()
+        off = [0]
+        for n in lens:
+            off.append(off[-1] + n)
+        return dict(cat=cat, scene_off=torch.tensor(off, dtype=torch.int32, device=cat.device), lens=lens)
+
+    def voxelize_batch(self, pts):
+        """-> (coors [V,4] int32 (b,z,y,x), mean feats [V,F], voxel_off [B+1] device, points_cat, scene_off, lens)."""
+        cat, scene_off, lens = self._concat_points(pts)
+        B = len(lens)
         vl = self.pts_voxel_layer
         max_voxels = vl.max_voxels[0] if self.training else vl.max_voxels[1]
         _, coors, num, mean, voxel_off = nv.voxelize_hard(cat, scene_off, B, max(lens), vl.voxel_size, vl.point_cloud_range,
                                                           vl.max_num_points, max_voxels, want_voxels=False, want_mean=True)
-        total = int(voxel_off[-1].item())          # the one host read the reference also has (ref :153)
+        if self.static_shapes:
+            total = coors.shape[0]                 # capacity B*max_voxels; rows past voxel_off[B] are (-1,...) and inert
+        else:
+            total = int(voxel_off[-1].item())      # the one host read the reference also has (ref :153)
         return coors[:total], mean[:total, : self.pts_voxel_encoder.num_features], voxel_off, cat, scene_off, lens
 
     def fps_queries(self, cat, scene_off, lens, coors, voxel_off):
@@ -147,20 +168,15 @@ class Uni3DETR(nn.Module):
         p_idx = idx[:B] + scene_off[:-1].long()[:, None]
         v_idx = idx[B:] + voxel_off[:-1].long()[:, None]
         a = cat[:, :3][p_idx]                                                             # [B,m,3] xyz
-        b = vox[v_idx][:, :, [2, 1, 0]]                                                   # [B,m,3] (x,y,z) voxel coords
+        b = vox[v_idx].flip(-1)                                                           # [B,m,3] (z,y,x) -> (x,y,z) voxel coords
         a = shift_scale_points(a, [a.min(dim=1)[0], a.max(dim=1)[0]])
         b = shift_scale_points(b, [b.min(dim=1)[0], b.max(dim=1)[0]])
         return torch.cat([a, b], 1)
 
     def voxelize_dynamic_batch(self, pts):
         """ref :155-167: per-point coors (-1 rows kept), DynamicSimpleVFE mean per voxel."""
-        B = len(pts)
-        lens = [int(p.shape[0]) for p in pts]
-        cat = torch.cat([p.float() for p in pts]).contiguous() if B > 1 else pts[0].float().contiguous()
-        off = [0]
-        for n in lens:
-            off.append(off[-1] + n)
-        scene_off = torch.tensor(off, dtype=torch.int32, device=cat.device)
+        cat, scene_off, lens = self._concat_points(pts)
+        B = len(lens)
         vl = self.pts_voxel_layer
         coors = nv.voxelize_dynamic(cat, scene_off, B, vl.voxel_size, vl.point_cloud_range)
         feats, fcoors = self.pts_voxel_encoder(cat, coors, batch_size=B)
@@ -169,11 +185,11 @@ class Uni3DETR(nn.Module):
     def extract_pts_feat(self, pts):
         if self.dynamic_voxelization:
             coors, feats, fcoors, cat, scene_off, lens = self.voxelize_dynamic_batch(pts)
-            x = self.pts_middle_encoder(feats, fcoors, len(pts))
+            x = self.pts_middle_encoder(feats, fcoors, len(lens))
             voxel_off = scene_off          # the voxel-coordinate FPS runs over the PER-POINT coors incl. -1 rows (ref :166,:183)
         else:
             coors, feats, voxel_off, cat, scene_off, lens = self.voxelize_batch(pts)
-            x = self.pts_middle_encoder(feats, coors, len(pts))
+            x = self.pts_middle_encoder(feats, coors, len(lens))
         amp = self.amp_dtype
         with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
             if self.with_pts_backbone:
@@ -216,6 +232,9 @@ class Uni3DETR(nn.Module):
         return self.simple_test_pts(pts_feat, img_metas, rescale=rescale, fpsbpts=fpsbpts)
 
     # ------------------------------------------------------------------------------------------
+    def pack_points(self, pts):
+        return self._pack_points(pts)
+
     def _parse_losses(self, losses):
         log_vars = OrderedDict((k, v.mean() if isinstance(v, torch.Tensor) else sum(x.mean() for x in v)) for k, v in losses.items())
         loss = sum(v for k, v in log_vars.items() if "loss" in k)

@@ -139,6 +139,9 @@ class Uni3DETRHead(nn.Module):
                             b[..., 0] + b[..., 3] / 2, b[..., 1] + b[..., 4] / 2, b[..., 2] + b[..., 5] / 2), dim=-1)
 
     def _pack_gts(self, gt_bboxes_list, gt_labels_list, device):
+        if isinstance(gt_bboxes_list, dict):       # pre-packed static buffers: dict(gt [cap,7] gravity-centre, labels int32 [cap], gt_off int32 [B+1], gmax int)
+            d = gt_bboxes_list
+            return d["gt"], d["labels"], d["gt_off"], int(d["gmax"])
         gts = []
         for g in gt_bboxes_list:
             if hasattr(g, "gravity_center"):
@@ -152,11 +155,16 @@ class Uni3DETRHead(nn.Module):
         labels = torch.cat([l.to(device) for l in gt_labels_list]).int() if sum(lens) else torch.zeros((0,), dtype=torch.int32, device=device)
         return gt[:, :7].contiguous(), labels.contiguous(), torch.tensor(off, dtype=torch.int32, device=device), max(lens) if lens else 0
 
-    def loss(self, gt_bboxes_list, gt_labels_list, preds_dicts, gt_bboxes_ignore=None):
-        assert gt_bboxes_ignore is None, f"{self.__class__.__name__} only supports for gt_bboxes_ignore setting to None."
+    def pack_gts(self, gt_bboxes_list, gt_labels_list, device):
+        """Pack a batch's GTs once (static input buffers for hipGraph replay); pass the result as `gt_bboxes_3d`."""
+        gt, labels, gt_off, gmax = self._pack_gts(gt_bboxes_list, gt_labels_list, device)
+        return dict(gt=gt, labels=labels, gt_off=gt_off, gmax=gmax)
+
+    def loss_targets(self, gt_bboxes_list, gt_labels_list, preds_dicts):
+        """Stage 1 of loss(): matching + target construction for all layers/scenes (no cross-rank communication).
+        Returns a dict with the assignment, targets and the LOCAL per-layer positive counts."""
         cls_all = preds_dicts["all_cls_scores"].float()
         box_all = preds_dicts["all_bbox_preds"].float()
-        iou_all = preds_dicts["all_iou_preds"].float()
         L, B, Q, C = cls_all.shape
         dev = cls_all.device
         gt, labels, gt_off, gmax = self._pack_gts(gt_bboxes_list, gt_labels_list, dev)
@@ -170,10 +178,17 @@ class Uni3DETRHead(nn.Module):
         else:
             tgt = box_all.new_zeros((L, B, Q, 7))
             lab = torch.full_like(asg, C)
-        num_pos = reduce_mean_(w.sum(dim=(1, 2)))                                      # [L]; one message for all layers (ref: 2 per layer)
-        cls_avg = num_pos.clamp(min=1) if self.sync_cls_avg_factor else w.sum(dim=(1, 2)).clamp(min=1)
-        npos = num_pos.clamp(min=1)
+        return dict(asg=asg, w=w, tgt=tgt, lab=lab, num_pos=w.sum(dim=(1, 2)))
 
+    def loss_from_targets(self, preds_dicts, T, num_pos):
+        """Stage 2 of loss(): the 4 losses x L layers given targets and the (rank-averaged) positive counts [L]."""
+        cls_all = preds_dicts["all_cls_scores"].float()
+        box_all = preds_dicts["all_bbox_preds"].float()
+        iou_all = preds_dicts["all_iou_preds"].float()
+        L, B, Q, C = cls_all.shape
+        w, tgt, lab = T["w"], T["tgt"], T["lab"]
+        cls_avg = num_pos.clamp(min=1) if self.sync_cls_avg_factor else T["num_pos"].clamp(min=1)
+        npos = num_pos.clamp(min=1)
         ntgt = normalize_bbox(tgt, self.pc_range)
         b3d = denormalize_bbox(box_all, self.pc_range)
         iou_bev = bbox_overlaps_nearest_3d(b3d, tgt, is_aligned=True)                  # [L,B,Q]
@@ -196,8 +211,14 @@ class Uni3DETRHead(nn.Module):
         for i in range(L - 1):
             out[f"d{i}.loss_cls"], out[f"d{i}.loss_bbox"] = losses_cls[i], losses_bbox[i]
             out[f"d{i}.loss_iou"], out[f"d{i}.loss_iou_pred"] = losses_iou[i], losses_ioup[i]
-        self._last_assigned = asg
+        self._last_assigned = T["asg"]
         return out
+
+    def loss(self, gt_bboxes_list, gt_labels_list, preds_dicts, gt_bboxes_ignore=None):
+        assert gt_bboxes_ignore is None, f"{self.__class__.__name__} only supports for gt_bboxes_ignore setting to None."
+        T = self.loss_targets(gt_bboxes_list, gt_labels_list, preds_dicts)
+        num_pos = reduce_mean_(T["num_pos"].clone())           # [L]; one message for all layers (ref: 2 scalar all-reduces per layer)
+        return self.loss_from_targets(preds_dicts, T, num_pos)
 
     def soft_nms(self, boxes, scores, gaussian_sigma=0.3, prune_threshold=1e-3):
         """Gaussian soft-NMS with rotated 3-D IoU (ref :796-823); sequential by nature, host loop over the HIP IoU kernel."""

@@ -77,6 +77,9 @@ class SparseEncoderHD(nn.Module):
         if fp16_enabled:
             self.fp16_enabled = fp16_enabled       # attribute only exists when enabled (ref :63-64)
         self.compute_dtype = torch.float32          # set to torch.bfloat16 for the throughput mode
+        # static-shape mode (hipGraph capture): row capacities of the strided levels, in order; None = exact sizes (host reads)
+        self.level_capacities = None
+        self.last_level_counts = []                 # device scalars (occupied rows per level) of the latest forward
         self.cin_pad = (in_channels + 7) // 8 * 8 if in_channels % 4 else in_channels
         self.conv_input = SparseConvModule(in_channels, base_channels, 3, norm_cfg, padding=1, subm=True)
         self.encoder_layers = nn.Sequential()
@@ -105,7 +108,11 @@ class SparseEncoderHD(nn.Module):
             geom = sp.subm_geom(lvl) if conv.ksize != (1, 1, 1) else sp.ConvGeom(None, None, lvl.n, lvl.n_dev, lvl.n, lvl.n_dev)
             new = lvl
         else:
-            new, geom = sp.strided_level(lvl, conv.ksize, conv.stride, conv.padding)
+            cap = None
+            if self.level_capacities is not None:
+                cap = self.level_capacities[len(self.last_level_counts) - 1]
+            new, geom = sp.strided_level(lvl, conv.ksize, conv.stride, conv.padding, capacity=cap)
+            self.last_level_counts.append(new.n_dev)
         y = sp.sparse_conv(x, conv.weight, geom)
         return sp.bn_rows(y, bn, new.n_dev, None, True), new
 
@@ -119,6 +126,7 @@ class SparseEncoderHD(nn.Module):
         coors = coors.int().contiguous()
         batch_size = int(batch_size)
         lvl, rank = sp.level_from_coors(coors, batch_size, self.sparse_shape)
+        self.last_level_counts = [lvl.n_dev]
         x = voxel_features.float()
         w_in = self.conv_input[0].weight
         if x.shape[1] % 4:      # e.g. nuScenes' 5 point features: zero-pad channels (and weight rows) to the kernel's granule

@@ -54,14 +54,16 @@ def subm_geom(lvl):
     return ConvGeom(fwd, bwd, lvl.n, lvl.n_dev, lvl.n, lvl.n_dev)
 
 
-def strided_level(lvl, ksize, stride, pad):
-    """Active output set + tables of a SparseConv3d (ref: sparse_encoder_hd.py:181-192).  One host read of the new
-    row count (the reference's own flow syncs at models/detectors/uni3detr.py:153)."""
+def strided_level(lvl, ksize, stride, pad, capacity=None):
+    """Active output set + tables of a SparseConv3d (ref: sparse_encoder_hd.py:181-192).
+    capacity=None: exact row count, one host read (the reference's own flow syncs at models/detectors/uni3detr.py:153).
+    capacity=int : static-shape mode for hipGraph capture — tensors are sized by the capacity, every kernel is bounded by the
+    device-side count, no host read (overflow is checked by the caller after the step: Level.count_dev vs capacity)."""
     dims_out = tuple((d + 2 * p - k) // s + 1 for d, k, s, p in zip(lvl.dims, ksize, stride, pad))
     g = nv.BitGrid(lvl.batch, dims_out, lvl.coords.device)
     g.mark_strided(lvl.coords, lvl.n_dev, ksize, stride, pad)
     g.scan()
-    n_out = int(g.count_dev.item())
+    n_out = int(g.count_dev.item()) if capacity is None else int(capacity)
     out = Level(g, g.coords(n_out), n_out, g.count_dev)
     fwd = lvl.grid.nbr_table(out.coords, out.n_dev, ksize, stride, pad, 0)
     bwd = g.nbr_table(lvl.coords, lvl.n_dev, ksize, stride, pad, 1)

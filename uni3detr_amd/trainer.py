@@ -1,0 +1,167 @@
+"""Training step driver: eager (DDP) or hipGraph-captured.
+
+Graph mode captures the step as three HIP graphs on static buffers — the MI355X answer to the ~3500 short launches a
+step consists of (host enqueue time ≈ GPU time in eager mode):
+    G1  voxelize -> sparse encoder -> dense stack -> FPS -> decoder/head -> match cost + Hungarian -> targets
+        [eager] all-reduce of the per-layer positive counts (3 floats; skipped for world size 1)
+    G2  losses + backward into ONE flat gradient buffer
+        [eager] all-reduce of the flat gradient buffer over RCCL/xGMI (world size > 1)
+    G3  gradient clipping + fused AdamW
+The sparse levels run in static-shape mode (capacity-sized tensors, device-side row counts; uni3detr_amd/sparse.py), so the
+captured launches are valid for any batch whose level sizes fit the capacities; `check_capacities()` verifies that.
+"""
+import torch
+import torch.distributed as dist
+
+
+class TrainStep:
+    def __init__(self, model, points, gt_bboxes_3d, gt_labels_3d, lr=2e-5, weight_decay=1e-4, max_norm=10.0, graph=True,
+                 capacity_margin=1.25):
+        self.model = model
+        self.dev = next(model.parameters()).device
+        self.dist_on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.dist_on else 1
+        self.max_norm = max_norm
+        self.graph = graph
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        # one flat gradient buffer; every .grad is a view of it (static addresses for capture, one all-reduce message)
+        n = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=self.dev)
+        o = 0
+        for p in self.params:
+            p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+            o += p.numel()
+        self.opt = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay, fused=True, capturable=graph)
+        self.pts = model.pack_points(points) if not isinstance(points, dict) else points
+        self.gts = model.pts_bbox_head.pack_gts(gt_bboxes_3d, gt_labels_3d, self.dev) if not isinstance(gt_bboxes_3d, dict) else gt_bboxes_3d
+        self.labels = gt_labels_3d
+        self.capacity_margin = capacity_margin
+        self._graphs = None
+        self.loss = None
+
+    # ---- the three stages (same code eager or captured) -------------------------------------------------------
+    def _stage1(self):
+        m = self.model
+        feat, fps = m.extract_pts_feat(self.pts)
+        amp = m.amp_dtype
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            self._outs = m.pts_bbox_head(feat, None, fps)
+        self._T = m.pts_bbox_head.loss_targets(self.gts, None, self._outs)
+        self._num_pos = self._T["num_pos"].clone()
+
+    def _reduce_num_pos(self):
+        if self.dist_on:
+            self._num_pos.div_(self.world)
+            dist.all_reduce(self._num_pos)
+
+    def _stage2(self):
+        self.flat_grad.zero_()
+        losses = self.model.pts_bbox_head.loss_from_targets(self._outs, self._T, self._num_pos)
+        self._losses = losses
+        loss = sum(v for k, v in losses.items() if "loss" in k)
+        loss.backward()
+        self.loss = loss.detach()
+
+    def _reduce_grads(self):
+        if self.dist_on:
+            self.flat_grad.div_(self.world)
+            dist.all_reduce(self.flat_grad)
+
+    def _stage3(self):
+        torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, foreach=True)
+        self.opt.step()
+
+    def eager_step(self):
+        self._stage1(); self._reduce_num_pos(); self._stage2(); self._reduce_grads(); self._stage3()
+        return self.loss
+
+    def enable_dist(self):
+        """Call AFTER dist.init_process_group.  hipGraph capture and an RCCL process group do not mix on this stack (the
+        process-group watchdog polls events while a capture is open -> hipErrorCapturedEvent), so bench.py captures first
+        and creates the process group afterwards; the warm-up/capture iterations have touched weights and optimizer state
+        with UNREDUCED gradients, so here every rank is reset to rank 0's model and a fresh optimizer state (in place: the
+        captured graphs hold these addresses)."""
+        self.dist_on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.dist_on else 1
+        if not self.dist_on:
+            return
+        with torch.no_grad():
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                dist.broadcast(t.data, 0)
+            for st in self.opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        torch.cuda.synchronize()
+
+    def snapshot(self):
+        return [t.detach().clone() for t in list(self.model.parameters()) + list(self.model.buffers())]
+
+    def restore(self, snap):
+        with torch.no_grad():
+            for t, s_ in zip(list(self.model.parameters()) + list(self.model.buffers()), snap):
+                t.copy_(s_)
+            for st in self.opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+
+    # ---- capture ------------------------------------------------------------------------------------------------
+    def measure_capacities(self):
+        """Run one exact-size eager step and size the strided sparse levels from it (x margin, multiple of 256)."""
+        m = self.model
+        m.static_shapes = False
+        m.pts_middle_encoder.level_capacities = None
+        self.eager_step()
+        counts = [int(c.item()) for c in m.pts_middle_encoder.last_level_counts]
+        caps = [((int(c * self.capacity_margin) + 255) // 256) * 256 for c in counts[1:]]
+        m.pts_middle_encoder.level_capacities = caps
+        m.static_shapes = True
+        return counts, caps
+
+    def check_capacities(self):
+        enc = self.model.pts_middle_encoder
+        counts = [int(c.item()) for c in enc.last_level_counts]
+        for c, cap in zip(counts[1:], enc.level_capacities):
+            if c > cap:
+                raise RuntimeError(f"sparse level overflow: {c} active rows > capacity {cap}; re-capture with a larger margin")
+        return counts
+
+    def capture(self, warmup=3):
+        assert self.graph
+        counts, caps = self.measure_capacities()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):                      # static-shape eager warm-up on the capture stream
+                self.eager_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        # drop the eager iteration's activations / autograd graph BEFORE capturing: releasing them from inside a capture
+        # (when the attributes are re-assigned) tears down autograd nodes mid-capture and crashes hipStreamEndCapture
+        self._outs = self._T = self._num_pos = self._losses = self.loss = None
+        torch.cuda.synchronize()
+        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(g1, pool=pool, stream=s, capture_error_mode="thread_local"):
+            self._stage1()
+        self._reduce_num_pos()
+        with torch.cuda.graph(g2, pool=pool, stream=s, capture_error_mode="thread_local"):
+            self._stage2()
+        self._reduce_grads()
+        with torch.cuda.graph(g3, pool=pool, stream=s, capture_error_mode="thread_local"):
+            self._stage3()
+        torch.cuda.synchronize()
+        self._graphs = (g1, g2, g3)
+        return counts, caps
+
+    def step(self):
+        if self._graphs is None:
+            return self.eager_step()
+        g1, g2, g3 = self._graphs
+        g1.replay()
+        self._reduce_num_pos()
+        g2.replay()
+        self._reduce_grads()
+        g3.replay()
+        return self.loss
