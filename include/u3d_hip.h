@@ -47,6 +47,9 @@ typedef struct u3d_bitgrid {
   int32_t batch, dz, dy, dx;
   int32_t layout;   /* 0: 4x4x4-block words (rank = block-major order, used by the conv levels);
                        1: linear, one bit per cell in (b,z,y,x) order (rank = lexicographic = torch.unique(dim=0) order) */
+  int32_t row_capacity; /* > 0: static-shape mode — rows are stored in buffers of this many rows; lookups (rank, neighbour
+                           tables) return -1 for any row id >= row_capacity, so an overflowing level degrades to dropped
+                           voxels instead of out-of-bounds gathers; 0: unlimited */
 } u3d_bitgrid;
 
 int64_t u3d_bitgrid_nwords(int32_t batch, int32_t dz, int32_t dy, int32_t dx);

@@ -32,6 +32,7 @@ struct BitGridDev {
   int B, Dz, Dy, Dx;           // logical extent (cells)
   int bz, by, bx;              // extent in 4x4x4 blocks
   int linear;                  // 1: one bit per cell in lexicographic (b,z,y,x) order (rank == torch.unique(dim=0) order)
+  int cap;                     // > 0: row capacity of the level; lookups never return a row id >= cap (static-shape overflow guard)
 };
 
 __host__ __device__ inline BitGridDev u3d_make_grid(const u3d_bitgrid* g) {
@@ -41,6 +42,7 @@ __host__ __device__ inline BitGridDev u3d_make_grid(const u3d_bitgrid* g) {
   d.B = g->batch; d.Dz = g->dz; d.Dy = g->dy; d.Dx = g->dx;
   d.bz = (g->dz + 3) >> 2; d.by = (g->dy + 3) >> 2; d.bx = (g->dx + 3) >> 2;
   d.linear = g->layout;
+  d.cap = g->row_capacity;
   return d;
 }
 
@@ -62,7 +64,8 @@ __device__ __forceinline__ int u3d_grid_lookup(const BitGridDev& g, int b, int z
   unsigned long long bits = g.words[w];
   int bit = u3d_bit_index(g, b, z, y, x);
   if (!((bits >> bit) & 1ull)) return -1;
-  return (int)(g.prefix[w] + __popcll(bits & ((1ull << bit) - 1ull)));
+  int r = (int)(g.prefix[w] + __popcll(bits & ((1ull << bit) - 1ull)));
+  return (g.cap > 0 && r >= g.cap) ? -1 : r;
 }
 
 // wave-level helpers (wave = 64 lanes)

@@ -20,7 +20,7 @@ class U3DError(RuntimeError):
 
 class BitGridStruct(C.Structure):
     _fields_ = [("words", C.c_void_p), ("prefix", C.c_void_p), ("batch", C.c_int32), ("dz", C.c_int32),
-                ("dy", C.c_int32), ("dx", C.c_int32), ("layout", C.c_int32)]
+                ("dy", C.c_int32), ("dx", C.c_int32), ("layout", C.c_int32), ("row_capacity", C.c_int32)]
 
 
 _lib = None
@@ -133,7 +133,10 @@ class BitGrid:
         self.words = torch.zeros(self.nwords, dtype=torch.int64, device=device)
         self.prefix = torch.empty(self.nwords + 1, dtype=torch.int32, device=device)
         self._scratch = torch.empty(int(lib().u3d_bitgrid_scan_scratch(self.nwords)), dtype=torch.int32, device=device)
-        self.c = BitGridStruct(self.words.data_ptr(), self.prefix.data_ptr(), self.batch, *self.dims, 1 if linear else 0)
+        self.c = BitGridStruct(self.words.data_ptr(), self.prefix.data_ptr(), self.batch, *self.dims, 1 if linear else 0, 0)
+
+    def set_row_capacity(self, cap):
+        self.c.row_capacity = int(cap)
 
     def mark(self, coors):
         _check(lib().u3d_bitgrid_mark(C.byref(self.c), _ptr(coors), coors.shape[0], _stream()), "bitgrid_mark")

@@ -44,6 +44,7 @@ def level_from_coors(coors, batch, dims):
     g.mark(coors)
     g.scan()
     n = coors.shape[0]
+    g.set_row_capacity(n)          # unique coors => count <= n always; guards static-shape buffers all the same
     rank = g.rank(coors)
     lvl = Level(g, g.coords(n), n, g.count_dev)
     return lvl, rank
@@ -64,6 +65,8 @@ def strided_level(lvl, ksize, stride, pad, capacity=None):
     g.mark_strided(lvl.coords, lvl.n_dev, ksize, stride, pad)
     g.scan()
     n_out = int(g.count_dev.item()) if capacity is None else int(capacity)
+    if capacity is not None:
+        g.set_row_capacity(n_out)
     out = Level(g, g.coords(n_out), n_out, g.count_dev)
     fwd = lvl.grid.nbr_table(out.coords, out.n_dev, ksize, stride, pad, 0)
     bwd = g.nbr_table(lvl.coords, lvl.n_dev, ksize, stride, pad, 1)
