@@ -159,8 +159,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
 #pragma unroll
         for (int a = 0; a < WM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr, acc[a][b], 0, 0, 0);
       }
+      // the next stage's tile goes to the OTHER buffer (free since the previous barrier): write it between the two k-steps so
+      // the ds_write stream issues underneath the second k-step's MFMAs instead of in front of the barrier
+      if (ks == 0 && st + 1 < nstage) store_lds(buf ^ 1);
     }
-    if (st + 1 < nstage) store_lds(buf ^ 1);
     __syncthreads();
   }
   // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + r
@@ -204,6 +206,8 @@ extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32
 #define IG_CASE(A, B, C, D)                                                                                                  \
   return transpose_w ? launch_igemm_fwd<A, B, C, D, false>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s)   \
                      : launch_igemm_fwd<A, B, C, D, true>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
+  // (a 128x128-tile variant for layers with few rows was measured SLOWER: 285 vs 512 TF/s at N=48000 — the L2->CU traffic of
+  //  the smaller tile outweighs the better CU fill; not dispatched)
   if (cout >= 256 && cout % 256 == 0) { IG_CASE(2, 4, 8, 4) }       // 256 x 256
   if (cout >= 128 && cout % 128 == 0) { IG_CASE(4, 2, 4, 4) }       // 256 x 128
   if (cout % 64 == 0) { IG_CASE(4, 1, 4, 4) }                        // 256 x 64
@@ -294,8 +298,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_wgrad(const u16
 #pragma unroll
           for (int b = 0; b < WN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[b], acc[a][b], 0, 0, 0);
         }
+        if (ks == 0 && t + 1 < t_end) store_lds(buf ^ 1);     // under the second k-step's MFMAs (see k_igemm_fwd)
       }
-      if (t + 1 < t_end) store_lds(buf ^ 1);
       __syncthreads();
     }
   }

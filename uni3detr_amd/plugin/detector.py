@@ -97,6 +97,7 @@ class Uni3DETR(nn.Module):
         # (DESIGN.md "FPS view"); set False to sample on true xyz instead.
         self.fps_packed_view = True
         self.amp_dtype = None           # torch.bfloat16 -> throughput mode (sparse encoder bf16 MFMA, dense + decoder autocast)
+        self._fps_stream = None
         self.static_shapes = False      # True: capacity-sized tensors + device-side counts, no host reads (hipGraph capturable)
 
     with_pts_backbone = property(lambda self: self.pts_backbone is not None)
@@ -189,6 +190,16 @@ class Uni3DETR(nn.Module):
             voxel_off = scene_off          # the voxel-coordinate FPS runs over the PER-POINT coors incl. -1 rows (ref :166,:183)
         else:
             coors, feats, voxel_off, cat, scene_off, lens = self.voxelize_batch(pts)
+        # the 300 serial FPS rounds (~1 ms on 2B CUs) only need points + voxel coords: run them on a side stream underneath the
+        # encoder / dense stack (fork-join, also valid inside a hipGraph capture)
+        cur = torch.cuda.current_stream()
+        if self._fps_stream is None:
+            self._fps_stream = torch.cuda.Stream()
+        side = self._fps_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            fpsbpts = self.fps_queries(cat, scene_off, lens, coors, voxel_off)
+        if not self.dynamic_voxelization:
             x = self.pts_middle_encoder(feats, coors, len(lens))
         amp = self.amp_dtype
         with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
@@ -196,7 +207,9 @@ class Uni3DETR(nn.Module):
                 x = self.pts_backbone(x)
             if self.with_pts_neck:
                 x = self.pts_neck(x)
-        fpsbpts = self.fps_queries(cat, scene_off, lens, coors, voxel_off)
+        cur.wait_stream(side)
+        for t in (cat, coors, voxel_off, scene_off):
+            t.record_stream(side)
         return x, fpsbpts
 
     def forward_pts_train(self, pts_feats, gt_bboxes_3d, gt_labels_3d, img_metas, gt_bboxes_ignore=None, fpsbpts=None):
