@@ -329,12 +329,16 @@ struct WgPlan { int tile; int ci_blocks, co_blocks, nsplit; };
 static WgPlan wgrad_plan(int n_out_cap, int cin, int cout, int kvol) {
   WgPlan p;
   int mn = cin < cout ? cin : cout;
-  p.tile = (mn >= 256 && cin % 256 == 0 && cout % 256 == 0) ? 256 : ((mn >= 128 && cin % 128 == 0 && cout % 128 == 0) ? 128 : 64);
+  if (mn >= 256 && cin % 256 == 0 && cout % 256 == 0) p.tile = 256;
+  else if (mn >= 128 && cin % 128 == 0 && cout % 128 == 0) p.tile = 128;
+  else if (cin % 64 == 0 && cout % 64 == 0) p.tile = 64;
+  else if (cin % 32 == 0 && cout % 32 == 0) p.tile = 32;       // sparse levels with 32 channels: load/latency bound
+  else p.tile = 16;
   p.ci_blocks = u3d_cdiv(cin, p.tile);
   p.co_blocks = u3d_cdiv(cout, p.tile);
   int ntiles = u3d_cdiv(n_out_cap > 0 ? n_out_cap : 1, 64);
   int wgs_per_split = kvol * p.ci_blocks * p.co_blocks;
-  int target = (p.tile == 256 ? 256 : 512) / wgs_per_split;
+  int target = (p.tile == 256 ? 256 : (p.tile >= 64 ? 512 : 2048)) / wgs_per_split;
   if (target < 1) target = 1;
   int ns = ntiles < target ? ntiles : target;
   // keep at least 8 stages per split so the prologue is amortised
@@ -366,14 +370,16 @@ extern "C" int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const 
                                         const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
                                         void* workspace, int64_t workspace_bytes, u3d_stream s) {
   U3D_REQUIRE(in && dout && dw && n_out_dev && workspace && (nbr || kvol == 1), U3D_ERR_ARG);
-  if (cin % 64 != 0 || cout % 64 != 0) return U3D_ERR_UNSUPPORTED;
+  if (cin % 16 != 0 || cout % 16 != 0) return U3D_ERR_UNSUPPORTED;
   WgPlan p = wgrad_plan(n_out_cap, cin, cout, kvol);
   long long n = (long long)kvol * cin * cout;
   U3D_REQUIRE(workspace_bytes >= (int64_t)p.nsplit * n * 4, U3D_ERR_WORKSPACE);
   int rc;
   if (p.tile == 256) rc = launch_igemm_wgrad<2, 4, 8, 4>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
   else if (p.tile == 128) rc = launch_igemm_wgrad<2, 2, 4, 4>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
-  else rc = launch_igemm_wgrad<2, 2, 2, 2>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
+  else if (p.tile == 64) rc = launch_igemm_wgrad<2, 2, 2, 2>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
+  else if (p.tile == 32) rc = launch_igemm_wgrad<2, 2, 1, 1>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
+  else rc = launch_igemm_wgrad<1, 1, 1, 1>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
   if (rc != U3D_OK) return rc;
   hipLaunchKernelGGL(k_igemm_wgrad_reduce, dim3(u3d_cdiv(n / 4, 256)), dim3(256), 0, s, (const float*)workspace, dw, n, p.nsplit);
   U3D_CHECK_LAUNCH();
