@@ -41,8 +41,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const u16* tile, int stride, int k0, i
 __device__ __forceinline__ bf16x8 direct_frag(const u16* tile, int stride, int r0, int k0, int lane) {
   const int g = lane >> 4, i = lane & 15;
   const u16* p = tile + (r0 + i) * stride + k0 + 4 * g;
-  s16x4 a = *(const s16x4*)p;
-  s16x4 b = *(const s16x4*)(p + 16);
+  // two SEPARATE ds_read_b64 (volatile keeps hipcc from fusing them into ds_read2_b64, whose 16-lane groups / mod-32 banking
+  // put rows r and r+8 of the 36-dword-stride tile on the same banks: PMC showed SQ_LDS_BANK_CONFLICT = 36 % of LDS cycles)
+  typedef const volatile s16x4 __attribute__((address_space(3))) * lds_vptr;
+  s16x4 a = *(lds_vptr)(p);
+  s16x4 b = *(lds_vptr)(p + 16);
   s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
