@@ -100,14 +100,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
   for (int u = 0; u < A_SEGS; ++u) { int sgi = tid + u * NT; a_row[u] = sgi / (BK / 8); a_part[u] = sgi % (BK / 8); }
 
   uint4 ra[A_SEGS], rw[W_SEGS];
-  int idx_cur[A_SEGS];
+  int idx_cur[A_SEGS], idx_nxt[A_SEGS];
 
-  auto load_idx = [&](int kap) {
+  // the neighbour indices of offset kappa+1 are fetched while offset kappa is being computed: the idx -> row gather chain
+  // (two dependent L2 round trips) must never sit in front of a stage, or layers with one stage per offset (Cin = 64) stall
+  auto load_idx_next = [&](int kap) {
 #pragma unroll
     for (int u = 0; u < A_SEGS; ++u) {
       int m = m0 + a_row[u];
-      idx_cur[u] = (m < n_out) ? (nbr ? nbr[(long long)kap * ld + m] : m) : -1;
+      idx_nxt[u] = (m < n_out && kap < kvol) ? (nbr ? nbr[(long long)kap * ld + m] : m) : -1;
     }
+  };
+  auto advance_idx = [&]() {
+#pragma unroll
+    for (int u = 0; u < A_SEGS; ++u) idx_cur[u] = idx_nxt[u];
   };
   auto issue_loads = [&](int st) {
     const int kap = st / kchunks, c0 = (st % kchunks) * BK;
@@ -144,14 +150,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
     }
   };
 
-  load_idx(0);
+  load_idx_next(0);
+  advance_idx();
+  load_idx_next(1);
   issue_loads(0);
   store_lds(0);
   __syncthreads();
   for (int st = 0; st < nstage; ++st) {
     const int buf = st & 1;
     if (st + 1 < nstage) {
-      if ((st + 1) % kchunks == 0) load_idx((st + 1) / kchunks);
+      if ((st + 1) % kchunks == 0) {                    // next stage starts a new offset: its indices arrived a whole offset ago
+        advance_idx();
+        load_idx_next((st + 1) / kchunks + 1);
+      }
       issue_loads(st + 1);                              // global loads in flight while this stage computes
     }
     const u16* A = smem + buf * STAGE_ELEMS;
@@ -260,14 +271,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_wgrad(const u16
   const int t_begin = split * per, t_end = min(ntiles, t_begin + per);
 
   uint4 ra[A_SEGS], rd[D_SEGS];
-  auto issue_loads = [&](int t) {
+  int src_cur[A_SEGS], src_nxt[A_SEGS];
+  auto load_src_next = [&](int t) {                     // gather indices of stage t, fetched one stage early
     const int r0 = t * RK;
 #pragma unroll
     for (int u = 0; u < A_SEGS; ++u) {
+      int m = r0 + (tid + u * NT) / (TM / 8);
+      src_nxt[u] = (t < t_end && m < n_out) ? (nbr ? nbr[(long long)kap * ld + m] : m) : -1;
+    }
+  };
+  auto issue_loads = [&](int t) {
+    const int r0 = t * RK;
+#pragma unroll
+    for (int u = 0; u < A_SEGS; ++u) src_cur[u] = src_nxt[u];
+    load_src_next(t + 1);
+#pragma unroll
+    for (int u = 0; u < A_SEGS; ++u) {
       int sgi = tid + u * NT;
-      int row = sgi / (TM / 8), part = sgi % (TM / 8);
-      int m = r0 + row;
-      int src = (m < n_out) ? (nbr ? nbr[(long long)kap * ld + m] : m) : -1;
+      int part = sgi % (TM / 8);
+      int src = src_cur[u];
       int c = ci0 + part * 8;
       ra[u] = (src >= 0 && c < cin) ? *(const uint4*)(in + (long long)src * cin + c) : make_uint4(0, 0, 0, 0);
     }
@@ -288,6 +310,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_wgrad(const u16
   };
 
   if (t_begin < t_end) {
+    load_src_next(t_begin);
     issue_loads(t_begin);
     store_lds(0);
     __syncthreads();
