@@ -230,7 +230,7 @@ extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32
   //  the smaller tile outweighs the better CU fill; not dispatched)
   if (cout >= 256 && cout % 256 == 0) { IG_CASE(2, 4, 8, 4) }       // 256 x 256
   if (cout >= 128 && cout % 128 == 0) { IG_CASE(4, 2, 4, 4) }       // 256 x 128
-  if (cout % 64 == 0) { IG_CASE(4, 1, 4, 4) }                        // 256 x 64
+  if (cout % 64 == 0) { IG_CASE(4, 1, 2, 4) }                        // 128 x 64: 57 KB LDS -> 2 workgroups per CU hide the gather latency
 #undef IG_CASE
   return U3D_ERR_UNSUPPORTED;
 }
