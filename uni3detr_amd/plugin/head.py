@@ -198,6 +198,26 @@ class Uni3DETRHead(nn.Module):
         quality = (iou_bev + iou_z) / 2                                                # not detached
         bw = w.unsqueeze(-1) * self.code_weights
         iou_true = bbox_overlaps_3d_aligned(b3d, tgt).view(L, B, Q)
+        from .losses import IoU3DLoss, L1Loss, SoftFocalLoss, _EPS32
+        if (type(self.loss_cls) is SoftFocalLoss and type(self.loss_bbox) is L1Loss and type(self.loss_iou) is IoU3DLoss
+                and self.loss_cls.reduction == self.loss_bbox.reduction == self.loss_iou.reduction == "mean"):
+            # all layers at once: the same arithmetic as the per-layer module calls below (weights of 1 on every label row,
+            # `mean` reduction with avg_factor), written on [L,B,Q,*] tensors — a third of the launches
+            a, gmm = self.loss_cls.alpha, self.loss_cls.gamma
+            ps = cls_all.sigmoid()
+            soft = F.one_hot(lab, C + 1)[..., :C].to(cls_all.dtype) * quality.unsqueeze(-1)
+            fw = ((1 - a) + (2 * a - 1) * soft) * (soft - ps).pow(gmm)
+            l_cls = (F.binary_cross_entropy_with_logits(cls_all, soft, reduction="none") * fw).sum(dim=(1, 2, 3)) / (cls_avg + _EPS32) * self.loss_cls.loss_weight
+            l_box = ((box_all[..., :10] - ntgt[..., :10]).abs() * bw[..., :10]).sum(dim=(1, 2, 3)) / (npos + _EPS32) * self.loss_bbox.loss_weight
+            l_iou = ((1 - iou_bev) * bw[..., :10].mean(-1)).sum(dim=(1, 2)) / (npos + _EPS32) * self.loss_iou.loss_weight
+            l_iou = l_iou + ((1 - iou_z) * bw[..., 0]).sum(dim=(1, 2)) / npos
+            l_ioup = (F.binary_cross_entropy_with_logits(iou_all.squeeze(-1), iou_true, reduction="none") * bw[..., 0]).sum(dim=(1, 2)) / npos * 1.2
+            out = {"loss_cls": l_cls[-1], "loss_bbox": l_box[-1], "loss_iou": l_iou[-1], "loss_iou_pred": l_ioup[-1]}
+            for i in range(L - 1):
+                out[f"d{i}.loss_cls"], out[f"d{i}.loss_bbox"] = l_cls[i], l_box[i]
+                out[f"d{i}.loss_iou"], out[f"d{i}.loss_iou_pred"] = l_iou[i], l_ioup[i]
+            self._last_assigned = T["asg"]
+            return out
         losses_cls, losses_bbox, losses_iou, losses_ioup = [], [], [], []
         for l in range(L):
             lc = self.loss_cls(cls_all[l].reshape(-1, C), [lab[l].reshape(-1), quality[l].reshape(-1)], w.new_ones(B * Q), avg_factor=cls_avg[l])
