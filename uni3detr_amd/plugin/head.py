@@ -120,14 +120,18 @@ class Uni3DETRHead(nn.Module):
         for lvl in range(hs.shape[0]):
             reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
             h = hs[lvl]
-            tmp = self.reg_branches[lvl](h).float()
+            reg = getattr(self.transformer.decoder, "_reg_outputs", None)
+            if self.with_box_refine and reg is not None and len(reg) == hs.shape[0]:
+                tmp = reg[lvl].float()         # the decoder already ran reg_branches[lvl] on this very state to refine its points
+            else:
+                tmp = self.reg_branches[lvl](h).float()
             assert reference.shape[-1] == 3
-            xy = (tmp[..., 0:2] + reference[..., 0:2]).sigmoid()
-            z = (tmp[..., 4:5] + reference[..., 2:3]).sigmoid()
-            x_ = xy[..., 0:1] * (pr[3] - pr[0]) + pr[0]
-            y_ = xy[..., 1:2] * (pr[4] - pr[1]) + pr[1]
-            z_ = z * (pr[5] - pr[2]) + pr[2]
-            coords.append(torch.cat([x_, y_, tmp[..., 2:4], z_, tmp[..., 5:]], -1))
+            t = tmp.unbind(-1)
+            rf = reference.unbind(-1)
+            x_ = (t[0] + rf[0]).sigmoid() * (pr[3] - pr[0]) + pr[0]
+            y_ = (t[1] + rf[1]).sigmoid() * (pr[4] - pr[1]) + pr[1]
+            z_ = (t[4] + rf[2]).sigmoid() * (pr[5] - pr[2]) + pr[2]
+            coords.append(torch.stack([x_, y_, t[2], t[3], z_, *t[5:]], -1))
             classes.append(self.cls_branches[lvl](h).float())
             ious.append(self.iou_branches[lvl](h).float())
         return {"all_cls_scores": torch.stack(classes), "all_bbox_preds": torch.stack(coords), "all_iou_preds": torch.stack(ious)}
@@ -192,9 +196,9 @@ class Uni3DETRHead(nn.Module):
         ntgt = normalize_bbox(tgt, self.pc_range)
         b3d = denormalize_bbox(box_all, self.pc_range)
         iou_bev = bbox_overlaps_nearest_3d(b3d, tgt, is_aligned=True)                  # [L,B,Q]
-        pz, tz = self._bbox_to_loss(b3d), self._bbox_to_loss(tgt)
-        z1, z2, z3, z4 = pz[..., 2], pz[..., 5], tz[..., 2], tz[..., 5]
-        iou_z = torch.max(torch.min(z2, z4) - torch.max(z1, z3), torch.zeros_like(z1)) / (torch.max(z2, z4) - torch.min(z1, z3))
+        pc, tc = b3d.unbind(-1), tgt.unbind(-1)                                        # z extents as _bbox_to_loss builds them (:671-674)
+        z1, z2, z3, z4 = pc[2] - pc[5] / 2, pc[2] + pc[5] / 2, tc[2] - tc[5] / 2, tc[2] + tc[5] / 2
+        iou_z = (torch.min(z2, z4) - torch.max(z1, z3)).clamp(min=0) / (torch.max(z2, z4) - torch.min(z1, z3))
         quality = (iou_bev + iou_z) / 2                                                # not detached
         bw = w.unsqueeze(-1) * self.code_weights
         iou_true = bbox_overlaps_3d_aligned(b3d, tgt).view(L, B, Q)

@@ -232,15 +232,17 @@ class Uni3DETRTransformerDecoder(nn.Module):
         """query [B,N,C], ref_logits [B,N,3] -> (states [L,B,N,C], refs [L,B,N,3] logits after each layer's refinement)."""
         out = query
         states, refs = [], []
+        self._reg_outputs = [] if reg_branches is not None else None     # reused by Uni3DETRHead.forward (same module, same input)
         for lid, layer in enumerate(self.layers):
             raw = self.ref_point_head(get_sine_pos_embed(ref_logits.sigmoid()).to(out.dtype))
             pos = raw if lid == 0 else self.query_scale(out) * raw
             out = layer.forward_bf(out, pos, value, ref_logits, group)
             if reg_branches is not None:
                 tmp = reg_branches[lid](out)
+                self._reg_outputs.append(tmp)
                 assert ref_logits.shape[-1] == 3
-                new_ref = torch.cat([tmp[..., :2] + ref_logits[..., :2], tmp[..., 4:5] + ref_logits[..., 2:3]], -1)
-                ref_logits = new_ref.detach()
+                td = tmp.detach()
+                ref_logits = torch.stack((td[..., 0] + ref_logits[..., 0], td[..., 1] + ref_logits[..., 1], td[..., 4] + ref_logits[..., 2]), -1).detach()
             states.append(out)
             refs.append(ref_logits)
         if self.return_intermediate:

@@ -140,6 +140,11 @@ class TrainStep:
         # drop the eager iteration's activations / autograd graph BEFORE capturing: releasing them from inside a capture
         # (when the attributes are re-assigned) tears down autograd nodes mid-capture and crashes hipStreamEndCapture
         self._outs = self._T = self._num_pos = self._losses = self.loss = None
+        dec = getattr(getattr(self.model.pts_bbox_head, "transformer", None), "decoder", None)
+        if dec is not None:
+            dec._reg_outputs = None
+        import gc
+        gc.collect()
         torch.cuda.synchronize()
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         pool = torch.cuda.graph_pool_handle()
