@@ -60,7 +60,7 @@ template <int WAVES_M, int WAVES_N, int WM, int WN, bool W_KMAJOR>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* __restrict__ in, const u16* __restrict__ w,
                                                                       const int* __restrict__ nbr, int ld, u16* __restrict__ out,
                                                                       const int* __restrict__ n_out_dev, int n_out_cap, int cin,
-                                                                      int cout, int kvol) {
+                                                                      int cout, int kvol, const float* __restrict__ bias, int relu) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, BK = 64;
   constexpr int LDA = BK + 8;                           // A tile [BM][BK] (k contiguous): 36-dword stride -> conflict-free b64 reads
@@ -196,14 +196,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
 #pragma unroll
       for (int b = 0; b < WN; ++b) {
         int col = col0 + (wn * WN + b) * 16 + li;
-        if (col < cout) out[(long long)m * cout + col] = f2bf(acc[a][b][r]);
+        if (col < cout) {
+          float v = acc[a][b][r];
+          if (bias) v += bias[col];
+          if (relu) v = fmaxf(v, 0.f);
+          out[(long long)m * cout + col] = f2bf(v);
+        }
       }
     }
 }
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, bool WK>
 static int launch_igemm_fwd(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev,
-                            int n_out_cap, int cin, int cout, int kvol, hipStream_t s) {
+                            int n_out_cap, int cin, int cout, int kvol, hipStream_t s, const float* bias = nullptr, int relu = 0) {
   constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, BK = 64;
   constexpr int LDA = BK + 8, LDW = WK ? BN + 16 : BK + 8;
   constexpr size_t lds = 2 * (size_t)(BM * LDA + (WK ? BK * LDW : BN * LDW)) * 2;
@@ -212,8 +217,20 @@ static int launch_igemm_fwd(const void* in, const void* w, const int32_t* nbr, i
   if (!attr_set && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev,
-                     n_out_cap, cin, cout, kvol);
+                     n_out_cap, cin, cout, kvol, bias, relu);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
+}
+
+// Dense layer on rows: out[M,N] = act(x[M,K] @ W[N,K]^T + bias) — nn.Linear layout, bf16 in/out, f32 accumulate/bias.
+// Small M (decoder: B*900 rows): 128x64 tiles so that a few hundred workgroups exist.
+extern "C" int32_t u3d_linear_bf16(const void* x, const void* w, const float* bias, int32_t relu, void* out,
+                                   const int32_t* m_dev, int32_t m_cap, int32_t k, int32_t n, u3d_stream s) {
+  U3D_REQUIRE(x && w && out && m_dev, U3D_ERR_ARG);
+  if (k % 64 != 0 || n % 64 != 0) return U3D_ERR_UNSUPPORTED;
+  if (m_cap <= 0) return U3D_OK;
+  if (m_cap >= 65536 && n % 256 == 0) return launch_igemm_fwd<2, 4, 8, 4, false>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
+  if (m_cap >= 32768 && n % 128 == 0) return launch_igemm_fwd<4, 2, 4, 4, false>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
+  return launch_igemm_fwd<4, 1, 2, 4, false>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
 }
 
 // returns U3D_ERR_UNSUPPORTED when the shape is better served by the first-generation kernel

@@ -53,6 +53,7 @@ _SIGS = {
     "u3d_spconv_wgrad_workspace": (_L, [_I, _I, _I, _I]),
     "u3d_spconv_wgrad": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "u3d_igemm_fwd_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "u3d_linear_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "u3d_igemm_wgrad_bf16_workspace": (_L, [_I, _I, _I, _I]),
     "u3d_igemm_wgrad_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
     "u3d_bn_stats_workspace": (_L, [_I, _I]),
@@ -470,3 +471,28 @@ def nms3d_classwise(boxes, scores, labels, thr):
     _check(lib().u3d_nms3d(_ptr(b), _ptr(l), n, float(thr), _ptr(keep), _ptr(ws), wsb, _stream()), "nms3d")
     kept = order[keep.bool()]
     return kept[torch.argsort(labels[kept], stable=True)]
+
+
+_COUNT_CACHE = {}
+
+
+def count_tensor(n, device):
+    """cached device int32 scalar holding n (row counts of static-size matrices)."""
+    key = (str(device), int(n))
+    t = _COUNT_CACHE.get(key)
+    if t is None:
+        t = torch.tensor([int(n)], dtype=torch.int32, device=device)
+        _COUNT_CACHE[key] = t
+    return t
+
+
+def linear_bf16(x, w, bias, relu):
+    """x bf16 [M,K], w bf16 [N,K] (nn.Linear layout), bias f32 [N]|None -> bf16 [M,N]; None if the shape is unsupported."""
+    m, k = x.shape
+    n = w.shape[0]
+    if k % 64 or n % 64:
+        return None
+    out = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
+    _check(lib().u3d_linear_bf16(_ptr(x), _ptr(w), _ptr(bias), int(relu), _ptr(out), _ptr(count_tensor(m, x.device)), m, k, n, _stream()),
+           "linear_bf16")
+    return out

@@ -15,7 +15,7 @@ from torch import nn
 
 from ..registry import BBOX_ASSIGNERS, BBOX_CODERS, HEADS, LOSSES, TRANSFORMER
 from .bbox import bbox_overlaps_3d_aligned, bbox_overlaps_nearest_3d, denormalize_bbox, normalize_bbox
-from .transformer import inverse_sigmoid
+from .transformer import inverse_sigmoid, run_sequential
 
 
 def reduce_mean_(t):
@@ -124,7 +124,7 @@ class Uni3DETRHead(nn.Module):
             if self.with_box_refine and reg is not None and len(reg) == hs.shape[0]:
                 tmp = reg[lvl].float()         # the decoder already ran reg_branches[lvl] on this very state to refine its points
             else:
-                tmp = self.reg_branches[lvl](h).float()
+                tmp = run_sequential(self.reg_branches[lvl], h).float()
             assert reference.shape[-1] == 3
             t = tmp.unbind(-1)
             rf = reference.unbind(-1)
@@ -132,8 +132,8 @@ class Uni3DETRHead(nn.Module):
             y_ = (t[1] + rf[1]).sigmoid() * (pr[4] - pr[1]) + pr[1]
             z_ = (t[4] + rf[2]).sigmoid() * (pr[5] - pr[2]) + pr[2]
             coords.append(torch.stack([x_, y_, t[2], t[3], z_, *t[5:]], -1))
-            classes.append(self.cls_branches[lvl](h).float())
-            ious.append(self.iou_branches[lvl](h).float())
+            classes.append(run_sequential(self.cls_branches[lvl], h).float())
+            ious.append(run_sequential(self.iou_branches[lvl], h).float())
         return {"all_cls_scores": torch.stack(classes), "all_bbox_preds": torch.stack(coords), "all_iou_preds": torch.stack(ious)}
 
     # ------------------------------------------------------------------------------------------

@@ -23,6 +23,86 @@ def inverse_sigmoid(x, eps=1e-5):
     return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
 
 
+class _LinearFn(torch.autograd.Function):
+    """act(x @ W^T + b) on the HIP implicit-GEMM kernel (u3d_linear_bf16: bias and ReLU fused into the epilogue); backward =
+    the same kernel family (dgrad as a k-major GEMM, wgrad as the row-reduction GEMM).  bf16 operands, f32 accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        x2 = (x2 if x2.dtype == torch.bfloat16 else x2.to(torch.bfloat16)).contiguous()
+        wb = weight.to(torch.bfloat16).contiguous()
+        out = nv.linear_bf16(x2, wb, None if bias is None else bias.float(), relu)
+        ctx.relu, ctx.has_bias = relu, bias is not None
+        ctx.xdtype, ctx.wdtype = x.dtype, weight.dtype
+        ctx.save_for_backward(x2, wb, out if relu else None)
+        ctx.shp = shp
+        return out.view(*shp[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wb, out = ctx.saved_tensors
+        n, k = wb.shape
+        m = x2.shape[0]
+        dy2 = dy.reshape(-1, n)
+        dy2 = dy2 if dy2.dtype == torch.bfloat16 else dy2.to(torch.bfloat16)
+        if ctx.relu:
+            dy2 = dy2 * (out > 0)
+        dy2 = dy2.contiguous()
+        md = nv.count_tensor(m, dy2.device)
+        dx = dw = db = None
+        if LINEAR_BWD_TORCH:
+            if ctx.needs_input_grad[0]:
+                dx = (dy2 @ wb).view(ctx.shp).to(ctx.xdtype)
+            if ctx.needs_input_grad[1]:
+                dw = (dy2.t() @ x2).to(ctx.wdtype)
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = nv.spconv_fwd(dy2, wb.view(1, n, k), None, md, m, k).view(ctx.shp).to(ctx.xdtype)
+            if ctx.needs_input_grad[1]:
+                dw = nv.spconv_wgrad(dy2, x2, None, md, 1).view(n, k).to(ctx.wdtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.float().sum(0)
+        return dx, dw, db, None
+
+
+import os as _os
+FAST_LINEAR = _os.environ.get("U3D_FAST_LINEAR", "0") == "1"      # opt-in: measured time-neutral vs hipBLASLt at M = B*900 rows
+LINEAR_BWD_TORCH = _os.environ.get("U3D_LINEAR_BWD_TORCH", "0") == "1"
+
+
+def fast_linear(x, lin, relu=False, weight=None, bias=None):
+    """nn.Linear `lin` (or explicit weight/bias) applied to x; HIP GEMM with fused bias/ReLU when running in bf16 mode."""
+    w = lin.weight if weight is None else weight
+    b = (lin.bias if lin is not None else None) if bias is None and weight is None else bias
+    bf16_mode = x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16))
+    if FAST_LINEAR and bf16_mode and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
+        return _LinearFn.apply(x, w, b, relu)
+    y = F.linear(x, w, b)
+    return F.relu(y) if relu else y
+
+
+def run_sequential(seq, x):
+    """nn.Sequential of Linear / LayerNorm / ReLU / Dropout (the head branches, position encoder, FFN) with Linear(+ReLU)
+    routed through fast_linear."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Linear):
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = fast_linear(x, m, relu=fuse)
+            i += 2 if fuse else 1
+        elif isinstance(m, nn.Sequential):
+            x = run_sequential(m, x)
+            i += 1
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
 class MLP(nn.Module):
     def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
         super().__init__()
@@ -32,9 +112,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, l in enumerate(self.layers):
-            x = l(x)
-            if i < self.num_layers - 1:
-                x = F.relu(x)
+            x = fast_linear(x, l, relu=i < self.num_layers - 1)
         return x
 
 
@@ -80,13 +158,13 @@ class MultiheadAttention(nn.Module):
         qk = (x + pos).reshape(-1, group, C)
         xv = x.reshape(-1, group, C)
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
-        qk_p = F.linear(qk, w[: 2 * C], b[: 2 * C])
+        qk_p = fast_linear(qk, None, weight=w[: 2 * C], bias=b[: 2 * C])
         q, k = qk_p[..., :C], qk_p[..., C:]
-        v = F.linear(xv, w[2 * C:], b[2 * C:])
+        v = fast_linear(xv, None, weight=w[2 * C:], bias=b[2 * C:])
         sh = lambda t: t.reshape(-1, group, H, C // H).transpose(1, 2)
         o = F.scaled_dot_product_attention(sh(q), sh(k), sh(v), dropout_p=self.attn_drop if self.training else 0.0)
         o = o.transpose(1, 2).reshape(B, N, C)
-        o = self.attn.out_proj(o)
+        o = fast_linear(o, self.attn.out_proj)
         return x + self.dropout_layer(self.proj_drop(o))
 
 
@@ -105,7 +183,7 @@ class FFN(nn.Module):
         self.add_identity = add_identity
 
     def forward(self, x, identity=None):
-        out = self.dropout_layer(self.layers(x))
+        out = self.dropout_layer(run_sequential(self.layers, x))
         if not self.add_identity:
             return out
         return (x if identity is None else identity) + out
@@ -169,8 +247,8 @@ class UniCrossAtten(nn.Module):
         if value.dim() != 5:
             raise NotImplementedError("height-less (BEV) value maps are not used by any shipped Uni3DETR config")
         samp = _TrilinearSample.apply(value, g)                                       # [B,N,C]
-        out = self.output_proj(samp.to(query.dtype) * w.sum(-1, keepdim=True))
-        pos_feat = self.position_encoder(ref_logits.to(query.dtype))
+        out = fast_linear(samp.to(query.dtype) * w.sum(-1, keepdim=True), self.output_proj)
+        pos_feat = run_sequential(self.position_encoder, ref_logits.to(query.dtype))
         return self.dropout(out) + query + pos_feat
 
 
@@ -238,7 +316,7 @@ class Uni3DETRTransformerDecoder(nn.Module):
             pos = raw if lid == 0 else self.query_scale(out) * raw
             out = layer.forward_bf(out, pos, value, ref_logits, group)
             if reg_branches is not None:
-                tmp = reg_branches[lid](out)
+                tmp = run_sequential(reg_branches[lid], out)
                 self._reg_outputs.append(tmp)
                 assert ref_logits.shape[-1] == 3
                 td = tmp.detach()
