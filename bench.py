@@ -53,13 +53,14 @@ def make_batch(rank, B, npts, dev):
     return dict(points=pts, img_metas=None, gt_bboxes_3d=gts, gt_labels_3d=labels)
 
 
-def cpu_baseline(npts):
-    """The oracle restatement (pure torch CPU, fp32) timed fwd+bwd on ONE scene on this host's cores ("port")."""
+def cpu_baseline(npts, budget_s=25.0):
+    """The oracle restatement (pure torch CPU, fp32) timed fwd+bwd on ONE scene on this host's cores ("port").
+    Bounded: iterations stop once `budget_s` seconds of CPU work are spent (at least one iteration is always measured)."""
     from oracle import model as om
     from uni3detr_amd.configs.sunrgbd import model as MODEL_CFG
     from uni3detr_amd.registry import build_model
     from uni3detr_amd.synth import room_scene
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = build_model(MODEL_CFG)
@@ -70,16 +71,20 @@ def cpu_baseline(npts):
     gb[:, 2] -= gb[:, 5] / 2
     cfg = om.sunrgbd_cfg()
     times = []
-    for it in range(3):
+    t_start = time.perf_counter()
+    while True:
         t0 = time.perf_counter()
         losses, _ = om.forward_train(sd, [p], [gb], [torch.from_numpy(l)], cfg)
         sum(losses.values()).backward()
         times.append(time.perf_counter() - t0)
         for v in sd.values():
             v.grad = None
-    t = float(np.median(times[1:]))
+        if time.perf_counter() - t_start > budget_s or len(times) >= 4:
+            break
+    use = times[1:] if len(times) > 1 else times          # first iteration = warm-up when there was time for more
+    t = float(np.median(use))
     return dict(value=1.0 / t, unit="scenes/s", cores=cores, kind="port",
-                sample=f"oracle/model.py fwd+bwd, fp32, 1 scene x {npts} pts, median of 2 after 1 warm-up ({t:.2f} s/scene)")
+                sample=f"oracle/model.py fwd+bwd, fp32, 1 scene x {npts} pts, {len(use)} timed iteration(s) of {len(times)} ({t:.2f} s/scene)")
 
 
 def main():
@@ -166,6 +171,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     loss_val = float(last.detach())
+    if not np.isfinite(loss_val):
+        raise SystemExit(f"bench: training diverged (loss = {loss_val}) — a throughput number for a broken step would be meaningless")
 
     if rank == 0:
         scenes = world * args.batch * args.steps
@@ -223,6 +230,7 @@ def main():
             if os.environ.get("U3D_BENCH_DUMP_CALLS"):
                 json.dump(calls, open(os.environ["U3D_BENCH_DUMP_CALLS"], "w"))
         if not args.no_cpu_baseline and world == 1:
+            faulthandler.cancel_dump_traceback_later()       # CPU leg: no GPU work can hang here
             out["cpu_baseline"] = cpu_baseline(args.points)
         result_line = json.dumps(out)
     else:

@@ -66,3 +66,30 @@ def test_capacity_overflow_is_reported(cuda):
     ts.eager_step()
     with pytest.raises(RuntimeError, match="overflow"):
         ts.check_capacities()
+
+
+def test_graph_replay_gradients_match_eager_and_stay_finite(cuda):
+    """Regression for the HIP-graph reduction hazard (tools/reduce_probe.py): every parameter gradient of a replayed step must
+    equal the eager one (dropout off), over several replays — torch column reductions replayed from a graph return garbage on
+    this stack, so the step routes them through GEMV (transformer.colsum / head.layer_sums)."""
+    pts, gts, labels = _data(cuda, B=2, n=10000)
+    ref = _model(cuda)
+    sd = copy.deepcopy(ref.state_dict())
+    eager = TrainStep(ref, pts, gts, labels, graph=False, lr=0.0)          # lr 0: weights frozen, every step sees the same problem
+    eager.step()
+    g_ref = eager.flat_grad.clone()
+    names = [n for n, p in ref.named_parameters() if p.requires_grad]
+    sizes = [p.numel() for p in ref.parameters() if p.requires_grad]
+    m2 = _model(cuda, sd)
+    ts = TrainStep(m2, pts, gts, labels, graph=True, lr=0.0)
+    snap = ts.snapshot(); ts.capture(); ts.restore(snap)
+    for it in range(6):
+        ts.step()
+        torch.cuda.synchronize()
+        assert torch.isfinite(ts.flat_grad).all(), f"non-finite gradient at replay {it}"
+        o = 0
+        for n_, k in zip(names, sizes):
+            a, b = ts.flat_grad[o:o + k], g_ref[o:o + k]
+            o += k
+            err = float((a - b).norm())
+            assert err <= 3e-2 * float(b.norm()) + 1e-4, (it, n_, err, float(b.norm()))

@@ -15,7 +15,7 @@ from torch import nn
 
 from ..registry import BBOX_ASSIGNERS, BBOX_CODERS, HEADS, LOSSES, TRANSFORMER
 from .bbox import bbox_overlaps_3d_aligned, bbox_overlaps_nearest_3d, denormalize_bbox, normalize_bbox
-from .transformer import inverse_sigmoid, run_sequential
+from .transformer import colsum, inverse_sigmoid, run_sequential
 
 
 def reduce_mean_(t):
@@ -24,6 +24,11 @@ def reduce_mean_(t):
         t.div_(dist.get_world_size())
         dist.all_reduce(t)
     return t
+
+
+def layer_sums(x):
+    """x [L, ...] -> [L] sums of everything but the first dim, as a GEMV (graph-replay-safe, see transformer.colsum)."""
+    return colsum(x.reshape(x.shape[0], -1).t())
 
 
 def _clones(m, n):
@@ -182,7 +187,7 @@ class Uni3DETRHead(nn.Module):
         else:
             tgt = box_all.new_zeros((L, B, Q, 7))
             lab = torch.full_like(asg, C)
-        return dict(asg=asg, w=w, tgt=tgt, lab=lab, num_pos=w.sum(dim=(1, 2)))
+        return dict(asg=asg, w=w, tgt=tgt, lab=lab, num_pos=layer_sums(w))
 
     def loss_from_targets(self, preds_dicts, T, num_pos):
         """Stage 2 of loss(): the 4 losses x L layers given targets and the (rank-averaged) positive counts [L]."""
@@ -211,11 +216,11 @@ class Uni3DETRHead(nn.Module):
             ps = cls_all.sigmoid()
             soft = F.one_hot(lab, C + 1)[..., :C].to(cls_all.dtype) * quality.unsqueeze(-1)
             fw = ((1 - a) + (2 * a - 1) * soft) * (soft - ps).pow(gmm)
-            l_cls = (F.binary_cross_entropy_with_logits(cls_all, soft, reduction="none") * fw).sum(dim=(1, 2, 3)) / (cls_avg + _EPS32) * self.loss_cls.loss_weight
-            l_box = ((box_all[..., :10] - ntgt[..., :10]).abs() * bw[..., :10]).sum(dim=(1, 2, 3)) / (npos + _EPS32) * self.loss_bbox.loss_weight
-            l_iou = ((1 - iou_bev) * bw[..., :10].mean(-1)).sum(dim=(1, 2)) / (npos + _EPS32) * self.loss_iou.loss_weight
-            l_iou = l_iou + ((1 - iou_z) * bw[..., 0]).sum(dim=(1, 2)) / npos
-            l_ioup = (F.binary_cross_entropy_with_logits(iou_all.squeeze(-1), iou_true, reduction="none") * bw[..., 0]).sum(dim=(1, 2)) / npos * 1.2
+            l_cls = layer_sums(F.binary_cross_entropy_with_logits(cls_all, soft, reduction="none") * fw) / (cls_avg + _EPS32) * self.loss_cls.loss_weight
+            l_box = layer_sums((box_all[..., :10] - ntgt[..., :10]).abs() * bw[..., :10]) / (npos + _EPS32) * self.loss_bbox.loss_weight
+            l_iou = layer_sums((1 - iou_bev) * bw[..., :10].mean(-1)) / (npos + _EPS32) * self.loss_iou.loss_weight
+            l_iou = l_iou + layer_sums((1 - iou_z) * bw[..., 0]) / npos
+            l_ioup = layer_sums(F.binary_cross_entropy_with_logits(iou_all.squeeze(-1), iou_true, reduction="none") * bw[..., 0]) / npos * 1.2
             out = {"loss_cls": l_cls[-1], "loss_bbox": l_box[-1], "loss_iou": l_iou[-1], "loss_iou_pred": l_ioup[-1]}
             for i in range(L - 1):
                 out[f"d{i}.loss_cls"], out[f"d{i}.loss_bbox"] = l_cls[i], l_box[i]

@@ -63,8 +63,50 @@ class _LinearFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw = nv.spconv_wgrad(dy2, x2, None, md, 1).view(n, k).to(ctx.wdtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.float().sum(0)
+            db = colsum(dy2.float())
         return dx, dw, db, None
+
+
+_ONES = {}
+
+
+def ones_vector(n, device, dtype):
+    key = (str(device), int(n), dtype)
+    t = _ONES.get(key)
+    if t is None:
+        t = torch.ones(int(n), device=device, dtype=dtype)
+        _ONES[key] = t
+    return t
+
+
+def colsum(x2):
+    """Column sums of a [M, N] matrix as a GEMV with a ones vector.  NOT x2.sum(0): torch's multi-block reduce kernel returns
+    garbage for ~30 % of such reductions when replayed from a HIP graph on this stack (tools/reduce_probe.py), GEMV does not."""
+    return torch.mv(x2.t(), ones_vector(x2.shape[0], x2.device, x2.dtype))
+
+
+class _TorchLinearFn(torch.autograd.Function):
+    """F.linear with a graph-replay-safe backward (bias gradient through colsum)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy2.to(weight.dtype) @ weight).view(x.shape).to(x.dtype)
+        if ctx.needs_input_grad[1]:
+            dw = (dy2.t().to(x2.dtype) @ x2).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy2.float())
+        return dx, dw, db
 
 
 import os as _os
@@ -79,7 +121,14 @@ def fast_linear(x, lin, relu=False, weight=None, bias=None):
     bf16_mode = x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16))
     if FAST_LINEAR and bf16_mode and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
         return _LinearFn.apply(x, w, b, relu)
-    y = F.linear(x, w, b)
+    if x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_gpu_dtype()
+            y = _TorchLinearFn.apply(x.to(dt), w.to(dt), None if b is None else b.to(dt))
+        else:
+            y = _TorchLinearFn.apply(x, w, b)
+    else:
+        y = F.linear(x, w, b)
     return F.relu(y) if relu else y
 
 
@@ -241,7 +290,7 @@ class UniCrossAtten(nn.Module):
 
     def forward_bf(self, query, query_pos, value, ref_logits):
         """query/query_pos [B,N,C]; value [B,C,D,H,W] (or [B,C,H,W]); ref_logits [B,N,3] -> [B,N,C]."""
-        w = self.attention_weights(query + query_pos).sigmoid()                       # [B,N,P]
+        w = fast_linear(query + query_pos, self.attention_weights).sigmoid()          # [B,N,P]
         g = (ref_logits.sigmoid() - 0.5) * 2
         B, N, _ = g.shape
         if value.dim() != 5:
