@@ -111,6 +111,7 @@ class _TorchLinearFn(torch.autograd.Function):
 
 import os as _os
 FAST_LINEAR = _os.environ.get("U3D_FAST_LINEAR", "0") == "1"      # opt-in: measured time-neutral vs hipBLASLt at M = B*900 rows
+SAFE_LINEAR = _os.environ.get("U3D_UNSAFE_LINEAR", "0") != "1"      # test hook: "1" restores torch's own Linear backward
 LINEAR_BWD_TORCH = _os.environ.get("U3D_LINEAR_BWD_TORCH", "0") == "1"
 
 
@@ -121,7 +122,7 @@ def fast_linear(x, lin, relu=False, weight=None, bias=None):
     bf16_mode = x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16))
     if FAST_LINEAR and bf16_mode and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
         return _LinearFn.apply(x, w, b, relu)
-    if x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+    if SAFE_LINEAR and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
         if torch.is_autocast_enabled():
             dt = torch.get_autocast_gpu_dtype()
             y = _TorchLinearFn.apply(x.to(dt), w.to(dt), None if b is None else b.to(dt))
