@@ -163,6 +163,12 @@ int32_t u3d_spconv_wgrad(const void* in, const void* dout, const int32_t* nbr, i
                          const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
                          int32_t dtype, void* workspace, int64_t workspace_bytes, u3d_stream s);
 
+/* out[c] = sum_r x[r, c] over a dense [n, C] matrix (f32 or bf16 in, f32 out, fixed summation order): the bias gradient of every
+ * nn.Linear of the decoder / head (ref: uni3detr_transformer.py:93-214, uni3detr_head.py:95-125 — autograd's sum-to-size there). */
+int64_t u3d_colsum_workspace(int32_t n, int32_t c);
+int32_t u3d_colsum(const void* x, int32_t n, int32_t c, int32_t dtype, float* out, void* workspace,
+                   int64_t workspace_bytes, u3d_stream s);
+
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm1d over sparse rows [n, C] (training statistics) with optional residual add and ReLU
  * (ref: sparse_encoder_hd.py:40; upstream make_sparse_convmodule / SparseBasicBlock).

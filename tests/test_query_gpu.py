@@ -193,3 +193,72 @@ def test_fast_linear_matches_torch(cuda, m, k, n, relu):
     assert (w2.grad - wr.grad).abs().max().item() <= 2e-2 * max(1.0, wr.grad.abs().max().item())
     exp_b = (gy * ((ref > 0) if relu else 1)).reshape(-1, n).sum(0)
     assert (b2.grad - exp_b).abs().max().item() <= 2e-2 * m ** 0.5
+
+
+@pytest.mark.parametrize("n,c,dtype", [(7200, 256, torch.bfloat16), (21600, 10, torch.float32), (333, 1024, torch.bfloat16), (1, 8, torch.float32),
+                                       (0, 16, torch.float32), (4097, 36, torch.bfloat16)])
+def test_colsum_matches_float64_sum(cuda, n, c, dtype):
+    torch.manual_seed(n + c)
+    x = torch.randn(n, c, device=cuda).to(dtype)
+    got = nv.colsum(x)
+    exp = x.double().sum(0)
+    assert got.dtype == torch.float32 and got.shape == (c,)
+    assert (got.double() - exp).abs().max().item() <= 1e-4 * max(1.0, n ** 0.5) if n else float(got.abs().sum()) == 0.0
+    assert torch.equal(got, nv.colsum(x))                      # fixed summation order
+
+
+@pytest.mark.parametrize("amp", [True, False])
+def test_safe_linear_and_in_proj_backward_match_torch(cuda, amp):
+    """fast_linear (shadow weights, HIP wgrad + colsum backward) and the packed in-projection against plain F.linear autograd."""
+    from uni3detr_amd.plugin import transformer as T
+    from uni3detr_amd.shadow import ShadowSet
+    torch.manual_seed(3)
+    C = 256
+    lin = torch.nn.Linear(C, 512).to(cuda)
+    mha = torch.nn.MultiheadAttention(C, 8).to(cuda)
+    x = torch.randn(8, 900, C, device=cuda)
+    pos = torch.randn(8, 900, C, device=cuda)
+    q = lambda t: t.detach().bfloat16().float() if amp else t.detach().clone()
+    # reference: fp32 math on (bf16-rounded when amp) operands
+    xr, pr = q(x).requires_grad_(True), q(pos).requires_grad_(True)
+    wl, bl = q(lin.weight).requires_grad_(True), q(lin.bias).requires_grad_(True)
+    wi, bi = q(mha.in_proj_weight).requires_grad_(True), q(mha.in_proj_bias).requires_grad_(True)
+    qk_r = q(xr + pr) if amp else xr + pr
+    y_ref = torch.nn.functional.linear(xr, wl, bl)
+    qkp_ref = torch.nn.functional.linear(xr + pr, wi[: 2 * C], bi[: 2 * C])
+    v_ref = torch.nn.functional.linear(xr, wi[2 * C:], bi[2 * C:])
+    gy, gq, gv = torch.randn_like(y_ref), torch.randn_like(qkp_ref), torch.randn_like(v_ref)
+    if amp:
+        gy, gq, gv = gy.bfloat16().float(), gq.bfloat16().float(), gv.bfloat16().float()
+    (y_ref * gy).sum().backward(retain_graph=True)
+    ((qkp_ref * gq).sum() + (v_ref * gv).sum()).backward()
+    x2, p2 = x.detach().clone().requires_grad_(True), pos.detach().clone().requires_grad_(True)
+    shadows = ShadowSet([lin.weight, lin.bias, mha.in_proj_weight, mha.in_proj_bias], torch.bfloat16)
+    import contextlib
+    with (shadows.active() if amp else contextlib.nullcontext()), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        y = T.fast_linear(x2, lin)
+        qkp, v = T._InProjFn.apply(x2 + p2, x2, mha.in_proj_weight, mha.in_proj_bias, torch.bfloat16 if amp else None)
+    assert y.dtype == (torch.bfloat16 if amp else torch.float32)
+    tol = 3e-2 if amp else 2e-3
+    rel = lambda a, b: (a.float() - b.float()).abs().max().item() / max(1.0, b.abs().max().item())
+    assert rel(y, y_ref) <= tol and rel(qkp, qkp_ref) <= tol and rel(v, v_ref) <= tol
+    ((y.float() * gy).sum() + (qkp.float() * gq).sum() + (v.float() * gv).sum()).backward()
+    assert lin.weight.grad.dtype == torch.float32 and mha.in_proj_weight.grad.shape == (3 * C, C)
+    assert rel(lin.weight.grad, wl.grad) <= tol and rel(lin.bias.grad, bl.grad) <= tol
+    assert rel(mha.in_proj_weight.grad, wi.grad) <= tol and rel(mha.in_proj_bias.grad, bi.grad) <= tol
+    assert rel(x2.grad, xr.grad) <= tol and rel(p2.grad, pr.grad) <= tol
+    # stale shadows are never used: modify the parameter after the refresh -> the cast path must pick up the new value
+    if amp:
+        with torch.no_grad():
+            lin.weight.mul_(2.0)
+        with shadows.active():
+            pass
+        with torch.no_grad():
+            lin.weight.mul_(0.5)
+        from uni3detr_amd import shadow as S
+        S._ACTIVE[0] = True
+        try:
+            w_now = S.compute_copy(lin.weight, torch.bfloat16)
+        finally:
+            S._ACTIVE[0] = False
+        assert torch.equal(w_now, lin.weight.detach().bfloat16())

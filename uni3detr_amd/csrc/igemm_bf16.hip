@@ -375,14 +375,9 @@ __global__ void k_igemm_wgrad_reduce(const float* __restrict__ partial, float* _
 }
 
 struct WgPlan { int tile; int ci_blocks, co_blocks, nsplit; };
-static WgPlan wgrad_plan(int n_out_cap, int cin, int cout, int kvol) {
+static WgPlan wgrad_plan_tile(int tile, int n_out_cap, int cin, int cout, int kvol) {
   WgPlan p;
-  int mn = cin < cout ? cin : cout;
-  if (mn >= 256 && cin % 256 == 0 && cout % 256 == 0) p.tile = 256;
-  else if (mn >= 128 && cin % 128 == 0 && cout % 128 == 0) p.tile = 128;
-  else if (cin % 64 == 0 && cout % 64 == 0) p.tile = 64;
-  else if (cin % 32 == 0 && cout % 32 == 0) p.tile = 32;       // sparse levels with 32 channels: load/latency bound
-  else p.tile = 16;
+  p.tile = tile;
   p.ci_blocks = u3d_cdiv(cin, p.tile);
   p.co_blocks = u3d_cdiv(cout, p.tile);
   int ntiles = u3d_cdiv(n_out_cap > 0 ? n_out_cap : 1, 64);
@@ -393,6 +388,19 @@ static WgPlan wgrad_plan(int n_out_cap, int cin, int cout, int kvol) {
   // keep at least 8 stages per split so the prologue is amortised
   while (ns > 1 && ntiles / ns < 8) --ns;
   p.nsplit = ns < 1 ? 1 : ns;
+  return p;
+}
+static WgPlan wgrad_plan(int n_out_cap, int cin, int cout, int kvol) {
+  int mn = cin < cout ? cin : cout;
+  int tile;
+  if (mn >= 256 && cin % 256 == 0 && cout % 256 == 0) tile = 256;
+  else if (mn >= 128 && cin % 128 == 0 && cout % 128 == 0) tile = 128;
+  else if (cin % 64 == 0 && cout % 64 == 0) tile = 64;
+  else if (cin % 32 == 0 && cout % 32 == 0) tile = 32;       // sparse levels with 32 channels: load/latency bound
+  else tile = 16;
+  WgPlan p = wgrad_plan_tile(tile, n_out_cap, cin, cout, kvol);
+  // few rows (the decoder / head linears: kvol 1, <= 10^4 rows): the row split cannot fill 256 CUs with big tiles -> smaller tiles
+  while (p.tile > 64 && (long long)p.nsplit * kvol * p.ci_blocks * p.co_blocks < 192) p = wgrad_plan_tile(p.tile / 2, n_out_cap, cin, cout, kvol);
   return p;
 }
 

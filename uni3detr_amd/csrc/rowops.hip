@@ -215,6 +215,76 @@ extern "C" int32_t u3d_bn_bwd_stats(const void* dy, const void* y, const void* x
   return run_stats<1>(x, dy, y, mean, invstd, relu, n_dev, n_cap, c, dtype, sums, workspace, workspace_bytes, s);
 }
 
+// ---------------------------------------------------------------------------------------------
+// column sums of a dense [n, C] matrix (bias gradients of the query decoder / head linears), f32 accumulation in a fixed
+// order: stage 1 = one workgroup per CS_ROWS rows -> partial[block][C]; stage 2 = one thread per column over the blocks.
+// ---------------------------------------------------------------------------------------------
+#define CS_ROWS 32
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_colsum_partial(const T* __restrict__ x, int n, int c, float* __restrict__ partial) {
+  __shared__ float red[256 * 8];
+  const int cv = (c + V - 1) / V;
+  const int cw = cv < 256 ? cv : 256;
+  const int rl = 256 / cw;
+  const int tcol = threadIdx.x % cw, trow = threadIdx.x / cw;
+  const int r0 = blockIdx.x * CS_ROWS, r1 = min(n, r0 + CS_ROWS);
+  for (int cb = 0; cb < cv; cb += cw) {
+    const int vc = cb + tcol;
+    float s[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) s[e] = 0.f;
+    if (vc < cv && trow < rl) {
+      for (int r = r0 + trow; r < r1; r += rl) {
+        const long long o = (long long)r * c + (long long)vc * V;
+        float xv[V];
+        if constexpr (V == 1) xv[0] = ld_elem(x, o); else load_vec<T>(x + o, xv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[e] += xv[e];
+      }
+    }
+    if (trow < rl) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) red[(trow * cw + tcol) * V + e] = s[e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cw * V; i += 256) {
+      if (cb * V + i < c) {
+        float a = 0.f;
+        for (int j = 0; j < rl; ++j) a += red[j * cw * V + i];
+        partial[(long long)blockIdx.x * c + cb * V + i] = a;
+      }
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ partial, int nb, int c, float* __restrict__ out) {
+  int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (col >= c) return;
+  float s = 0.f;
+  for (int b = lane; b < nb; b += 64) s += partial[(long long)b * c + col];
+  s = u3d_wave_sum(s);
+  if (lane == 0) out[col] = s;
+}
+extern "C" int64_t u3d_colsum_workspace(int32_t n, int32_t c) { return (int64_t)u3d_cdiv(n > 0 ? n : 1, CS_ROWS) * c * 4; }
+extern "C" int32_t u3d_colsum(const void* x, int32_t n, int32_t c, int32_t dtype, float* out, void* workspace,
+                              int64_t workspace_bytes, u3d_stream s) {
+  U3D_REQUIRE(out && c > 0 && n >= 0, U3D_ERR_ARG);
+  if (n == 0) { hipMemsetAsync(out, 0, sizeof(float) * c, s); return U3D_OK; }
+  U3D_REQUIRE(x && workspace && workspace_bytes >= u3d_colsum_workspace(n, c), U3D_ERR_WORKSPACE);
+  const int nb = u3d_cdiv(n, CS_ROWS);
+  float* ws = (float*)workspace;
+  if (dtype == U3D_F32) {
+    if (c % 4 == 0) hipLaunchKernelGGL((k_colsum_partial<float, 4>), dim3(nb), dim3(256), 0, s, (const float*)x, n, c, ws);
+    else hipLaunchKernelGGL((k_colsum_partial<float, 1>), dim3(nb), dim3(256), 0, s, (const float*)x, n, c, ws);
+  } else if (dtype == U3D_BF16) {
+    if (c % 8 == 0) hipLaunchKernelGGL((k_colsum_partial<u16, 8>), dim3(nb), dim3(256), 0, s, (const u16*)x, n, c, ws);
+    else hipLaunchKernelGGL((k_colsum_partial<u16, 1>), dim3(nb), dim3(256), 0, s, (const u16*)x, n, c, ws);
+  } else return U3D_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_colsum_final, dim3(u3d_cdiv(c, 4)), dim3(256), 0, s, (const float*)ws, nb, c, out);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
 // sums -> mean / invstd (biased variance) and the running-stat update of nn.BatchNorm1d (unbiased variance), one launch
 __global__ void k_bn_finalize(const double* __restrict__ sums, const int* __restrict__ n_dev, int n_cap, int c, float eps,
                               float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,

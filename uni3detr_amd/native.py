@@ -56,6 +56,8 @@ _SIGS = {
     "u3d_linear_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "u3d_igemm_wgrad_bf16_workspace": (_L, [_I, _I, _I, _I]),
     "u3d_igemm_wgrad_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
+    "u3d_colsum_workspace": (_L, [_I, _I]),
+    "u3d_colsum": (_I, [_P, _I, _I, _I, _P, _P, _L, _P]),
     "u3d_bn_stats_workspace": (_L, [_I, _I]),
     "u3d_bn_stats": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _P]),
     "u3d_bn_finalize": (_I, [_P, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
@@ -317,6 +319,17 @@ def spconv_wgrad(inp, dout, nbr, n_out_dev, kvol):
     if t is not None:
         t.end("spconv_wgrad", e0, meta)
     return dw
+
+
+def colsum(x):
+    """f32 column sums of a dense [n, C] f32/bf16 matrix (fixed order; safe under HIP-graph replay, unlike torch's sum(0))."""
+    x = x if x.is_contiguous() else x.contiguous()
+    n, c = x.shape
+    out = torch.empty((c,), dtype=torch.float32, device=x.device)
+    wsb = int(lib().u3d_colsum_workspace(n, c))
+    ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=x.device)
+    _check(lib().u3d_colsum(_ptr(x), n, c, dtype_code(x), _ptr(out), _ptr(ws), wsb, _stream()), "colsum")
+    return out
 
 
 def bn_stats(x, n_dev):

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import native as nv
+from ..shadow import compute_copy
 from ..registry import ATTENTION, FEEDFORWARD_NETWORK, TRANSFORMER, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE
 
 
@@ -63,7 +64,7 @@ class _LinearFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw = nv.spconv_wgrad(dy2, x2, None, md, 1).view(n, k).to(ctx.wdtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy2.float())
+            db = nv.colsum(dy2)
         return dx, dw, db, None
 
 
@@ -80,54 +81,127 @@ def ones_vector(n, device, dtype):
 
 
 def colsum(x2):
-    """Column sums of a [M, N] matrix as a GEMV with a ones vector.  NOT x2.sum(0): torch's multi-block reduce kernel returns
-    garbage for ~30 % of such reductions when replayed from a HIP graph on this stack (tools/reduce_probe.py), GEMV does not."""
+    """Differentiable column sums of a [M, N] matrix as a GEMV with a ones vector.  NOT x2.sum(0): torch's multi-block reduce
+    kernel returns garbage for ~30 % of such reductions when replayed from a HIP graph on this stack (tools/reduce_probe.py),
+    GEMV does not.  (Inside backward passes the HIP kernel nv.colsum is used instead: rocBLAS gemv takes ~70 us here.)"""
     return torch.mv(x2.t(), ones_vector(x2.shape[0], x2.device, x2.dtype))
 
 
+def _mm_f32(a, b):
+    """a @ b for bf16 operands with an f32 result, in one launch when the BLAS backend supports out_dtype."""
+    if MM_OUT_DTYPE[0] is None:
+        try:
+            torch.mm(a[:1], b, out_dtype=torch.float32)
+            MM_OUT_DTYPE[0] = True
+        except Exception:                                     # noqa: BLE001 - capability probe
+            MM_OUT_DTYPE[0] = False
+    if MM_OUT_DTYPE[0]:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    return (a @ b).float()
+
+
+MM_OUT_DTYPE = [None]
+
+
+def _linear_backward(dy2, x2, wc, need_dx, need_dw, need_db, xdtype):
+    """Shared backward of y = x2 @ wc^T + b.  dy2 [M,N], x2 [M,K], wc [N,K] (compute dtype).  Parameter gradients come back
+    in f32 (dW from the HIP row-split wgrad kernel when bf16: hipBLASLt runs these [N,M]x[M,K] products with M = B*900 on
+    16 tiles; db from u3d_colsum — NOT dy.sum(0), see colsum)."""
+    n, k = wc.shape
+    m = x2.shape[0]
+    dx = dw = db = None
+    bf16 = wc.dtype == torch.bfloat16
+    if need_dx:
+        dx = _mm_f32(dy2, wc) if (bf16 and xdtype == torch.float32) else (dy2 @ wc).to(xdtype)
+    if need_dw:
+        if bf16 and OWN_WGRAD and n % 16 == 0 and k % 16 == 0 and m > 0:
+            dw = nv.spconv_wgrad(dy2, x2.contiguous(), None, nv.count_tensor(m, dy2.device), 1).view(n, k)
+        elif bf16:
+            dw = _mm_f32(dy2.t(), x2)
+        else:
+            dw = dy2.t() @ x2
+    if need_db:
+        db = nv.colsum(dy2)
+    return dx, dw, db
+
+
 class _TorchLinearFn(torch.autograd.Function):
-    """F.linear with a graph-replay-safe backward (bias gradient through colsum)."""
+    """F.linear on the fp32 master parameters, computed in `cdt` (None = as is): the low-precision weight comes from the
+    per-step shadow set (uni3detr_amd/shadow.py), the backward is graph-replay-safe and returns f32 parameter gradients."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+    def forward(ctx, x, weight, bias, cdt):
+        if cdt is not None:
+            xc = x if x.dtype == cdt else x.to(cdt)
+            wc, bc = compute_copy(weight, cdt), compute_copy(bias, cdt)
+        else:
+            xc, wc, bc = x, weight, bias
+        ctx.save_for_backward(xc, wc)
+        ctx.has_bias, ctx.xdtype = bias is not None, x.dtype
+        return F.linear(xc, wc, bc)
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        xc, wc = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
-        x2 = x.reshape(-1, x.shape[-1])
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = (dy2.to(weight.dtype) @ weight).view(x.shape).to(x.dtype)
-        if ctx.needs_input_grad[1]:
-            dw = (dy2.t().to(x2.dtype) @ x2).to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy2.float())
-        return dx, dw, db
+        dy2 = (dy2 if dy2.dtype == wc.dtype else dy2.to(wc.dtype)).contiguous()
+        x2 = xc.reshape(-1, xc.shape[-1])
+        dx, dw, db = _linear_backward(dy2, x2, wc, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                      ctx.has_bias and ctx.needs_input_grad[2], ctx.xdtype)
+        return (None if dx is None else dx.view(xc.shape)), dw, db, None
+
+
+class _InProjFn(torch.autograd.Function):
+    """nn.MultiheadAttention's packed in-projection with q = k input `qk` and value input `xv`:
+    (qk @ W[:2C]^T + b[:2C],  xv @ W[2C:]^T + b[2C:]) with ONE gradient for the packed parameter."""
+
+    @staticmethod
+    def forward(ctx, qk, xv, weight, bias, cdt):
+        c = weight.shape[1]
+        if cdt is not None:
+            qc = qk if qk.dtype == cdt else qk.to(cdt)
+            vc = xv if xv.dtype == cdt else xv.to(cdt)
+            wc, bc = compute_copy(weight, cdt), compute_copy(bias, cdt)
+        else:
+            qc, vc, wc, bc = qk, xv, weight, bias
+        ctx.save_for_backward(qc, vc, wc)
+        ctx.qdtype, ctx.vdtype = qk.dtype, xv.dtype
+        return F.linear(qc, wc[: 2 * c], bc[: 2 * c]), F.linear(vc, wc[2 * c:], bc[2 * c:])
+
+    @staticmethod
+    def backward(ctx, dqk, dv):
+        qc, vc, wc = ctx.saved_tensors
+        c = wc.shape[1]
+        cast = lambda t: (t if t.dtype == wc.dtype else t.to(wc.dtype)).reshape(-1, t.shape[-1]).contiguous()
+        dqk2, dv2 = cast(dqk), cast(dv)
+        need_w = ctx.needs_input_grad[2]
+        dq_in, dw1, db1 = _linear_backward(dqk2, qc.reshape(-1, c), wc[: 2 * c], ctx.needs_input_grad[0], need_w, need_w, ctx.qdtype)
+        dv_in, dw2, db2 = _linear_backward(dv2, vc.reshape(-1, c), wc[2 * c:], ctx.needs_input_grad[1], need_w, need_w, ctx.vdtype)
+        dw = torch.cat((dw1, dw2)) if need_w else None
+        db = torch.cat((db1, db2)) if need_w else None
+        return (None if dq_in is None else dq_in.view(qc.shape)), (None if dv_in is None else dv_in.view(vc.shape)), dw, db, None
 
 
 import os as _os
 FAST_LINEAR = _os.environ.get("U3D_FAST_LINEAR", "0") == "1"      # opt-in: measured time-neutral vs hipBLASLt at M = B*900 rows
 SAFE_LINEAR = _os.environ.get("U3D_UNSAFE_LINEAR", "0") != "1"      # test hook: "1" restores torch's own Linear backward
 LINEAR_BWD_TORCH = _os.environ.get("U3D_LINEAR_BWD_TORCH", "0") == "1"
+OWN_WGRAD = _os.environ.get("U3D_OWN_WGRAD", "1") == "1"          # dW of the decoder/head linears on u3d_igemm_wgrad_bf16
+
+
+def _autocast_dtype(x):
+    return torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled()) else None
 
 
 def fast_linear(x, lin, relu=False, weight=None, bias=None):
     """nn.Linear `lin` (or explicit weight/bias) applied to x; HIP GEMM with fused bias/ReLU when running in bf16 mode."""
     w = lin.weight if weight is None else weight
     b = (lin.bias if lin is not None else None) if bias is None and weight is None else bias
-    bf16_mode = x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16))
+    bf16_mode = x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16))
     if FAST_LINEAR and bf16_mode and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
         return _LinearFn.apply(x, w, b, relu)
     if SAFE_LINEAR and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
-        if torch.is_autocast_enabled():
-            dt = torch.get_autocast_gpu_dtype()
-            y = _TorchLinearFn.apply(x.to(dt), w.to(dt), None if b is None else b.to(dt))
-        else:
-            y = _TorchLinearFn.apply(x, w, b)
+        y = _TorchLinearFn.apply(x, w, b, _autocast_dtype(x))
     else:
         y = F.linear(x, w, b)
     return F.relu(y) if relu else y
@@ -208,9 +282,12 @@ class MultiheadAttention(nn.Module):
         qk = (x + pos).reshape(-1, group, C)
         xv = x.reshape(-1, group, C)
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
-        qk_p = fast_linear(qk, None, weight=w[: 2 * C], bias=b[: 2 * C])
+        if SAFE_LINEAR and not FAST_LINEAR and x.is_cuda and torch.is_grad_enabled() and b is not None:
+            qk_p, v = _InProjFn.apply(qk, xv, w, b, _autocast_dtype(x))
+        else:
+            qk_p = fast_linear(qk, None, weight=w[: 2 * C], bias=b[: 2 * C])
+            v = fast_linear(xv, None, weight=w[2 * C:], bias=b[2 * C:])
         q, k = qk_p[..., :C], qk_p[..., C:]
-        v = fast_linear(xv, None, weight=w[2 * C:], bias=b[2 * C:])
         sh = lambda t: t.reshape(-1, group, H, C // H).transpose(1, 2)
         o = F.scaled_dot_product_attention(sh(q), sh(k), sh(v), dropout_p=self.attn_drop if self.training else 0.0)
         o = o.transpose(1, 2).reshape(B, N, C)

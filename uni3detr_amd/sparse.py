@@ -7,6 +7,7 @@ Replaces spconv's SparseConvTensor / indice_key machinery used by the reference 
 import torch
 
 from . import native as nv
+from .shadow import compute_copy
 
 K3, S1, P1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
 
@@ -77,8 +78,8 @@ class _SparseConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, weight, geom):
         # weight: [kD,kH,kW,Cin,Cout] (mmcv spconv-1.x layout) or [1,1,1,Cin,Cout]
-        w = weight.reshape(-1, weight.shape[-2], weight.shape[-1])
-        wc = w if w.dtype == feats.dtype else w.to(feats.dtype)
+        wc = compute_copy(weight, feats.dtype).reshape(-1, weight.shape[-2], weight.shape[-1])
+        w = wc
         ctx.geom = geom
         ctx.save_for_backward(feats, wc)
         ctx.wshape, ctx.wdtype = weight.shape, weight.dtype
@@ -138,9 +139,8 @@ class _BNRows(torch.autograd.Function):
             dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, zero, ctx.relu, ctx.n_dev, ctx.has_res)
         else:
             dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, ctx.relu, ctx.n_dev, ctx.has_res)
-        dgamma = sums[1].to(ctx.pdtype)
-        dbeta = sums[0].to(ctx.pdtype)
-        return dx, dgamma, dbeta, dres, None, None, None, None
+        s32 = sums.to(ctx.pdtype)
+        return dx, s32[1], s32[0], dres, None, None, None, None
 
 
 def bn_rows(x, bn, n_dev, residual=None, relu=True):

@@ -28,8 +28,10 @@ class TrainStep:
         n = sum(p.numel() for p in self.params)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=self.dev)
         o = 0
+        self.views = []
         for p in self.params:
-            p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+            self.views.append(self.flat_grad[o:o + p.numel()].view_as(p))
+            p.grad = self.views[-1]
             o += p.numel()
         self.opt = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay, fused=True, capturable=graph)
         self.pts = model.pack_points(points) if not isinstance(points, dict) else points
@@ -42,10 +44,11 @@ class TrainStep:
     # ---- the three stages (same code eager or captured) -------------------------------------------------------
     def _stage1(self):
         m = self.model
-        feat, fps = m.extract_pts_feat(self.pts)
-        amp = m.amp_dtype
-        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
-            self._outs = m.pts_bbox_head(feat, None, fps)
+        with m.shadow_scope():
+            feat, fps = m.extract_pts_feat(self.pts)
+            amp = m.amp_dtype
+            with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+                self._outs = m.pts_bbox_head(feat, None, fps)
         self._T = m.pts_bbox_head.loss_targets(self.gts, None, self._outs)
         self._num_pos = self._T["num_pos"].clone()
 
@@ -55,12 +58,25 @@ class TrainStep:
             dist.all_reduce(self._num_pos)
 
     def _stage2(self):
-        self.flat_grad.zero_()
+        # .grad = None: autograd hands each parameter its gradient tensor as is (no per-parameter "grad += new" launch, ~270 of
+        # them); one multi-tensor copy then packs them into the flat buffer the all-reduce / clip / AdamW stages work on
+        for p in self.params:
+            p.grad = None
         losses = self.model.pts_bbox_head.loss_from_targets(self._outs, self._T, self._num_pos)
         self._losses = losses
         loss = sum(v for k, v in losses.items() if "loss" in k)
         loss.backward()
         self.loss = loss.detach()
+        dst, src, missing = [], [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                missing.append(v)
+            else:
+                dst.append(v); src.append(p.grad)
+            p.grad = v
+        torch._foreach_copy_(dst, src)
+        if missing:
+            torch._foreach_zero_(missing)
 
     def _reduce_grads(self):
         if self.dist_on:
