@@ -1,0 +1,85 @@
+"""Per-layer timing of the implicit-GEMM kernels on the bench workload's layer shapes (GPU).
+usage: python tools/conv_bench.py [--only dense256] [--iters 20] [--check]
+Prints one line per (layer, pass): ms, TFLOP/s (pair-based flops), algorithmic GB/s."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from uni3detr_amd import native as nv  # noqa: E402
+
+LAYERS = {
+    # name: (batch, dims(z,y,x), cin, cout, ksize, stride, pad)
+    "dense256": (8, (15, 40, 40), 256, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    "dense128k9": (8, (15, 40, 40), 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    "dense256k9": (8, (15, 20, 20), 256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    "dense512k9": (8, (15, 10, 10), 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    "dense64": (8, (15, 40, 40), 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+}
+
+
+def ref_fwd(x, w, nbr, n):
+    out = torch.zeros(n, w.shape[2], dtype=torch.float32, device=x.device)
+    xf = torch.cat([x.float(), torch.zeros(1, x.shape[1], device=x.device)])
+    for k in range(w.shape[0]):
+        idx = nbr[k, :n].long()
+        idx = torch.where(idx < 0, torch.full_like(idx, x.shape[0]), idx)
+        out += xf[idx] @ w[k].float()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--check", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    for name, (B, dims, cin, cout, ks, st, pad) in LAYERS.items():
+        if a.only and a.only not in name:
+            continue
+        n = B * dims[0] * dims[1] * dims[2]
+        kvol = ks[0] * ks[1] * ks[2]
+        nbr = nv.dense_nbr_table(B, dims, dims, ks, st, pad, 0, dev)
+        nbr_b = nv.dense_nbr_table(B, dims, dims, ks, st, pad, 1, dev)
+        nd = nv.count_tensor(n, dev)
+        torch.manual_seed(0)
+        x = torch.randn(n, cin, device=dev).bfloat16()
+        dy = torch.randn(n, cout, device=dev).bfloat16()
+        w = (torch.randn(kvol, cin, cout, device=dev) * 0.05).bfloat16()
+        pairs = int((nbr[:, :n] >= 0).sum())
+        flops = 2.0 * pairs * cin * cout
+        byt = n * cin * 2 + n * cout * 2 + 8 * pairs + kvol * cin * cout * 2
+        passes = {
+            "fwd": lambda: nv.spconv_fwd(x, w, nbr, nd, n, cout),
+            "dgrad": lambda: nv.spconv_fwd(dy, w, nbr_b, nd, n, cin, transpose_w=True),
+            "wgrad": lambda: nv.spconv_wgrad(x, dy, nbr, nd, kvol),
+        }
+        for pname, fn in passes.items():
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            print(f"{name:12s} {pname:6s} N={n} {cin}->{cout} K={kvol}: {ms:8.4f} ms  {flops / ms / 1e9:8.1f} TF/s  {byt / ms / 1e6:8.1f} GB/s", flush=True)
+        if a.check:
+            m = min(n, 4096)
+            got = nv.spconv_fwd(x, w, nbr, nd, n, cout)[:m].float()
+            exp = ref_fwd(x, w, nbr, m)
+            err = (got - exp).abs().max().item() / max(1.0, exp.abs().max().item())
+            gd = nv.spconv_fwd(dy, w, nbr_b, nd, n, cin, transpose_w=True)[:m].float()
+            ed = ref_fwd(dy, w.transpose(1, 2), nbr_b, m)
+            errd = (gd - ed).abs().max().item() / max(1.0, ed.abs().max().item())
+            print(f"{name:12s} check: fwd rel err {err:.2e}  dgrad rel err {errd:.2e}", flush=True)
+            assert err < 2e-2 and errd < 2e-2
+
+
+if __name__ == "__main__":
+    main()

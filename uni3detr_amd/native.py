@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libu3d_hip.so")
+LIB_PATH = os.environ.get("U3D_LIB_PATH") or os.path.join(_HERE, "libu3d_hip.so")      # override: kernel experiments (tools/build_variant.sh)
 
 F32, BF16 = 0, 1
 
