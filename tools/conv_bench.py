@@ -77,8 +77,16 @@ def main():
             gd = nv.spconv_fwd(dy, w, nbr_b, nd, n, cin, transpose_w=True)[:m].float()
             ed = ref_fwd(dy, w.transpose(1, 2), nbr_b, m)
             errd = (gd - ed).abs().max().item() / max(1.0, ed.abs().max().item())
-            print(f"{name:12s} check: fwd rel err {err:.2e}  dgrad rel err {errd:.2e}", flush=True)
-            assert err < 2e-2 and errd < 2e-2
+            gw = nv.spconv_wgrad(x, dy, nbr, nd, kvol)
+            errw = 0.0
+            xf = torch.cat([x.float(), torch.zeros(1, cin, device=dev)])
+            for k in sorted({0, kvol // 2, kvol - 1}):
+                idx = nbr[k, :n].long()
+                idx = torch.where(idx < 0, torch.full_like(idx, n), idx)
+                ew = xf[idx].t() @ dy.float()
+                errw = max(errw, (gw[k] - ew).abs().max().item() / max(1.0, ew.abs().max().item()))
+            print(f"{name:12s} check: fwd rel err {err:.2e}  dgrad rel err {errd:.2e}  wgrad rel err {errw:.2e}", flush=True)
+            assert err < 2e-2 and errd < 2e-2 and errw < 2e-2
 
 
 if __name__ == "__main__":

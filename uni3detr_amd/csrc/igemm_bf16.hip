@@ -18,7 +18,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef IGEMM_PP
-#define IGEMM_PP 1       /* 1: 256x256 tiles run the ping-pong kernel (k_igemm_pp), 0: k_igemm_fwd<2,4,8,4> */
+#define IGEMM_PP 0       /* 1: 256x256 tiles run the experimental ping-pong kernel (k_igemm_pp; measured on par with k_igemm_fwd<2,4,8,4>: DESIGN.md) */
 #endif
 #ifndef IGEMM_STORE_KS
 #define IGEMM_STORE_KS 0   /* k-step after which the next stage's registers are written to LDS (0: mid-stage, 1: end of stage) */
@@ -539,6 +539,10 @@ extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32
     return transpose_w ? launch_igemm_pp<false>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s)
                        : launch_igemm_pp<true>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
 #endif
+  // few row tiles (the stride-4 branch of SECOND3D: 12000 rows): 256 x 256 tiles leave most CUs idle -> narrower tiles
+  const long long wg256 = (long long)u3d_cdiv(n_out_cap, 256) * (cout / 256 > 0 ? cout / 256 : 1);
+  if (cout % 256 == 0 && wg256 < 128) { IG_CASE(4, 2, 4, 4) }       // measured: 94 workgroups (N=12000, 512 ch) 0.136 -> 0.100 ms;
+                                                                    // 188 workgroups (N=48000, 256 ch) stay faster on 256 x 256
   if (cout >= 256 && cout % 256 == 0) { IG_CASE(2, 4, 8, 4) }       // 256 x 256
   if (cout >= 128 && cout % 128 == 0) { IG_CASE(4, 2, 4, 4) }       // 256 x 128
   if (cout % 64 == 0) { IG_CASE(4, 1, 2, 4) }                        // 128 x 64: 57 KB LDS -> 2 workgroups per CU hide the gather latency
@@ -581,69 +585,157 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_wgrad(const u16
   const int per = (ntiles + nsplit - 1) / nsplit;
   const int t_begin = split * per, t_end = min(ntiles, t_begin + per);
 
-  uint4 ra[A_SEGS], rd[D_SEGS];
-  int src_cur[A_SEGS], src_nxt[A_SEGS];
-  auto load_src_next = [&](int t) {                     // gather indices of stage t, fetched one stage early
-    const int r0 = t * RK;
-#pragma unroll
-    for (int u = 0; u < A_SEGS; ++u) {
-      int m = r0 + (tid + u * NT) / (TM / 8);
-      src_nxt[u] = (t < t_end && m < n_out) ? (nbr ? nbr[(long long)kap * ld + m] : m) : -1;
-    }
-  };
-  auto issue_loads = [&](int t) {
-    const int r0 = t * RK;
-#pragma unroll
-    for (int u = 0; u < A_SEGS; ++u) src_cur[u] = src_nxt[u];
-    load_src_next(t + 1);
-#pragma unroll
+  // Two operand-fetch variants (measured, tools/conv_bench.py): raw buffer loads + branch-free stage body win for the 128 / 64 /
+  // 32 / 16 tiles (+35...65 %), the 256 x 256 tile schedules better with the plain predicated loads (879 vs 707 TFLOP/s).
+  if constexpr (TM < 256) {
+    // operand fetch as in k_igemm_fwd: raw buffer loads, missing rows = out-of-range offset (hardware zero fill), one branch-free
+    // stage body, gather indices consumed one stage after they were requested
+    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc((void*)dout, 0, -1, 0x00020000);
+    const unsigned in_row_bytes = (unsigned)cin * 2u, d_row_bytes = (unsigned)cout * 2u;
+    int a_row[A_SEGS], d_row[D_SEGS];
+    unsigned a_col[A_SEGS], d_col[D_SEGS];
+  #pragma unroll
     for (int u = 0; u < A_SEGS; ++u) {
       int sgi = tid + u * NT;
-      int part = sgi % (TM / 8);
-      int src = src_cur[u];
-      int c = ci0 + part * 8;
-      ra[u] = (src >= 0 && c < cin) ? *(const uint4*)(in + (long long)src * cin + c) : make_uint4(0, 0, 0, 0);
+      a_row[u] = sgi / (TM / 8);
+      int c = ci0 + (sgi % (TM / 8)) * 8;
+      a_col[u] = c < cin ? (unsigned)c * 2u : 0xFFFFFFFFu;
     }
-#pragma unroll
+  #pragma unroll
     for (int u = 0; u < D_SEGS; ++u) {
       int sgi = tid + u * NT;
-      int row = sgi / (TN / 8), part = sgi % (TN / 8);
-      int m = r0 + row;
-      int c = co0 + part * 8;
-      rd[u] = (m < n_out && c < cout) ? *(const uint4*)(dout + (long long)m * cout + c) : make_uint4(0, 0, 0, 0);
+      d_row[u] = sgi / (TN / 8);
+      int c = co0 + (sgi % (TN / 8)) * 8;
+      d_col[u] = c < cout ? (unsigned)c * 2u : 0xFFFFFFFFu;
     }
-  };
-  auto store_lds = [&](int buf) {
-#pragma unroll
-    for (int u = 0; u < A_SEGS; ++u) { int sgi = tid + u * NT; *(uint4*)(smem + buf * STAGE_ELEMS + (sgi / (TM / 8)) * LDA + (sgi % (TM / 8)) * 8) = ra[u]; }
-#pragma unroll
-    for (int u = 0; u < D_SEGS; ++u) { int sgi = tid + u * NT; *(uint4*)(smem + buf * STAGE_ELEMS + A_ELEMS + (sgi / (TN / 8)) * LDD + (sgi % (TN / 8)) * 8) = rd[u]; }
-  };
-
-  if (t_begin < t_end) {
-    load_src_next(t_begin);
-    issue_loads(t_begin);
-    store_lds(0);
-    __syncthreads();
-    for (int t = t_begin; t < t_end; ++t) {
-      const int buf = (t - t_begin) & 1;
-      if (t + 1 < t_end) issue_loads(t + 1);
-      const u16* A = smem + buf * STAGE_ELEMS;
-      const u16* D = A + A_ELEMS;
-#pragma unroll
-      for (int ks = 0; ks < RK / 32; ++ks) {
-        bf16x8 bfr[WN];
-#pragma unroll
-        for (int b = 0; b < WN; ++b) bfr[b] = tr_frag(D, LDD, ks * 32, (wn * WN + b) * 16, lane);
-#pragma unroll
-        for (int a = 0; a < WM; ++a) {
-          bf16x8 af = tr_frag(A, LDA, ks * 32, (wm * WM + a) * 16, lane);
-#pragma unroll
-          for (int b = 0; b < WN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[b], acc[a][b], 0, 0, 0);
-        }
-        if (ks == 0 && t + 1 < t_end) store_lds(buf ^ 1);     // under the second k-step's MFMAs (see k_igemm_fwd)
+    u32x4 ra[A_SEGS], rd[D_SEGS];
+    int src_nxt[A_SEGS];
+    auto load_src_next = [&](int t) {                     // gather indices of stage t, fetched one stage early (raw: masked at use)
+      const int r0 = t * RK;
+  #pragma unroll
+      for (int u = 0; u < A_SEGS; ++u) {
+        int m = r0 + a_row[u];
+        int mc = m < n_out ? m : n_out - 1;
+        src_nxt[u] = nbr ? nbr[(long long)kap * ld + mc] : mc;
       }
+    };
+    auto issue_loads = [&](int t) {
+      const int r0 = t * RK;
+      const bool live = t < t_end;
+  #pragma unroll
+      for (int u = 0; u < A_SEGS; ++u) {
+        const bool ok = live && (r0 + a_row[u] < n_out) && src_nxt[u] >= 0 && a_col[u] != 0xFFFFFFFFu;
+        unsigned voff = ok ? (unsigned)src_nxt[u] * in_row_bytes + a_col[u] : 0xFFFFFFFFu;
+        ra[u] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, voff, 0, 0);
+      }
+  #pragma unroll
+      for (int u = 0; u < D_SEGS; ++u) {
+        const int m = r0 + d_row[u];
+        const bool ok = live && m < n_out && d_col[u] != 0xFFFFFFFFu;
+        unsigned voff = ok ? (unsigned)m * d_row_bytes + d_col[u] : 0xFFFFFFFFu;
+        rd[u] = __builtin_amdgcn_raw_buffer_load_b128(d_rs, voff, 0, 0);
+      }
+      load_src_next(t + 1);
+    };
+    auto store_lds = [&](int buf) {
+  #pragma unroll
+      for (int u = 0; u < A_SEGS; ++u) { int sgi = tid + u * NT; *(u32x4*)(smem + buf * STAGE_ELEMS + a_row[u] * LDA + (sgi % (TM / 8)) * 8) = ra[u]; }
+  #pragma unroll
+      for (int u = 0; u < D_SEGS; ++u) { int sgi = tid + u * NT; *(u32x4*)(smem + buf * STAGE_ELEMS + A_ELEMS + d_row[u] * LDD + (sgi % (TN / 8)) * 8) = rd[u]; }
+    };
+
+    if (t_begin < t_end) {
+      load_src_next(t_begin);
+      issue_loads(t_begin);
+      store_lds(0);
       __syncthreads();
+      for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        issue_loads(t + 1);                               // past the last stage: all offsets out of range -> zeros into the idle buffer
+        const u16* A = smem + buf * STAGE_ELEMS;
+        const u16* D = A + A_ELEMS;
+  #pragma unroll
+        for (int ks = 0; ks < RK / 32; ++ks) {
+          bf16x8 bfr[WN];
+  #pragma unroll
+          for (int b = 0; b < WN; ++b) bfr[b] = tr_frag(D, LDD, ks * 32, (wn * WN + b) * 16, lane);
+  #pragma unroll
+          for (int a = 0; a < WM; ++a) {
+            bf16x8 af = tr_frag(A, LDA, ks * 32, (wm * WM + a) * 16, lane);
+  #pragma unroll
+            for (int b = 0; b < WN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[b], acc[a][b], 0, 0, 0);
+          }
+          if (ks == 0) store_lds(buf ^ 1);                // under the second k-step's MFMAs (see k_igemm_fwd)
+        }
+        __syncthreads();
+      }
+    }
+  } else {
+    uint4 ra[A_SEGS], rd[D_SEGS];
+    int src_cur[A_SEGS], src_nxt[A_SEGS];
+    auto load_src_next = [&](int t) {                     // gather indices of stage t, fetched one stage early
+      const int r0 = t * RK;
+  #pragma unroll
+      for (int u = 0; u < A_SEGS; ++u) {
+        int m = r0 + (tid + u * NT) / (TM / 8);
+        src_nxt[u] = (t < t_end && m < n_out) ? (nbr ? nbr[(long long)kap * ld + m] : m) : -1;
+      }
+    };
+    auto issue_loads = [&](int t) {
+      const int r0 = t * RK;
+  #pragma unroll
+      for (int u = 0; u < A_SEGS; ++u) src_cur[u] = src_nxt[u];
+      load_src_next(t + 1);
+  #pragma unroll
+      for (int u = 0; u < A_SEGS; ++u) {
+        int sgi = tid + u * NT;
+        int part = sgi % (TM / 8);
+        int src = src_cur[u];
+        int c = ci0 + part * 8;
+        ra[u] = (src >= 0 && c < cin) ? *(const uint4*)(in + (long long)src * cin + c) : make_uint4(0, 0, 0, 0);
+      }
+  #pragma unroll
+      for (int u = 0; u < D_SEGS; ++u) {
+        int sgi = tid + u * NT;
+        int row = sgi / (TN / 8), part = sgi % (TN / 8);
+        int m = r0 + row;
+        int c = co0 + part * 8;
+        rd[u] = (m < n_out && c < cout) ? *(const uint4*)(dout + (long long)m * cout + c) : make_uint4(0, 0, 0, 0);
+      }
+    };
+    auto store_lds = [&](int buf) {
+  #pragma unroll
+      for (int u = 0; u < A_SEGS; ++u) { int sgi = tid + u * NT; *(uint4*)(smem + buf * STAGE_ELEMS + (sgi / (TM / 8)) * LDA + (sgi % (TM / 8)) * 8) = ra[u]; }
+  #pragma unroll
+      for (int u = 0; u < D_SEGS; ++u) { int sgi = tid + u * NT; *(uint4*)(smem + buf * STAGE_ELEMS + A_ELEMS + (sgi / (TN / 8)) * LDD + (sgi % (TN / 8)) * 8) = rd[u]; }
+    };
+
+    if (t_begin < t_end) {
+      load_src_next(t_begin);
+      issue_loads(t_begin);
+      store_lds(0);
+      __syncthreads();
+      for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        if (t + 1 < t_end) issue_loads(t + 1);
+        const u16* A = smem + buf * STAGE_ELEMS;
+        const u16* D = A + A_ELEMS;
+  #pragma unroll
+        for (int ks = 0; ks < RK / 32; ++ks) {
+          bf16x8 bfr[WN];
+  #pragma unroll
+          for (int b = 0; b < WN; ++b) bfr[b] = tr_frag(D, LDD, ks * 32, (wn * WN + b) * 16, lane);
+  #pragma unroll
+          for (int a = 0; a < WM; ++a) {
+            bf16x8 af = tr_frag(A, LDA, ks * 32, (wm * WM + a) * 16, lane);
+  #pragma unroll
+            for (int b = 0; b < WN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[b], acc[a][b], 0, 0, 0);
+          }
+          if (ks == 0 && t + 1 < t_end) store_lds(buf ^ 1);     // under the second k-step's MFMAs (see k_igemm_fwd)
+        }
+        __syncthreads();
+      }
     }
   }
   float* p = partial + ((long long)split * kvol + kap) * cin * cout;
