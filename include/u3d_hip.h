@@ -187,13 +187,14 @@ int32_t u3d_bn_apply(const void* x, const float* mean, const float* invstd, cons
                      const float* beta, const void* residual, int32_t relu, void* y,
                      const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, u3d_stream s);
 /* backward: given dy (grad wrt y), y (for relu mask), x: sums f64 [2*C] = (sum g, sum g*xhat) where
- * g = dy * (y>0 if relu). */
+ * g = dy * (y>0 if relu).  y may be NULL when relu is set and the forward had NO residual: the mask is then recomputed as
+ * (x-mean)*invstd*gamma+beta > 0 (the forward's own expression; gamma/beta required) - one tensor less to stream. */
 int32_t u3d_bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
-                         int32_t relu, const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype,
-                         double* sums, void* workspace, int64_t workspace_bytes, u3d_stream s);
-/* dx = gamma*invstd*( g - sum_g/n - xhat*sum_gx/n ); dres = g (optional, may be NULL). */
+                         const float* gamma, const float* beta, int32_t relu, const int32_t* n_dev, int32_t n_cap,
+                         int32_t c, int32_t dtype, double* sums, void* workspace, int64_t workspace_bytes, u3d_stream s);
+/* dx = gamma*invstd*( g - sum_g/n - xhat*sum_gx/n ); dres = g (optional, may be NULL).  y NULL: as above (beta required). */
 int32_t u3d_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
-                         const float* gamma, const double* sums, int32_t relu, void* dx, void* dres,
+                         const float* gamma, const float* beta, const double* sums, int32_t relu, void* dx, void* dres,
                          const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------

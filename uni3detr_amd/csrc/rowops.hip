@@ -43,7 +43,8 @@ __device__ __forceinline__ void load_vec<u16>(const u16* p, float* out) {
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void k_col_stats_vec(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
-                                                       const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
                                                        const int* __restrict__ n_dev, int n_cap, int c, double* __restrict__ partial) {
   constexpr int V = VecOf<T>::N;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -62,10 +63,15 @@ __global__ __launch_bounds__(256) void k_col_stats_vec(const T* __restrict__ x, 
     for (int e = 0; e < V; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
     const bool active = vc < cv && trow < rl;
     if (active) {
-      float mu[V], is[V];
+      float mu[V], is[V], ga[V], be[V];
+      const bool remask = MODE == 1 && relu && y == nullptr;     // ReLU mask recomputed from x (no residual): one tensor less to read
       if (MODE == 1) {
 #pragma unroll
         for (int e = 0; e < V; ++e) { mu[e] = mean[vc * V + e]; is[e] = invstd[vc * V + e]; }
+        if (remask) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) { ga[e] = gamma[vc * V + e]; be[e] = beta[vc * V + e]; }
+        }
       }
       for (int r = r0 + trow; r < r1; r += rl) {
         const long long o = (long long)r * c + (long long)vc * V;
@@ -77,10 +83,11 @@ __global__ __launch_bounds__(256) void k_col_stats_vec(const T* __restrict__ x, 
         } else {
           float gv[V], yv[V];
           load_vec<T>(dy + o, gv);
-          if (relu) load_vec<T>(y + o, yv);
+          if (relu && !remask) load_vec<T>(y + o, yv);
 #pragma unroll
           for (int e = 0; e < V; ++e) {
             float g = gv[e];
+            if (remask) yv[e] = (xv[e] - mu[e]) * is[e] * ga[e] + be[e];
             if (relu && !(yv[e] > 0.f)) g = 0.f;
             s0[e] += g;
             s1[e] += g * ((xv[e] - mu[e]) * is[e]);
@@ -112,7 +119,8 @@ __global__ __launch_bounds__(256) void k_col_stats_vec(const T* __restrict__ x, 
 // scalar fallback for channel counts that are not a multiple of the vector width
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void k_col_stats(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
-                                                   const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
                                                    const int* __restrict__ n_dev, int n_cap, int c, double* __restrict__ partial) {
   __shared__ double red[2][256];
   const int n = min(*n_dev, n_cap);
@@ -125,8 +133,10 @@ __global__ __launch_bounds__(256) void k_col_stats(const T* __restrict__ x, cons
     int col = cb + tcol;
     double s0 = 0.0, s1 = 0.0;
     if (col < c && trow < rl) {
-      float mu = 0.f, is = 0.f;
+      float mu = 0.f, is = 0.f, ga = 0.f, be = 0.f;
+      const bool remask = MODE == 1 && relu && y == nullptr;
       if (MODE == 1) { mu = mean[col]; is = invstd[col]; }
+      if (remask) { ga = gamma[col]; be = beta[col]; }
       for (int r = r0 + trow; r < r1; r += rl) {
         long long o = (long long)r * c + col;
         if (MODE == 0) {
@@ -135,7 +145,8 @@ __global__ __launch_bounds__(256) void k_col_stats(const T* __restrict__ x, cons
           s1 += (double)v * (double)v;
         } else {
           float g = ld_elem(dy, o);
-          if (relu && !(ld_elem(y, o) > 0.f)) g = 0.f;
+          float yv = remask ? (ld_elem(x, o) - mu) * is * ga + be : (relu ? ld_elem(y, o) : 1.f);
+          if (relu && !(yv > 0.f)) g = 0.f;
           float xh = (ld_elem(x, o) - mu) * is;
           s0 += (double)g;
           s1 += (double)g * (double)xh;
@@ -176,8 +187,8 @@ extern "C" int64_t u3d_bn_stats_workspace(int32_t n_cap, int32_t c) {
 }
 
 template <int MODE>
-static int run_stats(const void* x, const void* dy, const void* y, const float* mean, const float* invstd, int relu,
-                     const int32_t* n_dev, int n_cap, int c, int dtype, double* sums, void* ws, int64_t ws_bytes, hipStream_t s) {
+static int run_stats(const void* x, const void* dy, const void* y, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, int relu, const int32_t* n_dev, int n_cap, int c, int dtype, double* sums, void* ws, int64_t ws_bytes, hipStream_t s) {
   U3D_REQUIRE(x && n_dev && sums && ws && c > 0, U3D_ERR_ARG);
   if (n_cap <= 0) { hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, s); return U3D_OK; }
   U3D_REQUIRE(ws_bytes >= u3d_bn_stats_workspace(n_cap, c), U3D_ERR_WORKSPACE);
@@ -186,17 +197,17 @@ static int run_stats(const void* x, const void* dy, const void* y, const float* 
     if (c % 4 == 0) {
       int cw = (c / 4) < 256 ? (c / 4) : 256; int rl = 256 / cw;
       size_t lds = (size_t)2 * rl * cw * 4 * sizeof(double);
-      hipLaunchKernelGGL((k_col_stats_vec<float, MODE>), dim3(nb), dim3(256), lds, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, relu, n_dev, n_cap, c, (double*)ws);
+      hipLaunchKernelGGL((k_col_stats_vec<float, MODE>), dim3(nb), dim3(256), lds, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws);
     } else {
-      hipLaunchKernelGGL((k_col_stats<float, MODE>), dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, relu, n_dev, n_cap, c, (double*)ws);
+      hipLaunchKernelGGL((k_col_stats<float, MODE>), dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws);
     }
   } else if (dtype == U3D_BF16) {
     if (c % 8 == 0) {
       int cw = (c / 8) < 256 ? (c / 8) : 256; int rl = 256 / cw;
       size_t lds = (size_t)2 * rl * cw * 8 * sizeof(double);
-      hipLaunchKernelGGL((k_col_stats_vec<u16, MODE>), dim3(nb), dim3(256), lds, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, relu, n_dev, n_cap, c, (double*)ws);
+      hipLaunchKernelGGL((k_col_stats_vec<u16, MODE>), dim3(nb), dim3(256), lds, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws);
     } else {
-      hipLaunchKernelGGL((k_col_stats<u16, MODE>), dim3(nb), dim3(256), 0, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, relu, n_dev, n_cap, c, (double*)ws);
+      hipLaunchKernelGGL((k_col_stats<u16, MODE>), dim3(nb), dim3(256), 0, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws);
     }
   } else return U3D_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_col_stats_final, dim3(u3d_cdiv(2 * c, 4)), dim3(256), 0, s, (const double*)ws, nb, n_dev, n_cap, c, sums);
@@ -206,13 +217,13 @@ static int run_stats(const void* x, const void* dy, const void* y, const float* 
 
 extern "C" int32_t u3d_bn_stats(const void* x, const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, double* sums,
                                 void* workspace, int64_t workspace_bytes, u3d_stream s) {
-  return run_stats<0>(x, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, dtype, sums, workspace, workspace_bytes, s);
+  return run_stats<0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, dtype, sums, workspace, workspace_bytes, s);
 }
 extern "C" int32_t u3d_bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
-                                    int32_t relu, const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, double* sums,
-                                    void* workspace, int64_t workspace_bytes, u3d_stream s) {
-  U3D_REQUIRE(dy && mean && invstd && (!relu || y), U3D_ERR_ARG);
-  return run_stats<1>(x, dy, y, mean, invstd, relu, n_dev, n_cap, c, dtype, sums, workspace, workspace_bytes, s);
+                                    const float* gamma, const float* beta, int32_t relu, const int32_t* n_dev, int32_t n_cap,
+                                    int32_t c, int32_t dtype, double* sums, void* workspace, int64_t workspace_bytes, u3d_stream s) {
+  U3D_REQUIRE(dy && mean && invstd && (!relu || y || (gamma && beta)), U3D_ERR_ARG);
+  return run_stats<1>(x, dy, y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, dtype, sums, workspace, workspace_bytes, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -336,21 +347,115 @@ __global__ void k_bn_apply(const T* __restrict__ x, const float* __restrict__ me
 template <typename T>
 __global__ void k_bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
                                const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-                               const double* __restrict__ sums, int relu, T* __restrict__ dx, T* __restrict__ dres,
-                               const int* __restrict__ n_dev, int n_cap, int c) {
+                               const float* __restrict__ beta, const double* __restrict__ sums, int relu, T* __restrict__ dx,
+                               T* __restrict__ dres, const int* __restrict__ n_dev, int n_cap, int c) {
   int n = min(*n_dev, n_cap);
   long long total = (long long)n * c;
   double inv_n = n > 0 ? 1.0 / (double)n : 0.0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     int col = (int)(i % c);
     float g = ld_elem(dy, i);
-    if (relu && !(ld_elem(y, i) > 0.f)) g = 0.f;
+    if (relu) {
+      float yv = y ? ld_elem(y, i) : (ld_elem(x, i) - mean[col]) * invstd[col] * gamma[col] + beta[col];
+      if (!(yv > 0.f)) g = 0.f;
+    }
     float is = invstd[col];
     float xh = (ld_elem(x, i) - mean[col]) * is;
     float mg = (float)(sums[col] * inv_n), mgx = (float)(sums[c + col] * inv_n);
     st_elem(dx, i, gamma[col] * is * (g - mg - xh * mgx));
     if (dres) st_elem(dres, i, g);
   }
+}
+
+// Vectorized forms (C a multiple of the 16-byte vector width and C/V a divisor of 256): a thread keeps ONE column group, so the
+// per-column parameters live in registers; 16-byte loads/stores; rows strided over the grid.
+template <typename T>
+__device__ __forceinline__ void store_vec(T* p, const float* v);
+template <>
+__device__ __forceinline__ void store_vec<float>(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+template <>
+__device__ __forceinline__ void store_vec<u16>(u16* p, const float* v) {
+  unsigned w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u16 lo, hi;
+    st_elem(&lo, 0, v[2 * i]);
+    st_elem(&hi, 0, v[2 * i + 1]);
+    w[i] = (unsigned)lo | ((unsigned)hi << 16);
+  }
+  *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_apply_vec(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const T* __restrict__ res, int relu, T* __restrict__ y,
+                                                      const int* __restrict__ n_dev, int n_cap, int c) {
+  constexpr int V = VecOf<T>::N;
+  const int n = min(*n_dev, n_cap), cv = c / V, rpb = 256 / cv;
+  const int vc = threadIdx.x % cv, rl = threadIdx.x / cv;
+  float mu[V], is[V], ga[V], be[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { mu[e] = mean[vc * V + e]; is[e] = invstd[vc * V + e]; ga[e] = gamma[vc * V + e]; be[e] = beta[vc * V + e]; }
+  for (int r = blockIdx.x * rpb + rl; r < n; r += gridDim.x * rpb) {
+    const long long o = (long long)r * c + (long long)vc * V;
+    float xv[V], rv[V], out[V];
+    load_vec<T>(x + o, xv);
+    if (res) load_vec<T>(res + o, rv);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float v = (xv[e] - mu[e]) * is[e] * ga[e] + be[e];
+      if (res) v += rv[e];
+      if (relu) v = v > 0.f ? v : 0.f;
+      out[e] = v;
+    }
+    store_vec<T>(y + o, out);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_vec(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const double* __restrict__ sums, int relu, T* __restrict__ dx,
+                                                          T* __restrict__ dres, const int* __restrict__ n_dev, int n_cap, int c) {
+  constexpr int V = VecOf<T>::N;
+  const int n = min(*n_dev, n_cap), cv = c / V, rpb = 256 / cv;
+  const int vc = threadIdx.x % cv, rl = threadIdx.x / cv;
+  const double inv_n = n > 0 ? 1.0 / (double)n : 0.0;
+  const bool remask = relu && y == nullptr;
+  float mu[V], is[V], ga[V], be[V], mg[V], mgx[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const int col = vc * V + e;
+    mu[e] = mean[col]; is[e] = invstd[col]; ga[e] = gamma[col]; be[e] = remask ? beta[col] : 0.f;
+    mg[e] = (float)(sums[col] * inv_n); mgx[e] = (float)(sums[c + col] * inv_n);
+  }
+  for (int r = blockIdx.x * rpb + rl; r < n; r += gridDim.x * rpb) {
+    const long long o = (long long)r * c + (long long)vc * V;
+    float gv[V], xv[V], yv[V], dxv[V];
+    load_vec<T>(dy + o, gv);
+    load_vec<T>(x + o, xv);
+    if (relu && !remask) load_vec<T>(y + o, yv);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float g = gv[e];
+      if (remask) yv[e] = (xv[e] - mu[e]) * is[e] * ga[e] + be[e];
+      if (relu && !(yv[e] > 0.f)) g = 0.f;
+      const float xh = (xv[e] - mu[e]) * is[e];
+      dxv[e] = ga[e] * is[e] * (g - mg[e] - xh * mgx[e]);
+      gv[e] = g;
+    }
+    store_vec<T>(dx + o, dxv);
+    if (dres) store_vec<T>(dres + o, gv);
+  }
+}
+
+static inline bool bn_vec_ok(int c, int v) { return c % v == 0 && (c / v) <= 256 && 256 % (c / v) == 0; }
+static inline int bn_vec_grid(int n_cap, int c, int v) {
+  int rpb = 256 / (c / v);
+  long long b = ((long long)n_cap + rpb - 1) / rpb;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
 static inline int ew_grid(long long total) {
@@ -364,7 +469,11 @@ extern "C" int32_t u3d_bn_apply(const void* x, const float* mean, const float* i
   U3D_REQUIRE(x && mean && invstd && gamma && beta && y && n_dev && c > 0, U3D_ERR_ARG);
   if (n_cap <= 0) return U3D_OK;
   int g = ew_grid((long long)n_cap * c);
-  if (dtype == U3D_F32)
+  if (dtype == U3D_F32 && bn_vec_ok(c, 4))
+    hipLaunchKernelGGL(k_bn_apply_vec<float>, dim3(bn_vec_grid(n_cap, c, 4)), dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const float*)residual, relu, (float*)y, n_dev, n_cap, c);
+  else if (dtype == U3D_BF16 && bn_vec_ok(c, 8))
+    hipLaunchKernelGGL(k_bn_apply_vec<u16>, dim3(bn_vec_grid(n_cap, c, 8)), dim3(256), 0, s, (const u16*)x, mean, invstd, gamma, beta, (const u16*)residual, relu, (u16*)y, n_dev, n_cap, c);
+  else if (dtype == U3D_F32)
     hipLaunchKernelGGL(k_bn_apply<float>, dim3(g), dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const float*)residual, relu, (float*)y, n_dev, n_cap, c);
   else if (dtype == U3D_BF16)
     hipLaunchKernelGGL(k_bn_apply<u16>, dim3(g), dim3(256), 0, s, (const u16*)x, mean, invstd, gamma, beta, (const u16*)residual, relu, (u16*)y, n_dev, n_cap, c);
@@ -374,15 +483,19 @@ extern "C" int32_t u3d_bn_apply(const void* x, const float* mean, const float* i
 }
 
 extern "C" int32_t u3d_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
-                                    const float* gamma, const double* sums, int32_t relu, void* dx, void* dres,
+                                    const float* gamma, const float* beta, const double* sums, int32_t relu, void* dx, void* dres,
                                     const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, u3d_stream s) {
-  U3D_REQUIRE(dy && x && mean && invstd && gamma && sums && dx && n_dev && c > 0 && (!relu || y), U3D_ERR_ARG);
+  U3D_REQUIRE(dy && x && mean && invstd && gamma && sums && dx && n_dev && c > 0 && (!relu || y || beta), U3D_ERR_ARG);
   if (n_cap <= 0) return U3D_OK;
   int g = ew_grid((long long)n_cap * c);
-  if (dtype == U3D_F32)
-    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(256), 0, s, (const float*)dy, (const float*)y, (const float*)x, mean, invstd, gamma, sums, relu, (float*)dx, (float*)dres, n_dev, n_cap, c);
+  if (dtype == U3D_F32 && bn_vec_ok(c, 4))
+    hipLaunchKernelGGL(k_bn_bwd_apply_vec<float>, dim3(bn_vec_grid(n_cap, c, 4)), dim3(256), 0, s, (const float*)dy, (const float*)y, (const float*)x, mean, invstd, gamma, beta, sums, relu, (float*)dx, (float*)dres, n_dev, n_cap, c);
+  else if (dtype == U3D_BF16 && bn_vec_ok(c, 8))
+    hipLaunchKernelGGL(k_bn_bwd_apply_vec<u16>, dim3(bn_vec_grid(n_cap, c, 8)), dim3(256), 0, s, (const u16*)dy, (const u16*)y, (const u16*)x, mean, invstd, gamma, beta, sums, relu, (u16*)dx, (u16*)dres, n_dev, n_cap, c);
+  else if (dtype == U3D_F32)
+    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(256), 0, s, (const float*)dy, (const float*)y, (const float*)x, mean, invstd, gamma, beta, sums, relu, (float*)dx, (float*)dres, n_dev, n_cap, c);
   else if (dtype == U3D_BF16)
-    hipLaunchKernelGGL(k_bn_bwd_apply<u16>, dim3(g), dim3(256), 0, s, (const u16*)dy, (const u16*)y, (const u16*)x, mean, invstd, gamma, sums, relu, (u16*)dx, (u16*)dres, n_dev, n_cap, c);
+    hipLaunchKernelGGL(k_bn_bwd_apply<u16>, dim3(g), dim3(256), 0, s, (const u16*)dy, (const u16*)y, (const u16*)x, mean, invstd, gamma, beta, sums, relu, (u16*)dx, (u16*)dres, n_dev, n_cap, c);
   else return U3D_ERR_UNSUPPORTED;
   U3D_CHECK_LAUNCH();
   return U3D_OK;

@@ -62,8 +62,8 @@ _SIGS = {
     "u3d_bn_stats": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _P]),
     "u3d_bn_finalize": (_I, [_P, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     "u3d_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
-    "u3d_bn_bwd_stats": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
-    "u3d_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "u3d_bn_bwd_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
+    "u3d_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "u3d_to_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     "u3d_from_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     "u3d_fps": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _L, _P]),
@@ -358,21 +358,22 @@ def bn_apply(x, mean, invstd, gamma, beta, residual, relu, n_dev):
     return y
 
 
-def bn_bwd_stats(dy, y, x, mean, invstd, relu, n_dev):
+def bn_bwd_stats(dy, y, x, mean, invstd, relu, n_dev, gamma=None, beta=None):
+    """y may be None (relu, no residual in the forward): the ReLU mask is recomputed from x with gamma/beta."""
     n, c = x.shape
     sums = torch.empty((2, c), dtype=torch.float64, device=x.device)
     wsb = int(lib().u3d_bn_stats_workspace(n, c))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-    _check(lib().u3d_bn_bwd_stats(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), int(relu), _ptr(n_dev), n, c,
+    _check(lib().u3d_bn_bwd_stats(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), int(relu), _ptr(n_dev), n, c,
                                   dtype_code(x), _ptr(sums), _ptr(ws), wsb, _stream()), "bn_bwd_stats")
     return sums
 
 
-def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, relu, n_dev, want_dres):
+def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, relu, n_dev, want_dres, beta=None):
     n, c = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
-    _check(lib().u3d_bn_bwd_apply(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums), int(relu),
+    _check(lib().u3d_bn_bwd_apply(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(sums), int(relu),
                                   _ptr(dx), _ptr(dres), _ptr(n_dev), n, c, dtype_code(x), _stream()), "bn_bwd_apply")
     return dx, dres
 

@@ -123,22 +123,24 @@ class _BNRows(torch.autograd.Function):
             invstd = torch.rsqrt(bn.running_var + bn.eps)
         g32, b32 = gamma.float(), beta.float()
         y = nv.bn_apply(x, mean, invstd, g32, b32, residual, relu, n_dev)
-        ctx.save_for_backward(x, y, mean, invstd, g32)
+        # ReLU without residual: the backward recomputes the mask from x (same expression) instead of streaming y again
+        ctx.remask = bool(relu and residual is None)
+        ctx.save_for_backward(x, None if ctx.remask else y, mean, invstd, g32, b32)
         ctx.n_dev, ctx.relu, ctx.training, ctx.has_res = n_dev, relu, training, residual is not None
         ctx.pdtype = gamma.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, invstd, gamma = ctx.saved_tensors
+        x, y, mean, invstd, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
-        sums = nv.bn_bwd_stats(dy, y, x, mean, invstd, ctx.relu, ctx.n_dev)
+        sums = nv.bn_bwd_stats(dy, y, x, mean, invstd, ctx.relu, ctx.n_dev, gamma, beta)
         if not ctx.training:
             # eval statistics are constants: dx = gamma*invstd*g
             zero = torch.zeros_like(sums)
-            dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, zero, ctx.relu, ctx.n_dev, ctx.has_res)
+            dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, zero, ctx.relu, ctx.n_dev, ctx.has_res, beta)
         else:
-            dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, ctx.relu, ctx.n_dev, ctx.has_res)
+            dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, ctx.relu, ctx.n_dev, ctx.has_res, beta)
         s32 = sums.to(ctx.pdtype)
         return dx, s32[1], s32[0], dres, None, None, None, None
 
