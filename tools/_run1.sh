@@ -1,4 +1,3 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_sparse_gpu.py -x -q -m gpu -k "bn_fwd_bwd" 2>&1 | tail -12
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_h.json 2> gpurun_out/bench_h.err; tail -c 400 gpurun_out/bench_h.err; cut -c1-420 gpurun_out/bench_h.json
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_i.json 2> gpurun_out/bench_i.err; cut -c1-330 gpurun_out/bench_i.json
+timeout 800 bash tools/prof_stats.sh r01_i_graph_bf16 python bench.py --steps 10 --warmup 3 --no-roofline --no-cpu-baseline

@@ -20,7 +20,7 @@ __device__ __forceinline__ void st_elem(u16* p, long long i, float v) {
 // row lanes (LDS) -> partial[block][2][C] (f64); stage 2 sums the blocks in order (deterministic).
 // MODE 0: (x, x^2).  MODE 1: g = dy*(relu? y>0), (g, g*xhat).   Requires C % VEC == 0 (else the scalar kernel).
 // ---------------------------------------------------------------------------------------------
-#define ST_ROWS_PER_BLOCK 512
+#define ST_ROWS_PER_BLOCK 128   /* 512 left a 48 000-row layer with 94 workgroups: latency-bound at ~1 TB/s */
 
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { static constexpr int N = 4; };
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void k_col_stats_vec(const T* __restrict__ x, 
           for (int e = 0; e < V; ++e) { ga[e] = gamma[vc * V + e]; be[e] = beta[vc * V + e]; }
         }
       }
+#pragma unroll 4
       for (int r = r0 + trow; r < r1; r += rl) {
         const long long o = (long long)r * c + (long long)vc * V;
         float xv[V];
@@ -351,7 +352,7 @@ __global__ void k_bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ y
                                T* __restrict__ dres, const int* __restrict__ n_dev, int n_cap, int c) {
   int n = min(*n_dev, n_cap);
   long long total = (long long)n * c;
-  double inv_n = n > 0 ? 1.0 / (double)n : 0.0;
+  float inv_n = n > 0 ? 1.f / (float)n : 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     int col = (int)(i % c);
     float g = ld_elem(dy, i);
@@ -361,7 +362,7 @@ __global__ void k_bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ y
     }
     float is = invstd[col];
     float xh = (ld_elem(x, i) - mean[col]) * is;
-    float mg = (float)(sums[col] * inv_n), mgx = (float)(sums[c + col] * inv_n);
+    float mg = (float)sums[col] * inv_n, mgx = (float)sums[c + col] * inv_n;
     st_elem(dx, i, gamma[col] * is * (g - mg - xh * mgx));
     if (dres) st_elem(dres, i, g);
   }
@@ -422,15 +423,16 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_vec(const T* __restrict__ 
   constexpr int V = VecOf<T>::N;
   const int n = min(*n_dev, n_cap), cv = c / V, rpb = 256 / cv;
   const int vc = threadIdx.x % cv, rl = threadIdx.x / cv;
-  const double inv_n = n > 0 ? 1.0 / (double)n : 0.0;
+  const float inv_n = n > 0 ? 1.f / (float)n : 0.f;               // f32: a per-thread f64 divide + 16 f64 multiplies cost as much as the stream
   const bool remask = relu && y == nullptr;
   float mu[V], is[V], ga[V], be[V], mg[V], mgx[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) {
     const int col = vc * V + e;
     mu[e] = mean[col]; is[e] = invstd[col]; ga[e] = gamma[col]; be[e] = remask ? beta[col] : 0.f;
-    mg[e] = (float)(sums[col] * inv_n); mgx[e] = (float)(sums[c + col] * inv_n);
+    mg[e] = (float)sums[col] * inv_n; mgx[e] = (float)sums[c + col] * inv_n;
   }
+#pragma unroll 2
   for (int r = blockIdx.x * rpb + rl; r < n; r += gridDim.x * rpb) {
     const long long o = (long long)r * c + (long long)vc * V;
     float gv[V], xv[V], yv[V], dxv[V];
@@ -455,7 +457,7 @@ static inline bool bn_vec_ok(int c, int v) { return c % v == 0 && (c / v) <= 256
 static inline int bn_vec_grid(int n_cap, int c, int v) {
   int rpb = 256 / (c / v);
   long long b = ((long long)n_cap + rpb - 1) / rpb;
-  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));                // >= 8 waves per SIMD of loads in flight, per-thread parameter setup amortised
 }
 
 static inline int ew_grid(long long total) {
