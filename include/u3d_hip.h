@@ -256,6 +256,18 @@ int64_t u3d_nms3d_workspace(int32_t n);
 int32_t u3d_nms3d(const float* boxes, const int32_t* labels, int32_t n, float thr, uint8_t* keep, void* workspace,
                   int64_t workspace_bytes, u3d_stream s);
 
+/* ------------------------------------------------------------------------------------------------
+ * Parameter update of the training step: global-norm gradient clipping + AdamW over FLAT f32 buffers
+ * (ref: projects/configs/uni3detr/uni3detr_sunrgbd.py:234-235 — AdamW(lr, weight_decay=0.01), grad_clip max_norm=10; upstream
+ * torch.optim.AdamW + torch.nn.utils.clip_grad_norm_, same arithmetic: coef = min(1, max_norm/(||g||+1e-6)), decoupled decay,
+ * bias-corrected moments).  state: 8 floats of device memory, zero-initialised by the caller: [0] step count (incremented here),
+ * [1] clip coefficient, [2] 1-beta1^t, [3] 1-beta2^t, [4] ||g||.  max_norm <= 0: no clipping.  All pointers 16-byte aligned.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t u3d_adamw_workspace(int64_t n);
+int32_t u3d_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, float max_norm, float* state, void* workspace,
+                       int64_t workspace_bytes, u3d_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,3 +1,3 @@
 cd /root/repo
-timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_i.json 2> gpurun_out/bench_i.err; cut -c1-330 gpurun_out/bench_i.json
-timeout 800 bash tools/prof_stats.sh r01_i_graph_bf16 python bench.py --steps 10 --warmup 3 --no-roofline --no-cpu-baseline
+timeout 900 python -m pytest tests/test_trainer_gpu.py -x -q -m gpu 2>&1 | tail -5
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_j.json 2> gpurun_out/bench_j.err; tail -c 300 gpurun_out/bench_j.err; cut -c1-330 gpurun_out/bench_j.json

@@ -1,0 +1,120 @@
+// Flat AdamW with global-norm gradient clipping: the parameter-update end of the training step
+// (ref: projects/configs/uni3detr/uni3detr_sunrgbd.py:234-235 — AdamW(lr, weight_decay=0.01), grad_clip max_norm=10, norm_type=2;
+//  upstream torch.optim.AdamW + torch.nn.utils.clip_grad_norm_).  Parameters, gradients and both moments live in four flat f32
+// buffers, so the whole update is three launches (partial sum of squares -> coefficients -> element-wise update) that stream
+// 7 x 4 bytes per parameter once, instead of ~30 multi-tensor launches.  Capturable: the step counter is device state.
+#include "common.h"
+
+#define OPT_BLOCK 256
+#define OPT_ELEMS_PER_BLOCK (OPT_BLOCK * 4 * 8)          // 8 float4 per thread
+
+__global__ __launch_bounds__(OPT_BLOCK) void k_sumsq_partial(const float* __restrict__ g, long long n, double* __restrict__ partial) {
+  const long long base = (long long)blockIdx.x * OPT_ELEMS_PER_BLOCK;
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    long long o = base + ((long long)i * OPT_BLOCK + threadIdx.x) * 4;
+    if (o + 3 < n) {
+      float4 v = *(const float4*)(g + o);
+      acc += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (o + e < n) acc += (double)g[o + e] * (double)g[o + e];
+    }
+  }
+  acc = u3d_wave_sum_d(acc);
+  __shared__ double red[OPT_BLOCK / 64];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < OPT_BLOCK / 64; ++i) s += red[i];
+    partial[blockIdx.x] = s;
+  }
+}
+
+// state: [0] step count (as float, like torch's capturable AdamW), [1] clip coefficient, [2] 1 - beta1^t, [3] 1 - beta2^t,
+//        [4] total gradient norm (for logging)
+__global__ __launch_bounds__(256) void k_adamw_prepare(const double* __restrict__ partial, int nb, float max_norm, float beta1,
+                                                       float beta2, float* __restrict__ state) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+  s = u3d_wave_sum_d(s);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = sqrt(red[0] + red[1] + red[2] + red[3]);
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+      coef = max_norm / ((float)tot + 1e-6f);              // torch.nn.utils.clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
+      coef = coef < 1.f ? coef : 1.f;
+    }
+    float t = state[0] + 1.f;
+    state[0] = t;
+    state[1] = coef;
+    state[2] = 1.f - powf(beta1, t);
+    state[3] = 1.f - powf(beta2, t);
+    state[4] = (float)tot;
+  }
+}
+
+__global__ __launch_bounds__(OPT_BLOCK) void k_adamw_flat(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, long long n, float lr, float beta1, float beta2,
+                                                          float eps, float wd, const float* __restrict__ state) {
+  const float coef = state[1], bc1 = state[2], bc2 = state[3];
+  const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2), decay = 1.f - lr * wd;
+  const long long base = (long long)blockIdx.x * OPT_ELEMS_PER_BLOCK;
+#pragma unroll 2
+  for (int i = 0; i < 8; ++i) {
+    long long o = base + ((long long)i * OPT_BLOCK + threadIdx.x) * 4;
+    if (o >= n) break;
+    float pv[4], gv[4], mv[4], vv[4];
+    const bool full = o + 3 < n;
+    if (full) {
+      float4 a = *(const float4*)(p + o), b = *(const float4*)(g + o), c = *(const float4*)(m + o), d = *(const float4*)(v + o);
+      pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w; gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+      mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w; vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
+    } else {
+      for (int e = 0; e < 4; ++e) {
+        bool ok = o + e < n;
+        pv[e] = ok ? p[o + e] : 0.f; gv[e] = ok ? g[o + e] : 0.f; mv[e] = ok ? m[o + e] : 0.f; vv[e] = ok ? v[o + e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = gv[e] * coef;
+      float pe = pv[e] * decay;                            // decoupled weight decay
+      mv[e] = mv[e] + (gr - mv[e]) * (1.f - beta1);        // lerp form, as torch's fused kernel
+      vv[e] = beta2 * vv[e] + (1.f - beta2) * gr * gr;
+      const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+      pv[e] = pe - step_size * (mv[e] / denom);
+    }
+    if (full) {
+      *(float4*)(p + o) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      *(float4*)(m + o) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *(float4*)(v + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (o + e < n) { p[o + e] = pv[e]; m[o + e] = mv[e]; v[o + e] = vv[e]; }
+    }
+  }
+}
+
+extern "C" int64_t u3d_adamw_workspace(int64_t n) { return (int64_t)u3d_cdiv(n > 0 ? n : 1, OPT_ELEMS_PER_BLOCK) * 8; }
+
+extern "C" int32_t u3d_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                                  float beta2, float eps, float weight_decay, float max_norm, float* state, void* workspace,
+                                  int64_t workspace_bytes, u3d_stream s) {
+  U3D_REQUIRE(param && grad && exp_avg && exp_avg_sq && state && workspace && n >= 0, U3D_ERR_ARG);
+  U3D_REQUIRE(workspace_bytes >= u3d_adamw_workspace(n), U3D_ERR_WORKSPACE);
+  U3D_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0, U3D_ERR_ARG);
+  const int nb = u3d_cdiv(n > 0 ? n : 1, OPT_ELEMS_PER_BLOCK);
+  hipLaunchKernelGGL(k_sumsq_partial, dim3(nb), dim3(OPT_BLOCK), 0, s, grad, (long long)n, (double*)workspace);
+  hipLaunchKernelGGL(k_adamw_prepare, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, max_norm, beta1, beta2, state);
+  if (n > 0)
+    hipLaunchKernelGGL(k_adamw_flat, dim3(nb), dim3(OPT_BLOCK), 0, s, param, grad, exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps,
+                       weight_decay, (const float*)state);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}

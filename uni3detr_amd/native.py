@@ -74,6 +74,8 @@ _SIGS = {
     "u3d_nms3d_workspace": (_L, [_I]),
     "u3d_nms3d": (_I, [_P, _P, _I, C.c_float, _P, _P, _L, _P]),
     "u3d_iou3d_rotated_aligned": (_I, [_P, _P, _I, _P, _P]),
+    "u3d_adamw_workspace": (_L, [_L]),
+    "u3d_adamw_step": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _L, _P]),
     "u3d_gather_rows": (_I, [_P, _P, _I, _I, _P, _P]),
     "u3d_scatter_rows": (_I, [_P, _P, _I, _I, _P, _P]),
 }
@@ -510,3 +512,12 @@ def linear_bf16(x, w, bias, relu):
     _check(lib().u3d_linear_bf16(_ptr(x), _ptr(w), _ptr(bias), int(relu), _ptr(out), _ptr(count_tensor(m, x.device)), m, k, n, _stream()),
            "linear_bf16")
     return out
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, state, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=0.0, workspace=None):
+    """In-place clip + AdamW on flat f32 buffers; `state` = 8 zero-initialised device floats (see include/u3d_hip.h)."""
+    n = param.numel()
+    wsb = int(lib().u3d_adamw_workspace(n))
+    ws = workspace if workspace is not None else torch.empty(wsb, dtype=torch.uint8, device=param.device)
+    _check(lib().u3d_adamw_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, lr, betas[0], betas[1], eps, weight_decay,
+                                float(max_norm), _ptr(state), _ptr(ws), ws.numel(), _stream()), "adamw_step")

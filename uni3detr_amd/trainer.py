@@ -13,10 +13,12 @@ captured launches are valid for any batch whose level sizes fit the capacities; 
 import torch
 import torch.distributed as dist
 
+from . import native as nv
+
 
 class TrainStep:
-    def __init__(self, model, points, gt_bboxes_3d, gt_labels_3d, lr=2e-5, weight_decay=1e-4, max_norm=10.0, graph=True,
-                 capacity_margin=1.25):
+    def __init__(self, model, points, gt_bboxes_3d, gt_labels_3d, lr=1e-4, weight_decay=0.01, max_norm=10.0, graph=True,
+                 capacity_margin=1.25, flat_update=True):
         self.model = model
         self.dev = next(model.parameters()).device
         self.dist_on = dist.is_available() and dist.is_initialized()
@@ -33,7 +35,26 @@ class TrainStep:
             self.views.append(self.flat_grad[o:o + p.numel()].view_as(p))
             p.grad = self.views[-1]
             o += p.numel()
-        self.opt = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay, fused=True, capturable=graph)
+        self.lr, self.weight_decay = lr, weight_decay
+        self.flat_update = flat_update
+        if flat_update:
+            # parameters re-homed into ONE flat buffer (each p.data becomes a view; names/shapes/state_dict unchanged), moments flat:
+            # clip + AdamW is u3d_adamw_step - three launches that stream the 7 arrays once (torch: ~30 multi-tensor launches)
+            self.flat_param = torch.empty(n, dtype=torch.float32, device=self.dev)
+            o = 0
+            with torch.no_grad():
+                for p in self.params:
+                    v = self.flat_param[o:o + p.numel()].view_as(p)
+                    v.copy_(p.data)
+                    p.data = v
+                    o += p.numel()
+            self.exp_avg = torch.zeros_like(self.flat_param)
+            self.exp_avg_sq = torch.zeros_like(self.flat_param)
+            self.opt_state = torch.zeros(8, dtype=torch.float32, device=self.dev)
+            self._opt_ws = torch.empty(int(nv.lib().u3d_adamw_workspace(n)), dtype=torch.uint8, device=self.dev)
+            self.opt = None
+        else:
+            self.opt = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay, fused=True, capturable=graph)
         self.pts = model.pack_points(points) if not isinstance(points, dict) else points
         self.gts = model.pts_bbox_head.pack_gts(gt_bboxes_3d, gt_labels_3d, self.dev) if not isinstance(gt_bboxes_3d, dict) else gt_bboxes_3d
         self.labels = gt_labels_3d
@@ -84,8 +105,23 @@ class TrainStep:
             dist.all_reduce(self.flat_grad)
 
     def _stage3(self):
+        if self.flat_update:
+            nv.adamw_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.opt_state, self.lr, (0.9, 0.999), 1e-8,
+                          self.weight_decay, self.max_norm, self._opt_ws)
+            return
         torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, foreach=True)
         self.opt.step()
+
+    def _reset_opt_state(self):
+        if self.flat_update:
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            self.opt_state.zero_()
+            return
+        for st in self.opt.state.values():
+            for v in st.values():
+                if torch.is_tensor(v):
+                    v.zero_()
 
     def eager_step(self):
         self._stage1(); self._reduce_num_pos(); self._stage2(); self._reduce_grads(); self._stage3()
@@ -104,10 +140,7 @@ class TrainStep:
         with torch.no_grad():
             for t in list(self.model.parameters()) + list(self.model.buffers()):
                 dist.broadcast(t.data, 0)
-            for st in self.opt.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+            self._reset_opt_state()
         torch.cuda.synchronize()
 
     def snapshot(self):
@@ -117,10 +150,7 @@ class TrainStep:
         with torch.no_grad():
             for t, s_ in zip(list(self.model.parameters()) + list(self.model.buffers()), snap):
                 t.copy_(s_)
-            for st in self.opt.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+            self._reset_opt_state()
 
     # ---- capture ------------------------------------------------------------------------------------------------
     def measure_capacities(self):
