@@ -256,6 +256,13 @@ int64_t u3d_nms3d_workspace(int32_t n);
 int32_t u3d_nms3d(const float* boxes, const int32_t* labels, int32_t n, float thr, uint8_t* keep, void* workspace,
                   int64_t workspace_bytes, u3d_stream s);
 
+/* Second half of the strided-convolution input gradient (first half: P = dout @ [W_0^T | ... | W_{K-1}^T] with u3d_linear_bf16 on
+ * the weight viewed as [K*Cin, Cout]): din[i][c] = sum_kappa P[nbr[kappa][i]][kappa*C + c], nbr = transposed table (mode 1 of
+ * u3d_nbr_table / u3d_dense_nbr_table), f32 accumulation.  Replaces the dgrad half of spconv's indice_conv_backward / cuDNN dgrad
+ * for stride > 1 (ref: models/backbones/second_3d.py:52-76 first conv of each block). */
+int32_t u3d_tap_gather_sum(const void* p, const int32_t* nbr, int32_t ld, const int32_t* n_dev, int32_t n_cap, int32_t c,
+                           int32_t kvol, int32_t dtype, void* out, u3d_stream s);
+
 /* ------------------------------------------------------------------------------------------------
  * Parameter update of the training step: global-norm gradient clipping + AdamW over FLAT f32 buffers
  * (ref: projects/configs/uni3detr/uni3detr_sunrgbd.py:234-235 — AdamW(lr, weight_decay=0.01), grad_clip max_norm=10; upstream

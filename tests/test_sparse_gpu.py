@@ -359,6 +359,41 @@ def test_dense_lattice_conv_matches_conv3d(cuda):
         assert (yv.detach().cpu() - ref.detach()).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("stride,cout", [((1, 2, 2), 128), ((1, 4, 4), 256), ((2, 2, 2), 64)])
+def test_strided_dgrad_split_path_matches_conv3d(cuda, stride, cout):
+    """bf16 input gradient of a strided lattice conv through (per-offset GEMM over output rows + u3d_tap_gather_sum) equals the
+    output-stationary dgrad kernel and F.conv3d's input gradient."""
+    import torch.nn.functional as F
+    from uni3detr_amd.plugin import dense as dn
+    from uni3detr_amd import sparse as sp
+    torch.manual_seed(11)
+    B, C, D, H, W = 2, 64, 6, 16, 12
+    k = (3, 3, 3) if stride[0] > 1 else (1, 3, 3)
+    p = (1, 1, 1) if stride[0] > 1 else (0, 1, 1)
+    x = torch.randn(B, C, D, H, W).bfloat16().float()
+    w = (torch.randn(cout, C, *k) * 0.05).bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv3d(xr, w, None, stride, p)
+    gy = torch.randn_like(ref).bfloat16().float()
+    ref.backward(gy)
+    geom, dims_out = dn.Lattice.conv(cuda, B, (D, H, W), k, stride, p)
+    assert geom.strided
+    got = {}
+    for split in (True, False):
+        sp.STRIDED_DGRAD_SPLIT = split
+        try:
+            rows = x.permute(0, 2, 3, 4, 1).reshape(-1, C).contiguous().to(cuda).bfloat16().requires_grad_(True)
+            y = sp.sparse_conv(rows, w.to(cuda).permute(2, 3, 4, 1, 0).contiguous(), geom)
+            y.backward(gy.permute(0, 2, 3, 4, 1).reshape(-1, cout).contiguous().to(cuda).bfloat16())
+            got[split] = rows.grad.float().view(B, D, H, W, C).permute(0, 4, 1, 2, 3).cpu()
+        finally:
+            sp.STRIDED_DGRAD_SPLIT = True
+    scale = xr.grad.abs().max().item()
+    assert (got[True] - xr.grad).abs().max().item() <= 2e-2 * scale
+    assert (got[False] - xr.grad).abs().max().item() <= 2e-2 * scale
+    assert (got[True] - got[False]).abs().max().item() <= 2e-2 * scale
+
+
 def test_dynamic_voxelize_and_scatter_mean(cuda):
     from uni3detr_amd.plugin.detector import DynamicSimpleVFE
     rng = np.random.default_rng(2)

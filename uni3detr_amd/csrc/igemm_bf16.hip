@@ -209,7 +209,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
         for (int a = 0; a < WM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr, acc[a][b], 0, 0, 0);
       }
       // the next stage's tile goes to the OTHER buffer (free since the previous barrier)
+#ifndef IGEMM_EXP_SKIP_STORE
       if (ks == IGEMM_STORE_KS) store_lds(buf ^ 1);
+#endif
     }
     __syncthreads();
   }
@@ -246,6 +248,169 @@ static int launch_igemm_fwd(const void* in, const void* w, const int32_t* nbr, i
   dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev,
                      n_out_cap, cin, cout, kvol, bias, relu);
+  return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
+}
+
+// =============================================================================================
+// forward / dgrad with LDS-DMA staging (256 x 256 tile, n-major weights w[kappa][n][k]).
+//
+// Ablation of k_igemm_fwd (tools/conv_bench.py): without the register->LDS stores of the next stage it runs at 1.2-1.4 PFLOP/s
+// instead of 0.9 - the ds_write_b128 stream (13 clk each on the shared VGPR->LDS path, behind a vmcnt wait) is its largest
+// overhead; and the k-major weight tile (transpose reads) costs another ~15 % against the n-major one.  Here both operand tiles go
+// global -> LDS with `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write, zero fill for missing neighbours by an
+// out-of-range offset), issued at the top of a stage into the idle buffer and in flight during the whole stage.  LDS-DMA writes
+// lane-linearly (1 KiB per wave-instruction = 8 rows x 128 B), so the tiles are unpadded [256][64] and bank conflicts are avoided
+// by an XOR swizzle applied on the SOURCE side: 16-byte part p of row r is stored in slot p ^ ((r >> 1) & 7); a fragment read
+// (16 rows x 8 B per k-group) then covers all 64 banks exactly once.
+// =============================================================================================
+#ifndef IGEMM_GLDS
+#define IGEMM_GLDS 1
+#endif
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+__global__ __launch_bounds__(512) void k_igemm_glds(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
+                                                    int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
+                                                    int cin, int cout, int kvol, const float* __restrict__ bias, int relu) {
+  constexpr int WAVES_N = 4, WM = 8, WN = 4;
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int TILE_ELEMS = 256 * BK;                  // 32 KiB per operand tile
+  constexpr int STAGE_ELEMS = 2 * TILE_ELEMS;
+  constexpr int SEGS = 4;                               // wave-instructions per wave per tile: 256 rows / 8 rows / 8 waves
+  extern __shared__ __attribute__((aligned(1024))) u16 smem[];
+
+  const int n_out = min(*n_out_dev, n_out_cap);
+  const int ntile = gridDim.x;
+  const int xq = ntile >> 3, xr = ntile & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+  const int m0 = tile * BM;
+  if (m0 >= n_out) return;
+  const int col0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+  const int kchunks = cin / BK;
+  const int nstage = kvol * kchunks;
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, -1, 0x00020000);
+  const unsigned row_bytes = (unsigned)cin * 2u;
+  // loader role: wave-instruction u of this wave fills rows (wv*4+u)*8 .. +7 of a tile; lane = (row in group, 16-byte slot)
+  const int lrow = lane >> 3, lslot = lane & 7;
+  unsigned a_part16[SEGS], w_voff[SEGS];
+  int arow[SEGS];
+#pragma unroll
+  for (int u = 0; u < SEGS; ++u) {
+    const int r = (wv * SEGS + u) * 8 + lrow;
+    const int part = lslot ^ ((r >> 1) & 7);
+    arow[u] = r;
+    a_part16[u] = (unsigned)part * 16u;
+    w_voff[u] = (col0 + r < cout) ? (unsigned)((col0 + r) * cin + part * 8) * 2u : 0xFFFFFFFFu;
+  }
+  int idx_cur[SEGS], idx_nxt[SEGS];
+  auto load_idx_next = [&](int stage) {
+    const int kap = stage % kvol;
+#pragma unroll
+    for (int u = 0; u < SEGS; ++u) {
+      int m = m0 + arow[u];
+      int mc = m < n_out ? m : n_out - 1;
+      idx_nxt[u] = nbr ? nbr[(long long)kap * ld + mc] : mc;           // raw: masked when consumed (see k_igemm_fwd)
+    }
+  };
+  auto advance_idx = [&]() {
+#pragma unroll
+    for (int u = 0; u < SEGS; ++u) idx_cur[u] = (m0 + arow[u] < n_out) ? idx_nxt[u] : -1;
+  };
+  auto issue = [&](int st, int buf) {
+    const int kap = st % kvol, c0 = (st / kvol) * BK;
+    u16* Ab = smem + buf * STAGE_ELEMS + wv * (SEGS * 512);
+    u16* Wb = Ab + TILE_ELEMS;
+    const unsigned a_soff = (unsigned)c0 * 2u;
+    const unsigned w_soff = (unsigned)(kap * cin * cout + c0) * 2u;
+#pragma unroll
+    for (int u = 0; u < SEGS; ++u) {
+      unsigned voff = idx_cur[u] >= 0 ? (unsigned)idx_cur[u] * row_bytes + a_part16[u] : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void_ptr)(Ab + u * 512), 16, voff, a_soff, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < SEGS; ++u)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_ptr)(Wb + u * 512), 16, w_voff[u], w_soff, 0, 0);
+  };
+  // fragment offsets inside a 64-element row: slot of part (ks*4 + g/2 [+2]) under this lane's row swizzle, plus the 8-byte half
+  const int g = lane >> 4, li = lane & 15, fsw = (lane >> 1) & 7;
+  int foff[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) foff[ks][j] = (((ks * 4 + (g >> 1) + 2 * j) ^ fsw) << 3) + (g & 1) * 4;
+  typedef const volatile s16x4 __attribute__((address_space(3))) * lds_vptr;
+  auto frag = [&](const u16* rowp, int ks) {
+    s16x4 x = *(lds_vptr)(rowp + foff[ks][0]);
+    s16x4 y = *(lds_vptr)(rowp + foff[ks][1]);
+    s16x8 v = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  load_idx_next(0);
+  advance_idx();
+  load_idx_next(1 < nstage ? 1 : 0);
+  issue(0, 0);
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int buf = st & 1;
+    const int nx = st + 1 < nstage ? st + 1 : st;       // the last stage re-fetches itself into the idle buffer: branch-free body
+    advance_idx();
+    load_idx_next(st + 2 < nstage ? st + 2 : nstage - 1);
+    issue(nx, buf ^ 1);                                 // in flight during the whole stage; buffer free since the last barrier
+    const u16* A = smem + buf * STAGE_ELEMS + (wm * WM * 16 + li) * BK;
+    const u16* W = smem + buf * STAGE_ELEMS + TILE_ELEMS + (wn * WN * 16 + li) * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[WM];
+#pragma unroll
+      for (int a = 0; a < WM; ++a) af[a] = frag(A + a * 16 * BK, ks);
+#pragma unroll
+      for (int b = 0; b < WN; ++b) {
+        bf16x8 bfr = frag(W + b * 16 * BK, ks);
+#pragma unroll
+        for (int a = 0; a < WM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr, acc[a][b], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                    // also drains this wave's LDS-DMA (vmcnt) before anyone reads the next buffer
+  }
+  const int r4 = g * 4;
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int m = m0 + (wm * WM + a) * 16 + r4 + r;
+      if (m >= n_out) continue;
+#pragma unroll
+      for (int b = 0; b < WN; ++b) {
+        int col = col0 + (wn * WN + b) * 16 + li;
+        if (col < cout) {
+          float v = acc[a][b][r];
+          if (bias) v += bias[col];
+          if (relu) v = fmaxf(v, 0.f);
+          out[(long long)m * cout + col] = f2bf(v);
+        }
+      }
+    }
+}
+
+static int launch_igemm_glds(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev,
+                             int n_out_cap, int cin, int cout, int kvol, hipStream_t s, const float* bias = nullptr, int relu = 0) {
+  constexpr size_t lds = 2 * 2 * (size_t)256 * 64 * 2;  // 128 KiB
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_igemm_glds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  dim3 grid(u3d_cdiv(n_out_cap, 256), u3d_cdiv(cout, 256));
+  hipLaunchKernelGGL(k_igemm_glds, grid, dim3(512), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin,
+                     cout, kvol, bias, relu);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
 }
 
@@ -534,13 +699,17 @@ extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32
                      : launch_igemm_fwd<A, B, C, D, true>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
   // (a 128x128-tile variant for layers with few rows was measured SLOWER: 285 vs 512 TF/s at N=48000 — the L2->CU traffic of
   //  the smaller tile outweighs the better CU fill; not dispatched)
+  // few row tiles (the stride-4 branch of SECOND3D: 12000 rows): 256 x 256 tiles leave most CUs idle -> narrower tiles
+  const long long wg256 = (long long)u3d_cdiv(n_out_cap, 256) * (cout / 256 > 0 ? cout / 256 : 1);
+#if IGEMM_GLDS
+  if (transpose_w && cout % 256 == 0 && wg256 >= 128)               // n-major weights, 256 x 256 tile, LDS-DMA staging
+    return launch_igemm_glds(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
+#endif
 #if IGEMM_PP
   if (cout % 256 == 0)                                              // 256 x 256, ping-pong schedule
     return transpose_w ? launch_igemm_pp<false>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s)
                        : launch_igemm_pp<true>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
 #endif
-  // few row tiles (the stride-4 branch of SECOND3D: 12000 rows): 256 x 256 tiles leave most CUs idle -> narrower tiles
-  const long long wg256 = (long long)u3d_cdiv(n_out_cap, 256) * (cout / 256 > 0 ? cout / 256 : 1);
   if (cout % 256 == 0 && wg256 < 128) { IG_CASE(4, 2, 4, 4) }       // measured: 94 workgroups (N=12000, 512 ch) 0.136 -> 0.100 ms;
                                                                     // 188 workgroups (N=48000, 256 ch) stay faster on 256 x 256
   if (cout >= 256 && cout % 256 == 0) { IG_CASE(2, 4, 8, 4) }       // 256 x 256

@@ -74,6 +74,7 @@ _SIGS = {
     "u3d_nms3d_workspace": (_L, [_I]),
     "u3d_nms3d": (_I, [_P, _P, _I, C.c_float, _P, _P, _L, _P]),
     "u3d_iou3d_rotated_aligned": (_I, [_P, _P, _I, _P, _P]),
+    "u3d_tap_gather_sum": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "u3d_adamw_workspace": (_L, [_L]),
     "u3d_adamw_step": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _L, _P]),
     "u3d_gather_rows": (_I, [_P, _P, _I, _I, _P, _P]),
@@ -521,3 +522,11 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, state, lr, betas=(0.9, 0.999), 
     ws = workspace if workspace is not None else torch.empty(wsb, dtype=torch.uint8, device=param.device)
     _check(lib().u3d_adamw_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, lr, betas[0], betas[1], eps, weight_decay,
                                 float(max_norm), _ptr(state), _ptr(ws), ws.numel(), _stream()), "adamw_step")
+
+
+def tap_gather_sum(p, nbr, n_dev, n, c, kvol):
+    """din[i] = sum_k p[nbr[k][i], k*c:(k+1)*c] (f32 accumulate); p: [n_out, kvol*c]."""
+    out = torch.empty((n, c), dtype=p.dtype, device=p.device)
+    _check(lib().u3d_tap_gather_sum(_ptr(p), _ptr(nbr), nbr.shape[1], _ptr(n_dev), n, c, kvol, dtype_code(p), _ptr(out), _stream()),
+           "tap_gather_sum")
+    return out

@@ -57,7 +57,7 @@ class Lattice:
             bwd = None if one else nv.dense_nbr_table(batch, dims_in, dims_out, ksize, stride, pad, 1, device)
             n_in_dev = torch.tensor([n_in], dtype=torch.int32, device=device)
             n_out_dev = torch.tensor([n_out], dtype=torch.int32, device=device)
-            g = (sp.ConvGeom(fwd, bwd, n_in, n_in_dev, n_out, n_out_dev, kind="dense"), dims_out)
+            g = (sp.ConvGeom(fwd, bwd, n_in, n_in_dev, n_out, n_out_dev, kind="dense", strided=any(s > 1 for s in stride)), dims_out)
             cls._cache[key] = g
         return g
 

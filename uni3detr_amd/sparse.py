@@ -32,7 +32,8 @@ class Level:
 class ConvGeom:
     """Tables of one convolution instance: forward (output-stationary), transposed (input-stationary), sizes."""
 
-    def __init__(self, nbr_fwd, nbr_bwd, n_in, n_in_dev, n_out, n_out_dev, kind="sparse"):
+    def __init__(self, nbr_fwd, nbr_bwd, n_in, n_in_dev, n_out, n_out_dev, kind="sparse", strided=False):
+        self.strided = strided      # stride > 1: bf16 dgrad = per-offset products over the output rows + gather (u3d_tap_gather_sum)
         self.nbr_fwd, self.nbr_bwd = nbr_fwd, nbr_bwd
         self.n_in, self.n_in_dev, self.n_out, self.n_out_dev = n_in, n_in_dev, n_out, n_out_dev
         self.kind = kind            # "sparse" (encoder levels) or "dense" (SECOND3D/FPN lattice): bench.py tags timings with it
@@ -74,6 +75,10 @@ def strided_level(lvl, ksize, stride, pad, capacity=None):
     return out, ConvGeom(fwd, bwd, lvl.n, lvl.n_dev, n_out, out.n_dev)
 
 
+import os as _os
+STRIDED_DGRAD_SPLIT = _os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
+
+
 class _SparseConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, weight, geom):
@@ -97,7 +102,13 @@ class _SparseConv(torch.autograd.Function):
         nv.CALL_KIND = g.kind
         if ctx.needs_input_grad[0]:
             nbr = g.nbr_bwd if kvol > 1 else None
-            din = nv.spconv_fwd(dout, wc.contiguous(), nbr, g.n_in_dev, g.n_in, wc.shape[1], transpose_w=True)
+            cin, cout = wc.shape[1], wc.shape[2]
+            if (STRIDED_DGRAD_SPLIT and g.strided and kvol > 1 and dout.dtype == torch.bfloat16 and cout % 64 == 0
+                    and (kvol * cin) % 64 == 0 and g.n_out * 4 <= g.n_in):
+                prod = nv.linear_bf16(dout, wc.contiguous().view(kvol * cin, cout), None, False)      # [n_out, K*Cin]
+                din = nv.tap_gather_sum(prod, nbr, g.n_in_dev, g.n_in, cin, kvol)
+            else:
+                din = nv.spconv_fwd(dout, wc.contiguous(), nbr, g.n_in_dev, g.n_in, cin, transpose_w=True)
         if ctx.needs_input_grad[1]:
             nbr = g.nbr_fwd if kvol > 1 else None
             dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol).reshape(ctx.wshape).to(ctx.wdtype)
