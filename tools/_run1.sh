@@ -1,4 +1,3 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_sparse_gpu.py -x -q -m gpu -k "strided or lattice" 2>&1 | tail -5
-timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_k.json 2> gpurun_out/bench_k.err; tail -c 200 gpurun_out/bench_k.err; cut -c1-330 gpurun_out/bench_k.json
-U3D_STRIDED_DGRAD_SPLIT=0 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-330
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_l.json 2> gpurun_out/bench_l.err; tail -c 200 gpurun_out/bench_l.err; cut -c1-330 gpurun_out/bench_l.json

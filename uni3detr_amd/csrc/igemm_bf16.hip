@@ -268,15 +268,17 @@ static int launch_igemm_fwd(const void* in, const void* w, const int32_t* nbr, i
 #endif
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-__global__ __launch_bounds__(512) void k_igemm_glds(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
-                                                    int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
-                                                    int cin, int cout, int kvol, const float* __restrict__ bias, int relu) {
-  constexpr int WAVES_N = 4, WM = 8, WN = 4;
-  constexpr int BM = 256, BN = 256, BK = 64;
-  constexpr int TILE_ELEMS = 256 * BK;                  // 32 KiB per operand tile
-  constexpr int STAGE_ELEMS = 2 * TILE_ELEMS;
-  constexpr int SEGS = 4;                               // wave-instructions per wave per tile: 256 rows / 8 rows / 8 waves
-  extern __shared__ __attribute__((aligned(1024))) u16 smem[];
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
+                                                int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
+                                                int cin, int cout, int kvol, const float* __restrict__ bias, int relu) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, BK = 64;
+  constexpr int A_ELEMS = BM * BK, W_ELEMS = BN * BK;   // unpadded tiles, 128 B per row
+  constexpr int STAGE_ELEMS = A_ELEMS + W_ELEMS;
+  constexpr int SEGS_A = BM / 8 / NW, SEGS_W = BN / 8 / NW;   // wave-instructions (8 rows x 128 B = 1 KiB) per wave per tile
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
 
   const int n_out = min(*n_out_dev, n_out_cap);
   const int ntile = gridDim.x;
@@ -302,21 +304,25 @@ __global__ __launch_bounds__(512) void k_igemm_glds(const u16* __restrict__ in, 
   const unsigned row_bytes = (unsigned)cin * 2u;
   // loader role: wave-instruction u of this wave fills rows (wv*4+u)*8 .. +7 of a tile; lane = (row in group, 16-byte slot)
   const int lrow = lane >> 3, lslot = lane & 7;
-  unsigned a_part16[SEGS], w_voff[SEGS];
-  int arow[SEGS];
+  unsigned a_part16[SEGS_A], w_voff[SEGS_W];
+  int arow[SEGS_A];
 #pragma unroll
-  for (int u = 0; u < SEGS; ++u) {
-    const int r = (wv * SEGS + u) * 8 + lrow;
-    const int part = lslot ^ ((r >> 1) & 7);
+  for (int u = 0; u < SEGS_A; ++u) {
+    const int r = (wv * SEGS_A + u) * 8 + lrow;
     arow[u] = r;
-    a_part16[u] = (unsigned)part * 16u;
+    a_part16[u] = (unsigned)(lslot ^ ((r >> 1) & 7)) * 16u;
+  }
+#pragma unroll
+  for (int u = 0; u < SEGS_W; ++u) {
+    const int r = (wv * SEGS_W + u) * 8 + lrow;
+    const int part = lslot ^ ((r >> 1) & 7);
     w_voff[u] = (col0 + r < cout) ? (unsigned)((col0 + r) * cin + part * 8) * 2u : 0xFFFFFFFFu;
   }
-  int idx_cur[SEGS], idx_nxt[SEGS];
+  int idx_cur[SEGS_A], idx_nxt[SEGS_A];
   auto load_idx_next = [&](int stage) {
     const int kap = stage % kvol;
 #pragma unroll
-    for (int u = 0; u < SEGS; ++u) {
+    for (int u = 0; u < SEGS_A; ++u) {
       int m = m0 + arow[u];
       int mc = m < n_out ? m : n_out - 1;
       idx_nxt[u] = nbr ? nbr[(long long)kap * ld + mc] : mc;           // raw: masked when consumed (see k_igemm_fwd)
@@ -324,21 +330,21 @@ __global__ __launch_bounds__(512) void k_igemm_glds(const u16* __restrict__ in, 
   };
   auto advance_idx = [&]() {
 #pragma unroll
-    for (int u = 0; u < SEGS; ++u) idx_cur[u] = (m0 + arow[u] < n_out) ? idx_nxt[u] : -1;
+    for (int u = 0; u < SEGS_A; ++u) idx_cur[u] = (m0 + arow[u] < n_out) ? idx_nxt[u] : -1;
   };
   auto issue = [&](int st, int buf) {
     const int kap = st % kvol, c0 = (st / kvol) * BK;
-    u16* Ab = smem + buf * STAGE_ELEMS + wv * (SEGS * 512);
-    u16* Wb = Ab + TILE_ELEMS;
+    u16* Ab = smem + buf * STAGE_ELEMS + wv * (SEGS_A * 512);
+    u16* Wb = smem + buf * STAGE_ELEMS + A_ELEMS + wv * (SEGS_W * 512);
     const unsigned a_soff = (unsigned)c0 * 2u;
     const unsigned w_soff = (unsigned)(kap * cin * cout + c0) * 2u;
 #pragma unroll
-    for (int u = 0; u < SEGS; ++u) {
+    for (int u = 0; u < SEGS_A; ++u) {
       unsigned voff = idx_cur[u] >= 0 ? (unsigned)idx_cur[u] * row_bytes + a_part16[u] : 0xFFFFFFFFu;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void_ptr)(Ab + u * 512), 16, voff, a_soff, 0, 0);
     }
 #pragma unroll
-    for (int u = 0; u < SEGS; ++u)
+    for (int u = 0; u < SEGS_W; ++u)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_ptr)(Wb + u * 512), 16, w_voff[u], w_soff, 0, 0);
   };
   // fragment offsets inside a 64-element row: slot of part (ks*4 + g/2 [+2]) under this lane's row swizzle, plus the 8-byte half
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(512) void k_igemm_glds(const u16* __restrict__ in, 
     load_idx_next(st + 2 < nstage ? st + 2 : nstage - 1);
     issue(nx, buf ^ 1);                                 // in flight during the whole stage; buffer free since the last barrier
     const u16* A = smem + buf * STAGE_ELEMS + (wm * WM * 16 + li) * BK;
-    const u16* W = smem + buf * STAGE_ELEMS + TILE_ELEMS + (wn * WN * 16 + li) * BK;
+    const u16* W = smem + buf * STAGE_ELEMS + A_ELEMS + (wn * WN * 16 + li) * BK;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[WM];
@@ -403,13 +409,29 @@ __global__ __launch_bounds__(512) void k_igemm_glds(const u16* __restrict__ in, 
     }
 }
 
+// concrete kernels (a __global__ TEMPLATE with this body lost its host stub under hipcc 7.2: undefined symbol at load time)
+#define U3D_GLDS_KERNEL(NAME, A, B, C, D)                                                                                        \
+  __global__ __launch_bounds__(A* B * 64) void NAME(const u16* in, const u16* w, const int* nbr, int ld, u16* out,               \
+                                                    const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,            \
+                                                    const float* bias, int relu) {                                               \
+    igemm_glds_body<A, B, C, D>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu);                          \
+  }
+U3D_GLDS_KERNEL(k_igemm_glds_256x256, 2, 4, 8, 4)
+U3D_GLDS_KERNEL(k_igemm_glds_256x128, 4, 2, 4, 4)
+U3D_GLDS_KERNEL(k_igemm_glds_128x64, 4, 1, 2, 4)
+#undef U3D_GLDS_KERNEL
+typedef void (*glds_kernel_t)(const u16*, const u16*, const int*, int, u16*, const int*, int, int, int, int, const float*, int);
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
 static int launch_igemm_glds(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev,
                              int n_out_cap, int cin, int cout, int kvol, hipStream_t s, const float* bias = nullptr, int relu = 0) {
-  constexpr size_t lds = 2 * 2 * (size_t)256 * 64 * 2;  // 128 KiB
+  constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;        // 256 x 256: 128 KiB
+  glds_kernel_t kern = (BM == 256 && BN == 256) ? k_igemm_glds_256x256 : (BM == 256 ? k_igemm_glds_256x128 : k_igemm_glds_128x64);
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_igemm_glds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  dim3 grid(u3d_cdiv(n_out_cap, 256), u3d_cdiv(cout, 256));
-  hipLaunchKernelGGL(k_igemm_glds, grid, dim3(512), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin,
+  if (!attr_set && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin,
                      cout, kvol, bias, relu);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
 }
@@ -702,8 +724,11 @@ extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32
   // few row tiles (the stride-4 branch of SECOND3D: 12000 rows): 256 x 256 tiles leave most CUs idle -> narrower tiles
   const long long wg256 = (long long)u3d_cdiv(n_out_cap, 256) * (cout / 256 > 0 ? cout / 256 : 1);
 #if IGEMM_GLDS
-  if (transpose_w && cout % 256 == 0 && wg256 >= 128)               // n-major weights, 256 x 256 tile, LDS-DMA staging
-    return launch_igemm_glds(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
+  if (transpose_w) {                                                // n-major weights: LDS-DMA staged kernels
+    if (cout % 256 == 0 && wg256 >= 128) return launch_igemm_glds<2, 4, 8, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
+    if (cout % 128 == 0) return launch_igemm_glds<4, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
+    if (cout % 64 == 0) return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
+  }
 #endif
 #if IGEMM_PP
   if (cout % 256 == 0)                                              // 256 x 256, ping-pong schedule

@@ -263,7 +263,7 @@ CALL_KIND = "sparse"
 USE_IGEMM_V2 = True
 
 
-def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False):
+def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False, tag=None):
     """out[m] = sum_k in[nbr[k][m]] @ W[k]; w: [K, Cin_w, Cout_w] contiguous. Returns [n_out, cout]."""
     kvol = w.shape[0]
     cin = inp.shape[1]
@@ -288,7 +288,7 @@ def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False):
             meta = dict(kind=CALL_KIND, v2=bool(rc == 0), n_in=inp.shape[0], n_out=n_out, cin=cin, cout=cout, kvol=kvol, pairs=pairs,
                         bytes=inp.shape[0] * cin * s + n_out * cout * s + 8 * pairs + kvol * cin * cout * s,
                         flops=2 * pairs * cin * cout)
-        t.end("spconv_dgrad" if transpose_w else "spconv_fwd", e0, meta)
+        t.end(tag or ("spconv_dgrad" if transpose_w else "spconv_fwd"), e0, meta)
     return out
 
 

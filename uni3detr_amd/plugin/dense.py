@@ -108,8 +108,7 @@ def to_volume(rows, B, dims):
 def conv_bn_relu(rows, B, dims, conv, bn):
     ks, st, pd = tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding)
     geom, dims_out = Lattice.conv(rows.device, B, dims, ks, st, pd)
-    w = conv.weight.permute(2, 3, 4, 1, 0)                 # [Cout,Cin,kd,kh,kw] -> [kd,kh,kw,Cin,Cout]
-    y = sp.sparse_conv(rows, w, geom)
+    y = sp.sparse_conv(rows, conv.weight, geom, "oidhw")   # nn.Conv3d layout [Cout,Cin,kd,kh,kw]; re-laid-out by the shadow set
     return sp.bn_rows(y, bn, geom.n_out_dev, None, True), dims_out
 
 

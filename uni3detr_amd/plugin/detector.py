@@ -193,14 +193,19 @@ class Uni3DETR(nn.Module):
         if self.amp_dtype is None or dev.type != "cuda" or not torch.is_grad_enabled():
             return contextlib.nullcontext()
         if self._shadows is None or self._shadows.dtype != self.amp_dtype or self._shadows.params[0].device != dev:
-            ps = []
+            ps, convs = [], {}
             for m in self.modules():
                 if isinstance(m, nn.Linear):
                     ps += [m.weight] + ([m.bias] if m.bias is not None else [])
                 elif isinstance(m, nn.MultiheadAttention):
                     ps += [m.in_proj_weight, m.in_proj_bias]
-            ps += [p for p in self.parameters() if p.dim() == 5]
-            self._shadows = ShadowSet(list({id(p): p for p in ps}.values()), self.amp_dtype)
+                elif isinstance(m, nn.Conv3d):
+                    convs[m.weight] = "oidhw"
+            if self.pts_middle_encoder is not None:
+                for p in self.pts_middle_encoder.parameters():
+                    if p.dim() == 5:
+                        convs[p] = "dhwio"
+            self._shadows = ShadowSet(list({id(p): p for p in ps}.values()), self.amp_dtype, convs)
         return self._shadows.active()
 
     def extract_pts_feat(self, pts):

@@ -1,9 +1,15 @@
 """Per-step low-precision copies ("shadows") of the fp32 master parameters.
 
 In bf16 mode every conv / linear used to cast its own weight (and bias) on every forward: ~170 cast launches per step of a few
-microseconds each.  A ShadowSet keeps one persistent bf16 tensor per parameter and refreshes ALL of them with one
-multi-tensor copy at the top of the training step; `compute_copy()` hands the shadow out while the set is active and falls
-back to an on-the-spot cast otherwise (eval, modules called on their own, parameters modified since the refresh).
+microseconds each.  A ShadowSet keeps persistent bf16 tensors per parameter and refreshes ALL of them at the top of the training
+step (one multi-tensor copy for the linears; the conv weights are re-laid-out at the same time); `compute_copy()` /
+`conv_weights()` hand the shadows out while the set is active and fall back to an on-the-spot cast otherwise (eval, modules
+called on their own, parameters modified since the refresh).
+
+Conv weights get TWO shadows, both [K, ., .] with K = kD*kH*kW:
+    kio [K, Cin, Cout]  - what dgrad reads (n-major for the input-gradient GEMM) and the k-major forward kernels
+    koi [K, Cout, Cin]  - n-major for the forward GEMM: the LDS-DMA kernel (k_igemm_glds) stages both operands row-linearly
+from either checkpoint layout: "dhwio" = [kD,kH,kW,Cin,Cout] (mmcv spconv-1.x, SparseEncoderHD) or "oidhw" = nn.Conv3d.
 """
 import contextlib
 
@@ -12,23 +18,49 @@ import torch
 _ACTIVE = [False]
 
 
+def _conv_views(p, layout):
+    """(kio_view, koi_view) of a conv weight in `layout`, as (possibly strided) views [kD,kH,kW,.,.]."""
+    if layout == "dhwio":
+        return p, p.transpose(-1, -2)
+    if layout == "oidhw":
+        return p.permute(2, 3, 4, 1, 0), p.permute(2, 3, 4, 0, 1)
+    raise ValueError(layout)
+
+
 class ShadowSet:
-    def __init__(self, params, dtype):
+    def __init__(self, params, dtype, conv_layouts=None):
+        """params: parameters to shadow as they are; conv_layouts: {parameter: "dhwio" | "oidhw"} for 5-D conv weights."""
         self.dtype = dtype
-        self.params = [p for p in params if p.is_floating_point() and p.dtype != dtype]
+        conv_layouts = conv_layouts or {}
+        conv_ids = {id(p) for p in conv_layouts}
+        self.params = [p for p in params if p.is_floating_point() and p.dtype != dtype and id(p) not in conv_ids]
         self.shadows = [torch.empty_like(p, dtype=dtype) for p in self.params]
         for p, s in zip(self.params, self.shadows):
             p._u3d_shadow = [s, -1]
+        self.conv_params, self._conv_src, self._conv_dst = [], [], []
+        for p, layout in conv_layouts.items():
+            kio_v, koi_v = _conv_views(p.detach(), layout)
+            kio = torch.empty(kio_v.shape, dtype=dtype, device=p.device)
+            koi = torch.empty(koi_v.shape, dtype=dtype, device=p.device)
+            self.conv_params.append(p)
+            self._conv_src += [kio_v, koi_v]
+            self._conv_dst += [kio, koi]
+            p._u3d_conv_shadow = [kio.view(-1, kio.shape[-2], kio.shape[-1]), koi.view(-1, koi.shape[-2], koi.shape[-1]), -1, layout]
 
     def refresh(self):
         with torch.no_grad():
-            torch._foreach_copy_(self.shadows, self.params)
+            if self.shadows:
+                torch._foreach_copy_(self.shadows, self.params)
+            if self._conv_dst:
+                torch._foreach_copy_(self._conv_dst, self._conv_src)        # strided sources: cast + re-layout in one pass per tensor
         for p in self.params:
             p._u3d_shadow[1] = p._version
+        for p in self.conv_params:
+            p._u3d_conv_shadow[2] = p._version
 
     @contextlib.contextmanager
     def active(self):
-        """Refresh, then let compute_copy() use the shadows for the duration of the block (one training forward)."""
+        """Refresh, then let compute_copy() / conv_weights() use the shadows for the duration of the block (one training forward)."""
         self.refresh()
         prev = _ACTIVE[0]
         _ACTIVE[0] = True
@@ -47,3 +79,15 @@ def compute_copy(p, dtype):
         if sh is not None and sh[0].dtype == dtype and sh[1] == p._version:
             return sh[0]
     return p.detach().to(dtype)
+
+
+def conv_weights(p, layout, dtype, want_koi=True):
+    """(kio [K,Cin,Cout], koi [K,Cout,Cin] or None) of conv weight `p` (checkpoint `layout`) in `dtype`, contiguous."""
+    if _ACTIVE[0]:
+        sh = getattr(p, "_u3d_conv_shadow", None)
+        if sh is not None and sh[0].dtype == dtype and sh[2] == p._version and sh[3] == layout:
+            return sh[0], sh[1]
+    kio_v, koi_v = _conv_views(p.detach(), layout)
+    kio = kio_v.to(dtype).contiguous()
+    koi = koi_v.to(dtype).contiguous() if want_koi else None
+    return kio.view(-1, kio.shape[-2], kio.shape[-1]), (None if koi is None else koi.view(-1, koi.shape[-2], koi.shape[-1]))

@@ -7,7 +7,7 @@ Replaces spconv's SparseConvTensor / indice_key machinery used by the reference 
 import torch
 
 from . import native as nv
-from .shadow import compute_copy
+from .shadow import conv_weights
 
 K3, S1, P1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
 
@@ -77,20 +77,26 @@ def strided_level(lvl, ksize, stride, pad, capacity=None):
 
 import os as _os
 STRIDED_DGRAD_SPLIT = _os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
+NMAJOR_FWD = _os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
 
 
 class _SparseConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, weight, geom):
-        # weight: [kD,kH,kW,Cin,Cout] (mmcv spconv-1.x layout) or [1,1,1,Cin,Cout]
-        wc = compute_copy(weight, feats.dtype).reshape(-1, weight.shape[-2], weight.shape[-1])
-        w = wc
-        ctx.geom = geom
-        ctx.save_for_backward(feats, wc)
-        ctx.wshape, ctx.wdtype = weight.shape, weight.dtype
-        nbr = geom.nbr_fwd if w.shape[0] > 1 else None
+    def forward(ctx, feats, weight, geom, layout):
+        # weight: the PARAMETER in its checkpoint layout: "dhwio" [kD,kH,kW,Cin,Cout] (mmcv spconv-1.x) or "oidhw" (nn.Conv3d)
+        bf16 = feats.dtype == torch.bfloat16
+        kio_shape = weight.shape if layout == "dhwio" else tuple(weight.shape[i] for i in (2, 3, 4, 1, 0))
+        cin, cout = kio_shape[3], kio_shape[4]
+        nmajor = NMAJOR_FWD and bf16 and cin % 64 == 0 and cout % 64 == 0
+        kio, koi = conv_weights(weight, layout, feats.dtype, want_koi=nmajor)
+        ctx.geom, ctx.layout = geom, layout
+        ctx.save_for_backward(feats, kio)
+        ctx.kio_shape, ctx.wdtype = kio_shape, weight.dtype
+        nbr = geom.nbr_fwd if kio.shape[0] > 1 else None
         nv.CALL_KIND = geom.kind
-        return nv.spconv_fwd(feats, wc.contiguous(), nbr, geom.n_out_dev, geom.n_out, w.shape[2])
+        if nmajor:      # forward on the LDS-DMA kernel (n-major weight shadow)
+            return nv.spconv_fwd(feats, koi, nbr, geom.n_out_dev, geom.n_out, cout, transpose_w=True, tag="spconv_fwd")
+        return nv.spconv_fwd(feats, kio, nbr, geom.n_out_dev, geom.n_out, cout)
 
     @staticmethod
     def backward(ctx, dout):
@@ -105,18 +111,21 @@ class _SparseConv(torch.autograd.Function):
             cin, cout = wc.shape[1], wc.shape[2]
             if (STRIDED_DGRAD_SPLIT and g.strided and kvol > 1 and dout.dtype == torch.bfloat16 and cout % 64 == 0
                     and (kvol * cin) % 64 == 0 and g.n_out * 4 <= g.n_in):
-                prod = nv.linear_bf16(dout, wc.contiguous().view(kvol * cin, cout), None, False)      # [n_out, K*Cin]
+                prod = nv.linear_bf16(dout, wc.view(kvol * cin, cout), None, False)      # [n_out, K*Cin]
                 din = nv.tap_gather_sum(prod, nbr, g.n_in_dev, g.n_in, cin, kvol)
             else:
-                din = nv.spconv_fwd(dout, wc.contiguous(), nbr, g.n_in_dev, g.n_in, cin, transpose_w=True)
+                din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True)
         if ctx.needs_input_grad[1]:
             nbr = g.nbr_fwd if kvol > 1 else None
-            dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol).reshape(ctx.wshape).to(ctx.wdtype)
-        return din, dw, None
+            dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol).reshape(ctx.kio_shape).to(ctx.wdtype)
+            if ctx.layout == "oidhw":
+                dw = dw.permute(4, 3, 0, 1, 2)
+        return din, dw, None, None
 
 
-def sparse_conv(feats, weight, geom):
-    return _SparseConv.apply(feats, weight, geom)
+def sparse_conv(feats, weight, geom, layout="dhwio"):
+    """weight: conv PARAMETER in checkpoint layout ("dhwio" = [kD,kH,kW,Cin,Cout]; "oidhw" = nn.Conv3d's [Cout,Cin,kD,kH,kW])."""
+    return _SparseConv.apply(feats, weight, geom, layout)
 
 
 class _BNRows(torch.autograd.Function):
