@@ -1,3 +1,3 @@
 cd /root/repo
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_l.json 2> gpurun_out/bench_l.err; tail -c 200 gpurun_out/bench_l.err; cut -c1-330 gpurun_out/bench_l.json
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_m.json 2> gpurun_out/bench_m.err; tail -c 200 gpurun_out/bench_m.err; cut -c1-330 gpurun_out/bench_m.json

@@ -946,6 +946,153 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_wgrad(const u16
       }
 }
 
+// ---------------------------------------------------------------------------------------------
+// weight gradient with LDS-DMA staging: both stage tiles ([64 rows][TM] gathered input rows, [64 rows][TN] dout rows) go global ->
+// LDS with `buffer_load_dwordx4 ... lds`, lane-linear, unpadded.  Transpose reads of an unpadded tile would put the 8 rows of a
+// 32-lane group on the same banks (row stride = multiple of 256 B), so 16-column tile T of row r is stored at tile position
+// T ^ (r & 7) (source-side swizzle; r & 7 is a per-lane constant of the reading lane: its rows are k0 + 4g + j (+16)).
+// Requires cin % TM == 0 and cout % TN == 0 (dispatch), TM, TN in {64, 128, 256}.
+// ---------------------------------------------------------------------------------------------
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__device__ __forceinline__ void igemm_wgrad_glds_body(const u16* __restrict__ in, const u16* __restrict__ dout,
+                                                      const int* __restrict__ nbr, int ld, float* __restrict__ partial,
+                                                      const int* __restrict__ n_out_dev, int n_out_cap, int cin, int cout, int kvol,
+                                                      int co_blocks) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int TM = WAVES_M * WM * 16, TN = WAVES_N * WN * 16, RK = 64;
+  constexpr int A_ELEMS = RK * TM, D_ELEMS = RK * TN, STAGE_ELEMS = A_ELEMS + D_ELEMS;
+  constexpr int A_LPR = TM / 8, D_LPR = TN / 8;                  // lanes (16-byte slots) per row
+  constexpr int A_RPI = 64 / A_LPR, D_RPI = 64 / D_LPR;          // rows per wave-instruction (1 KiB)
+  constexpr int A_SEGS = RK / A_RPI / NW, D_SEGS = RK / D_RPI / NW;
+  constexpr int A_YMASK = (TM / 16 >= 8) ? 7 : (TM / 16 - 1), D_YMASK = (TN / 16 >= 8) ? 7 : (TN / 16 - 1);
+  static_assert(RK % (A_RPI * NW) == 0 && RK % (D_RPI * NW) == 0, "tile/wave mismatch");
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+
+  const int n_out = min(*n_out_dev, n_out_cap);
+  const int nsplit = gridDim.x, split = blockIdx.x, kap = blockIdx.y;
+  const int ci0 = (blockIdx.z / co_blocks) * TM, co0 = (blockIdx.z % co_blocks) * TN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = (n_out + RK - 1) / RK;
+  const int per = (ntiles + nsplit - 1) / nsplit;
+  const int t_begin = split * per, t_end = min(ntiles, t_begin + per);
+
+  const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc((void*)dout, 0, -1, 0x00020000);
+  const unsigned in_row_bytes = (unsigned)cin * 2u, d_row_bytes = (unsigned)cout * 2u;
+  // loader role
+  int a_row[A_SEGS], d_row[D_SEGS];
+  unsigned a_col[A_SEGS], d_col[D_SEGS];
+#pragma unroll
+  for (int u = 0; u < A_SEGS; ++u) {
+    const int r = (wv * A_SEGS + u) * A_RPI + lane / A_LPR, slot = lane % A_LPR;
+    const int chunk = slot ^ (((r & 7) & A_YMASK) << 1);         // 16-column tile T = chunk >> 1 is XORed with r & 7
+    a_row[u] = r;
+    a_col[u] = (unsigned)(ci0 + chunk * 8) * 2u;
+  }
+#pragma unroll
+  for (int u = 0; u < D_SEGS; ++u) {
+    const int r = (wv * D_SEGS + u) * D_RPI + lane / D_LPR, slot = lane % D_LPR;
+    const int chunk = slot ^ (((r & 7) & D_YMASK) << 1);
+    d_row[u] = r;
+    d_col[u] = (unsigned)(co0 + chunk * 8) * 2u;
+  }
+  int src_nxt[A_SEGS];
+  auto load_src_next = [&](int t) {
+    const int r0 = t * RK;
+#pragma unroll
+    for (int u = 0; u < A_SEGS; ++u) {
+      int m = r0 + a_row[u];
+      int mc = m < n_out ? m : n_out - 1;
+      src_nxt[u] = nbr ? nbr[(long long)kap * ld + mc] : mc;
+    }
+  };
+  auto issue = [&](int t, int buf) {
+    const int r0 = t * RK;
+    const bool live = t < t_end;
+    u16* Ab = smem + buf * STAGE_ELEMS + wv * (A_SEGS * 512);
+    u16* Db = smem + buf * STAGE_ELEMS + A_ELEMS + wv * (D_SEGS * 512);
+#pragma unroll
+    for (int u = 0; u < A_SEGS; ++u) {
+      const bool ok = live && (r0 + a_row[u] < n_out) && src_nxt[u] >= 0;
+      unsigned voff = ok ? (unsigned)src_nxt[u] * in_row_bytes + a_col[u] : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void_ptr)(Ab + u * 512), 16, voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < D_SEGS; ++u) {
+      const int m = r0 + d_row[u];
+      unsigned voff = (live && m < n_out) ? (unsigned)m * d_row_bytes + d_col[u] : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rs, (lds_void_ptr)(Db + u * 512), 16, voff, 0, 0, 0);
+    }
+    load_src_next(t + 1);
+  };
+  // reader role: transpose-read fragments; this lane's rows are k0 + 4g + j (+16): y = (4g + j) & 7
+  const int g = lane >> 4, L = lane & 15, j = L >> 2, q = L & 3;
+  const int ya = ((4 * g + j) & 7) & A_YMASK, yd = ((4 * g + j) & 7) & D_YMASK;
+  auto trf = [&](const u16* tile, int stride, int k0, int T, int y) {
+    const u16* p0 = tile + (k0 + 4 * g + j) * stride + ((T ^ y) << 4) + 4 * q;
+    s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(p0));
+    s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(p0 + 16 * stride));
+    s16x8 v = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  if (t_begin < t_end) {
+    load_src_next(t_begin);
+    issue(t_begin, 0);
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+      const int buf = (t - t_begin) & 1;
+      issue(t + 1, buf ^ 1);                            // past the last stage: all offsets out of range -> zeros into the idle buffer
+      const u16* A = smem + buf * STAGE_ELEMS;
+      const u16* D = A + A_ELEMS;
+#pragma unroll
+      for (int ks = 0; ks < RK / 32; ++ks) {
+        bf16x8 bfr[WN];
+#pragma unroll
+        for (int b = 0; b < WN; ++b) bfr[b] = trf(D, TN, ks * 32, wn * WN + b, yd);
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+          bf16x8 af = trf(A, TM, ks * 32, wm * WM + a, ya);
+#pragma unroll
+          for (int b = 0; b < WN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[b], acc[a][b], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  float* p = partial + ((long long)split * kvol + kap) * cin * cout;
+  const int li = lane & 15;
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int ci = ci0 + (wm * WM + a) * 16 + g * 4 + r;
+        int co = co0 + (wn * WN + b) * 16 + li;
+        p[(long long)ci * cout + co] = acc[a][b][r];
+      }
+}
+#define U3D_WGRAD_GLDS_KERNEL(NAME, A, B, C, D)                                                                                   \
+  __global__ __launch_bounds__(A* B * 64) void NAME(const u16* in, const u16* dout, const int* nbr, int ld, float* partial,        \
+                                                    const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol, int co_blocks) { \
+    igemm_wgrad_glds_body<A, B, C, D>(in, dout, nbr, ld, partial, n_out_dev, n_out_cap, cin, cout, kvol, co_blocks);               \
+  }
+U3D_WGRAD_GLDS_KERNEL(k_igemm_wgrad_glds_256, 2, 4, 8, 4)
+U3D_WGRAD_GLDS_KERNEL(k_igemm_wgrad_glds_128, 2, 2, 4, 4)
+U3D_WGRAD_GLDS_KERNEL(k_igemm_wgrad_glds_64, 2, 2, 2, 2)
+#undef U3D_WGRAD_GLDS_KERNEL
+typedef void (*wgrad_glds_kernel_t)(const u16*, const u16*, const int*, int, float*, const int*, int, int, int, int, int);
+
 __global__ void k_igemm_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, long long n, int nsplit) {
   long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
@@ -1003,6 +1150,23 @@ static int launch_igemm_wgrad(const void* in, const void* dout, const int32_t* n
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
 }
 
+#ifndef IGEMM_WGRAD_GLDS
+#define IGEMM_WGRAD_GLDS 1
+#endif
+static int launch_igemm_wgrad_glds(int tile, const void* in, const void* dout, const int32_t* nbr, int ld, float* partial,
+                                   const int32_t* n_out_dev, int n_out_cap, int cin, int cout, int kvol, const WgPlan& p, hipStream_t s) {
+  wgrad_glds_kernel_t kern = tile == 256 ? k_igemm_wgrad_glds_256 : (tile == 128 ? k_igemm_wgrad_glds_128 : k_igemm_wgrad_glds_64);
+  const int nthreads = tile == 256 ? 512 : 256;
+  const size_t lds = 2 * (size_t)(64 * tile + 64 * tile) * 2;
+  static bool attr_set[3] = {false, false, false};
+  const int ai = tile == 256 ? 0 : (tile == 128 ? 1 : 2);
+  if (!attr_set[ai] && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[ai] = true; }
+  dim3 grid(p.nsplit, kvol, p.ci_blocks * p.co_blocks);
+  hipLaunchKernelGGL(kern, grid, dim3(nthreads), lds, s, (const u16*)in, (const u16*)dout, nbr, ld, partial, n_out_dev, n_out_cap, cin, cout,
+                     kvol, p.co_blocks);
+  return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
+}
+
 extern "C" int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const int32_t* nbr, int32_t ld, float* dw,
                                         const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
                                         void* workspace, int64_t workspace_bytes, u3d_stream s) {
@@ -1012,6 +1176,11 @@ extern "C" int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const 
   long long n = (long long)kvol * cin * cout;
   U3D_REQUIRE(workspace_bytes >= (int64_t)p.nsplit * n * 4, U3D_ERR_WORKSPACE);
   int rc;
+#if IGEMM_WGRAD_GLDS
+  if (p.tile >= 64 && cin % p.tile == 0 && cout % p.tile == 0)
+    rc = launch_igemm_wgrad_glds(p.tile, in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
+  else
+#endif
   if (p.tile == 256) rc = launch_igemm_wgrad<2, 4, 8, 4>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
   else if (p.tile == 128) rc = launch_igemm_wgrad<2, 2, 4, 4>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
   else if (p.tile == 64) rc = launch_igemm_wgrad<2, 2, 2, 2>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
