@@ -704,9 +704,12 @@ extern "C" int32_t u3d_linear_bf16(const void* x, const void* w, const float* bi
   U3D_REQUIRE(x && w && out && m_dev, U3D_ERR_ARG);
   if (k % 64 != 0 || n % 64 != 0) return U3D_ERR_UNSUPPORTED;
   if (m_cap <= 0) return U3D_OK;
-  if (m_cap >= 65536 && n % 256 == 0) return launch_igemm_fwd<2, 4, 8, 4, false>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
-  if (m_cap >= 32768 && n % 128 == 0) return launch_igemm_fwd<4, 2, 4, 4, false>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
-  return launch_igemm_fwd<4, 1, 2, 4, false>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
+  // nn.Linear's [N, K] weight IS the n-major layout of the LDS-DMA kernels
+  const long long wg256 = (long long)u3d_cdiv(m_cap, 256) * (n / 256);
+  if (n % 256 == 0 && wg256 >= 128) return launch_igemm_glds<2, 4, 8, 4>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
+  if (n % 128 == 0 && (long long)u3d_cdiv(m_cap, 256) * (n / 128) >= 128)
+    return launch_igemm_glds<4, 2, 4, 4>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
+  return launch_igemm_glds<4, 1, 2, 4>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
 }
 
 // returns U3D_ERR_UNSUPPORTED when the shape is better served by the first-generation kernel

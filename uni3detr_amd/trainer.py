@@ -27,27 +27,29 @@ class TrainStep:
         self.graph = graph
         self.params = [p for p in model.parameters() if p.requires_grad]
         # one flat gradient buffer; every .grad is a view of it (static addresses for capture, one all-reduce message)
-        n = sum(p.numel() for p in self.params)
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=self.dev)
-        o = 0
-        self.views = []
+        # every parameter starts on a 256-byte boundary of the flat buffers: torch picks its vectorised kernels (LayerNorm, bias
+        # adds) by pointer alignment, and packed offsets had silently moved LayerNorm to the scalar RowwiseMoments path
+        ALIGN = 64
+        self.offsets, n = [], 0
         for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=self.dev)
+        self.views = []
+        for p, o in zip(self.params, self.offsets):
             self.views.append(self.flat_grad[o:o + p.numel()].view_as(p))
             p.grad = self.views[-1]
-            o += p.numel()
         self.lr, self.weight_decay = lr, weight_decay
         self.flat_update = flat_update
         if flat_update:
             # parameters re-homed into ONE flat buffer (each p.data becomes a view; names/shapes/state_dict unchanged), moments flat:
             # clip + AdamW is u3d_adamw_step - three launches that stream the 7 arrays once (torch: ~30 multi-tensor launches)
-            self.flat_param = torch.empty(n, dtype=torch.float32, device=self.dev)
-            o = 0
+            self.flat_param = torch.zeros(n, dtype=torch.float32, device=self.dev)
             with torch.no_grad():
-                for p in self.params:
+                for p, o in zip(self.params, self.offsets):
                     v = self.flat_param[o:o + p.numel()].view_as(p)
                     v.copy_(p.data)
                     p.data = v
-                    o += p.numel()
             self.exp_avg = torch.zeros_like(self.flat_param)
             self.exp_avg_sq = torch.zeros_like(self.flat_param)
             self.opt_state = torch.zeros(8, dtype=torch.float32, device=self.dev)
