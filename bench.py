@@ -216,7 +216,8 @@ def main():
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get(out["dtype"], {}).get("heaviest_launch_hbm_bytes")
             out["roofline"] = {
-                "kernel": ("k_igemm_fwd" if h.get("v2") else "k_spconv_fwd") + f" [{h['tag']}, {h['kind']} lattice, N={h['n_out']}, "
+                "kernel": (("k_igemm_wgrad_glds" if "wgrad" in h["tag"] else "k_igemm_glds") if h.get("v2") else
+                           ("k_spconv_wgrad" if "wgrad" in h["tag"] else "k_spconv_fwd")) + f" [{h['tag']}, {h['kind']} lattice, N={h['n_out']}, "
                           f"Cin={h['cin']}, Cout={h['cout']}, K={h['kvol']}, pairs={h['pairs']}]",
                 "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
                 "launch_ms": h["ms"], "algorithmic_bytes": h["bytes"], "flops": h["flops"], "arithmetic_intensity": ai,

@@ -1,3 +1,5 @@
 cd /root/repo
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_m.json 2> gpurun_out/bench_m.err; tail -c 200 gpurun_out/bench_m.err; cut -c1-330 gpurun_out/bench_m.json
+for i in 1 2; do
+U3D_FAST_LINEAR=0 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-200
+U3D_FAST_LINEAR=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-200
+done

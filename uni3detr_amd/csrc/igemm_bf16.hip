@@ -417,6 +417,8 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
     igemm_glds_body<A, B, C, D>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu);                          \
   }
 U3D_GLDS_KERNEL(k_igemm_glds_256x256, 2, 4, 8, 4)
+// (a 4-wave variant with 128 x 128 per wave - 1.5x fewer LDS fragment bytes per MFMA - compiled to 512 VGPRs + spills and ran at
+//  877 vs 1076 TFLOP/s: it needs a hand-scheduled fragment pipeline, not another template instance)
 U3D_GLDS_KERNEL(k_igemm_glds_256x128, 4, 2, 4, 4)
 U3D_GLDS_KERNEL(k_igemm_glds_128x64, 4, 1, 2, 4)
 #undef U3D_GLDS_KERNEL
