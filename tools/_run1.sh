@@ -1,5 +1,4 @@
 cd /root/repo
-for i in 1 2; do
-U3D_FAST_LINEAR=0 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-200
-U3D_FAST_LINEAR=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-200
-done
+U3D_FORCE_DDP=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | cut -c1-260
+U3D_FORCE_DDP=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-graph 2>&1 | tail -1 | cut -c1-260
+timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3

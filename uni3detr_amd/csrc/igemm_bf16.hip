@@ -421,6 +421,7 @@ U3D_GLDS_KERNEL(k_igemm_glds_256x256, 2, 4, 8, 4)
 //  877 vs 1076 TFLOP/s: it needs a hand-scheduled fragment pipeline, not another template instance)
 U3D_GLDS_KERNEL(k_igemm_glds_256x128, 4, 2, 4, 4)
 U3D_GLDS_KERNEL(k_igemm_glds_128x64, 4, 1, 2, 4)
+U3D_GLDS_KERNEL(k_igemm_glds_128x128, 2, 2, 4, 4)      /* 4 waves, 64 KiB LDS: two workgroups per CU run out of phase */
 #undef U3D_GLDS_KERNEL
 typedef void (*glds_kernel_t)(const u16*, const u16*, const int*, int, u16*, const int*, int, int, int, int, const float*, int);
 
@@ -429,7 +430,8 @@ static int launch_igemm_glds(const void* in, const void* w, const int32_t* nbr, 
                              int n_out_cap, int cin, int cout, int kvol, hipStream_t s, const float* bias = nullptr, int relu = 0) {
   constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
   constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;        // 256 x 256: 128 KiB
-  glds_kernel_t kern = (BM == 256 && BN == 256) ? k_igemm_glds_256x256 : (BM == 256 ? k_igemm_glds_256x128 : k_igemm_glds_128x64);
+  glds_kernel_t kern = (BM == 256 && BN == 256) ? k_igemm_glds_256x256
+                       : (BM == 256 ? k_igemm_glds_256x128 : (BN == 128 ? k_igemm_glds_128x128 : k_igemm_glds_128x64));
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
@@ -731,7 +733,8 @@ extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32
 #if IGEMM_GLDS
   if (transpose_w) {                                                // n-major weights: LDS-DMA staged kernels
     if (cout % 256 == 0 && wg256 >= 128) return launch_igemm_glds<2, 4, 8, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
-    if (cout % 128 == 0) return launch_igemm_glds<4, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
+    // 128 x 128 (4 waves, 64 KiB LDS, two workgroups per CU out of phase): +3...6 % over 256 x 128 on the 128- and 512-channel layers
+    if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
     if (cout % 64 == 0) return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
   }
 #endif
