@@ -13,6 +13,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
@@ -384,29 +385,29 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
       for (int b = 0; b < WN; ++b) {
         bf16x8 bfr = frag(W + b * 16 * BK, ks);
 #pragma unroll
-        for (int a = 0; a < WM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr, acc[a][b], 0, 0, 0);
+        // operands swapped: the MFMA produces the TRANSPOSED 16x16 block, i.e. this lane ends up with 4 consecutive output
+        // COLUMNS (4g..4g+3) of row li - one 8-byte store per block in the epilogue instead of four 2-byte ones
+        for (int a = 0; a < WM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af[a], acc[a][b], 0, 0, 0);
       }
     }
     __syncthreads();                                    // also drains this wave's LDS-DMA (vmcnt) before anyone reads the next buffer
   }
-  const int r4 = g * 4;
+  // epilogue: acc[a][b][r] = C[row (wm*WM+a)*16 + li][col (wn*WN+b)*16 + 4g + r]; v_cvt_pk_bf16_f32 (RNE) via convertvector
 #pragma unroll
-  for (int a = 0; a < WM; ++a)
+  for (int a = 0; a < WM; ++a) {
+    const int m = m0 + (wm * WM + a) * 16 + li;
+    if (m >= n_out) continue;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int m = m0 + (wm * WM + a) * 16 + r4 + r;
-      if (m >= n_out) continue;
-#pragma unroll
-      for (int b = 0; b < WN; ++b) {
-        int col = col0 + (wn * WN + b) * 16 + li;
-        if (col < cout) {
-          float v = acc[a][b][r];
-          if (bias) v += bias[col];
-          if (relu) v = fmaxf(v, 0.f);
-          out[(long long)m * cout + col] = f2bf(v);
-        }
+    for (int b = 0; b < WN; ++b) {
+      const int col = col0 + (wn * WN + b) * 16 + 4 * g;
+      if (col < cout) {                                 // cout % 8 == 0: the 4-column group is in or out as a whole
+        f32x4 v = acc[a][b];
+        if (bias) { const f32x4 bv = *(const f32x4*)(bias + col); v += bv; }
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *(bf16x4*)(out + (long long)m * cout + col) = __builtin_convertvector(v, bf16x4);
       }
     }
+  }
 }
 
 // concrete kernels (a __global__ TEMPLATE with this body lost its host stub under hipcc 7.2: undefined symbol at load time)
@@ -1071,24 +1072,23 @@ __device__ __forceinline__ void igemm_wgrad_glds_body(const u16* __restrict__ in
         for (int a = 0; a < WM; ++a) {
           bf16x8 af = trf(A, TM, ks * 32, wm * WM + a, ya);
 #pragma unroll
-          for (int b = 0; b < WN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < WN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af, acc[a][b], 0, 0, 0);   // transposed block
         }
       }
       __syncthreads();
     }
   }
+  // acc[a][b][r] = dW[ci (wm*WM+a)*16 + li][co (wn*WN+b)*16 + 4g + r]: one 16-byte store per block
   float* p = partial + ((long long)split * kvol + kap) * cin * cout;
   const int li = lane & 15;
 #pragma unroll
   for (int a = 0; a < WM; ++a)
 #pragma unroll
-    for (int b = 0; b < WN; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int ci = ci0 + (wm * WM + a) * 16 + g * 4 + r;
-        int co = co0 + (wn * WN + b) * 16 + li;
-        p[(long long)ci * cout + co] = acc[a][b][r];
-      }
+    for (int b = 0; b < WN; ++b) {
+      const int ci = ci0 + (wm * WM + a) * 16 + li;
+      const int co = co0 + (wn * WN + b) * 16 + 4 * g;
+      *(f32x4*)(p + (long long)ci * cout + co) = acc[a][b];
+    }
 }
 #define U3D_WGRAD_GLDS_KERNEL(NAME, A, B, C, D)                                                                                   \
   __global__ __launch_bounds__(A* B * 64) void NAME(const u16* in, const u16* dout, const int* nbr, int ld, float* partial,        \

@@ -376,15 +376,10 @@ template <>
 __device__ __forceinline__ void store_vec<float>(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
 template <>
 __device__ __forceinline__ void store_vec<u16>(u16* p, const float* v) {
-  unsigned w[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    u16 lo, hi;
-    st_elem(&lo, 0, v[2 * i]);
-    st_elem(&hi, 0, v[2 * i + 1]);
-    w[i] = (unsigned)lo | ((unsigned)hi << 16);
-  }
-  *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+  typedef float f32x8_t __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  f32x8_t f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+  *(bf16x8_t*)p = __builtin_convertvector(f, bf16x8_t);        // 4 x v_cvt_pk_bf16_f32 (round to nearest even), one 16-byte store
 }
 
 template <typename T>
