@@ -1,4 +1,3 @@
 cd /root/repo
-U3D_FORCE_DDP=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | cut -c1-260
-U3D_FORCE_DDP=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-graph 2>&1 | tail -1 | cut -c1-260
-timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_n.json 2> gpurun_out/bench_n.err; tail -c 200 gpurun_out/bench_n.err; cat gpurun_out/bench_n.json

@@ -1098,6 +1098,8 @@ __device__ __forceinline__ void igemm_wgrad_glds_body(const u16* __restrict__ in
 U3D_WGRAD_GLDS_KERNEL(k_igemm_wgrad_glds_256, 2, 4, 8, 4)
 U3D_WGRAD_GLDS_KERNEL(k_igemm_wgrad_glds_128, 2, 2, 4, 4)
 U3D_WGRAD_GLDS_KERNEL(k_igemm_wgrad_glds_64, 2, 2, 2, 2)
+// (32- and 16-channel tiles were tried on this kernel too: correct, but no faster than k_igemm_wgrad - those layers are bound by
+//  the L2 gather, not by staging - so they stay on the buffer-load kernel)
 #undef U3D_WGRAD_GLDS_KERNEL
 typedef void (*wgrad_glds_kernel_t)(const u16*, const u16*, const int*, int, float*, const int*, int, int, int, int, int);
 
@@ -1161,6 +1163,9 @@ static int launch_igemm_wgrad(const void* in, const void* dout, const int32_t* n
 #ifndef IGEMM_WGRAD_GLDS
 #define IGEMM_WGRAD_GLDS 1
 #endif
+#ifndef IGEMM_WGRAD_GLDS_MIN_TILE
+#define IGEMM_WGRAD_GLDS_MIN_TILE 64
+#endif
 static int launch_igemm_wgrad_glds(int tile, const void* in, const void* dout, const int32_t* nbr, int ld, float* partial,
                                    const int32_t* n_out_dev, int n_out_cap, int cin, int cout, int kvol, const WgPlan& p, hipStream_t s) {
   wgrad_glds_kernel_t kern = tile == 256 ? k_igemm_wgrad_glds_256 : (tile == 128 ? k_igemm_wgrad_glds_128 : k_igemm_wgrad_glds_64);
@@ -1185,7 +1190,7 @@ extern "C" int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const 
   U3D_REQUIRE(workspace_bytes >= (int64_t)p.nsplit * n * 4, U3D_ERR_WORKSPACE);
   int rc;
 #if IGEMM_WGRAD_GLDS
-  if (p.tile >= 64 && cin % p.tile == 0 && cout % p.tile == 0)
+  if (p.tile >= IGEMM_WGRAD_GLDS_MIN_TILE && cin % p.tile == 0 && cout % p.tile == 0)
     rc = launch_igemm_wgrad_glds(p.tile, in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
   else
 #endif
