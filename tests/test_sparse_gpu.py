@@ -312,8 +312,30 @@ def test_spconv_fwd_bwd_bf16(cuda, cin, cout, kvol, v2):
         y = nv.spconv_fwd(xd, wd, nbr, nd, n, cout)
         dx = nv.spconv_fwd(gyd, wd, nbr_t, nd, n, cin, transpose_w=True)
         dw = nv.spconv_wgrad(xd, gyd, nbr, nd, kvol)
+        # n-major weights ([K, Cout, Cin]): the LDS-DMA forward the model uses must give the k-major kernel's result
+        y_nm = nv.spconv_fwd(xd, wd.transpose(1, 2).contiguous(), nbr, nd, n, cout, transpose_w=True)
+        # capacity mode: buffers larger than the device-side row count; rows past the count are never produced from
+        cap = n + 777
+        xpad = torch.cat([xd, torch.full((cap - n, cin), float("nan"), device=cuda, dtype=torch.bfloat16)])
+        gpad = torch.cat([gyd, torch.full((cap - n, cout), float("nan"), device=cuda, dtype=torch.bfloat16)])
+        nbr_c = nbr_tc = None
+        if nbr is not None:
+            nbr_c = torch.full((kvol, (cap + 127) // 128 * 128), -1, dtype=torch.int32, device=cuda)
+            nbr_tc = nbr_c.clone()
+            nbr_c[:, :n] = nbr[:, :n]
+            nbr_tc[:, :n] = nbr_t[:, :n]
+        y_cap = nv.spconv_fwd(xpad, wd, nbr_c, nd, cap, cout)
+        dx_cap = nv.spconv_fwd(gpad, wd, nbr_tc, nd, cap, cin, transpose_w=True)
+        dw_cap = nv.spconv_wgrad(xpad, gpad, nbr_c, nd, kvol)
+        zero = torch.zeros(1, dtype=torch.int32, device=cuda)
+        dw_zero = nv.spconv_wgrad(xpad, gpad, nbr_c, zero, kvol)
     finally:
         nv.USE_IGEMM_V2 = old
+    assert (y_nm.float() - y.float()).abs().max().item() <= 1e-2 * yr.abs().max().item()
+    assert torch.equal(y_cap[:n], y) and torch.equal(dx_cap[:n], dx)
+    # the row split of the weight gradient follows the capacity: same terms, different f32 summation order (and no NaN leaked in)
+    assert (dw_cap - dw).abs().max().item() <= 1e-4 * max(1.0, dw.abs().max().item())
+    assert float(dw_zero.abs().max()) == 0.0
     assert (y.float().cpu() - yr.detach()).abs().max().item() <= 1e-2 * yr.abs().max().item()          # bf16 output rounding
     assert (dx.float().cpu() - xr.grad).abs().max().item() <= 1e-2 * xr.grad.abs().max().item()
     assert (dw.cpu() - wr.grad).abs().max().item() <= 2e-3 * wr.grad.abs().max().item()                 # f32 accumulate, f32 output
