@@ -207,6 +207,11 @@ def fast_linear(x, lin, relu=False, weight=None, bias=None):
     return F.relu(y) if relu else y
 
 
+def residual_add(x, o):
+    """x + o with o brought to x's dtype first (see MultiheadAttention.forward_grouped on mixed-dtype adds)."""
+    return x + (o if o.dtype == x.dtype else o.to(x.dtype))
+
+
 def run_sequential(seq, x):
     """nn.Sequential of Linear / LayerNorm / ReLU / Dropout (the head branches, position encoder, FFN) with Linear(+ReLU)
     routed through fast_linear."""
@@ -279,8 +284,16 @@ class MultiheadAttention(nn.Module):
         """x, pos: [B, G*group, C]; attention within each group of `group` queries."""
         B, N, C = x.shape
         H = self.num_heads
-        qk = (x + pos).reshape(-1, group, C)
-        xv = x.reshape(-1, group, C)
+        cdt = _autocast_dtype(x)
+        if cdt is not None and x.dtype != cdt:
+            # one cast of the f32 stream serves q = k and v; a mixed f32 + bf16 add runs on torch's "templated" kernel at ~40 us
+            # for [8,900,256] (a same-dtype add: 4 us), so every mixed add of the layer is written as cast + add
+            xb = x.to(cdt)
+            qk = (xb + pos.to(cdt)).reshape(-1, group, C)
+            xv = xb.reshape(-1, group, C)
+        else:
+            qk = (x + pos).reshape(-1, group, C)
+            xv = x.reshape(-1, group, C)
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
         if SAFE_LINEAR and not FAST_LINEAR and x.is_cuda and torch.is_grad_enabled() and b is not None:
             qk_p, v = _InProjFn.apply(qk, xv, w, b, _autocast_dtype(x))
@@ -292,7 +305,7 @@ class MultiheadAttention(nn.Module):
         o = F.scaled_dot_product_attention(sh(q), sh(k), sh(v), dropout_p=self.attn_drop if self.training else 0.0)
         o = o.transpose(1, 2).reshape(B, N, C)
         o = fast_linear(o, self.attn.out_proj)
-        return x + self.dropout_layer(self.proj_drop(o))
+        return residual_add(x, self.dropout_layer(self.proj_drop(o)))
 
 
 @FEEDFORWARD_NETWORK.register_module()
@@ -313,7 +326,7 @@ class FFN(nn.Module):
         out = self.dropout_layer(run_sequential(self.layers, x))
         if not self.add_identity:
             return out
-        return (x if identity is None else identity) + out
+        return residual_add(x if identity is None else identity, out)
 
 
 class _TrilinearSample(torch.autograd.Function):
@@ -368,15 +381,23 @@ class UniCrossAtten(nn.Module):
 
     def forward_bf(self, query, query_pos, value, ref_logits):
         """query/query_pos [B,N,C]; value [B,C,D,H,W] (or [B,C,H,W]); ref_logits [B,N,3] -> [B,N,C]."""
-        w = fast_linear(query + query_pos, self.attention_weights).sigmoid()          # [B,N,P]
+        cdt = _autocast_dtype(query)
+        qp = (query.to(cdt) + query_pos.to(cdt)) if (cdt is not None and query.dtype != cdt) else query + query_pos
+        w = fast_linear(qp, self.attention_weights).sigmoid()                         # [B,N,P]
         g = (ref_logits.sigmoid() - 0.5) * 2
         B, N, _ = g.shape
         if value.dim() != 5:
             raise NotImplementedError("height-less (BEV) value maps are not used by any shipped Uni3DETR config")
         samp = _TrilinearSample.apply(value, g)                                       # [B,N,C]
-        out = fast_linear(samp.to(query.dtype) * w.sum(-1, keepdim=True), self.output_proj)
+        wsum = w.sum(-1, keepdim=True)
+        cdt = _autocast_dtype(query)
+        if cdt is not None:             # gate in the compute dtype: the product feeds a bf16 GEMM directly
+            gated = samp.to(cdt) * wsum.to(cdt)
+        else:
+            gated = samp.to(query.dtype) * wsum
+        out = fast_linear(gated, self.output_proj)
         pos_feat = run_sequential(self.position_encoder, ref_logits.to(query.dtype))
-        return self.dropout(out) + query + pos_feat
+        return residual_add(residual_add(query, self.dropout(out)), pos_feat)
 
 
 @TRANSFORMER_LAYER.register_module()
