@@ -1111,6 +1111,9 @@ __global__ void k_igemm_wgrad_reduce(const float* __restrict__ partial, float* _
   *(f32x4*)(dw + i) = s;
 }
 
+#ifndef IGEMM_WGRAD_MIN_STAGES_K1
+#define IGEMM_WGRAD_MIN_STAGES_K1 8   /* 4 and 2 measured slower end-to-end (33.4 / 33.9 vs 33.3 ms per step) */
+#endif
 struct WgPlan { int tile; int ci_blocks, co_blocks, nsplit; };
 static WgPlan wgrad_plan_tile(int tile, int n_out_cap, int cin, int cout, int kvol) {
   WgPlan p;
@@ -1122,8 +1125,10 @@ static WgPlan wgrad_plan_tile(int tile, int n_out_cap, int cin, int cout, int kv
   int target = (p.tile == 256 ? 256 : (p.tile >= 64 ? 512 : 2048)) / wgs_per_split;
   if (target < 1) target = 1;
   int ns = ntiles < target ? ntiles : target;
-  // keep at least 8 stages per split so the prologue is amortised
-  while (ns > 1 && ntiles / ns < 8) --ns;
+  // keep at least 8 stages per split so the prologue is amortised (4 for the single-offset products of the decoder / head linears:
+  // ~113 stages in all, latency-bound - more, shorter workgroups finish sooner)
+  const int min_stages = (kvol == 1 && ntiles <= 256) ? IGEMM_WGRAD_MIN_STAGES_K1 : 8;
+  while (ns > 1 && ntiles / ns < min_stages) --ns;
   p.nsplit = ns < 1 ? 1 : ns;
   return p;
 }
