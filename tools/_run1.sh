@@ -1,5 +1,3 @@
 cd /root/repo
-for v in ms8 main ms2 ms8 main ms2; do
-  if [ $v = main ]; then timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c60-200;
-  else U3D_LIB_PATH=uni3detr_amd/_variants/$v.so timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c60-200; fi
-done
+timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_trainer_gpu.py tests/test_configs_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-330

@@ -125,6 +125,9 @@ class Uni3DETRHead(nn.Module):
         for lvl in range(hs.shape[0]):
             reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
             h = hs[lvl]
+            sc = getattr(self.transformer.decoder, "_states_c", None)
+            if sc is not None and len(sc) == hs.shape[0] and torch.is_autocast_enabled():
+                h = sc[lvl]                    # the decoder's own compute-dtype copy of this state (one cast serves every branch)
             reg = getattr(self.transformer.decoder, "_reg_outputs", None)
             if self.with_box_refine and reg is not None and len(reg) == hs.shape[0]:
                 tmp = reg[lvl].float()         # the decoder already ran reg_branches[lvl] on this very state to refine its points

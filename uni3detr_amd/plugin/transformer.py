@@ -280,15 +280,15 @@ class MultiheadAttention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.dropout_layer = nn.Dropout(dropout_layer["drop_prob"]) if dropout_layer else nn.Identity()
 
-    def forward_grouped(self, x, pos, group):
-        """x, pos: [B, G*group, C]; attention within each group of `group` queries."""
+    def forward_grouped(self, x, pos, group, x_c=None):
+        """x, pos: [B, G*group, C]; attention within each group of `group` queries.  x_c: x already in the compute dtype."""
         B, N, C = x.shape
         H = self.num_heads
         cdt = _autocast_dtype(x)
         if cdt is not None and x.dtype != cdt:
             # one cast of the f32 stream serves q = k and v; a mixed f32 + bf16 add runs on torch's "templated" kernel at ~40 us
             # for [8,900,256] (a same-dtype add: 4 us), so every mixed add of the layer is written as cast + add
-            xb = x.to(cdt)
+            xb = x_c if x_c is not None else x.to(cdt)
             qk = (xb + pos.to(cdt)).reshape(-1, group, C)
             xv = xb.reshape(-1, group, C)
         else:
@@ -428,11 +428,11 @@ class BaseTransformerLayer(nn.Module):
         if self.pre_norm:
             raise NotImplementedError("pre-norm ordering is not used by any shipped Uni3DETR config")
 
-    def forward_bf(self, x, pos, value, ref_logits, group):
+    def forward_bf(self, x, pos, value, ref_logits, group, x_c=None):
         ai = ni = fi = 0
         for op in self.operation_order:
             if op == "self_attn":
-                x = self.attentions[ai].forward_grouped(x, pos, group); ai += 1
+                x = self.attentions[ai].forward_grouped(x, pos, group, x_c if ai == 0 else None); ai += 1
             elif op == "cross_attn":
                 x = self.attentions[ai].forward_bf(x, pos, value, ref_logits); ai += 1
             elif op == "norm":
@@ -459,12 +459,18 @@ class Uni3DETRTransformerDecoder(nn.Module):
         out = query
         states, refs = [], []
         self._reg_outputs = [] if reg_branches is not None else None     # reused by Uni3DETRHead.forward (same module, same input)
+        cdt = _autocast_dtype(query)
+        self._states_c = [] if cdt is not None else None      # each layer state once in the compute dtype: shared by the reg branch,
+        out_c = None                                          # query_scale, the next layer's self-attention and the head's cls / iou branches
         for lid, layer in enumerate(self.layers):
             raw = self.ref_point_head(get_sine_pos_embed(ref_logits.sigmoid()).to(out.dtype))
-            pos = raw if lid == 0 else self.query_scale(out) * raw
-            out = layer.forward_bf(out, pos, value, ref_logits, group)
+            pos = raw if lid == 0 else self.query_scale(out if out_c is None else out_c) * raw
+            out = layer.forward_bf(out, pos, value, ref_logits, group, out_c)
+            if cdt is not None:
+                out_c = out.to(cdt)
+                self._states_c.append(out_c)
             if reg_branches is not None:
-                tmp = run_sequential(reg_branches[lid], out)
+                tmp = run_sequential(reg_branches[lid], out if out_c is None else out_c)
                 self._reg_outputs.append(tmp)
                 assert ref_logits.shape[-1] == 3
                 td = tmp.detach()

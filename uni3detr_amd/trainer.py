@@ -191,6 +191,7 @@ class TrainStep:
         dec = getattr(getattr(self.model.pts_bbox_head, "transformer", None), "decoder", None)
         if dec is not None:
             dec._reg_outputs = None
+            dec._states_c = None
         import gc
         gc.collect()
         torch.cuda.synchronize()
