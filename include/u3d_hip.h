@@ -182,6 +182,10 @@ int32_t u3d_bn_stats(const void* x, const int32_t* n_dev, int32_t n_cap, int32_t
 int32_t u3d_bn_finalize(const double* sums, const int32_t* n_dev, int32_t n_cap, int32_t c, float eps, float momentum,
                         float* running_mean, float* running_var, int64_t* num_batches, float* mean, float* invstd,
                         u3d_stream s);
+/* u3d_bn_stats + u3d_bn_finalize in two launches (stage 2 of the reduction fused with the finalisation); same results. */
+int32_t u3d_bn_forward_stats(const void* x, const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, float eps,
+                             float momentum, float* running_mean, float* running_var, int64_t* num_batches, float* mean,
+                             float* invstd, void* workspace, int64_t workspace_bytes, u3d_stream s);
 /* y = relu?( (x-mean)*invstd*gamma + beta (+ residual) ); mean/invstd/gamma/beta f32 [C]. */
 int32_t u3d_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, const void* residual, int32_t relu, void* y,

@@ -226,6 +226,13 @@ def test_bn_fwd_bwd(cuda, c, relu, res):
     np.testing.assert_allclose(mean.cpu().numpy(), x.double().mean(0).numpy(), rtol=1e-6, atol=1e-7)
     invstd = (1.0 / torch.sqrt(var + 1e-3)).float()
     meanf = mean.float()
+    # fused statistics + finalisation (what the model calls) == the two-step path, incl. the running-stat update
+    rm, rv, nb_t = torch.zeros(c, device=cuda), torch.ones(c, device=cuda), torch.zeros(1, dtype=torch.int64, device=cuda)
+    m2, i2 = nv.bn_forward_stats(xd, nd, 1e-3, 0.1, rm, rv, nb_t)
+    rm_ref, rv_ref, nb_ref = torch.zeros(c, device=cuda), torch.ones(c, device=cuda), torch.zeros(1, dtype=torch.int64, device=cuda)
+    m3, i3 = nv.bn_finalize(sums, nd, n, 1e-3, 0.1, rm_ref, rv_ref, nb_ref)
+    assert torch.equal(m2, m3) and torch.equal(i2, i3) and int(nb_t) == 1
+    assert torch.allclose(rm, rm_ref, rtol=1e-6, atol=0) and torch.allclose(rv, rv_ref, rtol=1e-6, atol=0)     # fma contraction may differ
     y = nv.bn_apply(xd, meanf, invstd, gamma.to(cuda), beta.to(cuda), r.to(cuda) if res else None, relu, nd)
     assert (y.cpu() - yr.detach()).abs().max().item() <= 2e-5 * max(1.0, yr.abs().max().item())
     gyd = gy.to(cuda)

@@ -368,6 +368,64 @@ __global__ void k_bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ y
   }
 }
 
+// forward statistics in two launches instead of three: stage 2 of the reduction and the mean / invstd / running-stat update in one
+// kernel (one wave per column: lanes stride over the row-block partials of sum and sum of squares, fixed tree order)
+__global__ __launch_bounds__(256) void k_bn_final_finalize(const double* __restrict__ partial, int nblocks, const int* __restrict__ n_dev,
+                                                           int n_cap, int c, float eps, float momentum, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, long long* __restrict__ num_batches,
+                                                           float* __restrict__ mean, float* __restrict__ invstd) {
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
+  if (col >= c) return;
+  const int n = min(*n_dev, n_cap);
+  int used = (n + ST_ROWS_PER_BLOCK - 1) / ST_ROWS_PER_BLOCK;
+  if (used > nblocks) used = nblocks;
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = lane; b < used; b += 64) {
+    s0 += partial[((long long)b * 2 + 0) * c + col];
+    s1 += partial[((long long)b * 2 + 1) * c + col];
+  }
+  s0 = u3d_wave_sum_d(s0);
+  s1 = u3d_wave_sum_d(s1);
+  if (lane != 0) return;
+  const double nn = n > 0 ? (double)n : 1.0;
+  const double mu = s0 / nn;
+  double var = s1 / nn - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[col] = (float)mu;
+  invstd[col] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = n > 1 ? var * nn / (nn - 1.0) : var;
+    running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * (float)mu;
+    running_var[col] = (1.f - momentum) * running_var[col] + momentum * (float)unbiased;
+  }
+}
+extern "C" int32_t u3d_bn_forward_stats(const void* x, const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, float eps,
+                                        float momentum, float* running_mean, float* running_var, int64_t* num_batches, float* mean,
+                                        float* invstd, void* workspace, int64_t workspace_bytes, u3d_stream s) {
+  U3D_REQUIRE(x && n_dev && mean && invstd && workspace && c > 0 && (!running_mean || running_var), U3D_ERR_ARG);
+  U3D_REQUIRE(workspace_bytes >= u3d_bn_stats_workspace(n_cap, c), U3D_ERR_WORKSPACE);
+  const int nb = n_cap > 0 ? u3d_cdiv(n_cap, ST_ROWS_PER_BLOCK) : 0;
+  if (nb > 0) {
+    const bool f32 = dtype == U3D_F32;
+    if (!f32 && dtype != U3D_BF16) return U3D_ERR_UNSUPPORTED;
+    const int v = f32 ? 4 : 8;
+    if (c % v == 0) {
+      int cw = (c / v) < 256 ? (c / v) : 256; int rl = 256 / cw;
+      size_t lds = (size_t)2 * rl * cw * v * sizeof(double);
+      if (f32) hipLaunchKernelGGL((k_col_stats_vec<float, 0>), dim3(nb), dim3(256), lds, s, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace);
+      else hipLaunchKernelGGL((k_col_stats_vec<u16, 0>), dim3(nb), dim3(256), lds, s, (const u16*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace);
+    } else {
+      if (f32) hipLaunchKernelGGL((k_col_stats<float, 0>), dim3(nb), dim3(256), 0, s, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace);
+      else hipLaunchKernelGGL((k_col_stats<u16, 0>), dim3(nb), dim3(256), 0, s, (const u16*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace);
+    }
+  }
+  hipLaunchKernelGGL(k_bn_final_finalize, dim3(u3d_cdiv(c, 4)), dim3(256), 0, s, (const double*)workspace, nb, n_dev, n_cap, c, eps, momentum,
+                     running_mean, running_var, (long long*)num_batches, mean, invstd);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
 // Vectorized forms (C a multiple of the 16-byte vector width and C/V a divisor of 256): a thread keeps ONE column group, so the
 // per-column parameters live in registers; 16-byte loads/stores; rows strided over the grid.
 template <typename T>

@@ -61,6 +61,7 @@ _SIGS = {
     "u3d_bn_stats_workspace": (_L, [_I, _I]),
     "u3d_bn_stats": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _P]),
     "u3d_bn_finalize": (_I, [_P, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
+    "u3d_bn_forward_stats": (_I, [_P, _P, _I, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, _L, _P]),
     "u3d_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "u3d_bn_bwd_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
     "u3d_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
@@ -350,6 +351,18 @@ def bn_finalize(sums, n_dev, n_cap, eps, momentum, running_mean=None, running_va
     invstd = torch.empty((c,), dtype=torch.float32, device=sums.device)
     _check(lib().u3d_bn_finalize(_ptr(sums), _ptr(n_dev), n_cap, c, eps, momentum, _ptr(running_mean), _ptr(running_var),
                                  _ptr(num_batches), _ptr(mean), _ptr(invstd), _stream()), "bn_finalize")
+    return mean, invstd
+
+
+def bn_forward_stats(x, n_dev, eps, momentum, running_mean=None, running_var=None, num_batches=None):
+    """Training statistics of a row matrix: (mean, invstd) f32 [C]; updates the running statistics like nn.BatchNorm1d."""
+    n, c = x.shape
+    mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+    invstd = torch.empty((c,), dtype=torch.float32, device=x.device)
+    wsb = int(lib().u3d_bn_stats_workspace(n, c))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=x.device)
+    _check(lib().u3d_bn_forward_stats(_ptr(x), _ptr(n_dev), n, c, dtype_code(x), eps, momentum, _ptr(running_mean), _ptr(running_var),
+                                      _ptr(num_batches), _ptr(mean), _ptr(invstd), _ptr(ws), ws.numel(), _stream()), "bn_forward_stats")
     return mean, invstd
 
 

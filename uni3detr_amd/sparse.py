@@ -135,9 +135,8 @@ class _BNRows(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, residual, n_dev, bn, relu, training):
         n = x.shape[0]
         if training:
-            sums = nv.bn_stats(x, n_dev)
-            mean, invstd = nv.bn_finalize(sums, n_dev, n, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
-                                          bn.running_mean, bn.running_var, bn.num_batches_tracked)
+            mean, invstd = nv.bn_forward_stats(x, n_dev, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                                               bn.running_mean, bn.running_var, bn.num_batches_tracked)
         else:
             mean = bn.running_mean
             invstd = torch.rsqrt(bn.running_var + bn.eps)
