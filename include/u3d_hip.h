@@ -169,6 +169,17 @@ int64_t u3d_colsum_workspace(int32_t n, int32_t c);
 int32_t u3d_colsum(const void* x, int32_t n, int32_t c, int32_t dtype, float* out, void* workspace,
                    int64_t workspace_bytes, u3d_stream s);
 
+/* Batched forms for the parameter gradients of the decoder / head linears (one shape per call, count <= 48 / 64): all weight
+ * gradients dW_b = in_b^T @ dout_b (bf16 [n_rows, cin] x [n_rows, cout] -> f32 [cin, cout]) in two launches, all bias gradients
+ * in two launches; pointer arrays are HOST arrays of device pointers (they travel in the kernel arguments). */
+int64_t u3d_wgrad_batched_workspace(int32_t count, int32_t n_rows, int32_t cin, int32_t cout);
+int32_t u3d_wgrad_batched_bf16(const void* const* in, const void* const* dout, float* const* dw, int32_t count,
+                               const int32_t* n_dev, int32_t n_rows, int32_t cin, int32_t cout, void* workspace,
+                               int64_t workspace_bytes, u3d_stream s);
+int64_t u3d_colsum_batched_workspace(int32_t count, int32_t n, int32_t c);
+int32_t u3d_colsum_batched(const void* const* x, float* const* out, int32_t count, int32_t n, int32_t c, int32_t dtype,
+                           void* workspace, int64_t workspace_bytes, u3d_stream s);
+
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm1d over sparse rows [n, C] (training statistics) with optional residual add and ReLU
  * (ref: sparse_encoder_hd.py:40; upstream make_sparse_convmodule / SparseBasicBlock).

@@ -207,8 +207,8 @@ def test_colsum_matches_float64_sum(cuda, n, c, dtype):
     assert torch.equal(got, nv.colsum(x))                      # fixed summation order
 
 
-@pytest.mark.parametrize("amp", [True, False])
-def test_safe_linear_and_in_proj_backward_match_torch(cuda, amp):
+@pytest.mark.parametrize("amp,defer", [(True, False), (False, False), (True, True)])
+def test_safe_linear_and_in_proj_backward_match_torch(cuda, amp, defer):
     """fast_linear (shadow weights, HIP wgrad + colsum backward) and the packed in-projection against plain F.linear autograd."""
     from uni3detr_amd.plugin import transformer as T
     from uni3detr_amd.shadow import ShadowSet
@@ -235,6 +235,7 @@ def test_safe_linear_and_in_proj_backward_match_torch(cuda, amp):
     x2, p2 = x.detach().clone().requires_grad_(True), pos.detach().clone().requires_grad_(True)
     shadows = ShadowSet([lin.weight, lin.bias, mha.in_proj_weight, mha.in_proj_bias], torch.bfloat16)
     import contextlib
+    T.reset_param_uses()
     with (shadows.active() if amp else contextlib.nullcontext()), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
         y = T.fast_linear(x2, lin)
         qkp, v = T._InProjFn.apply(x2 + p2, x2, mha.in_proj_weight, mha.in_proj_bias, torch.bfloat16 if amp else None)
@@ -242,7 +243,11 @@ def test_safe_linear_and_in_proj_backward_match_torch(cuda, amp):
     tol = 3e-2 if amp else 2e-3
     rel = lambda a, b: (a.float() - b.float()).abs().max().item() / max(1.0, b.abs().max().item())
     assert rel(y, y_ref) <= tol and rel(qkp, qkp_ref) <= tol and rel(v, v_ref) <= tol
-    ((y.float() * gy).sum() + (qkp.float() * gq).sum() + (v.float() * gv).sum()).backward()
+    # defer=True: parameter gradients are queued during backward and produced by the batched kernels at the end of the block
+    with (T.deferred_param_grads() if defer else contextlib.nullcontext()):
+        ((y.float() * gy).sum() + (qkp.float() * gq).sum() + (v.float() * gv).sum()).backward()
+        if defer:
+            assert len(T._Deferred.items) == 3                 # linear + the two halves of the packed in-projection
     assert lin.weight.grad.dtype == torch.float32 and mha.in_proj_weight.grad.shape == (3 * C, C)
     assert rel(lin.weight.grad, wl.grad) <= tol and rel(lin.bias.grad, bl.grad) <= tol
     assert rel(mha.in_proj_weight.grad, wi.grad) <= tol and rel(mha.in_proj_bias.grad, bi.grad) <= tol
@@ -262,3 +267,19 @@ def test_safe_linear_and_in_proj_backward_match_torch(cuda, amp):
         finally:
             S._ACTIVE[0] = False
         assert torch.equal(w_now, lin.weight.detach().bfloat16())
+
+
+@pytest.mark.parametrize("m,n,k,cnt", [(7200, 256, 256, 5), (7200, 512, 256, 2), (7200, 256, 384, 1), (1000, 64, 128, 3), (333, 256, 512, 50)])
+def test_batched_weight_and_bias_gradients(cuda, m, n, k, cnt):
+    """u3d_wgrad_batched_bf16 / u3d_colsum_batched: every product of the batch against its own f32 reference (NaN-prefilled outputs)."""
+    torch.manual_seed(m + n + k + cnt)
+    ins = [torch.randn(m, n, device=cuda).bfloat16() for _ in range(cnt)]
+    dos = [torch.randn(m, k, device=cuda).bfloat16() for _ in range(cnt)]
+    dws = [torch.full((n, k), float("nan"), device=cuda) for _ in range(cnt)]
+    dbs = [torch.full((n,), float("nan"), device=cuda) for _ in range(cnt)]
+    nv.wgrad_batched(ins, dos, dws)
+    nv.colsum_batched(ins, dbs)
+    for i in range(cnt):
+        ref = ins[i].float().t() @ dos[i].float()
+        assert (dws[i] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+        assert (dbs[i] - ins[i].float().sum(0)).abs().max().item() <= 1e-3

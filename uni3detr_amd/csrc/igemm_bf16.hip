@@ -966,7 +966,7 @@ template <int WAVES_M, int WAVES_N, int WM, int WN>
 __device__ __forceinline__ void igemm_wgrad_glds_body(const u16* __restrict__ in, const u16* __restrict__ dout,
                                                       const int* __restrict__ nbr, int ld, float* __restrict__ partial,
                                                       const int* __restrict__ n_out_dev, int n_out_cap, int cin, int cout, int kvol,
-                                                      int co_blocks) {
+                                                      int co_blocks, int kap_override = -1) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int TM = WAVES_M * WM * 16, TN = WAVES_N * WN * 16, RK = 64;
   constexpr int A_ELEMS = RK * TM, D_ELEMS = RK * TN, STAGE_ELEMS = A_ELEMS + D_ELEMS;
@@ -978,7 +978,7 @@ __device__ __forceinline__ void igemm_wgrad_glds_body(const u16* __restrict__ in
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
 
   const int n_out = min(*n_out_dev, n_out_cap);
-  const int nsplit = gridDim.x, split = blockIdx.x, kap = blockIdx.y;
+  const int nsplit = gridDim.x, split = blockIdx.x, kap = kap_override >= 0 ? kap_override : (int)blockIdx.y;
   const int ci0 = (blockIdx.z / co_blocks) * TM, co0 = (blockIdx.z % co_blocks) * TN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1101,6 +1101,35 @@ U3D_WGRAD_GLDS_KERNEL(k_igemm_wgrad_glds_64, 2, 2, 2, 2)
 // (32- and 16-channel tiles were tried on this kernel too: correct, but no faster than k_igemm_wgrad - those layers are bound by
 //  the L2 gather, not by staging - so they stay on the buffer-load kernel)
 #undef U3D_WGRAD_GLDS_KERNEL
+// ---- batched form for the decoder / head linears: `count` independent products dW_b = in_b^T @ dout_b of ONE shape in one launch
+//      (grid.y = batch index; pointers arrive by value in the kernel arguments - no device-side table, capturable as is)
+#define U3D_WGRAD_BATCH_MAX 48
+struct WgradBatch {
+  const u16* in[U3D_WGRAD_BATCH_MAX];
+  const u16* dout[U3D_WGRAD_BATCH_MAX];
+  float* dw[U3D_WGRAD_BATCH_MAX];
+};
+#define U3D_WGRAD_BATCH_KERNEL(NAME, A, B, C, D)                                                                                    \
+  __global__ __launch_bounds__(A* B * 64) void NAME(WgradBatch bt, float* partial, const int* n_dev, int n_cap, int cin, int cout,   \
+                                                    int co_blocks, long long partial_stride) {                                      \
+    const int b = blockIdx.y;                                                                                                        \
+    igemm_wgrad_glds_body<A, B, C, D>(bt.in[b], bt.dout[b], nullptr, 0, partial + (long long)b * partial_stride, n_dev, n_cap, cin,   \
+                                      cout, 1, co_blocks, 0);                                                                         \
+  }
+U3D_WGRAD_BATCH_KERNEL(k_wgrad_batch_256, 2, 4, 8, 4)
+U3D_WGRAD_BATCH_KERNEL(k_wgrad_batch_128, 2, 2, 4, 4)
+U3D_WGRAD_BATCH_KERNEL(k_wgrad_batch_64, 2, 2, 2, 2)
+#undef U3D_WGRAD_BATCH_KERNEL
+__global__ void k_wgrad_batch_reduce(WgradBatch bt, const float* __restrict__ partial, long long n, int nsplit, long long partial_stride) {
+  const int b = blockIdx.y;
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float* p = partial + (long long)b * partial_stride;
+  f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < nsplit; ++k) s += *(const f32x4*)(p + (long long)k * n + i);
+  *(f32x4*)(bt.dw[b] + i) = s;
+}
+
 typedef void (*wgrad_glds_kernel_t)(const u16*, const u16*, const int*, int, float*, const int*, int, int, int, int, int);
 
 __global__ void k_igemm_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, long long n, int nsplit) {
@@ -1206,6 +1235,63 @@ extern "C" int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const 
   else rc = launch_igemm_wgrad<1, 1, 1, 1>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
   if (rc != U3D_OK) return rc;
   hipLaunchKernelGGL(k_igemm_wgrad_reduce, dim3(u3d_cdiv(n / 4, 256)), dim3(256), 0, s, (const float*)workspace, dw, n, p.nsplit);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+// dW_b = in_b^T @ dout_b for b < count, all [n_rows, cin] x [n_rows, cout] bf16 -> f32 [cin, cout] (deterministic row split + ordered
+// reduce, as u3d_igemm_wgrad_bf16 with kvol = 1).  Two launches for the whole batch.
+// plan for `count` same-shape products in one launch: the batch itself fills the chip, so prefer big tiles and few, long row splits
+static WgPlan wgrad_plan_batched(int count, int n_rows, int cin, int cout) {
+  int mn = cin < cout ? cin : cout;
+  int tile = (mn >= 256 && cin % 256 == 0 && cout % 256 == 0) ? 256 : ((mn >= 128 && cin % 128 == 0 && cout % 128 == 0) ? 128 : 64);
+  const int ntiles = u3d_cdiv(n_rows > 0 ? n_rows : 1, 64);
+  WgPlan p;
+  for (;;) {
+    p.tile = tile;
+    p.ci_blocks = u3d_cdiv(cin, tile);
+    p.co_blocks = u3d_cdiv(cout, tile);
+    const int per = (count > 0 ? count : 1) * p.ci_blocks * p.co_blocks;
+    int ns = u3d_cdiv(768, per);
+    int max_ns = ntiles / 8 > 0 ? ntiles / 8 : 1;
+    if (ns > max_ns) ns = max_ns;
+    if (ns < 1) ns = 1;
+    p.nsplit = ns;
+    if (tile == 64 || (long long)per * ns >= 192) break;
+    tile /= 2;
+  }
+  return p;
+}
+extern "C" int64_t u3d_wgrad_batched_workspace(int32_t count, int32_t n_rows, int32_t cin, int32_t cout) {
+  WgPlan p = wgrad_plan_batched(count, n_rows, cin, cout);
+  return (int64_t)count * p.nsplit * cin * cout * 4;
+}
+extern "C" int32_t u3d_wgrad_batched_bf16(const void* const* in, const void* const* dout, float* const* dw, int32_t count,
+                                          const int32_t* n_dev, int32_t n_rows, int32_t cin, int32_t cout, void* workspace,
+                                          int64_t workspace_bytes, u3d_stream s) {
+  U3D_REQUIRE(in && dout && dw && n_dev && workspace && count >= 0 && count <= U3D_WGRAD_BATCH_MAX, U3D_ERR_ARG);
+  if (count == 0) return U3D_OK;
+  if (cin % 64 != 0 || cout % 64 != 0) return U3D_ERR_UNSUPPORTED;
+  WgPlan p = wgrad_plan_batched(count, n_rows, cin, cout);
+  U3D_REQUIRE(workspace_bytes >= u3d_wgrad_batched_workspace(count, n_rows, cin, cout), U3D_ERR_WORKSPACE);
+  WgradBatch bt;
+  for (int i = 0; i < count; ++i) { bt.in[i] = (const u16*)in[i]; bt.dout[i] = (const u16*)dout[i]; bt.dw[i] = dw[i]; }
+  for (int i = count; i < U3D_WGRAD_BATCH_MAX; ++i) { bt.in[i] = nullptr; bt.dout[i] = nullptr; bt.dw[i] = nullptr; }
+  const long long n = (long long)cin * cout, stride = (long long)p.nsplit * n;
+  const size_t lds = 2 * (size_t)(64 * p.tile + 64 * p.tile) * 2;
+  dim3 grid(p.nsplit, count, p.ci_blocks * p.co_blocks);
+  if (p.tile == 256) {
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute((const void*)k_wgrad_batch_256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a = true; }
+    hipLaunchKernelGGL(k_wgrad_batch_256, grid, dim3(512), lds, s, bt, (float*)workspace, n_dev, n_rows, cin, cout, p.co_blocks, stride);
+  } else if (p.tile == 128) {
+    static bool a = false;
+    if (!a && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)k_wgrad_batch_128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a = true; }
+    hipLaunchKernelGGL(k_wgrad_batch_128, grid, dim3(256), lds, s, bt, (float*)workspace, n_dev, n_rows, cin, cout, p.co_blocks, stride);
+  } else {
+    hipLaunchKernelGGL(k_wgrad_batch_64, grid, dim3(256), lds, s, bt, (float*)workspace, n_dev, n_rows, cin, cout, p.co_blocks, stride);
+  }
+  hipLaunchKernelGGL(k_wgrad_batch_reduce, dim3(u3d_cdiv(n / 4, 256), count), dim3(256), 0, s, bt, (const float*)workspace, n, p.nsplit, stride);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

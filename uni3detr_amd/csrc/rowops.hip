@@ -277,6 +277,83 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
   s = u3d_wave_sum(s);
   if (lane == 0) out[col] = s;
 }
+#define U3D_COLSUM_BATCH_MAX 64
+struct ColsumBatch { const void* x[U3D_COLSUM_BATCH_MAX]; float* out[U3D_COLSUM_BATCH_MAX]; };
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_colsum_partial_b(ColsumBatch bt, int n, int c, float* __restrict__ partial, long long pstride) {
+  // same body as k_colsum_partial, batch index = blockIdx.y
+  const T* x = (const T*)bt.x[blockIdx.y];
+  partial += (long long)blockIdx.y * pstride;
+  __shared__ float red[256 * 8];
+  const int cv = (c + V - 1) / V;
+  const int cw = cv < 256 ? cv : 256;
+  const int rl = 256 / cw;
+  const int tcol = threadIdx.x % cw, trow = threadIdx.x / cw;
+  const int r0 = blockIdx.x * CS_ROWS, r1 = min(n, r0 + CS_ROWS);
+  for (int cb = 0; cb < cv; cb += cw) {
+    const int vc = cb + tcol;
+    float s[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) s[e] = 0.f;
+    if (vc < cv && trow < rl) {
+      for (int r = r0 + trow; r < r1; r += rl) {
+        const long long o = (long long)r * c + (long long)vc * V;
+        float xv[V];
+        if constexpr (V == 1) xv[0] = ld_elem(x, o); else load_vec<T>(x + o, xv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[e] += xv[e];
+      }
+    }
+    if (trow < rl) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) red[(trow * cw + tcol) * V + e] = s[e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cw * V; i += 256) {
+      if (cb * V + i < c) {
+        float a = 0.f;
+        for (int j = 0; j < rl; ++j) a += red[j * cw * V + i];
+        partial[(long long)blockIdx.x * c + cb * V + i] = a;
+      }
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k_colsum_final_b(ColsumBatch bt, const float* __restrict__ partial, int nb, int c, long long pstride) {
+  int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (col >= c) return;
+  const float* p = partial + (long long)blockIdx.y * pstride;
+  float s = 0.f;
+  for (int b = lane; b < nb; b += 64) s += p[(long long)b * c + col];
+  s = u3d_wave_sum(s);
+  if (lane == 0) bt.out[blockIdx.y][col] = s;
+}
+extern "C" int64_t u3d_colsum_batched_workspace(int32_t count, int32_t n, int32_t c) {
+  return (int64_t)count * u3d_cdiv(n > 0 ? n : 1, CS_ROWS) * c * 4;
+}
+extern "C" int32_t u3d_colsum_batched(const void* const* x, float* const* out, int32_t count, int32_t n, int32_t c, int32_t dtype,
+                                      void* workspace, int64_t workspace_bytes, u3d_stream s) {
+  U3D_REQUIRE(x && out && workspace && count >= 0 && count <= U3D_COLSUM_BATCH_MAX && n > 0 && c > 0, U3D_ERR_ARG);
+  if (count == 0) return U3D_OK;
+  U3D_REQUIRE(workspace_bytes >= u3d_colsum_batched_workspace(count, n, c), U3D_ERR_WORKSPACE);
+  ColsumBatch bt;
+  for (int i = 0; i < U3D_COLSUM_BATCH_MAX; ++i) { bt.x[i] = i < count ? x[i] : nullptr; bt.out[i] = i < count ? out[i] : nullptr; }
+  const int nb = u3d_cdiv(n, CS_ROWS);
+  const long long pstride = (long long)nb * c;
+  float* ws = (float*)workspace;
+  dim3 grid(nb, count);
+  if (dtype == U3D_F32) {
+    if (c % 4 == 0) hipLaunchKernelGGL((k_colsum_partial_b<float, 4>), grid, dim3(256), 0, s, bt, n, c, ws, pstride);
+    else hipLaunchKernelGGL((k_colsum_partial_b<float, 1>), grid, dim3(256), 0, s, bt, n, c, ws, pstride);
+  } else if (dtype == U3D_BF16) {
+    if (c % 8 == 0) hipLaunchKernelGGL((k_colsum_partial_b<u16, 8>), grid, dim3(256), 0, s, bt, n, c, ws, pstride);
+    else hipLaunchKernelGGL((k_colsum_partial_b<u16, 1>), grid, dim3(256), 0, s, bt, n, c, ws, pstride);
+  } else return U3D_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_colsum_final_b, dim3(u3d_cdiv(c, 4), count), dim3(256), 0, s, bt, (const float*)ws, nb, c, pstride);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
 extern "C" int64_t u3d_colsum_workspace(int32_t n, int32_t c) { return (int64_t)u3d_cdiv(n > 0 ? n : 1, CS_ROWS) * c * 4; }
 extern "C" int32_t u3d_colsum(const void* x, int32_t n, int32_t c, int32_t dtype, float* out, void* workspace,
                               int64_t workspace_bytes, u3d_stream s) {

@@ -76,6 +76,10 @@ _SIGS = {
     "u3d_nms3d": (_I, [_P, _P, _I, C.c_float, _P, _P, _L, _P]),
     "u3d_iou3d_rotated_aligned": (_I, [_P, _P, _I, _P, _P]),
     "u3d_tap_gather_sum": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
+    "u3d_wgrad_batched_workspace": (_L, [_I, _I, _I, _I]),
+    "u3d_wgrad_batched_bf16": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _L, _P]),
+    "u3d_colsum_batched_workspace": (_L, [_I, _I, _I]),
+    "u3d_colsum_batched": (_I, [_P, _P, _I, _I, _I, _I, _P, _L, _P]),
     "u3d_adamw_workspace": (_L, [_L]),
     "u3d_adamw_step": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _L, _P]),
     "u3d_gather_rows": (_I, [_P, _P, _I, _I, _P, _P]),
@@ -543,3 +547,37 @@ def tap_gather_sum(p, nbr, n_dev, n, c, kvol):
     _check(lib().u3d_tap_gather_sum(_ptr(p), _ptr(nbr), nbr.shape[1], _ptr(n_dev), n, c, kvol, dtype_code(p), _ptr(out), _stream()),
            "tap_gather_sum")
     return out
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def wgrad_batched(ins, douts, dws):
+    """dws[b] <- ins[b]^T @ douts[b] for same-shape bf16 [M,Cin] / [M,Cout] pairs (f32 [Cin,Cout] outputs, preallocated)."""
+    m, cin = ins[0].shape
+    cout = douts[0].shape[1]
+    dev = ins[0].device
+    MAXB = 48
+    for o in range(0, len(ins), MAXB):
+        a, b, c = ins[o:o + MAXB], douts[o:o + MAXB], dws[o:o + MAXB]
+        wsb = int(lib().u3d_wgrad_batched_workspace(len(a), m, cin, cout))
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        _check(lib().u3d_wgrad_batched_bf16(_ptr_array(a), _ptr_array(b), _ptr_array(c), len(a), _ptr(count_tensor(m, dev)), m, cin, cout,
+                                            _ptr(ws), ws.numel(), _stream()), "wgrad_batched_bf16")
+
+
+def colsum_batched(xs, outs):
+    """outs[b] <- column sums of xs[b] (same-shape [n, C] matrices, f32 [C] outputs, preallocated)."""
+    n, c = xs[0].shape
+    dev = xs[0].device
+    MAXB = 64
+    for o in range(0, len(xs), MAXB):
+        a, b = xs[o:o + MAXB], outs[o:o + MAXB]
+        wsb = int(lib().u3d_colsum_batched_workspace(len(a), n, c))
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        _check(lib().u3d_colsum_batched(_ptr_array(a), _ptr_array(b), len(a), n, c, dtype_code(a[0]), _ptr(ws), ws.numel(), _stream()),
+               "colsum_batched")

@@ -103,7 +103,58 @@ def _mm_f32(a, b):
 MM_OUT_DTYPE = [None]
 
 
-def _linear_backward(dy2, x2, wc, need_dx, need_dw, need_db, xdtype):
+class _Deferred:
+    """Deferred parameter gradients of the decoder / head linears.  Inside `deferred_param_grads()` a linear whose weight was used
+    ONCE in the forward hands autograd freshly allocated, UNWRITTEN dW / db placeholders and queues (dy, x, parameter);
+    `flush_deferred()` then writes all of them - into whatever tensor autograd stored as `.grad` - with one batched launch per shape
+    (u3d_wgrad_batched_bf16 / u3d_colsum_batched): ~45 independent [N x 7200] x [7200 x K] products of 14 us each become two
+    launches.  Valid because nothing reads a parameter gradient before the flush: with `.grad = None` AccumulateGrad keeps the
+    incoming tensor as is (a weight used twice would accumulate, hence the use count; no reference to the placeholder is kept
+    here, so it is not cloned either)."""
+    active = False
+    items = []          # (dy2 [M,N], x2 [M,K], weight id, first row, last row, has_bias)
+    uses = {}           # id(weight) -> number of forward uses in this step
+    params = {}         # id(weight) -> (weight, bias)
+
+
+def reset_param_uses():
+    _Deferred.uses, _Deferred.params = {}, {}
+
+
+def flush_deferred():
+    items, _Deferred.items = _Deferred.items, []
+    groups, bgroups = {}, {}
+    for dy2, x2, wid, r0, r1, has_bias in items:
+        w, b = _Deferred.params[wid]
+        if w.grad is None or w.grad.dtype != torch.float32 or not w.grad.is_contiguous():
+            raise RuntimeError("deferred weight gradient: autograd did not leave a contiguous f32 .grad to write into")
+        groups.setdefault((dy2.shape[0], dy2.shape[1], x2.shape[1]), []).append((dy2, x2, w.grad[r0:r1]))
+        if has_bias:
+            if b.grad is None or b.grad.dtype != torch.float32:
+                raise RuntimeError("deferred bias gradient: no f32 .grad to write into")
+            bgroups.setdefault((dy2.shape[0], dy2.shape[1]), []).append((dy2, b.grad[r0:r1]))
+    for g in groups.values():
+        nv.wgrad_batched([a for a, _, _ in g], [b for _, b, _ in g], [c for _, _, c in g])
+    for g in bgroups.values():
+        nv.colsum_batched([a for a, _ in g], [b for _, b in g])
+
+
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def deferred_param_grads():
+    prev = _Deferred.active
+    _Deferred.active, _Deferred.items = True, []
+    try:
+        yield
+        flush_deferred()
+    finally:
+        _Deferred.active, _Deferred.items = prev, []
+
+
+def _linear_backward(dy2, x2, wc, need_dx, need_dw, need_db, xdtype, defer=None, dw_out=None, db_out=None):
+    """defer = (weight id, first row, last row) queues the parameter gradients (see _Deferred) instead of computing them now."""
     """Shared backward of y = x2 @ wc^T + b.  dy2 [M,N], x2 [M,K], wc [N,K] (compute dtype).  Parameter gradients come back
     in f32 (dW from the HIP row-split wgrad kernel when bf16: hipBLASLt runs these [N,M]x[M,K] products with M = B*900 on
     16 tiles; db from u3d_colsum — NOT dy.sum(0), see colsum)."""
@@ -113,6 +164,11 @@ def _linear_backward(dy2, x2, wc, need_dx, need_dw, need_db, xdtype):
     bf16 = wc.dtype == torch.bfloat16
     if need_dx:
         dx = _mm_f32(dy2, wc) if (bf16 and xdtype == torch.float32) else (dy2 @ wc).to(xdtype)
+    if defer is not None and need_dw and bf16 and OWN_WGRAD and n % 64 == 0 and k % 64 == 0 and m > 0:
+        _Deferred.items.append((dy2, x2.contiguous(), defer[0], defer[1], defer[2], bool(need_db)))
+        dw = dw_out if dw_out is not None else torch.empty((n, k), dtype=torch.float32, device=dy2.device)     # placeholder
+        db = (db_out if db_out is not None else torch.empty((n,), dtype=torch.float32, device=dy2.device)) if need_db else None
+        return dx, dw, db
     if need_dw:
         if bf16 and OWN_WGRAD and n % 16 == 0 and k % 16 == 0 and m > 0:
             dw = nv.spconv_wgrad(dy2, x2.contiguous(), None, nv.count_tensor(m, dy2.device), 1).view(n, k)
@@ -120,8 +176,14 @@ def _linear_backward(dy2, x2, wc, need_dx, need_dw, need_db, xdtype):
             dw = _mm_f32(dy2.t(), x2)
         else:
             dw = dy2.t() @ x2
+        if dw_out is not None:
+            dw_out.copy_(dw)
+            dw = dw_out
     if need_db:
         db = nv.colsum(dy2)
+        if db_out is not None:
+            db_out.copy_(db)
+            db = db_out
     return dx, dw, db
 
 
@@ -138,6 +200,9 @@ class _TorchLinearFn(torch.autograd.Function):
             xc, wc, bc = x, weight, bias
         ctx.save_for_backward(xc, wc)
         ctx.has_bias, ctx.xdtype = bias is not None, x.dtype
+        ctx.wid = id(weight)
+        _Deferred.uses[ctx.wid] = _Deferred.uses.get(ctx.wid, 0) + 1
+        _Deferred.params[ctx.wid] = (weight, bias)
         return F.linear(xc, wc, bc)
 
     @staticmethod
@@ -146,8 +211,10 @@ class _TorchLinearFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         dy2 = (dy2 if dy2.dtype == wc.dtype else dy2.to(wc.dtype)).contiguous()
         x2 = xc.reshape(-1, xc.shape[-1])
-        dx, dw, db = _linear_backward(dy2, x2, wc, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                      ctx.has_bias and ctx.needs_input_grad[2], ctx.xdtype)
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        ok = _Deferred.active and _Deferred.uses.get(ctx.wid, 0) == 1 and (need_db or not ctx.has_bias)
+        dx, dw, db = _linear_backward(dy2, x2, wc, ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db, ctx.xdtype,
+                                      (ctx.wid, 0, wc.shape[0]) if ok else None)
         return (None if dx is None else dx.view(xc.shape)), dw, db, None
 
 
@@ -166,6 +233,9 @@ class _InProjFn(torch.autograd.Function):
             qc, vc, wc, bc = qk, xv, weight, bias
         ctx.save_for_backward(qc, vc, wc)
         ctx.qdtype, ctx.vdtype = qk.dtype, xv.dtype
+        ctx.wid = id(weight)
+        _Deferred.uses[ctx.wid] = _Deferred.uses.get(ctx.wid, 0) + 1
+        _Deferred.params[ctx.wid] = (weight, bias)
         return F.linear(qc, wc[: 2 * c], bc[: 2 * c]), F.linear(vc, wc[2 * c:], bc[2 * c:])
 
     @staticmethod
@@ -175,10 +245,13 @@ class _InProjFn(torch.autograd.Function):
         cast = lambda t: (t if t.dtype == wc.dtype else t.to(wc.dtype)).reshape(-1, t.shape[-1]).contiguous()
         dqk2, dv2 = cast(dqk), cast(dv)
         need_w = ctx.needs_input_grad[2]
-        dq_in, dw1, db1 = _linear_backward(dqk2, qc.reshape(-1, c), wc[: 2 * c], ctx.needs_input_grad[0], need_w, need_w, ctx.qdtype)
-        dv_in, dw2, db2 = _linear_backward(dv2, vc.reshape(-1, c), wc[2 * c:], ctx.needs_input_grad[1], need_w, need_w, ctx.vdtype)
-        dw = torch.cat((dw1, dw2)) if need_w else None
-        db = torch.cat((db1, db2)) if need_w else None
+        ok = _Deferred.active and _Deferred.uses.get(ctx.wid, 0) == 1 and need_w and ctx.needs_input_grad[3]
+        dw = torch.empty((3 * c, c), dtype=torch.float32, device=dqk2.device) if need_w else None
+        db = torch.empty((3 * c,), dtype=torch.float32, device=dqk2.device) if need_w else None
+        dq_in, _, _ = _linear_backward(dqk2, qc.reshape(-1, c), wc[: 2 * c], ctx.needs_input_grad[0], need_w, need_w, ctx.qdtype,
+                                       (ctx.wid, 0, 2 * c) if ok else None, None if dw is None else dw[: 2 * c], None if db is None else db[: 2 * c])
+        dv_in, _, _ = _linear_backward(dv2, vc.reshape(-1, c), wc[2 * c:], ctx.needs_input_grad[1], need_w, need_w, ctx.vdtype,
+                                       (ctx.wid, 2 * c, 3 * c) if ok else None, None if dw is None else dw[2 * c:], None if db is None else db[2 * c:])
         return (None if dq_in is None else dq_in.view(qc.shape)), (None if dv_in is None else dv_in.view(vc.shape)), dw, db, None
 
 

@@ -78,6 +78,7 @@ def strided_level(lvl, ksize, stride, pad, capacity=None):
 import os as _os
 STRIDED_DGRAD_SPLIT = _os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
 NMAJOR_FWD = _os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
+STRIDED_SPLIT_MIN_RATIO = int(_os.environ.get("U3D_STRIDED_SPLIT_MIN_RATIO", "16"))
 
 
 class _SparseConv(torch.autograd.Function):
@@ -110,7 +111,7 @@ class _SparseConv(torch.autograd.Function):
             nbr = g.nbr_bwd if kvol > 1 else None
             cin, cout = wc.shape[1], wc.shape[2]
             if (STRIDED_DGRAD_SPLIT and g.strided and kvol > 1 and dout.dtype == torch.bfloat16 and cout % 64 == 0
-                    and (kvol * cin) % 64 == 0 and g.n_out * 16 <= g.n_in):      # stride 4: 15/16 of the direct dgrad's MFMAs hit zero rows
+                    and (kvol * cin) % 64 == 0 and g.n_out * STRIDED_SPLIT_MIN_RATIO <= g.n_in):      # stride 4: 15/16 of the direct dgrad's MFMAs hit zero rows
                 prod = nv.linear_bf16(dout, wc.view(kvol * cin, cout), None, False)      # [n_out, K*Cin]
                 din = nv.tap_gather_sum(prod, nbr, g.n_in_dev, g.n_in, cin, kvol)
             else:

@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 
 from . import native as nv
+from .plugin import transformer as _T
 
 
 class TrainStep:
@@ -67,6 +68,7 @@ class TrainStep:
     # ---- the three stages (same code eager or captured) -------------------------------------------------------
     def _stage1(self):
         m = self.model
+        _T.reset_param_uses()
         with m.shadow_scope():
             feat, fps = m.extract_pts_feat(self.pts)
             amp = m.amp_dtype
@@ -88,7 +90,8 @@ class TrainStep:
         losses = self.model.pts_bbox_head.loss_from_targets(self._outs, self._T, self._num_pos)
         self._losses = losses
         loss = sum(v for k, v in losses.items() if "loss" in k)
-        loss.backward()
+        with _T.deferred_param_grads():          # dW / db of the decoder + head linears: queued, then one batched launch per shape
+            loss.backward()
         self.loss = loss.detach()
         dst, src, missing = [], [], []
         for p, v in zip(self.params, self.views):
