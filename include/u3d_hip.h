@@ -279,6 +279,21 @@ int32_t u3d_tap_gather_sum(const void* p, const int32_t* nbr, int32_t ld, const 
                            int32_t kvol, int32_t dtype, void* out, u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension of a row matrix [n, C] (C <= 1024) with optional fused ReLU; input and output dtypes are
+ * independent (f32 / bf16).  Replaces nn.LayerNorm (+ nn.ReLU) of the decoder layers, the position encoder and the head branches
+ * (ref: models/utils/uni3detr_transformer.py:232-236, models/dense_heads/uni3detr_head.py:95-125, mmcv BaseTransformerLayer).
+ * fwd: y = relu?((x-mean)*rstd*gamma+beta); mean/rstd f32 [n] are saved for the backward.
+ * bwd: dx (dtype of x) and partial f32 [2][u3d_layernorm_blocks(n)][C] = per-workgroup sums of (dgamma, dbeta) terms; the caller
+ *      column-sums them (u3d_colsum / u3d_colsum_batched).  With relu the mask is recomputed from x.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t u3d_layernorm_blocks(int32_t n);
+int32_t u3d_layernorm_fwd(const void* x, int32_t x_dtype, int32_t n, int32_t c, const float* gamma, const float* beta,
+                          float eps, int32_t relu, void* y, int32_t y_dtype, float* mean, float* rstd, u3d_stream s);
+int32_t u3d_layernorm_bwd(const void* dy, int32_t y_dtype, const void* x, int32_t x_dtype, int32_t n, int32_t c,
+                          const float* gamma, const float* beta, const float* mean, const float* rstd, int32_t relu,
+                          void* dx, float* partial, u3d_stream s);
+
+/* ------------------------------------------------------------------------------------------------
  * Parameter update of the training step: global-norm gradient clipping + AdamW over FLAT f32 buffers
  * (ref: projects/configs/uni3detr/uni3detr_sunrgbd.py:234-235 — AdamW(lr, weight_decay=0.01), grad_clip max_norm=10; upstream
  * torch.optim.AdamW + torch.nn.utils.clip_grad_norm_, same arithmetic: coef = min(1, max_norm/(||g||+1e-6)), decoupled decay,

@@ -283,3 +283,47 @@ def test_batched_weight_and_bias_gradients(cuda, m, n, k, cnt):
         ref = ins[i].float().t() @ dos[i].float()
         assert (dws[i] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
         assert (dbs[i] - ins[i].float().sum(0)).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("n,c,xdt,ydt,relu", [(7200, 256, torch.float32, torch.float32, False), (7200, 256, torch.bfloat16, torch.bfloat16, True),
+                                              (999, 384, torch.float32, torch.bfloat16, True), (33, 1024, torch.bfloat16, torch.float32, False),
+                                              (5, 100, torch.float32, torch.float32, True)])
+def test_fused_layer_norm_matches_torch(cuda, n, c, xdt, ydt, relu):
+    from uni3detr_amd.plugin import transformer as T
+    torch.manual_seed(n + c)
+    ln = torch.nn.LayerNorm(c).to(cuda)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.normal_(0, 0.2)
+    x = (torch.randn(n, c, device=cuda) * 2 + 0.3).to(xdt)
+    xr = x.float().detach().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (c,), ln.weight, ln.bias, ln.eps)
+    ref = torch.relu(ref) if relu else ref
+    gy = torch.randn_like(ref).to(ydt).float()
+    gw_ref, gb_ref = torch.autograd.grad(ref, [ln.weight, ln.bias], gy, retain_graph=True)
+    (gx_ref,) = torch.autograd.grad(ref, [xr], gy)
+    xq = x.detach().clone().requires_grad_(True)
+    T.reset_param_uses()
+    y = T.fused_layer_norm(xq.view(1, n, c), ln, relu=relu, out_dtype=ydt).view(n, c)
+    assert y.dtype == ydt
+    tol = 2e-2 if (xdt == torch.bfloat16 or ydt == torch.bfloat16) else 2e-5
+    assert (y.float() - ref.detach()).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    ln.weight.grad = ln.bias.grad = None
+    y.backward(gy.to(ydt))
+    assert (xq.grad.float() - gx_ref).abs().max().item() <= tol * max(1.0, gx_ref.abs().max().item())
+    edge = 2e-2 if relu else 1.0       # bf16 rounding of x can flip a few ReLU edges: compare the sums loosely then
+    assert (ln.weight.grad - gw_ref).abs().max().item() <= max(tol, 1e-4) * max(1.0, gw_ref.abs().max().item()) * (1 + (edge < 1) * 5)
+    assert (ln.bias.grad - gb_ref).abs().max().item() <= max(tol, 1e-4) * max(1.0, gb_ref.abs().max().item()) * (1 + (edge < 1) * 5)
+    # deferred parameter gradients give the same values
+    if n >= 33:
+        T.reset_param_uses()
+        ln.weight.grad = ln.bias.grad = None
+        xq2 = x.detach().clone().requires_grad_(True)
+        y2 = T.fused_layer_norm(xq2, ln, relu=relu, out_dtype=ydt)
+        gw_now, gb_now = None, None
+        with T.deferred_param_grads():
+            y2.backward(gy.to(ydt))
+        y3 = T.fused_layer_norm(x.detach().clone().requires_grad_(True), ln, relu=relu, out_dtype=ydt)
+        w_def, b_def = ln.weight.grad.clone(), ln.bias.grad.clone()
+        ln.weight.grad = ln.bias.grad = None
+        y3.backward(gy.to(ydt))
+        assert torch.allclose(w_def, ln.weight.grad, rtol=1e-5, atol=1e-5) and torch.allclose(b_def, ln.bias.grad, rtol=1e-5, atol=1e-5)

@@ -718,3 +718,148 @@ extern "C" int32_t u3d_tap_gather_sum(const void* p, const int32_t* nbr, int32_t
   return U3D_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension of a row matrix (+ optional ReLU), forward and backward, for the decoder / head
+// (ref: nn.LayerNorm in uni3detr_transformer.py:232-236, uni3detr_head.py:95-125 and the mmcv BaseTransformerLayer norms).
+// One wavefront per row (lanes stride over the columns, C <= 1024), 32 rows per workgroup.  Input and output dtypes are independent
+// (f32 or bf16): the bf16 output feeds the next GEMM without a cast launch.  Backward emits per-workgroup partial sums of
+// dgamma / dbeta ([2][nblocks][C] f32); the caller reduces them (u3d_colsum / u3d_colsum_batched).
+// ---------------------------------------------------------------------------------------------
+#define LN_ROWS_PER_BLOCK 32
+#define LN_MAXJ 16
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void k_layernorm_fwd(const TX* __restrict__ x, int n, int c, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, int relu, TY* __restrict__ y,
+                                                       float* __restrict__ mean, float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nj = (c + 63) >> 6;
+  float ga[LN_MAXJ], be[LN_MAXJ];
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    const int col = lane + 64 * j;
+    ga[j] = (j < nj && col < c) ? gamma[col] : 0.f;
+    be[j] = (j < nj && col < c) ? beta[col] : 0.f;
+  }
+  const float inv_c = 1.f / (float)c;
+  for (int rr = 0; rr < LN_ROWS_PER_BLOCK / 4; ++rr) {
+    const int r = blockIdx.x * LN_ROWS_PER_BLOCK + wv * (LN_ROWS_PER_BLOCK / 4) + rr;
+    if (r >= n) break;
+    float v[LN_MAXJ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      const int col = lane + 64 * j;
+      v[j] = (j < nj && col < c) ? ld_elem(x, (long long)r * c + col) : 0.f;
+      s += v[j];
+    }
+    const float mu = u3d_wave_sum(s) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      const int col = lane + 64 * j;
+      const float d = (j < nj && col < c) ? v[j] - mu : 0.f;
+      q += d * d;
+    }
+    const float rs = rsqrtf(u3d_wave_sum(q) * inv_c + eps);
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      const int col = lane + 64 * j;
+      if (j < nj && col < c) {
+        float o = (v[j] - mu) * rs * ga[j] + be[j];
+        if (relu) o = o > 0.f ? o : 0.f;
+        st_elem(y, (long long)r * c + col, o);
+      }
+    }
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+  }
+}
+
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void k_layernorm_bwd(const TY* __restrict__ dy, const TX* __restrict__ x, int n, int c,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, int relu,
+                                                       TX* __restrict__ dx, float* __restrict__ partial, int nblocks) {
+  __shared__ float red[2][4][64 * LN_MAXJ > 1024 ? 1024 : 64 * LN_MAXJ];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nj = (c + 63) >> 6;
+  float ga[LN_MAXJ], be[LN_MAXJ], dg[LN_MAXJ], db[LN_MAXJ];
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    const int col = lane + 64 * j;
+    ga[j] = (j < nj && col < c) ? gamma[col] : 0.f;
+    be[j] = (j < nj && col < c) ? beta[col] : 0.f;
+    dg[j] = 0.f; db[j] = 0.f;
+  }
+  const float inv_c = 1.f / (float)c;
+  for (int rr = 0; rr < LN_ROWS_PER_BLOCK / 4; ++rr) {
+    const int r = blockIdx.x * LN_ROWS_PER_BLOCK + wv * (LN_ROWS_PER_BLOCK / 4) + rr;
+    if (r >= n) break;
+    const float mu = mean[r], rs = rstd[r];
+    float xh[LN_MAXJ], gg[LN_MAXJ];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      const int col = lane + 64 * j;
+      xh[j] = 0.f; gg[j] = 0.f;
+      if (j < nj && col < c) {
+        const long long o = (long long)r * c + col;
+        xh[j] = (ld_elem(x, o) - mu) * rs;
+        float g = ld_elem(dy, o);
+        if (relu && !(xh[j] * ga[j] + be[j] > 0.f)) g = 0.f;
+        dg[j] += g * xh[j];
+        db[j] += g;
+        gg[j] = g * ga[j];
+        a += gg[j];
+        b += gg[j] * xh[j];
+      }
+    }
+    a = u3d_wave_sum(a) * inv_c;
+    b = u3d_wave_sum(b) * inv_c;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      const int col = lane + 64 * j;
+      if (j < nj && col < c) st_elem(dx, (long long)r * c + col, rs * (gg[j] - a - xh[j] * b));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    if (j < nj) { red[0][wv][lane + 64 * j] = dg[j]; red[1][wv][lane + 64 * j] = db[j]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c; i += 256) {
+    partial[((long long)0 * nblocks + blockIdx.x) * c + i] = red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i];
+    partial[((long long)1 * nblocks + blockIdx.x) * c + i] = red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i];
+  }
+}
+
+extern "C" int32_t u3d_layernorm_blocks(int32_t n) { return u3d_cdiv(n > 0 ? n : 1, LN_ROWS_PER_BLOCK); }
+
+extern "C" int32_t u3d_layernorm_fwd(const void* x, int32_t x_dtype, int32_t n, int32_t c, const float* gamma, const float* beta,
+                                     float eps, int32_t relu, void* y, int32_t y_dtype, float* mean, float* rstd, u3d_stream s) {
+  U3D_REQUIRE(x && gamma && beta && y && mean && rstd && c > 0 && c <= 64 * LN_MAXJ && n >= 0, U3D_ERR_ARG);
+  if (n == 0) return U3D_OK;
+  dim3 grid(u3d_layernorm_blocks(n));
+  if (x_dtype == U3D_F32 && y_dtype == U3D_F32) hipLaunchKernelGGL((k_layernorm_fwd<float, float>), grid, dim3(256), 0, s, (const float*)x, n, c, gamma, beta, eps, relu, (float*)y, mean, rstd);
+  else if (x_dtype == U3D_F32 && y_dtype == U3D_BF16) hipLaunchKernelGGL((k_layernorm_fwd<float, u16>), grid, dim3(256), 0, s, (const float*)x, n, c, gamma, beta, eps, relu, (u16*)y, mean, rstd);
+  else if (x_dtype == U3D_BF16 && y_dtype == U3D_F32) hipLaunchKernelGGL((k_layernorm_fwd<u16, float>), grid, dim3(256), 0, s, (const u16*)x, n, c, gamma, beta, eps, relu, (float*)y, mean, rstd);
+  else if (x_dtype == U3D_BF16 && y_dtype == U3D_BF16) hipLaunchKernelGGL((k_layernorm_fwd<u16, u16>), grid, dim3(256), 0, s, (const u16*)x, n, c, gamma, beta, eps, relu, (u16*)y, mean, rstd);
+  else return U3D_ERR_UNSUPPORTED;
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+extern "C" int32_t u3d_layernorm_bwd(const void* dy, int32_t y_dtype, const void* x, int32_t x_dtype, int32_t n, int32_t c,
+                                     const float* gamma, const float* beta, const float* mean, const float* rstd, int32_t relu,
+                                     void* dx, float* partial, u3d_stream s) {
+  U3D_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && partial && c > 0 && c <= 64 * LN_MAXJ && n > 0, U3D_ERR_ARG);
+  const int nb = u3d_layernorm_blocks(n);
+  dim3 grid(nb);
+  if (x_dtype == U3D_F32 && y_dtype == U3D_F32) hipLaunchKernelGGL((k_layernorm_bwd<float, float>), grid, dim3(256), 0, s, (const float*)dy, (const float*)x, n, c, gamma, beta, mean, rstd, relu, (float*)dx, partial, nb);
+  else if (x_dtype == U3D_F32 && y_dtype == U3D_BF16) hipLaunchKernelGGL((k_layernorm_bwd<float, u16>), grid, dim3(256), 0, s, (const u16*)dy, (const float*)x, n, c, gamma, beta, mean, rstd, relu, (float*)dx, partial, nb);
+  else if (x_dtype == U3D_BF16 && y_dtype == U3D_F32) hipLaunchKernelGGL((k_layernorm_bwd<u16, float>), grid, dim3(256), 0, s, (const float*)dy, (const u16*)x, n, c, gamma, beta, mean, rstd, relu, (u16*)dx, partial, nb);
+  else if (x_dtype == U3D_BF16 && y_dtype == U3D_BF16) hipLaunchKernelGGL((k_layernorm_bwd<u16, u16>), grid, dim3(256), 0, s, (const u16*)dy, (const u16*)x, n, c, gamma, beta, mean, rstd, relu, (u16*)dx, partial, nb);
+  else return U3D_ERR_UNSUPPORTED;
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}

@@ -80,6 +80,9 @@ _SIGS = {
     "u3d_wgrad_batched_bf16": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _L, _P]),
     "u3d_colsum_batched_workspace": (_L, [_I, _I, _I]),
     "u3d_colsum_batched": (_I, [_P, _P, _I, _I, _I, _I, _P, _L, _P]),
+    "u3d_layernorm_blocks": (_I, [_I]),
+    "u3d_layernorm_fwd": (_I, [_P, _I, _I, _I, _P, _P, C.c_float, _I, _P, _I, _P, _P, _P]),
+    "u3d_layernorm_bwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "u3d_adamw_workspace": (_L, [_L]),
     "u3d_adamw_step": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _L, _P]),
     "u3d_gather_rows": (_I, [_P, _P, _I, _I, _P, _P]),
@@ -581,3 +584,25 @@ def colsum_batched(xs, outs):
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         _check(lib().u3d_colsum_batched(_ptr_array(a), _ptr_array(b), len(a), n, c, dtype_code(a[0]), _ptr(ws), ws.numel(), _stream()),
                "colsum_batched")
+
+
+def layernorm_fwd(x2, gamma, beta, eps, relu, out_dtype):
+    """x2 [n, C] f32/bf16 -> (y [n, C] out_dtype, mean [n], rstd [n])."""
+    n, c = x2.shape
+    y = torch.empty((n, c), dtype=out_dtype, device=x2.device)
+    mean = torch.empty((n,), dtype=torch.float32, device=x2.device)
+    rstd = torch.empty((n,), dtype=torch.float32, device=x2.device)
+    _check(lib().u3d_layernorm_fwd(_ptr(x2), dtype_code(x2), n, c, _ptr(gamma), _ptr(beta), eps, int(relu), _ptr(y), dtype_code(y),
+                                   _ptr(mean), _ptr(rstd), _stream()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy2, x2, gamma, beta, mean, rstd, relu):
+    """-> (dx [n, C] in x2's dtype, partial f32 [2, nblocks, C] whose column sums are dgamma, dbeta)."""
+    n, c = x2.shape
+    dx = torch.empty_like(x2)
+    nb = int(lib().u3d_layernorm_blocks(n))
+    partial = torch.empty((2, nb, c), dtype=torch.float32, device=x2.device)
+    _check(lib().u3d_layernorm_bwd(_ptr(dy2), dtype_code(dy2), _ptr(x2), dtype_code(x2), n, c, _ptr(gamma), _ptr(beta), _ptr(mean),
+                                   _ptr(rstd), int(relu), _ptr(dx), _ptr(partial), _stream()), "layernorm_bwd")
+    return dx, partial

@@ -113,6 +113,7 @@ class _Deferred:
     here, so it is not cloned either)."""
     active = False
     items = []          # (dy2 [M,N], x2 [M,K], weight id, first row, last row, has_bias)
+    sum_items = []      # (matrix [rows, C] f32, parameter): parameter.grad <- column sums
     uses = {}           # id(weight) -> number of forward uses in this step
     params = {}         # id(weight) -> (weight, bias)
 
@@ -123,7 +124,12 @@ def reset_param_uses():
 
 def flush_deferred():
     items, _Deferred.items = _Deferred.items, []
+    sums, _Deferred.sum_items = _Deferred.sum_items, []
     groups, bgroups = {}, {}
+    for mat, param in sums:                   # column sums of a [rows, C] f32 matrix into param.grad (LayerNorm dgamma / dbeta)
+        if param.grad is None or param.grad.dtype != torch.float32:
+            raise RuntimeError("deferred column sum: no f32 .grad to write into")
+        bgroups.setdefault((mat.shape[0], mat.shape[1], "f32"), []).append((mat, param.grad))
     for dy2, x2, wid, r0, r1, has_bias in items:
         w, b = _Deferred.params[wid]
         if w.grad is None or w.grad.dtype != torch.float32 or not w.grad.is_contiguous():
@@ -145,12 +151,12 @@ import contextlib as _contextlib
 @_contextlib.contextmanager
 def deferred_param_grads():
     prev = _Deferred.active
-    _Deferred.active, _Deferred.items = True, []
+    _Deferred.active, _Deferred.items, _Deferred.sum_items = True, [], []
     try:
         yield
         flush_deferred()
     finally:
-        _Deferred.active, _Deferred.items = prev, []
+        _Deferred.active, _Deferred.items, _Deferred.sum_items = prev, [], []
 
 
 def _linear_backward(dy2, x2, wc, need_dx, need_dw, need_db, xdtype, defer=None, dw_out=None, db_out=None):
@@ -280,6 +286,54 @@ def fast_linear(x, lin, relu=False, weight=None, bias=None):
     return F.relu(y) if relu else y
 
 
+class _FusedLN(torch.autograd.Function):
+    """nn.LayerNorm (+ ReLU) on the HIP row kernels: one launch forward, one backward; the output can be produced directly in the
+    compute dtype of the GEMM that follows; dgamma / dbeta are deferred and batched like the linear parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, relu, out_dtype):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        y, mean, rstd = nv.layernorm_fwd(x2, weight, bias, eps, relu, out_dtype)
+        ctx.save_for_backward(x2, weight, bias, mean, rstd)
+        ctx.relu, ctx.shp = relu, shp
+        ctx.wid = id(weight)
+        _Deferred.uses[ctx.wid] = _Deferred.uses.get(ctx.wid, 0) + 1
+        _Deferred.params[ctx.wid] = (weight, bias)
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias, mean, rstd = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dx, partial = nv.layernorm_bwd(dy2, x2, weight, bias, mean, rstd, ctx.relu)
+        c = x2.shape[1]
+        if _Deferred.active and _Deferred.uses.get(ctx.wid, 0) == 1 and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            _Deferred.sum_items.append((partial[0], weight))
+            _Deferred.sum_items.append((partial[1], bias))
+            dg = torch.empty((c,), dtype=torch.float32, device=x2.device)          # placeholders, written by flush_deferred()
+            db = torch.empty((c,), dtype=torch.float32, device=x2.device)
+        else:
+            dg, db = nv.colsum(partial[0]), nv.colsum(partial[1])
+        return dx.view(ctx.shp), dg, db, None, None, None
+
+
+FUSED_LN = _os.environ.get("U3D_FUSED_LN", "1") == "1"
+
+
+def fused_layer_norm(x, ln, relu=False, out_dtype=None):
+    """`ln` (nn.LayerNorm over the last dim) applied to x, optionally followed by ReLU, on the HIP kernels when x is on the GPU."""
+    if (FUSED_LN and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and ln.elementwise_affine and ln.bias is not None
+            and len(ln.normalized_shape) == 1 and x.shape[-1] == ln.normalized_shape[0] and x.shape[-1] <= 1024 and x.numel() > 0
+            and ln.weight.dtype == torch.float32):
+        return _FusedLN.apply(x, ln.weight, ln.bias, ln.eps, relu, out_dtype or x.dtype)
+    y = ln(x)
+    y = F.relu(y) if relu else y
+    return y if out_dtype is None else y.to(out_dtype)
+
+
 def residual_add(x, o):
     """x + o with o brought to x's dtype first (see MultiheadAttention.forward_grouped on mixed-dtype adds)."""
     return x + (o if o.dtype == x.dtype else o.to(x.dtype))
@@ -292,7 +346,14 @@ def run_sequential(seq, x):
     i = 0
     while i < len(mods):
         m = mods[i]
-        if isinstance(m, nn.Linear):
+        if isinstance(m, nn.LayerNorm):
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            nxt = mods[i + (2 if fuse else 1)] if i + (2 if fuse else 1) < len(mods) else None
+            cdt = _autocast_dtype(x)
+            # a Linear right behind it takes the compute dtype straight from the norm kernel (no cast launch)
+            x = fused_layer_norm(x, m, relu=fuse, out_dtype=cdt if (cdt is not None and isinstance(nxt, nn.Linear)) else None)
+            i += 2 if fuse else 1
+        elif isinstance(m, nn.Linear):
             fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
             x = fast_linear(x, m, relu=fuse)
             i += 2 if fuse else 1
@@ -509,7 +570,7 @@ class BaseTransformerLayer(nn.Module):
             elif op == "cross_attn":
                 x = self.attentions[ai].forward_bf(x, pos, value, ref_logits); ai += 1
             elif op == "norm":
-                x = self.norms[ni](x); ni += 1
+                x = fused_layer_norm(x, self.norms[ni]); ni += 1
             elif op == "ffn":
                 x = self.ffns[fi](x); fi += 1
         return x
