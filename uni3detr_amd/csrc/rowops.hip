@@ -726,105 +726,137 @@ extern "C" int32_t u3d_tap_gather_sum(const void* p, const int32_t* nbr, int32_t
 // (f32 or bf16): the bf16 output feeds the next GEMM without a cast launch.  Backward emits per-workgroup partial sums of
 // dgamma / dbeta ([2][nblocks][C] f32); the caller reduces them (u3d_colsum / u3d_colsum_batched).
 // ---------------------------------------------------------------------------------------------
-#define LN_ROWS_PER_BLOCK 32
+#define LN_ROWS_PER_BLOCK 8        /* 2 rows per wave: 900 workgroups for the decoder's 7200 rows (32 rows/block left 225 on 256 CUs) */
 #define LN_MAXJ 16
-template <typename TX, typename TY>
+
+// NJ > 0: C == 64 * NJ exactly, lane owns NJ CONSECUTIVE columns (vector loads/stores); NJ == 0: any C <= 1024, lanes stride.
+template <typename T, int NJ>
+__device__ __forceinline__ void ln_load_row(const T* __restrict__ p, int c, int lane, float* v) {
+  if constexpr (NJ == 4 && std::is_same<T, float>::value) {
+    float4 t = *(const float4*)(p + lane * 4);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if constexpr (NJ == 4) {
+    uint2 t = *(const uint2*)(p + lane * 4);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  } else if constexpr (NJ > 0) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) v[j] = ld_elem(p, lane * NJ + j);
+  } else {
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) { const int col = lane + 64 * j; v[j] = col < c ? ld_elem(p, col) : 0.f; }
+  }
+}
+template <typename T, int NJ>
+__device__ __forceinline__ void ln_store_row(T* __restrict__ p, int c, int lane, const float* v) {
+  if constexpr (NJ == 4 && std::is_same<T, float>::value) {
+    *(float4*)(p + lane * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (NJ == 4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    f4 f = {v[0], v[1], v[2], v[3]};
+    *(b4*)(p + lane * 4) = __builtin_convertvector(f, b4);
+  } else if constexpr (NJ > 0) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) st_elem(p, lane * NJ + j, v[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) { const int col = lane + 64 * j; if (col < c) st_elem(p, col, v[j]); }
+  }
+}
+template <int NJ>
+__device__ __forceinline__ int ln_col(int lane, int j) { return NJ > 0 ? lane * NJ + j : lane + 64 * j; }
+
+template <typename TX, typename TY, int NJ>
 __global__ __launch_bounds__(256) void k_layernorm_fwd(const TX* __restrict__ x, int n, int c, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int relu, TY* __restrict__ y,
                                                        float* __restrict__ mean, float* __restrict__ rstd) {
+  constexpr int J = NJ > 0 ? NJ : LN_MAXJ;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int nj = (c + 63) >> 6;
-  float ga[LN_MAXJ], be[LN_MAXJ];
+  float ga[J], be[J];
 #pragma unroll
-  for (int j = 0; j < LN_MAXJ; ++j) {
-    const int col = lane + 64 * j;
-    ga[j] = (j < nj && col < c) ? gamma[col] : 0.f;
-    be[j] = (j < nj && col < c) ? beta[col] : 0.f;
+  for (int j = 0; j < J; ++j) {
+    const int col = ln_col<NJ>(lane, j);
+    ga[j] = col < c ? gamma[col] : 0.f;
+    be[j] = col < c ? beta[col] : 0.f;
   }
   const float inv_c = 1.f / (float)c;
+#pragma unroll
   for (int rr = 0; rr < LN_ROWS_PER_BLOCK / 4; ++rr) {
     const int r = blockIdx.x * LN_ROWS_PER_BLOCK + wv * (LN_ROWS_PER_BLOCK / 4) + rr;
     if (r >= n) break;
-    float v[LN_MAXJ];
+    float v[J];
+    ln_load_row<TX, NJ>(x + (long long)r * c, c, lane, v);
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXJ; ++j) {
-      const int col = lane + 64 * j;
-      v[j] = (j < nj && col < c) ? ld_elem(x, (long long)r * c + col) : 0.f;
-      s += v[j];
-    }
+    for (int j = 0; j < J; ++j) s += v[j];
     const float mu = u3d_wave_sum(s) * inv_c;
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXJ; ++j) {
-      const int col = lane + 64 * j;
-      const float d = (j < nj && col < c) ? v[j] - mu : 0.f;
+    for (int j = 0; j < J; ++j) {
+      const float d = ln_col<NJ>(lane, j) < c ? v[j] - mu : 0.f;
       q += d * d;
     }
     const float rs = rsqrtf(u3d_wave_sum(q) * inv_c + eps);
 #pragma unroll
-    for (int j = 0; j < LN_MAXJ; ++j) {
-      const int col = lane + 64 * j;
-      if (j < nj && col < c) {
-        float o = (v[j] - mu) * rs * ga[j] + be[j];
-        if (relu) o = o > 0.f ? o : 0.f;
-        st_elem(y, (long long)r * c + col, o);
-      }
+    for (int j = 0; j < J; ++j) {
+      float o = (v[j] - mu) * rs * ga[j] + be[j];
+      v[j] = relu ? (o > 0.f ? o : 0.f) : o;
     }
+    ln_store_row<TY, NJ>(y + (long long)r * c, c, lane, v);
     if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
   }
 }
 
-template <typename TX, typename TY>
+template <typename TX, typename TY, int NJ>
 __global__ __launch_bounds__(256) void k_layernorm_bwd(const TY* __restrict__ dy, const TX* __restrict__ x, int n, int c,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, int relu,
                                                        TX* __restrict__ dx, float* __restrict__ partial, int nblocks) {
-  __shared__ float red[2][4][64 * LN_MAXJ > 1024 ? 1024 : 64 * LN_MAXJ];
+  constexpr int J = NJ > 0 ? NJ : LN_MAXJ;
+  __shared__ float red[2][4][64 * J];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int nj = (c + 63) >> 6;
-  float ga[LN_MAXJ], be[LN_MAXJ], dg[LN_MAXJ], db[LN_MAXJ];
+  float ga[J], be[J], dg[J], db[J];
 #pragma unroll
-  for (int j = 0; j < LN_MAXJ; ++j) {
-    const int col = lane + 64 * j;
-    ga[j] = (j < nj && col < c) ? gamma[col] : 0.f;
-    be[j] = (j < nj && col < c) ? beta[col] : 0.f;
+  for (int j = 0; j < J; ++j) {
+    const int col = ln_col<NJ>(lane, j);
+    ga[j] = col < c ? gamma[col] : 0.f;
+    be[j] = col < c ? beta[col] : 0.f;
     dg[j] = 0.f; db[j] = 0.f;
   }
   const float inv_c = 1.f / (float)c;
+#pragma unroll
   for (int rr = 0; rr < LN_ROWS_PER_BLOCK / 4; ++rr) {
     const int r = blockIdx.x * LN_ROWS_PER_BLOCK + wv * (LN_ROWS_PER_BLOCK / 4) + rr;
     if (r >= n) break;
     const float mu = mean[r], rs = rstd[r];
-    float xh[LN_MAXJ], gg[LN_MAXJ];
+    float xh[J], gg[J];
+    ln_load_row<TX, NJ>(x + (long long)r * c, c, lane, xh);
+    ln_load_row<TY, NJ>(dy + (long long)r * c, c, lane, gg);
     float a = 0.f, b = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXJ; ++j) {
-      const int col = lane + 64 * j;
-      xh[j] = 0.f; gg[j] = 0.f;
-      if (j < nj && col < c) {
-        const long long o = (long long)r * c + col;
-        xh[j] = (ld_elem(x, o) - mu) * rs;
-        float g = ld_elem(dy, o);
-        if (relu && !(xh[j] * ga[j] + be[j] > 0.f)) g = 0.f;
-        dg[j] += g * xh[j];
-        db[j] += g;
-        gg[j] = g * ga[j];
-        a += gg[j];
-        b += gg[j] * xh[j];
-      }
+    for (int j = 0; j < J; ++j) {
+      const bool in = ln_col<NJ>(lane, j) < c;
+      xh[j] = in ? (xh[j] - mu) * rs : 0.f;
+      float g = in ? gg[j] : 0.f;
+      if (relu && !(xh[j] * ga[j] + be[j] > 0.f)) g = 0.f;
+      dg[j] += g * xh[j];
+      db[j] += g;
+      gg[j] = g * ga[j];
+      a += gg[j];
+      b += gg[j] * xh[j];
     }
     a = u3d_wave_sum(a) * inv_c;
     b = u3d_wave_sum(b) * inv_c;
 #pragma unroll
-    for (int j = 0; j < LN_MAXJ; ++j) {
-      const int col = lane + 64 * j;
-      if (j < nj && col < c) st_elem(dx, (long long)r * c + col, rs * (gg[j] - a - xh[j] * b));
-    }
+    for (int j = 0; j < J; ++j) gg[j] = rs * (gg[j] - a - xh[j] * b);
+    ln_store_row<TX, NJ>(dx + (long long)r * c, c, lane, gg);
   }
 #pragma unroll
-  for (int j = 0; j < LN_MAXJ; ++j) {
-    if (j < nj) { red[0][wv][lane + 64 * j] = dg[j]; red[1][wv][lane + 64 * j] = db[j]; }
+  for (int j = 0; j < J; ++j) {
+    const int col = ln_col<NJ>(lane, j);
+    red[0][wv][col < 64 * J ? col : 0] = dg[j];
+    red[1][wv][col < 64 * J ? col : 0] = db[j];
   }
   __syncthreads();
   for (int i = threadIdx.x; i < c; i += 256) {
@@ -835,16 +867,25 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const TY* __restrict__ dy
 
 extern "C" int32_t u3d_layernorm_blocks(int32_t n) { return u3d_cdiv(n > 0 ? n : 1, LN_ROWS_PER_BLOCK); }
 
+#define LN_FWD_CASE(TX, TY, NJ) hipLaunchKernelGGL((k_layernorm_fwd<TX, TY, NJ>), grid, dim3(256), 0, s, (const TX*)x, n, c, gamma, beta, eps, relu, (TY*)y, mean, rstd)
+#define LN_BWD_CASE(TX, TY, NJ) hipLaunchKernelGGL((k_layernorm_bwd<TX, TY, NJ>), grid, dim3(256), 0, s, (const TY*)dy, (const TX*)x, n, c, gamma, beta, mean, rstd, relu, (TX*)dx, partial, nb)
+#define LN_DISPATCH(CASE)                                                                                        \
+  do {                                                                                                           \
+    const bool xf = x_dtype == U3D_F32, yf = y_dtype == U3D_F32;                                                 \
+    if ((!xf && x_dtype != U3D_BF16) || (!yf && y_dtype != U3D_BF16)) return U3D_ERR_UNSUPPORTED;                \
+    if (c == 256) {                                                                                              \
+      if (xf && yf) CASE(float, float, 4); else if (xf) CASE(float, u16, 4); else if (yf) CASE(u16, float, 4); else CASE(u16, u16, 4); \
+    } else {                                                                                                     \
+      if (xf && yf) CASE(float, float, 0); else if (xf) CASE(float, u16, 0); else if (yf) CASE(u16, float, 0); else CASE(u16, u16, 0); \
+    }                                                                                                            \
+  } while (0)
+
 extern "C" int32_t u3d_layernorm_fwd(const void* x, int32_t x_dtype, int32_t n, int32_t c, const float* gamma, const float* beta,
                                      float eps, int32_t relu, void* y, int32_t y_dtype, float* mean, float* rstd, u3d_stream s) {
   U3D_REQUIRE(x && gamma && beta && y && mean && rstd && c > 0 && c <= 64 * LN_MAXJ && n >= 0, U3D_ERR_ARG);
   if (n == 0) return U3D_OK;
   dim3 grid(u3d_layernorm_blocks(n));
-  if (x_dtype == U3D_F32 && y_dtype == U3D_F32) hipLaunchKernelGGL((k_layernorm_fwd<float, float>), grid, dim3(256), 0, s, (const float*)x, n, c, gamma, beta, eps, relu, (float*)y, mean, rstd);
-  else if (x_dtype == U3D_F32 && y_dtype == U3D_BF16) hipLaunchKernelGGL((k_layernorm_fwd<float, u16>), grid, dim3(256), 0, s, (const float*)x, n, c, gamma, beta, eps, relu, (u16*)y, mean, rstd);
-  else if (x_dtype == U3D_BF16 && y_dtype == U3D_F32) hipLaunchKernelGGL((k_layernorm_fwd<u16, float>), grid, dim3(256), 0, s, (const u16*)x, n, c, gamma, beta, eps, relu, (float*)y, mean, rstd);
-  else if (x_dtype == U3D_BF16 && y_dtype == U3D_BF16) hipLaunchKernelGGL((k_layernorm_fwd<u16, u16>), grid, dim3(256), 0, s, (const u16*)x, n, c, gamma, beta, eps, relu, (u16*)y, mean, rstd);
-  else return U3D_ERR_UNSUPPORTED;
+  LN_DISPATCH(LN_FWD_CASE);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
@@ -855,11 +896,7 @@ extern "C" int32_t u3d_layernorm_bwd(const void* dy, int32_t y_dtype, const void
   U3D_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && partial && c > 0 && c <= 64 * LN_MAXJ && n > 0, U3D_ERR_ARG);
   const int nb = u3d_layernorm_blocks(n);
   dim3 grid(nb);
-  if (x_dtype == U3D_F32 && y_dtype == U3D_F32) hipLaunchKernelGGL((k_layernorm_bwd<float, float>), grid, dim3(256), 0, s, (const float*)dy, (const float*)x, n, c, gamma, beta, mean, rstd, relu, (float*)dx, partial, nb);
-  else if (x_dtype == U3D_F32 && y_dtype == U3D_BF16) hipLaunchKernelGGL((k_layernorm_bwd<float, u16>), grid, dim3(256), 0, s, (const u16*)dy, (const float*)x, n, c, gamma, beta, mean, rstd, relu, (float*)dx, partial, nb);
-  else if (x_dtype == U3D_BF16 && y_dtype == U3D_F32) hipLaunchKernelGGL((k_layernorm_bwd<u16, float>), grid, dim3(256), 0, s, (const float*)dy, (const u16*)x, n, c, gamma, beta, mean, rstd, relu, (u16*)dx, partial, nb);
-  else if (x_dtype == U3D_BF16 && y_dtype == U3D_BF16) hipLaunchKernelGGL((k_layernorm_bwd<u16, u16>), grid, dim3(256), 0, s, (const u16*)dy, (const u16*)x, n, c, gamma, beta, mean, rstd, relu, (u16*)dx, partial, nb);
-  else return U3D_ERR_UNSUPPORTED;
+  LN_DISPATCH(LN_BWD_CASE);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
