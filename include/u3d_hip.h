@@ -294,6 +294,27 @@ int32_t u3d_layernorm_bwd(const void* dy, int32_t y_dtype, const void* x, int32_
                           void* dx, float* partial, u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------
+ * Detection losses of Uni3DETRHead for all L decoder layers at once (ref: models/dense_heads/uni3detr_head.py:579-720 loss_single /
+ * loss, models/losses/rdiouloss.py:93-223, core/bbox/util.py:8-80).  m = B*Q elements per layer, tensors [L, m, *] contiguous f32:
+ * cls [L,m,C] logits, box [L,m,code] codes (code 8 or 10), iou_logit [L,m], tgt [L,m,code-1] assigned GT boxes (zeros for
+ * background), lab int64 [L,m] (C = background), w [L,m] (1 for matched), iou_true [L,m] rotated 3-D IoU targets, cls_avg / npos [L]
+ * avg factors (already clamped to >= 1), code_w [code].  out [L][4] = (loss_cls, loss_bbox, loss_iou, loss_iou_pred) per layer.
+ * bwd: gout [L][4] = incoming gradients of those scalars; dcls / dbox / diou have the shapes of cls / box / iou_logit.
+ * The quality (soft) target of the focal loss is NOT detached; gamma of the focal weight is 2.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t u3d_det_loss_workspace(int32_t L, int32_t m);
+int32_t u3d_det_loss_fwd(const float* cls, const float* box, const float* iou_logit, const float* tgt, const int64_t* lab,
+                         const float* w, const float* iou_true, const float* cls_avg, const float* npos, const float* code_w,
+                         int32_t L, int32_t m, int32_t c, int32_t code, int32_t tdim, float alpha, float w_cls, float w_box,
+                         float w_iou, float eps, float* out, void* workspace, int64_t workspace_bytes, u3d_stream s);
+int32_t u3d_det_loss_bwd(const float* cls, const float* box, const float* iou_logit, const float* tgt, const int64_t* lab,
+                         const float* w, const float* iou_true, const float* cls_avg, const float* npos, const float* code_w,
+                         const float* gout, int32_t L, int32_t m, int32_t c, int32_t code, int32_t tdim, float alpha, float w_cls,
+                         float w_box, float w_iou, float eps, float* dcls, float* dbox, float* diou, u3d_stream s);
+/* codes [n, code] -> boxes [n, 7] (cx, cy, cz, dx, dy, dz, yaw) (ref: core/bbox/util.py denormalize_bbox). */
+int32_t u3d_denormalize_boxes(const float* codes, int32_t n, int32_t code, float* boxes, u3d_stream s);
+
+/* ------------------------------------------------------------------------------------------------
  * Parameter update of the training step: global-norm gradient clipping + AdamW over FLAT f32 buffers
  * (ref: projects/configs/uni3detr/uni3detr_sunrgbd.py:234-235 — AdamW(lr, weight_decay=0.01), grad_clip max_norm=10; upstream
  * torch.optim.AdamW + torch.nn.utils.clip_grad_norm_, same arithmetic: coef = min(1, max_norm/(||g||+1e-6)), decoupled decay,

@@ -2,6 +2,7 @@
  (1) golden vectors produced by the reference's own head/transformer/assigner/loss files, and
  (2) the CPU oracle of the whole training forward (oracle/model.py) on a seeded synthetic scene.
 fp32 mode; tolerance 1e-3 relative on logits / losses (BASELINE.json north_star)."""
+import copy
 import os
 
 import numpy as np
@@ -114,3 +115,47 @@ def test_full_training_forward_matches_cpu_oracle(cuda, B):
     sum(losses.values()).backward()
     g = model.pts_middle_encoder.conv_input[0].weight.grad
     assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
+
+
+@pytest.mark.parametrize("code", [8, 10])
+def test_fused_detection_loss_matches_torch_formulation(cuda, code):
+    """u3d_det_loss_fwd/_bwd (in-kernel forward-mode derivatives) == the torch formulation of Uni3DETRHead.loss_from_targets:
+    all 12 loss scalars and the gradients w.r.t. class logits, box codes and IoU logits, incl. background rows and a scene without GT."""
+    from uni3detr_amd.plugin import head as H
+    torch.manual_seed(code)
+    m = build_model(copy.deepcopy(MODEL_CFG)).pts_bbox_head.to(cuda)
+    if code == 10:
+        m.code_weights = torch.nn.Parameter(torch.tensor([1.0] * 8 + [0.2, 0.2], device=cuda), requires_grad=False)
+    L, B, Q, C = 3, 4, 60, m.num_classes
+    tdim = code - 1
+    cls = torch.randn(L, B, Q, C, device=cuda)
+    box = torch.randn(L, B, Q, code, device=cuda) * 0.5
+    iou = torch.randn(L, B, Q, 1, device=cuda)
+    w = (torch.rand(L, B, Q, device=cuda) < 0.3).float()
+    w[:, 3] = 0                                                              # one scene without any assigned GT
+    tgt = torch.cat([torch.randn(L, B, Q, 3, device=cuda), torch.rand(L, B, Q, 3, device=cuda) + 0.2,
+                     (torch.rand(L, B, Q, 1, device=cuda) - 0.5) * 6.0] + ([torch.randn(L, B, Q, 2, device=cuda)] if code == 10 else []), -1)
+    tgt = tgt * w.unsqueeze(-1)
+    # matched predictions near their targets so that the IoU terms are exercised
+    from uni3detr_amd.plugin.bbox import normalize_bbox
+    box = torch.where(w.unsqueeze(-1) > 0, normalize_bbox(tgt)[..., :code] + 0.15 * torch.randn_like(box), box)
+    lab = torch.where(w > 0, torch.randint(0, C, (L, B, Q), device=cuda), torch.full((L, B, Q), C, device=cuda))
+    T = dict(w=w, tgt=tgt, lab=lab, asg=None, num_pos=H.layer_sums(w))
+    num_pos = T["num_pos"].clone() * 0.75 + 0.5
+    res = {}
+    for fused in (False, True):
+        H.FUSED_DET_LOSS = fused
+        try:
+            a, b, c = cls.clone().requires_grad_(True), box.clone().requires_grad_(True), iou.clone().requires_grad_(True)
+            out = m.loss_from_targets({"all_cls_scores": a, "all_bbox_preds": b, "all_iou_preds": c}, T, num_pos)
+            coef = {k: 0.5 + 0.1 * i for i, k in enumerate(sorted(out))}    # distinct upstream gradients per loss scalar
+            sum(out[k] * coef[k] for k in out).backward()
+            res[fused] = ({k: float(v) for k, v in out.items()}, a.grad.clone(), b.grad.clone(), c.grad.clone())
+        finally:
+            H.FUSED_DET_LOSS = True
+    ref, got = res[False], res[True]
+    assert set(ref[0]) == set(got[0]) and len(ref[0]) == 4 * L
+    for k in ref[0]:
+        assert abs(ref[0][k] - got[0][k]) <= 2e-4 * max(1.0, abs(ref[0][k])), (k, ref[0][k], got[0][k])
+    for r, g, name in zip(ref[1:], got[1:], ("dcls", "dbox", "diou")):
+        assert (r - g).abs().max().item() <= 2e-4 * max(1e-3, r.abs().max().item()), name

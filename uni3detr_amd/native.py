@@ -83,6 +83,10 @@ _SIGS = {
     "u3d_layernorm_blocks": (_I, [_I]),
     "u3d_layernorm_fwd": (_I, [_P, _I, _I, _I, _P, _P, C.c_float, _I, _P, _I, _P, _P, _P]),
     "u3d_layernorm_bwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "u3d_det_loss_workspace": (_L, [_I, _I]),
+    "u3d_det_loss_fwd": (_I, [_P] * 10 + [_I] * 5 + [C.c_float] * 5 + [_P, _P, _L, _P]),
+    "u3d_det_loss_bwd": (_I, [_P] * 11 + [_I] * 5 + [C.c_float] * 5 + [_P, _P, _P, _P]),
+    "u3d_denormalize_boxes": (_I, [_P, _I, _I, _P, _P]),
     "u3d_adamw_workspace": (_L, [_L]),
     "u3d_adamw_step": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _L, _P]),
     "u3d_gather_rows": (_I, [_P, _P, _I, _I, _P, _P]),
@@ -606,3 +610,34 @@ def layernorm_bwd(dy2, x2, gamma, beta, mean, rstd, relu):
     _check(lib().u3d_layernorm_bwd(_ptr(dy2), dtype_code(dy2), _ptr(x2), dtype_code(x2), n, c, _ptr(gamma), _ptr(beta), _ptr(mean),
                                    _ptr(rstd), int(relu), _ptr(dx), _ptr(partial), _stream()), "layernorm_bwd")
     return dx, partial
+
+
+def denormalize_boxes(codes):
+    """codes [n, code>=8] f32 -> boxes [n, 7]."""
+    codes = codes.contiguous()
+    n, code = codes.shape
+    out = torch.empty((n, 7), dtype=torch.float32, device=codes.device)
+    _check(lib().u3d_denormalize_boxes(_ptr(codes), n, code, _ptr(out), _stream()), "denormalize_boxes")
+    return out
+
+
+def det_loss_fwd(cls, box, iou_logit, tgt, lab, w, iou_true, cls_avg, npos, code_w, alpha, w_cls, w_box, w_iou, eps):
+    L, m, c = cls.shape
+    code, tdim = box.shape[-1], tgt.shape[-1]
+    out = torch.empty((L, 4), dtype=torch.float32, device=cls.device)
+    wsb = int(lib().u3d_det_loss_workspace(L, m))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=cls.device)
+    _check(lib().u3d_det_loss_fwd(_ptr(cls), _ptr(box), _ptr(iou_logit), _ptr(tgt), _ptr(lab), _ptr(w), _ptr(iou_true), _ptr(cls_avg),
+                                  _ptr(npos), _ptr(code_w), L, m, c, code, tdim, alpha, w_cls, w_box, w_iou, eps, _ptr(out), _ptr(ws),
+                                  ws.numel(), _stream()), "det_loss_fwd")
+    return out
+
+
+def det_loss_bwd(cls, box, iou_logit, tgt, lab, w, iou_true, cls_avg, npos, code_w, gout, alpha, w_cls, w_box, w_iou, eps):
+    L, m, c = cls.shape
+    code, tdim = box.shape[-1], tgt.shape[-1]
+    dcls, dbox, diou = torch.empty_like(cls), torch.empty_like(box), torch.empty_like(iou_logit)
+    _check(lib().u3d_det_loss_bwd(_ptr(cls), _ptr(box), _ptr(iou_logit), _ptr(tgt), _ptr(lab), _ptr(w), _ptr(iou_true), _ptr(cls_avg),
+                                  _ptr(npos), _ptr(code_w), _ptr(gout), L, m, c, code, tdim, alpha, w_cls, w_box, w_iou, eps, _ptr(dcls),
+                                  _ptr(dbox), _ptr(diou), _stream()), "det_loss_bwd")
+    return dcls, dbox, diou

@@ -13,6 +13,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 from torch import nn
 
+from .. import native as nv
 from ..registry import BBOX_ASSIGNERS, BBOX_CODERS, HEADS, LOSSES, TRANSFORMER
 from .bbox import bbox_overlaps_3d_aligned, bbox_overlaps_nearest_3d, denormalize_bbox, normalize_bbox
 from .transformer import colsum, inverse_sigmoid, run_sequential
@@ -24,6 +25,35 @@ def reduce_mean_(t):
         t.div_(dist.get_world_size())
         dist.all_reduce(t)
     return t
+
+
+import os as _os
+FUSED_DET_LOSS = _os.environ.get("U3D_FUSED_DET_LOSS", "1") == "1"
+
+
+class _DetLoss(torch.autograd.Function):
+    """[L,4] per-layer (loss_cls, loss_bbox, loss_iou, loss_iou_pred) on the fused HIP kernels; gradients w.r.t. the class logits,
+    box codes and IoU logits come from the in-kernel forward-mode derivatives (uni3detr_amd/csrc/loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, cls, box, iou_logit, tgt, lab, w, cls_avg, npos, code_w, alpha, w_cls, w_box, w_iou, eps):
+        cls, box, iou_logit = cls.contiguous(), box.contiguous(), iou_logit.contiguous()
+        tgt, lab, w = tgt.contiguous().float(), lab.contiguous().long(), w.contiguous().float()
+        L, m, _ = cls.shape
+        boxes = nv.denormalize_boxes(box.view(L * m, -1))
+        iou_true = nv.iou3d_rotated_aligned(boxes, tgt.view(L * m, -1)[:, :7].contiguous())         # detached target, as the reference
+        cls_avg, npos, code_w = cls_avg.contiguous(), npos.contiguous(), code_w.contiguous()
+        out = nv.det_loss_fwd(cls, box, iou_logit, tgt, lab, w, iou_true, cls_avg, npos, code_w, alpha, w_cls, w_box, w_iou, eps)
+        ctx.save_for_backward(cls, box, iou_logit, tgt, lab, w, iou_true, cls_avg, npos, code_w)
+        ctx.cfg = (alpha, w_cls, w_box, w_iou, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        cls, box, iou_logit, tgt, lab, w, iou_true, cls_avg, npos, code_w = ctx.saved_tensors
+        dcls, dbox, diou = nv.det_loss_bwd(cls, box, iou_logit, tgt, lab, w, iou_true, cls_avg, npos, code_w, gout.contiguous().float(),
+                                           *ctx.cfg)
+        return (dcls, dbox, diou) + (None,) * 11
 
 
 def layer_sums(x):
@@ -201,6 +231,22 @@ class Uni3DETRHead(nn.Module):
         w, tgt, lab = T["w"], T["tgt"], T["lab"]
         cls_avg = num_pos.clamp(min=1) if self.sync_cls_avg_factor else T["num_pos"].clamp(min=1)
         npos = num_pos.clamp(min=1)
+        from .losses import IoU3DLoss, L1Loss, SoftFocalLoss, _EPS32
+        if (FUSED_DET_LOSS and cls_all.is_cuda and type(self.loss_cls) is SoftFocalLoss and type(self.loss_bbox) is L1Loss
+                and type(self.loss_iou) is IoU3DLoss and self.loss_cls.reduction == self.loss_bbox.reduction == self.loss_iou.reduction == "mean"
+                and float(self.loss_cls.gamma) == 2.0 and box_all.shape[-1] in (8, 10) and tgt.shape[-1] == box_all.shape[-1] - 1
+                and self.code_weights.numel() == box_all.shape[-1]):
+            # all four losses of all layers: one HIP launch forward (+ a 12-value reduce), one backward (u3d_det_loss_fwd / _bwd)
+            per = _DetLoss.apply(cls_all.reshape(L, B * Q, C), box_all.reshape(L, B * Q, -1), iou_all.reshape(L, B * Q),
+                                 tgt.reshape(L, B * Q, -1), lab.reshape(L, B * Q), w.reshape(L, B * Q), cls_avg.float(), npos.float(),
+                                 self.code_weights.detach().float(), float(self.loss_cls.alpha), float(self.loss_cls.loss_weight),
+                                 float(self.loss_bbox.loss_weight), float(self.loss_iou.loss_weight), float(_EPS32))   # [L, 4]
+            out = {"loss_cls": per[L - 1, 0], "loss_bbox": per[L - 1, 1], "loss_iou": per[L - 1, 2], "loss_iou_pred": per[L - 1, 3]}
+            for i in range(L - 1):
+                out[f"d{i}.loss_cls"], out[f"d{i}.loss_bbox"] = per[i, 0], per[i, 1]
+                out[f"d{i}.loss_iou"], out[f"d{i}.loss_iou_pred"] = per[i, 2], per[i, 3]
+            self._last_assigned = T["asg"]
+            return out
         ntgt = normalize_bbox(tgt, self.pc_range)
         b3d = denormalize_bbox(box_all, self.pc_range)
         iou_bev = bbox_overlaps_nearest_3d(b3d, tgt, is_aligned=True)                  # [L,B,Q]
