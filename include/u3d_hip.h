@@ -152,9 +152,10 @@ int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32_t* nbr, in
 int32_t u3d_linear_bf16(const void* x, const void* w, const float* bias, int32_t relu, void* out, const int32_t* m_dev,
                         int32_t m_cap, int32_t k, int32_t n, u3d_stream s);
 int64_t u3d_igemm_wgrad_bf16_workspace(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol);
+/* out_layout 0: dw [K][Cin][Cout] (spconv-1.x / this library's layout); 1: dw [Cout][Cin][K] (nn.Conv3d's [Cout,Cin,kD,kH,kW]). */
 int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const int32_t* nbr, int32_t ld, float* dw,
                              const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
-                             void* workspace, int64_t workspace_bytes, u3d_stream s);
+                             int32_t out_layout, void* workspace, int64_t workspace_bytes, u3d_stream s);
 
 /* dW[kappa] = sum_m in[nbr[kappa][m],:]^T @ dout[m,:]   (f32 accumulate, dW f32 [K,Cin,Cout], overwritten).
  * workspace: u3d_spconv_wgrad_workspace() bytes. */

@@ -1143,6 +1143,20 @@ __global__ void k_igemm_wgrad_reduce(const float* __restrict__ partial, float* _
 #ifndef IGEMM_WGRAD_MIN_STAGES_K1
 #define IGEMM_WGRAD_MIN_STAGES_K1 8   /* 4 and 2 measured slower end-to-end (33.4 / 33.9 vs 33.3 ms per step) */
 #endif
+// same reduction, result written as [Cout][Cin][K] (nn.Conv3d's checkpoint layout): the gradient lands in the parameter's own
+// layout and autograd keeps it as is (a permuted view would be cloned into a contiguous tensor by AccumulateGrad: one more launch)
+__global__ void k_igemm_wgrad_reduce_oik(const float* __restrict__ partial, float* __restrict__ dw, long long n, int nsplit, int kvol,
+                                         int cin, int cout) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += partial[(long long)k * n + i];
+  const int co = (int)(i % cout);
+  const long long r = i / cout;
+  const int ci = (int)(r % cin), kap = (int)(r / cin);
+  dw[((long long)co * cin + ci) * kvol + kap] = s;
+}
+
 struct WgPlan { int tile; int ci_blocks, co_blocks, nsplit; };
 static WgPlan wgrad_plan_tile(int tile, int n_out_cap, int cin, int cout, int kvol) {
   WgPlan p;
@@ -1216,7 +1230,7 @@ static int launch_igemm_wgrad_glds(int tile, const void* in, const void* dout, c
 
 extern "C" int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const int32_t* nbr, int32_t ld, float* dw,
                                         const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
-                                        void* workspace, int64_t workspace_bytes, u3d_stream s) {
+                                        int32_t out_layout, void* workspace, int64_t workspace_bytes, u3d_stream s) {
   U3D_REQUIRE(in && dout && dw && n_out_dev && workspace && (nbr || kvol == 1), U3D_ERR_ARG);
   if (cin % 16 != 0 || cout % 16 != 0) return U3D_ERR_UNSUPPORTED;
   WgPlan p = wgrad_plan(n_out_cap, cin, cout, kvol);
@@ -1234,7 +1248,10 @@ extern "C" int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const 
   else if (p.tile == 32) rc = launch_igemm_wgrad<2, 2, 1, 1>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
   else rc = launch_igemm_wgrad<1, 1, 1, 1>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
   if (rc != U3D_OK) return rc;
-  hipLaunchKernelGGL(k_igemm_wgrad_reduce, dim3(u3d_cdiv(n / 4, 256)), dim3(256), 0, s, (const float*)workspace, dw, n, p.nsplit);
+  if (out_layout == 1)
+    hipLaunchKernelGGL(k_igemm_wgrad_reduce_oik, dim3(u3d_cdiv(n, 256)), dim3(256), 0, s, (const float*)workspace, dw, n, p.nsplit, kvol, cin, cout);
+  else
+    hipLaunchKernelGGL(k_igemm_wgrad_reduce, dim3(u3d_cdiv(n / 4, 256)), dim3(256), 0, s, (const float*)workspace, dw, n, p.nsplit);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

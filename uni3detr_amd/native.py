@@ -55,7 +55,7 @@ _SIGS = {
     "u3d_igemm_fwd_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "u3d_linear_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "u3d_igemm_wgrad_bf16_workspace": (_L, [_I, _I, _I, _I]),
-    "u3d_igemm_wgrad_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
+    "u3d_igemm_wgrad_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "u3d_colsum_workspace": (_L, [_I, _I]),
     "u3d_colsum": (_I, [_P, _I, _I, _I, _P, _P, _L, _P]),
     "u3d_bn_stats_workspace": (_L, [_I, _I]),
@@ -304,9 +304,12 @@ def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False, tag=None)
     return out
 
 
-def spconv_wgrad(inp, dout, nbr, n_out_dev, kvol):
+def spconv_wgrad(inp, dout, nbr, n_out_dev, kvol, out_oik=False):
+    """-> f32 [K, Cin, Cout]; with out_oik (bf16 second-generation path only): [Cout, Cin, K] (nn.Conv3d's layout)."""
     cin, cout, n_out = inp.shape[1], dout.shape[1], dout.shape[0]
-    dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=inp.device)
+    v2 = bool(inp.dtype == torch.bfloat16 and USE_IGEMM_V2 and cin % 16 == 0 and cout % 16 == 0)
+    assert v2 or not out_oik, "out_oik needs the bf16 implicit-GEMM weight-gradient path"
+    dw = torch.empty((cout, cin, kvol) if out_oik else (kvol, cin, cout), dtype=torch.float32, device=inp.device)
     t = TIMER
     meta = None
     if t is not None and t.mode == "census":
@@ -321,7 +324,7 @@ def spconv_wgrad(inp, dout, nbr, n_out_dev, kvol):
         ld = nbr.shape[1] if nbr is not None else 0
         e0 = t.begin() if t is not None else None
         _check(lib().u3d_igemm_wgrad_bf16(_ptr(inp), _ptr(dout), _ptr(nbr), ld, _ptr(dw), _ptr(n_out_dev), n_out, cin, cout, kvol,
-                                          _ptr(ws), wsb, _stream()), "igemm_wgrad_bf16")
+                                          1 if out_oik else 0, _ptr(ws), wsb, _stream()), "igemm_wgrad_bf16")
         if t is not None:
             t.end("spconv_wgrad", e0, meta)
         return dw
@@ -488,9 +491,13 @@ def trilinear_fwd(value_rows, grid, batch, dims):
     return out
 
 
-def trilinear_bwd(value_rows, grid, dout, batch, dims, want_dvalue=True, want_dgrid=True):
+def trilinear_bwd(value_rows, grid, dout, batch, dims, want_dvalue=True, want_dgrid=True, dvalue_accum=None):
+    """dvalue_accum: an existing f32 [rows, C] buffer to ACCUMULATE the value gradient into (the kernel adds with atomics)."""
     nq, c = grid.shape[1], value_rows.shape[1]
-    dvalue = torch.zeros(value_rows.shape, dtype=torch.float32, device=value_rows.device) if want_dvalue else None
+    if want_dvalue:
+        dvalue = dvalue_accum if dvalue_accum is not None else torch.zeros(value_rows.shape, dtype=torch.float32, device=value_rows.device)
+    else:
+        dvalue = None
     dgrid = torch.empty((batch, nq, 3), dtype=torch.float32, device=value_rows.device) if want_dgrid else None
     _check(lib().u3d_trilinear_bwd(_ptr(value_rows), _ptr(grid), _ptr(dout), batch, nq, dims[0], dims[1], dims[2], c, _ptr(dvalue),
                                    _ptr(dgrid), dtype_code(value_rows), _stream()), "trilinear_bwd")

@@ -321,6 +321,7 @@ class _FusedLN(torch.autograd.Function):
 
 
 FUSED_LN = _os.environ.get("U3D_FUSED_LN", "1") == "1"
+SHARED_VALUE_GRAD = _os.environ.get("U3D_SHARED_VALUE_GRAD", "1") == "1"
 
 
 def fused_layer_norm(x, ln, relu=False, out_dtype=None):
@@ -463,27 +464,49 @@ class FFN(nn.Module):
         return residual_add(x if identity is None else identity, out)
 
 
+class ValueGradAccum:
+    """Shared f32 accumulator for the gradient of ONE voxel volume sampled by several decoder layers: every layer's backward adds
+    into the same buffer and only the last one to run hands the sum (cast once) to autograd - instead of a zero-fill, a cast and a
+    gradient-accumulation add of the whole [B*D*H*W, C] volume per layer."""
+
+    def __init__(self, uses):
+        self.remaining, self.buf = uses, None
+
+
 class _TrilinearSample(torch.autograd.Function):
     """F.grid_sample(value [B,C,D,H,W], grid [B,1,1,N,3]) -> [B,N,C] on the HIP sampler (channels-last rows)."""
 
     @staticmethod
-    def forward(ctx, value, grid):
+    def forward(ctx, value, grid, accum=None):
         B, C, D, H, W = value.shape
         rows = value.permute(0, 2, 3, 4, 1).reshape(-1, C)      # no copy for channels_last_3d volumes
         rows = rows if rows.is_contiguous() else rows.contiguous()
         g = grid.float().contiguous()
         ctx.save_for_backward(rows, g)
         ctx.shape = (B, C, D, H, W)
+        ctx.accum = accum
         return nv.trilinear_fwd(rows, g, B, (D, H, W))
 
     @staticmethod
     def backward(ctx, dout):
         rows, g = ctx.saved_tensors
         B, C, D, H, W = ctx.shape
-        dv, dg = nv.trilinear_bwd(rows, g, dout.contiguous().to(rows.dtype), B, (D, H, W), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        if dv is not None:
-            dv = dv.to(rows.dtype).view(B, D, H, W, C).permute(0, 4, 1, 2, 3)
-        return dv, dg
+        acc = ctx.accum
+        want_dv = ctx.needs_input_grad[0]
+        if acc is None or not want_dv:
+            dv, dg = nv.trilinear_bwd(rows, g, dout.contiguous().to(rows.dtype), B, (D, H, W), want_dv, ctx.needs_input_grad[1])
+            if dv is not None:
+                dv = dv.to(rows.dtype).view(B, D, H, W, C).permute(0, 4, 1, 2, 3)
+            return dv, dg, None
+        if acc.buf is None:
+            acc.buf = torch.zeros(rows.shape, dtype=torch.float32, device=rows.device)
+        _, dg = nv.trilinear_bwd(rows, g, dout.contiguous().to(rows.dtype), B, (D, H, W), True, ctx.needs_input_grad[1], dvalue_accum=acc.buf)
+        acc.remaining -= 1
+        dv = None
+        if acc.remaining == 0:
+            dv = acc.buf.to(rows.dtype).view(B, D, H, W, C).permute(0, 4, 1, 2, 3)
+            acc.buf = None
+        return dv, dg, None
 
 
 @ATTENTION.register_module()
@@ -513,7 +536,7 @@ class UniCrossAtten(nn.Module):
         nn.init.xavier_uniform_(self.output_proj.weight)
         nn.init.constant_(self.output_proj.bias, 0.0)
 
-    def forward_bf(self, query, query_pos, value, ref_logits):
+    def forward_bf(self, query, query_pos, value, ref_logits, accum=None):
         """query/query_pos [B,N,C]; value [B,C,D,H,W] (or [B,C,H,W]); ref_logits [B,N,3] -> [B,N,C]."""
         cdt = _autocast_dtype(query)
         qp = (query.to(cdt) + query_pos.to(cdt)) if (cdt is not None and query.dtype != cdt) else query + query_pos
@@ -522,7 +545,7 @@ class UniCrossAtten(nn.Module):
         B, N, _ = g.shape
         if value.dim() != 5:
             raise NotImplementedError("height-less (BEV) value maps are not used by any shipped Uni3DETR config")
-        samp = _TrilinearSample.apply(value, g)                                       # [B,N,C]
+        samp = _TrilinearSample.apply(value, g, accum)                                # [B,N,C]
         wsum = w.sum(-1, keepdim=True)
         cdt = _autocast_dtype(query)
         if cdt is not None:             # gate in the compute dtype: the product feeds a bf16 GEMM directly
@@ -562,13 +585,13 @@ class BaseTransformerLayer(nn.Module):
         if self.pre_norm:
             raise NotImplementedError("pre-norm ordering is not used by any shipped Uni3DETR config")
 
-    def forward_bf(self, x, pos, value, ref_logits, group, x_c=None):
+    def forward_bf(self, x, pos, value, ref_logits, group, x_c=None, accum=None):
         ai = ni = fi = 0
         for op in self.operation_order:
             if op == "self_attn":
                 x = self.attentions[ai].forward_grouped(x, pos, group, x_c if ai == 0 else None); ai += 1
             elif op == "cross_attn":
-                x = self.attentions[ai].forward_bf(x, pos, value, ref_logits); ai += 1
+                x = self.attentions[ai].forward_bf(x, pos, value, ref_logits, accum); ai += 1
             elif op == "norm":
                 x = fused_layer_norm(x, self.norms[ni]); ni += 1
             elif op == "ffn":
@@ -593,13 +616,16 @@ class Uni3DETRTransformerDecoder(nn.Module):
         out = query
         states, refs = [], []
         self._reg_outputs = [] if reg_branches is not None else None     # reused by Uni3DETRHead.forward (same module, same input)
+        # one gradient accumulator for the sampled volume when every layer samples it exactly once (the shipped layer layout)
+        n_cross = sum(l.operation_order.count("cross_attn") for l in self.layers)
+        accum = ValueGradAccum(n_cross) if (SHARED_VALUE_GRAD and value.requires_grad and torch.is_grad_enabled() and n_cross > 1) else None
         cdt = _autocast_dtype(query)
         self._states_c = [] if cdt is not None else None      # each layer state once in the compute dtype: shared by the reg branch,
         out_c = None                                          # query_scale, the next layer's self-attention and the head's cls / iou branches
         for lid, layer in enumerate(self.layers):
             raw = self.ref_point_head(get_sine_pos_embed(ref_logits.sigmoid()).to(out.dtype))
             pos = raw if lid == 0 else self.query_scale(out if out_c is None else out_c) * raw
-            out = layer.forward_bf(out, pos, value, ref_logits, group, out_c)
+            out = layer.forward_bf(out, pos, value, ref_logits, group, out_c, accum)
             if cdt is not None:
                 out_c = out.to(cdt)
                 self._states_c.append(out_c)

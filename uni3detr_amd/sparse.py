@@ -118,9 +118,16 @@ class _SparseConv(torch.autograd.Function):
                 din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True)
         if ctx.needs_input_grad[1]:
             nbr = g.nbr_fwd if kvol > 1 else None
-            dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol).reshape(ctx.kio_shape).to(ctx.wdtype)
-            if ctx.layout == "oidhw":
-                dw = dw.permute(4, 3, 0, 1, 2)
+            cin_w, cout_w = wc.shape[1], wc.shape[2]
+            if (ctx.layout == "oidhw" and feats.dtype == torch.bfloat16 and nv.USE_IGEMM_V2 and cin_w % 16 == 0 and cout_w % 16 == 0
+                    and ctx.wdtype == torch.float32):
+                # the reduction stage writes nn.Conv3d's own [Cout,Cin,kD,kH,kW] layout: autograd keeps the tensor as the gradient
+                ks = ctx.kio_shape
+                dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol, out_oik=True).view(ks[4], ks[3], ks[0], ks[1], ks[2])
+            else:
+                dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol).reshape(ctx.kio_shape).to(ctx.wdtype)
+                if ctx.layout == "oidhw":
+                    dw = dw.permute(4, 3, 0, 1, 2)
         return din, dw, None, None
 
 
