@@ -417,6 +417,14 @@ def test_strided_dgrad_split_path_matches_conv3d(cuda, stride, cout):
             got[split] = rows.grad.float().view(B, D, H, W, C).permute(0, 4, 1, 2, 3).cpu()
         finally:
             sp.STRIDED_DGRAD_SPLIT = True
+    # nn.Conv3d-layout parameter ("oidhw"): the bf16 weight gradient comes back in the parameter's own layout
+    wr = w.clone().requires_grad_(True)
+    F.conv3d(x, wr, None, stride, p).backward(gy)
+    wp = torch.nn.Parameter(w.to(cuda))
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, C).contiguous().to(cuda).bfloat16()
+    sp.sparse_conv(rows, wp, geom, "oidhw").backward(gy.permute(0, 2, 3, 4, 1).reshape(-1, cout).contiguous().to(cuda).bfloat16())
+    assert wp.grad.shape == wp.shape and wp.grad.is_contiguous()
+    assert (wp.grad.cpu() - wr.grad).abs().max().item() <= 2e-2 * wr.grad.abs().max().item()
     scale = xr.grad.abs().max().item()
     assert (got[True] - xr.grad).abs().max().item() <= 2e-2 * scale
     assert (got[False] - xr.grad).abs().max().item() <= 2e-2 * scale
