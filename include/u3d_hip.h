@@ -151,6 +151,15 @@ int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32_t* nbr, in
  * models/dense_heads/uni3detr_head.py:365-387.)  U3D_ERR_UNSUPPORTED unless K % 64 == 0 and N % 64 == 0. */
 int32_t u3d_linear_bf16(const void* x, const void* w, const float* bias, int32_t relu, void* out, const int32_t* m_dev,
                         int32_t m_cap, int32_t k, int32_t n, u3d_stream s);
+/* Forward with n-major weights w[K][Cout][Cin] (the layout u3d_igemm_fwd_bf16 takes with transpose_w = 1) that also emits the
+ * BatchNorm statistics of its (bf16-rounded) output per row tile: stats f64 [ceil(n_out_cap / T)][2][Cout] with
+ * T = u3d_igemm_fwd_stats_tile_rows(...) (0: shape not served - use u3d_igemm_fwd_bf16 + u3d_bn_stats).  Feeds
+ * u3d_bn_finalize_partials; saves the separate statistics pass over the conv output (ref: conv -> BatchNorm pairs of
+ * sparse_encoder_hd.py:71-104 and second_3d.py:52-76). */
+int32_t u3d_igemm_fwd_stats_tile_rows(int32_t n_out_cap, int32_t cin, int32_t cout);
+int32_t u3d_igemm_fwd_stats_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,
+                                 const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
+                                 double* stats, u3d_stream s);
 int64_t u3d_igemm_wgrad_bf16_workspace(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol);
 /* out_layout 0: dw [K][Cin][Cout] (spconv-1.x / this library's layout); 1: dw [Cout][Cin][K] (nn.Conv3d's [Cout,Cin,kD,kH,kW]). */
 int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const int32_t* nbr, int32_t ld, float* dw,
@@ -198,6 +207,11 @@ int32_t u3d_bn_finalize(const double* sums, const int32_t* n_dev, int32_t n_cap,
 int32_t u3d_bn_forward_stats(const void* x, const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, float eps,
                              float momentum, float* running_mean, float* running_var, int64_t* num_batches, float* mean,
                              float* invstd, void* workspace, int64_t workspace_bytes, u3d_stream s);
+/* Same finalisation from statistics the producing convolution already reduced per row tile (u3d_igemm_fwd_stats_bf16):
+ * partial f64 [nblocks][2][C], tile b = rows [b*rows_per_block, (b+1)*rows_per_block). */
+int32_t u3d_bn_finalize_partials(const double* partial, int32_t nblocks, int32_t rows_per_block, const int32_t* n_dev,
+                                 int32_t n_cap, int32_t c, float eps, float momentum, float* running_mean, float* running_var,
+                                 int64_t* num_batches, float* mean, float* invstd, u3d_stream s);
 /* y = relu?( (x-mean)*invstd*gamma + beta (+ residual) ); mean/invstd/gamma/beta f32 [C]. */
 int32_t u3d_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, const void* residual, int32_t relu, void* y,

@@ -431,6 +431,44 @@ def test_strided_dgrad_split_path_matches_conv3d(cuda, stride, cout):
     assert (got[True] - got[False]).abs().max().item() <= 2e-2 * scale
 
 
+@pytest.mark.parametrize("cin,cout,B,dims", [(64, 64, 2, (5, 12, 10)), (128, 256, 3, (4, 11, 9)), (256, 256, 8, (15, 40, 40))])
+def test_conv_epilogue_bn_statistics_match_separate_pass(cuda, cin, cout, B, dims):
+    """conv -> BatchNorm with the statistics reduced in the conv epilogue (u3d_igemm_fwd_stats_bf16 + u3d_bn_finalize_partials) equals
+    the conv followed by the stand-alone statistics pass: outputs, running statistics, and the backward through both."""
+    from uni3detr_amd.plugin import dense as dn
+    from uni3detr_amd import sparse as sp
+    torch.manual_seed(cin + cout)
+    D, H, W = dims
+    k, s_, p = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    geom, _ = dn.Lattice.conv(cuda, B, dims, k, s_, p)
+    n = B * D * H * W
+    x = torch.randn(n, cin, device=cuda).bfloat16()
+    w = torch.nn.Parameter((torch.randn(*k, cin, cout, device=cuda) * 0.05))
+    gy = torch.randn(n, cout, device=cuda).bfloat16()
+    res = {}
+    for fused in (True, False):
+        sp.FUSED_CONV_STATS = fused
+        try:
+            bn = torch.nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01).to(cuda).train()
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.1)
+            torch.manual_seed(1)
+            with torch.no_grad():
+                bn.weight.copy_(torch.linspace(0.5, 1.5, cout)); bn.bias.copy_(torch.linspace(-0.2, 0.2, cout))
+            xq = x.clone().requires_grad_(True)
+            w.grad = None
+            y = sp.conv_bn(xq, w, geom, bn, geom.n_out_dev, None, True)
+            y.backward(gy)
+            res[fused] = (y.detach().float(), bn.running_mean.clone(), bn.running_var.clone(), xq.grad.float(), w.grad.clone(), bn.weight.grad.clone())
+        finally:
+            sp.FUSED_CONV_STATS = True
+    a, b = res[True], res[False]
+    assert (a[0] - b[0]).abs().max().item() <= 2e-2 * max(1.0, b[0].abs().max().item())
+    assert torch.allclose(a[1], b[1], rtol=1e-4, atol=1e-6) and torch.allclose(a[2], b[2], rtol=1e-4, atol=1e-6)
+    for i in (3, 4, 5):
+        assert (a[i] - b[i]).abs().max().item() <= 3e-2 * max(1e-3, b[i].abs().max().item()), i
+
+
 def test_dynamic_voxelize_and_scatter_mean(cuda):
     from uni3detr_amd.plugin.detector import DynamicSimpleVFE
     rng = np.random.default_rng(2)

@@ -272,7 +272,8 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 template <int WAVES_M, int WAVES_N, int WM, int WN>
 __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
                                                 int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
-                                                int cin, int cout, int kvol, const float* __restrict__ bias, int relu) {
+                                                int cin, int cout, int kvol, const float* __restrict__ bias, int relu,
+                                                double* __restrict__ stats) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, BK = 64;
   constexpr int A_ELEMS = BM * BK, W_ELEMS = BN * BK;   // unpadded tiles, 128 B per row
@@ -393,6 +394,9 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
     __syncthreads();                                    // also drains this wave's LDS-DMA (vmcnt) before anyone reads the next buffer
   }
   // epilogue: acc[a][b][r] = C[row (wm*WM+a)*16 + li][col (wn*WN+b)*16 + 4g + r]; v_cvt_pk_bf16_f32 (RNE) via convertvector
+  f32x4 cs[WN], cq[WN];                                 // BatchNorm statistics of this wave's rows: column sums / sums of squares
+#pragma unroll
+  for (int b = 0; b < WN; ++b) { cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
   for (int a = 0; a < WM; ++a) {
     const int m = m0 + (wm * WM + a) * 16 + li;
@@ -404,7 +408,42 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
         f32x4 v = acc[a][b];
         if (bias) { const f32x4 bv = *(const f32x4*)(bias + col); v += bv; }
         if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        *(bf16x4*)(out + (long long)m * cout + col) = __builtin_convertvector(v, bf16x4);
+        const bf16x4 o = __builtin_convertvector(v, bf16x4);
+        *(bf16x4*)(out + (long long)m * cout + col) = o;
+        if (stats) {                                    // statistics of the ROUNDED values: what the BatchNorm that follows reads
+          const f32x4 vr = __builtin_convertvector(o, f32x4);
+          cs[b] += vr;
+          cq[b] += vr * vr;
+        }
+      }
+    }
+  }
+  if (stats) {
+    // the BatchNorm behind this conv needs per-column sum / sum of squares over ALL rows: reduce this tile here (16 lanes of a
+    // column group by shuffles, the row waves through LDS) and leave one f64 partial per (row tile, column) - the separate
+    // statistics pass over the output (one full read of the tensor) disappears
+    float* red = (float*)smem;                          // [WAVES_M][2][BN] floats; the stage buffers are dead after the last barrier
+#pragma unroll
+    for (int b = 0; b < WN; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = cs[b][r], s2 = cq[b][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (li == 0) {
+          const int cl = (wn * WN + b) * 16 + 4 * g + r;
+          red[(wm * 2 + 0) * BN + cl] = s1;
+          red[(wm * 2 + 1) * BN + cl] = s2;
+        }
+      }
+    __syncthreads();
+    for (int t = tid; t < 2 * BN; t += NW * 64) {
+      const int which = t / BN, cl = t % BN;
+      if (col0 + cl < cout) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < WAVES_M; ++k) a += (double)red[(k * 2 + which) * BN + cl];
+        stats[((long long)tile * 2 + which) * cout + col0 + cl] = a;
       }
     }
   }
@@ -414,8 +453,8 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
 #define U3D_GLDS_KERNEL(NAME, A, B, C, D)                                                                                        \
   __global__ __launch_bounds__(A* B * 64) void NAME(const u16* in, const u16* w, const int* nbr, int ld, u16* out,               \
                                                     const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,            \
-                                                    const float* bias, int relu) {                                               \
-    igemm_glds_body<A, B, C, D>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu);                          \
+                                                    const float* bias, int relu, double* stats) {                                \
+    igemm_glds_body<A, B, C, D>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats);                   \
   }
 U3D_GLDS_KERNEL(k_igemm_glds_256x256, 2, 4, 8, 4)
 // (a 4-wave variant with 128 x 128 per wave - 1.5x fewer LDS fragment bytes per MFMA - compiled to 512 VGPRs + spills and ran at
@@ -424,11 +463,12 @@ U3D_GLDS_KERNEL(k_igemm_glds_256x128, 4, 2, 4, 4)
 U3D_GLDS_KERNEL(k_igemm_glds_128x64, 4, 1, 2, 4)
 U3D_GLDS_KERNEL(k_igemm_glds_128x128, 2, 2, 4, 4)      /* 4 waves, 64 KiB LDS: two workgroups per CU run out of phase */
 #undef U3D_GLDS_KERNEL
-typedef void (*glds_kernel_t)(const u16*, const u16*, const int*, int, u16*, const int*, int, int, int, int, const float*, int);
+typedef void (*glds_kernel_t)(const u16*, const u16*, const int*, int, u16*, const int*, int, int, int, int, const float*, int, double*);
 
 template <int WAVES_M, int WAVES_N, int WM, int WN>
 static int launch_igemm_glds(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev,
-                             int n_out_cap, int cin, int cout, int kvol, hipStream_t s, const float* bias = nullptr, int relu = 0) {
+                             int n_out_cap, int cin, int cout, int kvol, hipStream_t s, const float* bias = nullptr, int relu = 0,
+                             double* stats = nullptr) {
   constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
   constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;        // 256 x 256: 128 KiB
   glds_kernel_t kern = (BM == 256 && BN == 256) ? k_igemm_glds_256x256
@@ -437,7 +477,7 @@ static int launch_igemm_glds(const void* in, const void* w, const int32_t* nbr, 
   if (!attr_set && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin,
-                     cout, kvol, bias, relu);
+                     cout, kvol, bias, relu, stats);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
 }
 
@@ -715,6 +755,26 @@ extern "C" int32_t u3d_linear_bf16(const void* x, const void* w, const float* bi
   if (n % 128 == 0 && (long long)u3d_cdiv(m_cap, 256) * (n / 128) >= 128)
     return launch_igemm_glds<4, 2, 4, 4>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
   return launch_igemm_glds<4, 1, 2, 4>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
+}
+
+// row-tile height of the n-major (LDS-DMA) kernel u3d_igemm_fwd_stats_bf16 would launch for this shape; 0 = not served by it
+extern "C" int32_t u3d_igemm_fwd_stats_tile_rows(int32_t n_out_cap, int32_t cin, int32_t cout) {
+  if (!IGEMM_GLDS || cin % 64 != 0 || cout % 64 != 0 || n_out_cap <= 0) return 0;
+  const long long wg256 = (long long)u3d_cdiv(n_out_cap, 256) * (cout / 256 > 0 ? cout / 256 : 1);
+  if (cout % 256 == 0 && wg256 >= 128) return 256;
+  return 128;
+}
+// forward with n-major weights w[kappa][cout][cin] that also leaves the per-row-tile BatchNorm statistics of the (bf16-rounded)
+// output: stats f64 [ceil(n_out_cap / tile_rows)][2][cout] = (sum, sum of squares) per tile and column
+extern "C" int32_t u3d_igemm_fwd_stats_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,
+                                            const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
+                                            double* stats, u3d_stream s) {
+  U3D_REQUIRE(in && w && out && n_out_dev && stats && (nbr || kvol == 1), U3D_ERR_ARG);
+  const int tr = u3d_igemm_fwd_stats_tile_rows(n_out_cap, cin, cout);
+  if (tr == 0) return U3D_ERR_UNSUPPORTED;
+  if (tr == 256) return launch_igemm_glds<2, 4, 8, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);
+  if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);
+  return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);
 }
 
 // returns U3D_ERR_UNSUPPORTED when the shape is better served by the first-generation kernel

@@ -447,7 +447,8 @@ __global__ void k_bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ y
 
 // forward statistics in two launches instead of three: stage 2 of the reduction and the mean / invstd / running-stat update in one
 // kernel (one wave per column: lanes stride over the row-block partials of sum and sum of squares, fixed tree order)
-__global__ __launch_bounds__(256) void k_bn_final_finalize(const double* __restrict__ partial, int nblocks, const int* __restrict__ n_dev,
+__global__ __launch_bounds__(256) void k_bn_final_finalize(const double* __restrict__ partial, int nblocks, int rows_per_block,
+                                                           const int* __restrict__ n_dev,
                                                            int n_cap, int c, float eps, float momentum, float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, long long* __restrict__ num_batches,
                                                            float* __restrict__ mean, float* __restrict__ invstd) {
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(256) void k_bn_final_finalize(const double* __restr
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
   if (col >= c) return;
   const int n = min(*n_dev, n_cap);
-  int used = (n + ST_ROWS_PER_BLOCK - 1) / ST_ROWS_PER_BLOCK;
+  int used = (n + rows_per_block - 1) / rows_per_block;
   if (used > nblocks) used = nblocks;
   double s0 = 0.0, s1 = 0.0;
   for (int b = lane; b < used; b += 64) {
@@ -497,7 +498,18 @@ extern "C" int32_t u3d_bn_forward_stats(const void* x, const int32_t* n_dev, int
       else hipLaunchKernelGGL((k_col_stats<u16, 0>), dim3(nb), dim3(256), 0, s, (const u16*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace);
     }
   }
-  hipLaunchKernelGGL(k_bn_final_finalize, dim3(u3d_cdiv(c, 4)), dim3(256), 0, s, (const double*)workspace, nb, n_dev, n_cap, c, eps, momentum,
+  hipLaunchKernelGGL(k_bn_final_finalize, dim3(u3d_cdiv(c, 4)), dim3(256), 0, s, (const double*)workspace, nb, ST_ROWS_PER_BLOCK, n_dev, n_cap, c,
+                     eps, momentum, running_mean, running_var, (long long*)num_batches, mean, invstd);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+// statistics already reduced per row block by the producer (u3d_igemm_fwd_stats_bf16): partial f64 [nblocks][2][C], block b covering
+// rows [b*rows_per_block, (b+1)*rows_per_block) - only the blocks below the device-side row count are summed
+extern "C" int32_t u3d_bn_finalize_partials(const double* partial, int32_t nblocks, int32_t rows_per_block, const int32_t* n_dev,
+                                            int32_t n_cap, int32_t c, float eps, float momentum, float* running_mean,
+                                            float* running_var, int64_t* num_batches, float* mean, float* invstd, u3d_stream s) {
+  U3D_REQUIRE(partial && n_dev && mean && invstd && c > 0 && nblocks >= 0 && rows_per_block > 0 && (!running_mean || running_var), U3D_ERR_ARG);
+  hipLaunchKernelGGL(k_bn_final_finalize, dim3(u3d_cdiv(c, 4)), dim3(256), 0, s, partial, nblocks, rows_per_block, n_dev, n_cap, c, eps, momentum,
                      running_mean, running_var, (long long*)num_batches, mean, invstd);
   U3D_CHECK_LAUNCH();
   return U3D_OK;

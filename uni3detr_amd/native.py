@@ -62,6 +62,9 @@ _SIGS = {
     "u3d_bn_stats": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _P]),
     "u3d_bn_finalize": (_I, [_P, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     "u3d_bn_forward_stats": (_I, [_P, _P, _I, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "u3d_bn_finalize_partials": (_I, [_P, _I, _I, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
+    "u3d_igemm_fwd_stats_tile_rows": (_I, [_I, _I, _I]),
+    "u3d_igemm_fwd_stats_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
     "u3d_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "u3d_bn_bwd_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
     "u3d_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
@@ -273,6 +276,42 @@ class KernelTimer:
 TIMER = None
 CALL_KIND = "sparse"
 USE_IGEMM_V2 = True
+
+
+def spconv_fwd_stats(inp, w_nmajor, nbr, n_out_dev, n_out, cout):
+    """Forward with n-major weights [K, Cout, Cin] + per-row-tile BatchNorm statistics of the output.
+    -> (out [n_out, cout], stats f64 [nblocks, 2, cout], tile_rows) or None when the shape is not served by that kernel."""
+    cin, kvol = inp.shape[1], w_nmajor.shape[0]
+    if inp.dtype != torch.bfloat16 or not USE_IGEMM_V2:
+        return None
+    tr = int(lib().u3d_igemm_fwd_stats_tile_rows(n_out, cin, cout))
+    if tr == 0:
+        return None
+    out = torch.empty((n_out, cout), dtype=inp.dtype, device=inp.device)
+    nblocks = (n_out + tr - 1) // tr
+    stats = torch.empty((nblocks, 2, cout), dtype=torch.float64, device=inp.device)
+    ld = nbr.shape[1] if nbr is not None else 0
+    t = TIMER
+    e0 = t.begin() if t is not None else None
+    _check(lib().u3d_igemm_fwd_stats_bf16(_ptr(inp), _ptr(w_nmajor), _ptr(nbr), ld, _ptr(out), _ptr(n_out_dev), n_out, cin, cout, kvol,
+                                          _ptr(stats), _stream()), "igemm_fwd_stats_bf16")
+    if t is not None:
+        meta = None
+        if t.mode == "census":
+            pairs = int((nbr[:, :n_out] >= 0).sum().item()) if nbr is not None else n_out
+            meta = dict(kind=CALL_KIND, v2=True, n_in=inp.shape[0], n_out=n_out, cin=cin, cout=cout, kvol=kvol, pairs=pairs,
+                        bytes=inp.shape[0] * cin * 2 + n_out * cout * 2 + 8 * pairs + kvol * cin * cout * 2, flops=2 * pairs * cin * cout)
+        t.end("spconv_fwd", e0, meta)
+    return out, stats, tr
+
+
+def bn_finalize_partials(stats, tile_rows, n_dev, n_cap, eps, momentum, running_mean=None, running_var=None, num_batches=None):
+    nblocks, _, c = stats.shape
+    mean = torch.empty((c,), dtype=torch.float32, device=stats.device)
+    invstd = torch.empty((c,), dtype=torch.float32, device=stats.device)
+    _check(lib().u3d_bn_finalize_partials(_ptr(stats), nblocks, tile_rows, _ptr(n_dev), n_cap, c, eps, momentum, _ptr(running_mean),
+                                          _ptr(running_var), _ptr(num_batches), _ptr(mean), _ptr(invstd), _stream()), "bn_finalize_partials")
+    return mean, invstd
 
 
 def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False, tag=None):

@@ -108,8 +108,8 @@ def to_volume(rows, B, dims):
 def conv_bn_relu(rows, B, dims, conv, bn):
     ks, st, pd = tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding)
     geom, dims_out = Lattice.conv(rows.device, B, dims, ks, st, pd)
-    y = sp.sparse_conv(rows, conv.weight, geom, "oidhw")   # nn.Conv3d layout [Cout,Cin,kd,kh,kw]; re-laid-out by the shadow set
-    return sp.bn_rows(y, bn, geom.n_out_dev, None, True), dims_out
+    # nn.Conv3d layout [Cout,Cin,kd,kh,kw] (re-laid-out by the shadow set); BatchNorm statistics come out of the conv's epilogue
+    return sp.conv_bn(rows, conv.weight, geom, bn, geom.n_out_dev, None, True, "oidhw"), dims_out
 
 
 def deconv_bn_relu(rows, B, dims, deconv, bn):

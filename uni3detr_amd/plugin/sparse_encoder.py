@@ -113,13 +113,12 @@ class SparseEncoderHD(nn.Module):
                 cap = self.level_capacities[len(self.last_level_counts) - 1]
             new, geom = sp.strided_level(lvl, conv.ksize, conv.stride, conv.padding, capacity=cap)
             self.last_level_counts.append(new.n_dev)
-        y = sp.sparse_conv(x, conv.weight, geom)
-        return sp.bn_rows(y, bn, new.n_dev, None, True), new
+        return sp.conv_bn(x, conv.weight, geom, bn, new.n_dev, None, True), new
 
     def _block(self, blk, x, lvl):
         geom = sp.subm_geom(lvl)
-        o = sp.bn_rows(sp.sparse_conv(x, blk.conv1.weight, geom), blk.bn1, lvl.n_dev, None, True)
-        return sp.bn_rows(sp.sparse_conv(o, blk.conv2.weight, geom), blk.bn2, lvl.n_dev, x, True)
+        o = sp.conv_bn(x, blk.conv1.weight, geom, blk.bn1, lvl.n_dev, None, True)
+        return sp.conv_bn(o, blk.conv2.weight, geom, blk.bn2, lvl.n_dev, x, True)
 
     def forward(self, voxel_features, coors, batch_size):
         """voxel_features [N,C], coors int [N,4] (b,z,y,x), batch_size -> [B, C_out, D, H, W] (ref :106-138)."""

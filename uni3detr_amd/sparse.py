@@ -83,8 +83,10 @@ STRIDED_SPLIT_MIN_RATIO = int(_os.environ.get("U3D_STRIDED_SPLIT_MIN_RATIO", "16
 
 class _SparseConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, weight, geom, layout):
+    def forward(ctx, feats, weight, geom, layout, want_stats=False):
         # weight: the PARAMETER in its checkpoint layout: "dhwio" [kD,kH,kW,Cin,Cout] (mmcv spconv-1.x) or "oidhw" (nn.Conv3d)
+        # want_stats: also return the per-row-tile BatchNorm statistics of the output (empty tensor when the kernel serving this
+        # shape does not produce them) - second, non-differentiable output
         bf16 = feats.dtype == torch.bfloat16
         kio_shape = weight.shape if layout == "dhwio" else tuple(weight.shape[i] for i in (2, 3, 4, 1, 0))
         cin, cout = kio_shape[3], kio_shape[4]
@@ -95,12 +97,23 @@ class _SparseConv(torch.autograd.Function):
         ctx.kio_shape, ctx.wdtype = kio_shape, weight.dtype
         nbr = geom.nbr_fwd if kio.shape[0] > 1 else None
         nv.CALL_KIND = geom.kind
+        if want_stats:
+            res = nv.spconv_fwd_stats(feats, koi, nbr, geom.n_out_dev, geom.n_out, cout) if nmajor else None
+            if res is not None:
+                y, stats, tr = res
+                stats._u3d_tile_rows = tr
+            else:
+                y = (nv.spconv_fwd(feats, koi, nbr, geom.n_out_dev, geom.n_out, cout, transpose_w=True, tag="spconv_fwd") if nmajor
+                     else nv.spconv_fwd(feats, kio, nbr, geom.n_out_dev, geom.n_out, cout))
+                stats = torch.empty(0, dtype=torch.float64, device=feats.device)
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         if nmajor:      # forward on the LDS-DMA kernel (n-major weight shadow)
             return nv.spconv_fwd(feats, koi, nbr, geom.n_out_dev, geom.n_out, cout, transpose_w=True, tag="spconv_fwd")
         return nv.spconv_fwd(feats, kio, nbr, geom.n_out_dev, geom.n_out, cout)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dstats=None):
         feats, wc = ctx.saved_tensors
         g = ctx.geom
         dout = dout.contiguous()
@@ -128,7 +141,7 @@ class _SparseConv(torch.autograd.Function):
                 dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol).reshape(ctx.kio_shape).to(ctx.wdtype)
                 if ctx.layout == "oidhw":
                     dw = dw.permute(4, 3, 0, 1, 2)
-        return din, dw, None, None
+        return din, dw, None, None, None
 
 
 def sparse_conv(feats, weight, geom, layout="dhwio"):
@@ -136,13 +149,33 @@ def sparse_conv(feats, weight, geom, layout="dhwio"):
     return _SparseConv.apply(feats, weight, geom, layout)
 
 
+FUSED_CONV_STATS = _os.environ.get("U3D_FUSED_CONV_STATS", "1") == "1"
+
+
+def conv_bn(feats, weight, geom, bn, n_dev, residual=None, relu=True, layout="dhwio"):
+    """conv -> BatchNorm rows (+ residual) (+ ReLU).  In training the conv's epilogue already reduces the BatchNorm statistics per row
+    tile where its kernel supports it (bf16, channels % 64 == 0): the separate statistics pass over the conv output disappears."""
+    if FUSED_CONV_STATS and bn.training and feats.dtype == torch.bfloat16 and feats.is_cuda:
+        y, stats = _SparseConv.apply(feats, weight, geom, layout, True)
+        if stats.numel():
+            tr = getattr(stats, "_u3d_tile_rows", None)
+            if tr is None:                      # attribute lost on the way through autograd: recover it from the shape
+                tr = 128 if (y.shape[0] + 127) // 128 == stats.shape[0] else 256
+            return _BNRows.apply(y, bn.weight, bn.bias, residual, n_dev, bn, relu, True, stats, tr)
+        return bn_rows(y, bn, n_dev, residual, relu)
+    return bn_rows(sparse_conv(feats, weight, geom, layout), bn, n_dev, residual, relu)
+
+
 class _BNRows(torch.autograd.Function):
     """BatchNorm1d over active rows (+ residual) (+ ReLU), training or eval statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, n_dev, bn, relu, training):
+    def forward(ctx, x, gamma, beta, residual, n_dev, bn, relu, training, stats=None, tile_rows=0):
         n = x.shape[0]
-        if training:
+        if training and stats is not None:
+            mean, invstd = nv.bn_finalize_partials(stats, tile_rows, n_dev, n, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                                                   bn.running_mean, bn.running_var, bn.num_batches_tracked)
+        elif training:
             mean, invstd = nv.bn_forward_stats(x, n_dev, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
                                                bn.running_mean, bn.running_var, bn.num_batches_tracked)
         else:
@@ -169,7 +202,7 @@ class _BNRows(torch.autograd.Function):
         else:
             dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, ctx.relu, ctx.n_dev, ctx.has_res, beta)
         s32 = sums.to(ctx.pdtype)
-        return dx, s32[1], s32[0], dres, None, None, None, None
+        return dx, s32[1], s32[0], dres, None, None, None, None, None, None
 
 
 def bn_rows(x, bn, n_dev, residual=None, relu=True):
