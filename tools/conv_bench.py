@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--rotate", type=int, default=1, help="cycle through this many input/gradient tensors so the working set exceeds the 256 MB Infinity Cache (the training step never re-reads a tensor it just used)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     for name, (B, dims, cin, cout, ks, st, pad) in LAYERS.items():
@@ -48,16 +49,22 @@ def main():
         nbr_b = nv.dense_nbr_table(B, dims, dims, ks, st, pad, 1, dev)
         nd = nv.count_tensor(n, dev)
         torch.manual_seed(0)
-        x = torch.randn(n, cin, device=dev).bfloat16()
-        dy = torch.randn(n, cout, device=dev).bfloat16()
+        xs = [torch.randn(n, cin, device=dev).bfloat16() for _ in range(a.rotate)]
+        dys = [torch.randn(n, cout, device=dev).bfloat16() for _ in range(a.rotate)]
+        x, dy = xs[0], dys[0]
+        ctr = [0]
+
+        def nxt():
+            ctr[0] += 1
+            return xs[ctr[0] % a.rotate], dys[ctr[0] % a.rotate]
         w = (torch.randn(kvol, cin, cout, device=dev) * 0.05).bfloat16()
         pairs = int((nbr[:, :n] >= 0).sum())
         flops = 2.0 * pairs * cin * cout
         byt = n * cin * 2 + n * cout * 2 + 8 * pairs + kvol * cin * cout * 2
         passes = {
-            "fwd": lambda: nv.spconv_fwd(x, w, nbr, nd, n, cout),
-            "dgrad": lambda: nv.spconv_fwd(dy, w, nbr_b, nd, n, cin, transpose_w=True),
-            "wgrad": lambda: nv.spconv_wgrad(x, dy, nbr, nd, kvol),
+            "fwd": lambda: nv.spconv_fwd(nxt()[0], w, nbr, nd, n, cout),
+            "dgrad": lambda: nv.spconv_fwd(nxt()[1], w, nbr_b, nd, n, cin, transpose_w=True),
+            "wgrad": lambda: nv.spconv_wgrad(*nxt(), nbr, nd, kvol),
         }
         for pname, fn in passes.items():
             for _ in range(3):
