@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--data", default="randn", choices=["randn", "relu", "small", "zeros", "bn"], help="value distribution of the activation / gradient operands (kernel time depends on operand values through power/clock management)")
     ap.add_argument("--rotate", type=int, default=1, help="cycle through this many input/gradient tensors so the working set exceeds the 256 MB Infinity Cache (the training step never re-reads a tensor it just used)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -49,8 +50,19 @@ def main():
         nbr_b = nv.dense_nbr_table(B, dims, dims, ks, st, pad, 1, dev)
         nd = nv.count_tensor(n, dev)
         torch.manual_seed(0)
-        xs = [torch.randn(n, cin, device=dev).bfloat16() for _ in range(a.rotate)]
-        dys = [torch.randn(n, cout, device=dev).bfloat16() for _ in range(a.rotate)]
+        def gen(c):
+            t = torch.randn(n, c, device=dev)
+            if a.data == "relu":
+                t = torch.relu(t)
+            elif a.data == "small":
+                t = t * 1e-3
+            elif a.data == "zeros":
+                t = t * 0
+            elif a.data == "bn":
+                t = torch.relu(t * 0.7 + 0.1)
+            return t.bfloat16()
+        xs = [gen(cin) for _ in range(a.rotate)]
+        dys = [gen(cout) for _ in range(a.rotate)]
         x, dy = xs[0], dys[0]
         ctr = [0]
 
