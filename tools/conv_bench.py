@@ -18,6 +18,8 @@ LAYERS = {
     "dense512k9": (8, (15, 10, 10), 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     "dense64": (8, (15, 40, 40), 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     "dense32": (8, (30, 60, 24), 32, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    "dense32to64": (8, (30, 60, 24), 32, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    "dense16to32": (8, (20, 40, 20), 16, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     "dense16": (8, (20, 40, 20), 16, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
 }
 

@@ -18,6 +18,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef IGEMM_SMALL_C
+#define IGEMM_SMALL_C 1
+#endif
 #ifndef IGEMM_PP
 #define IGEMM_PP 0       /* 1: 256x256 tiles run the experimental ping-pong kernel (k_igemm_pp; measured on par with k_igemm_fwd<2,4,8,4>: DESIGN.md) */
 #endif
@@ -64,20 +67,21 @@ __device__ __forceinline__ bf16x8 direct_frag(const u16* tile, int stride, int r
 //   W_KMAJOR = true : global W[kappa][k][n]  (forward; staged row-major [k][n], fetched with transpose reads)
 //   W_KMAJOR = false: global W[kappa][n][k]  (dgrad: the forward weight read transposed; staged [n][k], direct reads)
 // =============================================================================================
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool W_KMAJOR>
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool W_KMAJOR, int BK = 64>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* __restrict__ in, const u16* __restrict__ w,
                                                                       const int* __restrict__ nbr, int ld, u16* __restrict__ out,
                                                                       const int* __restrict__ n_out_dev, int n_out_cap, int cin,
                                                                       int cout, int kvol, const float* __restrict__ bias, int relu) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, BK = 64;
-  constexpr int LDA = BK + 8;                           // A tile [BM][BK] (k contiguous): 36-dword stride -> conflict-free b64 reads
+  constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;   // BK = 64, or 32 for the 16/32-channel sparse levels (one MFMA k-step)
+  constexpr int LDA = BK + 8;                           // A tile [BM][BK] (k contiguous): 36- / 20-dword stride -> conflict-free b64 reads
   constexpr int LDW = W_KMAJOR ? BN + 16 : BK + 8;      // W tile [BK][BN] (transpose reads: +16) or [BN][BK] (direct: +8)
   constexpr int A_ELEMS = BM * LDA;
   constexpr int W_ELEMS = W_KMAJOR ? BK * LDW : BN * LDW;
   constexpr int A_SEGS = BM * (BK / 8) / NT;            // 16-byte segments per thread per stage
-  constexpr int W_SEGS = BK * BN / 8 / NT;
-  static_assert(BM * (BK / 8) % NT == 0 && BK * BN / 8 % NT == 0, "tile/thread mismatch");
+  constexpr int W_TOTAL = BK * BN / 8;                  // 16-byte segments of the W tile; small tiles leave some threads without one
+  constexpr int W_SEGS = (W_TOTAL + NT - 1) / NT;
+  static_assert(BM * (BK / 8) % NT == 0 && (BK == 64 || BK == 32), "tile/thread mismatch");
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   constexpr int STAGE_ELEMS = A_ELEMS + W_ELEMS;        // buffer b: A at smem + b*STAGE_ELEMS, W right behind it
 
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
   const int col0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv / WAVES_N, wn = wv % WAVES_N;
-  const int kchunks = cin / BK;                         // cin % 64 == 0 (dispatch guarantees)
+  const int kchunks = (cin + BK - 1) / BK;              // cin % 16 == 0 (dispatch); a short last chunk is zero-filled
   const int nstage = kvol * kchunks;
 
   f32x4 acc[WM][WN];
@@ -113,16 +117,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
   const int a_row0 = tid / (BK / 8);                                   // segment u covers row a_row0 + u * (NT / (BK/8))
   constexpr int A_ROW_STEP = NT / (BK / 8);
   unsigned w_voff[W_SEGS];
+  int w_k[W_SEGS];                                      // reduction index (within the chunk) of the segment's first element
 #pragma unroll
   for (int u = 0; u < W_SEGS; ++u) {
     int sgi = tid + u * NT;
+    const bool live = sgi < W_TOTAL;
     if (W_KMAJOR) {
       int k = sgi / (BN / 8), part = sgi % (BN / 8);
       int n = col0 + part * 8;
-      w_voff[u] = (n < cout) ? (unsigned)(k * cout + n) * 2u : 0xFFFFFFFFu;
+      w_k[u] = k;
+      w_voff[u] = (live && n < cout) ? (unsigned)(k * cout + n) * 2u : 0xFFFFFFFFu;
     } else {
       int n = sgi / (BK / 8), part = sgi % (BK / 8);
-      w_voff[u] = (col0 + n < cout) ? (unsigned)((col0 + n) * cin + part * 8) * 2u : 0xFFFFFFFFu;
+      w_k[u] = part * 8;
+      w_voff[u] = (live && col0 + n < cout) ? (unsigned)((col0 + n) * cin + part * 8) * 2u : 0xFFFFFFFFu;
     }
   }
 
@@ -154,9 +162,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
   auto issue_loads = [&](int st) {
     const int kap = st % kvol, c0 = (st / kvol) * BK;
     const unsigned a_soff = (unsigned)c0 * 2u;
+    const bool a_in = BK == 64 || (c0 + (int)(a_part16 >> 1) < cin);   // BK = 32 with cin = 16: the upper half of the chunk is zero
 #pragma unroll
     for (int u = 0; u < A_SEGS; ++u) {
-      unsigned voff = idx_cur[u] >= 0 ? (unsigned)idx_cur[u] * row_bytes + a_part16 : 0xFFFFFFFFu;
+      unsigned voff = (idx_cur[u] >= 0 && a_in) ? (unsigned)idx_cur[u] * row_bytes + a_part16 : 0xFFFFFFFFu;
 #ifdef IGEMM_EXP_SKIP_A
       if (st > 0) continue;
 #endif
@@ -167,7 +176,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
     if (st > 0) return;
 #endif
 #pragma unroll
-    for (int u = 0; u < W_SEGS; ++u) rw[u] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_voff[u], w_soff, 0);
+    for (int u = 0; u < W_SEGS; ++u) {
+      const unsigned vo = (BK == 64 || c0 + w_k[u] < cin) ? w_voff[u] : 0xFFFFFFFFu;
+      rw[u] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, vo, w_soff, 0);
+    }
   };
   auto store_lds = [&](int buf) {
     u16* Ab = smem + buf * STAGE_ELEMS;
@@ -177,6 +189,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
 #pragma unroll
     for (int u = 0; u < W_SEGS; ++u) {
       int sgi = tid + u * NT;
+      if (sgi >= W_TOTAL) continue;
       if (W_KMAJOR) { int k = sgi / (BN / 8), part = sgi % (BN / 8); *(u32x4*)(Wb + k * LDW + part * 8) = rw[u]; }
       else { int n = sgi / (BK / 8), part = sgi % (BK / 8); *(u32x4*)(Wb + n * LDW + part * 8) = rw[u]; }
     }
@@ -237,13 +250,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
     }
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool WK>
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool WK, int BK = 64>
 static int launch_igemm_fwd(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev,
                             int n_out_cap, int cin, int cout, int kvol, hipStream_t s, const float* bias = nullptr, int relu = 0) {
-  constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, BK = 64;
+  constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
   constexpr int LDA = BK + 8, LDW = WK ? BN + 16 : BK + 8;
   constexpr size_t lds = 2 * (size_t)(BM * LDA + (WK ? BK * LDW : BN * LDW)) * 2;
-  auto kern = k_igemm_fwd<WAVES_M, WAVES_N, WM, WN, WK>;
+  auto kern = k_igemm_fwd<WAVES_M, WAVES_N, WM, WN, WK, BK>;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
@@ -782,6 +795,23 @@ extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32
                                       const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
                                       int32_t transpose_w, u3d_stream s) {
   U3D_REQUIRE(in && w && out && n_out_dev && (nbr || kvol == 1), U3D_ERR_ARG);
+#if IGEMM_SMALL_C
+  // 16/32-channel sparse levels (and the 32<->64 transitions): 256-row tiles, one MFMA k-step per stage (BK = 32), the same
+  // register-staged, software-pipelined loop as the wide layers - the first-generation kernel it replaces does
+  // "indices -> barrier -> gather -> barrier -> MFMA -> barrier" per offset with nothing in flight across the barriers
+  if (n_out_cap > 0 && cin % 16 == 0 && cout % 16 == 0 && cin <= 64 && cout <= 64 && (cin < 64 || cout < 64)) {
+#define IG_SMALL(WNV, BKV)                                                                                                          \
+    return transpose_w ? launch_igemm_fwd<4, 1, 4, WNV, false, BKV>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s)   \
+                       : launch_igemm_fwd<4, 1, 4, WNV, true, BKV>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
+    // (cin = 64 -> cout 32/16, the dgrad of the 32->64 transition, measured slower here than on the first-generation kernel: 212 vs 170 us)
+    if (cin == 16 || cin == 32) {
+      if (cout == 16) { IG_SMALL(1, 32) }
+      if (cout == 32) { IG_SMALL(2, 32) }
+      if (cout == 64) { IG_SMALL(4, 32) }
+    }
+#undef IG_SMALL
+  }
+#endif
   if (cin % 64 != 0 || cout % 8 != 0 || cout < 64) return U3D_ERR_UNSUPPORTED;
   if (n_out_cap <= 0) return U3D_OK;
 #define IG_CASE(A, B, C, D)                                                                                                  \
