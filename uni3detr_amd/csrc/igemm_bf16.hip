@@ -1235,16 +1235,32 @@ __global__ void k_igemm_wgrad_reduce(const float* __restrict__ partial, float* _
 #endif
 // same reduction, result written as [Cout][Cin][K] (nn.Conv3d's checkpoint layout): the gradient lands in the parameter's own
 // layout and autograd keeps it as is (a permuted view would be cloned into a contiguous tensor by AccumulateGrad: one more launch)
-__global__ void k_igemm_wgrad_reduce_oik(const float* __restrict__ partial, float* __restrict__ dw, long long n, int nsplit, int kvol,
-                                         int cin, int cout) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += partial[(long long)k * n + i];
-  const int co = (int)(i % cout);
-  const long long r = i / cout;
-  const int ci = (int)(r % cin), kap = (int)(r / cin);
-  dw[((long long)co * cin + ci) * kvol + kap] = s;
+__global__ __launch_bounds__(256) void k_igemm_wgrad_reduce_oik(const float* __restrict__ partial, float* __restrict__ dw, long long n,
+                                                                int nsplit, int kvol, int cin, int cout) {
+  // workgroup = (ci, 64 output channels, a third of the offsets): reads run along co (coalesced; splits summed in a fixed order), the
+  // [co][k] tile is turned in LDS, writes run along k (the innermost dimension of [Cout][Cin][K])
+  __shared__ float tile[64][10];
+  const int ci = blockIdx.x, co0 = blockIdx.y * 64;
+  const int kper = (kvol + gridDim.z - 1) / gridDim.z, k0 = blockIdx.z * kper, k1 = min(kvol, k0 + kper);
+  const int t = threadIdx.x, col = t & 63;
+  for (int k = k0 + (t >> 6); k < k1; k += 4) {
+    float s = 0.f;
+    if (co0 + col < cout) {
+      const float* p = partial + ((long long)k * cin + ci) * cout + co0 + col;
+      float s0 = 0.f, s1 = 0.f;
+      int sp = 0;
+      for (; sp + 1 < nsplit; sp += 2) { s0 += p[(long long)sp * n]; s1 += p[(long long)(sp + 1) * n]; }
+      if (sp < nsplit) s0 += p[(long long)sp * n];
+      s = s0 + s1;
+    }
+    tile[col][k - k0] = s;
+  }
+  __syncthreads();
+  const int nk = k1 - k0;
+  for (int idx = t; idx < 64 * nk; idx += 256) {
+    const int cl = idx / nk, k = idx % nk;
+    if (co0 + cl < cout) dw[((long long)(co0 + cl) * cin + ci) * kvol + k0 + k] = tile[cl][k];
+  }
 }
 
 struct WgPlan { int tile; int ci_blocks, co_blocks, nsplit; };
@@ -1338,8 +1354,9 @@ extern "C" int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const 
   else if (p.tile == 32) rc = launch_igemm_wgrad<2, 2, 1, 1>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
   else rc = launch_igemm_wgrad<1, 1, 1, 1>(in, dout, nbr, ld, (float*)workspace, n_out_dev, n_out_cap, cin, cout, kvol, p, s);
   if (rc != U3D_OK) return rc;
+  if (out_layout == 1 && kvol > 27) return U3D_ERR_UNSUPPORTED;
   if (out_layout == 1)
-    hipLaunchKernelGGL(k_igemm_wgrad_reduce_oik, dim3(u3d_cdiv(n, 256)), dim3(256), 0, s, (const float*)workspace, dw, n, p.nsplit, kvol, cin, cout);
+    hipLaunchKernelGGL(k_igemm_wgrad_reduce_oik, dim3(cin, u3d_cdiv(cout, 64), kvol > 9 ? 3 : 1), dim3(256), 0, s, (const float*)workspace, dw, n, p.nsplit, kvol, cin, cout);
   else
     hipLaunchKernelGGL(k_igemm_wgrad_reduce, dim3(u3d_cdiv(n / 4, 256)), dim3(256), 0, s, (const float*)workspace, dw, n, p.nsplit);
   U3D_CHECK_LAUNCH();
