@@ -190,6 +190,11 @@ int64_t u3d_colsum_batched_workspace(int32_t count, int32_t n, int32_t c);
 int32_t u3d_colsum_batched(const void* const* x, float* const* out, int32_t count, int32_t n, int32_t c, int32_t dtype,
                            void* workspace, int64_t workspace_bytes, u3d_stream s);
 
+/* Weight gradient of a linear layer with <= 16 input or output features (bf16 dy [m, n], x [m, k]): partial f32
+ * [u3d_skinny_wgrad_chunks(m)][n*k]; the column sums over the chunks are dW [n][k] (u3d_colsum / u3d_colsum_batched). */
+int32_t u3d_skinny_wgrad_chunks(int32_t m);
+int32_t u3d_skinny_wgrad_bf16(const void* dy, const void* x, int32_t m, int32_t n, int32_t k, float* partial, u3d_stream s);
+
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm1d over sparse rows [n, C] (training statistics) with optional residual add and ReLU
  * (ref: sparse_encoder_hd.py:40; upstream make_sparse_convmodule / SparseBasicBlock).

@@ -912,3 +912,56 @@ extern "C" int32_t u3d_layernorm_bwd(const void* dy, int32_t y_dtype, const void
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// "Skinny" weight gradient of a linear layer whose input OR output has <= 16 features (the heads' final 256 -> 10 / 8 / 1 layers,
+// the position encoder's 3 -> 256): dW[n][k] = sum_m dy[m][n] * x[m][k].  hipBLASLt runs these [n x 7200] x [7200 x k] products
+// at 20-50 us; here one thread owns one element of the WIDE dimension and keeps the <= 16 accumulators of the skinny one, a
+// workgroup covers SK_ROWS rows -> partial f32 [chunks][n*k]; the caller column-sums the chunks (u3d_colsum / u3d_colsum_batched).
+// ---------------------------------------------------------------------------------------------
+#define SK_ROWS 128
+#define SK_MAX 16
+template <bool DY_SKINNY>
+__global__ __launch_bounds__(256) void k_skinny_wgrad(const u16* __restrict__ dy, const u16* __restrict__ x, int m, int n, int k,
+                                                      float* __restrict__ partial) {
+  // DY_SKINNY: n <= 16, thread = column of x (k wide);  else k <= 16, thread = column of dy (n wide)
+  const int wide = DY_SKINNY ? k : n, small = DY_SKINNY ? n : k;
+  const int col = blockIdx.y * 256 + threadIdx.x;
+  const int r0 = blockIdx.x * SK_ROWS, r1 = min(m, r0 + SK_ROWS);
+  __shared__ float sk[SK_ROWS][SK_MAX];                 // the skinny operand of this row chunk
+  const u16* skp = DY_SKINNY ? dy : x;
+  for (int i = threadIdx.x; i < (r1 - r0) * small; i += 256) {
+    const int rr = i / small, s = i % small;
+    sk[rr][s] = ld_elem(skp, (long long)(r0 + rr) * small + s);
+  }
+  __syncthreads();
+  float acc[SK_MAX];
+#pragma unroll
+  for (int s = 0; s < SK_MAX; ++s) acc[s] = 0.f;
+  if (col < wide) {
+    const u16* wp = DY_SKINNY ? x : dy;
+    for (int r = r0; r < r1; ++r) {
+      const float v = ld_elem(wp, (long long)r * wide + col);
+#pragma unroll
+      for (int s = 0; s < SK_MAX; ++s)
+        if (s < small) acc[s] += sk[r - r0][s] * v;
+    }
+    float* p = partial + (long long)blockIdx.x * n * k;
+#pragma unroll
+    for (int s = 0; s < SK_MAX; ++s)
+      if (s < small) {
+        if (DY_SKINNY) p[(long long)s * k + col] = acc[s];      // dW[n = s][k = col]
+        else p[(long long)col * k + s] = acc[s];                // dW[n = col][k = s]
+      }
+  }
+}
+extern "C" int32_t u3d_skinny_wgrad_chunks(int32_t m) { return u3d_cdiv(m > 0 ? m : 1, SK_ROWS); }
+extern "C" int32_t u3d_skinny_wgrad_bf16(const void* dy, const void* x, int32_t m, int32_t n, int32_t k, float* partial, u3d_stream s) {
+  U3D_REQUIRE(dy && x && partial && m > 0 && n > 0 && k > 0, U3D_ERR_ARG);
+  if (n > SK_MAX && k > SK_MAX) return U3D_ERR_UNSUPPORTED;
+  const int chunks = u3d_skinny_wgrad_chunks(m);
+  if (n <= SK_MAX) hipLaunchKernelGGL(k_skinny_wgrad<true>, dim3(chunks, u3d_cdiv(k, 256)), dim3(256), 0, s, (const u16*)dy, (const u16*)x, m, n, k, partial);
+  else hipLaunchKernelGGL(k_skinny_wgrad<false>, dim3(chunks, u3d_cdiv(n, 256)), dim3(256), 0, s, (const u16*)dy, (const u16*)x, m, n, k, partial);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}

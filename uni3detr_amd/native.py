@@ -81,6 +81,8 @@ _SIGS = {
     "u3d_tap_gather_sum": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "u3d_wgrad_batched_workspace": (_L, [_I, _I, _I, _I]),
     "u3d_wgrad_batched_bf16": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _L, _P]),
+    "u3d_skinny_wgrad_chunks": (_I, [_I]),
+    "u3d_skinny_wgrad_bf16": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "u3d_colsum_batched_workspace": (_L, [_I, _I, _I]),
     "u3d_colsum_batched": (_I, [_P, _P, _I, _I, _I, _I, _P, _L, _P]),
     "u3d_layernorm_blocks": (_I, [_I]),
@@ -687,3 +689,13 @@ def det_loss_bwd(cls, box, iou_logit, tgt, lab, w, iou_true, cls_avg, npos, code
                                   _ptr(npos), _ptr(code_w), _ptr(gout), L, m, c, code, tdim, alpha, w_cls, w_box, w_iou, eps, _ptr(dcls),
                                   _ptr(dbox), _ptr(diou), _stream()), "det_loss_bwd")
     return dcls, dbox, diou
+
+
+def skinny_wgrad_partial(dy2, x2):
+    """bf16 dy2 [m, n], x2 [m, k] with min(n, k) <= 16 -> f32 [chunks, n*k] whose column sums are dW [n, k]."""
+    m, n = dy2.shape
+    k = x2.shape[1]
+    chunks = int(lib().u3d_skinny_wgrad_chunks(m))
+    partial = torch.empty((chunks, n * k), dtype=torch.float32, device=dy2.device)
+    _check(lib().u3d_skinny_wgrad_bf16(_ptr(dy2), _ptr(x2), m, n, k, _ptr(partial), _stream()), "skinny_wgrad_bf16")
+    return partial

@@ -126,10 +126,10 @@ def flush_deferred():
     items, _Deferred.items = _Deferred.items, []
     sums, _Deferred.sum_items = _Deferred.sum_items, []
     groups, bgroups = {}, {}
-    for mat, param in sums:                   # column sums of a [rows, C] f32 matrix into param.grad (LayerNorm dgamma / dbeta)
-        if param.grad is None or param.grad.dtype != torch.float32:
-            raise RuntimeError("deferred column sum: no f32 .grad to write into")
-        bgroups.setdefault((mat.shape[0], mat.shape[1], "f32"), []).append((mat, param.grad))
+    for mat, param in sums:                   # column sums of a [rows, C] matrix into param.grad (LayerNorm dgamma / dbeta, skinny dW / db)
+        if param.grad is None or param.grad.dtype != torch.float32 or not param.grad.is_contiguous() or param.grad.numel() != mat.shape[1]:
+            raise RuntimeError("deferred column sum: no matching contiguous f32 .grad to write into")
+        bgroups.setdefault((mat.shape[0], mat.shape[1], str(mat.dtype)), []).append((mat, param.grad))
     for dy2, x2, wid, r0, r1, has_bias in items:
         w, b = _Deferred.params[wid]
         if w.grad is None or w.grad.dtype != torch.float32 or not w.grad.is_contiguous():
@@ -174,6 +174,22 @@ def _linear_backward(dy2, x2, wc, need_dx, need_dw, need_db, xdtype, defer=None,
         _Deferred.items.append((dy2, x2.contiguous(), defer[0], defer[1], defer[2], bool(need_db)))
         dw = dw_out if dw_out is not None else torch.empty((n, k), dtype=torch.float32, device=dy2.device)     # placeholder
         db = (db_out if db_out is not None else torch.empty((n,), dtype=torch.float32, device=dy2.device)) if need_db else None
+        return dx, dw, db
+    if need_dw and bf16 and OWN_WGRAD and SKINNY_WGRAD and m > 0 and min(n, k) <= 16 and (dw_out is None and db_out is None):
+        # skinny product (heads' final layers, position encoder input): own kernel -> per-chunk partials; the sums are deferred
+        # (batched with the LayerNorm parameter sums) when possible
+        partial = nv.skinny_wgrad_partial(dy2, x2.contiguous())
+        if defer is not None and defer[1] == 0 and defer[2] == n:
+            w_, b_ = _Deferred.params[defer[0]]
+            _Deferred.sum_items.append((partial, w_))
+            dw = torch.empty((n, k), dtype=torch.float32, device=dy2.device)
+            if need_db:
+                _Deferred.sum_items.append((dy2, b_))
+                db = torch.empty((n,), dtype=torch.float32, device=dy2.device)
+            return dx, dw, db
+        dw = nv.colsum(partial).view(n, k)
+        if need_db:
+            db = nv.colsum(dy2)
         return dx, dw, db
     if need_dw:
         if bf16 and OWN_WGRAD and n % 16 == 0 and k % 16 == 0 and m > 0:
@@ -266,6 +282,9 @@ FAST_LINEAR = _os.environ.get("U3D_FAST_LINEAR", "0") == "1"      # opt-in: meas
 SAFE_LINEAR = _os.environ.get("U3D_UNSAFE_LINEAR", "0") != "1"      # test hook: "1" restores torch's own Linear backward
 LINEAR_BWD_TORCH = _os.environ.get("U3D_LINEAR_BWD_TORCH", "0") == "1"
 OWN_WGRAD = _os.environ.get("U3D_OWN_WGRAD", "1") == "1"          # dW of the decoder/head linears on u3d_igemm_wgrad_bf16
+# dW of the <= 16-feature linears on u3d_skinny_wgrad_bf16: correct (tests) but measured SLOWER end to end than hipBLASLt's
+# small products (30.3 vs 29.7 ms per step: 57 workgroups per launch) - opt-in until the kernel splits the wide dimension too
+SKINNY_WGRAD = _os.environ.get("U3D_SKINNY_WGRAD", "0") == "1"
 
 
 def _autocast_dtype(x):
