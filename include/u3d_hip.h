@@ -217,20 +217,25 @@ int32_t u3d_bn_forward_stats(const void* x, const int32_t* n_dev, int32_t n_cap,
 int32_t u3d_bn_finalize_partials(const double* partial, int32_t nblocks, int32_t rows_per_block, const int32_t* n_dev,
                                  int32_t n_cap, int32_t c, float eps, float momentum, float* running_mean, float* running_var,
                                  int64_t* num_batches, float* mean, float* invstd, u3d_stream s);
-/* y = relu?( (x-mean)*invstd*gamma + beta (+ residual) ); mean/invstd/gamma/beta f32 [C]. */
+/* y = relu?( (x-mean)*invstd*gamma + beta (+ residual) ); mean/invstd/gamma/beta f32 [C].
+ * row_map (nullable; all three functions): y / dy are stored in a permuted row order, row r of x <-> row row_map[r] of y / dy
+ * (a bijection of [0, n)).  The (1,s,s)/(1,s,s) transposed convolutions of the FPN (ref: second3d_fpn.py:60-75) produce their
+ * rows tap-major; their BatchNorm writes the lattice order directly instead of a separate row gather.  Requires no residual /
+ * dres and C % 8 == 0 (bf16) or C % 4 == 0 (f32). */
 int32_t u3d_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, const void* residual, int32_t relu, void* y,
-                     const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, u3d_stream s);
+                     const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, const int32_t* row_map, u3d_stream s);
 /* backward: given dy (grad wrt y), y (for relu mask), x: sums f64 [2*C] = (sum g, sum g*xhat) where
  * g = dy * (y>0 if relu).  y may be NULL when relu is set and the forward had NO residual: the mask is then recomputed as
  * (x-mean)*invstd*gamma+beta > 0 (the forward's own expression; gamma/beta required) - one tensor less to stream. */
 int32_t u3d_bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, int32_t relu, const int32_t* n_dev, int32_t n_cap,
-                         int32_t c, int32_t dtype, double* sums, void* workspace, int64_t workspace_bytes, u3d_stream s);
+                         int32_t c, int32_t dtype, double* sums, void* workspace, int64_t workspace_bytes,
+                         const int32_t* row_map, u3d_stream s);
 /* dx = gamma*invstd*( g - sum_g/n - xhat*sum_gx/n ); dres = g (optional, may be NULL).  y NULL: as above (beta required). */
 int32_t u3d_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, const double* sums, int32_t relu, void* dx, void* dres,
-                         const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, u3d_stream s);
+                         const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, const int32_t* row_map, u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * SparseConvTensor.dense() (ref: sparse_encoder_hd.py:133): rows -> channels-last dense volume

@@ -266,6 +266,47 @@ def test_bn_fwd_bwd(cuda, c, relu, res):
         assert dresb.dtype == torch.bfloat16
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c", [64, 256])
+def test_bn_mapped_row_order_equals_gather_then_bn(cuda, c, dtype):
+    """row_map (u3d_bn_apply / _bwd_stats / _bwd_apply): BatchNorm that writes row r of x to row row_map[r] of y == a row gather
+    followed by BatchNorm, forward and backward, bit for bit in the outputs (same per-row arithmetic; the f64 column sums only
+    differ in summation order)."""
+    from uni3detr_amd import sparse as sp
+    torch.manual_seed(c)
+    n = 4096 + 128
+    x = (torch.randn(n, c, device=cuda) * 1.5 + 0.3).to(dtype)
+    perm = torch.randperm(n, device=cuda)                     # idx: output row -> source row
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n, device=cuda)
+    idx32, inv32 = perm.int().contiguous(), inv.int().contiguous()
+    nd = torch.tensor([n], dtype=torch.int32, device=cuda)
+    gy = torch.randn(n, c, device=cuda).to(dtype)
+    outs = []
+    for mapped in (False, True):
+        torch.manual_seed(1)                                      # same affine parameters in both runs
+        bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(cuda).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(c, device=cuda) + 0.5); bn.bias.copy_(torch.randn(c, device=cuda) * 0.1)
+        xr = x.clone().requires_grad_(True)
+        if mapped:
+            y = sp.bn_rows(xr, bn, nd, None, True, row_map=inv32)
+            y.backward(gy)
+            dx = xr.grad
+        else:
+            xg = nv.gather_rows(x, idx32).requires_grad_(True)
+            y = sp.bn_rows(xg, bn, nd, None, True)
+            y.backward(gy)
+            dx = nv.gather_rows(xg.grad, inv32)               # back to the source row order
+        outs.append((y.detach(), dx, bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone()))
+    (y0, dx0, gw0, gb0, rm0, rv0), (y1, dx1, gw1, gb1, rm1, rv1) = outs
+    assert torch.allclose(rm0, rm1, rtol=1e-6, atol=1e-7) and torch.allclose(rv0, rv1, rtol=1e-6, atol=1e-7)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert (y0.float() - y1.float()).abs().max().item() <= tol * max(1.0, y0.float().abs().max().item())
+    assert (dx0.float() - dx1.float()).abs().max().item() <= tol * max(1.0, dx0.float().abs().max().item())
+    assert torch.allclose(gw0, gw1, rtol=1e-4, atol=1e-3) and torch.allclose(gb0, gb1, rtol=1e-4, atol=1e-3)
+
+
 def test_dense_roundtrip(cuda):
     rc = _level0(cuda, 2, 1500)
     dims = (15, 40, 40)

@@ -45,7 +45,8 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void k_col_stats_vec(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                                       const int* __restrict__ n_dev, int n_cap, int c, double* __restrict__ partial) {
+                                                       const int* __restrict__ n_dev, int n_cap, int c, double* __restrict__ partial,
+                                                       const int* __restrict__ row_map) {
   constexpr int V = VecOf<T>::N;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* red = (double*)smem_raw;                 // [2][rl][cw*V] laid out as [which][rowlane][col]
@@ -83,8 +84,9 @@ __global__ __launch_bounds__(256) void k_col_stats_vec(const T* __restrict__ x, 
           for (int e = 0; e < V; ++e) { s0[e] += xv[e]; s1[e] += xv[e] * xv[e]; }
         } else {
           float gv[V], yv[V];
-          load_vec<T>(dy + o, gv);
-          if (relu && !remask) load_vec<T>(y + o, yv);
+          const long long oy = row_map ? (long long)row_map[r] * c + (long long)vc * V : o;   // y / dy live in the mapped row order
+          load_vec<T>(dy + oy, gv);
+          if (relu && !remask) load_vec<T>(y + oy, yv);
 #pragma unroll
           for (int e = 0; e < V; ++e) {
             float g = gv[e];
@@ -189,8 +191,10 @@ extern "C" int64_t u3d_bn_stats_workspace(int32_t n_cap, int32_t c) {
 
 template <int MODE>
 static int run_stats(const void* x, const void* dy, const void* y, const float* mean, const float* invstd, const float* gamma,
-                     const float* beta, int relu, const int32_t* n_dev, int n_cap, int c, int dtype, double* sums, void* ws, int64_t ws_bytes, hipStream_t s) {
+                     const float* beta, int relu, const int32_t* n_dev, int n_cap, int c, int dtype, double* sums, void* ws, int64_t ws_bytes, hipStream_t s,
+                     const int32_t* row_map = nullptr) {
   U3D_REQUIRE(x && n_dev && sums && ws && c > 0, U3D_ERR_ARG);
+  U3D_REQUIRE(!row_map || (dtype == U3D_F32 ? c % 4 == 0 : c % 8 == 0), U3D_ERR_UNSUPPORTED);   // mapped rows: vector kernels only
   if (n_cap <= 0) { hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, s); return U3D_OK; }
   U3D_REQUIRE(ws_bytes >= u3d_bn_stats_workspace(n_cap, c), U3D_ERR_WORKSPACE);
   int nb = u3d_cdiv(n_cap, ST_ROWS_PER_BLOCK);
@@ -198,7 +202,7 @@ static int run_stats(const void* x, const void* dy, const void* y, const float* 
     if (c % 4 == 0) {
       int cw = (c / 4) < 256 ? (c / 4) : 256; int rl = 256 / cw;
       size_t lds = (size_t)2 * rl * cw * 4 * sizeof(double);
-      hipLaunchKernelGGL((k_col_stats_vec<float, MODE>), dim3(nb), dim3(256), lds, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws);
+      hipLaunchKernelGGL((k_col_stats_vec<float, MODE>), dim3(nb), dim3(256), lds, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws, row_map);
     } else {
       hipLaunchKernelGGL((k_col_stats<float, MODE>), dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws);
     }
@@ -206,7 +210,7 @@ static int run_stats(const void* x, const void* dy, const void* y, const float* 
     if (c % 8 == 0) {
       int cw = (c / 8) < 256 ? (c / 8) : 256; int rl = 256 / cw;
       size_t lds = (size_t)2 * rl * cw * 8 * sizeof(double);
-      hipLaunchKernelGGL((k_col_stats_vec<u16, MODE>), dim3(nb), dim3(256), lds, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws);
+      hipLaunchKernelGGL((k_col_stats_vec<u16, MODE>), dim3(nb), dim3(256), lds, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws, row_map);
     } else {
       hipLaunchKernelGGL((k_col_stats<u16, MODE>), dim3(nb), dim3(256), 0, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws);
     }
@@ -222,9 +226,10 @@ extern "C" int32_t u3d_bn_stats(const void* x, const int32_t* n_dev, int32_t n_c
 }
 extern "C" int32_t u3d_bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                                     const float* gamma, const float* beta, int32_t relu, const int32_t* n_dev, int32_t n_cap,
-                                    int32_t c, int32_t dtype, double* sums, void* workspace, int64_t workspace_bytes, u3d_stream s) {
+                                    int32_t c, int32_t dtype, double* sums, void* workspace, int64_t workspace_bytes,
+                                    const int32_t* row_map, u3d_stream s) {
   U3D_REQUIRE(dy && mean && invstd && (!relu || y || (gamma && beta)), U3D_ERR_ARG);
-  return run_stats<1>(x, dy, y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, dtype, sums, workspace, workspace_bytes, s);
+  return run_stats<1>(x, dy, y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, dtype, sums, workspace, workspace_bytes, s, row_map);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -491,8 +496,8 @@ extern "C" int32_t u3d_bn_forward_stats(const void* x, const int32_t* n_dev, int
     if (c % v == 0) {
       int cw = (c / v) < 256 ? (c / v) : 256; int rl = 256 / cw;
       size_t lds = (size_t)2 * rl * cw * v * sizeof(double);
-      if (f32) hipLaunchKernelGGL((k_col_stats_vec<float, 0>), dim3(nb), dim3(256), lds, s, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace);
-      else hipLaunchKernelGGL((k_col_stats_vec<u16, 0>), dim3(nb), dim3(256), lds, s, (const u16*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace);
+      if (f32) hipLaunchKernelGGL((k_col_stats_vec<float, 0>), dim3(nb), dim3(256), lds, s, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace, (const int*)nullptr);
+      else hipLaunchKernelGGL((k_col_stats_vec<u16, 0>), dim3(nb), dim3(256), lds, s, (const u16*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace, (const int*)nullptr);
     } else {
       if (f32) hipLaunchKernelGGL((k_col_stats<float, 0>), dim3(nb), dim3(256), 0, s, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace);
       else hipLaunchKernelGGL((k_col_stats<u16, 0>), dim3(nb), dim3(256), 0, s, (const u16*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace);
@@ -533,7 +538,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_bn_apply_vec(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const T* __restrict__ res, int relu, T* __restrict__ y,
-                                                      const int* __restrict__ n_dev, int n_cap, int c) {
+                                                      const int* __restrict__ n_dev, int n_cap, int c, const int* __restrict__ row_map) {
   constexpr int V = VecOf<T>::N;
   const int n = min(*n_dev, n_cap), cv = c / V, rpb = 256 / cv;
   const int vc = threadIdx.x % cv, rl = threadIdx.x / cv;
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(256) void k_bn_apply_vec(const T* __restrict__ x, c
       if (relu) v = v > 0.f ? v : 0.f;
       out[e] = v;
     }
-    store_vec<T>(y + o, out);
+    store_vec<T>(row_map ? y + (long long)row_map[r] * c + (long long)vc * V : y + o, out);
   }
 }
 
@@ -561,7 +566,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_vec(const T* __restrict__ 
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const double* __restrict__ sums, int relu, T* __restrict__ dx,
-                                                          T* __restrict__ dres, const int* __restrict__ n_dev, int n_cap, int c) {
+                                                          T* __restrict__ dres, const int* __restrict__ n_dev, int n_cap, int c,
+                                                          const int* __restrict__ row_map) {
   constexpr int V = VecOf<T>::N;
   const int n = min(*n_dev, n_cap), cv = c / V, rpb = 256 / cv;
   const int vc = threadIdx.x % cv, rl = threadIdx.x / cv;
@@ -578,9 +584,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_vec(const T* __restrict__ 
   for (int r = blockIdx.x * rpb + rl; r < n; r += gridDim.x * rpb) {
     const long long o = (long long)r * c + (long long)vc * V;
     float gv[V], xv[V], yv[V], dxv[V];
-    load_vec<T>(dy + o, gv);
+    const long long oy = row_map ? (long long)row_map[r] * c + (long long)vc * V : o;
+    load_vec<T>(dy + oy, gv);
     load_vec<T>(x + o, xv);
-    if (relu && !remask) load_vec<T>(y + o, yv);
+    if (relu && !remask) load_vec<T>(y + oy, yv);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       float g = gv[e];
@@ -609,14 +616,15 @@ static inline int ew_grid(long long total) {
 
 extern "C" int32_t u3d_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                 const void* residual, int32_t relu, void* y, const int32_t* n_dev, int32_t n_cap, int32_t c,
-                                int32_t dtype, u3d_stream s) {
+                                int32_t dtype, const int32_t* row_map, u3d_stream s) {
   U3D_REQUIRE(x && mean && invstd && gamma && beta && y && n_dev && c > 0, U3D_ERR_ARG);
+  U3D_REQUIRE(!row_map || (!residual && bn_vec_ok(c, dtype == U3D_F32 ? 4 : 8)), U3D_ERR_UNSUPPORTED);
   if (n_cap <= 0) return U3D_OK;
   int g = ew_grid((long long)n_cap * c);
   if (dtype == U3D_F32 && bn_vec_ok(c, 4))
-    hipLaunchKernelGGL(k_bn_apply_vec<float>, dim3(bn_vec_grid(n_cap, c, 4)), dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const float*)residual, relu, (float*)y, n_dev, n_cap, c);
+    hipLaunchKernelGGL(k_bn_apply_vec<float>, dim3(bn_vec_grid(n_cap, c, 4)), dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const float*)residual, relu, (float*)y, n_dev, n_cap, c, row_map);
   else if (dtype == U3D_BF16 && bn_vec_ok(c, 8))
-    hipLaunchKernelGGL(k_bn_apply_vec<u16>, dim3(bn_vec_grid(n_cap, c, 8)), dim3(256), 0, s, (const u16*)x, mean, invstd, gamma, beta, (const u16*)residual, relu, (u16*)y, n_dev, n_cap, c);
+    hipLaunchKernelGGL(k_bn_apply_vec<u16>, dim3(bn_vec_grid(n_cap, c, 8)), dim3(256), 0, s, (const u16*)x, mean, invstd, gamma, beta, (const u16*)residual, relu, (u16*)y, n_dev, n_cap, c, row_map);
   else if (dtype == U3D_F32)
     hipLaunchKernelGGL(k_bn_apply<float>, dim3(g), dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const float*)residual, relu, (float*)y, n_dev, n_cap, c);
   else if (dtype == U3D_BF16)
@@ -628,14 +636,15 @@ extern "C" int32_t u3d_bn_apply(const void* x, const float* mean, const float* i
 
 extern "C" int32_t u3d_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                                     const float* gamma, const float* beta, const double* sums, int32_t relu, void* dx, void* dres,
-                                    const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, u3d_stream s) {
+                                    const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, const int32_t* row_map, u3d_stream s) {
   U3D_REQUIRE(dy && x && mean && invstd && gamma && sums && dx && n_dev && c > 0 && (!relu || y || beta), U3D_ERR_ARG);
+  U3D_REQUIRE(!row_map || (!dres && bn_vec_ok(c, dtype == U3D_F32 ? 4 : 8)), U3D_ERR_UNSUPPORTED);
   if (n_cap <= 0) return U3D_OK;
   int g = ew_grid((long long)n_cap * c);
   if (dtype == U3D_F32 && bn_vec_ok(c, 4))
-    hipLaunchKernelGGL(k_bn_bwd_apply_vec<float>, dim3(bn_vec_grid(n_cap, c, 4)), dim3(256), 0, s, (const float*)dy, (const float*)y, (const float*)x, mean, invstd, gamma, beta, sums, relu, (float*)dx, (float*)dres, n_dev, n_cap, c);
+    hipLaunchKernelGGL(k_bn_bwd_apply_vec<float>, dim3(bn_vec_grid(n_cap, c, 4)), dim3(256), 0, s, (const float*)dy, (const float*)y, (const float*)x, mean, invstd, gamma, beta, sums, relu, (float*)dx, (float*)dres, n_dev, n_cap, c, row_map);
   else if (dtype == U3D_BF16 && bn_vec_ok(c, 8))
-    hipLaunchKernelGGL(k_bn_bwd_apply_vec<u16>, dim3(bn_vec_grid(n_cap, c, 8)), dim3(256), 0, s, (const u16*)dy, (const u16*)y, (const u16*)x, mean, invstd, gamma, beta, sums, relu, (u16*)dx, (u16*)dres, n_dev, n_cap, c);
+    hipLaunchKernelGGL(k_bn_bwd_apply_vec<u16>, dim3(bn_vec_grid(n_cap, c, 8)), dim3(256), 0, s, (const u16*)dy, (const u16*)y, (const u16*)x, mean, invstd, gamma, beta, sums, relu, (u16*)dx, (u16*)dres, n_dev, n_cap, c, row_map);
   else if (dtype == U3D_F32)
     hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(256), 0, s, (const float*)dy, (const float*)y, (const float*)x, mean, invstd, gamma, beta, sums, relu, (float*)dx, (float*)dres, n_dev, n_cap, c);
   else if (dtype == U3D_BF16)

@@ -421,31 +421,32 @@ def bn_forward_stats(x, n_dev, eps, momentum, running_mean=None, running_var=Non
     return mean, invstd
 
 
-def bn_apply(x, mean, invstd, gamma, beta, residual, relu, n_dev):
+def bn_apply(x, mean, invstd, gamma, beta, residual, relu, n_dev, row_map=None):
+    """row_map (int32 [n], a bijection): row r of x lands in row row_map[r] of y (see include/u3d_hip.h)."""
     n, c = x.shape
     y = torch.empty_like(x)
     _check(lib().u3d_bn_apply(_ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(residual), int(relu),
-                              _ptr(y), _ptr(n_dev), n, c, dtype_code(x), _stream()), "bn_apply")
+                              _ptr(y), _ptr(n_dev), n, c, dtype_code(x), _ptr(row_map), _stream()), "bn_apply")
     return y
 
 
-def bn_bwd_stats(dy, y, x, mean, invstd, relu, n_dev, gamma=None, beta=None):
+def bn_bwd_stats(dy, y, x, mean, invstd, relu, n_dev, gamma=None, beta=None, row_map=None):
     """y may be None (relu, no residual in the forward): the ReLU mask is recomputed from x with gamma/beta."""
     n, c = x.shape
     sums = torch.empty((2, c), dtype=torch.float64, device=x.device)
     wsb = int(lib().u3d_bn_stats_workspace(n, c))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
     _check(lib().u3d_bn_bwd_stats(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), int(relu), _ptr(n_dev), n, c,
-                                  dtype_code(x), _ptr(sums), _ptr(ws), wsb, _stream()), "bn_bwd_stats")
+                                  dtype_code(x), _ptr(sums), _ptr(ws), wsb, _ptr(row_map), _stream()), "bn_bwd_stats")
     return sums
 
 
-def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, relu, n_dev, want_dres, beta=None):
+def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, relu, n_dev, want_dres, beta=None, row_map=None):
     n, c = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     _check(lib().u3d_bn_bwd_apply(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(sums), int(relu),
-                                  _ptr(dx), _ptr(dres), _ptr(n_dev), n, c, dtype_code(x), _stream()), "bn_bwd_apply")
+                                  _ptr(dx), _ptr(dres), _ptr(n_dev), n, c, dtype_code(x), _ptr(row_map), _stream()), "bn_bwd_apply")
     return dx, dres
 
 

@@ -8,6 +8,8 @@ kernels as the sparse encoder, over channels-last rows [B*D*H*W, C] with a stati
 The nn.Conv3d / nn.BatchNorm3d modules are kept as parameter holders so that state_dict names and shapes are the
 reference checkpoints' (`blocks.{i}.{3j}.weight` [Cout,Cin,kd,kh,kw], `deblocks.{i}.0.weight`, `extra_blocks.{3j}.weight`).
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -82,6 +84,9 @@ class Lattice:
         return v
 
 
+FUSED_UPSAMPLE_ORDER = os.environ.get("U3D_FUSED_UPSAMPLE", "1") == "1"
+
+
 class _GatherBijection(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rows, idx, inv):
@@ -121,8 +126,12 @@ def deconv_bn_relu(rows, B, dims, deconv, bn):
     w = deconv.weight.permute(0, 2, 3, 4, 1).reshape(1, 1, 1, cin, s * s * cout)     # columns = (tap, cout)
     y = sp.sparse_conv(rows, w, geom).view(n_in * s * s, cout)
     idx, inv, dims_out = Lattice.upsample_index(rows.device, B, dims, s)
-    y = _GatherBijection.apply(y, idx, inv)
     n_dev = Lattice.conv(rows.device, B, dims_out, (1, 1, 1), (1, 1, 1), (0, 0, 0))[0].n_out_dev
+    if FUSED_UPSAMPLE_ORDER:
+        # the GEMM leaves the rows tap-major; BatchNorm statistics do not care about row order, and its apply kernel writes
+        # row r to its lattice position inv[r] (the backward reads dy there) - no separate gather pass over the upsampled volume
+        return sp.bn_rows(y, bn, n_dev, None, True, row_map=inv), dims_out
+    y = _GatherBijection.apply(y, idx, inv)
     return sp.bn_rows(y, bn, n_dev, None, True), dims_out
 
 

@@ -170,7 +170,7 @@ class _BNRows(torch.autograd.Function):
     """BatchNorm1d over active rows (+ residual) (+ ReLU), training or eval statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, n_dev, bn, relu, training, stats=None, tile_rows=0):
+    def forward(ctx, x, gamma, beta, residual, n_dev, bn, relu, training, stats=None, tile_rows=0, row_map=None):
         n = x.shape[0]
         if training and stats is not None:
             mean, invstd = nv.bn_finalize_partials(stats, tile_rows, n_dev, n, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
@@ -182,31 +182,33 @@ class _BNRows(torch.autograd.Function):
             mean = bn.running_mean
             invstd = torch.rsqrt(bn.running_var + bn.eps)
         g32, b32 = gamma.float(), beta.float()
-        y = nv.bn_apply(x, mean, invstd, g32, b32, residual, relu, n_dev)
+        y = nv.bn_apply(x, mean, invstd, g32, b32, residual, relu, n_dev, row_map)
         # ReLU without residual: the backward recomputes the mask from x (same expression) instead of streaming y again
         ctx.remask = bool(relu and residual is None)
         ctx.save_for_backward(x, None if ctx.remask else y, mean, invstd, g32, b32)
         ctx.n_dev, ctx.relu, ctx.training, ctx.has_res = n_dev, relu, training, residual is not None
         ctx.pdtype = gamma.dtype
+        ctx.row_map = row_map
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, mean, invstd, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
-        sums = nv.bn_bwd_stats(dy, y, x, mean, invstd, ctx.relu, ctx.n_dev, gamma, beta)
+        sums = nv.bn_bwd_stats(dy, y, x, mean, invstd, ctx.relu, ctx.n_dev, gamma, beta, ctx.row_map)
         if not ctx.training:
             # eval statistics are constants: dx = gamma*invstd*g
             zero = torch.zeros_like(sums)
-            dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, zero, ctx.relu, ctx.n_dev, ctx.has_res, beta)
+            dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, zero, ctx.relu, ctx.n_dev, ctx.has_res, beta, ctx.row_map)
         else:
-            dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, ctx.relu, ctx.n_dev, ctx.has_res, beta)
+            dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, ctx.relu, ctx.n_dev, ctx.has_res, beta, ctx.row_map)
         s32 = sums.to(ctx.pdtype)
-        return dx, s32[1], s32[0], dres, None, None, None, None, None, None
+        return dx, s32[1], s32[0], dres, None, None, None, None, None, None, None
 
 
-def bn_rows(x, bn, n_dev, residual=None, relu=True):
-    return _BNRows.apply(x, bn.weight, bn.bias, residual, n_dev, bn, relu, bn.training)
+def bn_rows(x, bn, n_dev, residual=None, relu=True, row_map=None):
+    """row_map: the output (and its gradient) use a permuted row order, y[row_map[r]] = bn(x[r]) - see u3d_bn_apply."""
+    return _BNRows.apply(x, bn.weight, bn.bias, residual, n_dev, bn, relu, bn.training, None, 0, row_map)
 
 
 class _ToDense(torch.autograd.Function):
