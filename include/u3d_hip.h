@@ -227,11 +227,12 @@ int32_t u3d_bn_apply(const void* x, const float* mean, const float* invstd, cons
                      const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, const int32_t* row_map, u3d_stream s);
 /* backward: given dy (grad wrt y), y (for relu mask), x: sums f64 [2*C] = (sum g, sum g*xhat) where
  * g = dy * (y>0 if relu).  y may be NULL when relu is set and the forward had NO residual: the mask is then recomputed as
- * (x-mean)*invstd*gamma+beta > 0 (the forward's own expression; gamma/beta required) - one tensor less to stream. */
+ * (x-mean)*invstd*gamma+beta > 0 (the forward's own expression; gamma/beta required) - one tensor less to stream.
+ * sums_f32 (nullable, f32 [2*C]): the same sums rounded to f32 = (d beta, d gamma), the parameter gradients as torch stores them. */
 int32_t u3d_bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, int32_t relu, const int32_t* n_dev, int32_t n_cap,
                          int32_t c, int32_t dtype, double* sums, void* workspace, int64_t workspace_bytes,
-                         const int32_t* row_map, u3d_stream s);
+                         const int32_t* row_map, float* sums_f32, u3d_stream s);
 /* dx = gamma*invstd*( g - sum_g/n - xhat*sum_gx/n ); dres = g (optional, may be NULL).  y NULL: as above (beta required). */
 int32_t u3d_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, const double* sums, int32_t relu, void* dx, void* dres,
@@ -350,6 +351,22 @@ int64_t u3d_adamw_workspace(int64_t n);
 int32_t u3d_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                        float beta2, float eps, float weight_decay, float max_norm, float* state, void* workspace,
                        int64_t workspace_bytes, u3d_stream s);
+
+/* bf16 shadows of the flat f32 parameter buffer, refreshed once per training step (bf16 mode; upstream has no counterpart: its
+ * fp32 run reads the parameters directly).  u3d_cast_bf16: dst[i] = bf16(src[i]) (round to nearest even), 16-byte aligned pointers.
+ * u3d_permute_bf16_batched: for every descriptor, dst[dst_off + (k*rows + r)*cols + c] = src[src_off + k*stride_k + r*stride_r +
+ * c*stride_c] for k < n/(rows*cols): the conv-weight layouts the implicit-GEMM kernels stage row-linearly, i.e. [K,Cout,Cin] from
+ * spconv's [K,Cin,Cout] and both [K,Cin,Cout] / [K,Cout,Cin] from nn.Conv3d's [Cout,Cin,K].  blocks_dev: int32 pairs (descriptor
+ * index, first element) - one per u3d_permute_block_elems() output elements; dst_off multiples of 8; descriptors in device memory. */
+typedef struct u3d_permute_desc {
+  int64_t src_off, dst_off;
+  int32_t n, rows, cols, reserved;
+  int64_t stride_k, stride_r, stride_c;
+} u3d_permute_desc;
+int32_t u3d_cast_bf16(const float* src, void* dst, int64_t n, u3d_stream s);
+int32_t u3d_permute_block_elems(void);
+int32_t u3d_permute_bf16_batched(const void* src, void* dst, const u3d_permute_desc* descs_dev, const int32_t* blocks_dev,
+                                 int32_t nblocks, u3d_stream s);
 
 #ifdef __cplusplus
 }

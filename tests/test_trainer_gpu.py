@@ -131,3 +131,31 @@ def test_flat_update_step_matches_torch_optimizer_step(cuda):
     # parameters stay addressable under their reference names / shapes after being re-homed into the flat buffer
     assert set(m2.state_dict().keys()) == set(sd.keys())
     assert all(m2.state_dict()[k].shape == sd[k].shape for k in sd)
+
+
+def test_flat_parameter_shadows_equal_per_tensor_casts(cuda):
+    """u3d_cast_bf16 + u3d_permute_bf16_batched (shadow refresh over the flat parameter buffer): every linear shadow and both conv
+    layouts ([K,Cin,Cout], [K,Cout,Cin]) of every conv weight, from both checkpoint layouts, bit-equal to the per-tensor cast."""
+    from uni3detr_amd import shadow as S
+    pts, gts, labels = _data(cuda, B=1, n=4000)
+    m = _model(cuda)
+    ts = TrainStep(m, pts, gts, labels, graph=False, flat_update=True)
+    with torch.no_grad():
+        ts.flat_param.add_(torch.randn_like(ts.flat_param) * 1e-3)          # parameters differ from what any earlier cast saw
+    with m.shadow_scope():
+        sh = m._shadows
+        assert sh.flat is ts.flat_param
+        n_lin = n_conv = 0
+        for p in sh.params:
+            assert torch.equal(S.compute_copy(p, torch.bfloat16), p.detach().to(torch.bfloat16)) and p._u3d_shadow[0].data_ptr() != p.data_ptr()
+            n_lin += 1
+        layouts = set()
+        for p in sh.conv_params:
+            layout = p._u3d_conv_shadow[3]
+            layouts.add(layout)
+            kio, koi = S.conv_weights(p, layout, torch.bfloat16)
+            kio_v, koi_v = S._conv_views(p.detach(), layout)
+            assert torch.equal(kio, kio_v.to(torch.bfloat16).reshape(kio.shape)) and torch.equal(koi, koi_v.to(torch.bfloat16).reshape(koi.shape))
+            assert kio.is_contiguous() and koi.is_contiguous()
+            n_conv += 1
+    assert n_lin > 50 and n_conv > 30 and layouts == {"dhwio", "oidhw"}

@@ -24,9 +24,36 @@ def main():
         ts.eager_step()
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack="--stack" in sys.argv) as prof:
         ts.eager_step()
         torch.cuda.synchronize()
+    if "--stack" in sys.argv:
+        # attribute every kernel-launching ATen op to the python line (forward) or the autograd node (backward) that issued it
+        agg = {}
+        for e in prof.events():
+            t = getattr(e, "self_device_time_total", 0) or 0
+            if t <= 0 or not e.name.startswith("aten::"):
+                continue
+            key = None
+            for fr in (e.stack or []):
+                if "uni3detr_amd" in fr or "projects/" in fr:
+                    key = fr.split("/root/repo/")[-1] if "/root/repo/" in fr else fr[-70:]
+                    break
+            if key is None:
+                par = e.cpu_parent
+                while par is not None:
+                    if "Backward" in par.name or "evaluate_function" in par.name:
+                        key = par.name.replace("autograd::engine::evaluate_function: ", "bwd:")
+                        break
+                    par = par.cpu_parent
+            k = (key or "?", e.name)
+            a = agg.setdefault(k, [0, 0.0])
+            a[0] += 1; a[1] += t
+        tot = sum(a[1] for a in agg.values())
+        print(f"aten ops with device time: {sum(a[0] for a in agg.values())} launches, {tot:.0f} us")
+        for (key, name), (cnt, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:110]:
+            print(f"{t:8.0f} us {cnt:4d}x  {name:28s} {key}")
+        return
     print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=50,
                                                               max_shapes_column_width=70))
 

@@ -118,3 +118,70 @@ extern "C" int32_t u3d_adamw_step(float* param, const float* grad, float* exp_av
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// bf16 shadows of the flat f32 parameter buffer (uni3detr_amd/shadow.py): one cast launch for every parameter in its own layout
+// (linears, dhwio conv weights as [K,Cin,Cout]) + one batched re-layout launch for the conv-weight layouts the GEMM kernels read
+// row-linearly (koi [K,Cout,Cin]; both layouts of nn.Conv3d's [Cout,Cin,K]).  Replaces ~140 per-tensor cast / strided-copy launches.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned short u16;
+#define SH_ELEMS_PER_BLOCK 2048                                  // 256 threads x 8 bf16 = one 16-byte store per thread
+
+__global__ __launch_bounds__(256) void k_cast_bf16_flat(const float* __restrict__ src, u16* __restrict__ dst, long long n) {
+  typedef float f32x8_t __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  for (long long o = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; o < n; o += (long long)gridDim.x * 2048) {
+    if (o + 7 < n) {
+      float4 a = *(const float4*)(src + o), b = *(const float4*)(src + o + 4);
+      f32x8_t f = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      *(bf16x8_t*)(dst + o) = __builtin_convertvector(f, bf16x8_t);
+    } else {
+      for (int e = 0; e < 8 && o + e < n; ++e) { __bf16 h = (__bf16)src[o + e]; dst[o + e] = *(u16*)&h; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_permute_bf16(const u16* __restrict__ src, u16* __restrict__ dst,
+                                                      const u3d_permute_desc* __restrict__ descs, const int2* __restrict__ blocks) {
+  const int2 b = blocks[blockIdx.x];
+  const u3d_permute_desc d = descs[b.x];
+  const int e0 = b.y + threadIdx.x * 8;
+  if (e0 >= d.n) return;
+  const int rc = d.rows * d.cols;
+  u16 v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int e = e0 + j;
+    const int k = e / rc, rem = e - k * rc, r = rem / d.cols, c = rem - r * d.cols;
+    v[j] = e < d.n ? src[d.src_off + k * d.stride_k + r * d.stride_r + c * d.stride_c] : (u16)0;
+  }
+  u16* out = dst + d.dst_off + e0;
+  if (e0 + 7 < d.n) {
+    uint4 w = {(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16), (unsigned)v[4] | ((unsigned)v[5] << 16),
+               (unsigned)v[6] | ((unsigned)v[7] << 16)};
+    *(uint4*)out = w;
+  } else {
+    for (int j = 0; j < 8 && e0 + j < d.n; ++j) out[j] = v[j];
+  }
+}
+
+extern "C" int32_t u3d_cast_bf16(const float* src, void* dst, int64_t n, u3d_stream s) {
+  U3D_REQUIRE(src && dst && n >= 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, U3D_ERR_ARG);
+  if (n == 0) return U3D_OK;
+  long long nb = (n + SH_ELEMS_PER_BLOCK - 1) / SH_ELEMS_PER_BLOCK;
+  hipLaunchKernelGGL(k_cast_bf16_flat, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, s, src, (u16*)dst, (long long)n);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+extern "C" int32_t u3d_permute_block_elems(void) { return SH_ELEMS_PER_BLOCK; }
+
+extern "C" int32_t u3d_permute_bf16_batched(const void* src, void* dst, const u3d_permute_desc* descs_dev, const int32_t* blocks_dev,
+                                            int32_t nblocks, u3d_stream s) {
+  U3D_REQUIRE(src && dst && descs_dev && blocks_dev && nblocks >= 0 && ((uintptr_t)dst & 15) == 0, U3D_ERR_ARG);
+  if (nblocks == 0) return U3D_OK;
+  hipLaunchKernelGGL(k_permute_bf16, dim3(nblocks), dim3(256), 0, s, (const u16*)src, (u16*)dst, descs_dev, (const int2*)blocks_dev);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_col_stats(const T* __restrict__ x, cons
 
 // stage 2: 64 threads per output column-value cooperate over the blocks (fixed tree order -> deterministic)
 __global__ __launch_bounds__(256) void k_col_stats_final(const double* __restrict__ partial, int nblocks, const int* __restrict__ n_dev,
-                                                         int n_cap, int c, double* __restrict__ sums) {
+                                                         int n_cap, int c, double* __restrict__ sums, float* __restrict__ sums_f32) {
   int i = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per output value
   int lane = threadIdx.x & 63;
   if (i >= 2 * c) return;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_col_stats_final(const double* __restric
   double s = 0.0;
   for (int b = lane; b < used; b += 64) s += partial[((long long)b * 2 + which) * c + col];
   s = u3d_wave_sum_d(s);
-  if (lane == 0) sums[i] = s;
+  if (lane == 0) { sums[i] = s; if (sums_f32) sums_f32[i] = (float)s; }
 }
 
 extern "C" int64_t u3d_bn_stats_workspace(int32_t n_cap, int32_t c) {
@@ -192,7 +192,7 @@ extern "C" int64_t u3d_bn_stats_workspace(int32_t n_cap, int32_t c) {
 template <int MODE>
 static int run_stats(const void* x, const void* dy, const void* y, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, int relu, const int32_t* n_dev, int n_cap, int c, int dtype, double* sums, void* ws, int64_t ws_bytes, hipStream_t s,
-                     const int32_t* row_map = nullptr) {
+                     const int32_t* row_map = nullptr, float* sums_f32 = nullptr) {
   U3D_REQUIRE(x && n_dev && sums && ws && c > 0, U3D_ERR_ARG);
   U3D_REQUIRE(!row_map || (dtype == U3D_F32 ? c % 4 == 0 : c % 8 == 0), U3D_ERR_UNSUPPORTED);   // mapped rows: vector kernels only
   if (n_cap <= 0) { hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, s); return U3D_OK; }
@@ -215,7 +215,7 @@ static int run_stats(const void* x, const void* dy, const void* y, const float* 
       hipLaunchKernelGGL((k_col_stats<u16, MODE>), dim3(nb), dim3(256), 0, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws);
     }
   } else return U3D_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_col_stats_final, dim3(u3d_cdiv(2 * c, 4)), dim3(256), 0, s, (const double*)ws, nb, n_dev, n_cap, c, sums);
+  hipLaunchKernelGGL(k_col_stats_final, dim3(u3d_cdiv(2 * c, 4)), dim3(256), 0, s, (const double*)ws, nb, n_dev, n_cap, c, sums, sums_f32);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
@@ -227,9 +227,9 @@ extern "C" int32_t u3d_bn_stats(const void* x, const int32_t* n_dev, int32_t n_c
 extern "C" int32_t u3d_bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                                     const float* gamma, const float* beta, int32_t relu, const int32_t* n_dev, int32_t n_cap,
                                     int32_t c, int32_t dtype, double* sums, void* workspace, int64_t workspace_bytes,
-                                    const int32_t* row_map, u3d_stream s) {
+                                    const int32_t* row_map, float* sums_f32, u3d_stream s) {
   U3D_REQUIRE(dy && mean && invstd && (!relu || y || (gamma && beta)), U3D_ERR_ARG);
-  return run_stats<1>(x, dy, y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, dtype, sums, workspace, workspace_bytes, s, row_map);
+  return run_stats<1>(x, dy, y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, dtype, sums, workspace, workspace_bytes, s, row_map, sums_f32);
 }
 
 // ---------------------------------------------------------------------------------------------

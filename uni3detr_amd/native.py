@@ -430,15 +430,16 @@ def bn_apply(x, mean, invstd, gamma, beta, residual, relu, n_dev, row_map=None):
     return y
 
 
-def bn_bwd_stats(dy, y, x, mean, invstd, relu, n_dev, gamma=None, beta=None, row_map=None):
+def bn_bwd_stats(dy, y, x, mean, invstd, relu, n_dev, gamma=None, beta=None, row_map=None, want_f32=False):
     """y may be None (relu, no residual in the forward): the ReLU mask is recomputed from x with gamma/beta."""
     n, c = x.shape
     sums = torch.empty((2, c), dtype=torch.float64, device=x.device)
     wsb = int(lib().u3d_bn_stats_workspace(n, c))
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    s32 = torch.empty((2, c), dtype=torch.float32, device=x.device) if want_f32 else None
     _check(lib().u3d_bn_bwd_stats(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), int(relu), _ptr(n_dev), n, c,
-                                  dtype_code(x), _ptr(sums), _ptr(ws), wsb, _ptr(row_map), _stream()), "bn_bwd_stats")
-    return sums
+                                  dtype_code(x), _ptr(sums), _ptr(ws), wsb, _ptr(row_map), _ptr(s32), _stream()), "bn_bwd_stats")
+    return (sums, s32) if want_f32 else sums
 
 
 def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, relu, n_dev, want_dres, beta=None, row_map=None):
@@ -700,3 +701,36 @@ def skinny_wgrad_partial(dy2, x2):
     partial = torch.empty((chunks, n * k), dtype=torch.float32, device=dy2.device)
     _check(lib().u3d_skinny_wgrad_bf16(_ptr(dy2), _ptr(x2), m, n, k, _ptr(partial), _stream()), "skinny_wgrad_bf16")
     return partial
+
+
+def cast_bf16(src, dst):
+    """dst[i] = bf16(src[i]) over flat buffers (u3d_cast_bf16)."""
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+    _check(lib().u3d_cast_bf16(_ptr(src), _ptr(dst), C.c_int64(src.numel()), _stream()), "cast_bf16")
+    return dst
+
+
+PERMUTE_DESC_DTYPE = [("src_off", "<i8"), ("dst_off", "<i8"), ("n", "<i4"), ("rows", "<i4"), ("cols", "<i4"), ("reserved", "<i4"),
+                      ("stride_k", "<i8"), ("stride_r", "<i8"), ("stride_c", "<i8")]          # = struct u3d_permute_desc
+
+
+def permute_plan(descs, device):
+    """descs: list of dicts with the u3d_permute_desc fields -> (descs_dev uint8, blocks_dev int32 [nblocks, 2], nblocks)."""
+    import numpy as np
+    arr = np.zeros(len(descs), dtype=PERMUTE_DESC_DTYPE)
+    per = int(lib().u3d_permute_block_elems())
+    blocks = []
+    for i, d in enumerate(descs):
+        for k, v in d.items():
+            arr[i][k] = v
+        assert d["dst_off"] % 8 == 0
+        blocks += [(i, o) for o in range(0, d["n"], per)]
+    descs_dev = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).to(device)
+    blocks_dev = torch.tensor(blocks, dtype=torch.int32).reshape(-1, 2).to(device)
+    return descs_dev, blocks_dev, len(blocks)
+
+
+def permute_bf16_batched(src, dst, plan):
+    descs_dev, blocks_dev, nblocks = plan
+    _check(lib().u3d_permute_bf16_batched(_ptr(src), _ptr(dst), _ptr(descs_dev), _ptr(blocks_dev), nblocks, _stream()), "permute_bf16_batched")
+    return dst

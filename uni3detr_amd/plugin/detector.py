@@ -205,7 +205,7 @@ class Uni3DETR(nn.Module):
                 for p in self.pts_middle_encoder.parameters():
                     if p.dim() == 5:
                         convs[p] = "dhwio"
-            self._shadows = ShadowSet(list({id(p): p for p in ps}.values()), self.amp_dtype, convs)
+            self._shadows = ShadowSet(list({id(p): p for p in ps}.values()), self.amp_dtype, convs, flat=getattr(self, "_flat_params", None))
         return self._shadows.active()
 
     def extract_pts_feat(self, pts):

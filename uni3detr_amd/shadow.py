@@ -28,10 +28,18 @@ def _conv_views(p, layout):
 
 
 class ShadowSet:
-    def __init__(self, params, dtype, conv_layouts=None):
-        """params: parameters to shadow as they are; conv_layouts: {parameter: "dhwio" | "oidhw"} for 5-D conv weights."""
+    def __init__(self, params, dtype, conv_layouts=None, flat=None):
+        """params: parameters to shadow as they are; conv_layouts: {parameter: "dhwio" | "oidhw"} for 5-D conv weights.
+        flat: (flat f32 buffer, {id(parameter): element offset}) when every parameter is a view of ONE flat buffer (the training
+        step's layout, uni3detr_amd/trainer.py): the refresh is then two launches - a flat cast (the shadows are views of its
+        output) and one batched re-layout for the conv-weight layouts that are not the checkpoint's own."""
         self.dtype = dtype
         conv_layouts = conv_layouts or {}
+        self.flat = None
+        if (flat is not None and dtype == torch.bfloat16 and flat[0].is_cuda
+                and all(id(p) in flat[1] for p in list(params) + list(conv_layouts))):
+            self._init_flat(params, conv_layouts, flat)
+            return
         conv_ids = {id(p) for p in conv_layouts}
         self.params = [p for p in params if p.is_floating_point() and p.dtype != dtype and id(p) not in conv_ids]
         self.shadows = [torch.empty_like(p, dtype=dtype) for p in self.params]
@@ -47,7 +55,62 @@ class ShadowSet:
             self._conv_dst += [kio, koi]
             p._u3d_conv_shadow = [kio.view(-1, kio.shape[-2], kio.shape[-1]), koi.view(-1, koi.shape[-2], koi.shape[-1]), -1, layout]
 
+    def _init_flat(self, params, conv_layouts, flat):
+        from . import native as nv
+        src, offsets = flat
+        self.flat = src
+        self.flat_shadow = torch.empty(src.numel(), dtype=torch.bfloat16, device=src.device)
+        self.params = [p for p in params if p.is_floating_point() and p.dtype != self.dtype and id(p) not in {id(q) for q in conv_layouts}]
+        self.shadows = []
+        for p in self.params:
+            o = offsets[id(p)]
+            sh = self.flat_shadow[o:o + p.numel()].view(p.shape)
+            self.shadows.append(sh)
+            p._u3d_shadow = [sh, -1]
+        self.conv_params = list(conv_layouts)
+        descs, n_perm = [], 0
+
+        def add(src_off, n, rows, cols, sk, sr, sc):
+            nonlocal n_perm
+            d = dict(src_off=src_off, dst_off=n_perm, n=n, rows=rows, cols=cols, stride_k=sk, stride_r=sr, stride_c=sc)
+            descs.append(d)
+            n_perm += (n + 63) // 64 * 64
+            return d
+
+        pending = []
+        for p, layout in conv_layouts.items():
+            o, n = offsets[id(p)], p.numel()
+            if layout == "dhwio":
+                K, ci, co = p.shape[0] * p.shape[1] * p.shape[2], p.shape[3], p.shape[4]
+                kio = self.flat_shadow[o:o + n].view(K, ci, co)                   # the checkpoint layout IS [K,Cin,Cout]
+                pending.append((p, layout, kio, None, add(o, n, co, ci, ci * co, 1, co), (K, co, ci)))
+            elif layout == "oidhw":
+                co, ci, K = p.shape[0], p.shape[1], p.shape[2] * p.shape[3] * p.shape[4]
+                pending.append((p, layout, None, add(o, n, ci, co, 1, K, ci * K), add(o, n, co, ci, 1, ci * K, K), (K, ci, co)))
+            else:
+                raise ValueError(layout)
+        self.perm = torch.empty(max(n_perm, 64), dtype=torch.bfloat16, device=src.device)
+        for p, layout, kio, d_kio, d_koi, dims in pending:
+            if kio is None:
+                K, ci, co = dims
+                kio = self.perm[d_kio["dst_off"]:d_kio["dst_off"] + p.numel()].view(K, ci, co)
+                koi = self.perm[d_koi["dst_off"]:d_koi["dst_off"] + p.numel()].view(K, co, ci)
+            else:
+                K, co, ci = dims
+                koi = self.perm[d_koi["dst_off"]:d_koi["dst_off"] + p.numel()].view(K, co, ci)
+            p._u3d_conv_shadow = [kio, koi, -1, layout]
+        self._plan = nv.permute_plan(descs, src.device)
+
     def refresh(self):
+        if self.flat is not None:
+            from . import native as nv
+            nv.cast_bf16(self.flat, self.flat_shadow)
+            nv.permute_bf16_batched(self.flat_shadow, self.perm, self._plan)
+            for p in self.params:
+                p._u3d_shadow[1] = p._version
+            for p in self.conv_params:
+                p._u3d_conv_shadow[2] = p._version
+            return
         with torch.no_grad():
             if self.shadows:
                 torch._foreach_copy_(self.shadows, self.params)

@@ -87,6 +87,7 @@ class _SparseConv(torch.autograd.Function):
         # weight: the PARAMETER in its checkpoint layout: "dhwio" [kD,kH,kW,Cin,Cout] (mmcv spconv-1.x) or "oidhw" (nn.Conv3d)
         # want_stats: also return the per-row-tile BatchNorm statistics of the output (empty tensor when the kernel serving this
         # shape does not produce them) - second, non-differentiable output
+        ctx.set_materialize_grads(False)        # else autograd zero-fills a gradient for the statistics output on every backward
         bf16 = feats.dtype == torch.bfloat16
         kio_shape = weight.shape if layout == "dhwio" else tuple(weight.shape[i] for i in (2, 3, 4, 1, 0))
         cin, cout = kio_shape[3], kio_shape[4]
@@ -116,6 +117,8 @@ class _SparseConv(torch.autograd.Function):
     def backward(ctx, dout, _dstats=None):
         feats, wc = ctx.saved_tensors
         g = ctx.geom
+        if dout is None:
+            return None, None, None, None, None
         dout = dout.contiguous()
         kvol = wc.shape[0]
         din = dw = None
@@ -195,14 +198,15 @@ class _BNRows(torch.autograd.Function):
     def backward(ctx, dy):
         x, y, mean, invstd, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
-        sums = nv.bn_bwd_stats(dy, y, x, mean, invstd, ctx.relu, ctx.n_dev, gamma, beta, ctx.row_map)
+        sums, s32 = nv.bn_bwd_stats(dy, y, x, mean, invstd, ctx.relu, ctx.n_dev, gamma, beta, ctx.row_map, want_f32=True)
         if not ctx.training:
             # eval statistics are constants: dx = gamma*invstd*g
             zero = torch.zeros_like(sums)
             dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, zero, ctx.relu, ctx.n_dev, ctx.has_res, beta, ctx.row_map)
         else:
             dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, ctx.relu, ctx.n_dev, ctx.has_res, beta, ctx.row_map)
-        s32 = sums.to(ctx.pdtype)
+        if ctx.pdtype != torch.float32:
+            s32 = s32.to(ctx.pdtype)
         return dx, s32[1], s32[0], dres, None, None, None, None, None, None, None
 
 

@@ -51,6 +51,10 @@ class TrainStep:
                     v = self.flat_param[o:o + p.numel()].view_as(p)
                     v.copy_(p.data)
                     p.data = v
+            # the bf16 parameter shadows of the model are (re)built over the flat buffer: refresh = cast + one re-layout launch
+            model._flat_params = (self.flat_param, {id(p): o for p, o in zip(self.params, self.offsets)})
+            if hasattr(model, "_shadows"):
+                model._shadows = None
             self.exp_avg = torch.zeros_like(self.flat_param)
             self.exp_avg_sq = torch.zeros_like(self.flat_param)
             self.opt_state = torch.zeros(8, dtype=torch.float32, device=self.dev)
