@@ -339,6 +339,14 @@ int32_t u3d_det_loss_bwd(const float* cls, const float* box, const float* iou_lo
                          float w_box, float w_iou, float eps, float* dcls, float* dbox, float* diou, u3d_stream s);
 /* codes [n, code] -> boxes [n, 7] (cx, cy, cz, dx, dy, dz, yaw) (ref: core/bbox/util.py denormalize_bbox). */
 int32_t u3d_denormalize_boxes(const float* codes, int32_t n, int32_t code, float* boxes, u3d_stream s);
+/* Box decode of the head (ref: dense_heads/uni3detr_head.py:475-490): out = tmp with columns 0,1,4 replaced by
+ * sigmoid(tmp + inverse_sigmoid(ref)[x,y,z]) * (pc_range hi - lo) + lo.  tmp [n, code] f32 or bf16 (dtype), ref [n, 3] f32 in
+ * sigmoid space (inverse_sigmoid clamps at eps, 1e-5 upstream), pc_range 6 host floats, out f32 [n, code].  The backward returns
+ * dtmp in tmp's dtype and, when dref != NULL, the gradient w.r.t. ref (layer 0's reference points depend on learned anchors). */
+int32_t u3d_box_decode_fwd(const void* tmp, int32_t dtype, const float* ref, int32_t n, int32_t code, const float* pc_range,
+                           float eps, float* out, u3d_stream s);
+int32_t u3d_box_decode_bwd(const void* tmp, int32_t dtype, const float* ref, const float* dout, int32_t n, int32_t code,
+                           const float* pc_range, float eps, void* dtmp, float* dref, u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * Parameter update of the training step: global-norm gradient clipping + AdamW over FLAT f32 buffers

@@ -159,3 +159,36 @@ def test_fused_detection_loss_matches_torch_formulation(cuda, code):
         assert abs(ref[0][k] - got[0][k]) <= 2e-4 * max(1.0, abs(ref[0][k])), (k, ref[0][k], got[0][k])
     for r, g, name in zip(ref[1:], got[1:], ("dcls", "dbox", "diou")):
         assert (r - g).abs().max().item() <= 2e-4 * max(1e-3, r.abs().max().item()), name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("code", [8, 10])
+def test_fused_box_decode_matches_torch_formulation(cuda, code, dtype):
+    """u3d_box_decode_fwd/_bwd == the torch formulation of uni3detr_head.py:475-490 (inverse_sigmoid of the reference point, sigmoid +
+    point-cloud range on columns 0,1,4): values and the gradients w.r.t. the branch output and the reference point, incl. reference
+    points on / beyond the clamp edges."""
+    from uni3detr_amd.plugin.head import _BoxDecode
+    from uni3detr_amd.plugin.transformer import inverse_sigmoid
+    torch.manual_seed(code)
+    pr = [-3.2, -0.2, -2.0, 3.2, 6.2, 0.56]
+    n = 1000
+    tmp = (torch.randn(4, n // 4, code, device=cuda) * 1.5).to(dtype)
+    ref = torch.rand(4, n // 4, 3, device=cuda)
+    ref.view(-1)[:8] = torch.tensor([0.0, 1.0, 1e-6, 1 - 1e-6, 0.5, 2e-5, 1 - 2e-5, 0.25], device=cuda)
+    gout = torch.randn(4, n // 4, code, device=cuda)
+    a, ra = tmp.clone().requires_grad_(True), ref.clone().requires_grad_(True)
+    out = _BoxDecode.apply(a, ra, tuple(pr))
+    out.backward(gout)
+    b, rb = tmp.clone().requires_grad_(True), ref.clone().requires_grad_(True)
+    t = b.float().unbind(-1)
+    rf = inverse_sigmoid(rb).unbind(-1)
+    exp = torch.stack([(t[0] + rf[0]).sigmoid() * (pr[3] - pr[0]) + pr[0], (t[1] + rf[1]).sigmoid() * (pr[4] - pr[1]) + pr[1], t[2], t[3],
+                       (t[4] + rf[2]).sigmoid() * (pr[5] - pr[2]) + pr[2], *t[5:]], -1)
+    exp.backward(gout)
+    assert out.dtype == torch.float32 and (out - exp).abs().max().item() <= 1e-5 * 10
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert (a.grad.float() - b.grad.float()).abs().max().item() <= tol * max(1.0, b.grad.float().abs().max().item())
+    interior = (ref > 1e-4) & (ref < 1 - 1e-4)                   # on the clamp edges the one-sided derivative is a convention
+    d = (ra.grad - rb.grad).abs()
+    assert (d[interior] <= 1e-4 * rb.grad.abs()[interior].clamp_min(1.0)).all()
+    assert torch.isfinite(ra.grad).all()

@@ -734,3 +734,25 @@ def permute_bf16_batched(src, dst, plan):
     descs_dev, blocks_dev, nblocks = plan
     _check(lib().u3d_permute_bf16_batched(_ptr(src), _ptr(dst), _ptr(descs_dev), _ptr(blocks_dev), nblocks, _stream()), "permute_bf16_batched")
     return dst
+
+
+def _pc_range6(pc_range):
+    return (C.c_float * 6)(*[float(v) for v in pc_range])
+
+
+def box_decode_fwd(tmp, ref, pc_range, eps=1e-5):
+    """tmp [n, code] f32|bf16, ref [n, 3] f32 (sigmoid space) -> decoded codes f32 [n, code] (u3d_box_decode_fwd)."""
+    n, code = tmp.shape
+    out = torch.empty((n, code), dtype=torch.float32, device=tmp.device)
+    _check(lib().u3d_box_decode_fwd(_ptr(tmp), dtype_code(tmp), _ptr(ref), n, code, _pc_range6(pc_range), C.c_float(eps), _ptr(out), _stream()),
+           "box_decode_fwd")
+    return out
+
+
+def box_decode_bwd(tmp, ref, dout, pc_range, eps=1e-5, want_dref=False):
+    n, code = tmp.shape
+    dtmp = torch.empty_like(tmp)
+    dref = torch.empty((n, 3), dtype=torch.float32, device=tmp.device) if want_dref else None
+    _check(lib().u3d_box_decode_bwd(_ptr(tmp), dtype_code(tmp), _ptr(ref), _ptr(dout), n, code, _pc_range6(pc_range), C.c_float(eps),
+                                    _ptr(dtmp), _ptr(dref), _stream()), "box_decode_bwd")
+    return dtmp, dref

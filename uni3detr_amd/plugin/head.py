@@ -28,6 +28,7 @@ def reduce_mean_(t):
 
 
 import os as _os
+FUSED_BOX_DECODE = _os.environ.get("U3D_FUSED_BOX_DECODE", "1") == "1"
 FUSED_DET_LOSS = _os.environ.get("U3D_FUSED_DET_LOSS", "1") == "1"
 
 
@@ -54,6 +55,25 @@ class _DetLoss(torch.autograd.Function):
         dcls, dbox, diou = nv.det_loss_bwd(cls, box, iou_logit, tgt, lab, w, iou_true, cls_avg, npos, code_w, gout.contiguous().float(),
                                            *ctx.cfg)
         return (dcls, dbox, diou) + (None,) * 11
+
+
+class _BoxDecode(torch.autograd.Function):
+    """Regression-branch output + reference point -> normalised box code in ONE launch each way (u3d_box_decode_fwd/_bwd; ref:
+    uni3detr_head.py:475-490).  tmp [..., code] f32|bf16, ref [..., 3] sigmoid space."""
+
+    @staticmethod
+    def forward(ctx, tmp, ref, pc_range):
+        t2 = tmp.reshape(-1, tmp.shape[-1]).contiguous()
+        r2 = ref.reshape(-1, 3).contiguous().float()
+        ctx.save_for_backward(t2, r2)
+        ctx.pc_range, ctx.shape, ctx.ref_shape, ctx.ref_dtype = pc_range, tmp.shape, ref.shape, ref.dtype
+        return nv.box_decode_fwd(t2, r2, pc_range).view(tmp.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        t2, r2 = ctx.saved_tensors
+        dtmp, dref = nv.box_decode_bwd(t2, r2, dout.reshape(t2.shape).contiguous().float(), ctx.pc_range, want_dref=ctx.needs_input_grad[1])
+        return dtmp.view(ctx.shape), (None if dref is None else dref.view(ctx.ref_shape).to(ctx.ref_dtype)), None
 
 
 def layer_sums(x):
@@ -153,23 +173,27 @@ class Uni3DETRHead(nn.Module):
         pr = self.pc_range
         classes, coords, ious = [], [], []
         for lvl in range(hs.shape[0]):
-            reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
+            ref_s = init_reference if lvl == 0 else inter_references[lvl - 1]
             h = hs[lvl]
             sc = getattr(self.transformer.decoder, "_states_c", None)
             if sc is not None and len(sc) == hs.shape[0] and torch.is_autocast_enabled():
                 h = sc[lvl]                    # the decoder's own compute-dtype copy of this state (one cast serves every branch)
             reg = getattr(self.transformer.decoder, "_reg_outputs", None)
             if self.with_box_refine and reg is not None and len(reg) == hs.shape[0]:
-                tmp = reg[lvl].float()         # the decoder already ran reg_branches[lvl] on this very state to refine its points
+                tmp = reg[lvl]                 # the decoder already ran reg_branches[lvl] on this very state to refine its points
             else:
-                tmp = run_sequential(self.reg_branches[lvl], h).float()
-            assert reference.shape[-1] == 3
-            t = tmp.unbind(-1)
-            rf = reference.unbind(-1)
-            x_ = (t[0] + rf[0]).sigmoid() * (pr[3] - pr[0]) + pr[0]
-            y_ = (t[1] + rf[1]).sigmoid() * (pr[4] - pr[1]) + pr[1]
-            z_ = (t[4] + rf[2]).sigmoid() * (pr[5] - pr[2]) + pr[2]
-            coords.append(torch.stack([x_, y_, t[2], t[3], z_, *t[5:]], -1))
+                tmp = run_sequential(self.reg_branches[lvl], h)
+            assert ref_s.shape[-1] == 3
+            if FUSED_BOX_DECODE and tmp.is_cuda and tmp.dtype in (torch.float32, torch.bfloat16) and tmp.shape[-1] <= 16:
+                coords.append(_BoxDecode.apply(tmp, ref_s, tuple(float(v) for v in pr)))
+            else:
+                reference = inverse_sigmoid(ref_s)
+                t = tmp.float().unbind(-1)
+                rf = reference.unbind(-1)
+                x_ = (t[0] + rf[0]).sigmoid() * (pr[3] - pr[0]) + pr[0]
+                y_ = (t[1] + rf[1]).sigmoid() * (pr[4] - pr[1]) + pr[1]
+                z_ = (t[4] + rf[2]).sigmoid() * (pr[5] - pr[2]) + pr[2]
+                coords.append(torch.stack([x_, y_, t[2], t[3], z_, *t[5:]], -1))
             classes.append(run_sequential(self.cls_branches[lvl], h).float())
             ious.append(run_sequential(self.iou_branches[lvl], h).float())
         return {"all_cls_scores": torch.stack(classes), "all_bbox_preds": torch.stack(coords), "all_iou_preds": torch.stack(ious)}
