@@ -357,3 +357,32 @@ def test_skinny_linear_parameter_gradients(cuda, k, n, defer):
     rel = lambda a, b: (a.float() - b.float()).abs().max().item() / max(1.0, b.abs().max().item())
     assert lin.weight.grad.shape == (n, k) and rel(lin.weight.grad, wr.grad) <= 3e-2 and rel(lin.bias.grad, br.grad) <= 3e-2
     assert rel(xq.grad, xr.grad) <= 3e-2
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_linear_relu_epilogue_matches_linear_then_relu(cuda, amp):
+    """fast_linear(relu=True) (bias + ReLU in the GEMM epilogue, mask re-applied in the backward) == F.relu(F.linear(.)) with autograd:
+    output, input gradient and parameter gradients."""
+    import contextlib
+    from uni3detr_amd.plugin import transformer as T
+    from uni3detr_amd.shadow import ShadowSet
+    torch.manual_seed(9)
+    lin = torch.nn.Linear(256, 512).to(cuda)
+    x = torch.randn(8, 900, 256, device=cuda)
+    q = lambda t: t.detach().bfloat16().float() if amp else t.detach().clone()
+    xr, wr, br = q(x).requires_grad_(True), q(lin.weight).requires_grad_(True), q(lin.bias).requires_grad_(True)
+    ref = torch.relu(torch.nn.functional.linear(xr, wr, br))
+    gy = q(torch.randn_like(ref))
+    (ref * gy).sum().backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    shadows = ShadowSet([lin.weight, lin.bias], torch.bfloat16)
+    T.reset_param_uses()
+    assert T.RELU_EPILOGUE
+    with (shadows.active() if amp else contextlib.nullcontext()), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        y = T.fast_linear(x2, lin, relu=True)
+    assert y.dtype == (torch.bfloat16 if amp else torch.float32) and (y >= 0).all()
+    (y.float() * gy).sum().backward()
+    tol = 3e-2 if amp else 2e-3
+    rel = lambda a, b: (a.float() - b.float()).abs().max().item() / max(1.0, b.abs().max().item())
+    assert rel(y, ref) <= tol and rel(x2.grad, xr.grad) <= tol
+    assert rel(lin.weight.grad, wr.grad) <= tol and rel(lin.bias.grad, br.grad) <= tol

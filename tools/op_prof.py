@@ -24,7 +24,8 @@ def main():
         ts.eager_step()
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack="--stack" in sys.argv) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack="--stack" in sys.argv,
+                 experimental_config=(torch._C._profiler._ExperimentalConfig(verbose=True) if "--stack" in sys.argv else None)) as prof:
         ts.eager_step()
         torch.cuda.synchronize()
     if "--stack" in sys.argv:

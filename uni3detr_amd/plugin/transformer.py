@@ -214,22 +214,35 @@ class _TorchLinearFn(torch.autograd.Function):
     per-step shadow set (uni3detr_amd/shadow.py), the backward is graph-replay-safe and returns f32 parameter gradients."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cdt):
+    def forward(ctx, x, weight, bias, cdt, relu=False):
         if cdt is not None:
             xc = x if x.dtype == cdt else x.to(cdt)
             wc, bc = compute_copy(weight, cdt), compute_copy(bias, cdt)
         else:
             xc, wc, bc = x, weight, bias
-        ctx.save_for_backward(xc, wc)
         ctx.has_bias, ctx.xdtype = bias is not None, x.dtype
         ctx.wid = id(weight)
         _Deferred.uses[ctx.wid] = _Deferred.uses.get(ctx.wid, 0) + 1
         _Deferred.params[ctx.wid] = (weight, bias)
+        ctx.relu = relu
+        if relu:
+            if bc is not None and xc.dim() >= 2 and bc.dtype == xc.dtype == wc.dtype:
+                # bias + ReLU in the GEMM epilogue (hipBLASLt), not a separate pass over the output
+                y = torch._addmm_activation(bc, xc.reshape(-1, xc.shape[-1]), wc.t(), use_gelu=False).view(*xc.shape[:-1], wc.shape[0])
+            else:
+                y = F.linear(xc, wc, bc).relu_()
+            ctx.save_for_backward(xc, wc, y)
+            return y
+        ctx.save_for_backward(xc, wc)
         return F.linear(xc, wc, bc)
 
     @staticmethod
     def backward(ctx, dy):
-        xc, wc = ctx.saved_tensors
+        if ctx.relu:
+            xc, wc, y = ctx.saved_tensors
+            dy = torch.ops.aten.threshold_backward(dy.contiguous() if dy.dtype == y.dtype else dy.to(y.dtype), y, 0)
+        else:
+            xc, wc = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
         dy2 = (dy2 if dy2.dtype == wc.dtype else dy2.to(wc.dtype)).contiguous()
         x2 = xc.reshape(-1, xc.shape[-1])
@@ -237,7 +250,7 @@ class _TorchLinearFn(torch.autograd.Function):
         ok = _Deferred.active and _Deferred.uses.get(ctx.wid, 0) == 1 and (need_db or not ctx.has_bias)
         dx, dw, db = _linear_backward(dy2, x2, wc, ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_db, ctx.xdtype,
                                       (ctx.wid, 0, wc.shape[0]) if ok else None)
-        return (None if dx is None else dx.view(xc.shape)), dw, db, None
+        return (None if dx is None else dx.view(xc.shape)), dw, db, None, None
 
 
 class _InProjFn(torch.autograd.Function):
@@ -284,6 +297,7 @@ LINEAR_BWD_TORCH = _os.environ.get("U3D_LINEAR_BWD_TORCH", "0") == "1"
 OWN_WGRAD = _os.environ.get("U3D_OWN_WGRAD", "1") == "1"          # dW of the decoder/head linears on u3d_igemm_wgrad_bf16
 # dW of the <= 16-feature linears on u3d_skinny_wgrad_bf16: correct (tests) but measured SLOWER end to end than hipBLASLt's
 # small products (30.3 vs 29.7 ms per step: 57 workgroups per launch) - opt-in until the kernel splits the wide dimension too
+RELU_EPILOGUE = _os.environ.get("U3D_RELU_EPILOGUE", "1") == "1"   # Linear+ReLU: activation in the GEMM epilogue (torch._addmm_activation)
 SKINNY_WGRAD = _os.environ.get("U3D_SKINNY_WGRAD", "0") == "1"
 
 
@@ -299,6 +313,8 @@ def fast_linear(x, lin, relu=False, weight=None, bias=None):
     if FAST_LINEAR and bf16_mode and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
         return _LinearFn.apply(x, w, b, relu)
     if SAFE_LINEAR and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        if relu and RELU_EPILOGUE:
+            return _TorchLinearFn.apply(x, w, b, _autocast_dtype(x), True)
         y = _TorchLinearFn.apply(x, w, b, _autocast_dtype(x))
     else:
         y = F.linear(x, w, b)
