@@ -10,6 +10,7 @@
 // Operands whose reduction index is the LDS row (W[k][n] in forward, both operands in wgrad) are fetched with
 // ds_read_b64_tr_b16; rows are padded by 16 elements so that those reads are bank-conflict free.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -20,6 +21,9 @@ typedef unsigned short u16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef IGEMM_SMALL_C
 #define IGEMM_SMALL_C 1
+#endif
+#ifndef GLDS_PIPE
+#define GLDS_PIPE 0     /* 1: unit-level fragment pipeline in the LDS-DMA forward/dgrad kernels (igemm_glds_body); measured time-neutral */
 #endif
 #ifndef IGEMM_PP
 #define IGEMM_PP 0       /* 1: 256x256 tiles run the experimental ping-pong kernel (k_igemm_pp; measured on par with k_igemm_fwd<2,4,8,4>: DESIGN.md) */
@@ -377,6 +381,73 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
     return __builtin_bit_cast(bf16x8, v);
   };
 
+#if GLDS_PIPE
+  // Fragment pipeline.  A stage (64 reduction elements) is four UNITS: (k-step 0|1) x (lower|upper half of this wave's row blocks);
+  // a unit = WM/2 x WN MFMAs on fragments already in registers, issued right after the LDS reads of the NEXT unit's fragments, so
+  // every fragment read has a whole unit of MFMAs (>= 256 clk) to land.  Registers: two half-sets of A fragments and two sets of B
+  // fragments - as many as the unpipelined loop held (all A fragments of a k-step + one B fragment).  The stage barrier sits
+  // before the LAST unit: by then every fragment of the stage is in registers, so the last unit's MFMAs cover the first reads of
+  // the next stage (other buffer) and the LDS-DMA of stage st+2 starts into the buffer just released.
+  static_assert(WM % 2 == 0, "row blocks are processed in two halves");
+  constexpr int HM = WM / 2;
+  bf16x8 af[2][HM], bw[2][WN];
+  // (macros, not lambdas: the slot / half indices must be literal for the accumulators to stay in place in registers)
+#define GLDS_LOAD_A(SLOT, BUF, KS, HALF)                                                                             \
+  {                                                                                                                  \
+    const u16* A_ = smem + (BUF) * STAGE_ELEMS + ((wm * WM + (HALF) * HM) * 16 + li) * BK;                           \
+    _Pragma("unroll") for (int a = 0; a < HM; ++a) af[SLOT][a] = frag(A_ + a * 16 * BK, KS);                         \
+  }
+#define GLDS_LOAD_B(SLOT, BUF, KS)                                                                                   \
+  {                                                                                                                  \
+    const u16* W_ = smem + (BUF) * STAGE_ELEMS + A_ELEMS + (wn * WN * 16 + li) * BK;                                 \
+    _Pragma("unroll") for (int b = 0; b < WN; ++b) bw[SLOT][b] = frag(W_ + b * 16 * BK, KS);                         \
+  }
+#define GLDS_MMA(AS, BS, HALF)                                                                                       \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int b = 0; b < WN; ++b) {                                                                 \
+      _Pragma("unroll") for (int a = 0; a < HM; ++a)                                                                 \
+        acc[(HALF) * HM + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[BS][b], af[AS][a], acc[(HALF) * HM + a][b], 0, 0, 0); \
+    }                                                                                                                \
+  }
+  load_idx_next(0);
+  advance_idx();
+  load_idx_next(1 < nstage ? 1 : 0);
+  issue(0, 0);
+  advance_idx();
+  load_idx_next(2 < nstage ? 2 : nstage - 1);
+  issue(1 < nstage ? 1 : 0, 1);
+  __syncthreads();
+  GLDS_LOAD_B(0, 0, 0)
+  GLDS_LOAD_A(0, 0, 0, 0)
+  for (int st = 0; st < nstage; ++st) {
+    const int buf = st & 1;
+    GLDS_LOAD_A(1, buf, 0, 1)                           // unit (k0, lower): fetch (k0, upper) and k-step 1's B fragments
+    GLDS_LOAD_B(1, buf, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    GLDS_MMA(0, 0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    GLDS_LOAD_A(0, buf, 1, 0)                           // unit (k0, upper): fetch (k1, lower)
+    __builtin_amdgcn_sched_barrier(0);
+    GLDS_MMA(1, 0, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    GLDS_LOAD_A(1, buf, 1, 1)                           // unit (k1, lower): fetch (k1, upper)
+    __builtin_amdgcn_sched_barrier(0);
+    GLDS_MMA(0, 1, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                    // every wave holds all of stage st; stage st+1 has landed in the other buffer
+    advance_idx();
+    load_idx_next(st + 3 < nstage ? st + 3 : nstage - 1);
+    issue(st + 2 < nstage ? st + 2 : nstage - 1, buf);  // beyond the end: a harmless re-fetch into a buffer nobody reads again
+    GLDS_LOAD_B(0, buf ^ 1, 0)                          // unit (k1, upper): fetch the next stage's first unit
+    GLDS_LOAD_A(0, buf ^ 1, 0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    GLDS_MMA(1, 1, 1)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef GLDS_LOAD_A
+#undef GLDS_LOAD_B
+#undef GLDS_MMA
+#else
   load_idx_next(0);
   advance_idx();
   load_idx_next(1 < nstage ? 1 : 0);
@@ -406,6 +477,7 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
     }
     __syncthreads();                                    // also drains this wave's LDS-DMA (vmcnt) before anyone reads the next buffer
   }
+#endif
   // epilogue: acc[a][b][r] = C[row (wm*WM+a)*16 + li][col (wn*WN+b)*16 + 4g + r]; v_cvt_pk_bf16_f32 (RNE) via convertvector
   f32x4 cs[WN], cq[WN];                                 // BatchNorm statistics of this wave's rows: column sums / sums of squares
 #pragma unroll
