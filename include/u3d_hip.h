@@ -221,10 +221,13 @@ int32_t u3d_bn_finalize_partials(const double* partial, int32_t nblocks, int32_t
  * row_map (nullable; all three functions): y / dy are stored in a permuted row order, row r of x <-> row row_map[r] of y / dy
  * (a bijection of [0, n)).  The (1,s,s)/(1,s,s) transposed convolutions of the FPN (ref: second3d_fpn.py:60-75) produce their
  * rows tap-major; their BatchNorm writes the lattice order directly instead of a separate row gather.  Requires no residual /
- * dres and C % 8 == 0 (bf16) or C % 4 == 0 (f32). */
+ * dres and C % 8 == 0 (bf16) or C % 4 == 0 (f32).
+ * post_add (nullable, u3d_bn_apply): a tensor of y's shape and row order added AFTER the activation, y = act(..) + post_add - the
+ * running sum of the FPN's upsampled levels (ref: second3d_fpn.py:131-134) without a separate add pass. */
 int32_t u3d_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, const void* residual, int32_t relu, void* y,
-                     const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, const int32_t* row_map, u3d_stream s);
+                     const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, const int32_t* row_map, const void* post_add,
+                     u3d_stream s);
 /* backward: given dy (grad wrt y), y (for relu mask), x: sums f64 [2*C] = (sum g, sum g*xhat) where
  * g = dy * (y>0 if relu).  y may be NULL when relu is set and the forward had NO residual: the mask is then recomputed as
  * (x-mean)*invstd*gamma+beta > 0 (the forward's own expression; gamma/beta required) - one tensor less to stream.

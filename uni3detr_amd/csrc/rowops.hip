@@ -561,7 +561,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_bn_apply_vec(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const T* __restrict__ res, int relu, T* __restrict__ y,
-                                                      const int* __restrict__ n_dev, int n_cap, int c, const int* __restrict__ row_map) {
+                                                      const int* __restrict__ n_dev, int n_cap, int c, const int* __restrict__ row_map,
+                                                      const T* __restrict__ post_add) {
   constexpr int V = VecOf<T>::N;
   const int n = min(*n_dev, n_cap), cv = c / V, rpb = 256 / cv;
   const int vc = threadIdx.x % cv, rl = threadIdx.x / cv;
@@ -580,7 +581,14 @@ __global__ __launch_bounds__(256) void k_bn_apply_vec(const T* __restrict__ x, c
       if (relu) v = v > 0.f ? v : 0.f;
       out[e] = v;
     }
-    store_vec<T>(row_map ? y + (long long)row_map[r] * c + (long long)vc * V : y + o, out);
+    const long long oy = row_map ? (long long)row_map[r] * c + (long long)vc * V : o;
+    if (post_add) {                                   // y = act(bn(x)) + post_add (added AFTER the ReLU, in the output's row order)
+      float pv[V];
+      load_vec<T>(post_add + oy, pv);
+#pragma unroll
+      for (int e = 0; e < V; ++e) out[e] += pv[e];
+    }
+    store_vec<T>(y + oy, out);
   }
 }
 
@@ -639,15 +647,16 @@ static inline int ew_grid(long long total) {
 
 extern "C" int32_t u3d_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                 const void* residual, int32_t relu, void* y, const int32_t* n_dev, int32_t n_cap, int32_t c,
-                                int32_t dtype, const int32_t* row_map, u3d_stream s) {
+                                int32_t dtype, const int32_t* row_map, const void* post_add, u3d_stream s) {
   U3D_REQUIRE(x && mean && invstd && gamma && beta && y && n_dev && c > 0, U3D_ERR_ARG);
   U3D_REQUIRE(!row_map || (!residual && bn_vec_ok(c, dtype == U3D_F32 ? 4 : 8)), U3D_ERR_UNSUPPORTED);
+  U3D_REQUIRE(!post_add || bn_vec_ok(c, dtype == U3D_F32 ? 4 : 8), U3D_ERR_UNSUPPORTED);
   if (n_cap <= 0) return U3D_OK;
   int g = ew_grid((long long)n_cap * c);
   if (dtype == U3D_F32 && bn_vec_ok(c, 4))
-    hipLaunchKernelGGL(k_bn_apply_vec<float>, dim3(bn_vec_grid(n_cap, c, 4)), dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const float*)residual, relu, (float*)y, n_dev, n_cap, c, row_map);
+    hipLaunchKernelGGL(k_bn_apply_vec<float>, dim3(bn_vec_grid(n_cap, c, 4)), dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const float*)residual, relu, (float*)y, n_dev, n_cap, c, row_map, (const float*)post_add);
   else if (dtype == U3D_BF16 && bn_vec_ok(c, 8))
-    hipLaunchKernelGGL(k_bn_apply_vec<u16>, dim3(bn_vec_grid(n_cap, c, 8)), dim3(256), 0, s, (const u16*)x, mean, invstd, gamma, beta, (const u16*)residual, relu, (u16*)y, n_dev, n_cap, c, row_map);
+    hipLaunchKernelGGL(k_bn_apply_vec<u16>, dim3(bn_vec_grid(n_cap, c, 8)), dim3(256), 0, s, (const u16*)x, mean, invstd, gamma, beta, (const u16*)residual, relu, (u16*)y, n_dev, n_cap, c, row_map, (const u16*)post_add);
   else if (dtype == U3D_F32)
     hipLaunchKernelGGL(k_bn_apply<float>, dim3(g), dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const float*)residual, relu, (float*)y, n_dev, n_cap, c);
   else if (dtype == U3D_BF16)

@@ -65,9 +65,9 @@ _SIGS = {
     "u3d_bn_finalize_partials": (_I, [_P, _I, _I, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     "u3d_igemm_fwd_stats_tile_rows": (_I, [_I, _I, _I]),
     "u3d_igemm_fwd_stats_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
-    "u3d_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
-    "u3d_bn_bwd_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P]),
-    "u3d_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "u3d_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "u3d_bn_bwd_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P]),
+    "u3d_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
     "u3d_to_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     "u3d_from_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     "u3d_fps": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _L, _P]),
@@ -92,6 +92,11 @@ _SIGS = {
     "u3d_det_loss_fwd": (_I, [_P] * 10 + [_I] * 5 + [C.c_float] * 5 + [_P, _P, _L, _P]),
     "u3d_det_loss_bwd": (_I, [_P] * 11 + [_I] * 5 + [C.c_float] * 5 + [_P, _P, _P, _P]),
     "u3d_denormalize_boxes": (_I, [_P, _I, _I, _P, _P]),
+    "u3d_box_decode_fwd": (_I, [_P, _I, _P, _I, _I, _F6, C.c_float, _P, _P]),
+    "u3d_box_decode_bwd": (_I, [_P, _I, _P, _P, _I, _I, _F6, C.c_float, _P, _P, _P]),
+    "u3d_cast_bf16": (_I, [_P, _P, _L, _P]),
+    "u3d_permute_block_elems": (_I, []),
+    "u3d_permute_bf16_batched": (_I, [_P, _P, _P, _P, _I, _P]),
     "u3d_adamw_workspace": (_L, [_L]),
     "u3d_adamw_step": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _L, _P]),
     "u3d_gather_rows": (_I, [_P, _P, _I, _I, _P, _P]),
@@ -421,12 +426,12 @@ def bn_forward_stats(x, n_dev, eps, momentum, running_mean=None, running_var=Non
     return mean, invstd
 
 
-def bn_apply(x, mean, invstd, gamma, beta, residual, relu, n_dev, row_map=None):
+def bn_apply(x, mean, invstd, gamma, beta, residual, relu, n_dev, row_map=None, post_add=None):
     """row_map (int32 [n], a bijection): row r of x lands in row row_map[r] of y (see include/u3d_hip.h)."""
     n, c = x.shape
     y = torch.empty_like(x)
     _check(lib().u3d_bn_apply(_ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(residual), int(relu),
-                              _ptr(y), _ptr(n_dev), n, c, dtype_code(x), _ptr(row_map), _stream()), "bn_apply")
+                              _ptr(y), _ptr(n_dev), n, c, dtype_code(x), _ptr(row_map), _ptr(post_add), _stream()), "bn_apply")
     return y
 
 

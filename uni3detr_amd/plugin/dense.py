@@ -84,6 +84,7 @@ class Lattice:
         return v
 
 
+FUSED_LEVEL_SUM = os.environ.get("U3D_FUSED_LEVEL_SUM", "1") == "1"
 FUSED_UPSAMPLE_ORDER = os.environ.get("U3D_FUSED_UPSAMPLE", "1") == "1"
 
 
@@ -110,14 +111,14 @@ def to_volume(rows, B, dims):
     return rows.view(B, *dims, rows.shape[1]).permute(0, 4, 1, 2, 3)
 
 
-def conv_bn_relu(rows, B, dims, conv, bn):
+def conv_bn_relu(rows, B, dims, conv, bn, post_add=None):
     ks, st, pd = tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding)
     geom, dims_out = Lattice.conv(rows.device, B, dims, ks, st, pd)
     # nn.Conv3d layout [Cout,Cin,kd,kh,kw] (re-laid-out by the shadow set); BatchNorm statistics come out of the conv's epilogue
-    return sp.conv_bn(rows, conv.weight, geom, bn, geom.n_out_dev, None, True, "oidhw"), dims_out
+    return sp.conv_bn(rows, conv.weight, geom, bn, geom.n_out_dev, None, True, "oidhw", post_add), dims_out
 
 
-def deconv_bn_relu(rows, B, dims, deconv, bn):
+def deconv_bn_relu(rows, B, dims, deconv, bn, post_add=None):
     s = deconv.stride[1]
     assert tuple(deconv.kernel_size) == (1, s, s) and tuple(deconv.stride) == (1, s, s), "non-overlapping (1,s,s) upsampling only"
     cin, cout = deconv.weight.shape[0], deconv.weight.shape[1]
@@ -130,9 +131,9 @@ def deconv_bn_relu(rows, B, dims, deconv, bn):
     if FUSED_UPSAMPLE_ORDER:
         # the GEMM leaves the rows tap-major; BatchNorm statistics do not care about row order, and its apply kernel writes
         # row r to its lattice position inv[r] (the backward reads dy there) - no separate gather pass over the upsampled volume
-        return sp.bn_rows(y, bn, n_dev, None, True, row_map=inv), dims_out
+        return sp.bn_rows(y, bn, n_dev, None, True, row_map=inv, post_add=post_add), dims_out
     y = _GatherBijection.apply(y, idx, inv)
-    return sp.bn_rows(y, bn, n_dev, None, True), dims_out
+    return sp.bn_rows(y, bn, n_dev, None, True, post_add=post_add), dims_out
 
 
 @BACKBONES.register_module()
@@ -240,12 +241,14 @@ class SECOND3DFPN(nn.Module):
         out, odims, B = None, None, None
         for i, d in enumerate(self.deblocks):
             rows, B, dims = to_rows(x[i])
+            # the running sum of the levels rides in each level's BatchNorm apply kernel (y = relu(bn(x)) + sum so far)
+            fuse = FUSED_LEVEL_SUM and out is not None and rows.is_cuda and out.dtype == rows.dtype
             if isinstance(d[0], nn.ConvTranspose3d):
-                r, dd = deconv_bn_relu(rows, B, dims, d[0], d[1])
+                r, dd = deconv_bn_relu(rows, B, dims, d[0], d[1], out if fuse else None)
             else:
-                r, dd = conv_bn_relu(rows, B, dims, d[0], d[1])
+                r, dd = conv_bn_relu(rows, B, dims, d[0], d[1], out if fuse else None)
             assert odims is None or odims == dd, "FPN levels must land on one lattice"
-            out, odims = (r if out is None else out + r), dd
+            out, odims = (r if (out is None or fuse) else out + r), dd
         if self.extra_conv is not None:
             mods = list(self.extra_blocks)
             for j in range(0, len(mods), 3):

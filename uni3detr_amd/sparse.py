@@ -155,7 +155,7 @@ def sparse_conv(feats, weight, geom, layout="dhwio"):
 FUSED_CONV_STATS = _os.environ.get("U3D_FUSED_CONV_STATS", "1") == "1"
 
 
-def conv_bn(feats, weight, geom, bn, n_dev, residual=None, relu=True, layout="dhwio"):
+def conv_bn(feats, weight, geom, bn, n_dev, residual=None, relu=True, layout="dhwio", post_add=None):
     """conv -> BatchNorm rows (+ residual) (+ ReLU).  In training the conv's epilogue already reduces the BatchNorm statistics per row
     tile where its kernel supports it (bf16, channels % 64 == 0): the separate statistics pass over the conv output disappears."""
     if FUSED_CONV_STATS and bn.training and feats.dtype == torch.bfloat16 and feats.is_cuda:
@@ -164,16 +164,16 @@ def conv_bn(feats, weight, geom, bn, n_dev, residual=None, relu=True, layout="dh
             tr = getattr(stats, "_u3d_tile_rows", None)
             if tr is None:                      # attribute lost on the way through autograd: recover it from the shape
                 tr = 128 if (y.shape[0] + 127) // 128 == stats.shape[0] else 256
-            return _BNRows.apply(y, bn.weight, bn.bias, residual, n_dev, bn, relu, True, stats, tr)
-        return bn_rows(y, bn, n_dev, residual, relu)
-    return bn_rows(sparse_conv(feats, weight, geom, layout), bn, n_dev, residual, relu)
+            return _BNRows.apply(y, bn.weight, bn.bias, residual, n_dev, bn, relu, True, stats, tr, None, post_add)
+        return bn_rows(y, bn, n_dev, residual, relu, None, post_add)
+    return bn_rows(sparse_conv(feats, weight, geom, layout), bn, n_dev, residual, relu, None, post_add)
 
 
 class _BNRows(torch.autograd.Function):
     """BatchNorm1d over active rows (+ residual) (+ ReLU), training or eval statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, n_dev, bn, relu, training, stats=None, tile_rows=0, row_map=None):
+    def forward(ctx, x, gamma, beta, residual, n_dev, bn, relu, training, stats=None, tile_rows=0, row_map=None, post_add=None):
         n = x.shape[0]
         if training and stats is not None:
             mean, invstd = nv.bn_finalize_partials(stats, tile_rows, n_dev, n, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
@@ -185,13 +185,17 @@ class _BNRows(torch.autograd.Function):
             mean = bn.running_mean
             invstd = torch.rsqrt(bn.running_var + bn.eps)
         g32, b32 = gamma.float(), beta.float()
-        y = nv.bn_apply(x, mean, invstd, g32, b32, residual, relu, n_dev, row_map)
+        if post_add is not None:
+            assert relu and residual is None and post_add.shape == x.shape and post_add.dtype == x.dtype
+            post_add = post_add.contiguous()
+        y = nv.bn_apply(x, mean, invstd, g32, b32, residual, relu, n_dev, row_map, post_add)
         # ReLU without residual: the backward recomputes the mask from x (same expression) instead of streaming y again
         ctx.remask = bool(relu and residual is None)
         ctx.save_for_backward(x, None if ctx.remask else y, mean, invstd, g32, b32)
         ctx.n_dev, ctx.relu, ctx.training, ctx.has_res = n_dev, relu, training, residual is not None
         ctx.pdtype = gamma.dtype
         ctx.row_map = row_map
+        ctx.has_post = post_add is not None
         return y
 
     @staticmethod
@@ -207,12 +211,13 @@ class _BNRows(torch.autograd.Function):
             dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, ctx.relu, ctx.n_dev, ctx.has_res, beta, ctx.row_map)
         if ctx.pdtype != torch.float32:
             s32 = s32.to(ctx.pdtype)
-        return dx, s32[1], s32[0], dres, None, None, None, None, None, None, None
+        # post_add enters y by a plain sum: its gradient is dy itself (no launch)
+        return dx, s32[1], s32[0], dres, None, None, None, None, None, None, None, (dy if ctx.has_post else None)
 
 
-def bn_rows(x, bn, n_dev, residual=None, relu=True, row_map=None):
+def bn_rows(x, bn, n_dev, residual=None, relu=True, row_map=None, post_add=None):
     """row_map: the output (and its gradient) use a permuted row order, y[row_map[r]] = bn(x[r]) - see u3d_bn_apply."""
-    return _BNRows.apply(x, bn.weight, bn.bias, residual, n_dev, bn, relu, bn.training, None, 0, row_map)
+    return _BNRows.apply(x, bn.weight, bn.bias, residual, n_dev, bn, relu, bn.training, None, 0, row_map, post_add)
 
 
 class _ToDense(torch.autograd.Function):

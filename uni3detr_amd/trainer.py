@@ -93,7 +93,10 @@ class TrainStep:
             p.grad = None
         losses = self.model.pts_bbox_head.loss_from_targets(self._outs, self._T, self._num_pos)
         self._losses = losses
-        loss = sum(v for k, v in losses.items() if "loss" in k)
+        loss = getattr(self.model.pts_bbox_head, "_loss_total", None)          # = the sum below, reduced in one launch (fused loss path)
+        if loss is None or not all("loss" in k for k in losses):
+            loss = sum(v for k, v in losses.items() if "loss" in k)
+        self.model.pts_bbox_head._loss_total = None
         with _T.deferred_param_grads():          # dW / db of the decoder + head linears: queued, then one batched launch per shape
             loss.backward()
         self.loss = loss.detach()
@@ -195,6 +198,7 @@ class TrainStep:
         # drop the eager iteration's activations / autograd graph BEFORE capturing: releasing them from inside a capture
         # (when the attributes are re-assigned) tears down autograd nodes mid-capture and crashes hipStreamEndCapture
         self._outs = self._T = self._num_pos = self._losses = self.loss = None
+        self.model.pts_bbox_head._loss_total = None
         dec = getattr(getattr(self.model.pts_bbox_head, "transformer", None), "decoder", None)
         if dec is not None:
             dec._reg_outputs = None
