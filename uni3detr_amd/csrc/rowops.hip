@@ -41,6 +41,26 @@ __device__ __forceinline__ void load_vec<u16>(const u16* p, float* out) {
   for (int i = 0; i < 4; ++i) { out[2 * i] = __uint_as_float(w[i] << 16); out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
 }
 
+// per-thread column parameters (V consecutive columns) as 16-byte loads: one load per 4 columns instead of V strided dword loads
+// per array - with ~50 scalar loads per thread the address unit spent ~30 us per launch on parameter fetch alone, whatever N
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }      // column parameters are fetched with 16-byte loads
+template <int V>
+__device__ __forceinline__ void load_cols(const float* __restrict__ p, int col0, float* out) {
+#pragma unroll
+  for (int i = 0; i < V; i += 4) {
+    const float4 t = *(const float4*)(p + col0 + i);
+    out[i] = t.x; out[i + 1] = t.y; out[i + 2] = t.z; out[i + 3] = t.w;
+  }
+}
+template <int V>
+__device__ __forceinline__ void load_cols_d(const double* __restrict__ p, int col0, float scale, float* out) {
+#pragma unroll
+  for (int i = 0; i < V; i += 2) {
+    const double2 t = *(const double2*)(p + col0 + i);
+    out[i] = (float)t.x * scale; out[i + 1] = (float)t.y * scale;
+  }
+}
+
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void k_col_stats_vec(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -67,12 +87,9 @@ __global__ __launch_bounds__(256) void k_col_stats_vec(const T* __restrict__ x, 
       float mu[V], is[V], ga[V], be[V];
       const bool remask = MODE == 1 && relu && y == nullptr;     // ReLU mask recomputed from x (no residual): one tensor less to read
       if (MODE == 1) {
-#pragma unroll
-        for (int e = 0; e < V; ++e) { mu[e] = mean[vc * V + e]; is[e] = invstd[vc * V + e]; }
-        if (remask) {
-#pragma unroll
-          for (int e = 0; e < V; ++e) { ga[e] = gamma[vc * V + e]; be[e] = beta[vc * V + e]; }
-        }
+        load_cols<V>(mean, vc * V, mu);
+        load_cols<V>(invstd, vc * V, is);
+        if (remask) { load_cols<V>(gamma, vc * V, ga); load_cols<V>(beta, vc * V, be); }
       }
 #pragma unroll 4
       for (int r = r0 + trow; r < r1; r += rl) {
@@ -225,8 +242,10 @@ static int run_stats(const void* x, const void* dy, const void* y, const float* 
   if (n_cap <= 0) { hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, s); return U3D_OK; }
   U3D_REQUIRE(ws_bytes >= u3d_bn_stats_workspace(n_cap, c), U3D_ERR_WORKSPACE);
   int nb = u3d_cdiv(n_cap, ST_ROWS_PER_BLOCK);
+  const bool pal = al16(mean) && al16(invstd) && al16(gamma) && al16(beta);      // nullptr counts as aligned
+  U3D_REQUIRE(!row_map || pal, U3D_ERR_ARG);
   if (dtype == U3D_F32) {
-    if (c % 4 == 0) {
+    if (c % 4 == 0 && pal) {
       int cw = (c / 4) < 256 ? (c / 4) : 256; int rl = 256 / cw;
       size_t lds = (size_t)2 * rl * cw * 4 * sizeof(double);
       hipLaunchKernelGGL((k_col_stats_vec<float, MODE>), dim3(nb), dim3(256), lds, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws, row_map);
@@ -234,7 +253,7 @@ static int run_stats(const void* x, const void* dy, const void* y, const float* 
       hipLaunchKernelGGL((k_col_stats<float, MODE>), dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws);
     }
   } else if (dtype == U3D_BF16) {
-    if (c % 8 == 0) {
+    if (c % 8 == 0 && pal) {
       int cw = (c / 8) < 256 ? (c / 8) : 256; int rl = 256 / cw;
       size_t lds = (size_t)2 * rl * cw * 8 * sizeof(double);
       hipLaunchKernelGGL((k_col_stats_vec<u16, MODE>), dim3(nb), dim3(256), lds, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws, row_map);
@@ -567,8 +586,7 @@ __global__ __launch_bounds__(256) void k_bn_apply_vec(const T* __restrict__ x, c
   const int n = min(*n_dev, n_cap), cv = c / V, rpb = 256 / cv;
   const int vc = threadIdx.x % cv, rl = threadIdx.x / cv;
   float mu[V], is[V], ga[V], be[V];
-#pragma unroll
-  for (int e = 0; e < V; ++e) { mu[e] = mean[vc * V + e]; is[e] = invstd[vc * V + e]; ga[e] = gamma[vc * V + e]; be[e] = beta[vc * V + e]; }
+  load_cols<V>(mean, vc * V, mu); load_cols<V>(invstd, vc * V, is); load_cols<V>(gamma, vc * V, ga); load_cols<V>(beta, vc * V, be);
   for (int r = blockIdx.x * rpb + rl; r < n; r += gridDim.x * rpb) {
     const long long o = (long long)r * c + (long long)vc * V;
     float xv[V], rv[V], out[V];
@@ -605,12 +623,14 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_vec(const T* __restrict__ 
   const float inv_n = n > 0 ? 1.f / (float)n : 0.f;               // f32: a per-thread f64 divide + 16 f64 multiplies cost as much as the stream
   const bool remask = relu && y == nullptr;
   float mu[V], is[V], ga[V], be[V], mg[V], mgx[V];
+  load_cols<V>(mean, vc * V, mu); load_cols<V>(invstd, vc * V, is); load_cols<V>(gamma, vc * V, ga);
+  if (remask) load_cols<V>(beta, vc * V, be);
+  else {
 #pragma unroll
-  for (int e = 0; e < V; ++e) {
-    const int col = vc * V + e;
-    mu[e] = mean[col]; is[e] = invstd[col]; ga[e] = gamma[col]; be[e] = remask ? beta[col] : 0.f;
-    mg[e] = (float)sums[col] * inv_n; mgx[e] = (float)sums[c + col] * inv_n;
+    for (int e = 0; e < V; ++e) be[e] = 0.f;
   }
+  load_cols_d<V>(sums, vc * V, inv_n, mg);
+  load_cols_d<V>(sums + c, vc * V, inv_n, mgx);
 #pragma unroll 2
   for (int r = blockIdx.x * rpb + rl; r < n; r += gridDim.x * rpb) {
     const long long o = (long long)r * c + (long long)vc * V;
@@ -651,11 +671,13 @@ extern "C" int32_t u3d_bn_apply(const void* x, const float* mean, const float* i
   U3D_REQUIRE(x && mean && invstd && gamma && beta && y && n_dev && c > 0, U3D_ERR_ARG);
   U3D_REQUIRE(!row_map || (!residual && bn_vec_ok(c, dtype == U3D_F32 ? 4 : 8)), U3D_ERR_UNSUPPORTED);
   U3D_REQUIRE(!post_add || bn_vec_ok(c, dtype == U3D_F32 ? 4 : 8), U3D_ERR_UNSUPPORTED);
+  const bool pal = al16(mean) && al16(invstd) && al16(gamma) && al16(beta);
+  U3D_REQUIRE(!(row_map || post_add) || pal, U3D_ERR_ARG);
   if (n_cap <= 0) return U3D_OK;
   int g = ew_grid((long long)n_cap * c);
-  if (dtype == U3D_F32 && bn_vec_ok(c, 4))
+  if (dtype == U3D_F32 && bn_vec_ok(c, 4) && pal)
     hipLaunchKernelGGL(k_bn_apply_vec<float>, dim3(bn_vec_grid(n_cap, c, 4)), dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const float*)residual, relu, (float*)y, n_dev, n_cap, c, row_map, (const float*)post_add);
-  else if (dtype == U3D_BF16 && bn_vec_ok(c, 8))
+  else if (dtype == U3D_BF16 && bn_vec_ok(c, 8) && pal)
     hipLaunchKernelGGL(k_bn_apply_vec<u16>, dim3(bn_vec_grid(n_cap, c, 8)), dim3(256), 0, s, (const u16*)x, mean, invstd, gamma, beta, (const u16*)residual, relu, (u16*)y, n_dev, n_cap, c, row_map, (const u16*)post_add);
   else if (dtype == U3D_F32)
     hipLaunchKernelGGL(k_bn_apply<float>, dim3(g), dim3(256), 0, s, (const float*)x, mean, invstd, gamma, beta, (const float*)residual, relu, (float*)y, n_dev, n_cap, c);
@@ -671,11 +693,13 @@ extern "C" int32_t u3d_bn_bwd_apply(const void* dy, const void* y, const void* x
                                     const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, const int32_t* row_map, u3d_stream s) {
   U3D_REQUIRE(dy && x && mean && invstd && gamma && sums && dx && n_dev && c > 0 && (!relu || y || beta), U3D_ERR_ARG);
   U3D_REQUIRE(!row_map || (!dres && bn_vec_ok(c, dtype == U3D_F32 ? 4 : 8)), U3D_ERR_UNSUPPORTED);
+  const bool pal = al16(mean) && al16(invstd) && al16(gamma) && al16(beta) && al16(sums);
+  U3D_REQUIRE(!row_map || pal, U3D_ERR_ARG);
   if (n_cap <= 0) return U3D_OK;
   int g = ew_grid((long long)n_cap * c);
-  if (dtype == U3D_F32 && bn_vec_ok(c, 4))
+  if (dtype == U3D_F32 && bn_vec_ok(c, 4) && pal)
     hipLaunchKernelGGL(k_bn_bwd_apply_vec<float>, dim3(bn_vec_grid(n_cap, c, 4)), dim3(256), 0, s, (const float*)dy, (const float*)y, (const float*)x, mean, invstd, gamma, beta, sums, relu, (float*)dx, (float*)dres, n_dev, n_cap, c, row_map);
-  else if (dtype == U3D_BF16 && bn_vec_ok(c, 8))
+  else if (dtype == U3D_BF16 && bn_vec_ok(c, 8) && pal)
     hipLaunchKernelGGL(k_bn_bwd_apply_vec<u16>, dim3(bn_vec_grid(n_cap, c, 8)), dim3(256), 0, s, (const u16*)dy, (const u16*)y, (const u16*)x, mean, invstd, gamma, beta, sums, relu, (u16*)dx, (u16*)dres, n_dev, n_cap, c, row_map);
   else if (dtype == U3D_F32)
     hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(g), dim3(256), 0, s, (const float*)dy, (const float*)y, (const float*)x, mean, invstd, gamma, beta, sums, relu, (float*)dx, (float*)dres, n_dev, n_cap, c);
