@@ -20,7 +20,9 @@ __device__ __forceinline__ void st_elem(u16* p, long long i, float v) {
 // row lanes (LDS) -> partial[block][2][C] (f64); stage 2 sums the blocks in order (deterministic).
 // MODE 0: (x, x^2).  MODE 1: g = dy*(relu? y>0), (g, g*xhat).   Requires C % VEC == 0 (else the scalar kernel).
 // ---------------------------------------------------------------------------------------------
-#define ST_ROWS_PER_BLOCK 128   /* 512 left a 48 000-row layer with 94 workgroups: latency-bound at ~1 TB/s */
+// rows per workgroup of the statistics kernels: 128, but 16 for the smallest tensors (128 left the 12 000-row dense level with 94
+// workgroups: 17 us for 25 MB, 11 us at 16)
+static inline int st_rows_per_block(int n_cap) { return n_cap >= 32768 ? 128 : 16; }      // measured: 48 000 rows are better off at 128 (fewer f64 partials)
 
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { static constexpr int N = 4; };
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void k_col_stats_vec(const T* __restrict__ x, 
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
                                                        const int* __restrict__ n_dev, int n_cap, int c, double* __restrict__ partial,
-                                                       const int* __restrict__ row_map) {
+                                                       const int* __restrict__ row_map, int rows_per_block) {
   constexpr int V = VecOf<T>::N;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* red = (double*)smem_raw;                 // [2][rl][cw*V] laid out as [which][rowlane][col]
@@ -75,8 +77,8 @@ __global__ __launch_bounds__(256) void k_col_stats_vec(const T* __restrict__ x, 
   const int cw = cv < 256 ? cv : 256;              // vector-columns handled concurrently
   const int rl = 256 / cw;                         // row lanes
   const int tcol = threadIdx.x % cw, trow = threadIdx.x / cw;
-  const int r0 = blockIdx.x * ST_ROWS_PER_BLOCK;
-  const int r1 = min(n, r0 + ST_ROWS_PER_BLOCK);
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(n, r0 + rows_per_block);
   for (int cb = 0; cb < cv; cb += cw) {
     const int vc = cb + tcol;
     float s0[V], s1[V];
@@ -141,14 +143,15 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void k_col_stats(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                                   const int* __restrict__ n_dev, int n_cap, int c, double* __restrict__ partial) {
+                                                   const int* __restrict__ n_dev, int n_cap, int c, double* __restrict__ partial,
+                                                   int rows_per_block) {
   __shared__ double red[2][256];
   const int n = min(*n_dev, n_cap);
   const int cw = c < 256 ? c : 256;
   const int rl = 256 / cw;
   const int tcol = threadIdx.x % cw, trow = threadIdx.x / cw;
-  const int r0 = blockIdx.x * ST_ROWS_PER_BLOCK;
-  const int r1 = min(n, r0 + ST_ROWS_PER_BLOCK);
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(n, r0 + rows_per_block);
   for (int cb = 0; cb < c; cb += cw) {
     int col = cb + tcol;
     double s0 = 0.0, s1 = 0.0;
@@ -212,10 +215,11 @@ __device__ __forceinline__ void fin_reduce(const double* __restrict__ partial, i
 }
 
 __global__ __launch_bounds__(FIN_THREADS) void k_col_stats_final(const double* __restrict__ partial, int nblocks, const int* __restrict__ n_dev,
-                                                                 int n_cap, int c, double* __restrict__ sums, float* __restrict__ sums_f32) {
+                                                                 int n_cap, int c, double* __restrict__ sums, float* __restrict__ sums_f32,
+                                                                 int rows_per_block) {
   __shared__ double red[FIN_LANES][16];
   const int n = min(*n_dev, n_cap);
-  int used = (n + ST_ROWS_PER_BLOCK - 1) / ST_ROWS_PER_BLOCK;
+  int used = (n + rows_per_block - 1) / rows_per_block;
   if (used > nblocks) used = nblocks;
   const int col0 = blockIdx.x * 8;
   fin_reduce(partial, used, c, col0, red);
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_col_stats_final(const double* _
 }
 
 extern "C" int64_t u3d_bn_stats_workspace(int32_t n_cap, int32_t c) {
-  return (int64_t)u3d_cdiv(n_cap > 0 ? n_cap : 1, ST_ROWS_PER_BLOCK) * 2 * c * 8;
+  return (int64_t)u3d_cdiv(n_cap > 0 ? n_cap : 1, st_rows_per_block(n_cap)) * 2 * c * 8;
 }
 
 template <int MODE>
@@ -241,27 +245,28 @@ static int run_stats(const void* x, const void* dy, const void* y, const float* 
   U3D_REQUIRE(!row_map || (dtype == U3D_F32 ? c % 4 == 0 : c % 8 == 0), U3D_ERR_UNSUPPORTED);   // mapped rows: vector kernels only
   if (n_cap <= 0) { hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, s); return U3D_OK; }
   U3D_REQUIRE(ws_bytes >= u3d_bn_stats_workspace(n_cap, c), U3D_ERR_WORKSPACE);
-  int nb = u3d_cdiv(n_cap, ST_ROWS_PER_BLOCK);
+  const int rpb = st_rows_per_block(n_cap);
+  int nb = u3d_cdiv(n_cap, rpb);
   const bool pal = al16(mean) && al16(invstd) && al16(gamma) && al16(beta);      // nullptr counts as aligned
   U3D_REQUIRE(!row_map || pal, U3D_ERR_ARG);
   if (dtype == U3D_F32) {
     if (c % 4 == 0 && pal) {
       int cw = (c / 4) < 256 ? (c / 4) : 256; int rl = 256 / cw;
       size_t lds = (size_t)2 * rl * cw * 4 * sizeof(double);
-      hipLaunchKernelGGL((k_col_stats_vec<float, MODE>), dim3(nb), dim3(256), lds, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws, row_map);
+      hipLaunchKernelGGL((k_col_stats_vec<float, MODE>), dim3(nb), dim3(256), lds, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws, row_map, rpb);
     } else {
-      hipLaunchKernelGGL((k_col_stats<float, MODE>), dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws);
+      hipLaunchKernelGGL((k_col_stats<float, MODE>), dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws, rpb);
     }
   } else if (dtype == U3D_BF16) {
     if (c % 8 == 0 && pal) {
       int cw = (c / 8) < 256 ? (c / 8) : 256; int rl = 256 / cw;
       size_t lds = (size_t)2 * rl * cw * 8 * sizeof(double);
-      hipLaunchKernelGGL((k_col_stats_vec<u16, MODE>), dim3(nb), dim3(256), lds, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws, row_map);
+      hipLaunchKernelGGL((k_col_stats_vec<u16, MODE>), dim3(nb), dim3(256), lds, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws, row_map, rpb);
     } else {
-      hipLaunchKernelGGL((k_col_stats<u16, MODE>), dim3(nb), dim3(256), 0, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws);
+      hipLaunchKernelGGL((k_col_stats<u16, MODE>), dim3(nb), dim3(256), 0, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws, rpb);
     }
   } else return U3D_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_col_stats_final, dim3(u3d_cdiv(c, 8)), dim3(FIN_THREADS), 0, s, (const double*)ws, nb, n_dev, n_cap, c, sums, sums_f32);
+  hipLaunchKernelGGL(k_col_stats_final, dim3(u3d_cdiv(c, 8)), dim3(FIN_THREADS), 0, s, (const double*)ws, nb, n_dev, n_cap, c, sums, sums_f32, rpb);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
@@ -530,7 +535,8 @@ extern "C" int32_t u3d_bn_forward_stats(const void* x, const int32_t* n_dev, int
                                         float* invstd, void* workspace, int64_t workspace_bytes, u3d_stream s) {
   U3D_REQUIRE(x && n_dev && mean && invstd && workspace && c > 0 && (!running_mean || running_var), U3D_ERR_ARG);
   U3D_REQUIRE(workspace_bytes >= u3d_bn_stats_workspace(n_cap, c), U3D_ERR_WORKSPACE);
-  const int nb = n_cap > 0 ? u3d_cdiv(n_cap, ST_ROWS_PER_BLOCK) : 0;
+  const int rpb = st_rows_per_block(n_cap);
+  const int nb = n_cap > 0 ? u3d_cdiv(n_cap, rpb) : 0;
   if (nb > 0) {
     const bool f32 = dtype == U3D_F32;
     if (!f32 && dtype != U3D_BF16) return U3D_ERR_UNSUPPORTED;
@@ -538,14 +544,14 @@ extern "C" int32_t u3d_bn_forward_stats(const void* x, const int32_t* n_dev, int
     if (c % v == 0) {
       int cw = (c / v) < 256 ? (c / v) : 256; int rl = 256 / cw;
       size_t lds = (size_t)2 * rl * cw * v * sizeof(double);
-      if (f32) hipLaunchKernelGGL((k_col_stats_vec<float, 0>), dim3(nb), dim3(256), lds, s, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace, (const int*)nullptr);
-      else hipLaunchKernelGGL((k_col_stats_vec<u16, 0>), dim3(nb), dim3(256), lds, s, (const u16*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace, (const int*)nullptr);
+      if (f32) hipLaunchKernelGGL((k_col_stats_vec<float, 0>), dim3(nb), dim3(256), lds, s, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace, (const int*)nullptr, rpb);
+      else hipLaunchKernelGGL((k_col_stats_vec<u16, 0>), dim3(nb), dim3(256), lds, s, (const u16*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace, (const int*)nullptr, rpb);
     } else {
-      if (f32) hipLaunchKernelGGL((k_col_stats<float, 0>), dim3(nb), dim3(256), 0, s, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace);
-      else hipLaunchKernelGGL((k_col_stats<u16, 0>), dim3(nb), dim3(256), 0, s, (const u16*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace);
+      if (f32) hipLaunchKernelGGL((k_col_stats<float, 0>), dim3(nb), dim3(256), 0, s, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace, rpb);
+      else hipLaunchKernelGGL((k_col_stats<u16, 0>), dim3(nb), dim3(256), 0, s, (const u16*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace, rpb);
     }
   }
-  hipLaunchKernelGGL(k_bn_final_finalize, dim3(u3d_cdiv(c, 8)), dim3(FIN_THREADS), 0, s, (const double*)workspace, nb, ST_ROWS_PER_BLOCK, n_dev, n_cap, c,
+  hipLaunchKernelGGL(k_bn_final_finalize, dim3(u3d_cdiv(c, 8)), dim3(FIN_THREADS), 0, s, (const double*)workspace, nb, rpb, n_dev, n_cap, c,
                      eps, momentum, running_mean, running_var, (long long*)num_batches, mean, invstd);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
