@@ -20,9 +20,12 @@ __device__ __forceinline__ void st_elem(u16* p, long long i, float v) {
 // row lanes (LDS) -> partial[block][2][C] (f64); stage 2 sums the blocks in order (deterministic).
 // MODE 0: (x, x^2).  MODE 1: g = dy*(relu? y>0), (g, g*xhat).   Requires C % VEC == 0 (else the scalar kernel).
 // ---------------------------------------------------------------------------------------------
-// rows per workgroup of the statistics kernels: 128, but 16 for the smallest tensors (128 left the 12 000-row dense level with 94
-// workgroups: 17 us for 25 MB, 11 us at 16)
-static inline int st_rows_per_block(int n_cap) { return n_cap >= 32768 ? 128 : 16; }      // measured: 48 000 rows are better off at 128 (fewer f64 partials)
+// rows per workgroup of the statistics kernels: by tensor height and width - 16 for the smallest tensors (128 left the 12 000-row
+// dense level with 94 workgroups: 17 us for 25 MB, 11 us at 16), 256 / 512 for the large ones
+static inline int st_rows_per_block(int n_cap, int c) {
+  if (n_cap >= 131072) return c >= 128 ? 256 : 512;     // measured (kernel trace): 192000x256 35 -> 34 us, x128 22 -> 18, 338532x32 28 -> 14,
+  return n_cap >= 32768 ? 128 : 16;                     // and the second stage 9 -> 5 us (half / a quarter of the f64 partials)
+}
 
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { static constexpr int N = 4; };
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_col_stats_final(const double* _
 }
 
 extern "C" int64_t u3d_bn_stats_workspace(int32_t n_cap, int32_t c) {
-  return (int64_t)u3d_cdiv(n_cap > 0 ? n_cap : 1, st_rows_per_block(n_cap)) * 2 * c * 8;
+  return (int64_t)u3d_cdiv(n_cap > 0 ? n_cap : 1, st_rows_per_block(n_cap, c)) * 2 * c * 8;
 }
 
 template <int MODE>
@@ -245,7 +248,7 @@ static int run_stats(const void* x, const void* dy, const void* y, const float* 
   U3D_REQUIRE(!row_map || (dtype == U3D_F32 ? c % 4 == 0 : c % 8 == 0), U3D_ERR_UNSUPPORTED);   // mapped rows: vector kernels only
   if (n_cap <= 0) { hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, s); return U3D_OK; }
   U3D_REQUIRE(ws_bytes >= u3d_bn_stats_workspace(n_cap, c), U3D_ERR_WORKSPACE);
-  const int rpb = st_rows_per_block(n_cap);
+  const int rpb = st_rows_per_block(n_cap, c);
   int nb = u3d_cdiv(n_cap, rpb);
   const bool pal = al16(mean) && al16(invstd) && al16(gamma) && al16(beta);      // nullptr counts as aligned
   U3D_REQUIRE(!row_map || pal, U3D_ERR_ARG);
@@ -535,7 +538,7 @@ extern "C" int32_t u3d_bn_forward_stats(const void* x, const int32_t* n_dev, int
                                         float* invstd, void* workspace, int64_t workspace_bytes, u3d_stream s) {
   U3D_REQUIRE(x && n_dev && mean && invstd && workspace && c > 0 && (!running_mean || running_var), U3D_ERR_ARG);
   U3D_REQUIRE(workspace_bytes >= u3d_bn_stats_workspace(n_cap, c), U3D_ERR_WORKSPACE);
-  const int rpb = st_rows_per_block(n_cap);
+  const int rpb = st_rows_per_block(n_cap, c);
   const int nb = n_cap > 0 ? u3d_cdiv(n_cap, rpb) : 0;
   if (nb > 0) {
     const bool f32 = dtype == U3D_F32;
