@@ -863,10 +863,118 @@ extern "C" int32_t u3d_igemm_fwd_stats_bf16(const void* in, const void* w, const
 }
 
 // returns U3D_ERR_UNSUPPORTED when the shape is better served by the first-generation kernel
+
+// =============================================================================================
+// The encoder's input convolution: 4 point features (padded to 8) -> 16 channels, 27 offsets, ~128 k rows
+// (ref: sparse_encoder_hd.py:80-88).  0.9 GFLOP: far too small for a tiled MFMA kernel (the first-generation kernel spent 166 us on
+// it, its weight gradient 126 us) - plain VALU, one thread per output row, weights (27 x 8 x 16 f32 = 13.5 KB) in LDS read by
+// broadcast; rows without a neighbour at an offset skip it (6 % of the (offset,row) pairs exist at this level).
+// =============================================================================================
+#define CONVIN_CIN 8
+#define CONVIN_COUT 16
+#define CONVIN_MAXK 27
+#define CONVIN_WG_ROWS 128          /* rows per workgroup of the weight-gradient kernel */
+
+__device__ __forceinline__ float convin_bf(u16 v) { return __uint_as_float((unsigned)v << 16); }
+
+__global__ __launch_bounds__(256) void k_conv_in_fwd(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
+                                                     int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
+                                                     int kvol) {
+  __shared__ __attribute__((aligned(16))) float ws[CONVIN_MAXK * CONVIN_CIN * CONVIN_COUT];
+  for (int i = threadIdx.x; i < kvol * CONVIN_CIN * CONVIN_COUT; i += 256) ws[i] = convin_bf(w[i]);
+  __syncthreads();
+  const int n = min(*n_out_dev, n_out_cap);
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= n) return;
+  float acc[CONVIN_COUT];
+#pragma unroll
+  for (int co = 0; co < CONVIN_COUT; ++co) acc[co] = 0.f;
+  int idxs[CONVIN_MAXK];                       // all offsets' indices first: 27 independent loads in flight, not 27 round trips
+#pragma unroll
+  for (int k = 0; k < CONVIN_MAXK; ++k) idxs[k] = k < kvol ? (nbr ? nbr[(long long)k * ld + m] : m) : -1;
+#pragma unroll
+  for (int k = 0; k < CONVIN_MAXK; ++k) {
+    const int idx = idxs[k];
+    if (idx < 0) continue;
+    const uint4 xv = *(const uint4*)(in + (long long)idx * CONVIN_CIN);
+    const unsigned xw[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float* wk = ws + k * CONVIN_CIN * CONVIN_COUT;
+#pragma unroll
+    for (int ci = 0; ci < CONVIN_CIN; ++ci) {
+      const float x = (ci & 1) ? __uint_as_float(xw[ci >> 1] & 0xffff0000u) : __uint_as_float(xw[ci >> 1] << 16);
+#pragma unroll
+      for (int q = 0; q < CONVIN_COUT / 4; ++q) {
+        const float4 wv = *(const float4*)(wk + ci * CONVIN_COUT + q * 4);
+        acc[q * 4 + 0] += x * wv.x; acc[q * 4 + 1] += x * wv.y; acc[q * 4 + 2] += x * wv.z; acc[q * 4 + 3] += x * wv.w;
+      }
+    }
+  }
+  typedef float f32x8_t __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x8_t f = {acc[h * 8], acc[h * 8 + 1], acc[h * 8 + 2], acc[h * 8 + 3], acc[h * 8 + 4], acc[h * 8 + 5], acc[h * 8 + 6], acc[h * 8 + 7]};
+    *(bf16x8_t*)(out + (long long)m * CONVIN_COUT + h * 8) = __builtin_convertvector(f, bf16x8_t);
+  }
+}
+
+// weight gradient: dW[k][ci][:] = sum_rows in[nbr[k][row]][ci] * dout[row][:].  A workgroup owns CONVIN_WG_ROWS output rows (their
+// dout staged in LDS), thread (k, ci) walks them branch-free (absent neighbour -> factor 0) with the index and input loads of
+// several rows in flight; per-workgroup partials [blocks][K*8*16] are summed in order by k_igemm_wgrad_reduce.
+__global__ __launch_bounds__(256) void k_conv_in_wgrad(const u16* __restrict__ in, const u16* __restrict__ dout, const int* __restrict__ nbr,
+                                                       int ld, float* __restrict__ partial, const int* __restrict__ n_out_dev,
+                                                       int n_out_cap, int kvol) {
+  __shared__ __attribute__((aligned(16))) u16 dys[CONVIN_WG_ROWS * CONVIN_COUT];
+  const int n = min(*n_out_dev, n_out_cap);
+  const int r0 = blockIdx.x * CONVIN_WG_ROWS;
+  const int r1 = min(n, r0 + CONVIN_WG_ROWS);
+  for (int i = threadIdx.x; i < CONVIN_WG_ROWS * 2; i += 256) {
+    const int row = r0 + (i >> 1);
+    uint4 v = {0u, 0u, 0u, 0u};
+    if (row < r1) v = *(const uint4*)(dout + (long long)row * CONVIN_COUT + (i & 1) * 8);
+    *(uint4*)(dys + (i >> 1) * CONVIN_COUT + (i & 1) * 8) = v;
+  }
+  __syncthreads();
+  const int k = threadIdx.x >> 3, ci = threadIdx.x & 7;
+  if (k >= kvol) return;
+  float acc[CONVIN_COUT];
+#pragma unroll
+  for (int co = 0; co < CONVIN_COUT; ++co) acc[co] = 0.f;
+  const int* nk = nbr ? nbr + (long long)k * ld : nullptr;
+  for (int rb = r0; rb < r1; rb += 8) {
+    int idx8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) idx8[j] = (rb + j < r1) ? (nk ? nk[rb + j] : rb + j) : -1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+    const int r = rb + j, idx = idx8[j];
+    if (__builtin_amdgcn_ballot_w64(idx >= 0) == 0) continue;       // none of this wave's 8 offsets has a neighbour for row r (most rows)
+    const float x = idx >= 0 ? convin_bf(in[(long long)idx * CONVIN_CIN + ci]) : 0.f;
+    const uint4 a = *(const uint4*)(dys + (r - r0) * CONVIN_COUT), b = *(const uint4*)(dys + (r - r0) * CONVIN_COUT + 8);
+    const unsigned dw_[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      acc[2 * q] += x * __uint_as_float(dw_[q] << 16);
+      acc[2 * q + 1] += x * __uint_as_float(dw_[q] & 0xffff0000u);
+    }
+    }
+  }
+  float* p = partial + (long long)blockIdx.x * (kvol * CONVIN_CIN * CONVIN_COUT) + (k * CONVIN_CIN + ci) * CONVIN_COUT;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *(float4*)(p + q * 4) = make_float4(acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+}
+static inline bool convin_shape(int cin, int cout, int kvol) { return cin == CONVIN_CIN && cout == CONVIN_COUT && kvol >= 1 && kvol <= CONVIN_MAXK; }
+
 extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,
                                       const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
                                       int32_t transpose_w, u3d_stream s) {
   U3D_REQUIRE(in && w && out && n_out_dev && (nbr || kvol == 1), U3D_ERR_ARG);
+  if (!transpose_w && convin_shape(cin, cout, kvol)) {            // the encoder's input convolution (w = [K][8][16])
+    if (n_out_cap <= 0) return U3D_OK;
+    hipLaunchKernelGGL(k_conv_in_fwd, dim3(u3d_cdiv(n_out_cap, 256)), dim3(256), 0, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev,
+                       n_out_cap, kvol);
+    return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
+  }
 #if IGEMM_SMALL_C
   // 16/32-channel sparse levels (and the 32<->64 transitions): 256-row tiles, one MFMA k-step per stage (BK = 32), the same
   // register-staged, software-pipelined loop as the wide layers - the first-generation kernel it replaces does
@@ -1368,6 +1476,7 @@ static WgPlan wgrad_plan(int n_out_cap, int cin, int cout, int kvol) {
 }
 
 extern "C" int64_t u3d_igemm_wgrad_bf16_workspace(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol) {
+  if (convin_shape(cin, cout, kvol)) return (int64_t)u3d_cdiv(n_out_cap > 0 ? n_out_cap : 1, CONVIN_WG_ROWS) * kvol * cin * cout * 4;
   WgPlan p = wgrad_plan(n_out_cap, cin, cout, kvol);
   return (int64_t)p.nsplit * kvol * cin * cout * 4;
 }
@@ -1410,6 +1519,16 @@ extern "C" int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const 
                                         const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
                                         int32_t out_layout, void* workspace, int64_t workspace_bytes, u3d_stream s) {
   U3D_REQUIRE(in && dout && dw && n_out_dev && workspace && (nbr || kvol == 1), U3D_ERR_ARG);
+  if (convin_shape(cin, cout, kvol) && out_layout == 0) {         // the encoder's input convolution
+    const int nb = u3d_cdiv(n_out_cap > 0 ? n_out_cap : 1, CONVIN_WG_ROWS);
+    const long long nw = (long long)kvol * cin * cout;
+    U3D_REQUIRE(workspace_bytes >= (int64_t)nb * nw * 4, U3D_ERR_WORKSPACE);
+    hipLaunchKernelGGL(k_conv_in_wgrad, dim3(nb), dim3(256), 0, s, (const u16*)in, (const u16*)dout, nbr, ld, (float*)workspace, n_out_dev,
+                       n_out_cap, kvol);
+    hipLaunchKernelGGL(k_igemm_wgrad_reduce, dim3(u3d_cdiv(nw / 4, 256)), dim3(256), 0, s, (const float*)workspace, dw, nw, nb);
+    U3D_CHECK_LAUNCH();
+    return U3D_OK;
+  }
   if (cin % 16 != 0 || cout % 16 != 0) return U3D_ERR_UNSUPPORTED;
   WgPlan p = wgrad_plan(n_out_cap, cin, cout, kvol);
   long long n = (long long)kvol * cin * cout;

@@ -364,7 +364,7 @@ def spconv_wgrad(inp, dout, nbr, n_out_dev, kvol, out_oik=False):
         meta = dict(kind=CALL_KIND, v2=bool(inp.dtype == torch.bfloat16 and USE_IGEMM_V2 and cin % 16 == 0 and cout % 16 == 0),
                     n_in=inp.shape[0], n_out=n_out, cin=cin, cout=cout, kvol=kvol, pairs=pairs,
                     bytes=inp.shape[0] * cin * s + n_out * cout * s + 8 * pairs + kvol * cin * cout * 4, flops=2 * pairs * cin * cout)
-    if inp.dtype == torch.bfloat16 and USE_IGEMM_V2 and cin % 16 == 0 and cout % 16 == 0:
+    if inp.dtype == torch.bfloat16 and USE_IGEMM_V2 and ((cin % 16 == 0 and cout % 16 == 0) or (cin == 8 and cout == 16 and not out_oik and kvol <= 27)):
         wsb = int(lib().u3d_igemm_wgrad_bf16_workspace(n_out, cin, cout, kvol))
         ws = torch.empty(wsb, dtype=torch.uint8, device=inp.device)
         ld = nbr.shape[1] if nbr is not None else 0
