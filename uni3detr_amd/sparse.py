@@ -4,6 +4,9 @@ sparse-conv / BatchNorm1d / dense() kernels.  Every op calls libu3d_hip.so; noth
 Replaces spconv's SparseConvTensor / indice_key machinery used by the reference encoder
 (ref: models/pts_encoder/sparse_encoder_hd.py:106-138).
 """
+import contextlib
+import os
+
 import torch
 
 from . import native as nv
@@ -81,6 +84,33 @@ NMAJOR_FWD = _os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
 STRIDED_SPLIT_MIN_RATIO = int(_os.environ.get("U3D_STRIDED_SPLIT_MIN_RATIO", "16"))
 
 
+# Weight gradients on a side stream (opt-in, see wgrad_side_stream()): dW of a conv is off the backward's critical chain
+# (dy -> BN backward -> dgrad -> ...), so it can run next to the HBM-bound BatchNorm kernels of the layers below instead of in front
+# of them.  Operands are kept alive until the join (no allocator reuse while the side stream still reads them).
+# Measured in the captured step: 27.0 vs 26.45 ms - the two MFMA kernels running side by side cost more than the BatchNorm overlap
+# gains (as with the parallel SECOND3D branches, plugin/dense.py) -> off by default.
+WGRAD_SIDE = os.environ.get("U3D_WGRAD_SIDE", "0") == "1"
+_WG = {"active": False, "stream": None, "pending": []}
+
+
+@contextlib.contextmanager
+def wgrad_side_stream():
+    """Backward passes inside this block launch conv weight gradients on a side stream; the block joins it before returning
+    (the gradients are valid on the current stream afterwards)."""
+    if not (WGRAD_SIDE and torch.cuda.is_available()):
+        yield
+        return
+    if _WG["stream"] is None:
+        _WG["stream"] = torch.cuda.Stream()
+    _WG["active"] = True
+    try:
+        yield
+    finally:
+        _WG["active"] = False
+        torch.cuda.current_stream().wait_stream(_WG["stream"])
+        _WG["pending"].clear()
+
+
 class _SparseConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, weight, geom, layout, want_stats=False):
@@ -123,16 +153,8 @@ class _SparseConv(torch.autograd.Function):
         kvol = wc.shape[0]
         din = dw = None
         nv.CALL_KIND = g.kind
-        if ctx.needs_input_grad[0]:
-            nbr = g.nbr_bwd if kvol > 1 else None
-            cin, cout = wc.shape[1], wc.shape[2]
-            if (STRIDED_DGRAD_SPLIT and g.strided and kvol > 1 and dout.dtype == torch.bfloat16 and cout % 64 == 0
-                    and (kvol * cin) % 64 == 0 and g.n_out * STRIDED_SPLIT_MIN_RATIO <= g.n_in):      # stride 4: 15/16 of the direct dgrad's MFMAs hit zero rows
-                prod = nv.linear_bf16(dout, wc.view(kvol * cin, cout), None, False)      # [n_out, K*Cin]
-                din = nv.tap_gather_sum(prod, nbr, g.n_in_dev, g.n_in, cin, kvol)
-            else:
-                din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True)
-        if ctx.needs_input_grad[1]:
+
+        def weight_grad():
             nbr = g.nbr_fwd if kvol > 1 else None
             cin_w, cout_w = wc.shape[1], wc.shape[2]
             if (ctx.layout == "oidhw" and feats.dtype == torch.bfloat16 and nv.USE_IGEMM_V2 and cin_w % 16 == 0 and cout_w % 16 == 0
@@ -144,6 +166,26 @@ class _SparseConv(torch.autograd.Function):
                 dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol).reshape(ctx.kio_shape).to(ctx.wdtype)
                 if ctx.layout == "oidhw":
                     dw = dw.permute(4, 3, 0, 1, 2)
+            return dw
+
+        if ctx.needs_input_grad[1]:
+            if _WG["active"] and dout.is_cuda:
+                side = _WG["stream"]
+                side.wait_stream(torch.cuda.current_stream())          # dout is ready on the current stream
+                with torch.cuda.stream(side):
+                    dw = weight_grad()
+                _WG["pending"].append((feats, dout, dw))
+            else:
+                dw = weight_grad()
+        if ctx.needs_input_grad[0]:
+            nbr = g.nbr_bwd if kvol > 1 else None
+            cin, cout = wc.shape[1], wc.shape[2]
+            if (STRIDED_DGRAD_SPLIT and g.strided and kvol > 1 and dout.dtype == torch.bfloat16 and cout % 64 == 0
+                    and (kvol * cin) % 64 == 0 and g.n_out * STRIDED_SPLIT_MIN_RATIO <= g.n_in):      # stride 4: 15/16 of the direct dgrad's MFMAs hit zero rows
+                prod = nv.linear_bf16(dout, wc.view(kvol * cin, cout), None, False)      # [n_out, K*Cin]
+                din = nv.tap_gather_sum(prod, nbr, g.n_in_dev, g.n_in, cin, kvol)
+            else:
+                din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True)
         return din, dw, None, None, None
 
 

@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 
 from . import native as nv
+from . import sparse as _sp
 from .plugin import transformer as _T
 
 
@@ -97,7 +98,7 @@ class TrainStep:
         if loss is None or not all("loss" in k for k in losses):
             loss = sum(v for k, v in losses.items() if "loss" in k)
         self.model.pts_bbox_head._loss_total = None
-        with _T.deferred_param_grads():          # dW / db of the decoder + head linears: queued, then one batched launch per shape
+        with _sp.wgrad_side_stream(), _T.deferred_param_grads():      # dW / db of the decoder + head linears: queued, then one batched launch per shape
             loss.backward()
         self.loss = loss.detach()
         dst, src, missing = [], [], []
