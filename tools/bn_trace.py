@@ -1,3 +1,6 @@
+"""BatchNorm row kernels on ONE tensor shape, 30 iterations, no timing of its own: run it under
+`rocprofv3 --kernel-trace --stats -- python tools/bn_trace.py <rows> <channels>` to get DEVICE durations per kernel
+(tools/bn_bench.py's event timings are host-bound below ~50 MB: the ctypes call + two allocations take longer than the kernel)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from uni3detr_amd import native as nv
