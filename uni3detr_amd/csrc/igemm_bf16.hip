@@ -963,6 +963,28 @@ __global__ __launch_bounds__(256) void k_conv_in_wgrad(const u16* __restrict__ i
 #pragma unroll
   for (int q = 0; q < 4; ++q) *(float4*)(p + q * 4) = make_float4(acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
 }
+// few outputs (K*8*16 = 3456), many partials (one per 128 rows): 64 columns x 16 partial-lanes per workgroup, fixed order
+__global__ __launch_bounds__(1024) void k_conv_in_reduce(const float* __restrict__ partial, float* __restrict__ dw, int n, int nsplit) {
+  __shared__ float red[16][64];
+  const int c = threadIdx.x & 63, lane = threadIdx.x >> 6, col = blockIdx.x * 64 + c;
+  float a = 0.f, b = 0.f, cc = 0.f, d = 0.f;
+  if (col < n) {
+    const float* p = partial + col;
+    int k = lane;
+    for (; k + 48 < nsplit; k += 64) {
+      a += p[(long long)k * n]; b += p[(long long)(k + 16) * n]; cc += p[(long long)(k + 32) * n]; d += p[(long long)(k + 48) * n];
+    }
+    for (; k < nsplit; k += 16) a += p[(long long)k * n];
+  }
+  red[lane][c] = (a + b) + (cc + d);
+  __syncthreads();
+  if (threadIdx.x < 64 && col < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += red[j][threadIdx.x];
+    dw[col] = s;
+  }
+}
 static inline bool convin_shape(int cin, int cout, int kvol) { return cin == CONVIN_CIN && cout == CONVIN_COUT && kvol >= 1 && kvol <= CONVIN_MAXK; }
 
 extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,
@@ -1390,14 +1412,27 @@ U3D_WGRAD_BATCH_KERNEL(k_wgrad_batch_256, 2, 4, 8, 4)
 U3D_WGRAD_BATCH_KERNEL(k_wgrad_batch_128, 2, 2, 4, 4)
 U3D_WGRAD_BATCH_KERNEL(k_wgrad_batch_64, 2, 2, 2, 2)
 #undef U3D_WGRAD_BATCH_KERNEL
+// sum of the `nsplit` partials of one f32x4 in a FIXED order, as four independent chains: eight loads in flight per pass instead of
+// one (the reductions were latency chains: 20 us for 16 MB of partials)
+__device__ __forceinline__ f32x4 wgrad_sum_splits(const float* __restrict__ p, long long stride, int nsplit) {
+  f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, b = a, c = a, d = a;
+  int k = 0;
+  for (; k + 8 <= nsplit; k += 8) {
+    const f32x4 v0 = *(const f32x4*)(p + (long long)k * stride), v1 = *(const f32x4*)(p + (long long)(k + 1) * stride);
+    const f32x4 v2 = *(const f32x4*)(p + (long long)(k + 2) * stride), v3 = *(const f32x4*)(p + (long long)(k + 3) * stride);
+    const f32x4 v4 = *(const f32x4*)(p + (long long)(k + 4) * stride), v5 = *(const f32x4*)(p + (long long)(k + 5) * stride);
+    const f32x4 v6 = *(const f32x4*)(p + (long long)(k + 6) * stride), v7 = *(const f32x4*)(p + (long long)(k + 7) * stride);
+    a += v0; b += v1; c += v2; d += v3; a += v4; b += v5; c += v6; d += v7;
+  }
+  for (; k < nsplit; ++k) a += *(const f32x4*)(p + (long long)k * stride);
+  return (a + b) + (c + d);
+}
+
 __global__ void k_wgrad_batch_reduce(WgradBatch bt, const float* __restrict__ partial, long long n, int nsplit, long long partial_stride) {
   const int b = blockIdx.y;
   long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
-  const float* p = partial + (long long)b * partial_stride;
-  f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < nsplit; ++k) s += *(const f32x4*)(p + (long long)k * n + i);
-  *(f32x4*)(bt.dw[b] + i) = s;
+  *(f32x4*)(bt.dw[b] + i) = wgrad_sum_splits(partial + (long long)b * partial_stride + i, n, nsplit);
 }
 
 typedef void (*wgrad_glds_kernel_t)(const u16*, const u16*, const int*, int, float*, const int*, int, int, int, int, int);
@@ -1405,9 +1440,7 @@ typedef void (*wgrad_glds_kernel_t)(const u16*, const u16*, const int*, int, flo
 __global__ void k_igemm_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, long long n, int nsplit) {
   long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
-  f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < nsplit; ++k) s += *(const f32x4*)(partial + (long long)k * n + i);
-  *(f32x4*)(dw + i) = s;
+  *(f32x4*)(dw + i) = wgrad_sum_splits(partial + i, n, nsplit);
 }
 
 #ifndef IGEMM_WGRAD_MIN_STAGES_K1
@@ -1427,11 +1460,16 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad_reduce_oik(const float* __r
     float s = 0.f;
     if (co0 + col < cout) {
       const float* p = partial + ((long long)k * cin + ci) * cout + co0 + col;
-      float s0 = 0.f, s1 = 0.f;
+      float a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = 0.f;
       int sp = 0;
-      for (; sp + 1 < nsplit; sp += 2) { s0 += p[(long long)sp * n]; s1 += p[(long long)(sp + 1) * n]; }
-      if (sp < nsplit) s0 += p[(long long)sp * n];
-      s = s0 + s1;
+      for (; sp + 8 <= nsplit; sp += 8) {            // eight independent loads in flight, fixed summation order
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += p[(long long)(sp + j) * n];
+      }
+      for (; sp < nsplit; ++sp) a[0] += p[(long long)sp * n];
+      s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     tile[col][k - k0] = s;
   }
@@ -1525,7 +1563,7 @@ extern "C" int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const 
     U3D_REQUIRE(workspace_bytes >= (int64_t)nb * nw * 4, U3D_ERR_WORKSPACE);
     hipLaunchKernelGGL(k_conv_in_wgrad, dim3(nb), dim3(256), 0, s, (const u16*)in, (const u16*)dout, nbr, ld, (float*)workspace, n_out_dev,
                        n_out_cap, kvol);
-    hipLaunchKernelGGL(k_igemm_wgrad_reduce, dim3(u3d_cdiv(nw / 4, 256)), dim3(256), 0, s, (const float*)workspace, dw, nw, nb);
+    hipLaunchKernelGGL(k_conv_in_reduce, dim3(u3d_cdiv((int)nw, 64)), dim3(1024), 0, s, (const float*)workspace, dw, (int)nw, nb);
     U3D_CHECK_LAUNCH();
     return U3D_OK;
   }
