@@ -22,6 +22,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef IGEMM_SMALL_C
 #define IGEMM_SMALL_C 1
 #endif
+#ifndef GLDS256_CFG
+#define GLDS256_CFG 2, 4, 8, 4   /* waves (rows x cols) and 16x16 blocks per wave (rows x cols) of the 256x256-tile LDS-DMA kernel */
+#endif
 #ifndef GLDS_PIPE
 #define GLDS_PIPE 0     /* 1: unit-level fragment pipeline in the LDS-DMA forward/dgrad kernels (igemm_glds_body); measured time-neutral */
 #endif
@@ -541,7 +544,8 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
                                                     const float* bias, int relu, double* stats) {                                \
     igemm_glds_body<A, B, C, D>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats);                   \
   }
-U3D_GLDS_KERNEL(k_igemm_glds_256x256, 2, 4, 8, 4)
+#define U3D_GLDS_KERNEL_X(NAME, ...) U3D_GLDS_KERNEL(NAME, __VA_ARGS__)
+U3D_GLDS_KERNEL_X(k_igemm_glds_256x256, GLDS256_CFG)
 // (a 4-wave variant with 128 x 128 per wave - 1.5x fewer LDS fragment bytes per MFMA - compiled to 512 VGPRs + spills and ran at
 //  877 vs 1076 TFLOP/s: it needs a hand-scheduled fragment pipeline, not another template instance)
 U3D_GLDS_KERNEL(k_igemm_glds_256x128, 4, 2, 4, 4)
@@ -836,7 +840,7 @@ extern "C" int32_t u3d_linear_bf16(const void* x, const void* w, const float* bi
   if (m_cap <= 0) return U3D_OK;
   // nn.Linear's [N, K] weight IS the n-major layout of the LDS-DMA kernels
   const long long wg256 = (long long)u3d_cdiv(m_cap, 256) * (n / 256);
-  if (n % 256 == 0 && wg256 >= 128) return launch_igemm_glds<2, 4, 8, 4>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
+  if (n % 256 == 0 && wg256 >= 128) return launch_igemm_glds<GLDS256_CFG>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
   if (n % 128 == 0 && (long long)u3d_cdiv(m_cap, 256) * (n / 128) >= 128)
     return launch_igemm_glds<4, 2, 4, 4>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
   return launch_igemm_glds<4, 1, 2, 4>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
@@ -857,7 +861,7 @@ extern "C" int32_t u3d_igemm_fwd_stats_bf16(const void* in, const void* w, const
   U3D_REQUIRE(in && w && out && n_out_dev && stats && (nbr || kvol == 1), U3D_ERR_ARG);
   const int tr = u3d_igemm_fwd_stats_tile_rows(n_out_cap, cin, cout);
   if (tr == 0) return U3D_ERR_UNSUPPORTED;
-  if (tr == 256) return launch_igemm_glds<2, 4, 8, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);
+  if (tr == 256) return launch_igemm_glds<GLDS256_CFG>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);
   if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);
   return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);
 }
@@ -1025,7 +1029,7 @@ extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32
   const long long wg256 = (long long)u3d_cdiv(n_out_cap, 256) * (cout / 256 > 0 ? cout / 256 : 1);
 #if IGEMM_GLDS
   if (transpose_w) {                                                // n-major weights: LDS-DMA staged kernels
-    if (cout % 256 == 0 && wg256 >= 128) return launch_igemm_glds<2, 4, 8, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
+    if (cout % 256 == 0 && wg256 >= 128) return launch_igemm_glds<GLDS256_CFG>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
     // 128 x 128 (4 waves, 64 KiB LDS, two workgroups per CU out of phase): +3...6 % over 256 x 128 on the 128- and 512-channel layers
     if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
     if (cout % 64 == 0) return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
