@@ -78,10 +78,9 @@ def strided_level(lvl, ksize, stride, pad, capacity=None):
     return out, ConvGeom(fwd, bwd, lvl.n, lvl.n_dev, n_out, out.n_dev)
 
 
-import os as _os
-STRIDED_DGRAD_SPLIT = _os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
-NMAJOR_FWD = _os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
-STRIDED_SPLIT_MIN_RATIO = int(_os.environ.get("U3D_STRIDED_SPLIT_MIN_RATIO", "16"))
+STRIDED_DGRAD_SPLIT = os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
+NMAJOR_FWD = os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
+STRIDED_SPLIT_MIN_RATIO = int(os.environ.get("U3D_STRIDED_SPLIT_MIN_RATIO", "16"))
 
 
 # Weight gradients on a side stream (opt-in, see wgrad_side_stream()): dW of a conv is off the backward's critical chain
@@ -194,7 +193,7 @@ def sparse_conv(feats, weight, geom, layout="dhwio"):
     return _SparseConv.apply(feats, weight, geom, layout)
 
 
-FUSED_CONV_STATS = _os.environ.get("U3D_FUSED_CONV_STATS", "1") == "1"
+FUSED_CONV_STATS = os.environ.get("U3D_FUSED_CONV_STATS", "1") == "1"
 
 
 def conv_bn(feats, weight, geom, bn, n_dev, residual=None, relu=True, layout="dhwio", post_add=None):
