@@ -529,3 +529,59 @@ def test_dynamic_voxelize_and_scatter_mean(cuda):
     feats, fcoors = vfe(pts, coors, batch_size=2)
     assert np.array_equal(fcoors.cpu().numpy(), rvox)                  # lexicographic order == torch.unique(dim=0)
     np.testing.assert_allclose(feats.cpu().numpy(), rfeat, rtol=1e-5, atol=1e-5)
+
+
+def test_full_size_dominant_layer_properties(cuda):
+    """The layer `roofline` reports on, at BASELINE.json's full size (8 scenes: 192 000 lattice rows, 256 -> 256 channels, 3x3x3),
+    through the kernels the step uses (n-major forward + epilogue statistics, dgrad, weight gradient): size-independent properties
+    instead of a full oracle run -
+      * forward rows sampled all over the tensor (first / middle / last tiles) == f32 gather-GEMM of the same bf16 operands,
+      * the epilogue's BatchNorm statistics == column sums / sums of squares of the output it wrote,
+      * adjointness <conv(x), dy> == <x, dgrad(dy)> == <W, wgrad(x, dy)>  (one scalar ties the three kernels together),
+      * linearity conv(x1 + x2) == conv(x1) + conv(x2) up to bf16 output rounding."""
+    torch.manual_seed(3)
+    B, dims, C, ks = 8, (15, 40, 40), 256, (3, 3, 3)
+    n = B * dims[0] * dims[1] * dims[2]
+    nbr = nv.dense_nbr_table(B, dims, dims, ks, (1, 1, 1), (1, 1, 1), 0, cuda)
+    nbr_b = nv.dense_nbr_table(B, dims, dims, ks, (1, 1, 1), (1, 1, 1), 1, cuda)
+    nd = nv.count_tensor(n, cuda)
+    x = (torch.randn(n, C, device=cuda) * 0.5).bfloat16()
+    dy = (torch.randn(n, C, device=cuda) * 0.5).bfloat16()
+    w = (torch.randn(27, C, C, device=cuda) * 0.03).bfloat16()            # kio [K, Cin, Cout]
+    koi = w.transpose(1, 2).contiguous()                                  # n-major for the forward kernel
+    res = nv.spconv_fwd_stats(x, koi, nbr, nd, n, C)
+    assert res is not None
+    y, stats, tile_rows = res
+    # (1) sampled rows vs f32 gather-GEMM
+    rows = torch.cat([torch.arange(0, 300, device=cuda), torch.arange(n // 2 - 150, n // 2 + 150, device=cuda), torch.arange(n - 300, n, device=cuda)])
+    exp = torch.zeros(rows.numel(), C, device=cuda)
+    xf = torch.cat([x.float(), torch.zeros(1, C, device=cuda)])
+    for k in range(27):
+        idx = nbr[k, rows].long()
+        idx = torch.where(idx < 0, torch.full_like(idx, n), idx)
+        exp += xf[idx] @ w[k].float()
+    got = y[rows].float()
+    assert (got - exp).abs().max().item() <= 1.5e-2 * exp.abs().max().item()
+    # (2) epilogue statistics vs the stored output (f32 accumulators in the kernel, bf16-rounded output: loose on the squares)
+    yf = y.float()
+    s0, s1 = stats[:, 0].sum(0), stats[:, 1].sum(0)
+    assert stats.shape == ((n + tile_rows - 1) // tile_rows, 2, C)
+    assert torch.allclose(s0.float(), yf.sum(0), rtol=2e-2, atol=2.0)
+    assert torch.allclose(s1.float(), (yf * yf).sum(0), rtol=2e-2)
+    # (3) adjointness across the three kernels
+    dx = nv.spconv_fwd(dy, w, nbr_b, nd, n, C, transpose_w=True)
+    dw = nv.spconv_wgrad(x, dy, nbr, nd, 27)
+    a = (yf.double() * dy.double()).sum().item()
+    b = (x.double() * dx.double()).sum().item()
+    c = (w.double() * dw.double()).sum().item()
+    # y and dx are stored in bf16 (relative rounding 2^-9, random sign): the three sums of ~49 M zero-mean terms agree up to that
+    # rounding noise, whose scale is the root of the summed squares - not the (tiny) net sum
+    noise = ((yf.double() * dy.double()).pow(2).sum() + (x.double() * dx.double()).pow(2).sum()).sqrt().item()
+    assert abs(a - b) <= 1.5e-2 * noise and abs(a - c) <= 1.5e-2 * noise and abs(b - c) <= 1.5e-2 * noise, (a, b, c, noise)
+    # (4) linearity
+    x2 = (torch.randn(n, C, device=cuda) * 0.5).bfloat16()
+    xs = (x.float() + x2.float()).bfloat16()
+    y2 = nv.spconv_fwd(x2, koi, nbr, nd, n, C, transpose_w=True, tag="spconv_fwd")
+    ys = nv.spconv_fwd(xs, koi, nbr, nd, n, C, transpose_w=True, tag="spconv_fwd")
+    lin = (ys.float() - (yf + y2.float()))[rows]
+    assert lin.abs().max().item() <= 4e-2 * ys.float().abs().max().item()
