@@ -25,6 +25,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef GLDS256_CFG
 #define GLDS256_CFG 2, 4, 8, 4   /* waves (rows x cols) and 16x16 blocks per wave (rows x cols) of the 256x256-tile LDS-DMA kernel */
 #endif
+#ifndef GLDS_FRAG_B128
+#define GLDS_FRAG_B128 1   /* fragments as one ds_read_b128 per lane (0: two ds_read_b64 in the instruction's nominal k-order) */
+#endif
 #ifndef GLDS_PIPE
 #define GLDS_PIPE 0     /* 1: unit-level fragment pipeline in the LDS-DMA forward/dgrad kernels (igemm_glds_body); measured time-neutral */
 #endif
@@ -369,6 +372,21 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
     for (int u = 0; u < SEGS_W; ++u)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_ptr)(Wb + u * 512), 16, w_voff[u], w_soff, 0, 0);
   };
+#if GLDS_FRAG_B128
+  // fragment = ONE 16-byte LDS read: lane (g, row li) takes the 8 consecutive reduction elements of part ks*4+g of its row.  The MFMA
+  // only needs A and B to agree on which reduction element sits in which (lane group, position) - both go through this function -
+  // so the nominal k-order of the instruction does not matter.  Conflict-free under the source-side swizzle: in a 16-lane group
+  // (one g, rows 0..15) the slots (ks*4+g) ^ ((row>>1)&7) take all 8 values per row parity = every bank once.
+  const int g = lane >> 4, li = lane & 15, fsw = (lane >> 1) & 7;
+  int foff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) foff[ks] = ((ks * 4 + g) ^ fsw) << 3;
+  typedef const volatile s16x8 __attribute__((address_space(3))) * lds_vptr;
+  auto frag = [&](const u16* rowp, int ks) {
+    s16x8 v = *(lds_vptr)(rowp + foff[ks]);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+#else
   // fragment offsets inside a 64-element row: slot of part (ks*4 + g/2 [+2]) under this lane's row swizzle, plus the 8-byte half
   const int g = lane >> 4, li = lane & 15, fsw = (lane >> 1) & 7;
   int foff[2][2];
@@ -384,6 +402,7 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
     return __builtin_bit_cast(bf16x8, v);
   };
 
+#endif
 #if GLDS_PIPE
   // Fragment pipeline.  A stage (64 reduction elements) is four UNITS: (k-step 0|1) x (lower|upper half of this wave's row blocks);
   // a unit = WM/2 x WN MFMAs on fragments already in registers, issued right after the LDS reads of the NEXT unit's fragments, so
