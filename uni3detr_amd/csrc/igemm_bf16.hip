@@ -25,6 +25,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef GLDS256_CFG
 #define GLDS256_CFG 2, 4, 8, 4   /* waves (rows x cols) and 16x16 blocks per wave (rows x cols) of the 256x256-tile LDS-DMA kernel */
 #endif
+#ifndef WGRAD_DMA_SPREAD
+#define WGRAD_DMA_SPREAD 1   /* the same for the LDS-DMA weight-gradient kernel */
+#endif
+#ifndef GLDS_DMA_SPREAD
+#define GLDS_DMA_SPREAD 2   /* 1: one LDS-DMA instruction behind each MFMA group of the stage, 2: all of them within the first k-step */
+#endif
+#ifndef GLDS_EXP
+#define GLDS_EXP 0          /* timing experiments only (wrong results): 1 no LDS-DMA after the first stage, 2 no fragment reads in the loop, 4 activation rows from a 1024-row (cache-resident) window */
+#endif
 #ifndef GLDS_FRAG_B128
 #define GLDS_FRAG_B128 1   /* fragments as one ds_read_b128 per lane (0: two ds_read_b64 in the instruction's nominal k-order) */
 #endif
@@ -365,7 +374,11 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
     const unsigned w_soff = (unsigned)(kap * cin * cout + c0) * 2u;
 #pragma unroll
     for (int u = 0; u < SEGS_A; ++u) {
+#if GLDS_EXP & 4
+      unsigned voff = idx_cur[u] >= 0 ? (unsigned)(idx_cur[u] & 1023) * row_bytes + a_part16[u] : 0xFFFFFFFFu;      // timing experiment: 1024-row working set (cache hits)
+#else
       unsigned voff = idx_cur[u] >= 0 ? (unsigned)idx_cur[u] * row_bytes + a_part16[u] : 0xFFFFFFFFu;
+#endif
       __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void_ptr)(Ab + u * 512), 16, voff, a_soff, 0, 0);
     }
 #pragma unroll
@@ -373,6 +386,20 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_ptr)(Wb + u * 512), 16, w_voff[u], w_soff, 0, 0);
   };
 #if GLDS_FRAG_B128
+  // one LDS-DMA instruction of stage `st` (q < SEGS_A: activation rows, else weight rows): lets the stage loop feed the address unit
+  // between MFMA groups instead of queueing all of a stage's loads in front of them
+  auto issue_one = [&](int st, int buf, int q) {
+    const int kap = st % kvol, c0 = (st / kvol) * BK;
+    if (q < SEGS_A) {
+      u16* Ab = smem + buf * STAGE_ELEMS + wv * (SEGS_A * 512);
+      unsigned voff = idx_cur[q] >= 0 ? (unsigned)idx_cur[q] * row_bytes + a_part16[q] : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void_ptr)(Ab + q * 512), 16, voff, (unsigned)c0 * 2u, 0, 0);
+    } else {
+      const int u = q - SEGS_A;
+      u16* Wb = smem + buf * STAGE_ELEMS + A_ELEMS + wv * (SEGS_W * 512);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_ptr)(Wb + u * 512), 16, w_voff[u], (unsigned)(kap * cin * cout + c0) * 2u, 0, 0);
+    }
+  };
   // fragment = ONE 16-byte LDS read: lane (g, row li) takes the 8 consecutive reduction elements of part ks*4+g of its row.  The MFMA
   // only needs A and B to agree on which reduction element sits in which (lane group, position) - both go through this function -
   // so the nominal k-order of the instruction does not matter.  Conflict-free under the source-side swizzle: in a 16-lane group
@@ -480,21 +507,44 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
     const int nx = st + 1 < nstage ? st + 1 : st;       // the last stage re-fetches itself into the idle buffer: branch-free body
     advance_idx();
     load_idx_next(st + 2 < nstage ? st + 2 : nstage - 1);
+#if !(GLDS_EXP & 1) && !GLDS_DMA_SPREAD
     issue(nx, buf ^ 1);                                 // in flight during the whole stage; buffer free since the last barrier
+#endif
+#if GLDS_EXP & 2
+    const u16* A = smem + (wm * WM * 16 + li) * BK;     // timing experiment: fragments of stage 0 re-read by every stage -> loop-invariant, hoisted
+    const u16* W = smem + A_ELEMS + (wn * WN * 16 + li) * BK;
+    typedef const s16x8 __attribute__((address_space(3))) * lds_cptr;
+#define GLDS_FRAG(P, KS) __builtin_bit_cast(bf16x8, *(lds_cptr)((P) + foff[KS]))
+#else
     const u16* A = smem + buf * STAGE_ELEMS + (wm * WM * 16 + li) * BK;
     const u16* W = smem + buf * STAGE_ELEMS + A_ELEMS + (wn * WN * 16 + li) * BK;
+#define GLDS_FRAG(P, KS) frag(P, KS)
+#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[WM];
 #pragma unroll
-      for (int a = 0; a < WM; ++a) af[a] = frag(A + a * 16 * BK, ks);
+      for (int a = 0; a < WM; ++a) af[a] = GLDS_FRAG(A + a * 16 * BK, ks);
 #pragma unroll
       for (int b = 0; b < WN; ++b) {
-        bf16x8 bfr = frag(W + b * 16 * BK, ks);
+        bf16x8 bfr = GLDS_FRAG(W + b * 16 * BK, ks);
 #pragma unroll
         // operands swapped: the MFMA produces the TRANSPOSED 16x16 block, i.e. this lane ends up with 4 consecutive output
         // COLUMNS (4g..4g+3) of row li - one 8-byte store per block in the epilogue instead of four 2-byte ones
         for (int a = 0; a < WM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af[a], acc[a][b], 0, 0, 0);
+#if GLDS_DMA_SPREAD && !(GLDS_EXP & 1)
+        {   // the next stage's LDS-DMA instructions, dealt out behind the MFMA groups of the first part of this stage
+          constexpr int NQ = SEGS_A + SEGS_W, NG = (GLDS_DMA_SPREAD == 1) ? 2 * WN : WN;      // groups that carry loads
+          constexpr int PER = (NQ + NG - 1) / NG;
+          const int grp = ks * WN + b;
+          if (grp < NG) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+              if (grp * PER + j < NQ) issue_one(nx, buf ^ 1, grp * PER + j);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
       }
     }
     __syncthreads();                                    // also drains this wave's LDS-DMA (vmcnt) before anyone reads the next buffer
@@ -1358,6 +1408,24 @@ __device__ __forceinline__ void igemm_wgrad_glds_body(const u16* __restrict__ in
     }
     load_src_next(t + 1);
   };
+  // one LDS-DMA instruction of stage t (q < A_SEGS: gathered input rows, else gradient rows), dealt out behind MFMA groups (see
+  // GLDS_DMA_SPREAD in the forward kernel: a stage's loads queued in front of its MFMAs hold the waves at the address unit)
+  auto issue_one = [&](int t, int buf, int q) {
+    const int r0 = t * RK;
+    const bool live = t < t_end;
+    if (q < A_SEGS) {
+      u16* Ab = smem + buf * STAGE_ELEMS + wv * (A_SEGS * 512);
+      const bool ok = live && (r0 + a_row[q] < n_out) && src_nxt[q] >= 0;
+      unsigned voff = ok ? (unsigned)src_nxt[q] * in_row_bytes + a_col[q] : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void_ptr)(Ab + q * 512), 16, voff, 0, 0, 0);
+    } else {
+      const int u = q - A_SEGS;
+      u16* Db = smem + buf * STAGE_ELEMS + A_ELEMS + wv * (D_SEGS * 512);
+      const int m = r0 + d_row[u];
+      unsigned voff = (live && m < n_out) ? (unsigned)m * d_row_bytes + d_col[u] : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rs, (lds_void_ptr)(Db + u * 512), 16, voff, 0, 0, 0);
+    }
+  };
   // reader role: transpose-read fragments; this lane's rows are k0 + 4g + j (+16): y = (4g + j) & 7
   const int g = lane >> 4, L = lane & 15, j = L >> 2, q = L & 3;
   const int ya = ((4 * g + j) & 7) & A_YMASK, yd = ((4 * g + j) & 7) & D_YMASK;
@@ -1375,7 +1443,20 @@ __device__ __forceinline__ void igemm_wgrad_glds_body(const u16* __restrict__ in
     __syncthreads();
     for (int t = t_begin; t < t_end; ++t) {
       const int buf = (t - t_begin) & 1;
-      issue(t + 1, buf ^ 1);                            // past the last stage: all offsets out of range -> zeros into the idle buffer
+      // spreading pays on the 256 x 256 tile only (measured per tile size: +4.5 % there, a loss at step level when applied to all)
+      constexpr bool SPREAD = WGRAD_DMA_SPREAD && TM >= 256 && TN >= 256;
+      int src_nn[A_SEGS];                               // gather indices of stage t+2: requested now, moved into src_nxt at the end of the stage
+      if constexpr (!SPREAD) {
+        issue(t + 1, buf ^ 1);                          // past the last stage: all offsets out of range -> zeros into the idle buffer
+      } else {
+        const int r0n = (t + 2) * RK;
+#pragma unroll
+        for (int u = 0; u < A_SEGS; ++u) {
+          int m = r0n + a_row[u];
+          int mc = m < n_out ? m : n_out - 1;
+          src_nn[u] = nbr ? nbr[(long long)kap * ld + mc] : mc;
+        }
+      }
       const u16* A = smem + buf * STAGE_ELEMS;
       const u16* D = A + A_ELEMS;
 #pragma unroll
@@ -1388,7 +1469,18 @@ __device__ __forceinline__ void igemm_wgrad_glds_body(const u16* __restrict__ in
           bf16x8 af = trf(A, TM, ks * 32, wm * WM + a, ya);
 #pragma unroll
           for (int b = 0; b < WN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af, acc[a][b], 0, 0, 0);   // transposed block
+          if constexpr (SPREAD) if (ks == 0) {            // the next stage's loads behind the MFMA groups of the first k-step
+            constexpr int NQ = A_SEGS + D_SEGS, PER = (NQ + WM - 1) / WM;
+#pragma unroll
+            for (int jq = 0; jq < PER; ++jq)
+              if (a * PER + jq < NQ) issue_one(t + 1, buf ^ 1, a * PER + jq);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
+      }
+      if constexpr (SPREAD) {
+#pragma unroll
+        for (int u = 0; u < A_SEGS; ++u) src_nxt[u] = src_nn[u];
       }
       __syncthreads();
     }
