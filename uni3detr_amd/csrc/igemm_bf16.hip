@@ -534,7 +534,7 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
         for (int a = 0; a < WM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af[a], acc[a][b], 0, 0, 0);
 #if GLDS_DMA_SPREAD && !(GLDS_EXP & 1)
         {   // the next stage's LDS-DMA instructions, dealt out behind the MFMA groups of the first part of this stage
-          constexpr int NQ = SEGS_A + SEGS_W, NG = (GLDS_DMA_SPREAD == 1) ? 2 * WN : WN;      // groups that carry loads
+          constexpr int NQ = SEGS_A + SEGS_W, NG = (GLDS_DMA_SPREAD == 1) ? 2 * WN : (GLDS_DMA_SPREAD == 3 ? (WN > 1 ? WN / 2 : 1) : (GLDS_DMA_SPREAD == 4 ? WN + WN / 2 : WN));      // groups that carry loads
           constexpr int PER = (NQ + NG - 1) / NG;
           const int grp = ks * WN + b;
           if (grp < NG) {
