@@ -151,6 +151,14 @@ int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32_t* nbr, in
  * models/dense_heads/uni3detr_head.py:365-387.)  U3D_ERR_UNSUPPORTED unless K % 64 == 0 and N % 64 == 0. */
 int32_t u3d_linear_bf16(const void* x, const void* w, const float* bias, int32_t relu, void* out, const int32_t* m_dev,
                         int32_t m_cap, int32_t k, int32_t n, u3d_stream s);
+/* Dense-lattice forward / input gradient of a (kd,3,3) "same"-padded stride-1 convolution (SECOND3D / SECOND3DFPN dense blocks, ref:
+ * second_3d.py:52-76, second3d_fpn.py:77-100): rows = batch*D*H*W cells in (b,z,y,x) order, channels-last bf16.  No neighbour table:
+ * the nine in-plane offsets of a 256-row tile read ONE LDS window of 256 + 2W + 2 rows per (64-channel slice, z-offset).
+ * w n-major [kd*9][Cout][Cin]; transposed != 0 computes the input gradient (pass [K][Cin][Cout]).  stats: NULL or f64
+ * [ceil(rows/256)][2][Cout] per-tile BatchNorm sums as u3d_igemm_fwd_stats_bf16.  Returns U3D_ERR_UNSUPPORTED unless
+ * kd in {1,3}, Cin % 64 == 0, Cout % 256 == 0, W <= 43. */
+int32_t u3d_igemm_lattice_bf16(const void* in, const void* w, void* out, int32_t batch, int32_t D, int32_t H, int32_t W,
+                               int32_t cin, int32_t cout, int32_t kd, int32_t transposed, double* stats, u3d_stream s);
 /* Forward with n-major weights w[K][Cout][Cin] (the layout u3d_igemm_fwd_bf16 takes with transpose_w = 1) that also emits the
  * BatchNorm statistics of its (bf16-rounded) output per row tile: stats f64 [ceil(n_out_cap / T)][2][Cout] with
  * T = u3d_igemm_fwd_stats_tile_rows(...) (0: shape not served - use u3d_igemm_fwd_bf16 + u3d_bn_stats).  Feeds

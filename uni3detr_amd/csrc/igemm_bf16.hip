@@ -301,6 +301,72 @@ static int launch_igemm_fwd(const void* in, const void* w, const int32_t* nbr, i
 #endif
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
+// Epilogue shared by the LDS-DMA forward/dgrad kernels: bias / ReLU, bf16 store (transposed accumulator: 4 consecutive columns per
+// lane), optional per-tile BatchNorm statistics.
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__device__ __forceinline__ void glds_epilogue(f32x4 (&acc)[WM][WN], u16* smem, int m0, int col0, int tile, int n_out, int cout,
+                                              u16* __restrict__ out, const float* __restrict__ bias, int relu, double* __restrict__ stats) {
+  constexpr int NW = WAVES_M * WAVES_N, BN = WAVES_N * WN * 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+  const int g = lane >> 4, li = lane & 15;
+  // epilogue: acc[a][b][r] = C[row (wm*WM+a)*16 + li][col (wn*WN+b)*16 + 4g + r]; v_cvt_pk_bf16_f32 (RNE) via convertvector
+  f32x4 cs[WN], cq[WN];                                 // BatchNorm statistics of this wave's rows: column sums / sums of squares
+#pragma unroll
+  for (int b = 0; b < WN; ++b) { cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int a = 0; a < WM; ++a) {
+    const int m = m0 + (wm * WM + a) * 16 + li;
+    if (m >= n_out) continue;
+#pragma unroll
+    for (int b = 0; b < WN; ++b) {
+      const int col = col0 + (wn * WN + b) * 16 + 4 * g;
+      if (col < cout) {                                 // cout % 8 == 0: the 4-column group is in or out as a whole
+        f32x4 v = acc[a][b];
+        if (bias) { const f32x4 bv = *(const f32x4*)(bias + col); v += bv; }
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        const bf16x4 o = __builtin_convertvector(v, bf16x4);
+        *(bf16x4*)(out + (long long)m * cout + col) = o;
+        if (stats) {                                    // statistics of the ROUNDED values: what the BatchNorm that follows reads
+          const f32x4 vr = __builtin_convertvector(o, f32x4);
+          cs[b] += vr;
+          cq[b] += vr * vr;
+        }
+      }
+    }
+  }
+  if (stats) {
+    // the BatchNorm behind this conv needs per-column sum / sum of squares over ALL rows: reduce this tile here (16 lanes of a
+    // column group by shuffles, the row waves through LDS) and leave one f64 partial per (row tile, column) - the separate
+    // statistics pass over the output (one full read of the tensor) disappears
+    float* red = (float*)smem;                          // [WAVES_M][2][BN] floats; the stage buffers are dead after the last barrier
+#pragma unroll
+    for (int b = 0; b < WN; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = cs[b][r], s2 = cq[b][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (li == 0) {
+          const int cl = (wn * WN + b) * 16 + 4 * g + r;
+          red[(wm * 2 + 0) * BN + cl] = s1;
+          red[(wm * 2 + 1) * BN + cl] = s2;
+        }
+      }
+    __syncthreads();
+    for (int t = tid; t < 2 * BN; t += NW * 64) {
+      const int which = t / BN, cl = t % BN;
+      if (col0 + cl < cout) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < WAVES_M; ++k) a += (double)red[(k * 2 + which) * BN + cl];
+        stats[((long long)tile * 2 + which) * cout + col0 + cl] = a;
+      }
+    }
+  }
+}
+
 template <int WAVES_M, int WAVES_N, int WM, int WN>
 __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
                                                 int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
@@ -550,60 +616,7 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
     __syncthreads();                                    // also drains this wave's LDS-DMA (vmcnt) before anyone reads the next buffer
   }
 #endif
-  // epilogue: acc[a][b][r] = C[row (wm*WM+a)*16 + li][col (wn*WN+b)*16 + 4g + r]; v_cvt_pk_bf16_f32 (RNE) via convertvector
-  f32x4 cs[WN], cq[WN];                                 // BatchNorm statistics of this wave's rows: column sums / sums of squares
-#pragma unroll
-  for (int b = 0; b < WN; ++b) { cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-  for (int a = 0; a < WM; ++a) {
-    const int m = m0 + (wm * WM + a) * 16 + li;
-    if (m >= n_out) continue;
-#pragma unroll
-    for (int b = 0; b < WN; ++b) {
-      const int col = col0 + (wn * WN + b) * 16 + 4 * g;
-      if (col < cout) {                                 // cout % 8 == 0: the 4-column group is in or out as a whole
-        f32x4 v = acc[a][b];
-        if (bias) { const f32x4 bv = *(const f32x4*)(bias + col); v += bv; }
-        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        const bf16x4 o = __builtin_convertvector(v, bf16x4);
-        *(bf16x4*)(out + (long long)m * cout + col) = o;
-        if (stats) {                                    // statistics of the ROUNDED values: what the BatchNorm that follows reads
-          const f32x4 vr = __builtin_convertvector(o, f32x4);
-          cs[b] += vr;
-          cq[b] += vr * vr;
-        }
-      }
-    }
-  }
-  if (stats) {
-    // the BatchNorm behind this conv needs per-column sum / sum of squares over ALL rows: reduce this tile here (16 lanes of a
-    // column group by shuffles, the row waves through LDS) and leave one f64 partial per (row tile, column) - the separate
-    // statistics pass over the output (one full read of the tensor) disappears
-    float* red = (float*)smem;                          // [WAVES_M][2][BN] floats; the stage buffers are dead after the last barrier
-#pragma unroll
-    for (int b = 0; b < WN; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s1 = cs[b][r], s2 = cq[b][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        if (li == 0) {
-          const int cl = (wn * WN + b) * 16 + 4 * g + r;
-          red[(wm * 2 + 0) * BN + cl] = s1;
-          red[(wm * 2 + 1) * BN + cl] = s2;
-        }
-      }
-    __syncthreads();
-    for (int t = tid; t < 2 * BN; t += NW * 64) {
-      const int which = t / BN, cl = t % BN;
-      if (col0 + cl < cout) {
-        double a = 0.0;
-#pragma unroll
-        for (int k = 0; k < WAVES_M; ++k) a += (double)red[(k * 2 + which) * BN + cl];
-        stats[((long long)tile * 2 + which) * cout + col0 + cl] = a;
-      }
-    }
-  }
+  glds_epilogue<WAVES_M, WAVES_N, WM, WN>(acc, smem, m0, col0, tile, n_out, cout, out, bias, relu, stats);
 }
 
 // concrete kernels (a __global__ TEMPLATE with this body lost its host stub under hipcc 7.2: undefined symbol at load time)
@@ -636,6 +649,176 @@ static int launch_igemm_glds(const void* in, const void* w, const int32_t* nbr, 
   dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin,
                      cout, kvol, bias, relu, stats);
+  return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
+}
+
+// =============================================================================================
+// Dense-lattice forward / dgrad: 3x3 in-plane kernels on a full [B, D, H, W] lattice (SECOND3D / FPN), stride 1, "same" padding.
+// k_igemm_glds re-loads the 256-row activation tile for every offset: 27 x 32 KiB per 64-channel slice, and the LDS-DMA stream is
+// what that kernel pays for (1150 -> 1550 TF/s without it).  On a lattice the nine in-plane neighbours of rows
+// m0..m0+255 are rows of ONE window [m0 - W - 1, m0 + 255 + W + 1] of the same z-plane: the window (256 + 2W + 2 rows) is loaded once
+// per (channel slice, z-offset) and all nine offsets read their fragments from it at shifted rows; rows whose neighbour falls off
+// the lattice get a zero fragment (27-bit validity mask per row, computed from the cell coordinates).  LDS-DMA bytes per slice:
+// 27 x 32 (weights) + 3 x 43 (windows) = 993 KiB instead of 27 x 64 = 1728 KiB.
+// Same tile / wave layout, weight tiles, swizzle and epilogue as k_igemm_glds_256x256 (8 waves as 2 x 4, 128 x 64 per wave).
+// =============================================================================================
+struct LatGeom { int D, H, W, kd, sign; };     // kd: kernel extent in z (1 or 3); sign +1 forward (gather at +offset), -1 dgrad (transposed table)
+#define LAT_WIN_ROWS 344                        /* 256 + 2*W + 2 rows rounded up to 8, W <= 43 */
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__device__ __forceinline__ void igemm_lattice_body(const u16* __restrict__ in, const u16* __restrict__ w, u16* __restrict__ out,
+                                                   int n_rows, int cin, int cout, LatGeom lg, const float* __restrict__ bias, int relu,
+                                                   double* __restrict__ stats) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, BK = 64;
+  constexpr int WIN_ELEMS = LAT_WIN_ROWS * BK, W_ELEMS = BN * BK;
+  constexpr int WIN_SEGS = LAT_WIN_ROWS / 8;                       // wave-instructions (8 rows x 128 B) per window
+  constexpr int WIN_PER_WAVE = (WIN_SEGS + NW - 1) / NW;
+  constexpr int SEGS_W = BN / 8 / NW;
+  static_assert(BM == 256 && WIN_PER_WAVE <= 9, "window loads ride on the nine in-plane stages");
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];      // [2 windows][2 weight tiles]
+  u16* const win_base = smem;
+  u16* const wt_base = smem + 2 * WIN_ELEMS;
+
+  const int n_out = n_rows;
+  const int ntile = gridDim.x;
+  const int xq = ntile >> 3, xr = ntile & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+  const int m0 = tile * BM;
+  if (m0 >= n_out) return;
+  const int col0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+  const int kchunks = cin / BK;
+  const int HW = lg.H * lg.W, pz = lg.kd / 2;
+  const int ngroup = kchunks * lg.kd;                             // (channel slice, z-offset) pairs, nine stages each
+  const int nstage = ngroup * 9;
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, -1, 0x00020000);
+  const unsigned row_bytes = (unsigned)cin * 2u;
+  const int lrow = lane >> 3, lslot = lane & 7;
+  unsigned w_voff[SEGS_W];
+#pragma unroll
+  for (int u = 0; u < SEGS_W; ++u) {
+    const int r = (wv * SEGS_W + u) * 8 + lrow;
+    const int part = lslot ^ ((r >> 1) & 7);
+    w_voff[u] = (col0 + r < cout) ? (unsigned)((col0 + r) * cin + part * 8) * 2u : 0xFFFFFFFFu;
+  }
+  // one window instruction: window rows seg*8 .. seg*8+7 of group `grp` (channel slice grp / kd, z-offset grp % kd)
+  auto issue_win = [&](int grp, int j) {
+    const int seg = wv + j * NW;
+    if (seg >= WIN_SEGS) return;
+    const int c0 = (grp / lg.kd) * BK, dz = grp % lg.kd - pz;
+    const int wr = seg * 8 + lrow;                                                     // window row
+    const long long row = (long long)m0 + (long long)lg.sign * dz * HW - lg.W - 1 + wr;   // lattice row it holds
+    const int part = lslot ^ ((wr >> 1) & 7);
+    const unsigned voff = (row >= 0 && row < n_out) ? (unsigned)row * row_bytes + (unsigned)part * 16u : 0xFFFFFFFFu;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void_ptr)(win_base + (grp & 1) * WIN_ELEMS + seg * 512), 16, voff, (unsigned)c0 * 2u, 0, 0);
+  };
+  auto issue_w = [&](int st, int u) {
+    const int grp = st / 9, t9 = st - grp * 9;
+    const int c0 = (grp / lg.kd) * BK, kap = (grp % lg.kd) * 9 + t9;
+    u16* Wb = wt_base + (st & 1) * W_ELEMS + wv * (SEGS_W * 512);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_ptr)(Wb + u * 512), 16, w_voff[u], (unsigned)(kap * cin * cout + c0) * 2u, 0, 0);
+  };
+  // validity of the 27 (z, y, x) offsets for this lane's rows (one row per 16-row block a)
+  const int g = lane >> 4, li = lane & 15;
+  unsigned vmask[WM];
+#pragma unroll
+  for (int a = 0; a < WM; ++a) {
+    const int m = m0 + (wm * WM + a) * 16 + li;
+    unsigned bits = 0u;
+    if (m < n_out) {
+      const int x = m % lg.W, t = m / lg.W, y = t % lg.H, z = (t / lg.H) % lg.D;
+      for (int kz = 0; kz < lg.kd; ++kz) {
+        const int zz = z + lg.sign * (kz - pz);
+        for (int ky = 0; ky < 3; ++ky) {
+          const int yy = y + lg.sign * (ky - 1);
+          for (int kx = 0; kx < 3; ++kx) {
+            const int xx = x + lg.sign * (kx - 1);
+            const bool ok = (unsigned)zz < (unsigned)lg.D && (unsigned)yy < (unsigned)lg.H && (unsigned)xx < (unsigned)lg.W;
+            bits |= (ok ? 1u : 0u) << (kz * 9 + ky * 3 + kx);
+          }
+        }
+      }
+    }
+    vmask[a] = bits;
+  }
+  typedef const volatile s16x8 __attribute__((address_space(3))) * lds_vptr;
+  const bf16x8 zero8 = __builtin_bit_cast(bf16x8, (s16x8){0, 0, 0, 0, 0, 0, 0, 0});
+
+  // prologue: window of group 0, weight tile of stage 0
+#pragma unroll
+  for (int j = 0; j < WIN_PER_WAVE; ++j) issue_win(0, j);
+#pragma unroll
+  for (int u = 0; u < SEGS_W; ++u) issue_w(0, u);
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int grp = st / 9, t9 = st - grp * 9;
+    const int kap = (grp % lg.kd) * 9 + t9;
+    const int nx = st + 1 < nstage ? st + 1 : st;                 // the last stage re-fetches its own weight tile: branch-free body
+    // this offset's fragment rows inside the window: row (m - m0) + W + 1 + sign * ((ky-1) * W + (kx-1))
+    const int shift = lg.W + 1 + lg.sign * ((t9 / 3 - 1) * lg.W + (t9 % 3 - 1));
+    const int r0 = (wm * WM) * 16 + li + shift;
+    const int fsw = (r0 >> 1) & 7;                                // identical for every 16-row block a (a*16 >> 1 is a multiple of 8)
+    const u16* A = win_base + (grp & 1) * WIN_ELEMS + r0 * BK;
+    const u16* Wt = wt_base + (st & 1) * W_ELEMS + (wn * WN * 16 + li) * BK;
+    const int wsw = (lane >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int fa = ((ks * 4 + g) ^ fsw) << 3, fw = ((ks * 4 + g) ^ wsw) << 3;
+      bf16x8 af[WM];
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        const s16x8 v = *(lds_vptr)(A + a * 16 * BK + fa);
+        af[a] = ((vmask[a] >> kap) & 1u) ? __builtin_bit_cast(bf16x8, v) : zero8;
+      }
+#pragma unroll
+      for (int b = 0; b < WN; ++b) {
+        const s16x8 wv8 = *(lds_vptr)(Wt + b * 16 * BK + fw);
+        const bf16x8 bfr = __builtin_bit_cast(bf16x8, wv8);
+#pragma unroll
+        for (int a = 0; a < WM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af[a], acc[a][b], 0, 0, 0);
+        if (ks == 0) {                                            // next stage's weight tile (+ a slice of the next window) behind the MFMA groups
+          if (b < SEGS_W) issue_w(nx, b);
+          if (b == WN - 1 && grp + 1 < ngroup && t9 < WIN_PER_WAVE) issue_win(grp + 1, t9);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  glds_epilogue<WAVES_M, WAVES_N, WM, WN>(acc, smem, m0, col0, tile, n_out, cout, out, bias, relu, stats);
+}
+
+__global__ __launch_bounds__(512) void k_igemm_lattice_256x256(const u16* in, const u16* w, u16* out, int n_rows, int cin, int cout, LatGeom lg,
+                                                               const float* bias, int relu, double* stats) {
+  igemm_lattice_body<2, 4, 8, 4>(in, w, out, n_rows, cin, cout, lg, bias, relu, stats);
+}
+
+// rows = batch * D * H * W lattice cells in (b, z, y, x) order; w n-major [kd*9][Cout][Cin]; transposed != 0: the input gradient
+// (offsets negated; pass the [K][Cin][Cout] weight, i.e. n-major for that product).  stats as u3d_igemm_fwd_stats_bf16 (256-row tiles).
+extern "C" int32_t u3d_igemm_lattice_bf16(const void* in, const void* w, void* out, int32_t batch, int32_t D, int32_t H, int32_t W,
+                                          int32_t cin, int32_t cout, int32_t kd, int32_t transposed, double* stats, u3d_stream s) {
+  U3D_REQUIRE(in && w && out && batch > 0 && D > 0 && H > 0 && W > 0, U3D_ERR_ARG);
+  if ((kd != 1 && kd != 3) || cin % 64 != 0 || cout % 256 != 0 || 256 + 2 * W + 2 > LAT_WIN_ROWS) return U3D_ERR_UNSUPPORTED;
+  const long long n = (long long)batch * D * H * W;
+  if (n >= 0x7fffffffll / (cin > cout ? cin : cout) / 2) return U3D_ERR_UNSUPPORTED;      // 32-bit buffer offsets
+  LatGeom lg = {D, H, W, kd, transposed ? -1 : 1};
+  constexpr size_t lds = (2 * (size_t)LAT_WIN_ROWS * 64 + 2 * (size_t)256 * 64) * 2;      // 150.5 KiB
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_igemm_lattice_256x256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  dim3 grid(u3d_cdiv((int)n, 256), cout / 256);
+  hipLaunchKernelGGL(k_igemm_lattice_256x256, grid, dim3(512), lds, s, (const u16*)in, (const u16*)w, (u16*)out, (int)n, cin, cout, lg,
+                     (const float*)nullptr, 0, stats);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
 }
 

@@ -65,6 +65,7 @@ _SIGS = {
     "u3d_bn_finalize_partials": (_I, [_P, _I, _I, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     "u3d_igemm_fwd_stats_tile_rows": (_I, [_I, _I, _I]),
     "u3d_igemm_fwd_stats_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "u3d_igemm_lattice_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "u3d_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     "u3d_bn_bwd_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P]),
     "u3d_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
@@ -761,3 +762,20 @@ def box_decode_bwd(tmp, ref, dout, pc_range, eps=1e-5, want_dref=False):
     _check(lib().u3d_box_decode_bwd(_ptr(tmp), dtype_code(tmp), _ptr(ref), _ptr(dout), n, code, _pc_range6(pc_range), C.c_float(eps),
                                     _ptr(dtmp), _ptr(dref), _stream()), "box_decode_bwd")
     return dtmp, dref
+
+
+def lattice_conv(inp, w_nmajor, batch, dims, kd, transposed=False, want_stats=False):
+    """(kd,3,3) same-padded stride-1 conv on a dense [batch, D, H, W] lattice without a neighbour table (u3d_igemm_lattice_bf16).
+    inp [rows, Cin] bf16, w_nmajor [kd*9, N, K] (forward: [K, Cout, Cin]; transposed: [K, Cin, Cout]).  -> out [rows, N]
+    (+ stats f64 [tiles, 2, N] with 256-row tiles) or None when the shape is not served."""
+    n, cin = inp.shape
+    cout = w_nmajor.shape[1]
+    D, H, W = dims
+    out = torch.empty((n, cout), dtype=inp.dtype, device=inp.device)
+    stats = torch.empty(((n + 255) // 256, 2, cout), dtype=torch.float64, device=inp.device) if want_stats else None
+    rc = lib().u3d_igemm_lattice_bf16(_ptr(inp), _ptr(w_nmajor), _ptr(out), batch, D, H, W, cin, cout, kd, 1 if transposed else 0,
+                                      _ptr(stats), _stream())
+    if rc == -2:
+        return None
+    _check(rc, "igemm_lattice_bf16")
+    return (out, stats) if want_stats else out
