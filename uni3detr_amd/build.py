@@ -27,7 +27,7 @@ def _newer(target, deps):
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(HERE, "..", "include", "u3d_hip.h"))
     jobs = []
     objs = []

@@ -301,72 +301,6 @@ static int launch_igemm_fwd(const void* in, const void* w, const int32_t* nbr, i
 #endif
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-// Epilogue shared by the LDS-DMA forward/dgrad kernels: bias / ReLU, bf16 store (transposed accumulator: 4 consecutive columns per
-// lane), optional per-tile BatchNorm statistics.
-template <int WAVES_M, int WAVES_N, int WM, int WN>
-__device__ __forceinline__ void glds_epilogue(f32x4 (&acc)[WM][WN], u16* smem, int m0, int col0, int tile, int n_out, int cout,
-                                              u16* __restrict__ out, const float* __restrict__ bias, int relu, double* __restrict__ stats) {
-  constexpr int NW = WAVES_M * WAVES_N, BN = WAVES_N * WN * 16;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
-  const int g = lane >> 4, li = lane & 15;
-  // epilogue: acc[a][b][r] = C[row (wm*WM+a)*16 + li][col (wn*WN+b)*16 + 4g + r]; v_cvt_pk_bf16_f32 (RNE) via convertvector
-  f32x4 cs[WN], cq[WN];                                 // BatchNorm statistics of this wave's rows: column sums / sums of squares
-#pragma unroll
-  for (int b = 0; b < WN; ++b) { cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-  for (int a = 0; a < WM; ++a) {
-    const int m = m0 + (wm * WM + a) * 16 + li;
-    if (m >= n_out) continue;
-#pragma unroll
-    for (int b = 0; b < WN; ++b) {
-      const int col = col0 + (wn * WN + b) * 16 + 4 * g;
-      if (col < cout) {                                 // cout % 8 == 0: the 4-column group is in or out as a whole
-        f32x4 v = acc[a][b];
-        if (bias) { const f32x4 bv = *(const f32x4*)(bias + col); v += bv; }
-        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        const bf16x4 o = __builtin_convertvector(v, bf16x4);
-        *(bf16x4*)(out + (long long)m * cout + col) = o;
-        if (stats) {                                    // statistics of the ROUNDED values: what the BatchNorm that follows reads
-          const f32x4 vr = __builtin_convertvector(o, f32x4);
-          cs[b] += vr;
-          cq[b] += vr * vr;
-        }
-      }
-    }
-  }
-  if (stats) {
-    // the BatchNorm behind this conv needs per-column sum / sum of squares over ALL rows: reduce this tile here (16 lanes of a
-    // column group by shuffles, the row waves through LDS) and leave one f64 partial per (row tile, column) - the separate
-    // statistics pass over the output (one full read of the tensor) disappears
-    float* red = (float*)smem;                          // [WAVES_M][2][BN] floats; the stage buffers are dead after the last barrier
-#pragma unroll
-    for (int b = 0; b < WN; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s1 = cs[b][r], s2 = cq[b][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        if (li == 0) {
-          const int cl = (wn * WN + b) * 16 + 4 * g + r;
-          red[(wm * 2 + 0) * BN + cl] = s1;
-          red[(wm * 2 + 1) * BN + cl] = s2;
-        }
-      }
-    __syncthreads();
-    for (int t = tid; t < 2 * BN; t += NW * 64) {
-      const int which = t / BN, cl = t % BN;
-      if (col0 + cl < cout) {
-        double a = 0.0;
-#pragma unroll
-        for (int k = 0; k < WAVES_M; ++k) a += (double)red[(k * 2 + which) * BN + cl];
-        stats[((long long)tile * 2 + which) * cout + col0 + cl] = a;
-      }
-    }
-  }
-}
-
 template <int WAVES_M, int WAVES_N, int WM, int WN>
 __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
                                                 int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
@@ -616,7 +550,7 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
     __syncthreads();                                    // also drains this wave's LDS-DMA (vmcnt) before anyone reads the next buffer
   }
 #endif
-  glds_epilogue<WAVES_M, WAVES_N, WM, WN>(acc, smem, m0, col0, tile, n_out, cout, out, bias, relu, stats);
+#include "glds_epilogue.inc"
 }
 
 // concrete kernels (a __global__ TEMPLATE with this body lost its host stub under hipcc 7.2: undefined symbol at load time)
@@ -796,7 +730,7 @@ __device__ __forceinline__ void igemm_lattice_body(const u16* __restrict__ in, c
     }
     __syncthreads();
   }
-  glds_epilogue<WAVES_M, WAVES_N, WM, WN>(acc, smem, m0, col0, tile, n_out, cout, out, bias, relu, stats);
+#include "glds_epilogue.inc"
 }
 
 __global__ __launch_bounds__(512) void k_igemm_lattice_256x256(const u16* in, const u16* w, u16* out, int n_rows, int cin, int cout, LatGeom lg,
