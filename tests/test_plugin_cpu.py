@@ -92,3 +92,37 @@ def test_builtin_variants_equal_shipped_configs(name):
     from uni3detr_amd.configs import variants
     ref = Config.fromfile(os.path.join(REF_CFG, f"uni3detr_{name}.py")).model
     assert json.dumps(getattr(variants, name), sort_keys=True, default=list) == json.dumps(ref, sort_keys=True, default=list)
+
+
+def test_hot_kernels_keep_their_register_budget(tmp_path):
+    """Guard against silent register-allocation regressions in the built library (one refactor of the LDS-DMA kernels' epilogue made
+    the 256x256 kernel spill and halved the 128x128 kernel's occupancy: 25.4 -> 27.5 ms per step with every test green).  Reads the
+    gfx950 code objects' metadata: no scratch in the implicit-GEMM kernels; the 256x256 tiles fit two waves per SIMD (<= 256 VGPRs),
+    the 128x128 forward tile two workgroups per CU (<= 256 VGPR + AGPR)."""
+    import re
+    import shutil
+    import subprocess
+    from uni3detr_amd import native as nv
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and os.path.exists(nv.LIB_PATH)):
+        pytest.skip("ROCm LLVM tools or the built library are not available")
+    lib = shutil.copy(nv.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, check=True, capture_output=True)
+    kernels = {}
+    for co in sorted(tmp_path.glob("lib.so.*gfx950")):
+        notes = subprocess.run([readelf, "--notes", str(co)], capture_output=True, text=True).stdout
+        for blk in notes.split("  - .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            if not name:
+                continue
+            get = lambda key: int(re.search(rf"\.{key}:\s+(\d+)", blk).group(1))
+            kernels[name.group(1)] = dict(agpr=int(blk.split()[0]), vgpr=get("vgpr_count"), scratch=get("private_segment_fixed_size"))
+    find = lambda sub: [v for k, v in kernels.items() if sub in k]
+    assert len(kernels) > 50
+    for sub in ("k_igemm_glds_256x256", "k_igemm_glds_128x128", "k_igemm_glds_128x64", "k_igemm_wgrad_glds_256", "k_igemm_wgrad_glds_128",
+                "k_igemm_lattice_256x256"):
+        ks = find(sub)
+        assert ks, sub
+        assert all(k["scratch"] == 0 for k in ks), (sub, ks)
+    assert all(k["vgpr"] <= 256 and k["agpr"] == 0 for k in find("k_igemm_glds_256x256"))
+    assert all(k["vgpr"] + k["agpr"] <= 256 for k in find("k_igemm_glds_128x128"))
