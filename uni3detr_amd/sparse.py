@@ -40,6 +40,7 @@ class ConvGeom:
         self.nbr_fwd, self.nbr_bwd = nbr_fwd, nbr_bwd
         self.n_in, self.n_in_dev, self.n_out, self.n_out_dev = n_in, n_in_dev, n_out, n_out_dev
         self.kind = kind            # "sparse" (encoder levels) or "dense" (SECOND3D/FPN lattice): bench.py tags timings with it
+        self.lattice = None         # (batch, (D,H,W), kd) for a stride-1 "same" (kd,3,3) conv on a dense lattice (u3d_igemm_lattice_bf16)
 
 
 def level_from_coors(coors, batch, dims):
@@ -78,6 +79,7 @@ def strided_level(lvl, ksize, stride, pad, capacity=None):
     return out, ConvGeom(fwd, bwd, lvl.n, lvl.n_dev, n_out, out.n_dev)
 
 
+LATTICE_KERNEL = os.environ.get("U3D_LATTICE_KERNEL", "0") == "1"      # 27-offset dense convs on u3d_igemm_lattice_bf16 (measured on par: off)
 STRIDED_DGRAD_SPLIT = os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
 NMAJOR_FWD = os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
 STRIDED_SPLIT_MIN_RATIO = int(os.environ.get("U3D_STRIDED_SPLIT_MIN_RATIO", "16"))
@@ -127,8 +129,14 @@ class _SparseConv(torch.autograd.Function):
         ctx.kio_shape, ctx.wdtype = kio_shape, weight.dtype
         nbr = geom.nbr_fwd if kio.shape[0] > 1 else None
         nv.CALL_KIND = geom.kind
+        lat = geom.lattice if (LATTICE_KERNEL and nmajor and geom.lattice is not None and geom.lattice[2] == 3) else None
         if want_stats:
-            res = nv.spconv_fwd_stats(feats, koi, nbr, geom.n_out_dev, geom.n_out, cout) if nmajor else None
+            res = None
+            if lat is not None:
+                r = nv.lattice_conv(feats, koi, lat[0], lat[1], lat[2], want_stats=True)
+                res = None if r is None else (r[0], r[1], 256)
+            if res is None:
+                res = nv.spconv_fwd_stats(feats, koi, nbr, geom.n_out_dev, geom.n_out, cout) if nmajor else None
             if res is not None:
                 y, stats, tr = res
                 stats._u3d_tile_rows = tr
@@ -184,7 +192,11 @@ class _SparseConv(torch.autograd.Function):
                 prod = nv.linear_bf16(dout, wc.view(kvol * cin, cout), None, False)      # [n_out, K*Cin]
                 din = nv.tap_gather_sum(prod, nbr, g.n_in_dev, g.n_in, cin, kvol)
             else:
-                din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True)
+                din = None
+                if LATTICE_KERNEL and g.lattice is not None and g.lattice[2] == 3 and dout.dtype == torch.bfloat16:
+                    din = nv.lattice_conv(dout, wc, g.lattice[0], g.lattice[1], g.lattice[2], transposed=True)
+                if din is None:
+                    din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True)
         return din, dw, None, None, None
 
 
