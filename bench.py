@@ -123,9 +123,20 @@ def main():
     data = make_batch(rank, args.batch, args.points, dev)
     ts = TrainStep(model, data["points"], data["gt_bboxes_3d"], data["gt_labels_3d"], graph=not args.no_graph)
     caps = None
+    launch_mode = "eager" if args.no_graph else "hipGraph"
     if not args.no_graph:
         snap = ts.snapshot()
-        counts, caps = ts.capture()                     # exact-size step -> capacities -> static-shape warm-up -> 3 hipGraphs
+        try:
+            counts, caps = ts.capture()                 # exact-size step -> capacities -> static-shape warm-up -> 3 hipGraphs
+        except Exception as e:                          # safety net: a failed capture must not cost the run its number
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            ts._graphs = None
+            ts.graph = False
+            model.static_shapes = False
+            model.pts_middle_encoder.level_capacities = None
+            args.no_graph = True
+            launch_mode = "eager (capture failed)"
         ts.restore(snap)                                # capture/warm-up iterations do not count as training
         if use_dist:
             init_pg()                                   # process group only AFTER the captures (see TrainStep.enable_dist)
@@ -184,7 +195,7 @@ def main():
             "config": {"workload": "uni3detr_sunrgbd.py (BASELINE configs[1]): train step fwd+loss+bwd+clip+AdamW, "
                                    f"{args.batch} scenes/GPU x {args.points} pts, 300 queries x 3 groups, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss_val,
-                       "launch_mode": "eager" if args.no_graph else "hipGraph x3 (fwd+match | loss+bwd | clip+AdamW), static-shape sparse levels",
+                       "launch_mode": launch_mode if launch_mode != "hipGraph" else "hipGraph x3 (fwd+match | loss+bwd | clip+AdamW), static-shape sparse levels",
                        "sparse_level_capacities": caps},
         }
         if timer is not None and census:
