@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, overlap):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         import projects.mmdet3d_plugin  # noqa: F401
@@ -41,7 +41,8 @@ def _worker(rank, world, port, q):
             gb = torch.from_numpy(g).clone()
             gb[:, 2] -= gb[:, 5] / 2
             pts.append(torch.from_numpy(p).to(dev)); gts.append(Boxes3D(gb).to(dev)); labels.append(torch.from_numpy(l).to(dev))
-        ts = TrainStep(model, pts, gts, labels, graph=True, lr=2e-4)
+        ts = TrainStep(model, pts, gts, labels, graph=True, lr=2e-4, overlap_reduce=overlap)
+        assert ts.overlap == overlap
         snap = ts.snapshot()
         ts.capture()
         ts.restore(snap)
@@ -70,11 +71,12 @@ def _worker(rank, world, port, q):
         q.put((rank, False, repr(e) + traceback.format_exc()[-1500:], 0.0, False))
 
 
-def test_world2_graph_step_keeps_ranks_identical(cuda):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_world2_graph_step_keeps_ranks_identical(cuda, overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     out = [q.get(timeout=600) for _ in procs]

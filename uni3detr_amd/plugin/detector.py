@@ -226,6 +226,11 @@ class Uni3DETR(nn.Module):
             fpsbpts = self.fps_queries(cat, scene_off, lens, coors, voxel_off)
         if not self.dynamic_voxelization:
             x = self.pts_middle_encoder(feats, coors, len(lens))
+        self._encoder_out = self._encoder_cut = None
+        if getattr(self, "cut_encoder_backward", False) and torch.is_grad_enabled() and x.requires_grad:
+            # cut point of TrainStep's two-phase backward: everything above sees a detached leaf; phase B feeds its gradient into x
+            self._encoder_out = x
+            x = self._encoder_cut = x.detach().requires_grad_(True)
         amp = self.amp_dtype
         with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
             if self.with_pts_backbone:

@@ -20,7 +20,7 @@ from .plugin import transformer as _T
 
 class TrainStep:
     def __init__(self, model, points, gt_bboxes_3d, gt_labels_3d, lr=1e-4, weight_decay=0.01, max_norm=10.0, graph=True,
-                 capacity_margin=1.25, flat_update=True):
+                 capacity_margin=1.25, flat_update=True, overlap_reduce=False):
         self.model = model
         self.dev = next(model.parameters()).device
         self.dist_on = dist.is_available() and dist.is_initialized()
@@ -43,6 +43,19 @@ class TrainStep:
             p.grad = self.views[-1]
         self.lr, self.weight_decay = lr, weight_decay
         self.flat_update = flat_update
+        # overlap_reduce: the backward runs in two phases cut at the sparse encoder's dense() output.  Phase A (losses, head, decoder,
+        # dense stack: ~90 % of the gradient bytes) is followed by an ASYNCHRONOUS all-reduce of its slice of the flat buffer, which then
+        # rides under phase B (the sparse encoder's backward); only the encoder's small slice is reduced after it.  The encoder's
+        # parameters must form a prefix of the flat buffer (they do: it is the first parameterised child of the detector).
+        enc = getattr(model, "pts_middle_encoder", None)
+        enc_ids = {id(p) for p in enc.parameters()} if enc is not None else set()
+        n_enc = sum(1 for p in self.params if id(p) in enc_ids)
+        prefix = n_enc > 0 and all(id(p) in enc_ids for p in self.params[:n_enc]) and n_enc < len(self.params)
+        self.overlap = bool(overlap_reduce and prefix)
+        model.cut_encoder_backward = self.overlap
+        self.n_enc = n_enc
+        self.enc_end = self.offsets[n_enc] if self.overlap else 0          # flat offset where phase A's slice starts
+        self._work = None
         if flat_update:
             # parameters re-homed into ONE flat buffer (each p.data becomes a view; names/shapes/state_dict unchanged), moments flat:
             # clip + AdamW is u3d_adamw_step - three launches that stream the 7 arrays once (torch: ~30 multi-tensor launches)
@@ -112,6 +125,63 @@ class TrainStep:
         if missing:
             torch._foreach_zero_(missing)
 
+    def _pack(self, lo, hi):
+        """Gradients of params[lo:hi] (as autograd left them in .grad) -> their views of the flat buffer; .grad = the view again."""
+        dst, src, missing = [], [], []
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
+            if p.grad is None:
+                missing.append(v)
+            else:
+                dst.append(v); src.append(p.grad)
+            p.grad = v
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if missing:
+            torch._foreach_zero_(missing)
+
+    def _stage2a(self):
+        """Losses + backward down to the sparse encoder's dense() output (phase A of the two-phase backward)."""
+        for p in self.params:
+            p.grad = None
+        losses = self.model.pts_bbox_head.loss_from_targets(self._outs, self._T, self._num_pos)
+        self._losses = losses
+        loss = getattr(self.model.pts_bbox_head, "_loss_total", None)
+        if loss is None or not all("loss" in k for k in losses):
+            loss = sum(v for k, v in losses.items() if "loss" in k)
+        self.model.pts_bbox_head._loss_total = None
+        cut = self.model._encoder_cut                # detached leaf the dense stack / head were fed with (detector.extract_pts_feat)
+        cut.grad = None
+        with _sp.wgrad_side_stream(), _T.deferred_param_grads():
+            loss.backward()
+        self.loss = loss.detach()
+        self._pack(self.n_enc, len(self.params))
+        self._gx = cut.grad
+        cut.grad = None
+
+    def _stage2b(self):
+        """Phase B: the sparse encoder's backward from the gradient of its output."""
+        x = self.model._encoder_out
+        with _sp.wgrad_side_stream():
+            x.backward(self._gx)
+        self._pack(0, self.n_enc)
+        self._gx = None
+        self.model._encoder_out = self.model._encoder_cut = None
+
+    def _reduce_grads_a(self):
+        if self.dist_on:
+            a = self.flat_grad[self.enc_end:]
+            a.div_(self.world)
+            self._work = dist.all_reduce(a, async_op=True)          # in flight underneath phase B
+
+    def _reduce_grads_b(self):
+        if self.dist_on:
+            if self._work is not None:
+                self._work.wait()
+                self._work = None
+            b = self.flat_grad[:self.enc_end]
+            b.div_(self.world)
+            dist.all_reduce(b)
+
     def _reduce_grads(self):
         if self.dist_on:
             self.flat_grad.div_(self.world)
@@ -137,7 +207,12 @@ class TrainStep:
                     v.zero_()
 
     def eager_step(self):
-        self._stage1(); self._reduce_num_pos(); self._stage2(); self._reduce_grads(); self._stage3()
+        self._stage1(); self._reduce_num_pos()
+        if self.overlap:
+            self._stage2a(); self._reduce_grads_a(); self._stage2b(); self._reduce_grads_b()
+        else:
+            self._stage2(); self._reduce_grads()
+        self._stage3()
         return self.loss
 
     def enable_dist(self):
@@ -199,6 +274,8 @@ class TrainStep:
         # drop the eager iteration's activations / autograd graph BEFORE capturing: releasing them from inside a capture
         # (when the attributes are re-assigned) tears down autograd nodes mid-capture and crashes hipStreamEndCapture
         self._outs = self._T = self._num_pos = self._losses = self.loss = None
+        self._gx = None
+        self.model._encoder_out = self.model._encoder_cut = None
         self.model.pts_bbox_head._loss_total = None
         dec = getattr(getattr(self.model.pts_bbox_head, "transformer", None), "decoder", None)
         if dec is not None:
@@ -208,26 +285,40 @@ class TrainStep:
         gc.collect()
         torch.cuda.synchronize()
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        g2b = torch.cuda.CUDAGraph() if self.overlap else None
         pool = torch.cuda.graph_pool_handle()
         with torch.cuda.graph(g1, pool=pool, stream=s, capture_error_mode="thread_local"):
             self._stage1()
         self._reduce_num_pos()
-        with torch.cuda.graph(g2, pool=pool, stream=s, capture_error_mode="thread_local"):
-            self._stage2()
-        self._reduce_grads()
+        if self.overlap:
+            with torch.cuda.graph(g2, pool=pool, stream=s, capture_error_mode="thread_local"):
+                self._stage2a()
+            self._reduce_grads_a()
+            with torch.cuda.graph(g2b, pool=pool, stream=s, capture_error_mode="thread_local"):
+                self._stage2b()
+            self._reduce_grads_b()
+        else:
+            with torch.cuda.graph(g2, pool=pool, stream=s, capture_error_mode="thread_local"):
+                self._stage2()
+            self._reduce_grads()
         with torch.cuda.graph(g3, pool=pool, stream=s, capture_error_mode="thread_local"):
             self._stage3()
         torch.cuda.synchronize()
-        self._graphs = (g1, g2, g3)
+        self._graphs = (g1, g2, g2b, g3)
         return counts, caps
 
     def step(self):
         if self._graphs is None:
             return self.eager_step()
-        g1, g2, g3 = self._graphs
+        g1, g2, g2b, g3 = self._graphs
         g1.replay()
         self._reduce_num_pos()
         g2.replay()
-        self._reduce_grads()
+        if g2b is not None:
+            self._reduce_grads_a()
+            g2b.replay()
+            self._reduce_grads_b()
+        else:
+            self._reduce_grads()
         g3.replay()
         return self.loss
