@@ -197,7 +197,7 @@ def main():
             "config": {"workload": "uni3detr_sunrgbd.py (BASELINE configs[1]): train step fwd+loss+bwd+clip+AdamW, "
                                    f"{args.batch} scenes/GPU x {args.points} pts, 300 queries x 3 groups, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss_val,
-                       "launch_mode": launch_mode if launch_mode != "hipGraph" else "hipGraph x3 (fwd+match | loss+bwd | clip+AdamW), static-shape sparse levels",
+                       "launch_mode": launch_mode if launch_mode != "hipGraph" else (("hipGraph x4 (fwd+match | loss+bwd head/dense [all-reduce A overlaps] | bwd encoder | clip+AdamW)" if ts.overlap else "hipGraph x3 (fwd+match | loss+bwd | clip+AdamW)") + ", static-shape sparse levels"),
                        "sparse_level_capacities": caps},
         }
         if timer is not None and census:
