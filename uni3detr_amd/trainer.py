@@ -6,6 +6,8 @@ step consists of (host enqueue time ≈ GPU time in eager mode):
         [eager] all-reduce of the per-layer positive counts (3 floats; skipped for world size 1)
     G2  losses + backward into ONE flat gradient buffer
         [eager] all-reduce of the flat gradient buffer over RCCL/xGMI (world size > 1)
+        (overlap_reduce=True: G2a = losses + backward of head / decoder / dense stack, asynchronous all-reduce of their slice,
+         G2b = the sparse encoder's backward underneath it, then the all-reduce of the encoder's small slice)
     G3  gradient clipping + fused AdamW
 The sparse levels run in static-shape mode (capacity-sized tensors, device-side row counts; uni3detr_amd/sparse.py), so the
 captured launches are valid for any batch whose level sizes fit the capacities; `check_capacities()` verifies that.
