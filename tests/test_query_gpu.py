@@ -386,3 +386,30 @@ def test_linear_relu_epilogue_matches_linear_then_relu(cuda, amp):
     rel = lambda a, b: (a.float() - b.float()).abs().max().item() / max(1.0, b.abs().max().item())
     assert rel(y, ref) <= tol and rel(x2.grad, xr.grad) <= tol
     assert rel(lin.weight.grad, wr.grad) <= tol and rel(lin.bias.grad, br.grad) <= tol
+
+
+@pytest.mark.parametrize("nout,kin", [(10, 256), (1, 256), (256, 3)])
+def test_narrow_linear_bias_sum_is_deferred_and_correct(cuda, nout, kin):
+    """Linears whose weight gradient cannot ride the batched kernel (N or K not a multiple of 64) still queue their BIAS column sum:
+    inside deferred_param_grads() the bias gradient is produced by the batched sums at the end of the block and equals torch's."""
+    import contextlib
+    from uni3detr_amd.plugin import transformer as T
+    from uni3detr_amd.shadow import ShadowSet
+    torch.manual_seed(nout + kin)
+    lin = torch.nn.Linear(kin, nout).to(cuda)
+    x = torch.randn(8, 900, kin, device=cuda)
+    q = lambda t: t.detach().bfloat16().float()
+    xr, wr, br = q(x).requires_grad_(True), q(lin.weight).requires_grad_(True), q(lin.bias).requires_grad_(True)
+    ref = torch.nn.functional.linear(xr, wr, br)
+    gy = q(torch.randn_like(ref))
+    (ref * gy).sum().backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    shadows = ShadowSet([lin.weight, lin.bias], torch.bfloat16)
+    T.reset_param_uses()
+    with shadows.active(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = T.fast_linear(x2, lin)
+    with T.deferred_param_grads():
+        (y.float() * gy).sum().backward()
+        assert any(p is lin.bias for _, p in T._Deferred.sum_items)          # queued, not computed on the spot
+    rel = lambda a, b: (a.float() - b.float()).abs().max().item() / max(1.0, b.abs().max().item())
+    assert rel(lin.bias.grad, br.grad) <= 3e-2 and rel(lin.weight.grad, wr.grad) <= 3e-2 and rel(x2.grad, xr.grad) <= 3e-2

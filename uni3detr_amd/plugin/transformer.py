@@ -202,10 +202,17 @@ def _linear_backward(dy2, x2, wc, need_dx, need_dw, need_db, xdtype, defer=None,
             dw_out.copy_(dw)
             dw = dw_out
     if need_db:
-        db = nv.colsum(dy2)
-        if db_out is not None:
-            db_out.copy_(db)
-            db = db_out
+        if (defer is not None and _Deferred.active and db_out is None and defer[1] == 0 and defer[2] == n and dy2.is_cuda
+                and _Deferred.params[defer[0]][1] is not None):
+            # narrow linears (N or K not a multiple of 64: the heads' last layers, Linear(3,256), Linear(256,1)) keep their own dW path,
+            # but the bias column sum joins the batched sums: ~30 colsum launch pairs per step -> a handful
+            _Deferred.sum_items.append((dy2, _Deferred.params[defer[0]][1]))
+            db = torch.empty((n,), dtype=torch.float32, device=dy2.device)         # placeholder, written by flush_deferred()
+        else:
+            db = nv.colsum(dy2)
+            if db_out is not None:
+                db_out.copy_(db)
+                db = db_out
     return dx, dw, db
 
 
