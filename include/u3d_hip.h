@@ -358,6 +358,13 @@ int32_t u3d_box_decode_fwd(const void* tmp, int32_t dtype, const float* ref, int
                            float eps, float* out, u3d_stream s);
 int32_t u3d_box_decode_bwd(const void* tmp, int32_t dtype, const float* ref, const float* dout, int32_t n, int32_t code,
                            const float* pc_range, float eps, void* dtmp, float* dref, u3d_stream s);
+/* Sine position embedding of the decoder's reference points (ref: models/utils/uni3detr_transformer.py:33-65,181):
+ * out[n][j*nfeat + f] = (f even ? sin : cos)(sigmoid(logits[n][j]) * 2*pi / dim_t[f]); logits f32 [n, nc], dim_t f32 [nfeat] (host
+ * table T^(2*(f/2)/nfeat)), out f32 or bf16 [n, nc*nfeat].  Backward: dlogits f32 [n, nc] from dout (f32 or bf16). */
+int32_t u3d_sine_embed_fwd(const float* logits, const float* dim_t, int32_t n, int32_t nc, int32_t nfeat, int32_t out_dtype,
+                           void* out, u3d_stream s);
+int32_t u3d_sine_embed_bwd(const float* logits, const float* dim_t, const void* dout, int32_t dout_dtype, int32_t n, int32_t nc,
+                           int32_t nfeat, float* dlogits, u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * Parameter update of the training step: global-norm gradient clipping + AdamW over FLAT f32 buffers

@@ -413,3 +413,24 @@ def test_narrow_linear_bias_sum_is_deferred_and_correct(cuda, nout, kin):
         assert any(p is lin.bias for _, p in T._Deferred.sum_items)          # queued, not computed on the spot
     rel = lambda a, b: (a.float() - b.float()).abs().max().item() / max(1.0, b.abs().max().item())
     assert rel(lin.bias.grad, br.grad) <= 3e-2 and rel(lin.weight.grad, wr.grad) <= 3e-2 and rel(x2.grad, xr.grad) <= 3e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_sine_embedding_matches_torch_formulation(cuda, dtype):
+    """u3d_sine_embed_fwd/_bwd == get_sine_pos_embed(ref_logits.sigmoid()) (ref uni3detr_transformer.py:33-65,181): values in the
+    requested dtype and the gradient w.r.t. the reference-point logits."""
+    from uni3detr_amd.plugin import transformer as T
+    torch.manual_seed(4)
+    logits = (torch.randn(8, 900, 3, device=cuda) * 2.0)
+    a = logits.clone().requires_grad_(True)
+    out = T.sine_embed_of_logits(a, dtype)
+    assert out.shape == (8, 900, 384) and out.dtype == dtype
+    b = logits.clone().requires_grad_(True)
+    ref = T.get_sine_pos_embed(b.sigmoid())
+    g = torch.randn_like(ref)
+    tol = 2e-5 if dtype == torch.float32 else 8e-3
+    assert (out.float() - ref).abs().max().item() <= tol
+    out.backward(g.to(dtype))
+    ref.backward(g.to(dtype).float())
+    # sin/cos of arguments up to 2*pi with slopes up to 2*pi: f32 device sin/cos vs torch's agree to a few ulp
+    assert (a.grad - b.grad).abs().max().item() <= 2e-3 * max(1.0, b.grad.abs().max().item())

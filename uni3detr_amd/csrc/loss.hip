@@ -320,3 +320,67 @@ extern "C" int32_t u3d_box_decode_bwd(const void* tmp, int32_t dtype, const floa
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Sine position embedding of the decoder's reference points (ref: models/utils/uni3detr_transformer.py:33-65, called on
+// reference_points.sigmoid() at :181): out[n][j*F + f] = (f even ? sin : cos)(sigmoid(logit[n][j]) * 2*pi / dim_t[f]),
+// dim_t[f] = T^(2*(f/2)/F) (table computed on the host exactly as upstream does).  One launch instead of sigmoid + ~8 element-wise
+// kernels; the backward (layer 0's reference points depend on learned anchors) folds the F features back onto each coordinate.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_sine_embed_fwd(const float* __restrict__ logits, const float* __restrict__ dim_t, int n, int nc, int F, int bf16,
+                                 void* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)n * nc * F;
+  if (i >= total) return;
+  const int f = (int)(i % F);
+  const long long rj = i / F;                                         // row * nc + coordinate
+  const float pos = 1.f / (1.f + expf(-logits[rj]));
+  const float sarg = pos * 6.283185307179586f / dim_t[f];
+  const float v = (f & 1) ? cosf(sarg) : sinf(sarg);
+  if (bf16) { __bf16 h = (__bf16)v; ((unsigned short*)out)[i] = *(unsigned short*)&h; }
+  else ((float*)out)[i] = v;
+}
+
+// one wave per (row, coordinate): dlogit = sigmoid' * sum_f dout * d(sin|cos)/dpos
+__global__ __launch_bounds__(256) void k_sine_embed_bwd(const float* __restrict__ logits, const float* __restrict__ dim_t,
+                                                        const void* __restrict__ dout, int bf16, int n, int nc, int F,
+                                                        float* __restrict__ dlogits) {
+  const long long rj = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (rj >= (long long)n * nc) return;
+  const float pos = 1.f / (1.f + expf(-logits[rj]));
+  float acc = 0.f;
+  for (int f = lane; f < F; f += 64) {
+    const float sc = 6.283185307179586f / dim_t[f];
+    const float sarg = pos * 6.283185307179586f / dim_t[f];
+    const long long o = rj * F + f;
+    const float g = bf16 ? __uint_as_float((unsigned)((const unsigned short*)dout)[o] << 16) : ((const float*)dout)[o];
+    acc += g * ((f & 1) ? -sinf(sarg) : cosf(sarg)) * sc;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) dlogits[rj] = acc * pos * (1.f - pos);
+}
+
+extern "C" int32_t u3d_sine_embed_fwd(const float* logits, const float* dim_t, int32_t n, int32_t nc, int32_t nfeat, int32_t out_dtype,
+                                      void* out, u3d_stream s) {
+  U3D_REQUIRE(logits && dim_t && out && n >= 0 && nc > 0 && nfeat > 0, U3D_ERR_ARG);
+  U3D_REQUIRE(out_dtype == U3D_F32 || out_dtype == U3D_BF16, U3D_ERR_UNSUPPORTED);
+  if (n == 0) return U3D_OK;
+  const long long total = (long long)n * nc * nfeat;
+  hipLaunchKernelGGL(k_sine_embed_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, logits, dim_t, n, nc, nfeat, out_dtype == U3D_BF16, out);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+extern "C" int32_t u3d_sine_embed_bwd(const float* logits, const float* dim_t, const void* dout, int32_t dout_dtype, int32_t n, int32_t nc,
+                                      int32_t nfeat, float* dlogits, u3d_stream s) {
+  U3D_REQUIRE(logits && dim_t && dout && dlogits && n >= 0 && nc > 0 && nfeat > 0, U3D_ERR_ARG);
+  U3D_REQUIRE(dout_dtype == U3D_F32 || dout_dtype == U3D_BF16, U3D_ERR_UNSUPPORTED);
+  if (n == 0) return U3D_OK;
+  hipLaunchKernelGGL(k_sine_embed_bwd, dim3((unsigned)(((long long)n * nc + 3) / 4)), dim3(256), 0, s, logits, dim_t, dout, dout_dtype == U3D_BF16, n,
+                     nc, nfeat, dlogits);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}

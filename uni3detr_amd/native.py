@@ -95,6 +95,8 @@ _SIGS = {
     "u3d_denormalize_boxes": (_I, [_P, _I, _I, _P, _P]),
     "u3d_box_decode_fwd": (_I, [_P, _I, _P, _I, _I, _F6, C.c_float, _P, _P]),
     "u3d_box_decode_bwd": (_I, [_P, _I, _P, _P, _I, _I, _F6, C.c_float, _P, _P, _P]),
+    "u3d_sine_embed_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "u3d_sine_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "u3d_cast_bf16": (_I, [_P, _P, _L, _P]),
     "u3d_permute_block_elems": (_I, []),
     "u3d_permute_bf16_batched": (_I, [_P, _P, _P, _P, _I, _P]),
@@ -779,3 +781,20 @@ def lattice_conv(inp, w_nmajor, batch, dims, kd, transposed=False, want_stats=Fa
         return None
     _check(rc, "igemm_lattice_bf16")
     return (out, stats) if want_stats else out
+
+
+def sine_embed_fwd(logits, dim_t, out_dtype):
+    """logits f32 [n, nc] -> [n, nc * F] in out_dtype: sin/cos embedding of sigmoid(logits) (u3d_sine_embed_fwd)."""
+    n, nc = logits.shape
+    F_ = dim_t.numel()
+    out = torch.empty((n, nc * F_), dtype=out_dtype, device=logits.device)
+    _check(lib().u3d_sine_embed_fwd(_ptr(logits), _ptr(dim_t), n, nc, F_, dtype_code(out), _ptr(out), _stream()), "sine_embed_fwd")
+    return out
+
+
+def sine_embed_bwd(logits, dim_t, dout):
+    n, nc = logits.shape
+    dl = torch.empty((n, nc), dtype=torch.float32, device=logits.device)
+    _check(lib().u3d_sine_embed_bwd(_ptr(logits), _ptr(dim_t), _ptr(dout), dtype_code(dout), n, nc, dim_t.numel(), _ptr(dl), _stream()),
+           "sine_embed_bwd")
+    return dl

@@ -440,6 +440,40 @@ def get_sine_pos_embed(pos, num_pos_feats=128, temperature=10000, exchange_xy=Fa
     return emb.flatten(-2)
 
 
+class _SineEmbed(torch.autograd.Function):
+    """get_sine_pos_embed(ref_logits.sigmoid()) in the dtype the consumer wants: one HIP launch each way (u3d_sine_embed_fwd/_bwd)."""
+
+    @staticmethod
+    def forward(ctx, ref_logits, dim_t, out_dtype):
+        l2 = ref_logits.reshape(-1, ref_logits.shape[-1]).contiguous().float()
+        ctx.save_for_backward(l2, dim_t)
+        ctx.shape, ctx.in_dtype = ref_logits.shape, ref_logits.dtype
+        return nv.sine_embed_fwd(l2, dim_t, out_dtype).view(*ref_logits.shape[:-1], -1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        l2, dim_t = ctx.saved_tensors
+        d2 = dout.reshape(l2.shape[0], -1)
+        d2 = d2 if (d2.is_contiguous() and d2.dtype in (torch.float32, torch.bfloat16)) else d2.contiguous().float()
+        return nv.sine_embed_bwd(l2, dim_t, d2).view(ctx.shape).to(ctx.in_dtype), None, None
+
+
+FUSED_SINE_EMBED = _os.environ.get("U3D_FUSED_SINE_EMBED", "1") == "1"
+
+
+def sine_embed_of_logits(ref_logits, out_dtype, num_pos_feats=128, temperature=10000):
+    """get_sine_pos_embed(ref_logits.sigmoid()).to(out_dtype) (ref :181), fused on the GPU."""
+    if FUSED_SINE_EMBED and ref_logits.is_cuda and out_dtype in (torch.float32, torch.bfloat16):
+        key = (ref_logits.device, num_pos_feats, temperature)
+        dim_t = _SINE_CACHE.get(key)
+        if dim_t is None:
+            d = torch.arange(num_pos_feats, dtype=torch.float32, device=ref_logits.device)
+            dim_t = temperature ** (2 * torch.div(d, 2, rounding_mode="floor") / num_pos_feats)
+            _SINE_CACHE[key] = dim_t
+        return _SineEmbed.apply(ref_logits, dim_t, out_dtype)
+    return get_sine_pos_embed(ref_logits.sigmoid(), num_pos_feats, temperature).to(out_dtype)
+
+
 @ATTENTION.register_module()
 class MultiheadAttention(nn.Module):
     """mmcv wrapper semantics: q = k = query + query_pos, v = query, residual + dropout (legacy `dropout=` sets both the
@@ -665,7 +699,7 @@ class Uni3DETRTransformerDecoder(nn.Module):
         self._states_c = [] if cdt is not None else None      # each layer state once in the compute dtype: shared by the reg branch,
         out_c = None                                          # query_scale, the next layer's self-attention and the head's cls / iou branches
         for lid, layer in enumerate(self.layers):
-            raw = self.ref_point_head(get_sine_pos_embed(ref_logits.sigmoid()).to(out.dtype))
+            raw = self.ref_point_head(sine_embed_of_logits(ref_logits, cdt if cdt is not None else out.dtype))     # the MLP's input dtype: no cast launch
             pos = raw if lid == 0 else self.query_scale(out if out_c is None else out_c) * raw
             out = layer.forward_bf(out, pos, value, ref_logits, group, out_c, accum)
             if cdt is not None:
