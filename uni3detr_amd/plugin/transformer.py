@@ -622,7 +622,7 @@ class UniCrossAtten(nn.Module):
         if value.dim() != 5:
             raise NotImplementedError("height-less (BEV) value maps are not used by any shipped Uni3DETR config")
         samp = _TrilinearSample.apply(value, g, accum)                                # [B,N,C]
-        wsum = w.sum(-1, keepdim=True)
+        wsum = w if w.shape[-1] == 1 else w.sum(-1, keepdim=True)      # num_points = 1 in every shipped config: no reduction launch
         cdt = _autocast_dtype(query)
         if cdt is not None:             # gate in the compute dtype: the product feeds a bf16 GEMM directly
             gated = samp.to(cdt) * wsum.to(cdt)
