@@ -686,6 +686,7 @@ class Uni3DETRTransformerDecoder(nn.Module):
         self.d_model = d = 256
         self.query_scale = MLP(d, d, d, 3)
         self.ref_point_head = MLP(384, d, d, 3)
+        self._xyz_cols = None
 
     def forward_bf(self, query, ref_logits, value, reg_branches, group):
         """query [B,N,C], ref_logits [B,N,3] -> (states [L,B,N,C], refs [L,B,N,3] logits after each layer's refinement)."""
@@ -710,7 +711,10 @@ class Uni3DETRTransformerDecoder(nn.Module):
                 self._reg_outputs.append(tmp)
                 assert ref_logits.shape[-1] == 3
                 td = tmp.detach()
-                ref_logits = torch.stack((td[..., 0] + ref_logits[..., 0], td[..., 1] + ref_logits[..., 1], td[..., 4] + ref_logits[..., 2]), -1).detach()
+                if self._xyz_cols is None or self._xyz_cols.device != td.device:
+                    self._xyz_cols = torch.tensor([0, 1, 4], device=td.device)
+                # (x, y, z) offsets sit in code columns 0, 1, 4 (ref :194-202): one gather + one add instead of three adds + a stack
+                ref_logits = (ref_logits.detach() + td.index_select(-1, self._xyz_cols).to(ref_logits.dtype)).detach()
             states.append(out)
             refs.append(ref_logits)
         if self.return_intermediate:
