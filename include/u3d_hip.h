@@ -394,6 +394,111 @@ int32_t u3d_permute_block_elems(void);
 int32_t u3d_permute_bf16_batched(const void* src, void* dst, const u3d_permute_desc* descs_dev, const int32_t* blocks_dev,
                                  int32_t nblocks, u3d_stream s);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused decoder layer (bf16 MFMA, f32 accumulation / residual stream / LayerNorm statistics / softmax statistics).
+ * One call = one Uni3DETRTransformerDecoder layer over ALL query groups of all scenes, plus everything the decoder loop and the head
+ * hang on that layer's state (ref: models/utils/uni3detr_transformer.py:145-212 decoder loop, :33-65 sine embedding, :271-360
+ * UniCrossAtten; mmcv BaseTransformerLayer / MultiheadAttention / FFN as configured in the "transformer" section of the shipped configs;
+ * models/dense_heads/uni3detr_head.py:367-387 cls / reg / iou branches):
+ *
+ *   pos   = ref_point_head(sine(sigmoid(ref))) [* query_scale(x) for layers > 0]
+ *   x1    = LN1(x + dropout(out_proj(MHA(q = k = x + pos, v = x))))            attention inside each group of nq queries
+ *   x2    = LN2(x1 + dropout(output_proj(trilinear(value, ref) * sigmoid(attention_weights(x1 + pos)))) + position_encoder(ref))
+ *   x3    = LN3(x2 + dropout(W2 dropout(relu(W1 x2))))
+ *   reg   = reg_branch(x3), cls = cls_branch(x3), iou = iou_branch(x3)
+ *
+ * Rows are [B, G*nq] (scene-major), M = B*G*nq; embed dim 256, 8 heads, FFN 512, num_points 1 (every shipped config).
+ * Launches: forward 3 (row-chain kernel | attention | row-chain kernel), backward 4; the row-chain kernels keep a 32-row block of
+ * the layer state in LDS through the whole chain of GEMMs / LayerNorms and stream the bf16 weights from L2 straight into MFMA
+ * fragments.  Weight / bias gradients are NOT computed here: the backward leaves every linear's dY (bf16) and every LayerNorm's
+ * per-workgroup (dgamma, dbeta) partial sums in the gradient workspace; the caller batches dW = dY^T X over layers
+ * (u3d_wgrad_batched_bf16 / u3d_skinny_wgrad_bf16 / u3d_colsum_batched).  Slot offsets: u3d_decoder_layer_slots().
+ * Dropout: counter-based (hash of seed, layer, site, element index); the backward regenerates the masks from the same seed.
+ * ---------------------------------------------------------------------------------------------- */
+enum {  /* wide linears: w bf16 [N(pad)][K] (nn.Linear layout), wt bf16 [K][N(pad)] (dgrad), b f32 [N] */
+  U3D_DL_RPH0, U3D_DL_RPH1, U3D_DL_RPH2,      /* ref_point_head 384->256->256->256 */
+  U3D_DL_QS0, U3D_DL_QS1, U3D_DL_QS2,         /* query_scale 256->256->256->256 (layers > 0) */
+  U3D_DL_INQK, U3D_DL_INV,                    /* in_proj rows [0,512) and [512,768) */
+  U3D_DL_OUTP,                                /* attn.out_proj */
+  U3D_DL_OPROJ,                               /* UniCrossAtten.output_proj */
+  U3D_DL_PE1,                                 /* position_encoder[3] */
+  U3D_DL_FFN0, U3D_DL_FFN1,                   /* 256->512, 512->256 */
+  U3D_DL_REG0, U3D_DL_REG1, U3D_DL_REG2,      /* REG2 / CLS2 / IOU2: N <= 32, w padded to 64 rows, wt to 32 columns */
+  U3D_DL_CLS0, U3D_DL_CLS1, U3D_DL_CLS2,
+  U3D_DL_IOU0, U3D_DL_IOU1, U3D_DL_IOU2,
+  U3D_DL_NLIN
+};
+enum { U3D_DLN_1, U3D_DLN_2, U3D_DLN_3, U3D_DLN_PE0, U3D_DLN_PE1, U3D_DLN_C1, U3D_DLN_C2, U3D_DL_NLN };
+typedef struct u3d_declayer_params {
+  const void* w[U3D_DL_NLIN];
+  const void* wt[U3D_DL_NLIN];
+  const float* b[U3D_DL_NLIN];
+  const float* ln_g[U3D_DL_NLN];
+  const float* ln_b[U3D_DL_NLN];
+  const float* attw_w; const float* attw_b;   /* attention_weights: f32 [256], [1] */
+  const float* pe0_w;  const float* pe0_b;    /* position_encoder[0]: f32 [256,3], [256] */
+  const float* dim_t;                         /* f32 [128]: T^(2*(f/2)/128) */
+} u3d_declayer_params;
+typedef struct u3d_declayer_dims {
+  int32_t m;            /* rows = batch * queries_per_scene */
+  int32_t nq;           /* queries per attention group */
+  int32_t qps;          /* queries per scene (groups * nq) */
+  int32_t batch, dz, dy, dx;   /* value volume: rows [(b*dz+z)*dy+y)*dx+x][256] bf16 */
+  int32_t ncls, code;   /* widths of the cls / reg outputs (<= 32) */
+  int32_t has_qs;       /* 0: first layer (pos = ref_point_head output) */
+  int32_t need_dref;    /* backward: also produce the gradient w.r.t. the reference-point logits */
+  int32_t layer;        /* dropout stream id */
+  float p_attn, p_drop; /* dropout probabilities: attention weights | the four residual / FFN sites (0 = off) */
+  float ln_eps;
+} u3d_declayer_dims;
+/* forward-save slots (row matrices [m, cols]); u3d_decoder_layer_slots fills byte offsets (U3D_DS_COUNT + 1 entries, last = total) */
+enum {
+  U3D_DS_SINE, U3D_DS_RPH1, U3D_DS_RPH2, U3D_DS_RAW, U3D_DS_QS1, U3D_DS_QS2, U3D_DS_QS, U3D_DS_POS, U3D_DS_QKIN,
+  U3D_DS_QK, U3D_DS_V, U3D_DS_LSE, U3D_DS_O, U3D_DS_U1, U3D_DS_MR, U3D_DS_QP, U3D_DS_SAMP, U3D_DS_GATED, U3D_DS_PEH0,
+  U3D_DS_UPE1, U3D_DS_U2, U3D_DS_X2C, U3D_DS_FFH, U3D_DS_U3, U3D_DS_R1, U3D_DS_R2, U3D_DS_I1, U3D_DS_I2, U3D_DS_UC1,
+  U3D_DS_C1, U3D_DS_UC2, U3D_DS_C2, U3D_DS_COUNT
+};
+/* backward-workspace slots: dY of every linear (bf16), LayerNorm partials, intermediate f32 gradients */
+enum {
+  U3D_DG_CLSO, U3D_DG_C2U, U3D_DG_C1U, U3D_DG_IOUO, U3D_DG_I2, U3D_DG_I1, U3D_DG_REGO, U3D_DG_R2, U3D_DG_R1, U3D_DG_F,
+  U3D_DG_FFH, U3D_DG_OUT, U3D_DG_UPE1, U3D_DG_P0, U3D_DG_WL, U3D_DG_O2, U3D_DG_DO, U3D_DG_DQK, U3D_DG_DV, U3D_DG_QS,
+  U3D_DG_QS2, U3D_DG_QS1, U3D_DG_RAW, U3D_DG_RPH2, U3D_DG_RPH1, U3D_DG_LNP, U3D_DG_DU1, U3D_DG_DPOSA, U3D_DG_SINE,
+  U3D_DG_COUNT
+};
+int32_t u3d_decoder_layer_slots(int32_t m, int32_t ncls, int32_t code, int64_t* save_off, int64_t* grad_off);
+int32_t u3d_decoder_layer_blocks(int32_t m);   /* workgroups of the row-chain kernels = rows of every U3D_DG_LNP partial matrix */
+/* ROW PADDING: every row matrix this layer WRITES (x_out, xc_out, reg_out, cls_out, iou_out, dx, dref and all slots) must hold
+ * u3d_decoder_layer_blocks(m) * 32 rows; rows >= m receive values nobody reads.  Matrices it only READS (x, xc, ref, dx_out, dreg,
+ * dcls, diou) have m rows.  (The row kernels contain no branch on the row index: see csrc/decoder_common.h.) */
+/* x f32 [m,256] layer input, xc its bf16 copy, ref f32 [m,3] logits, value bf16 rows, rng: device uint64 seed.
+ * Outputs: x_out f32 / xc_out bf16 [m,256], reg_out f32 [m,code], cls_out f32 [m,ncls], iou_out f32 [m]; save: the slot buffer. */
+int32_t u3d_decoder_layer_fwd(const u3d_declayer_params* p, const u3d_declayer_dims* d, const float* x, const void* xc,
+                              const float* ref, const void* value, const uint64_t* rng, float* x_out, void* xc_out,
+                              float* reg_out, float* cls_out, float* iou_out, void* save, int64_t save_bytes, u3d_stream s);
+/* Gradients in: dx_out f32 [m,256] (NULL = zero), dreg f32 [m,code], dcls f32 [m,ncls], diou f32 [m].
+ * Out: dx f32 [m,256] (w.r.t. the layer input x), dvalue f32 rows (ACCUMULATED with atomics: caller zero-fills once per step),
+ * dref f32 [m,3] (only when need_dref), and the gradient workspace `grad` (dY slots for the caller's weight-gradient pass). */
+int32_t u3d_decoder_layer_bwd(const u3d_declayer_params* p, const u3d_declayer_dims* d, const float* x, const void* xc,
+                              const float* ref, const void* value, const uint64_t* rng, const void* xc_out, const void* save,
+                              const float* dx_out, const float* dreg, const float* dcls, const float* diou, float* dx,
+                              float* dvalue, float* dref, void* grad, int64_t grad_bytes, u3d_stream s);
+/* Self-attention over groups on its own (the middle launch of the layer): q,k rows of qk [m,512] (q | k), v [m,256], 8 heads x 32;
+ * o bf16 [m,256], lse f32 [m,8].  Backward: dqk [m,512], dv [m,256] bf16. */
+int32_t u3d_mha_fwd(const void* qk, const void* v, int32_t m, int32_t nq, float p_attn, int32_t layer, const uint64_t* rng, void* o,
+                    float* lse, u3d_stream s);
+int32_t u3d_mha_bwd(const void* qk, const void* v, const void* o, const void* d_o, const float* lse, int32_t m, int32_t nq,
+                    float p_attn, int32_t layer, const uint64_t* rng, void* dqk, void* dv, u3d_stream s);
+/* Refresh of the bf16 weight copies the fused layer reads: for each descriptor dst[n][k] = bf16(src[n][k]) (rows n >= N zero up to
+ * n_pad) and dst_t[k][n] = the transpose with n_pad_t columns.  descs in device memory; one launch for all linears of all layers. */
+typedef struct u3d_wpack_desc {
+  const float* src; void* dst; void* dst_t;
+  int32_t n, k, n_pad, n_pad_t;
+} u3d_wpack_desc;
+int32_t u3d_wpack_bf16(const u3d_wpack_desc* descs_dev, int32_t count, int32_t max_elems, u3d_stream s);
+/* keep-mask of the layer's dropout sites as bytes (testing aid): site 0..3 = out_proj, output_proj, FFN hidden, FFN out over
+ * [m, cols]; site 4 = attention weights over [m*8, nq] (row = (group*8 + head)*nq + query). */
+int32_t u3d_dropout_mask(const uint64_t* rng, int32_t layer, int32_t site, int64_t n, float p, uint8_t* keep, u3d_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -994,7 +994,7 @@ extern "C" int32_t u3d_layernorm_bwd(const void* dy, int32_t y_dtype, const void
 // workgroup covers SK_ROWS rows -> partial f32 [chunks][n*k]; the caller column-sums the chunks (u3d_colsum / u3d_colsum_batched).
 // ---------------------------------------------------------------------------------------------
 #define SK_ROWS 128
-#define SK_MAX 16
+#define SK_MAX 32
 template <bool DY_SKINNY>
 __global__ __launch_bounds__(256) void k_skinny_wgrad(const u16* __restrict__ dy, const u16* __restrict__ x, int m, int n, int k,
                                                       float* __restrict__ partial) {

@@ -23,6 +23,35 @@ class BitGridStruct(C.Structure):
                 ("dy", C.c_int32), ("dx", C.c_int32), ("layout", C.c_int32), ("row_capacity", C.c_int32)]
 
 
+DL_NLIN, DL_NLN = 22, 7
+(DL_RPH0, DL_RPH1, DL_RPH2, DL_QS0, DL_QS1, DL_QS2, DL_INQK, DL_INV, DL_OUTP, DL_OPROJ, DL_PE1, DL_FFN0, DL_FFN1, DL_REG0, DL_REG1,
+ DL_REG2, DL_CLS0, DL_CLS1, DL_CLS2, DL_IOU0, DL_IOU1, DL_IOU2) = range(DL_NLIN)
+(DLN_1, DLN_2, DLN_3, DLN_PE0, DLN_PE1, DLN_C1, DLN_C2) = range(DL_NLN)
+DS_NAMES = ("SINE RPH1 RPH2 RAW QS1 QS2 QS POS QKIN QK V LSE O U1 MR QP SAMP GATED PEH0 UPE1 U2 X2C FFH U3 R1 R2 I1 I2 UC1 C1 UC2 "
+            "C2").split()
+DG_NAMES = ("CLSO C2U C1U IOUO I2 I1 REGO R2 R1 F FFH OUT UPE1 P0 WL O2 DO DQK DV QS QS2 QS1 RAW RPH2 RPH1 LNP DU1 DPOSA "
+            "SINE").split()
+
+
+class DecLayerParams(C.Structure):
+    """u3d_declayer_params (include/u3d_hip.h)."""
+    _fields_ = [("w", C.c_void_p * DL_NLIN), ("wt", C.c_void_p * DL_NLIN), ("b", C.c_void_p * DL_NLIN),
+                ("ln_g", C.c_void_p * DL_NLN), ("ln_b", C.c_void_p * DL_NLN), ("attw_w", C.c_void_p), ("attw_b", C.c_void_p),
+                ("pe0_w", C.c_void_p), ("pe0_b", C.c_void_p), ("dim_t", C.c_void_p)]
+
+
+class DecLayerDims(C.Structure):
+    """u3d_declayer_dims."""
+    _fields_ = [(n, C.c_int32) for n in ("m", "nq", "qps", "batch", "dz", "dy", "dx", "ncls", "code", "has_qs", "need_dref", "layer")] + \
+               [("p_attn", C.c_float), ("p_drop", C.c_float), ("ln_eps", C.c_float)]
+
+
+class WPackDesc(C.Structure):
+    """u3d_wpack_desc."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_t", C.c_void_p), ("n", C.c_int32), ("k", C.c_int32),
+                ("n_pad", C.c_int32), ("n_pad_t", C.c_int32)]
+
+
 _lib = None
 _P = C.c_void_p
 _I = C.c_int32
@@ -103,6 +132,14 @@ _SIGS = {
     "u3d_adamw_workspace": (_L, [_L]),
     "u3d_adamw_step": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _L, _P]),
     "u3d_gather_rows": (_I, [_P, _P, _I, _I, _P, _P]),
+    "u3d_decoder_layer_slots": (_I, [_I, _I, _I, _P, _P]),
+    "u3d_decoder_layer_blocks": (_I, [_I]),
+    "u3d_decoder_layer_fwd": (_I, [C.POINTER(DecLayerParams), C.POINTER(DecLayerDims)] + [_P] * 11 + [_L, _P]),
+    "u3d_decoder_layer_bwd": (_I, [C.POINTER(DecLayerParams), C.POINTER(DecLayerDims)] + [_P] * 15 + [_L, _P]),
+    "u3d_mha_fwd": (_I, [_P, _P, _I, _I, C.c_float, _I, _P, _P, _P, _P]),
+    "u3d_mha_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, C.c_float, _I, _P, _P, _P, _P]),
+    "u3d_wpack_bf16": (_I, [_P, _I, _I, _P]),
+    "u3d_dropout_mask": (_I, [_P, _I, _I, _L, C.c_float, _P, _P]),
     "u3d_scatter_rows": (_I, [_P, _P, _I, _I, _P, _P]),
 }
 
@@ -798,3 +835,87 @@ def sine_embed_bwd(logits, dim_t, dout):
     _check(lib().u3d_sine_embed_bwd(_ptr(logits), _ptr(dim_t), _ptr(dout), dtype_code(dout), n, nc, dim_t.numel(), _ptr(dl), _stream()),
            "sine_embed_bwd")
     return dl
+
+
+# --------------------------------------------------------------------------------------------------
+# fused decoder layer (csrc/decoder.hip, csrc/decoder_bwd.hip)
+# --------------------------------------------------------------------------------------------------
+_SLOT_CACHE = {}
+
+
+def decoder_layer_slots(m, ncls, code):
+    """(save_off, grad_off): dicts slot name -> byte offset, plus "_total"."""
+    key = (m, ncls, code)
+    r = _SLOT_CACHE.get(key)
+    if r is None:
+        so = (C.c_int64 * (len(DS_NAMES) + 1))()
+        go = (C.c_int64 * (len(DG_NAMES) + 1))()
+        _check(lib().u3d_decoder_layer_slots(m, ncls, code, so, go), "decoder_layer_slots")
+        r = ({**{n: int(so[i]) for i, n in enumerate(DS_NAMES)}, "_total": int(so[len(DS_NAMES)])},
+             {**{n: int(go[i]) for i, n in enumerate(DG_NAMES)}, "_total": int(go[len(DG_NAMES)])})
+        _SLOT_CACHE[key] = r
+    return r
+
+
+def slot_view(buf, off, rows, cols, dtype):
+    """[rows, cols] view of `dtype` at byte offset `off` of the uint8 buffer `buf`."""
+    nbytes = rows * cols * torch.empty((), dtype=dtype).element_size()
+    return buf[off:off + nbytes].view(dtype).view(rows, cols)
+
+
+def decoder_rows(m):
+    """rows every buffer owned by the fused layer holds: m rounded up to whole 32-row blocks (the kernels never branch on the row)."""
+    return int(lib().u3d_decoder_layer_blocks(m)) * 32
+
+
+def decoder_layer_fwd(params, dims, x, xc, ref, value_rows, rng, save):
+    m, code, ncls = dims.m, dims.code, dims.ncls
+    mp = decoder_rows(m)
+    dev = x.device
+    x_out = torch.empty((mp, 256), dtype=torch.float32, device=dev)
+    xc_out = torch.empty((mp, 256), dtype=torch.bfloat16, device=dev)
+    reg = torch.empty((mp, code), dtype=torch.float32, device=dev)
+    cls = torch.empty((mp, ncls), dtype=torch.float32, device=dev)
+    iou = torch.empty((mp,), dtype=torch.float32, device=dev)
+    _check(lib().u3d_decoder_layer_fwd(C.byref(params), C.byref(dims), _ptr(x), _ptr(xc), _ptr(ref), _ptr(value_rows), _ptr(rng),
+                                       _ptr(x_out), _ptr(xc_out), _ptr(reg), _ptr(cls), _ptr(iou), _ptr(save), save.numel(), _stream()),
+           "decoder_layer_fwd")
+    return x_out[:m], xc_out[:m], reg[:m], cls[:m], iou[:m]
+
+
+def decoder_layer_bwd(params, dims, x, xc, ref, value_rows, rng, xc_out, save, dx_out, dreg, dcls, diou, dvalue, grad):
+    m = dims.m
+    mp = decoder_rows(m)
+    dx = torch.empty((mp, 256), dtype=torch.float32, device=ref.device)
+    dref = torch.empty((mp, 3), dtype=torch.float32, device=ref.device) if dims.need_dref else None
+    _check(lib().u3d_decoder_layer_bwd(C.byref(params), C.byref(dims), _ptr(x), _ptr(xc), _ptr(ref), _ptr(value_rows), _ptr(rng),
+                                       _ptr(xc_out), _ptr(save), _ptr(dx_out), _ptr(dreg), _ptr(dcls), _ptr(diou), _ptr(dx),
+                                       _ptr(dvalue), _ptr(dref), _ptr(grad), grad.numel(), _stream()), "decoder_layer_bwd")
+    return dx[:m], (None if dref is None else dref[:m])
+
+
+def mha_fwd(qk, v, nq, p_attn=0.0, layer=0, rng=None):
+    """qk bf16 [m,512] (q | k), v bf16 [m,256] -> (o bf16 [m,256], lse f32 [m,8] in log2 units)."""
+    m = qk.shape[0]
+    o = torch.empty((m, 256), dtype=torch.bfloat16, device=qk.device)
+    lse = torch.empty((m, 8), dtype=torch.float32, device=qk.device)
+    _check(lib().u3d_mha_fwd(_ptr(qk), _ptr(v), m, nq, p_attn, layer, _ptr(rng), _ptr(o), _ptr(lse), _stream()), "mha_fwd")
+    return o, lse
+
+
+def mha_bwd(qk, v, o, d_o, lse, nq, p_attn=0.0, layer=0, rng=None):
+    m = qk.shape[0]
+    dqk, dv = torch.empty_like(qk), torch.empty_like(v)
+    _check(lib().u3d_mha_bwd(_ptr(qk), _ptr(v), _ptr(o), _ptr(d_o), _ptr(lse), m, nq, p_attn, layer, _ptr(rng), _ptr(dqk), _ptr(dv),
+                             _stream()), "mha_bwd")
+    return dqk, dv
+
+
+def wpack_bf16(descs_dev, count, max_elems):
+    _check(lib().u3d_wpack_bf16(_ptr(descs_dev), count, max_elems, _stream()), "wpack_bf16")
+
+
+def dropout_mask(rng, layer, site, n, p):
+    keep = torch.empty((n,), dtype=torch.uint8, device=rng.device)
+    _check(lib().u3d_dropout_mask(_ptr(rng), layer, site, n, p, _ptr(keep), _stream()), "dropout_mask")
+    return keep

@@ -1,0 +1,396 @@
+"""Fused bf16 decoder path: every decoder layer (+ the reference-point / query-scale MLPs in front of it and the reg / cls / iou
+branches behind it) is ONE C-ABI call forward and one backward (u3d_decoder_layer_fwd / _bwd: csrc/decoder.hip, decoder_bwd.hip) -
+own MFMA row-chain kernels and own attention kernels; no torch GEMM / SDPA / element-wise launch in between.
+
+ref: projects/mmdet3d_plugin/models/utils/uni3detr_transformer.py:145-212 (decoder loop), :271-360 (UniCrossAtten),
+models/dense_heads/uni3detr_head.py:367-387, 470-490 (branches; the box decode stays in Uni3DETRHead.forward).
+
+The module layout is the registry's (plugin/transformer.py, plugin/head.py): this file only gathers the parameters, keeps bf16
+copies of the weights (one refresh launch per step: u3d_wpack_bf16) and turns the kernels' gradient slots into parameter
+gradients through the same deferred / batched mechanism the layer-by-layer path uses (plugin/transformer.py `_Deferred`).
+"""
+import ctypes as C
+import os
+
+import torch
+from torch import nn
+
+from .. import native as nv
+
+ENABLED = os.environ.get("U3D_FUSED_DECODER", "1") == "1"
+POISON = os.environ.get("U3D_DEC_POISON", "0") == "1"      # debugging: NaN-fill the workspaces (read-before-write shows up as NaN)
+DEBUG_KEEP = None          # tests: a list that receives every backward call's gradient workspace
+
+# (enum index, rows of the weight that belong to this linear) for the wide linears; narrow finals are padded
+_WIDE = [nv.DL_RPH0, nv.DL_RPH1, nv.DL_RPH2, nv.DL_QS0, nv.DL_QS1, nv.DL_QS2, nv.DL_INQK, nv.DL_INV, nv.DL_OUTP, nv.DL_OPROJ, nv.DL_PE1,
+         nv.DL_FFN0, nv.DL_FFN1, nv.DL_REG0, nv.DL_REG1, nv.DL_CLS0, nv.DL_CLS1, nv.DL_IOU0, nv.DL_IOU1]
+_NARROW = [nv.DL_REG2, nv.DL_CLS2, nv.DL_IOU2]
+
+
+def _is_seq(seq, kinds):
+    return isinstance(seq, nn.Sequential) and len(seq) == len(kinds) and all(isinstance(m, k) for m, k in zip(seq, kinds))
+
+
+class LayerSpec:
+    """Parameters of one fused layer, in the order of the C enums: lin[i] = (weight tensor, first row, rows, bias)."""
+
+    def __init__(self, decoder, lid, reg_branch, cls_branch, iou_branch):
+        from .transformer import FFN, MultiheadAttention, UniCrossAtten
+        layer = decoder.layers[lid]
+        if layer.operation_order != ("self_attn", "norm", "cross_attn", "norm", "ffn", "norm"):
+            raise ValueError("operation order")
+        sa, ca, ffn = layer.attentions[0], layer.attentions[1], layer.ffns[0]
+        if not (isinstance(sa, MultiheadAttention) and isinstance(ca, UniCrossAtten) and isinstance(ffn, FFN)):
+            raise ValueError("layer members")
+        if sa.embed_dims != 256 or sa.num_heads != 8 or ca.num_points != 1 or not ffn.add_identity:
+            raise ValueError("dims")
+        if not (_is_seq(ffn.layers, (nn.Sequential, nn.Linear, nn.Dropout)) and _is_seq(ffn.layers[0], (nn.Linear, nn.ReLU, nn.Dropout))):
+            raise ValueError("ffn layout")
+        f0, f1 = ffn.layers[0][0], ffn.layers[1]
+        if f0.out_features != 512 or f1.in_features != 512:
+            raise ValueError("ffn width")
+        pe = ca.position_encoder
+        if not _is_seq(pe, (nn.Linear, nn.LayerNorm, nn.ReLU, nn.Linear, nn.LayerNorm, nn.ReLU)):
+            raise ValueError("position encoder")
+        if not (_is_seq(reg_branch, (nn.Linear, nn.ReLU, nn.Linear, nn.ReLU, nn.Linear))
+                and _is_seq(iou_branch, (nn.Linear, nn.ReLU, nn.Linear, nn.ReLU, nn.Linear))
+                and _is_seq(cls_branch, (nn.Linear, nn.LayerNorm, nn.ReLU, nn.Linear, nn.LayerNorm, nn.ReLU, nn.Linear))):
+            raise ValueError("branch layout")
+        rph, qs = decoder.ref_point_head.layers, decoder.query_scale.layers
+        if len(rph) != 3 or len(qs) != 3 or rph[0].in_features != 384:
+            raise ValueError("mlp layout")
+        ipw, ipb = sa.attn.in_proj_weight, sa.attn.in_proj_bias
+        if ipw is None or ipb is None or sa.attn.out_proj.bias is None:
+            raise ValueError("in_proj")
+        L = lambda m: (m.weight, 0, m.weight.shape[0], m.bias)
+        self.lin = [None] * nv.DL_NLIN
+        for i, m in zip((nv.DL_RPH0, nv.DL_RPH1, nv.DL_RPH2), rph):
+            self.lin[i] = L(m)
+        for i, m in zip((nv.DL_QS0, nv.DL_QS1, nv.DL_QS2), qs):
+            self.lin[i] = L(m)
+        self.lin[nv.DL_INQK] = (ipw, 0, 512, ipb)
+        self.lin[nv.DL_INV] = (ipw, 512, 256, ipb)
+        self.lin[nv.DL_OUTP] = L(sa.attn.out_proj)
+        self.lin[nv.DL_OPROJ] = L(ca.output_proj)
+        self.lin[nv.DL_PE1] = L(pe[3])
+        self.lin[nv.DL_FFN0], self.lin[nv.DL_FFN1] = L(f0), L(f1)
+        self.lin[nv.DL_REG0], self.lin[nv.DL_REG1], self.lin[nv.DL_REG2] = L(reg_branch[0]), L(reg_branch[2]), L(reg_branch[4])
+        self.lin[nv.DL_CLS0], self.lin[nv.DL_CLS1], self.lin[nv.DL_CLS2] = L(cls_branch[0]), L(cls_branch[3]), L(cls_branch[6])
+        self.lin[nv.DL_IOU0], self.lin[nv.DL_IOU1], self.lin[nv.DL_IOU2] = L(iou_branch[0]), L(iou_branch[2]), L(iou_branch[4])
+        for w, _, _, b in self.lin:
+            if b is None or w.dtype != torch.float32:
+                raise ValueError("bias / dtype")
+        self.ln = [layer.norms[0], layer.norms[1], layer.norms[2], pe[1], pe[4], cls_branch[1], cls_branch[4]]
+        if any(abs(n.eps - self.ln[0].eps) > 0 or not n.elementwise_affine or n.normalized_shape != (256,) for n in self.ln):
+            raise ValueError("norms")
+        self.attw, self.pe0 = ca.attention_weights, pe[0]
+        self.ncls, self.code = cls_branch[6].out_features, reg_branch[4].out_features
+        if self.ncls > 32 or self.code > 32 or iou_branch[4].out_features != 1 or pe[0].in_features != 3:
+            raise ValueError("narrow widths")
+        # dropout: one probability for the four residual / FFN sites, one for the attention weights
+        ps = {float(sa.dropout_layer.p) if isinstance(sa.dropout_layer, nn.Dropout) else 0.0, float(ca.dropout.p),
+              float(ffn.layers[0][2].p), float(ffn.layers[2].p)}
+        if len(ps) != 1 or float(sa.proj_drop.p) != 0.0 or isinstance(ffn.dropout_layer, nn.Dropout):
+            raise ValueError("dropout layout")
+        self.p_drop, self.p_attn = ps.pop(), float(sa.attn_drop)
+        self.modules = (sa, ca, ffn)
+
+    def tensors(self):
+        """Flat list of the parameter tensors handed to autograd (order fixed: see FusedLayerFn.backward)."""
+        out = []
+        for w, _, _, b in self.lin:
+            out += [w, b]
+        for n in self.ln:
+            out += [n.weight, n.bias]
+        out += [self.attw.weight, self.attw.bias, self.pe0.weight, self.pe0.bias]
+        return out
+
+
+class FusedDecoder:
+    """bf16 weight copies + per-layer parameter blocks of one (decoder, head branches) pair."""
+
+    def __init__(self, decoder, reg_branches, cls_branches, iou_branches):
+        self.decoder = decoder
+        self.specs = [LayerSpec(decoder, i, reg_branches[i], cls_branches[i], iou_branches[i]) for i in range(decoder.num_layers)]
+        self._key = None
+        self.rng = None
+        self._dim_t = None
+
+    # ---- weight copies ---------------------------------------------------------------------------------------------------
+    def _build(self, dev):
+        uniq = {}                      # (id(weight), first row) -> (w, r0, rows)
+        for sp in self.specs:
+            for i, (w, r0, rows, _) in enumerate(sp.lin):
+                uniq.setdefault((id(w), r0), (w, r0, rows, i in _NARROW))
+        total = 0
+        plan = {}
+        for key, (w, r0, rows, narrow) in uniq.items():
+            k = w.shape[1]
+            n_pad = 64 if narrow else rows
+            n_pad_t = 32 if narrow else rows
+            plan[key] = (total, total + n_pad * k, n_pad, n_pad_t)
+            total += n_pad * k + k * n_pad_t
+            total = (total + 127) // 128 * 128
+        self.wbuf = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+        descs = (nv.WPackDesc * len(uniq))()
+        self._views = {}
+        max_elems = 1
+        for j, (key, (w, r0, rows, narrow)) in enumerate(uniq.items()):
+            k = w.shape[1]
+            o, ot, n_pad, n_pad_t = plan[key]
+            d = descs[j]
+            d.src = w.data_ptr() + r0 * k * 4
+            d.dst = self.wbuf.data_ptr() + o * 2
+            d.dst_t = self.wbuf.data_ptr() + ot * 2
+            d.n, d.k, d.n_pad, d.n_pad_t = rows, k, n_pad, n_pad_t
+            self._views[key] = (d.dst, d.dst_t)
+            max_elems = max(max_elems, n_pad * k, k * n_pad_t)
+        self._ndesc, self._max_elems = len(uniq), max_elems
+        self._descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        if self._dim_t is None or self._dim_t.device != dev:
+            d = torch.arange(128, dtype=torch.float32, device=dev)
+            self._dim_t = 10000 ** (2 * torch.div(d, 2, rounding_mode="floor") / 128)
+        self.params = []
+        for sp in self.specs:
+            p = nv.DecLayerParams()
+            for i, (w, r0, rows, b) in enumerate(sp.lin):
+                dst, dst_t = self._views[(id(w), r0)]
+                p.w[i], p.wt[i] = dst, dst_t
+                p.b[i] = b.data_ptr() + r0 * 4
+            for i, n in enumerate(sp.ln):
+                p.ln_g[i], p.ln_b[i] = n.weight.data_ptr(), n.bias.data_ptr()
+            p.attw_w, p.attw_b = sp.attw.weight.data_ptr(), sp.attw.bias.data_ptr()
+            p.pe0_w, p.pe0_b = sp.pe0.weight.data_ptr(), sp.pe0.bias.data_ptr()
+            p.dim_t = self._dim_t.data_ptr()
+            self.params.append(p)
+        if self.rng is None or self.rng.device != dev:
+            self.rng = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFF], dtype=torch.int64, device=dev)
+
+    def refresh(self, dev):
+        """bf16 copies of the current master weights (one launch); rebuilt when a parameter moved (e.g. into the trainer's flat buffer)."""
+        key = (str(dev),) + tuple(t.data_ptr() for sp in self.specs for t in sp.tensors())
+        if key != self._key:
+            self._build(dev)
+            self._key = key
+        nv.wpack_bf16(self._descs_dev, self._ndesc, self._max_elems)
+
+
+def eligible(decoder, query, value, reg_branches, head_branches):
+    if not (ENABLED and query.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        return False
+    if reg_branches is None or head_branches is None or value.dim() != 5 or value.shape[1] != 256 or query.shape[-1] != 256:
+        return False
+    if len(reg_branches) != decoder.num_layers or len({id(m) for m in reg_branches}) != decoder.num_layers:
+        return False
+    return True
+
+
+class FusedLayerFn(torch.autograd.Function):
+    """One decoder layer.  Inputs: x f32 [M,256]; xc bf16 copy of x or None; ref f32 [M,3] logits; rows bf16 [B*D*H*W,256]; meta."""
+
+    @staticmethod
+    def forward(ctx, x, xc, ref, rows, meta, *ptensors):
+        fd, lid, dims_t, accum = meta
+        sp = fd.specs[lid]
+        B, qps, nq, D, H, W = dims_t
+        M = x.shape[0]
+        x = x.contiguous()
+        xc = x.to(torch.bfloat16) if xc is None else xc
+        ref = ref.contiguous().float()
+        d = nv.DecLayerDims()
+        d.m, d.nq, d.qps, d.batch, d.dz, d.dy, d.dx = M, nq, qps, B, D, H, W
+        d.ncls, d.code, d.has_qs, d.need_dref, d.layer = sp.ncls, sp.code, int(lid > 0), 0, lid
+        train = fd.decoder.training
+        d.p_attn = sp.p_attn if train else 0.0
+        d.p_drop = sp.p_drop if train else 0.0
+        d.ln_eps = float(sp.ln[0].eps)
+        so, go = nv.decoder_layer_slots(M, sp.ncls, sp.code)
+        save = torch.empty(so["_total"], dtype=torch.uint8, device=x.device)
+        if POISON:
+            save.fill_(255)
+        x_out, xc_out, reg, cls, iou = nv.decoder_layer_fwd(fd.params[lid], d, x, xc, ref, rows, fd.rng, save)
+        ctx.save_for_backward(x, xc, ref, rows, xc_out, save)
+        ctx.meta, ctx.dims = meta, d
+        ctx.wids = []
+        from .transformer import _Deferred
+        for w, r0, rows_, b in sp.lin:
+            if r0 == 0:
+                _Deferred.uses[id(w)] = _Deferred.uses.get(id(w), 0) + 1
+                _Deferred.params[id(w)] = (w, b)
+        for t in (sp.attw.weight, sp.pe0.weight):
+            _Deferred.uses[id(t)] = _Deferred.uses.get(id(t), 0) + 1
+        for n in sp.ln:
+            _Deferred.uses[id(n.weight)] = _Deferred.uses.get(id(n.weight), 0) + 1
+        ctx.mark_non_differentiable(xc_out)
+        return x_out, xc_out, reg, cls, iou
+
+    @staticmethod
+    def backward(ctx, dx_out, _dxc, dreg, dcls, diou):
+        from .transformer import _Deferred
+        x, xc, ref, rows, xc_out, save = ctx.saved_tensors
+        fd, lid, dims_t, accum = ctx.meta
+        sp, d = fd.specs[lid], ctx.dims
+        M = x.shape[0]
+        dev = x.device
+        d.need_dref = int(ctx.needs_input_grad[2])
+        so, go = nv.decoder_layer_slots(M, sp.ncls, sp.code)
+        grad = torch.empty(go["_total"], dtype=torch.uint8, device=dev)
+        if POISON:
+            grad.fill_(255)
+        z = lambda t, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if t is None else t.contiguous().float()
+        dreg, dcls, diou = z(dreg, (M, sp.code)), z(dcls, (M, sp.ncls)), z(diou, (M,))
+        dx_out = None if dx_out is None else dx_out.contiguous().float()
+        want_dv = ctx.needs_input_grad[3]
+        if accum is not None:
+            if accum.buf is None:
+                accum.buf = torch.zeros(rows.shape, dtype=torch.float32, device=dev)
+            dvalue = accum.buf
+        else:
+            dvalue = torch.zeros(rows.shape, dtype=torch.float32, device=dev)
+        dx, dref = nv.decoder_layer_bwd(fd.params[lid], d, x, xc, ref, rows, fd.rng, xc_out, save, dx_out, dreg, dcls, diou, dvalue, grad)
+        if DEBUG_KEEP is not None:
+            DEBUG_KEEP.append(grad)
+        drows = None
+        if accum is not None:
+            accum.remaining -= 1
+            if accum.remaining == 0:
+                drows = accum.buf.to(rows.dtype) if want_dv else None
+                accum.buf = None
+        elif want_dv:
+            drows = dvalue.to(rows.dtype)
+        bf, f32 = torch.bfloat16, torch.float32
+        S = lambda name, cols, dt=bf: nv.slot_view(save, so[name], M, cols, dt)
+        Gv = lambda name, cols, dt=bf: nv.slot_view(grad, go[name], M, cols, dt)
+        if d.need_dref:      # the sine-embedding path of the reference-point gradient (ref_point_head's input)
+            dref = dref + nv.sine_embed_bwd(ref, fd._dim_t, Gv("SINE", 384))
+        # ---- parameter gradients: (dY, X) per linear --------------------------------------------------------------------------
+        pairs = {
+            nv.DL_RPH0: (Gv("RPH1", 256), S("SINE", 384)), nv.DL_RPH1: (Gv("RPH2", 256), S("RPH1", 256)),
+            nv.DL_RPH2: (Gv("RAW", 256), S("RPH2", 256)),
+            nv.DL_INQK: (Gv("DQK", 512), S("QKIN", 256)), nv.DL_INV: (Gv("DV", 256), xc),
+            nv.DL_OUTP: (Gv("O2", 256), S("O", 256)), nv.DL_OPROJ: (Gv("OUT", 256), S("GATED", 256)),
+            nv.DL_PE1: (Gv("UPE1", 256), S("PEH0", 256)), nv.DL_FFN0: (Gv("FFH", 512), S("X2C", 256)),
+            nv.DL_FFN1: (Gv("F", 256), S("FFH", 512)), nv.DL_REG0: (Gv("R1", 256), xc_out), nv.DL_REG1: (Gv("R2", 256), S("R1", 256)),
+            nv.DL_REG2: (Gv("REGO", sp.code), S("R2", 256)), nv.DL_CLS0: (Gv("C1U", 256), xc_out),
+            nv.DL_CLS1: (Gv("C2U", 256), S("C1", 256)), nv.DL_CLS2: (Gv("CLSO", sp.ncls), S("C2", 256)),
+            nv.DL_IOU0: (Gv("I1", 256), xc_out), nv.DL_IOU1: (Gv("I2", 256), S("I1", 256)), nv.DL_IOU2: (Gv("IOUO", 1), S("I2", 256)),
+        }
+        if lid > 0:
+            pairs.update({nv.DL_QS0: (Gv("QS1", 256), xc), nv.DL_QS1: (Gv("QS2", 256), S("QS1", 256)), nv.DL_QS2: (Gv("QS", 256), S("QS2", 256))})
+        deferred_ok = _Deferred.active
+        grads = []
+        wgrad_now = {}              # (n, k) -> list of (dy, x, out)
+        sums_now = []               # (matrix, out vector)
+        new = lambda *shape: torch.empty(shape, dtype=f32, device=dev)
+        inproj_dw = inproj_db = None
+        for i, (w, r0, rows_, b) in enumerate(sp.lin):
+            if i not in pairs:                                   # query_scale in the first layer: unused
+                grads += [None, None]
+                continue
+            dy, xin = pairs[i]
+            n, k = rows_, w.shape[1]
+            if i in (nv.DL_INQK, nv.DL_INV):
+                if inproj_dw is None:
+                    inproj_dw, inproj_db = new(*w.shape), new(w.shape[0])
+                dw, db = inproj_dw[r0:r0 + rows_], inproj_db[r0:r0 + rows_]
+            else:
+                dw, db = new(n, k), new(n)
+            single = _Deferred.uses.get(id(w), 0) == 1
+            if i in _NARROW:
+                part = nv.skinny_wgrad_partial(dy, xin)
+                if deferred_ok and single:
+                    _Deferred.sum_items.append((part, w))
+                    _Deferred.sum_items.append((dy, b))
+                else:
+                    sums_now += [(part, dw.view(-1)), (dy, db)]
+            elif deferred_ok and single:
+                _Deferred.items.append((dy, xin, id(w), r0, r0 + rows_, True))
+            else:
+                wgrad_now.setdefault((n, k), []).append((dy, xin, dw))
+                sums_now.append((dy, db))
+            if i == nv.DL_INV:
+                grads += []                                      # in_proj weight / bias were emitted with INQK
+            elif i == nv.DL_INQK:
+                grads += [inproj_dw, inproj_db]
+            else:
+                grads += [dw, db]
+        lnp = nv.slot_view(grad, go["LNP"], nv.DL_NLN * 2 * d_blocks(M), 256, f32)
+        nb = d_blocks(M)
+        for j, nmod in enumerate(sp.ln):
+            dg, db = new(256), new(256)
+            mg, mb = lnp[(2 * j) * nb:(2 * j + 1) * nb], lnp[(2 * j + 1) * nb:(2 * j + 2) * nb]
+            if deferred_ok and _Deferred.uses.get(id(nmod.weight), 0) == 1:
+                _Deferred.sum_items += [(mg, nmod.weight), (mb, nmod.bias)]
+            else:
+                sums_now += [(mg, dg), (mb, db)]
+            grads += [dg, db]
+        # attention_weights (256 -> 1) and the position encoder's first layer (3 -> 256): skinny products
+        for dy, xin, mod in ((Gv("WL", 1), S("QP", 256), sp.attw), (Gv("P0", 256), ref.to(bf), sp.pe0)):
+            dw, db = new(*mod.weight.shape), new(mod.bias.shape[0])
+            part = nv.skinny_wgrad_partial(dy, xin.contiguous())
+            if deferred_ok and _Deferred.uses.get(id(mod.weight), 0) == 1:
+                _Deferred.params[id(mod.weight)] = (mod.weight, mod.bias)
+                _Deferred.sum_items += [(part, mod.weight), (dy, mod.bias)]
+            else:
+                sums_now += [(part, dw.view(-1)), (dy, db)]
+            grads += [dw, db]
+        for (n, k), lst in wgrad_now.items():
+            nv.wgrad_batched([a for a, _, _ in lst], [b_ for _, b_, _ in lst], [c for _, _, c in lst])
+        groups = {}
+        for mat, out in sums_now:
+            groups.setdefault((mat.shape[0], mat.shape[1], str(mat.dtype)), []).append((mat, out))
+        for lst in groups.values():
+            nv.colsum_batched([a for a, _ in lst], [b_ for _, b_ in lst])
+        # in_proj appears twice in sp.lin (INQK, INV) but once in the tensor list: the INV entry added nothing above
+        return (dx, None, dref, drows, None) + tuple(grads)
+
+
+def d_blocks(m):
+    return int(nv.lib().u3d_decoder_layer_blocks(m))
+
+
+def tensor_list(sp):
+    """Parameter tensors in the order FusedLayerFn.backward emits their gradients."""
+    out = []
+    for i, (w, r0, rows, b) in enumerate(sp.lin):
+        if i == nv.DL_INV:
+            continue
+        out += [w, b]
+    for n in sp.ln:
+        out += [n.weight, n.bias]
+    out += [sp.attw.weight, sp.attw.bias, sp.pe0.weight, sp.pe0.bias]
+    return out
+
+
+def run(fd, query, ref_logits, value, group):
+    """query [B,N,256] f32, ref_logits [B,N,3], value [B,256,D,H,W] -> per-layer lists (states [B,N,256] f32, refs, reg, cls, iou)."""
+    from .transformer import ValueGradAccum
+    B, N, Cc = query.shape
+    _, _, D, H, W = value.shape
+    rows = value.permute(0, 2, 3, 4, 1).reshape(-1, Cc)
+    rows = rows if rows.dtype == torch.bfloat16 else rows.to(torch.bfloat16)
+    rows = rows if rows.is_contiguous() else rows.contiguous()
+    dev = query.device
+    fd.refresh(dev)
+    if fd.decoder.training:
+        fd.rng.add_(0x9E3779B1)                         # new dropout stream every step (captured: advances on every graph replay)
+    L = fd.decoder.num_layers
+    accum = ValueGradAccum(L) if (value.requires_grad and torch.is_grad_enabled()) else None
+    x = query.reshape(B * N, Cc).float()
+    xc = None
+    ref = ref_logits.reshape(B * N, 3).float()
+    states, refs, regs, clss, ious = [], [], [], [], []
+    cols = None
+    for lid in range(L):
+        sp = fd.specs[lid]
+        meta = (fd, lid, (B, N, group, D, H, W), accum)
+        x, xc, reg, cls, iou = FusedLayerFn.apply(x, xc, ref, rows, meta, *tensor_list(sp))
+        if cols is None:
+            cols = torch.tensor([0, 1, 4], device=dev)
+        ref = (ref.detach() + reg.detach().index_select(-1, cols)).detach()
+        states.append(x.view(B, N, Cc))
+        refs.append(ref.view(B, N, 3))
+        regs.append(reg.view(B, N, -1))
+        clss.append(cls.view(B, N, -1))
+        ious.append(iou.view(B, N, 1))
+    return states, refs, regs, clss, ious

@@ -167,6 +167,9 @@ class Uni3DETRHead(nn.Module):
             tgts.append(tgt[nq:])
         tgt_all = torch.cat(tgts)
         query_embeds = torch.cat([tgt_all.unsqueeze(0).expand(B, -1, -1), torch.cat(refs, 1).to(tgt_all.dtype)], -1)
+        dec = self.transformer.decoder
+        if self.with_box_refine and hasattr(dec, "forward_bf"):
+            object.__setattr__(dec, "_head_branches", (self.cls_branches, self.iou_branches))     # the fused bf16 path runs them per layer
         hs, init_reference, inter_references = self.transformer(
             pts_feats, query_embeds, nq, reg_branches=self.reg_branches if self.with_box_refine else None, img_metas=img_metas)
         hs = hs.permute(0, 2, 1, 3)                                                   # [L,B,N,C]
@@ -194,8 +197,13 @@ class Uni3DETRHead(nn.Module):
                 y_ = (t[1] + rf[1]).sigmoid() * (pr[4] - pr[1]) + pr[1]
                 z_ = (t[4] + rf[2]).sigmoid() * (pr[5] - pr[2]) + pr[2]
                 coords.append(torch.stack([x_, y_, t[2], t[3], z_, *t[5:]], -1))
-            classes.append(run_sequential(self.cls_branches[lvl], h).float())
-            ious.append(run_sequential(self.iou_branches[lvl], h).float())
+            cls_o, iou_o = getattr(dec, "_cls_outputs", None), getattr(dec, "_iou_outputs", None)
+            if cls_o is not None and iou_o is not None and len(cls_o) == hs.shape[0]:
+                classes.append(cls_o[lvl])          # produced by the fused decoder layer on this very state
+                ious.append(iou_o[lvl])
+            else:
+                classes.append(run_sequential(self.cls_branches[lvl], h).float())
+                ious.append(run_sequential(self.iou_branches[lvl], h).float())
         return {"all_cls_scores": torch.stack(classes), "all_bbox_preds": torch.stack(coords), "all_iou_preds": torch.stack(ious)}
 
     # ------------------------------------------------------------------------------------------

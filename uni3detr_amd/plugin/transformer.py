@@ -688,8 +688,34 @@ class Uni3DETRTransformerDecoder(nn.Module):
         self.ref_point_head = MLP(384, d, d, 3)
         self._xyz_cols = None
 
+    def _fused_decoder(self, query, value, reg_branches):
+        """The FusedDecoder serving this call, or None (fp32 mode, CPU, a layout the fused kernels do not cover)."""
+        from . import fused_decoder as _fdm
+        hb = getattr(self, "_head_branches", None)
+        if not _fdm.eligible(self, query, value, reg_branches, hb):
+            return None
+        key = (tuple(id(m) for m in reg_branches), tuple(id(m) for m in hb[0]), tuple(id(m) for m in hb[1]))
+        cached = getattr(self, "_fused_cache", None)
+        if cached is None or cached[0] != key:
+            try:
+                cached = (key, _fdm.FusedDecoder(self, reg_branches, hb[0], hb[1]))
+            except ValueError:
+                cached = (key, None)
+            object.__setattr__(self, "_fused_cache", cached)
+        return cached[1]
+
     def forward_bf(self, query, ref_logits, value, reg_branches, group):
         """query [B,N,C], ref_logits [B,N,3] -> (states [L,B,N,C], refs [L,B,N,3] logits after each layer's refinement)."""
+        self._cls_outputs = self._iou_outputs = None
+        fd = self._fused_decoder(query, value, reg_branches)
+        if fd is not None:
+            # bf16 throughput mode: every layer is one fused HIP call each way (plugin/fused_decoder.py; u3d_decoder_layer_fwd/_bwd)
+            from . import fused_decoder as _fdm
+            states, refs, regs, clss, ious = _fdm.run(fd, query, ref_logits, value, group)
+            self._reg_outputs, self._cls_outputs, self._iou_outputs, self._states_c = regs, clss, ious, None
+            if self.return_intermediate:
+                return torch.stack(states), torch.stack(refs)
+            return states[-1], refs[-1]
         out = query
         states, refs = [], []
         self._reg_outputs = [] if reg_branches is not None else None     # reused by Uni3DETRHead.forward (same module, same input)
