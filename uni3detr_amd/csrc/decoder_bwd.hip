@@ -6,6 +6,7 @@
 // Input gradients of every linear are GEMMs against the transposed bf16 weight copies (wt[.] = [K][N]); the dY of every linear is
 // left in the gradient workspace (bf16) for the caller's batched weight-gradient pass, LayerNorm (dgamma, dbeta) as per-workgroup
 // partial sums.
+#define DC_PF 4      /* weight-prefetch burst (k-steps): the backward row kernels carry more live state per lane than the forward ones */
 #include "decoder_common.h"
 
 struct DcSave {            // forward-save slots (read-only here)

@@ -81,38 +81,48 @@ struct DcDrop {
 
 // ---- the block GEMM: acc[mt][nt] (+)= X[32 rows] . W[NT*16 rows]^T over K ---------------------------------------------------
 // A: LDS activation tile (ldk = K); W: global weight rows, already offset to the wave's first output column.
+// The weight fragments of DC_PF k-steps are requested in ONE burst and consumed behind sched_barriers: left alone, hipcc's
+// scheduler sinks each load to just before its MFMA (2-3 loads in flight per wave), and with one wave per SIMD every k-step then
+// waits out a full L2 round trip (measured: 13 us per 256x256 stage, 4x the burst schedule).
+#ifndef DC_PF
+#define DC_PF 8
+#endif
+constexpr int dc_burst(int ks, int want) {          // largest divisor of ks that is <= want
+  int b = 1;
+  for (int d = 1; d <= want && d <= ks; ++d)
+    if (ks % d == 0) b = d;
+  return b;
+}
 template <int K, int NT>
 __device__ __forceinline__ void dc_gemm(const u16* A, const u16* __restrict__ W, f32x4 (&acc)[2][NT], int lane) {
   constexpr int KS = K / 32;
-  constexpr int PF = KS < 4 ? KS : 4;
+  constexpr int PF = dc_burst(KS, DC_PF);
   const int r16 = lane & 15, kq = lane >> 4;
   const u16* wp[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) wp[nt] = W + (size_t)(nt * 16 + r16) * K + kq * 8;
   const u16* ap0 = A + r16 * K;
   const u16* ap1 = A + (16 + r16) * K;
-  bf16x8 wf[PF][NT];
 #pragma unroll
-  for (int p = 0; p < PF; ++p)
+  for (int kb = 0; kb < KS; kb += PF) {
+    bf16x8 wf[PF][NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wf[p][nt] = *(const bf16x8*)(wp[nt] + p * 32);
+    for (int p = 0; p < PF; ++p)
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int ch = ((ks * 4 + kq) ^ r16) << 3;
-    const bf16x8 a0 = *(const bf16x8*)(ap0 + ch);
-    const bf16x8 a1 = *(const bf16x8*)(ap1 + ch);
-    bf16x8 wc[NT];
+      for (int nt = 0; nt < NT; ++nt) wf[p][nt] = *(const bf16x8*)(wp[nt] + (kb + p) * 32);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wc[nt] = wf[ks % PF][nt];
-    if (ks + PF < KS) {
+    for (int p = 0; p < PF; ++p) {
+      const int ch = (((kb + p) * 4 + kq) ^ r16) << 3;
+      const bf16x8 a0 = *(const bf16x8*)(ap0 + ch);
+      const bf16x8 a1 = *(const bf16x8*)(ap1 + ch);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wf[ks % PF][nt] = *(const bf16x8*)(wp[nt] + (ks + PF) * 32);
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[p][nt], a0, acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[p][nt], a1, acc[1][nt], 0, 0, 0);
+      }
     }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[nt], a0, acc[0][nt], 0, 0, 0);
-      acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[nt], a1, acc[1][nt], 0, 0, 0);
-    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

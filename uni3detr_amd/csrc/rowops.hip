@@ -993,20 +993,20 @@ extern "C" int32_t u3d_layernorm_bwd(const void* dy, int32_t y_dtype, const void
 // at 20-50 us; here one thread owns one element of the WIDE dimension and keeps the <= 16 accumulators of the skinny one, a
 // workgroup covers SK_ROWS rows -> partial f32 [chunks][n*k]; the caller column-sums the chunks (u3d_colsum / u3d_colsum_batched).
 // ---------------------------------------------------------------------------------------------
-#define SK_ROWS 128
+#define SK_ROWS 32              /* rows per workgroup: 7200 rows -> 225 workgroups per column block (128 rows left 3/4 of the CUs idle) */
 #define SK_MAX 32
 template <bool DY_SKINNY>
 __global__ __launch_bounds__(256) void k_skinny_wgrad(const u16* __restrict__ dy, const u16* __restrict__ x, int m, int n, int k,
                                                       float* __restrict__ partial) {
-  // DY_SKINNY: n <= 16, thread = column of x (k wide);  else k <= 16, thread = column of dy (n wide)
+  // DY_SKINNY: n <= SK_MAX, thread = column of x (k wide);  else k <= SK_MAX, thread = column of dy (n wide)
   const int wide = DY_SKINNY ? k : n, small = DY_SKINNY ? n : k;
   const int col = blockIdx.y * 256 + threadIdx.x;
   const int r0 = blockIdx.x * SK_ROWS, r1 = min(m, r0 + SK_ROWS);
-  __shared__ float sk[SK_ROWS][SK_MAX];                 // the skinny operand of this row chunk
+  __shared__ float sk[SK_ROWS][SK_MAX];                 // the skinny operand of this row chunk (zero rows past the end)
   const u16* skp = DY_SKINNY ? dy : x;
-  for (int i = threadIdx.x; i < (r1 - r0) * small; i += 256) {
+  for (int i = threadIdx.x; i < SK_ROWS * small; i += 256) {
     const int rr = i / small, s = i % small;
-    sk[rr][s] = ld_elem(skp, (long long)(r0 + rr) * small + s);
+    sk[rr][s] = r0 + rr < r1 ? ld_elem(skp, (long long)(r0 + rr) * small + s) : 0.f;
   }
   __syncthreads();
   float acc[SK_MAX];
@@ -1014,12 +1014,14 @@ __global__ __launch_bounds__(256) void k_skinny_wgrad(const u16* __restrict__ dy
   for (int s = 0; s < SK_MAX; ++s) acc[s] = 0.f;
   if (col < wide) {
     const u16* wp = DY_SKINNY ? x : dy;
-    for (int r = r0; r < r1; ++r) {
-      const float v = ld_elem(wp, (long long)r * wide + col);
+    float v[SK_ROWS];
+#pragma unroll
+    for (int rr = 0; rr < SK_ROWS; ++rr) v[rr] = ld_elem(wp, (long long)min(r0 + rr, r1 - 1) * wide + col);     // all loads in flight at once
+#pragma unroll
+    for (int rr = 0; rr < SK_ROWS; ++rr)
 #pragma unroll
       for (int s = 0; s < SK_MAX; ++s)
-        if (s < small) acc[s] += sk[r - r0][s] * v;
-    }
+        if (s < small) acc[s] += sk[rr][s] * v[rr];
     float* p = partial + (long long)blockIdx.x * n * k;
 #pragma unroll
     for (int s = 0; s < SK_MAX; ++s)

@@ -166,6 +166,13 @@ class FusedDecoder:
         if self.rng is None or self.rng.device != dev:
             self.rng = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFF], dtype=torch.int64, device=dev)
 
+    def xyz_cols(self, dev):
+        """code columns of the (x, y, z) offsets (ref :194-202), cached on the device: no host-to-device copy inside a graph capture"""
+        c = getattr(self, "_cols", None)
+        if c is None or c.device != dev:
+            c = self._cols = torch.tensor([0, 1, 4], device=dev)
+        return c
+
     def refresh(self, dev):
         """bf16 copies of the current master weights (one launch); rebuilt when a parameter moved (e.g. into the trainer's flat buffer)."""
         key = (str(dev),) + tuple(t.data_ptr() for sp in self.specs for t in sp.tensors())
@@ -386,7 +393,7 @@ def run(fd, query, ref_logits, value, group):
         meta = (fd, lid, (B, N, group, D, H, W), accum)
         x, xc, reg, cls, iou = FusedLayerFn.apply(x, xc, ref, rows, meta, *tensor_list(sp))
         if cols is None:
-            cols = torch.tensor([0, 1, 4], device=dev)
+            cols = fd.xyz_cols(dev)
         ref = (ref.detach() + reg.detach().index_select(-1, cols)).detach()
         states.append(x.view(B, N, Cc))
         refs.append(ref.view(B, N, 3))

@@ -283,6 +283,7 @@ class TrainStep:
         if dec is not None:
             dec._reg_outputs = None
             dec._states_c = None
+            dec._cls_outputs = dec._iou_outputs = None
         import gc
         gc.collect()
         torch.cuda.synchronize()
