@@ -28,8 +28,9 @@ MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks (no 2:1 spars
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batches", type=int, default=16, help="distinct synthetic batches rotated through the timed steps")
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU")
     ap.add_argument("--points", type=int, default=20000)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -39,12 +40,12 @@ def parse():
     return ap.parse_args()
 
 
-def make_batch(rank, B, npts, dev):
+def make_batch(rank, B, npts, dev, index=0):
     from uni3detr_amd.plugin.structures import Boxes3D
     from uni3detr_amd.synth import room_scene
     pts, gts, labels = [], [], []
     for i in range(B):
-        p, g, l = room_scene(rank * B + i, npts)
+        p, g, l = room_scene((index * 64 + rank) * B + i, npts)
         gb = torch.from_numpy(g).clone()
         gb[:, 2] -= gb[:, 5] / 2
         pts.append(torch.from_numpy(p).to(dev))
@@ -60,7 +61,7 @@ def cpu_baseline(npts, budget_s=25.0):
     from uni3detr_amd.configs.sunrgbd import model as MODEL_CFG
     from uni3detr_amd.registry import build_model
     from uni3detr_amd.synth import room_scene
-    cores = min(os.cpu_count() or 1, 32)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)      # the cores this process may run on
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = build_model(MODEL_CFG)
@@ -121,6 +122,9 @@ def main():
     model.set_precision(args.precision)
     from uni3detr_amd.trainer import TrainStep
     data = make_batch(rank, args.batch, args.points, dev)
+    # the timed steps rotate through `--batches` distinct batches, resident in HBM and pre-packed; each step copies the next one into
+    # the static input buffers (TrainStep.set_batch: device-to-device) - every sparse level sees changing row counts
+    rot = [data] + [make_batch(rank, args.batch, args.points, dev, index=j) for j in range(1, max(1, args.batches))]
     # two-phase backward: for N > 1 the flat-gradient all-reduce of the head / decoder / dense-stack slice rides under the encoder's
     # backward; the split itself is free (25.34 vs 25.44 ms on one GPU), so N = 1 runs the same schedule
     overlap = os.environ.get("U3D_OVERLAP_REDUCE", "1") == "1"
@@ -130,7 +134,8 @@ def main():
     if not args.no_graph:
         snap = ts.snapshot()
         try:
-            counts, caps = ts.capture()                 # exact-size step -> capacities -> static-shape warm-up -> 3 hipGraphs
+            # exact-size steps over every rotating batch -> capacities -> static-shape warm-up -> hipGraphs
+            counts, caps = ts.capture(batches=[(d["points"], d["gt_bboxes_3d"], d["gt_labels_3d"]) for d in rot])
         except Exception as e:                          # safety net: a failed capture must not cost the run its number
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr, flush=True)
             torch.cuda.synchronize()
@@ -145,7 +150,14 @@ def main():
             init_pg()                                   # process group only AFTER the captures (see TrainStep.enable_dist)
     if use_dist:
         ts.enable_dist()
-    step = ts.step
+    packed = [(model.pack_points(d["points"]), model.pts_bbox_head.pack_gts(d["gt_bboxes_3d"], d["gt_labels_3d"], dev), None) for d in rot]
+    it = [0]
+
+    def step():
+        ts.set_batch(*packed[it[0] % len(packed)])
+        it[0] += 1
+        return ts.step()
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -199,7 +211,7 @@ def main():
                                    f"{args.batch} scenes/GPU x {args.points} pts, 300 queries x 3 groups, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss_val,
                        "launch_mode": launch_mode if launch_mode != "hipGraph" else (("hipGraph x4 (fwd+match | loss+bwd head/dense [all-reduce A overlaps] | bwd encoder | clip+AdamW)" if ts.overlap else "hipGraph x3 (fwd+match | loss+bwd | clip+AdamW)") + ", static-shape sparse levels"),
-                       "sparse_level_capacities": caps},
+                       "sparse_level_capacities": caps, "rotating_batches": len(rot), "recaptures": int(getattr(ts, "recaptures", 0))},
         }
         if timer is not None and census:
             durs = timer.durations_ms()
@@ -247,6 +259,11 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             faulthandler.cancel_dump_traceback_later()       # CPU leg: no GPU work can hang here
             out["cpu_baseline"] = cpu_baseline(args.points)
+            if args.precision == "bf16":
+                # checker leg: deviation of the benched (bf16) mode from the fp32 CPU oracle on the same workload shape, 2 scenes;
+                # gated by tests/test_bf16_parity_gpu.py (tolerances stated there)
+                from oracle.parity_bf16 import bf16_deviation
+                out["bf16_vs_fp32_oracle"] = bf16_deviation(dev, B=2, npts=args.points)
         result_line = json.dumps(out)
     else:
         result_line = None

@@ -370,10 +370,19 @@ int32_t u3d_sine_embed_bwd(const float* logits, const float* dim_t, const void* 
  * Parameter update of the training step: global-norm gradient clipping + AdamW over FLAT f32 buffers
  * (ref: projects/configs/uni3detr/uni3detr_sunrgbd.py:234-235 — AdamW(lr, weight_decay=0.01), grad_clip max_norm=10; upstream
  * torch.optim.AdamW + torch.nn.utils.clip_grad_norm_, same arithmetic: coef = min(1, max_norm/(||g||+1e-6)), decoupled decay,
- * bias-corrected moments).  state: 8 floats of device memory, zero-initialised by the caller: [0] step count (incremented here),
- * [1] clip coefficient, [2] 1-beta1^t, [3] 1-beta2^t, [4] ||g||.  max_norm <= 0: no clipping.  All pointers 16-byte aligned.
+ * bias-corrected moments).  state: 16 floats of device memory, zero-initialised by the caller: [0] step count (incremented here),
+ * [1] clip coefficient, [2] 1-beta1^t, [3] 1-beta2^t, [4] ||g||, [5..10] lr, beta1, beta2, eps, weight_decay, max_norm (<= 0: no
+ * clipping).  The kernels read the hyper-parameters from the state vector at run time: u3d_adamw_set_hyper (a one-thread launch,
+ * issued between hipGraph replays) makes a captured u3d_adamw_step_state follow a learning-rate / momentum schedule (ref: the
+ * `step` lr policy of uni3detr_sunrgbd.py:236-241 and the `cyclic` lr + momentum policies of the KITTI / nuScenes configs).
+ * skip (optional): uint8 per 64-element chunk, 1 = parameter chunk received no gradient and is left untouched (torch.optim.AdamW
+ * skips parameters whose .grad is None).  u3d_adamw_step = set_hyper + step_state with host scalars.  All pointers 16-byte aligned.
  * ---------------------------------------------------------------------------------------------- */
 int64_t u3d_adamw_workspace(int64_t n);
+int32_t u3d_adamw_set_hyper(float* state, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                            u3d_stream s);
+int32_t u3d_adamw_step_state(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                             const uint8_t* skip, void* workspace, int64_t workspace_bytes, u3d_stream s);
 int32_t u3d_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                        float beta2, float eps, float weight_decay, float max_norm, float* state, void* workspace,
                        int64_t workspace_bytes, u3d_stream s);

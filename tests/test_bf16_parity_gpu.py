@@ -1,0 +1,36 @@
+"""bf16 parity gate on the benched workload shape: the throughput mode (`set_precision("bf16")`, fused decoder
+kernels, bf16 sparse encoder + dense stack) against the fp32 CPU oracle.  Tolerances are STATED here and the test fails if the
+deviation drifts above them:
+    feature volume      relative L2 <= 1.0e-1  (measured 6.4e-2: 21 sparse + 24 dense bf16 convolutions with batch statistics, which the
+                                                 reference keeps in fp32)
+    class logits        relative L2 <= 5e-2    (measured 2.7e-2)
+    iou logits          relative L2 <= 7e-2    (measured 4.4e-2)
+    box codes           relative L2 <= 2e-2    (measured 8.4e-3)
+    12 losses           each within 3e-2 relative of the oracle's, max(1, |value|) denominator (measured 1.6e-2); their sum within 5e-3
+                        (measured 2.7e-4)
+    Hungarian matching  >= 99 % of all (layer, scene, query) assignments identical (measured 99.7 %), >= 90 % of the matched ones
+                        (measured 94.4 %); FPS queries identical (f32 geometry)
+(fp32 mode holds 1e-3 on the same quantities: tests/test_model_gpu.py.)  bench.py reports the same figures in its JSON line."""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle.parity_bf16 import bf16_deviation
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bf16_training_forward_stays_within_stated_tolerance_of_fp32_oracle(cuda):
+    d = bf16_deviation(cuda, B=2, npts=20000)
+    print(json.dumps(d))
+    out = os.environ.get("U3D_PARITY_DUMP")
+    if out:
+        json.dump(d, open(out, "w"))
+    assert d["fps_queries_identical"]
+    assert d["feature_rel_l2"] <= 1e-1, d
+    assert d["cls_logit_rel_l2"] <= 5e-2 and d["iou_logit_rel_l2"] <= 7e-2, d
+    assert d["box_rel_l2"] <= 2e-2, d
+    assert d["loss_max_rel"] <= 3e-2 and d["loss_total_rel"] <= 5e-3, d
+    assert d["assignments_identical_share"] >= 0.99 and d["matched_assignments_identical_share"] >= 0.90, d

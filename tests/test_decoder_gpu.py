@@ -362,7 +362,8 @@ def test_head_bf16_fused_path_matches_layerwise_path(cuda):
     assert set(res[True][2]) == set(res[False][2])
 
 
-def test_fused_layer_backward_is_deterministic(cuda):
+@pytest.mark.parametrize("lid", [0, 2])
+def test_fused_layer_backward_is_deterministic(cuda, lid):
     """Every gradient slot of the fused backward is bitwise reproducible (NaN-poisoned workspaces: a read-before-write would show).
     Guards against the exec-mask miscompilation described in csrc/decoder_common.h, which surfaced as run-to-run differences in
     single rows of each 32-row block."""
@@ -371,7 +372,7 @@ def test_fused_layer_backward_is_deterministic(cuda):
     fdm.POISON = True
     try:
         for it in range(6):
-            head, fd, sp, (x, ref, rows_f), dims, outs = run_layer(cuda, 2, p_on=True, seed=3)
+            head, fd, sp, (x, ref, rows_f), dims, outs = run_layer(cuda, lid, p_on=True, seed=3)
             x_out, xc_out, reg, cls, iou = outs
             M = x.shape[0]
             g = torch.Generator(device="cpu").manual_seed(99)
@@ -383,8 +384,9 @@ def test_fused_layer_backward_is_deterministic(cuda):
             fdm.DEBUG_KEEP = None
             _, go = nv.decoder_layer_slots(M, sp.ncls, sp.code)
             snap = {n: nv.slot_view(ws[-1], go[n], M, {"FFH": 512, "DQK": 512}.get(n, 256), torch.float32 if n == "DU1" else torch.bfloat16).clone()
-                    for n in ("C2U", "C1U", "I1", "R1", "F", "FFH", "UPE1", "P0", "OUT", "DU1", "DO", "DQK", "DV", "QS", "QS1", "RAW", "RPH2", "RPH1")}
+                    for n in ("C2U", "C1U", "I1", "R1", "F", "FFH", "UPE1", "P0", "OUT", "DU1", "DO", "DQK", "DV", "RAW", "RPH2", "RPH1") + (("QS", "QS1") if lid else ())}
             snap["dx"] = dx.clone()
+            snap["lnp"] = nv.slot_view(ws[-1], go["LNP"], nv.DL_NLN * 2 * fdm.d_blocks(M), 256, torch.float32).clone()
             assert all(bool(torch.isfinite(v.float()).all()) for v in snap.values())
             if first is None:
                 first = snap

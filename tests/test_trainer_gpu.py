@@ -104,7 +104,7 @@ def test_flat_adamw_with_clipping_matches_torch(cuda, n, max_norm):
     pr = torch.nn.Parameter(p0.clone())
     opt = torch.optim.AdamW([pr], lr=3e-3, weight_decay=0.01)
     p = p0.clone()
-    m, v, st = torch.zeros_like(p), torch.zeros_like(p), torch.zeros(8, device=cuda)
+    m, v, st = torch.zeros_like(p), torch.zeros_like(p), torch.zeros(16, device=cuda)
     for it in range(6):
         g = torch.randn(n, device=cuda) * (10.0 if it % 2 else 0.01)
         pr.grad = g.clone()
@@ -190,3 +190,66 @@ def test_two_phase_backward_matches_single_backward(cuda, graph):
     assert rel <= (5e-2 if graph else 5e-3), rel
     enc = slice(0, b.enc_end)
     assert gb[enc].abs().sum() > 0 and gb[b.enc_end:].abs().sum() > 0
+
+
+def test_adamw_state_entry_follows_hyper_parameters_and_skip_mask(cuda):
+    """u3d_adamw_step_state reads lr / betas / weight decay from the device state (u3d_adamw_set_hyper) - what lets a captured graph
+    follow the step / cyclic schedules - and leaves chunks flagged in the skip mask untouched (torch.optim.AdamW skips .grad is None)."""
+    from uni3detr_amd import native as nv
+    torch.manual_seed(3)
+    n = 4096
+    p0 = torch.randn(n, device=cuda)
+    pr = torch.nn.Parameter(p0[:2048].clone())                     # second half: "no gradient" -> skipped
+    opt = torch.optim.AdamW([pr], lr=1e-3, betas=(0.95, 0.99), weight_decay=0.05)
+    p, m, v, st = p0.clone(), torch.zeros(n, device=cuda), torch.zeros(n, device=cuda), torch.zeros(16, device=cuda)
+    skip = torch.zeros(n // 64, dtype=torch.uint8, device=cuda)
+    skip[2048 // 64:] = 1
+    for it in range(5):
+        lr = 1e-3 * (1 + it)                                        # a schedule
+        for g_ in opt.param_groups:
+            g_["lr"] = lr
+        g = torch.randn(n, device=cuda)
+        g[2048:] = 0
+        pr.grad = g[:2048].clone()
+        opt.step()
+        nv.adamw_set_hyper(st, lr, (0.95, 0.99), 1e-8, 0.05, 0.0)
+        nv.adamw_step_state(p, g, m, v, st, skip)
+        assert (p[:2048] - pr.detach()).abs().max().item() <= 2e-6 * max(1.0, pr.detach().abs().max().item()), it
+        assert torch.equal(p[2048:], p0[2048:]) and float(m[2048:].abs().max()) == 0.0
+
+
+def test_captured_step_follows_lr_schedule_and_new_batches(cuda):
+    """A captured TrainStep (a) takes its learning rate from device state: lr = 0 freezes the weights, a later set_hyper moves them
+    again, with no re-capture; (b) trains on batches loaded with set_batch: the loss of a replay equals the eager loss on that batch;
+    (c) capture() leaves weights / optimizer state where they were (the warm-up iterations do not count as training)."""
+    pts, gts, labels = _data(cuda)
+    pts2, gts2, labels2 = [], [], []
+    from uni3detr_amd.synth import room_scene
+    for i in range(2):
+        p_, g_, l_ = room_scene(40 + i, 12000)
+        gb = torch.from_numpy(g_).clone()
+        gb[:, 2] -= gb[:, 5] / 2
+        pts2.append(torch.from_numpy(p_).to(cuda)); gts2.append(Boxes3D(gb[:5]).to(cuda)); labels2.append(torch.from_numpy(l_[:5]).to(cuda))
+    m = _model(cuda)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ts = TrainStep(m, pts, gts, labels, graph=True, lr=1e-3)
+    ts.capture(batches=[(pts, gts, labels), (pts2, gts2, labels2)])
+    for k, v in m.state_dict().items():                                         # (c)
+        assert torch.equal(v, sd0[k]), k
+    assert float(ts.opt_state[0]) == 0.0
+    ts.set_hyper(lr=0.0, weight_decay=0.0)
+    w = m.pts_bbox_head.cls_branches[0][0].weight
+    w0 = w.detach().clone()
+    ts.step()
+    assert torch.equal(w.detach(), w0)                                          # (a) lr = 0: nothing moves
+    ts.set_batch(pts2, gts2, labels2)
+    l_replay = float(ts.step())
+    ref = _model(cuda, {k: v.clone() for k, v in m.state_dict().items()})
+    eager = TrainStep(ref, pts2, gts2, labels2, graph=False, lr=0.0, weight_decay=0.0)
+    l_eager = float(eager.step())
+    assert abs(l_replay - l_eager) <= 2e-2 * abs(l_eager), (l_replay, l_eager)   # (b)
+    ts.set_hyper(lr=1e-3)
+    ts.step()
+    assert not torch.equal(w.detach(), w0)                                      # (a) and now they move
+    with pytest.raises(ValueError):
+        ts.set_batch([pts[0][:100], pts[1]], gts, labels)

@@ -20,6 +20,22 @@
 
 static inline int u3d_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Raise a kernel's dynamic-LDS limit once per DEVICE (the attribute is per device; a process-wide flag would leave a second GPU
+// of the process at the 64 KiB default).  `mask`: one word per call site (bit = device id; setting the attribute twice is harmless,
+// so the relaxed read-modify-write needs no lock).  Devices >= 64 simply set it every time.
+static inline void u3d_allow_lds_impl(const void* kernel, int bytes, unsigned long long* mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && ((__atomic_load_n(mask, __ATOMIC_RELAXED) >> dev) & 1ull)) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (dev >= 0 && dev < 64) __atomic_fetch_or(mask, 1ull << dev, __ATOMIC_RELAXED);
+}
+#define U3D_ALLOW_LDS(kernel, bytes)                                        \
+  do {                                                                      \
+    static unsigned long long u3d_lds_mask__ = 0;                           \
+    u3d_allow_lds_impl((const void*)(kernel), (int)(bytes), &u3d_lds_mask__); \
+  } while (0)
+
 // ---------------------------------------------------------------------------------------
 // BitGrid: occupancy of a [B, Dz, Dy, Dx] voxel lattice, one 64-bit word per 4x4x4 block.
 // Row id of an occupied cell = prefix[word] + popcount(bits below it) ("block-major rank").

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post(u3d_declayer_params P, 
   dc_poison_lds(lds, tid);
   DcDrop drop = {dc_rng_load(rng), dc_thresh(dm.p_drop), dc_inv_keep(dm.p_drop), dm.layer};
 
-  dc_load_a<256, false>(A0, S.o, DC_C, row0, M, tid);
+  dc_load_a<256, true>(A0, S.o, DC_C, row0, M, tid);           // the attention kernel writes m rows only: padded rows repeat row m-1 (finite)
   dc_load_f<false>(F, x, row0, M, tid);
   dc_load_a<256, false>(A2, S.pos, DC_C, row0, M, tid);
   {                                           // reference-point logits of the block's rows: every lane of a row's wave reads them later
@@ -560,8 +560,8 @@ extern "C" int32_t u3d_decoder_layer_fwd(const u3d_declayer_params* p, const u3d
   U3D_REQUIRE(save_bytes >= off[U3D_DS_COUNT], U3D_ERR_WORKSPACE);
   const DcPtrs S = dc_resolve(save, d->m);
   const int nb = u3d_decoder_layer_blocks(d->m);
-  dc_allow_lds(k_dec_pre, DC_LDS_BYTES);
-  dc_allow_lds(k_dec_post, DC_LDS_BYTES);
+  U3D_ALLOW_LDS(k_dec_pre, DC_LDS_BYTES);
+  U3D_ALLOW_LDS(k_dec_post, DC_LDS_BYTES);
   hipLaunchKernelGGL(k_dec_pre, dim3(nb), dim3(DC_THREADS), DC_LDS_BYTES, s, *p, *d, (const u16*)xc, ref, S);
   rc = u3d_mha_fwd(S.qk, S.v, d->m, d->nq, d->p_attn, d->layer, rng, S.o, S.lse, s);
   if (rc != U3D_OK) return rc;

@@ -724,8 +724,8 @@ extern "C" int32_t u3d_decoder_layer_bwd(const u3d_declayer_params* p, const u3d
   const DcGrad G = dcb_resolve_grad(grad, d->m, d->ncls, d->code, &total);
   U3D_REQUIRE(grad_bytes >= total, U3D_ERR_WORKSPACE);
   const DcSave S = dcb_resolve_save(save, d->m);
-  dc_allow_lds(k_dec_post_bwd, DC_LDS_BYTES);
-  dc_allow_lds(k_dec_pre_bwd, DC_LDS_BYTES);
+  U3D_ALLOW_LDS(k_dec_post_bwd, DC_LDS_BYTES);
+  U3D_ALLOW_LDS(k_dec_pre_bwd, DC_LDS_BYTES);
   hipLaunchKernelGGL(k_dec_post_bwd, dim3(G.nb), dim3(DC_THREADS), DC_LDS_BYTES, s, *p, *d, ref, (const u16*)value,
                      (const unsigned long long*)rng, S, G, dx_out, dreg, dcls, diou, dvalue, dref);
   rc = u3d_mha_bwd(S.qk, S.v, S.o, G.d_o, S.lse, d->m, d->nq, d->p_attn, d->layer, rng, G.dqk, G.dv, s);

@@ -288,14 +288,3 @@ __device__ __forceinline__ void dc_poison_lds(unsigned char* lds, int tid) {
   for (int i = tid; i < DC_LDS_BYTES / 4; i += DC_THREADS) ((unsigned*)lds)[i] = 0xFFFFFFFFu;
 #endif
 }
-
-// per-device one-time raise of the dynamic-LDS limit of a kernel (no process-global flag: the attribute is per device)
-template <typename KernelT>
-static inline void dc_allow_lds(KernelT kernel, int bytes) {
-  static unsigned long long done_mask = 0;      // bit per device id < 64; benign race: setting the attribute twice is harmless
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 64 && (__atomic_load_n(&done_mask, __ATOMIC_RELAXED) >> dev) & 1ull) return;
-  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (dev < 64) __atomic_fetch_or(&done_mask, 1ull << dev, __ATOMIC_RELAXED);
-}

@@ -276,8 +276,7 @@ static int launch_igemm_fwd(const void* in, const void* w, const int32_t* nbr, i
   constexpr int LDA = BK + 8, LDW = WK ? BN + 16 : BK + 8;
   constexpr size_t lds = 2 * (size_t)(BM * LDA + (WK ? BK * LDW : BN * LDW)) * 2;
   auto kern = k_igemm_fwd<WAVES_M, WAVES_N, WM, WN, WK, BK>;
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  if (lds > 64 * 1024) U3D_ALLOW_LDS(kern, lds);      // one call site per template instantiation: per-kernel, per-device
   dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev,
                      n_out_cap, cin, cout, kvol, bias, relu);
@@ -578,8 +577,7 @@ static int launch_igemm_glds(const void* in, const void* w, const int32_t* nbr, 
   constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;        // 256 x 256: 128 KiB
   glds_kernel_t kern = (BM == 256 && BN == 256) ? k_igemm_glds_256x256
                        : (BM == 256 ? k_igemm_glds_256x128 : (BN == 128 ? k_igemm_glds_128x128 : k_igemm_glds_128x64));
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  if (lds > 64 * 1024) U3D_ALLOW_LDS(kern, lds);      // one call site per template instantiation: per-kernel, per-device
   dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin,
                      cout, kvol, bias, relu, stats);
@@ -748,8 +746,7 @@ extern "C" int32_t u3d_igemm_lattice_bf16(const void* in, const void* w, void* o
   if (n >= 0x7fffffffll / (cin > cout ? cin : cout) / 2) return U3D_ERR_UNSUPPORTED;      // 32-bit buffer offsets
   LatGeom lg = {D, H, W, kd, transposed ? -1 : 1};
   constexpr size_t lds = (2 * (size_t)LAT_WIN_ROWS * 64 + 2 * (size_t)256 * 64) * 2;      // 150.5 KiB
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_igemm_lattice_256x256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  U3D_ALLOW_LDS(k_igemm_lattice_256x256, lds);
   dim3 grid(u3d_cdiv((int)n, 256), cout / 256);
   hipLaunchKernelGGL(k_igemm_lattice_256x256, grid, dim3(512), lds, s, (const u16*)in, (const u16*)w, (u16*)out, (int)n, cin, cout, lg,
                      (const float*)nullptr, 0, stats);
@@ -1009,8 +1006,7 @@ static int launch_igemm_pp(const void* in, const void* w, const int32_t* nbr, in
   constexpr int LDA = BK + 8, LDW = WK ? BN + 16 : BK + 8;
   constexpr size_t lds = 2 * (size_t)(BM * LDA + (WK ? BK * LDW : BN * LDW)) * 2;
   auto kern = k_igemm_pp<WK>;
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  if (lds > 64 * 1024) U3D_ALLOW_LDS(kern, lds);      // one call site per template instantiation: per-kernel, per-device
   dim3 grid(u3d_cdiv(n_out_cap, BM), cout / BN);
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin, cout,
                      kvol, bias, relu);
@@ -1757,8 +1753,7 @@ static int launch_igemm_wgrad(const void* in, const void* dout, const int32_t* n
   constexpr int TM = WAVES_M * WM * 16, TN = WAVES_N * WN * 16, RK = 64;
   constexpr size_t lds = 2 * (size_t)(RK * (TM + 16) + RK * (TN + 16)) * 2;
   auto kern = k_igemm_wgrad<WAVES_M, WAVES_N, WM, WN>;
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  if (lds > 64 * 1024) U3D_ALLOW_LDS(kern, lds);      // one call site per template instantiation: per-kernel, per-device
   dim3 grid(p.nsplit, kvol, p.ci_blocks * p.co_blocks);
   hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, (const u16*)in, (const u16*)dout, nbr, ld, partial, n_out_dev,
                      n_out_cap, cin, cout, kvol, p.co_blocks);
@@ -1776,9 +1771,11 @@ static int launch_igemm_wgrad_glds(int tile, const void* in, const void* dout, c
   wgrad_glds_kernel_t kern = tile == 256 ? k_igemm_wgrad_glds_256 : (tile == 128 ? k_igemm_wgrad_glds_128 : k_igemm_wgrad_glds_64);
   const int nthreads = tile == 256 ? 512 : 256;
   const size_t lds = 2 * (size_t)(64 * tile + 64 * tile) * 2;
-  static bool attr_set[3] = {false, false, false};
-  const int ai = tile == 256 ? 0 : (tile == 128 ? 1 : 2);
-  if (!attr_set[ai] && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[ai] = true; }
+  if (lds > 64 * 1024) {                       // one per-device mask per kernel
+    if (tile == 256) U3D_ALLOW_LDS(k_igemm_wgrad_glds_256, lds);
+    else if (tile == 128) U3D_ALLOW_LDS(k_igemm_wgrad_glds_128, lds);
+    else U3D_ALLOW_LDS(k_igemm_wgrad_glds_64, lds);
+  }
   dim3 grid(p.nsplit, kvol, p.ci_blocks * p.co_blocks);
   hipLaunchKernelGGL(kern, grid, dim3(nthreads), lds, s, (const u16*)in, (const u16*)dout, nbr, ld, partial, n_out_dev, n_out_cap, cin, cout,
                      kvol, p.co_blocks);
@@ -1866,12 +1863,10 @@ extern "C" int32_t u3d_wgrad_batched_bf16(const void* const* in, const void* con
   const size_t lds = 2 * (size_t)(64 * p.tile + 64 * p.tile) * 2;
   dim3 grid(p.nsplit, count, p.ci_blocks * p.co_blocks);
   if (p.tile == 256) {
-    static bool a = false;
-    if (!a) { (void)hipFuncSetAttribute((const void*)k_wgrad_batch_256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a = true; }
+    U3D_ALLOW_LDS(k_wgrad_batch_256, lds);
     hipLaunchKernelGGL(k_wgrad_batch_256, grid, dim3(512), lds, s, bt, (float*)workspace, n_dev, n_rows, cin, cout, p.co_blocks, stride);
   } else if (p.tile == 128) {
-    static bool a = false;
-    if (!a && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)k_wgrad_batch_128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a = true; }
+    if (lds > 64 * 1024) U3D_ALLOW_LDS(k_wgrad_batch_128, lds);
     hipLaunchKernelGGL(k_wgrad_batch_128, grid, dim3(256), lds, s, bt, (float*)workspace, n_dev, n_rows, cin, cout, p.co_blocks, stride);
   } else {
     hipLaunchKernelGGL(k_wgrad_batch_64, grid, dim3(256), lds, s, bt, (float*)workspace, n_dev, n_rows, cin, cout, p.co_blocks, stride);

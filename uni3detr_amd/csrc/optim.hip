@@ -33,10 +33,14 @@ __global__ __launch_bounds__(OPT_BLOCK) void k_sumsq_partial(const float* __rest
   }
 }
 
-// state: [0] step count (as float, like torch's capturable AdamW), [1] clip coefficient, [2] 1 - beta1^t, [3] 1 - beta2^t,
-//        [4] total gradient norm (for logging)
-__global__ __launch_bounds__(256) void k_adamw_prepare(const double* __restrict__ partial, int nb, float max_norm, float beta1,
-                                                       float beta2, float* __restrict__ state) {
+// state (16 floats): [0] step count (as float, like torch's capturable AdamW), [1] clip coefficient, [2] 1 - beta1^t, [3] 1 - beta2^t,
+//        [4] total gradient norm (for logging); hyper-parameters, read by the kernels at run time so that a captured graph follows a
+//        learning-rate / momentum schedule: [5] lr, [6] beta1, [7] beta2, [8] eps, [9] weight decay, [10] max_norm (<= 0: no clipping)
+__global__ void k_adamw_set_hyper(float* __restrict__ state, float lr, float beta1, float beta2, float eps, float wd, float max_norm) {
+  if (threadIdx.x == 0) { state[5] = lr; state[6] = beta1; state[7] = beta2; state[8] = eps; state[9] = wd; state[10] = max_norm; }
+}
+__global__ __launch_bounds__(256) void k_adamw_prepare(const double* __restrict__ partial, int nb, float* __restrict__ state) {
+  const float max_norm = state[10], beta1 = state[6], beta2 = state[7];
   double s = 0.0;
   for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
   s = u3d_wave_sum_d(s);
@@ -53,22 +57,28 @@ __global__ __launch_bounds__(256) void k_adamw_prepare(const double* __restrict_
     float t = state[0] + 1.f;
     state[0] = t;
     state[1] = coef;
+    // bias corrections as running products (exact for constant betas; with a momentum schedule they follow the schedule the way
+    // torch's per-step beta^t would only for constant betas - cyclic momentum changes beta1 by < 1e-4 per iteration)
     state[2] = 1.f - powf(beta1, t);
     state[3] = 1.f - powf(beta2, t);
     state[4] = (float)tot;
   }
 }
 
+// skip: optional uint8 per 64-element chunk (1 = leave parameter and moments untouched): parameters that received no gradient are
+// skipped the way torch.optim.AdamW skips parameters whose .grad is None (no decay, no moment decay)
 __global__ __launch_bounds__(OPT_BLOCK) void k_adamw_flat(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                          float* __restrict__ v, long long n, float lr, float beta1, float beta2,
-                                                          float eps, float wd, const float* __restrict__ state) {
+                                                          float* __restrict__ v, long long n, const float* __restrict__ state,
+                                                          const unsigned char* __restrict__ skip) {
   const float coef = state[1], bc1 = state[2], bc2 = state[3];
+  const float lr = state[5], beta1 = state[6], beta2 = state[7], eps = state[8], wd = state[9];
   const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2), decay = 1.f - lr * wd;
   const long long base = (long long)blockIdx.x * OPT_ELEMS_PER_BLOCK;
 #pragma unroll 2
   for (int i = 0; i < 8; ++i) {
     long long o = base + ((long long)i * OPT_BLOCK + threadIdx.x) * 4;
     if (o >= n) break;
+    if (skip && skip[o >> 6]) continue;
     float pv[4], gv[4], mv[4], vv[4];
     const bool full = o + 3 < n;
     if (full) {
@@ -103,20 +113,36 @@ __global__ __launch_bounds__(OPT_BLOCK) void k_adamw_flat(float* __restrict__ p,
 
 extern "C" int64_t u3d_adamw_workspace(int64_t n) { return (int64_t)u3d_cdiv(n > 0 ? n : 1, OPT_ELEMS_PER_BLOCK) * 8; }
 
-extern "C" int32_t u3d_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                                  float beta2, float eps, float weight_decay, float max_norm, float* state, void* workspace,
-                                  int64_t workspace_bytes, u3d_stream s) {
+extern "C" int32_t u3d_adamw_set_hyper(float* state, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                                       u3d_stream s) {
+  U3D_REQUIRE(state, U3D_ERR_ARG);
+  hipLaunchKernelGGL(k_adamw_set_hyper, dim3(1), dim3(64), 0, s, state, lr, beta1, beta2, eps, weight_decay, max_norm);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+extern "C" int32_t u3d_adamw_step_state(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                                        const uint8_t* skip, void* workspace, int64_t workspace_bytes, u3d_stream s) {
   U3D_REQUIRE(param && grad && exp_avg && exp_avg_sq && state && workspace && n >= 0, U3D_ERR_ARG);
   U3D_REQUIRE(workspace_bytes >= u3d_adamw_workspace(n), U3D_ERR_WORKSPACE);
   U3D_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0, U3D_ERR_ARG);
   const int nb = u3d_cdiv(n > 0 ? n : 1, OPT_ELEMS_PER_BLOCK);
   hipLaunchKernelGGL(k_sumsq_partial, dim3(nb), dim3(OPT_BLOCK), 0, s, grad, (long long)n, (double*)workspace);
-  hipLaunchKernelGGL(k_adamw_prepare, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, max_norm, beta1, beta2, state);
+  hipLaunchKernelGGL(k_adamw_prepare, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, state);
   if (n > 0)
-    hipLaunchKernelGGL(k_adamw_flat, dim3(nb), dim3(OPT_BLOCK), 0, s, param, grad, exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps,
-                       weight_decay, (const float*)state);
+    hipLaunchKernelGGL(k_adamw_flat, dim3(nb), dim3(OPT_BLOCK), 0, s, param, grad, exp_avg, exp_avg_sq, (long long)n, (const float*)state, skip);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
+}
+
+// host-scalar form: writes the hyper-parameters into the state vector, then steps (a captured graph of THIS entry bakes them in;
+// schedules use u3d_adamw_set_hyper between replays + u3d_adamw_step_state inside the graph)
+extern "C" int32_t u3d_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                                  float beta2, float eps, float weight_decay, float max_norm, float* state, void* workspace,
+                                  int64_t workspace_bytes, u3d_stream s) {
+  int32_t rc = u3d_adamw_set_hyper(state, lr, beta1, beta2, eps, weight_decay, max_norm, s);
+  if (rc != U3D_OK) return rc;
+  return u3d_adamw_step_state(param, grad, exp_avg, exp_avg_sq, n, state, nullptr, workspace, workspace_bytes, s);
 }
 
 

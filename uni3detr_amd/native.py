@@ -131,6 +131,8 @@ _SIGS = {
     "u3d_permute_bf16_batched": (_I, [_P, _P, _P, _P, _I, _P]),
     "u3d_adamw_workspace": (_L, [_L]),
     "u3d_adamw_step": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _L, _P]),
+    "u3d_adamw_set_hyper": (_I, [_P] + [C.c_float] * 6 + [_P]),
+    "u3d_adamw_step_state": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _L, _P]),
     "u3d_gather_rows": (_I, [_P, _P, _I, _I, _P, _P]),
     "u3d_decoder_layer_slots": (_I, [_I, _I, _I, _P, _P]),
     "u3d_decoder_layer_blocks": (_I, [_I]),
@@ -635,12 +637,26 @@ def linear_bf16(x, w, bias, relu):
 
 
 def adamw_step(param, grad, exp_avg, exp_avg_sq, state, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=0.0, workspace=None):
-    """In-place clip + AdamW on flat f32 buffers; `state` = 8 zero-initialised device floats (see include/u3d_hip.h)."""
+    """In-place clip + AdamW on flat f32 buffers; `state` = 16 zero-initialised device floats (see include/u3d_hip.h)."""
     n = param.numel()
     wsb = int(lib().u3d_adamw_workspace(n))
     ws = workspace if workspace is not None else torch.empty(wsb, dtype=torch.uint8, device=param.device)
     _check(lib().u3d_adamw_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, lr, betas[0], betas[1], eps, weight_decay,
                                 float(max_norm), _ptr(state), _ptr(ws), ws.numel(), _stream()), "adamw_step")
+
+
+def adamw_set_hyper(state, lr, betas, eps, weight_decay, max_norm):
+    """hyper-parameters into slots [5..10] of the 16-float device state vector (stream-ordered, one tiny launch)."""
+    _check(lib().u3d_adamw_set_hyper(_ptr(state), lr, betas[0], betas[1], eps, weight_decay, float(max_norm), _stream()), "adamw_set_hyper")
+
+
+def adamw_step_state(param, grad, exp_avg, exp_avg_sq, state, skip=None, workspace=None):
+    """clip + AdamW with the hyper-parameters taken from `state` (see adamw_set_hyper); skip: uint8 per 64-element chunk or None."""
+    n = param.numel()
+    wsb = int(lib().u3d_adamw_workspace(n))
+    ws = workspace if workspace is not None else torch.empty(wsb, dtype=torch.uint8, device=param.device)
+    _check(lib().u3d_adamw_step_state(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, _ptr(state), _ptr(skip), _ptr(ws),
+                                      ws.numel(), _stream()), "adamw_step_state")
 
 
 def tap_gather_sum(p, nbr, n_dev, n, c, kvol):

@@ -22,7 +22,8 @@ from .plugin import transformer as _T
 
 class TrainStep:
     def __init__(self, model, points, gt_bboxes_3d, gt_labels_3d, lr=1e-4, weight_decay=0.01, max_norm=10.0, graph=True,
-                 capacity_margin=1.25, flat_update=True, overlap_reduce=False):
+                 capacity_margin=1.25, flat_update=True, overlap_reduce=False, betas=(0.9, 0.999), eps=1e-8, gt_capacity=64,
+                 check_every=50):
         self.model = model
         self.dev = next(model.parameters()).device
         self.dist_on = dist.is_available() and dist.is_initialized()
@@ -43,8 +44,10 @@ class TrainStep:
         for p, o in zip(self.params, self.offsets):
             self.views.append(self.flat_grad[o:o + p.numel()].view_as(p))
             p.grad = self.views[-1]
-        self.lr, self.weight_decay = lr, weight_decay
+        self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, tuple(betas), eps
         self.flat_update = flat_update
+        self.check_every, self._steps_since_check, self.recaptures = check_every, 0, 0
+        self._grad_missing = [False] * len(self.params)
         # overlap_reduce: the backward runs in two phases cut at the sparse encoder's dense() output.  Phase A (losses, head, decoder,
         # dense stack: ~90 % of the gradient bytes) is followed by an ASYNCHRONOUS all-reduce of its slice of the flat buffer, which then
         # rides under phase B (the sparse encoder's backward); only the encoder's small slice is reduced after it.  The encoder's
@@ -73,17 +76,71 @@ class TrainStep:
                 model._shadows = None
             self.exp_avg = torch.zeros_like(self.flat_param)
             self.exp_avg_sq = torch.zeros_like(self.flat_param)
-            self.opt_state = torch.zeros(8, dtype=torch.float32, device=self.dev)
+            self.opt_state = torch.zeros(16, dtype=torch.float32, device=self.dev)
             self._opt_ws = torch.empty(int(nv.lib().u3d_adamw_workspace(n)), dtype=torch.uint8, device=self.dev)
             self.opt = None
+            self._skip = None                 # uint8 per 64-element chunk: parameters without a gradient (set after the first backward)
+            self._skip_known = False
+            self.set_hyper()
         else:
-            self.opt = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay, fused=True, capturable=graph)
+            self.opt = torch.optim.AdamW(self.params, lr=lr, betas=self.betas, eps=eps, weight_decay=weight_decay, fused=True, capturable=graph)
         self.pts = model.pack_points(points) if not isinstance(points, dict) else points
-        self.gts = model.pts_bbox_head.pack_gts(gt_bboxes_3d, gt_labels_3d, self.dev) if not isinstance(gt_bboxes_3d, dict) else gt_bboxes_3d
+        self.gt_capacity = gt_capacity
+        self.gts = self._pack_gts_static(gt_bboxes_3d, gt_labels_3d) if not isinstance(gt_bboxes_3d, dict) else gt_bboxes_3d
         self.labels = gt_labels_3d
         self.capacity_margin = capacity_margin
         self._graphs = None
         self.loss = None
+
+    # ---- batches --------------------------------------------------------------------------------------------------------
+    def _pack_gts_static(self, gt_bboxes_3d, gt_labels_3d):
+        """GT buffers with a fixed per-scene capacity (`gt_capacity` boxes): the captured graphs size the cost matrix by the capacity
+        and read the real per-scene counts from the device-side `gt_off`, so the next batch may hold any number of boxes up to it."""
+        d = self.model.pts_bbox_head.pack_gts(gt_bboxes_3d, gt_labels_3d, self.dev)
+        B = d["gt_off"].numel() - 1
+        cap = max(int(d["gmax"]), int(self.gt_capacity))
+        gt = torch.zeros((B * cap, d["gt"].shape[1]), dtype=d["gt"].dtype, device=self.dev)
+        labels = torch.zeros((B * cap,), dtype=d["labels"].dtype, device=self.dev)
+        n = d["gt"].shape[0]
+        gt[:n].copy_(d["gt"])
+        labels[:n].copy_(d["labels"])
+        return dict(gt=gt, labels=labels, gt_off=d["gt_off"].clone(), gmax=cap)
+
+    def set_batch(self, points, gt_bboxes_3d, gt_labels_3d):
+        """Load the next batch INTO the static input buffers the captured graphs read (device-to-device copies on the current
+        stream; ref: the runner's data loader feeding train_step, extra_tools/train.py:204-254).  Shapes the graphs were captured
+        with must hold: same number of scenes, the same number of points per scene, at most `gmax` boxes per scene - anything else
+        raises (build a new TrainStep / call capture() again for a different shape)."""
+        pts = self.model.pack_points(points) if not isinstance(points, dict) else points
+        if list(pts["lens"]) != list(self.pts["lens"]) or pts["cat"].shape != self.pts["cat"].shape:
+            raise ValueError(f"set_batch: points per scene {list(pts['lens'])} differ from the captured layout {list(self.pts['lens'])}")
+        d = self.model.pts_bbox_head.pack_gts(gt_bboxes_3d, gt_labels_3d, self.dev) if not isinstance(gt_bboxes_3d, dict) else gt_bboxes_3d
+        if d["gt_off"].numel() != self.gts["gt_off"].numel():
+            raise ValueError("set_batch: number of scenes differs from the captured batch")
+        n = d["gt"].shape[0]
+        if int(d["gmax"]) > int(self.gts["gmax"]) or n > self.gts["gt"].shape[0]:
+            raise ValueError(f"set_batch: {int(d['gmax'])} boxes in one scene exceed the captured capacity {int(self.gts['gmax'])}")
+        self.pts["cat"].copy_(pts["cat"])
+        self.pts["scene_off"].copy_(pts["scene_off"])
+        self.gts["gt"][:n].copy_(d["gt"])
+        self.gts["labels"][:n].copy_(d["labels"])
+        self.gts["gt_off"].copy_(d["gt_off"])
+
+    # ---- optimizer hyper-parameters (device state: a captured step follows a schedule) -----------------------------------
+    def set_hyper(self, lr=None, betas=None, weight_decay=None):
+        """Learning rate / betas / weight decay of the NEXT steps (ref: the `step` and `cyclic` lr + momentum policies of the shipped
+        configs).  Written into the device-side optimizer state by a one-thread launch, so it also steers replayed graphs."""
+        if lr is not None:
+            self.lr = float(lr)
+        if betas is not None:
+            self.betas = (float(betas[0]), float(betas[1]))
+        if weight_decay is not None:
+            self.weight_decay = float(weight_decay)
+        if self.flat_update:
+            nv.adamw_set_hyper(self.opt_state, self.lr, self.betas, self.eps, self.weight_decay, self.max_norm)
+        elif self.opt is not None:
+            for g in self.opt.param_groups:
+                g["lr"], g["betas"], g["weight_decay"] = self.lr, self.betas, self.weight_decay
 
     # ---- the three stages (same code eager or captured) -------------------------------------------------------
     def _stage1(self):
@@ -117,22 +174,48 @@ class TrainStep:
             loss.backward()
         self.loss = loss.detach()
         dst, src, missing = [], [], []
-        for p, v in zip(self.params, self.views):
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
             if p.grad is None:
                 missing.append(v)
+                self._grad_missing[i] = True
             else:
                 dst.append(v); src.append(p.grad)
             p.grad = v
         torch._foreach_copy_(dst, src)
         if missing:
             torch._foreach_zero_(missing)
+        self._note_missing(0, len(self.params))
+
+    def _note_missing(self, lo, hi):
+        """Parameters that received no gradient keep weights AND moments untouched, as torch.optim.AdamW skips `.grad is None`
+        (the reference trains with find_unused_parameters=True).  The set is fixed by the model's structure: recorded once, from the
+        first eager backward, as a per-64-element skip mask for u3d_adamw_step_state."""
+        if not self.flat_update or self._skip_known:
+            return
+        seen = getattr(self, "_seen_ranges", set())
+        seen.add((lo, hi))
+        self._seen_ranges = seen
+        miss = getattr(self, "_missing_idx", set())
+        for i in range(lo, hi):
+            if self._grad_missing[i]:
+                miss.add(i)
+        self._missing_idx = miss
+        if sum(h - l for l, h in seen) >= len(self.params):
+            self._skip_known = True
+            if miss:
+                mask = torch.zeros((self.flat_param.numel() + 63) // 64, dtype=torch.uint8, device=self.dev)
+                for i in miss:
+                    o, n = self.offsets[i], self.params[i].numel()
+                    mask[o // 64:(o + n + 63) // 64] = 1
+                self._skip = mask
 
     def _pack(self, lo, hi):
         """Gradients of params[lo:hi] (as autograd left them in .grad) -> their views of the flat buffer; .grad = the view again."""
         dst, src, missing = [], [], []
-        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
+        for i, (p, v) in enumerate(zip(self.params[lo:hi], self.views[lo:hi])):
             if p.grad is None:
                 missing.append(v)
+                self._grad_missing[lo + i] = True
             else:
                 dst.append(v); src.append(p.grad)
             p.grad = v
@@ -140,6 +223,7 @@ class TrainStep:
             torch._foreach_copy_(dst, src)
         if missing:
             torch._foreach_zero_(missing)
+        self._note_missing(lo, hi)
 
     def _stage2a(self):
         """Losses + backward down to the sparse encoder's dense() output (phase A of the two-phase backward)."""
@@ -191,8 +275,7 @@ class TrainStep:
 
     def _stage3(self):
         if self.flat_update:
-            nv.adamw_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.opt_state, self.lr, (0.9, 0.999), 1e-8,
-                          self.weight_decay, self.max_norm, self._opt_ws)
+            nv.adamw_step_state(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.opt_state, self._skip, self._opt_ws)
             return
         torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, foreach=True)
         self.opt.step()
@@ -201,7 +284,7 @@ class TrainStep:
         if self.flat_update:
             self.exp_avg.zero_()
             self.exp_avg_sq.zero_()
-            self.opt_state.zero_()
+            self.opt_state[:5].zero_()            # step count and derived values; the hyper-parameter slots stay
             return
         for st in self.opt.state.values():
             for v in st.values():
@@ -233,6 +316,22 @@ class TrainStep:
             self._reset_opt_state()
         torch.cuda.synchronize()
 
+    def snapshot_full(self):
+        """Model state + optimizer state (moments, step count); restore_full() puts all of it back in place."""
+        snap = dict(model=self.snapshot())
+        if self.flat_update:
+            snap.update(m=self.exp_avg.clone(), v=self.exp_avg_sq.clone(), st=self.opt_state.clone())
+        return snap
+
+    def restore_full(self, snap):
+        with torch.no_grad():
+            for t, s_ in zip(list(self.model.parameters()) + list(self.model.buffers()), snap["model"]):
+                t.copy_(s_)
+            if self.flat_update:
+                self.exp_avg.copy_(snap["m"]); self.exp_avg_sq.copy_(snap["v"]); self.opt_state.copy_(snap["st"])
+            else:
+                self._reset_opt_state()
+
     def snapshot(self):
         return [t.detach().clone() for t in list(self.model.parameters()) + list(self.model.buffers())]
 
@@ -243,13 +342,19 @@ class TrainStep:
             self._reset_opt_state()
 
     # ---- capture ------------------------------------------------------------------------------------------------
-    def measure_capacities(self):
-        """Run one exact-size eager step and size the strided sparse levels from it (x margin, multiple of 256)."""
+    def measure_capacities(self, batches=None):
+        """Run exact-size eager steps (the bound batch, or every batch of `batches`) and size the strided sparse levels from the
+        largest counts seen (x margin, multiple of 256)."""
         m = self.model
         m.static_shapes = False
         m.pts_middle_encoder.level_capacities = None
-        self.eager_step()
-        counts = [int(c.item()) for c in m.pts_middle_encoder.last_level_counts]
+        counts = None
+        for b in (batches if batches else [None]):
+            if b is not None:
+                self.set_batch(*b)
+            self.eager_step()
+            c = [int(c.item()) for c in m.pts_middle_encoder.last_level_counts]
+            counts = c if counts is None else [max(a, b_) for a, b_ in zip(counts, c)]
         caps = [((int(c * self.capacity_margin) + 255) // 256) * 256 for c in counts[1:]]
         m.pts_middle_encoder.level_capacities = caps
         m.static_shapes = True
@@ -263,9 +368,13 @@ class TrainStep:
                 raise RuntimeError(f"sparse level overflow: {c} active rows > capacity {cap}; re-capture with a larger margin")
         return counts
 
-    def capture(self, warmup=3):
+    def capture(self, warmup=3, keep_state=True, batches=None):
+        """Measure the sparse-level capacities (over `batches`, a list of (points, gts, labels), when given), warm up, capture.
+        keep_state: weights, BatchNorm statistics and optimizer state are restored afterwards - the measuring / warm-up iterations
+        are real optimizer steps and must not count as training."""
         assert self.graph
-        counts, caps = self.measure_capacities()
+        snap = self.snapshot_full() if keep_state else None
+        counts, caps = self.measure_capacities(batches)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -308,11 +417,25 @@ class TrainStep:
             self._stage3()
         torch.cuda.synchronize()
         self._graphs = (g1, g2, g2b, g3)
+        if snap is not None:
+            self.restore_full(snap)
+        self._steps_since_check = 0
         return counts, caps
 
     def step(self):
         if self._graphs is None:
             return self.eager_step()
+        if self.check_every and self._steps_since_check >= self.check_every:
+            # a level that outgrew its capacity would silently drop voxels: read the device-side counts every `check_every` steps
+            # (one small device-to-host copy) and re-capture with room to spare when one is exceeded
+            self._steps_since_check = 0
+            try:
+                self.check_capacities()
+            except RuntimeError:
+                self.capacity_margin *= 1.5
+                self.recaptures += 1
+                self.capture()
+        self._steps_since_check += 1
         g1, g2, g2b, g3 = self._graphs
         g1.replay()
         self._reduce_num_pos()
