@@ -61,7 +61,11 @@ def cpu_baseline(npts, budget_s=25.0):
     from uni3detr_amd.configs.sunrgbd import model as MODEL_CFG
     from uni3detr_amd.registry import build_model
     from uni3detr_amd.synth import room_scene
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)      # the cores this process may run on
+    host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # cores this process may run on
+    # threads actually used: this fp32 workload (many small sparse gathers + 256-channel 3-D convolutions on ONE scene) stops scaling
+    # near 32 threads, and with one thread per core of a 256-core host it ran 350x SLOWER (1790 s vs 5 s per scene: oversubscribed
+    # intra-op pools) - `cores` reports the threads used, `host_cores` what the box offers
+    cores = min(host_cores, 32)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = build_model(MODEL_CFG)
@@ -84,7 +88,7 @@ def cpu_baseline(npts, budget_s=25.0):
             break
     use = times[1:] if len(times) > 1 else times          # first iteration = warm-up when there was time for more
     t = float(np.median(use))
-    return dict(value=1.0 / t, unit="scenes/s", cores=cores, kind="port",
+    return dict(value=1.0 / t, unit="scenes/s", cores=cores, host_cores=host_cores, kind="port",
                 sample=f"oracle/model.py fwd+bwd, fp32, 1 scene x {npts} pts, {len(use)} timed iteration(s) of {len(times)} ({t:.2f} s/scene)")
 
 
