@@ -404,6 +404,21 @@ int32_t u3d_permute_bf16_batched(const void* src, void* dst, const u3d_permute_d
                                  int32_t nblocks, u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------
+ * Test-time post-processing.
+ * u3d_soft_nms: class-wise Gaussian soft-NMS with the rotated 3-D IoU (ref: models/dense_heads/uni3detr_head.py:796-823, per-class loop
+ *   :849-880).  boxes f32 [n,7] bottom-centre LiDAR boxes, scores f32 [n], labels int32 [n].  One workgroup per class; outputs
+ *   out_idx int32 / out_score f32 [num_classes][n] = indices into the input and decayed scores in selection order, out_cnt [num_classes].
+ * u3d_box_merge: the KITTI configs' `box_merging` (ref: core/bbox/bbox_merging.py:112-158 as called from uni3detr_head.py:881-891).
+ *   boxes f32 [n,7] / labels sorted by DESCENDING score (the caller sorts); keep[i] = survives the greedy sweep, merged [n,7] = for
+ *   kept boxes the per-coordinate median over itself and the same-class boxes it absorbed (overlap > thr), else a copy.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t u3d_soft_nms(const float* boxes, const float* scores, const int32_t* labels, int32_t n, int32_t num_classes, float sigma,
+                     float prune, int32_t* out_idx, float* out_score, int32_t* out_cnt, u3d_stream s);
+int64_t u3d_box_merge_workspace(int32_t n);
+int32_t u3d_box_merge(const float* boxes, const int32_t* labels, int32_t n, float thr, float* merged, uint8_t* keep, void* workspace,
+                      int64_t workspace_bytes, u3d_stream s);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused decoder layer (bf16 MFMA, f32 accumulation / residual stream / LayerNorm statistics / softmax statistics).
  * One call = one Uni3DETRTransformerDecoder layer over ALL query groups of all scenes, plus everything the decoder loop and the head
  * hang on that layer's state (ref: models/utils/uni3detr_transformer.py:145-212 decoder loop, :33-65 sine embedding, :271-360

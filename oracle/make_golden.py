@@ -123,6 +123,33 @@ def gen_small(ns):
     print("small_ops ok")
 
 
+def gen_decode(ns):
+    """NMSFreeCoder.decode of the reference file (core/bbox/coders/nms_free_coder.py:42-136) on seeded head outputs: three coder
+    settings (alpha, score threshold, a tight centre range) so that the top-k, the score / IoU blend and both masks are pinned."""
+    rng = np.random.default_rng(SEED + 1)
+    L, B, Q, C = 3, 2, 1200, 10
+    cls = torch.from_numpy(rng.normal(-2.0, 2.0, (L, B, Q, C)).astype(np.float32))
+    box = torch.from_numpy(np.concatenate([rng.uniform(-3.4, 3.4, (L, B, Q, 1)), rng.uniform(-0.4, 6.4, (L, B, Q, 1)),
+                                           rng.normal(0, 0.5, (L, B, Q, 2)), rng.uniform(-2.1, 0.7, (L, B, Q, 1)),
+                                           rng.normal(0, 0.5, (L, B, Q, 1)), rng.normal(0, 1, (L, B, Q, 2))], -1).astype(np.float32))
+    iou = torch.from_numpy(rng.normal(0, 1.5, (L, B, Q, 1)).astype(np.float32))
+    pc = [-3.2, -0.2, -2.0, 3.2, 6.2, 0.56]
+    out = dict(cls=cls.numpy(), box=box.numpy(), iou=iou.numpy(), pc_range=np.array(pc, np.float32))
+    settings = [dict(alpha=1.0, score_threshold=None, max_num=1000, post_center_range=pc),
+                dict(alpha=0.5, score_threshold=0.3, max_num=300, post_center_range=pc),
+                dict(alpha=0.25, score_threshold=None, max_num=500, post_center_range=[-2.0, 0.5, -1.5, 2.0, 5.0, 0.3])]
+    for si, st in enumerate(settings):
+        coder = ns.coder.NMSFreeCoder(pc_range=pc, voxel_size=[0.02, 0.02, 0.02], num_classes=C, **st)
+        res = coder.decode(dict(all_cls_scores=cls, all_bbox_preds=box, all_iou_preds=iou))
+        out[f"s{si}_cfg"] = np.array([st["alpha"], -1.0 if st["score_threshold"] is None else st["score_threshold"], st["max_num"]] +
+                                     list(st["post_center_range"]), np.float64)
+        for b, r in enumerate(res):
+            for k in ("bboxes", "scores", "labels", "ious"):
+                out[f"s{si}_b{b}_{k}"] = r[k].numpy()
+    np.savez_compressed(os.path.join(OUT, "coder_decode.npz"), **out)
+    print("coder_decode:", [int(out[f"s{si}_b0_scores"].shape[0]) for si in range(len(settings))])
+
+
 def main():
     if not rs.available():
         sys.exit("reference tree not available: goldens can only be generated in the build container")
@@ -131,6 +158,7 @@ def main():
     gen_small(ns)
     gen_head_train(ns)
     gen_head_eval(ns)
+    gen_decode(ns)
 
 
 if __name__ == "__main__":

@@ -165,3 +165,62 @@ def test_fps_tie_rule_and_coverage():
     q = np.random.default_rng(0).random((500, 3)).astype(np.float32)
     idx = om.fps_packed(q.reshape(-1), 500, 50)
     assert len(set(idx.tolist())) == 50
+
+
+def test_merge_oracle_overlap_closed_forms():
+    """oracle/postproc.py (restatement of core/bbox/bbox_merging.py; the file itself needs cv2 / shapely / numba and cannot be imported):
+    the overlap of axis-aligned boxes has a closed form, a 90-degree yaw swaps the footprint extents, and the polygon clip is checked
+    against a Monte-Carlo area on rotated pairs."""
+    import numpy as np
+    from oracle import postproc as pp
+    # boxes are (x, y, z, l, h, w, yaw): footprint in (x, z) with extents (l, w), "height" interval [y - h, y]
+    a = np.array([[0.0, 0.0, 0.0, 2.0, 1.0, 4.0, 0.0]])
+    b = np.array([[1.0, -0.5, 1.0, 2.0, 1.0, 4.0, 0.0]])
+    ca, cb = pp._corners(a), pp._corners(b)
+    shared = (2.0 - 1.0) * (4.0 - 1.0)            # x overlap 1, z overlap 3
+    inter = 0.5 * shared                           # shared height 0.5
+    union = 1.0 * 8.0 + 1.0 * 8.0
+    assert abs(pp._overlap(ca[0], cb)[0] - inter / (union - inter)) < 1e-6
+    # yaw = pi/2: the footprint of b becomes 4 (x) by 2 (z)
+    b2 = b.copy(); b2[0, 6] = np.pi / 2
+    cb2 = pp._corners(b2)
+    sx = min(1.0, 1.0 + 2.0) - max(-1.0, 1.0 - 2.0)      # a: x in [-1,1]; b2: x in [-1,3]
+    sz = min(2.0, 1.0 + 1.0) - max(-2.0, 1.0 - 1.0)      # a: z in [-2,2]; b2: z in [0,2]
+    inter = 0.5 * sx * sz
+    assert abs(pp._overlap(ca[0], cb2)[0] - inter / (16.0 - inter)) < 1e-6
+    # disjoint in height -> 0
+    b3 = b.copy(); b3[0, 1] = 5.0
+    assert pp._overlap(ca[0], pp._corners(b3))[0] == 0.0
+    # rotated pair: polygon clip vs Monte-Carlo
+    rng = np.random.default_rng(3)
+    p = np.array([[0.2, 0, -0.1, 3.0, 1, 1.5, 0.7]]); q = np.array([[0.9, 0, 0.4, 2.0, 1, 2.5, -0.4]])
+    P, Q = pp._corners(p)[0][:4][:, [0, 2]], pp._corners(q)[0][:4][:, [0, 2]]
+    pts = rng.uniform(-4, 4, (400000, 2))
+    def inside(poly, x):
+        s = None
+        for i in range(4):
+            e, v = poly[(i + 1) % 4] - poly[i], x - poly[i]
+            c = e[0] * v[:, 1] - e[1] * v[:, 0]
+            s = (c >= 0) if s is None else (s & (c >= 0))
+        return s
+    def ccw(poly):
+        return poly if _area2(poly) > 0 else poly[::-1]
+    def _area2(poly):
+        x, y = poly[:, 0], poly[:, 1]
+        return np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))
+    mc = (inside(ccw(P), pts) & inside(ccw(Q), pts)).mean() * 64.0
+    assert abs(pp._convex_intersection_area(P, Q) - mc) < 0.03
+
+
+def test_merge_oracle_median_and_sweep_order():
+    """three overlapping same-class boxes + one of another class + a far one: the best-scored box absorbs the two overlapping ones and
+    becomes their per-coordinate median; the other class and the far box survive untouched."""
+    import numpy as np
+    from oracle import postproc as pp
+    boxes = np.array([[0.0, 0, 0, 2, 1, 4, 0.00], [0.1, 0, 0.1, 2.2, 1, 4.2, 0.02], [-0.1, 0, 0.2, 1.8, 1, 3.8, -0.02],
+                      [0.0, 0, 0, 2, 1, 4, 0.0], [30.0, 0, 0, 2, 1, 4, 0.0]], np.float32)
+    labels = np.array([1, 1, 1, 2, 1])
+    scores = np.array([0.9, 0.8, 0.7, 0.6, 0.5], np.float32)
+    lab, bx, sc, idx, order = pp.merge_boxes(labels, boxes, scores, 0.1)
+    assert idx.tolist() == [0, 3, 4] and lab.tolist() == [1, 2, 1]
+    assert np.allclose(bx[0], np.median(boxes[:3], axis=0)) and np.allclose(bx[1], boxes[3]) and np.allclose(bx[2], boxes[4])

@@ -1,0 +1,116 @@
+"""Device post-processing (u3d_soft_nms, u3d_box_merge) against the CPU restatements of the reference routines (oracle/postproc.py:
+uni3detr_head.py:796-823 soft_nms + its per-class loop; core/bbox/bbox_merging.py:112-158), and the shipped KITTI configs'
+`box_merging` / the `soft_nms` option running end to end through Uni3DETRHead.get_bboxes."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import projects.mmdet3d_plugin  # noqa: F401
+from oracle import postproc as opp
+from uni3detr_amd import native as nv
+
+pytestmark = pytest.mark.gpu
+
+
+def _boxes(rng, n, clusters, spread=0.25):
+    cen = rng.uniform([-3, 0, -1.5], [3, 6, 0], (clusters, 3))
+    c = cen[rng.integers(0, clusters, n)] + rng.normal(0, spread, (n, 3))
+    dims = rng.uniform(0.4, 1.6, (n, 3))
+    yaw = rng.uniform(-3.1, 3.1, (n, 1))
+    return np.concatenate([c, dims, yaw], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,ncls", [(300, 10), (1, 3), (64, 1)])
+def test_soft_nms_matches_reference_loop(cuda, n, ncls):
+    rng = np.random.default_rng(n)
+    boxes = torch.from_numpy(_boxes(rng, n, 12))
+    scores = torch.from_numpy(rng.uniform(0.01, 1.0, n).astype(np.float32))
+    labels = torch.from_numpy(rng.integers(0, ncls, n))
+    ri, rs, rl = opp.soft_nms_classwise(boxes, scores, labels, ncls, 0.3, 1e-3)
+    gi, gs, gl = nv.soft_nms_classwise(boxes.to(cuda), scores.to(cuda), labels.to(cuda), ncls, 0.3, 1e-3)
+    assert gi.cpu().tolist() == ri.tolist() and gl.cpu().tolist() == rl.tolist()
+    assert (gs.cpu() - rs).abs().max().item() <= 1e-5
+
+
+def test_soft_nms_empty_input(cuda):
+    gi, gs, gl = nv.soft_nms_classwise(torch.zeros((0, 7), device=cuda), torch.zeros(0, device=cuda), torch.zeros(0, dtype=torch.long, device=cuda), 4, 0.3, 1e-3)
+    assert gi.numel() == 0 and gs.numel() == 0 and gl.numel() == 0
+
+
+@pytest.mark.parametrize("n,ncls,seed", [(400, 3, 0), (1000, 1, 1), (2, 2, 2), (129, 3, 3)])
+def test_box_merge_matches_reference_restatement(cuda, n, ncls, seed):
+    rng = np.random.default_rng(seed)
+    boxes = _boxes(rng, n, 25, 0.15)
+    boxes[:, 4] = rng.uniform(0.5, 1.5, n)                      # dy plays the "height" role in the reference's (mis)reading of the box
+    scores = rng.permutation(n).astype(np.float32) / n          # distinct scores: the order is unambiguous
+    labels = rng.integers(0, ncls, n)
+    lab, bx, sc, idx, order = opp.merge_boxes(labels, boxes.copy(), scores, 0.1)
+    bs = torch.from_numpy(boxes[order]).to(cuda)
+    merged, keep = nv.box_merge(bs, torch.from_numpy(labels[order]).to(cuda), 0.1)
+    assert keep.cpu().nonzero().reshape(-1).tolist() == idx.tolist()
+    assert len(idx) < n or n <= 2
+    assert np.abs(merged[keep].cpu().numpy() - bx).max() <= 1e-5
+
+
+@pytest.mark.parametrize("pp", [dict(type="box_merging", score_thr=[0.3, 0.25, 0.25], num_thr=500), dict(type="soft_nms", gaussian_sigma=0.3, prune_threshold=1e-3),
+                                dict(type="nms", nms_thr=0.5)])
+def test_get_bboxes_runs_every_shipped_post_processing(cuda, pp):
+    """the post-processing types the shipped configs name (nms: SUN RGB-D / ScanNet, box_merging: both KITTI configs,
+    uni3detr_kitti_3classes.py:115-117) and the soft_nms option of the head all run on the device and honour score_thr / num_thr."""
+    from uni3detr_amd.configs.sunrgbd import model as MODEL_CFG
+    from uni3detr_amd.registry import build_model
+    cfg = copy.deepcopy(MODEL_CFG)
+    cfg["pts_bbox_head"]["post_processing"] = pp
+    if pp["type"] == "box_merging":
+        cfg["pts_bbox_head"]["num_classes"] = 3
+        cfg["pts_bbox_head"]["bbox_coder"]["num_classes"] = 3
+    torch.manual_seed(0)
+    head = build_model(cfg).pts_bbox_head.to(cuda).eval()
+    C = head.num_classes
+    g = torch.Generator(device="cpu").manual_seed(1)
+    preds = dict(all_cls_scores=(torch.randn(3, 2, 1200, C, generator=g) - 1.0).to(cuda),
+                 all_bbox_preds=torch.cat([torch.rand(3, 2, 1200, 1, generator=g) * 6 - 3, torch.rand(3, 2, 1200, 1, generator=g) * 6,
+                                           torch.randn(3, 2, 1200, 2, generator=g) * 0.3, torch.rand(3, 2, 1200, 1, generator=g) * 2 - 1.8,
+                                           torch.randn(3, 2, 1200, 1, generator=g) * 0.3, torch.randn(3, 2, 1200, 2, generator=g)], -1).to(cuda),
+                 all_iou_preds=torch.randn(3, 2, 1200, 1, generator=g).to(cuda))
+    res = head.get_bboxes(preds, None)
+    assert len(res) == 2
+    for boxes, scores, labels in res:
+        assert boxes.shape[0] == scores.shape[0] == labels.shape[0] and boxes.shape[0] > 0 and boxes.shape[1] == 7
+        assert torch.isfinite(boxes).all() and int(labels.max()) < C
+        if "num_thr" in pp:
+            assert boxes.shape[0] <= pp["num_thr"]
+        if pp["type"] == "box_merging":
+            thr = scores.new_tensor(pp["score_thr"])[labels]
+            assert (scores > thr).all()
+
+
+def test_reloaded_checkpoint_gives_identical_detections(cuda, tmp_path):
+    """save_checkpoint (spconv-2.x layout, 'module.' prefix) -> load_checkpoint into a fresh model -> simple_test on the same scene:
+    identical boxes / scores / labels (ref: extra_tools/test.py:197 load_checkpoint + single_gpu_test)."""
+    from uni3detr_amd.checkpoint import load_checkpoint, save_checkpoint
+    from uni3detr_amd.configs.sunrgbd import model as MODEL_CFG
+    from uni3detr_amd.registry import build_model
+    from uni3detr_amd.synth import room_scene
+    torch.manual_seed(1)
+    a = build_model(copy.deepcopy(MODEL_CFG)).to(cuda).eval()
+    path = str(tmp_path / "ck.pth")
+    ck = save_checkpoint(a, path, to_spconv2=True)
+    ck["state_dict"] = {"module." + k: v for k, v in ck["state_dict"].items()}
+    torch.save(ck, path)
+    torch.manual_seed(2)
+    b = build_model(copy.deepcopy(MODEL_CFG))
+    load_checkpoint(b, path)
+    b = b.to(cuda).eval()
+    pts = [torch.from_numpy(room_scene(0, 12000)[0]).to(cuda)]
+    with torch.no_grad():
+        torch.manual_seed(7); ra = a.simple_test(None, pts)
+        torch.manual_seed(7); rb = b.simple_test(None, pts)
+    for k in ("boxes_3d", "scores_3d", "labels_3d"):
+        ta, tb = ra[0]["pts_bbox"][k] if "pts_bbox" in ra[0] else ra[0][k], rb[0]["pts_bbox"][k] if "pts_bbox" in rb[0] else rb[0][k]
+        ta = ta.tensor if hasattr(ta, "tensor") else ta
+        tb = tb.tensor if hasattr(tb, "tensor") else tb
+        assert torch.equal(ta, tb), k

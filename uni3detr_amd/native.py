@@ -134,6 +134,9 @@ _SIGS = {
     "u3d_adamw_set_hyper": (_I, [_P] + [C.c_float] * 6 + [_P]),
     "u3d_adamw_step_state": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _L, _P]),
     "u3d_gather_rows": (_I, [_P, _P, _I, _I, _P, _P]),
+    "u3d_soft_nms": (_I, [_P, _P, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P]),
+    "u3d_box_merge_workspace": (_L, [_I]),
+    "u3d_box_merge": (_I, [_P, _P, _I, C.c_float, _P, _P, _P, _L, _P]),
     "u3d_decoder_layer_slots": (_I, [_I, _I, _I, _P, _P]),
     "u3d_decoder_layer_blocks": (_I, [_I]),
     "u3d_decoder_layer_fwd": (_I, [C.POINTER(DecLayerParams), C.POINTER(DecLayerDims)] + [_P] * 11 + [_L, _P]),
@@ -612,6 +615,37 @@ def nms3d_classwise(boxes, scores, labels, thr):
 
 
 _COUNT_CACHE = {}
+
+
+def soft_nms_classwise(boxes, scores, labels, num_classes, sigma, prune):
+    """-> (idx long [k] into the input, decayed scores [k], labels long [k]) class-major, selection order inside a class."""
+    n = boxes.shape[0]
+    dev = boxes.device
+    if n == 0:
+        return (torch.zeros(0, dtype=torch.long, device=dev), torch.zeros(0, device=dev), torch.zeros(0, dtype=torch.long, device=dev))
+    b = boxes[:, :7].contiguous().float()
+    oi = torch.empty((num_classes, n), dtype=torch.int32, device=dev)
+    os_ = torch.empty((num_classes, n), dtype=torch.float32, device=dev)
+    oc = torch.empty((num_classes,), dtype=torch.int32, device=dev)
+    _check(lib().u3d_soft_nms(_ptr(b), _ptr(scores.contiguous().float()), _ptr(labels.contiguous().int()), n, num_classes, float(sigma),
+                              float(prune), _ptr(oi), _ptr(os_), _ptr(oc), _stream()), "soft_nms")
+    sel = torch.arange(n, device=dev)[None, :] < oc[:, None]              # variable-size result: the one sync of this routine
+    cls = torch.arange(num_classes, device=dev)[:, None].expand(-1, n)
+    return oi[sel].long(), os_[sel], cls[sel]
+
+
+def box_merge(boxes_sorted, labels_sorted, thr):
+    """boxes f32 [n,7] sorted by descending score -> (merged [n,7], keep bool [n])."""
+    n = boxes_sorted.shape[0]
+    dev = boxes_sorted.device
+    merged = torch.empty((n, 7), dtype=torch.float32, device=dev)
+    keep = torch.zeros((n,), dtype=torch.uint8, device=dev)
+    if n == 0:
+        return merged, keep.bool()
+    ws = torch.empty(max(int(lib().u3d_box_merge_workspace(n)), 16), dtype=torch.uint8, device=dev)
+    _check(lib().u3d_box_merge(_ptr(boxes_sorted.contiguous().float()), _ptr(labels_sorted.contiguous().int()), n, float(thr), _ptr(merged),
+                               _ptr(keep), _ptr(ws), ws.numel(), _stream()), "box_merge")
+    return merged, keep.bool()
 
 
 def count_tensor(n, device):

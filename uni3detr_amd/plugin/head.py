@@ -335,20 +335,10 @@ class Uni3DETRHead(nn.Module):
         return self.loss_from_targets(preds_dicts, T, num_pos)
 
     def soft_nms(self, boxes, scores, gaussian_sigma=0.3, prune_threshold=1e-3):
-        """Gaussian soft-NMS with rotated 3-D IoU (ref :796-823); sequential by nature, host loop over the HIP IoU kernel."""
-        boxes, scores = boxes.clone(), scores.clone()
-        idxs = torch.arange(scores.numel(), device=boxes.device)
-        out_i, out_s = [], []
-        while scores.numel() > 0:
-            top = int(torch.argmax(scores))
-            out_i.append(int(idxs[top]))
-            out_s.append(float(scores[top]))
-            ious = bbox_overlaps_3d_aligned(boxes[top:top + 1].expand_as(boxes).contiguous(), boxes)
-            scores = scores * torch.exp(-ious.pow(2) / gaussian_sigma)
-            keep = scores > prune_threshold
-            keep[top] = False
-            boxes, scores, idxs = boxes[keep], scores[keep], idxs[keep]
-        return torch.tensor(out_i, device=boxes.device, dtype=torch.long), torch.tensor(out_s, device=boxes.device)
+        """Gaussian soft-NMS with rotated 3-D IoU over ONE set of boxes (ref :796-823) on the device kernel (u3d_soft_nms)."""
+        idx, sc, _ = nv.soft_nms_classwise(boxes, scores, torch.zeros(boxes.shape[0], dtype=torch.int32, device=boxes.device), 1,
+                                           gaussian_sigma, prune_threshold)
+        return idx, sc
 
     def get_bboxes(self, preds_dicts, img_metas, rescale=False):
         """Decode + post-processing on the device (ref :827-918).  Returns [[boxes [n,7] bottom-centre, scores, labels], ...]."""
@@ -365,19 +355,17 @@ class Uni3DETRHead(nn.Module):
                     keep = nv.nms3d_classwise(boxes, scores, labels, pp["nms_thr"])
                     boxes, scores, labels = boxes[keep], scores[keep], labels[keep]
                 elif pp["type"] == "soft_nms":
-                    bs, ss, ls = [], [], []
-                    for j in range(self.num_classes):
-                        ind = labels == j
-                        if int(ind.sum()) == 0:
-                            continue
-                        ki, sc = self.soft_nms(boxes[ind][:, :7], scores[ind], pp["gaussian_sigma"], pp["prune_threshold"])
-                        bs.append(boxes[ind][ki]); ss.append(sc); ls.append(torch.full_like(ki, j))
-                    boxes = torch.cat(bs) if bs else boxes[:0]
-                    scores = torch.cat(ss) if ss else scores[:0]
-                    labels = torch.cat(ls) if ls else labels[:0]
+                    # all classes in one launch (one workgroup per class); result class-major like the reference's per-class loop
+                    ki, scores, labels = nv.soft_nms_classwise(boxes, scores, labels, self.num_classes, pp["gaussian_sigma"], pp["prune_threshold"])
+                    boxes = boxes[ki]
                 elif pp["type"] == "box_merging":
-                    raise NotImplementedError("KITTI 'box_merging' post-processing is CPU/shapely code outside the hot path "
-                                              "(SURVEY.md §2.1 row 16); use type='nms'")
+                    # ref :881-891: nms_boxes_3d_merge_only(..., overlapped_thres=0.1, top_k=-1): score sort, greedy same-class merge,
+                    # kept boxes replaced by the median of what they absorbed - on the device (u3d_box_merge)
+                    order = torch.argsort(-scores, stable=True)
+                    boxes, scores, labels = boxes[order], scores[order], labels[order]
+                    merged, keep = nv.box_merge(boxes[:, :7], labels, 0.1)
+                    boxes = torch.cat([merged, boxes[:, 7:]], 1)[keep] if boxes.shape[1] > 7 else merged[keep]
+                    scores, labels = scores[keep], labels[keep]
                 else:
                     raise NotImplementedError(pp["type"] + " not implemented.")
                 if "score_thr" in pp:
