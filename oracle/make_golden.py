@@ -123,6 +123,55 @@ def gen_small(ns):
     print("small_ops ok")
 
 
+def gen_head_variants(ns):
+    """The reference head / transformer with the two other head shapes the shipped configs use: KITTI (9 decoder layers, 3 classes;
+    uni3detr_kitti_3classes.py:64-77) through forward + loss + backward, and nuScenes (900 queries -> 2700 training queries, code size
+    10; uni3detr_nuscenes.py:69) through the forward only - its loss path is inconsistent upstream (9-dim GT into 7-dim targets)."""
+    out = {}
+    for name, B, vol, with_loss in (("kitti_3classes", 2, (5, 24, 22), True), ("nuscenes", 1, (5, 20, 20), False)):
+        m = rs.model_cfg(name)
+        hc = dict(m["pts_bbox_head"])
+        hc.pop("type")
+        hc["train_cfg"] = m["train_cfg"]["pts"]
+        head = ns.head.Uni3DETRHead(**hc)
+        sd = seeded_state_dict(head.state_dict().items(), SEED)
+        head.load_state_dict(sd)
+        head.eval()
+        nq = hc["num_query"]
+        feats = seeded_input(name + ".pts_feats", (B, 256) + vol, SEED, -0.5, 1.0).clamp_min(0)
+        fps = seeded_input(name + ".fpsbpts", (B, 2 * nq, 3), SEED, 0.0, 1.0)
+        feats.requires_grad_(True)
+        outs = head(feats, None, fps)
+        out[name + "_cls"] = outs["all_cls_scores"].detach().numpy()
+        out[name + "_box"] = outs["all_bbox_preds"].detach().numpy()
+        out[name + "_iou"] = outs["all_iou_preds"].detach().numpy()
+        out[name + "_shape"] = np.array((B, 256) + vol + (nq,))
+        if with_loss:
+            pr = m["pts_bbox_head"]["bbox_coder"]["pc_range"]
+            rng = np.random.default_rng(SEED + 5)
+            gts, labels = [], []
+            for b in range(B):
+                n = 6 - b
+                c = rng.uniform([pr[0] + 5, pr[1] + 5, pr[2] + 0.5], [pr[3] - 5, pr[4] - 5, pr[5] - 1.5], (n, 3))
+                g = np.concatenate([c, rng.uniform(0.6, 4.0, (n, 3)), rng.uniform(-3.1, 3.1, (n, 1))], 1).astype(np.float32)
+                gts.append(torch.from_numpy(g))
+                labels.append(torch.from_numpy(rng.integers(0, hc["num_classes"], n)))
+            losses = head.loss([rs.GTBoxes(g) for g in gts], labels, outs)
+            sum(losses.values()).backward()
+            out[name + "_loss_names"] = np.array(sorted(losses))
+            out[name + "_loss_values"] = np.array([float(losses[k]) for k in sorted(losses)], np.float64)
+            out[name + "_gt_lens"] = np.array([g.shape[0] for g in gts])
+            out[name + "_gts"] = torch.cat(gts).numpy()
+            out[name + "_labels"] = torch.cat(labels).numpy()
+            out[name + "_feats_grad_abs_sum"] = float(feats.grad.abs().sum())
+            pg = {k: p.grad for k, p in head.named_parameters() if p.grad is not None}
+            names = sorted(pg)
+            out[name + "_pgrad_names"] = np.array(names)
+            out[name + "_pgrad_l2"] = np.array([float(pg[k].norm()) for k in names], np.float64)
+        print(name, "head:", out[name + "_cls"].shape, out[name + "_box"].shape)
+    np.savez_compressed(os.path.join(OUT, "head_variants.npz"), seed=SEED, **out)
+
+
 def gen_decode(ns):
     """NMSFreeCoder.decode of the reference file (core/bbox/coders/nms_free_coder.py:42-136) on seeded head outputs: three coder
     settings (alpha, score threshold, a tight centre range) so that the top-k, the score / IoU blend and both masks are pinned."""
@@ -159,6 +208,7 @@ def main():
     gen_head_train(ns)
     gen_head_eval(ns)
     gen_decode(ns)
+    gen_head_variants(ns)
 
 
 if __name__ == "__main__":

@@ -36,6 +36,30 @@ def sunrgbd_cfg():
         code_weights=(1.0,) * 8, fps_packed_quirk=True)
 
 
+def _derive(**kw):
+    c = sunrgbd_cfg()
+    c.update(kw)
+    return c
+
+
+def kitti_cfg():
+    """projects/configs/uni3detr/uni3detr_kitti_3classes.py:10-11,28-41,64-77: outdoor range, 0.05/0.05/0.1 voxels, 9 decoder layers."""
+    return _derive(voxel_size=(0.05, 0.05, 0.1), pc_range=(0, -40, -3, 70.4, 40, 1), sparse_shape=(41, 1600, 1408), num_classes=3,
+                   dec_layers=9)
+
+
+def scannet_large_cfg():
+    """uni3detr_scannet_large.py:9-12,28-42,64-70: dynamic voxelization, base_channels 32, 512-channel encoder output, 18 classes."""
+    return _derive(pc_range=(-6.4, -6.4, -0.1, 6.4, 6.4, 2.46), sparse_shape=(128, 640, 640), dynamic=True, enc_base=32, enc_out=512,
+                   encoder_channels=((32, 32, 64), (64, 64, 128), (128, 128, 256), (256, 256)), bb_in=(512, 512, 512), num_classes=18)
+
+
+def nuscenes_cfg():
+    """uni3detr_nuscenes.py:13-14,31-46,69: 5-feature points, 10 points / voxel, 900 queries, code size 10 (the head's default)."""
+    return _derive(voxel_size=(0.075, 0.075, 0.2), pc_range=(-54, -54, -5.0, 54, 54, 3.0), sparse_shape=(41, 1440, 1440), max_points=10,
+                   max_voxels=(90000, 120000), num_features=5, enc_in=5, num_query=900, code_size=10, code_weights=(1.0,) * 10)
+
+
 # ==================================================================================================
 # a-4  SparseEncoderHD  (models/pts_encoder/sparse_encoder_hd.py:106-138, layer list :140-214)
 # ==================================================================================================
@@ -405,6 +429,30 @@ def head_loss(cls_all, box_all, iou_all, gts_bottom, labels, cfg):
 # ==================================================================================================
 # a-1  whole training forward (models/detectors/uni3detr.py:143-266)
 # ==================================================================================================
+def forward_features(sd, points_list, cfg):
+    """extract_pts_feat (uni3detr.py:143-190) for either voxelization mode -> (features [B,C,D,H,W], fpsbpts [B,2*nq,3])."""
+    B = len(points_list)
+    if cfg.get("dynamic"):
+        # :155-171: per-point coors (-1 rows kept), DynamicSimpleVFE mean; the voxel-coordinate FPS then runs over the PER-POINT coors
+        pcoors, feats, coors = og.voxelize_dynamic(points_list, cfg["voxel_size"], cfg["pc_range"])
+        feats = torch.from_numpy(feats[:, :cfg["num_features"]])
+        fps_coors = pcoors
+    else:
+        vox, coors, num = og.voxelize_batch(points_list, cfg["voxel_size"], cfg["pc_range"], cfg["max_points"], cfg["max_voxels"][0])
+        feats = torch.from_numpy(og.vfe_mean(vox, num, cfg["num_features"]))
+        fps_coors = coors
+    x = sparse_encoder(sd, "pts_middle_encoder.", feats, coors, B, cfg)
+    x = second3dfpn(sd, "pts_neck.", second3d(sd, "pts_backbone.", x, cfg), cfg)
+    return x, fps_queries(points_list, fps_coors, cfg)
+
+
+def forward_logits(sd, points_list, cfg):
+    """features + head outputs, no loss (nuScenes: the reference's loss path is inconsistent with its 9-dim GT)."""
+    x, fpsbpts = forward_features(sd, points_list, cfg)
+    cls, box, iou = head_forward(sd, "pts_bbox_head.", x, fpsbpts, cfg)
+    return dict(cls=cls, box=box, iou=iou, fpsbpts=fpsbpts, feats=x)
+
+
 def forward_train(sd, points_list, gts_bottom, labels, cfg):
     B = len(points_list)
     vox, coors, num = og.voxelize_batch(points_list, cfg["voxel_size"], cfg["pc_range"], cfg["max_points"], cfg["max_voxels"][0])

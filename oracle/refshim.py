@@ -457,6 +457,14 @@ def load_hot_path():
     return ns
 
 
+def model_cfg(name):
+    """The `model` dict of projects/configs/uni3detr/uni3detr_<name>.py, read by exec'ing the reference config where it lies."""
+    cfg_path = os.path.join(REF_ROOT, "projects", "configs", "uni3detr", f"uni3detr_{name}.py")
+    g = {}
+    exec(compile(open(cfg_path).read(), cfg_path, "exec"), g)
+    return copy.deepcopy(g["model"])
+
+
 def sunrgbd_head_cfg():
     """The pts_bbox_head + train_cfg dicts of projects/configs/uni3detr/uni3detr_sunrgbd.py, read by exec'ing the
     reference config where it lies (nothing copied)."""

@@ -77,3 +77,108 @@ def test_inference_path_runs(cuda):
         n = r["boxes_3d"].shape[0]
         assert r["boxes_3d"].shape[1] == 7 and r["scores_3d"].shape == (n,) and r["labels_3d"].shape == (n,)
         assert (r["scores_3d"] >= 0).all() and (r["scores_3d"] <= 1).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# fp32 parity of the other shipped configurations (BASELINE.json configs[2..4])
+# ---------------------------------------------------------------------------------------------------------------------------
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _no_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if hasattr(mod, "attn_drop"):
+            mod.attn_drop = 0.0
+    return m
+
+
+@pytest.mark.parametrize("name", ["kitti_3classes", "nuscenes"])
+def test_head_variants_match_reference_golden(cuda, name):
+    """Product head (fp32 mode) with the KITTI (9 decoder layers) and nuScenes (2700 training queries, code size 10) head shapes
+    against the REFERENCE head's outputs (tests/golden/head_variants.npz): logits 1e-3; KITTI also the 36 losses and the
+    per-parameter gradient norms (ref: uni3detr_kitti_3classes.py:64-77, uni3detr_nuscenes.py:69)."""
+    from oracle.weights import seeded_input, seeded_tensor
+    z = np.load(os.path.join(G, "head_variants.npz"))
+    seed = int(z["seed"])
+    B, C, D, H, W, nq = (int(v) for v in z[name + "_shape"])
+    head = build_model(_cfg(name)).pts_bbox_head
+    head.load_state_dict({k: seeded_tensor(k, tuple(v.shape), seed) for k, v in head.state_dict().items()})
+    head = _no_dropout(head).to(cuda).train()
+    feats = seeded_input(name + ".pts_feats", (B, C, D, H, W), seed, -0.5, 1.0).clamp_min(0).to(cuda).requires_grad_(True)
+    fps = seeded_input(name + ".fpsbpts", (B, 2 * nq, 3), seed, 0.0, 1.0).to(cuda)
+    outs = head(feats, None, fps)
+    for key, oname in (("_cls", "all_cls_scores"), ("_box", "all_bbox_preds"), ("_iou", "all_iou_preds")):
+        ref = torch.from_numpy(z[name + key])
+        assert outs[oname].shape == ref.shape
+        err = (outs[oname].detach().cpu() - ref).abs().max().item()
+        assert err <= 1e-3 * max(1.0, ref.abs().max().item()), (key, err)
+    if name + "_loss_values" in z:
+        gts, labels, o = [], [], 0
+        for n in z[name + "_gt_lens"]:
+            gts.append(Boxes3D(torch.from_numpy(z[name + "_gts"][o:o + n])).to(cuda))
+            labels.append(torch.from_numpy(z[name + "_labels"][o:o + n]).to(cuda))
+            o += n
+        losses = head.loss(gts, labels, outs)
+        for k, v in zip(z[name + "_loss_names"], z[name + "_loss_values"]):
+            assert abs(float(losses[str(k)]) - v) <= 1e-3 * max(1.0, abs(v)), (k, float(losses[str(k)]), v)
+        sum(losses.values()).backward()
+        assert abs(float(feats.grad.abs().sum()) - float(z[name + "_feats_grad_abs_sum"])) <= 5e-3 * float(z[name + "_feats_grad_abs_sum"])
+        pg = {k: float(p.grad.norm()) for k, p in head.named_parameters() if p.grad is not None}
+        for k, ref in zip(z[name + "_pgrad_names"], z[name + "_pgrad_l2"]):
+            assert abs(pg[str(k)] - ref) <= 2e-3 * max(ref, 1e-3) + 1e-5, (k, pg[str(k)], ref)
+
+
+@pytest.mark.parametrize("name,npts,with_loss", [("scannet_large", 100000, True), ("kitti_3classes", 18000, False), ("nuscenes", 250000, False)])
+def test_full_forward_matches_cpu_oracle_other_configs(cuda, name, npts, with_loss):
+    """fp32 mode, ONE scene at the configuration's real point count (ScanNet-large ~100 k points, dynamic voxelization, 32-channel base /
+    512-channel dense input; KITTI 18 000 sampled points; nuScenes 10 sweeps ~250 k points, 90 000-voxel cap, 2700 queries, code size
+    10) against oracle/model.py: features 1e-3, FPS queries identical, logits 1e-3, and for the configs with a consistent loss path the
+    losses 1e-3 and identical Hungarian assignments.
+
+    Conditioning: with random weights every decoder layer amplifies a perturbation of its reference points by the size of the sampled
+    lattice; on KITTI's 200 x 176 lattice and 9 layers the REFERENCE arithmetic itself moves by 5e-6 (layer 0) ... 0.4 (layer 8) between
+    fp32 and fp64 (measured with oracle/model.py run in both precisions, below).  The per-layer bound is therefore
+    max(1e-3, 4 x the oracle's own fp32-vs-fp64 deviation), the truth being the fp64 oracle; KITTI's losses (which need all 9 layers)
+    are pinned by the reference golden on a small lattice instead (test_head_variants_match_reference_golden)."""
+    from oracle import model as om
+    from oracle.weights import seeded_tensor
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ocfg = dict(scannet_large=om.scannet_large_cfg, kitti_3classes=om.kitti_cfg, nuscenes=om.nuscenes_cfg)[name]()
+    cfg = _cfg(name)
+    model = build_model(cfg)
+    sd = {k: seeded_tensor(k, tuple(v.shape), 21) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    model = _no_dropout(model).to(cuda).train()
+    rng_range = tuple(cfg["pts_voxel_layer"]["point_cloud_range"])
+    nfeat = cfg["pts_middle_encoder"]["in_channels"]
+    ncls = cfg["pts_bbox_head"]["num_classes"]
+    p, g, l = _scene(3, npts, rng_range, nfeat)
+    with torch.no_grad():
+        ref = om.forward_logits(sd, [p.numpy()], ocfg)
+    feat, fpsb = model.extract_pts_feat([p.to(cuda)])
+    assert torch.equal(fpsb.cpu(), ref["fpsbpts"])
+    err = (feat.detach().float().cpu() - ref["feats"]).abs().max().item()
+    assert err <= 1e-3 * ref["feats"].abs().max().item(), err
+    outs = model.pts_bbox_head(feat, None, fpsb)
+    with torch.no_grad():
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        ref64 = dict(zip(("cls", "box", "iou"), om.head_forward(sd64, "pts_bbox_head.", ref["feats"].double(), ref["fpsbpts"].double(), ocfg)))
+    for key, oname in (("cls", "all_cls_scores"), ("box", "all_bbox_preds"), ("iou", "all_iou_preds")):
+        got = outs[oname].detach().cpu().double()
+        for lyr in range(got.shape[0]):
+            cond = (ref[key][lyr].double() - ref64[key][lyr]).abs().max().item()          # the oracle's own fp32 noise at this layer
+            e = (got[lyr] - ref64[key][lyr]).abs().max().item()
+            assert e <= max(1e-3 * max(1.0, ref64[key][lyr].abs().max().item()), 4.0 * cond), (key, lyr, e, cond)
+        if got.shape[0] <= 3:                                                              # well-conditioned depth: plain 1e-3 vs the fp32 oracle too
+            e = (got.float() - ref[key]).abs().max().item()
+            assert e <= 1e-3 * max(1.0, ref[key].abs().max().item()), (key, e)
+    if with_loss:
+        lab = l % ncls
+        with torch.no_grad():
+            ref_losses, assigned = om.head_loss(ref["cls"], ref["box"], ref["iou"], [g], [lab], ocfg)
+        losses = model.pts_bbox_head.loss([Boxes3D(g).to(cuda)], [lab.to(cuda)], outs)
+        assert torch.equal(model.pts_bbox_head._last_assigned.cpu(), assigned)
+        for k, v in ref_losses.items():
+            assert abs(float(losses[k]) - float(v)) <= 1e-3 * max(1.0, abs(float(v))), (k, float(losses[k]), float(v))

@@ -224,3 +224,36 @@ def test_merge_oracle_median_and_sweep_order():
     lab, bx, sc, idx, order = pp.merge_boxes(labels, boxes, scores, 0.1)
     assert idx.tolist() == [0, 3, 4] and lab.tolist() == [1, 2, 1]
     assert np.allclose(bx[0], np.median(boxes[:3], axis=0)) and np.allclose(bx[1], boxes[3]) and np.allclose(bx[2], boxes[4])
+
+
+@pytest.mark.parametrize("name", ["kitti_3classes", "nuscenes"])
+def test_oracle_head_matches_reference_golden_for_other_head_shapes(name):
+    """oracle/model.py head_forward (+ head_loss) with the KITTI (9 decoder layers, 3 classes) and nuScenes (900 queries, code size 10)
+    numbers against the reference head's own outputs (tests/golden/head_variants.npz, oracle/make_golden.py gen_head_variants)."""
+    z = np.load(os.path.join(G, "head_variants.npz"))
+    seed = int(z["seed"])
+    cfg = om.kitti_cfg() if name == "kitti_3classes" else om.nuscenes_cfg()
+    B, C, D, H, W, nq = (int(v) for v in z[name + "_shape"])
+    L = z[name + "_cls"].shape[0]
+    assert L == cfg["dec_layers"] and nq == cfg["num_query"] and z[name + "_box"].shape[-1] == cfg["code_size"]
+    # state dict of the reference head: names / shapes follow from the layer count, class count and code size
+    import projects.mmdet3d_plugin  # noqa: F401
+    from uni3detr_amd.configs import variants
+    from uni3detr_amd.registry import build_model
+    head = build_model(getattr(variants, name)).pts_bbox_head
+    sd = {"pts_bbox_head." + k: seeded_tensor(k, tuple(v.shape), seed) for k, v in head.state_dict().items()}
+    feats = seeded_input(name + ".pts_feats", (B, C, D, H, W), seed, -0.5, 1.0).clamp_min(0)
+    fps = seeded_input(name + ".fpsbpts", (B, 2 * nq, 3), seed, 0.0, 1.0)
+    with torch.no_grad():
+        cls, box, iou = om.head_forward(sd, "pts_bbox_head.", feats, fps, cfg)
+    for got, key in ((cls, "_cls"), (box, "_box"), (iou, "_iou")):
+        ref = z[name + key]
+        assert got.shape == ref.shape and np.abs(got.numpy() - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), key
+    if name + "_loss_values" in z:
+        gts, labels, o = [], [], 0
+        for n in z[name + "_gt_lens"]:
+            gts.append(torch.from_numpy(z[name + "_gts"][o:o + n])); labels.append(torch.from_numpy(z[name + "_labels"][o:o + n])); o += n
+        with torch.no_grad():
+            losses, _ = om.head_loss(cls, box, iou, gts, labels, cfg)
+        for k, v in zip(z[name + "_loss_names"], z[name + "_loss_values"]):
+            assert abs(float(losses[str(k)]) - v) <= 1e-4 * max(1.0, abs(v)), (k, float(losses[str(k)]), v)
