@@ -22,6 +22,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef IGEMM_SMALL_C
 #define IGEMM_SMALL_C 1
 #endif
+#ifndef IGEMM_DIRECT
+#define IGEMM_DIRECT 1     /* narrow sparse levels on the direct-operand kernel (igemm_direct.hip); 0: the tiled BK = 32 kernels below */
+#endif
+int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev, int n_out_cap,
+                            int cin, int cout, int kvol, int transpose_w, hipStream_t s);
+#ifndef IGEMM_SMALL_PF
+#define IGEMM_SMALL_PF 1   /* stages of operand loads in flight in the 16/32-channel kernels (1: the wide layers' one-stage pipeline) */
+#endif
+#ifndef IGEMM_SMALL_WM
+#define IGEMM_SMALL_WM 4   /* 16-row blocks per wave: 4 waves x 4 = 256-row tiles */
+#endif
 #ifndef GLDS256_CFG
 #define GLDS256_CFG 2, 4, 8, 4   /* waves (rows x cols) and 16x16 blocks per wave (rows x cols) of the 256x256-tile LDS-DMA kernel */
 #endif
@@ -86,7 +97,7 @@ __device__ __forceinline__ bf16x8 direct_frag(const u16* tile, int stride, int r
 //   W_KMAJOR = true : global W[kappa][k][n]  (forward; staged row-major [k][n], fetched with transpose reads)
 //   W_KMAJOR = false: global W[kappa][n][k]  (dgrad: the forward weight read transposed; staged [n][k], direct reads)
 // =============================================================================================
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool W_KMAJOR, int BK = 64>
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool W_KMAJOR, int BK = 64, int PF = 1>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* __restrict__ in, const u16* __restrict__ w,
                                                                       const int* __restrict__ nbr, int ld, u16* __restrict__ out,
                                                                       const int* __restrict__ n_out_dev, int n_out_cap, int cin,
@@ -214,6 +225,107 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
     }
   };
 
+  if constexpr (PF > 1) {
+    // Deep-prefetch form for the narrow sparse levels (BK = 32: one MFMA k-step = ~130 clk of matrix work per stage).  In the loop
+    // below a stage's gather is requested one stage before it is stored to LDS, so every stage waits out a full L2/HBM round trip
+    // (measured: 1.5 us per stage with three workgroups per CU interleaved - the kernel moved ~1.1 TB/s).  Two things keep a
+    // deeper pipeline from forming there: the register set, and the gather INDICES - they come from a vector load too, vmcnt
+    // retires in order, so consuming an index waits for every row load issued before it.  Here the tile's whole neighbour table
+    // (kvol x BM ints, coalesced: the table is offset-major) is staged in LDS once (LDS reads count on lgkmcnt, not vmcnt), and
+    // the operand registers exist PF times: the loads of stage st + PF are issued when stage st + 1 has been written to LDS.
+    int* sidx = (int*)(smem + 2 * STAGE_ELEMS);
+    {
+      constexpr int IB = 9;                               // table loads in flight per thread (a plain loop waits out one round trip per entry)
+      const int total = kvol * BM;
+      for (int i0 = 0; i0 < total; i0 += IB * NT) {
+        int v[IB];
+#pragma unroll
+        for (int j = 0; j < IB; ++j) {
+          const int i = min(i0 + j * NT + tid, total - 1);
+          const int kap = i / BM, m = m0 + i % BM;
+          const int mc = m < n_out ? m : n_out - 1;
+          v[j] = nbr ? nbr[(long long)kap * ld + mc] : mc;
+        }
+#pragma unroll
+        for (int j = 0; j < IB; ++j) {
+          const int i = min(i0 + j * NT + tid, total - 1);
+          sidx[i] = (m0 + i % BM < n_out) ? v[j] : -1;
+        }
+      }
+    }
+    __syncthreads();
+    u32x4 pa[PF][A_SEGS], pw[PF][W_SEGS];
+    auto issue_p = [&](int st, u32x4* qa, u32x4* qw) {
+      const int kap = st % kvol, c0 = (st / kvol) * BK;
+      const unsigned a_soff = (unsigned)c0 * 2u;
+      const bool a_in = BK == 64 || (c0 + (int)(a_part16 >> 1) < cin);
+#pragma unroll
+      for (int u = 0; u < A_SEGS; ++u) {
+        const int idx = sidx[kap * BM + a_row0 + u * A_ROW_STEP];
+        unsigned voff = (idx >= 0 && a_in) ? (unsigned)idx * row_bytes + a_part16 : 0xFFFFFFFFu;
+        qa[u] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, voff, a_soff, 0);
+      }
+      const unsigned w_soff = W_KMAJOR ? (unsigned)((kap * cin + c0) * cout) * 2u : (unsigned)(kap * cin * cout + c0) * 2u;
+#pragma unroll
+      for (int u = 0; u < W_SEGS; ++u) {
+        const unsigned vo = (BK == 64 || c0 + w_k[u] < cin) ? w_voff[u] : 0xFFFFFFFFu;
+        qw[u] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, vo, w_soff, 0);
+      }
+    };
+    // LDS position of each weight segment; threads without one (small tiles) write their zeros to a scratch slot behind the
+    // neighbour table: no branch in the stage body (a divergent branch there makes hipcc fall back to `vmcnt(0)`)
+    int w_lds[W_SEGS];
+#pragma unroll
+    for (int u = 0; u < W_SEGS; ++u) {
+      const int sgi = tid + u * NT;
+      if (W_KMAJOR) w_lds[u] = A_ELEMS + (sgi / (BN / 8)) * LDW + (sgi % (BN / 8)) * 8;
+      else w_lds[u] = A_ELEMS + (sgi / (BK / 8)) * LDW + (sgi % (BK / 8)) * 8;
+      if (sgi >= W_TOTAL) w_lds[u] = -1;
+    }
+    u16* const scratch = (u16*)(sidx + kvol * BM) + tid * 8;
+    auto store_p = [&](int buf, const u32x4* qa, const u32x4* qw) {
+      u16* Ab = smem + buf * STAGE_ELEMS;
+#pragma unroll
+      for (int u = 0; u < A_SEGS; ++u) *(u32x4*)(Ab + (a_row0 + u * A_ROW_STEP) * LDA + (tid % (BK / 8)) * 8) = qa[u];
+#pragma unroll
+      for (int u = 0; u < W_SEGS; ++u) *(u32x4*)(w_lds[u] >= 0 ? Ab + w_lds[u] : scratch) = qw[u];
+    };
+    const int last = nstage - 1;
+#pragma unroll
+    for (int p = 0; p < PF; ++p) issue_p(p < last ? p : last, pa[p], pw[p]);
+    store_p(0, pa[0], pw[0]);
+    issue_p(PF < last ? PF : last, pa[0], pw[0]);
+    __syncthreads();
+    for (int st0 = 0; st0 < nstage; st0 += PF) {          // nstage % PF == 0 (dispatch)
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        const int st = st0 + p;
+        {
+          const int buf = st & 1;
+          const u16* A = smem + buf * STAGE_ELEMS;
+          const u16* W = A + A_ELEMS;
+#pragma unroll
+          for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 af[WM];
+#pragma unroll
+            for (int a = 0; a < WM; ++a) af[a] = direct_frag(A, LDA, (wm * WM + a) * 16, ks * 32, lane);
+#pragma unroll
+            for (int b = 0; b < WN; ++b) {
+              bf16x8 bfr = W_KMAJOR ? tr_frag(W, LDW, ks * 32, (wn * WN + b) * 16, lane)
+                                    : direct_frag(W, LDW, (wn * WN + b) * 16, ks * 32, lane);
+#pragma unroll
+              for (int a = 0; a < WM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr, acc[a][b], 0, 0, 0);
+            }
+          }
+          const int q = (p + 1) % PF;                     // register set of stage st + 1 (and, once stored, of stage st + 1 + PF)
+          store_p(buf ^ 1, pa[q], pw[q]);
+          const int nx = st + 1 + PF;
+          issue_p(nx < last ? nx : last, pa[q], pw[q]);
+          __syncthreads();
+        }
+      }
+    }
+  } else {
   load_idx_next(0);
   advance_idx();
   load_idx_next(1);
@@ -248,6 +360,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
     }
     __syncthreads();
   }
+  }
   // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + r
   const int li = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -269,13 +382,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
     }
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool WK, int BK = 64>
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool WK, int BK = 64, int PF = 1>
 static int launch_igemm_fwd(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev,
                             int n_out_cap, int cin, int cout, int kvol, hipStream_t s, const float* bias = nullptr, int relu = 0) {
   constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
   constexpr int LDA = BK + 8, LDW = WK ? BN + 16 : BK + 8;
-  constexpr size_t lds = 2 * (size_t)(BM * LDA + (WK ? BK * LDW : BN * LDW)) * 2;
-  auto kern = k_igemm_fwd<WAVES_M, WAVES_N, WM, WN, WK, BK>;
+  if (PF > 1 && (kvol * u3d_cdiv(cin, BK)) % PF != 0)      // the deep-prefetch loop is unrolled PF times without a tail
+    return launch_igemm_fwd<WAVES_M, WAVES_N, WM, WN, WK, BK, 1>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, bias, relu);
+  const size_t lds = 2 * (size_t)(BM * LDA + (WK ? BK * LDW : BN * LDW)) * 2 +
+                     (PF > 1 ? (size_t)kvol * BM * 4 + (size_t)WAVES_M * WAVES_N * 64 * 16 : 0);   // + the tile's neighbour table + scratch
+  auto kern = k_igemm_fwd<WAVES_M, WAVES_N, WM, WN, WK, BK, PF>;
   if (lds > 64 * 1024) U3D_ALLOW_LDS(kern, lds);      // one call site per template instantiation: per-kernel, per-device
   dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev,
@@ -1183,14 +1299,22 @@ extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32
                        n_out_cap, kvol);
     return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
   }
+#if IGEMM_DIRECT
+  // 16/32/64-channel sparse levels with 27 offsets (not 64 -> 64): activations gathered straight into the MFMA operand registers,
+  // all weights LDS-resident, persistent barrier-free waves (igemm_direct.hip)
+  {
+    const int rc = u3d_launch_igemm_direct(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, transpose_w, s);
+    if (rc != U3D_ERR_UNSUPPORTED) return rc;
+  }
+#endif
 #if IGEMM_SMALL_C
   // 16/32-channel sparse levels (and the 32<->64 transitions): 256-row tiles, one MFMA k-step per stage (BK = 32), the same
   // register-staged, software-pipelined loop as the wide layers - the first-generation kernel it replaces does
   // "indices -> barrier -> gather -> barrier -> MFMA -> barrier" per offset with nothing in flight across the barriers
   if (n_out_cap > 0 && cin % 16 == 0 && cout % 16 == 0 && cin <= 64 && cout <= 64 && (cin < 64 || cout < 64)) {
-#define IG_SMALL(WNV, BKV)                                                                                                          \
-    return transpose_w ? launch_igemm_fwd<4, 1, 4, WNV, false, BKV>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s)   \
-                       : launch_igemm_fwd<4, 1, 4, WNV, true, BKV>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
+#define IG_SMALL(WNV, BKV)                                                                                                                          \
+    return transpose_w ? launch_igemm_fwd<4, 1, IGEMM_SMALL_WM, WNV, false, BKV, IGEMM_SMALL_PF>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s)   \
+                       : launch_igemm_fwd<4, 1, IGEMM_SMALL_WM, WNV, true, BKV, IGEMM_SMALL_PF>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
     // (cin = 64 -> cout 32/16, the dgrad of the 32->64 transition, measured slower here than on the first-generation kernel: 212 vs 170 us)
     if (cin == 16 || cin == 32) {
       if (cout == 16) { IG_SMALL(1, 32) }

@@ -122,7 +122,11 @@ class _SparseConv(torch.autograd.Function):
         bf16 = feats.dtype == torch.bfloat16
         kio_shape = weight.shape if layout == "dhwio" else tuple(weight.shape[i] for i in (2, 3, 4, 1, 0))
         cin, cout = kio_shape[3], kio_shape[4]
-        nmajor = NMAJOR_FWD and bf16 and cin % 64 == 0 and cout % 64 == 0
+        # n-major forward weights: the LDS-DMA kernels (channels % 64) and the direct-operand kernel of the narrow 27-offset levels
+        # (igemm_direct.hip stages [K][Cout][Cin] rows as they are; the k-major layout costs it a transposing prologue)
+        kv = kio_shape[0] * kio_shape[1] * kio_shape[2]
+        narrow = kv == 27 and cin in (16, 32, 64) and cout in (16, 32, 64) and not (cin == 64 and cout == 64)
+        nmajor = NMAJOR_FWD and bf16 and ((cin % 64 == 0 and cout % 64 == 0) or narrow)
         kio, koi = conv_weights(weight, layout, feats.dtype, want_koi=nmajor)
         ctx.geom, ctx.layout = geom, layout
         ctx.save_for_backward(feats, kio)
