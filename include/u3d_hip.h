@@ -34,6 +34,14 @@ enum { U3D_F32 = 0, U3D_BF16 = 1 };
 int32_t u3d_version(void);
 const char* u3d_strerror(int32_t code);
 
+/* Measurement helpers (bench.py's roofline block): HIP events on the stream the kernels run on.  external != 0 records with
+ * hipEventRecordExternal: inside a stream capture the record becomes an event-record NODE of the graph, so a pair of them brackets
+ * one kernel as it runs inside every replay (elapsed time read after the replay).  Not part of the reference's interface. */
+int32_t u3d_event_create(void** event);
+int32_t u3d_event_record(void* event, int32_t external, u3d_stream s);
+int32_t u3d_event_elapsed_ms(void* start, void* stop, float* ms);     /* both events must have completed */
+int32_t u3d_event_destroy(void* event);
+
 /* ------------------------------------------------------------------------------------------------
  * Occupancy lattice ("BitGrid").  One 64-bit word per 4x4x4 block of cells, bit = (z&3)*16+(y&3)*4+(x&3),
  * word = ((b*bz + z/4)*by + y/4)*bx + x/4 with bz=ceil(dz/4) etc.  `prefix` = exclusive popcount scan

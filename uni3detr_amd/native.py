@@ -64,6 +64,10 @@ _SIGS = {
     # name: (restype, argtypes)
     "u3d_version": (_I, []),
     "u3d_strerror": (C.c_char_p, [_I]),
+    "u3d_event_create": (_I, [C.POINTER(C.c_void_p)]),
+    "u3d_event_record": (_I, [C.c_void_p, _I, _P]),
+    "u3d_event_elapsed_ms": (_I, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "u3d_event_destroy": (_I, [C.c_void_p]),
     "u3d_bitgrid_nwords": (_L, [_I, _I, _I, _I]),
     "u3d_bitgrid_nwords_layout": (_L, [_I, _I, _I, _I, _I]),
     "u3d_voxelize_dynamic": (_I, [_P, _P, _I, _I, _I, _F3, _F6, _P, _P]),
@@ -300,25 +304,72 @@ def scatter_mean(points, rank, n_voxels):
 # --------------------------------------------------------------------------------------------------
 # sparse conv / BN / dense
 # --------------------------------------------------------------------------------------------------
+class ExternalEvent:
+    """HIP event recorded with hipEventRecordExternal on torch's current stream (torch.cuda.Event(external=True) is refused on
+    ROCm builds): inside a capture it becomes an event-record node of the graph."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        _check(lib().u3d_event_create(C.byref(h)), "event_create")
+        self.h = h
+
+    def record(self):
+        _check(lib().u3d_event_record(self.h, 1, _stream()), "event_record")
+
+    def elapsed_time(self, other):
+        ms = C.c_float()
+        _check(lib().u3d_event_elapsed_ms(self.h, other.h, C.byref(ms)), "event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            lib().u3d_event_destroy(self.h)
+        except Exception:
+            pass
+
+
 class KernelTimer:
     """HIP-event timing of individual launches on the stream they run on (used by bench.py for the roofline block).
     mode 'census': also counts the valid rulebook pairs P of each call (host sync) to price its algorithmic bytes:
     N_in*Cin*s + N_out*Cout*s + 8*P + K*Cin*Cout*s."""
 
-    def __init__(self, mode="time"):
+    def __init__(self, mode="time", targets=(), per_step=0):
+        """mode 'mark': only the calls whose index within the step (call counter modulo `per_step`) is in `targets` get events,
+        and those are EXTERNAL events (hipEventRecordExternal): recorded inside a hipGraph capture they become event-record nodes
+        of the graph, so after a replay `marks[i]` times that launch as it ran INSIDE the replayed step."""
         self.mode, self.calls, self.census = mode, [], []
+        self.targets, self.per_step, self.counter, self.marks = set(targets), per_step, 0, {}
 
     def begin(self):
+        if self.mode == "mark":
+            i = self.counter % self.per_step if self.per_step else self.counter
+            self.counter += 1
+            if i not in self.targets:
+                return None
+            e = ExternalEvent()
+            e.record()
+            return (i, e)
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         return e
 
     def end(self, tag, e0, meta=None):
+        if self.mode == "mark":
+            if e0 is not None:
+                e1 = ExternalEvent()
+                e1.record()
+                self.marks[e0[0]] = (tag, e0[1], e1)          # the latest recording wins: the captured one
+            return
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         self.calls.append((tag, e0, e1))
         if self.mode == "census":
             self.census.append((tag, meta))
+
+    def mark_durations_ms(self):
+        """{index: ms} of the marked launches in the most recent (replayed) step."""
+        torch.cuda.synchronize()
+        return {i: a.elapsed_time(b) for i, (t, a, b) in self.marks.items()}
 
     def durations_ms(self):
         torch.cuda.synchronize()
