@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, overlap):
+def _worker(rank, world, port, q, overlap, backend="gloo"):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         import projects.mmdet3d_plugin  # noqa: F401
@@ -31,8 +31,9 @@ def _worker(rank, world, port, q, overlap):
         from uni3detr_amd.registry import build_model
         from uni3detr_amd.synth import room_scene
         from uni3detr_amd.trainer import TrainStep
-        dev = torch.device("cuda:0")
-        torch.cuda.set_device(0)
+        # gloo: both ranks share GPU 0 (collectives staged through the host); nccl (= RCCL): one GPU per rank, as the driver launches it
+        dev = torch.device("cuda", rank if backend == "nccl" else 0)
+        torch.cuda.set_device(dev)
         torch.manual_seed(100 + rank)                       # DIFFERENT initial weights per rank: enable_dist() must overwrite them
         model = build_model(copy.deepcopy(MODEL_CFG)).to(dev).train().set_precision("bf16")
         pts, gts, labels = [], [], []
@@ -46,7 +47,10 @@ def _worker(rank, world, port, q, overlap):
         snap = ts.snapshot()
         ts.capture()
         ts.restore(snap)
-        dist.init_process_group("gloo", rank=rank, world_size=world)          # after the captures, as bench.py does
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)      # after the captures, as bench.py does
         ts.enable_dist()
         assert ts.dist_on and ts.world == world
         p0 = torch.cat([p.detach().float().reshape(-1) for p in model.parameters()])
@@ -88,3 +92,24 @@ def test_world2_graph_step_keeps_ranks_identical(cuda, overlap):
         assert moved > 0.0                                   # the optimizer stepped
     assert out[0][2] != out[1][2]                            # different scenes -> different local losses ...
     # ... but one shared model: rank 0's and rank 1's parameters were compared bit for bit inside the workers
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: runs on a >= 2-GPU node only")
+def test_world2_rccl_graph_step_keeps_ranks_identical(cuda):
+    """The same flow over RCCL (backend 'nccl'), one process per GPU - what `bench.py --gpus 2` does under torch.distributed.run."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    env = dict(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(env)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, True, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    out.sort()
+    for rank, ok, losses, moved, finite in out:
+        assert ok and finite, (rank, losses)
+        assert moved > 0.0
+    assert out[0][2] != out[1][2]
