@@ -1,0 +1,184 @@
+"""On-device data path through the C ABI vs oracle/datapath.py: flip / rotate / scale of points and boxes,
+PointsRangeFilter, PointSample, and the shipped SUN RGB-D train pipeline end to end (ref: uni3detr_sunrgbd.py:150-174)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import datapath as od
+
+pytestmark = pytest.mark.gpu
+
+RANGE = [-3.2, -0.2, -2.0, 3.2, 6.2, 0.56]
+
+
+def _scenes(rng, lens, feat=4, spread=4.0):
+    out = []
+    for n in lens:
+        p = (rng.random((n, feat)).astype(np.float32) - 0.5) * 2 * spread
+        p[:, 1] += 3.0
+        out.append(p)
+    return out
+
+
+def _boxes(rng, counts, dim=7):
+    out = []
+    for g in counts:
+        b = rng.random((g, dim)).astype(np.float32)
+        b[:, :3] = (b[:, :3] - 0.5) * 6
+        b[:, 3:6] = 0.3 + b[:, 3:6] * 2
+        b[:, 6] = (b[:, 6] - 0.5) * 2 * np.pi
+        out.append(b)
+    return out
+
+
+@pytest.mark.parametrize("coord", [od.DEPTH, od.LIDAR])
+@pytest.mark.parametrize("dim", [7, 9])
+def test_augment_points_and_boxes_match_oracle(cuda, coord, dim):
+    from uni3detr_amd import datapath as dp
+    from uni3detr_amd import native as nv
+    rng = np.random.default_rng(5 + coord + dim)
+    lens, gcounts = [1500, 0, 37, 4096, 1], [3, 0, 1, 12, 0]          # ragged, an empty scene, a one-point scene, scenes without boxes
+    pts, boxes = _scenes(rng, lens), _boxes(rng, gcounts, dim)
+    B = len(lens)
+    fh = np.array([1, 0, 1, 0, 1], bool)
+    fv = np.array([0, 1, 1, 0, 0], bool)
+    ang = rng.uniform(-0.5236, 0.5236, B).astype(np.float32)
+    sc = rng.uniform(0.85, 1.15, B).astype(np.float32)
+    batch = dp.pack_batch([torch.from_numpy(p).cuda() for p in pts], [torch.from_numpy(b).cuda() for b in boxes],
+                          box_type_3d="LiDAR" if coord == od.LIDAR else "Depth")
+    tab = np.stack([fh, fv, np.sin(ang), np.cos(ang), ang, sc], 1).astype(np.float32)
+    tab = torch.from_numpy(tab).cuda()
+    nv.points_augment(batch["points"], batch["scene_off"], tab, coord, 3)
+    nv.boxes_augment(batch["gt_bboxes_3d"], batch["gt_off"], tab, coord)
+    got_p, got_b = batch["points"].cpu().numpy(), batch["gt_bboxes_3d"].cpu().numpy()
+    exp_p = np.concatenate([od.augment_points(p, fh[i], fv[i], ang[i], sc[i], coord, 3) for i, p in enumerate(pts)])
+    exp_b = np.concatenate([od.augment_boxes(b, fh[i], fv[i], ang[i], sc[i], coord) for i, b in enumerate(boxes)])
+    # f32 elementwise arithmetic on both sides; the device may contract a*b+c into an fma: 1 ulp of a coordinate of size <= 10
+    np.testing.assert_allclose(got_p, exp_p, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(got_b, exp_b, rtol=0, atol=2e-6)
+
+
+def test_range_filter_is_order_preserving_and_strict(cuda):
+    from uni3detr_amd import datapath as dp
+    from uni3detr_amd import native as nv
+    rng = np.random.default_rng(11)
+    lens = [5000, 0, 1023, 1024, 1025, 3, 20000]
+    pts = _scenes(rng, lens)
+    pts[5][:] = 100.0                                   # a scene that loses every point
+    pts[0][7, 0] = RANGE[0]                             # exactly on the lower bound: dropped (strict)
+    pts[0][8, 2] = RANGE[5]                             # exactly on the upper bound: dropped
+    pts[0][9, 1] = np.nan                               # NaN compares false: dropped
+    batch = dp.pack_batch([torch.from_numpy(p).cuda() for p in pts])
+    src = batch["points"].clone()
+    out, count = nv.points_range_filter(src, batch["scene_off"], RANGE)
+    off = batch["scene_off"].cpu().numpy()
+    for i, p in enumerate(pts):
+        exp = od.range_filter(p, RANGE)
+        assert int(count[i]) == len(exp)
+        np.testing.assert_array_equal(out[off[i]:off[i] + len(exp)].cpu().numpy(), exp)
+    # in place (out aliases the input): same result
+    out2, count2 = nv.points_range_filter(src, batch["scene_off"], RANGE, out=src)
+    assert torch.equal(count, count2)
+    for i in range(len(lens)):
+        n = int(count[i])
+        assert torch.equal(out2[off[i]:off[i] + n], out[off[i]:off[i] + n])
+
+
+def test_point_sample_distinct_rows_replacement_and_empty(cuda):
+    from uni3detr_amd import datapath as dp
+    from uni3detr_amd import native as nv
+    rng = np.random.default_rng(3)
+    lens = [5000, 300, 0, 1000, 1001]
+    pts = _scenes(rng, lens, feat=6)
+    batch = dp.pack_batch([torch.from_numpy(p).cuda() for p in pts])
+    count = torch.tensor([4000, 300, 0, 1000, 1001], dtype=torch.int32, device="cuda")      # scene 0: only the first 4000 rows are live
+    seed = torch.tensor([12345], dtype=torch.int64, device="cuda")
+    num = 1000
+    out, idx = nv.point_sample(batch["points"], batch["scene_off"], count, num, seed, want_idx=True)
+    out, idx = out.cpu().numpy().reshape(len(lens), num, 6), idx.cpu().numpy().reshape(len(lens), num)
+    for b, n in enumerate([4000, 300, 0, 1000, 1001]):
+        if n == 0:
+            assert (idx[b] == -1).all() and (out[b] == 0).all()
+            continue
+        assert idx[b].min() >= 0 and idx[b].max() < n
+        np.testing.assert_array_equal(out[b], pts[b][idx[b]])
+        if n >= num:
+            assert len(np.unique(idx[b])) == num                # without replacement
+        else:
+            assert len(np.unique(idx[b])) < num                 # with replacement (1000 draws from 300)
+    assert sorted(idx[3]) == list(range(1000))                  # n == num_points: a permutation
+    # another seed, another sample; the same seed, the same sample
+    seed2 = torch.tensor([12346], dtype=torch.int64, device="cuda")
+    _, idx2 = nv.point_sample(batch["points"], batch["scene_off"], count, num, seed2, want_idx=True)
+    _, idx3 = nv.point_sample(batch["points"], batch["scene_off"], count, num, seed, want_idx=True)
+    assert not np.array_equal(idx2.cpu().numpy().reshape(len(lens), num)[0], idx[0])
+    assert np.array_equal(idx3.cpu().numpy().reshape(len(lens), num), idx)
+    # every row is (about) equally likely: 4000 rows, 1000 picks, 400 seeds -> expected 100 hits per row
+    hits = np.zeros(4000)
+    for s in range(400):
+        sd = torch.tensor([1000 + s], dtype=torch.int64, device="cuda")
+        _, ii = nv.point_sample(batch["points"], batch["scene_off"], count, num, sd, want_idx=True)
+        hits += np.bincount(ii[:num].cpu().numpy(), minlength=4000)
+    assert hits.min() > 55 and hits.max() < 150 and abs(hits.mean() - 100) < 1e-9      # binomial(400, 0.25): sd 8.7
+
+
+def test_shipped_sunrgbd_train_pipeline_end_to_end(cuda):
+    """The device half of uni3detr_sunrgbd.py:150-174 with recorded draws == the oracle chain, scene by scene."""
+    from uni3detr_amd import datapath as dp
+    rng = np.random.default_rng(21)
+    point_cloud_range = RANGE
+    train_pipeline = [
+        dict(type="LoadPointsFromFile", coord_type="DEPTH", shift_height=True, load_dim=6, use_dim=[0, 1, 2]),
+        dict(type="LoadAnnotations3D"),
+        dict(type="RandomFlip3D", sync_2d=False, flip_ratio_bev_horizontal=0.5),
+        dict(type="GlobalRotScaleTrans", rot_range=[-0.523599, 0.523599], scale_ratio_range=[0.85, 1.15], shift_height=True),
+        dict(type="PointsRangeFilter", point_cloud_range=point_cloud_range),
+        dict(type="PointSample", num_points=2000),
+        dict(type="DefaultFormatBundle3D", class_names=["bed"]),
+        dict(type="Collect3D", keys=["points", "gt_bboxes_3d", "gt_labels_3d"]),
+    ]
+    pipe = dp.DevicePipeline(train_pipeline)
+    assert [type(t).__name__ for t in pipe.transforms] == ["RandomFlip3D", "GlobalRotScaleTrans", "PointsRangeFilter", "PointSample"]
+    lens, gcounts = [6000, 2500, 900], [4, 0, 2]
+    pts, boxes = _scenes(rng, lens), _boxes(rng, gcounts)
+    batch = dp.pack_batch([torch.from_numpy(p).cuda() for p in pts], [torch.from_numpy(b).cuda() for b in boxes])
+    np.random.seed(77)
+    batch = pipe(batch)
+    fh, ang, sc = batch["pcd_horizontal_flip"], batch["pcd_rotation_angle"], batch["pcd_scale_factor"]
+    assert not np.asarray(batch["pcd_vertical_flip"]).any() and np.all(np.abs(ang) <= 0.523599) and np.all((sc >= 0.85) & (sc <= 1.15))
+    got = batch["points"].cpu().numpy().reshape(3, 2000, 4)
+    gb = batch["gt_bboxes_3d"].cpu().numpy()
+    exp_b = np.concatenate([od.augment_boxes(b, fh[i], False, ang[i], sc[i], od.DEPTH) for i, b in enumerate(boxes)])
+    np.testing.assert_allclose(gb, exp_b, rtol=0, atol=2e-6)
+    for i, p in enumerate(pts):
+        kept = od.range_filter(od.augment_points(p, fh[i], False, ang[i], sc[i], od.DEPTH, 3), point_cloud_range)
+        # every sampled row is one of the scene's surviving augmented rows (the device and numpy draw different samples)
+        keys = {r.tobytes() for r in np.round(kept, 5)}
+        rows = np.round(got[i], 5)
+        # rounding at 1e-5 against the 2e-6 arithmetic tolerance: compare through nearest neighbours instead of hashing when it misses
+        miss = [r for r in rows if r.tobytes() not in keys]
+        for r in miss[:50]:
+            assert np.abs(kept - r).max(1).min() < 2e-5
+        assert len(miss) < len(rows) // 2
+        if len(kept) >= 2000:
+            assert len(np.unique(got[i], axis=0)) == 2000
+    assert batch["scene_off"].tolist() == [0, 2000, 4000, 6000]
+    m = batch["uni_rot_aug"][0]
+    np.testing.assert_allclose(m, od.uni_rot_aug(fh[0], False, ang[0], sc[0]), atol=1e-6)
+
+
+def test_full_size_batch_properties(cuda):
+    """8 scenes x 100 000 points (the config's PointSample size): counts equal the oracle's, every output row lies inside the range."""
+    from uni3detr_amd import datapath as dp
+    from uni3detr_amd import native as nv
+    rng = np.random.default_rng(2)
+    pts = _scenes(rng, [100000] * 8, feat=4, spread=3.6)
+    batch = dp.pack_batch([torch.from_numpy(p).cuda() for p in pts])
+    out, count = nv.points_range_filter(batch["points"], batch["scene_off"], RANGE)
+    exp = [len(od.range_filter(p, RANGE)) for p in pts]
+    assert count.tolist() == exp
+    seed = torch.tensor([9], dtype=torch.int64, device="cuda")
+    s = nv.point_sample(out, batch["scene_off"], count, 20000, seed).cpu().numpy()
+    lo, hi = np.array(RANGE[:3], np.float32), np.array(RANGE[3:], np.float32)
+    assert s.shape == (160000, 4) and (s[:, :3] > lo).all() and (s[:, :3] < hi).all()
+    assert len(np.unique(s[:20000], axis=0)) == 20000

@@ -257,3 +257,61 @@ def test_oracle_head_matches_reference_golden_for_other_head_shapes(name):
             losses, _ = om.head_loss(cls, box, iou, gts, labels, cfg)
         for k, v in zip(z[name + "_loss_names"], z[name + "_loss_values"]):
             assert abs(float(losses[str(k)]) - v) <= 1e-4 * max(1.0, abs(v)), (k, float(losses[str(k)]), v)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# data-path oracle: pinned to what transform_3d.py writes out itself
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_datapath_oracle_matches_the_matrices_the_reference_writes():
+    """ref transform_3d.py:380-383 (rot_mat_T, mmdet3d >= 1.0 branch), :429-431 (uni_scale_mat), :571-580 (flip_mat), :461-464 and
+    :564-567 (composition): for LiDAR coordinates the augmented xyz is xyz @ uni_rot_aug."""
+    from oracle import datapath as od
+    rng = np.random.default_rng(0)
+    p = rng.normal(size=(200, 4)).astype(np.float32)
+    a = 0.3
+    assert np.allclose(od.rot_mat_T(a), [[np.cos(a), np.sin(a), 0], [-np.sin(a), np.cos(a), 0], [0, 0, 1]], atol=1e-7)
+    assert np.array_equal(od.flip_mat(True, False), np.diag([1, -1, 1]).astype(np.float32))
+    assert np.array_equal(od.flip_mat(False, True), np.diag([-1, 1, 1]).astype(np.float32))
+    for fh, fv, ang, sc in [(0, 0, 0.3, 1.1), (1, 0, -0.4, 0.9), (0, 1, 0.2, 1.0), (1, 1, 0.5236, 1.15)]:
+        got = od.augment_points(p, fh, fv, ang, sc, od.LIDAR, 3)
+        assert np.allclose(got[:, :3], p[:, :3] @ od.uni_rot_aug(fh, fv, ang, sc), atol=2e-6)
+        assert np.allclose(got[:, 3], p[:, 3] * np.float32(sc))            # shift_height: the height attribute scales
+
+
+def _bev_corners(b):
+    c, s = np.cos(b[6]), np.sin(b[6])
+    out = []
+    for sx, sy in ((-0.5, -0.5), (0.5, -0.5), (0.5, 0.5), (-0.5, 0.5)):
+        x, y = sx * b[3], sy * b[4]
+        out.append((b[0] + x * c - y * s, b[1] + x * s + y * c))
+    return np.array(sorted(out))
+
+
+def test_datapath_oracle_boxes_move_with_their_corner_points():
+    """Self-consistency that fixes the yaw conventions: the BEV corners of the augmented box are the augmented corners of the box
+    (as a set: a mirror reverses their order), in both coordinate systems, for every flip combination."""
+    from oracle import datapath as od
+    rng = np.random.default_rng(1)
+    for coord in (od.DEPTH, od.LIDAR):
+        for fh in (0, 1):
+            for fv in (0, 1):
+                b = np.array([[1.0, -2.0, 0.3, 2.0, 0.8, 1.1, 0.7]], np.float32)
+                ang, sc = float(rng.uniform(-0.5, 0.5)), float(rng.uniform(0.85, 1.15))
+                nb = od.augment_boxes(b, fh, fv, ang, sc, coord)[0]
+                corners = _bev_corners(b[0])
+                pts = np.concatenate([corners, np.zeros((4, 1))], 1).astype(np.float32)
+                moved = od.augment_points(pts, fh, fv, ang, sc, coord)[:, :2]
+                assert np.allclose(_bev_corners(nb), np.array(sorted(map(tuple, moved))), atol=1e-5), (coord, fh, fv)
+                assert np.allclose(nb[3:6], b[0, 3:6] * np.float32(sc)) and np.isclose(nb[2], b[0, 2] * np.float32(sc))
+
+
+def test_datapath_oracle_filter_and_sample():
+    from oracle import datapath as od
+    p = np.array([[0, 0, 0, 1], [-3.2, 0, 0, 2], [1, 1, 0.56, 3], [1, 1, 0.5, 4], [np.nan, 0, 0, 5]], np.float32)
+    kept = od.range_filter(p, [-3.2, -0.2, -2.0, 3.2, 6.2, 0.56])
+    assert kept[:, 3].tolist() == [1.0, 4.0]                                # strict bounds, NaN dropped, order kept
+    rng = np.random.default_rng(0)
+    s, idx = od.point_sample(kept, 5, rng)
+    assert s.shape == (5, 4) and set(idx) <= {0, 1}                         # n < num_points: with replacement
+    s, idx = od.point_sample(np.arange(40, dtype=np.float32).reshape(10, 4), 6, rng)
+    assert len(set(idx)) == 6                                               # n >= num_points: without replacement

@@ -64,6 +64,10 @@ _SIGS = {
     # name: (restype, argtypes)
     "u3d_version": (_I, []),
     "u3d_strerror": (C.c_char_p, [_I]),
+    "u3d_points_augment": (_I, [_P, _P, _I, _I, _I, _P, _I, _I, _P]),
+    "u3d_boxes_augment": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
+    "u3d_points_range_filter": (_I, [_P, _P, _I, _I, C.POINTER(C.c_float), _P, _P, _P]),
+    "u3d_point_sample": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "u3d_event_create": (_I, [C.POINTER(C.c_void_p)]),
     "u3d_event_record": (_I, [C.c_void_p, _I, _P]),
     "u3d_event_elapsed_ms": (_I, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
@@ -1020,3 +1024,49 @@ def dropout_mask(rng, layer, site, n, p):
     keep = torch.empty((n,), dtype=torch.uint8, device=rng.device)
     _check(lib().u3d_dropout_mask(_ptr(rng), layer, site, n, p, _ptr(keep), _stream()), "dropout_mask")
     return keep
+
+
+# --------------------------------------------------------------------------------------------------
+# on-device data path
+# --------------------------------------------------------------------------------------------------
+AUG_NPARAM = 6
+
+
+def points_augment(points, scene_off, params, coord, height_dim=-1):
+    """In place on points [N,F] f32: per-scene flip -> rotation -> scale; params f32 [B,6] (flip_h, flip_v, sin, cos, angle, scale)."""
+    assert points.dtype == torch.float32 and points.is_contiguous() and params.dtype == torch.float32 and params.shape[1] == AUG_NPARAM
+    batch = scene_off.numel() - 1
+    _check(lib().u3d_points_augment(_ptr(points), _ptr(scene_off), batch, points.shape[0], points.shape[1], _ptr(params.contiguous()),
+                                    int(coord), int(height_dim), _stream()), "points_augment")
+    return points
+
+
+def boxes_augment(boxes, gt_off, params, coord):
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.shape[1] in (7, 9)
+    batch = gt_off.numel() - 1
+    _check(lib().u3d_boxes_augment(_ptr(boxes), _ptr(gt_off), batch, boxes.shape[0], boxes.shape[1], _ptr(params.contiguous()), int(coord),
+                                   _stream()), "boxes_augment")
+    return boxes
+
+
+def points_range_filter(points, scene_off, pc_range, out=None):
+    """-> (out [N,F] with every scene's survivors compacted to the front of its segment, count int32 [B])."""
+    assert points.dtype == torch.float32 and points.is_contiguous()
+    batch = scene_off.numel() - 1
+    out = torch.empty_like(points) if out is None else out
+    count = torch.empty((batch,), dtype=torch.int32, device=points.device)
+    rng = (C.c_float * 6)(*[float(v) for v in pc_range])
+    _check(lib().u3d_points_range_filter(_ptr(points), _ptr(scene_off), batch, points.shape[1], rng, _ptr(out), _ptr(count), _stream()),
+           "points_range_filter")
+    return out, count
+
+
+def point_sample(points, scene_off, count, num_points, seed, want_idx=False):
+    """-> out [B*num_points, F] (+ idx int32 [B*num_points]); seed: device int64/uint64 tensor with one element."""
+    assert points.dtype == torch.float32 and points.is_contiguous() and seed.numel() == 1 and seed.element_size() == 8
+    batch = scene_off.numel() - 1
+    out = torch.empty((batch * num_points, points.shape[1]), dtype=torch.float32, device=points.device)
+    idx = torch.empty((batch * num_points,), dtype=torch.int32, device=points.device) if want_idx else None
+    _check(lib().u3d_point_sample(_ptr(points), _ptr(scene_off), _ptr(count), batch, points.shape[1], int(num_points), _ptr(seed), _ptr(out),
+                                  _ptr(idx), _stream()), "point_sample")
+    return (out, idx) if want_idx else out
