@@ -1865,7 +1865,18 @@ static WgPlan wgrad_plan(int n_out_cap, int cin, int cout, int kvol) {
   return p;
 }
 
+#ifndef IGEMM_WGRAD_NARROW
+#define IGEMM_WGRAD_NARROW 1   /* 16/32-channel 27-offset weight gradients on wgrad_narrow.hip (0: the tiled kernels below) */
+#endif
+bool u3d_wgrad_narrow_shape(int cin, int cout, int kvol);
+int64_t u3d_wgrad_narrow_workspace(int n_out_cap, int cin, int cout);
+int u3d_launch_wgrad_narrow(const void* in, const void* dout, const int32_t* nbr, int ld, float* dw, const int32_t* n_out_dev, int n_out_cap,
+                            int cin, int cout, int kvol, int out_oik, void* workspace, int64_t workspace_bytes, hipStream_t s);
+
 extern "C" int64_t u3d_igemm_wgrad_bf16_workspace(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol) {
+#if IGEMM_WGRAD_NARROW
+  if (u3d_wgrad_narrow_shape(cin, cout, kvol)) return u3d_wgrad_narrow_workspace(n_out_cap, cin, cout);
+#endif
   if (convin_shape(cin, cout, kvol)) return (int64_t)u3d_cdiv(n_out_cap > 0 ? n_out_cap : 1, CONVIN_WG_ROWS) * kvol * cin * cout * 4;
   WgPlan p = wgrad_plan(n_out_cap, cin, cout, kvol);
   return (int64_t)p.nsplit * kvol * cin * cout * 4;
@@ -1921,6 +1932,12 @@ extern "C" int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const 
     return U3D_OK;
   }
   if (cin % 16 != 0 || cout % 16 != 0) return U3D_ERR_UNSUPPORTED;
+#if IGEMM_WGRAD_NARROW
+  if (nbr && u3d_wgrad_narrow_shape(cin, cout, kvol)) {
+    if (n_out_cap <= 0) { hipMemsetAsync(dw, 0, sizeof(float) * kvol * cin * cout, s); return U3D_OK; }
+    return u3d_launch_wgrad_narrow(in, dout, nbr, ld, dw, n_out_dev, n_out_cap, cin, cout, kvol, out_layout, workspace, workspace_bytes, s);
+  }
+#endif
   WgPlan p = wgrad_plan(n_out_cap, cin, cout, kvol);
   long long n = (long long)kvol * cin * cout;
   U3D_REQUIRE(workspace_bytes >= (int64_t)p.nsplit * n * 4, U3D_ERR_WORKSPACE);
