@@ -210,6 +210,10 @@ int32_t u3d_colsum_batched(const void* const* x, float* const* out, int32_t coun
  * [u3d_skinny_wgrad_chunks(m)][n*k]; the column sums over the chunks are dW [n][k] (u3d_colsum / u3d_colsum_batched). */
 int32_t u3d_skinny_wgrad_chunks(int32_t m);
 int32_t u3d_skinny_wgrad_bf16(const void* dy, const void* x, int32_t m, int32_t n, int32_t k, float* partial, u3d_stream s);
+/* `count` (<= 32) such products over the same m rows in one launch; dy / x / partial / n / k are HOST arrays of length count;
+ * dy_skinny != 0: every n[i] <= 32 (thread = column of x), else every k[i] <= 32 (thread = column of dy). */
+int32_t u3d_skinny_wgrad_batched(const void* const* dy, const void* const* x, float* const* partial, const int32_t* n, const int32_t* k,
+                                 int32_t count, int32_t m, int32_t dy_skinny, u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm1d over sparse rows [n, C] (training statistics) with optional residual add and ReLU

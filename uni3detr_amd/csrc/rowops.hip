@@ -996,8 +996,8 @@ extern "C" int32_t u3d_layernorm_bwd(const void* dy, int32_t y_dtype, const void
 #define SK_ROWS 32              /* rows per workgroup: 7200 rows -> 225 workgroups per column block (128 rows left 3/4 of the CUs idle) */
 #define SK_MAX 32
 template <bool DY_SKINNY>
-__global__ __launch_bounds__(256) void k_skinny_wgrad(const u16* __restrict__ dy, const u16* __restrict__ x, int m, int n, int k,
-                                                      float* __restrict__ partial) {
+__device__ __forceinline__ void skinny_wgrad_body(const u16* __restrict__ dy, const u16* __restrict__ x, int m, int n, int k,
+                                                  float* __restrict__ partial) {
   // DY_SKINNY: n <= SK_MAX, thread = column of x (k wide);  else k <= SK_MAX, thread = column of dy (n wide)
   const int wide = DY_SKINNY ? k : n, small = DY_SKINNY ? n : k;
   const int col = blockIdx.y * 256 + threadIdx.x;
@@ -1031,7 +1031,40 @@ __global__ __launch_bounds__(256) void k_skinny_wgrad(const u16* __restrict__ dy
       }
   }
 }
+template <bool DY_SKINNY>
+__global__ __launch_bounds__(256) void k_skinny_wgrad(const u16* __restrict__ dy, const u16* __restrict__ x, int m, int n, int k,
+                                                      float* __restrict__ partial) {
+  skinny_wgrad_body<DY_SKINNY>(dy, x, m, n, k, partial);
+}
+// `count` independent skinny products over the same m rows in ONE launch (blockIdx.z = product; operands arrive by value in the
+// kernel arguments: capturable as is).  The decoder's backward has 15 of them per step, 20-27 us each when launched one by one.
+#define SKB_MAX 32
+struct SkinnyBatch { const u16* dy[SKB_MAX]; const u16* x[SKB_MAX]; float* partial[SKB_MAX]; int n[SKB_MAX]; int k[SKB_MAX]; };
+template <bool DY_SKINNY>
+__global__ __launch_bounds__(256) void k_skinny_wgrad_b(SkinnyBatch bt, int m) {
+  const int b = blockIdx.z;
+  const int n = bt.n[b], k = bt.k[b];
+  if ((int)blockIdx.y * 256 >= (DY_SKINNY ? k : n)) return;          // the grid is sized for the widest product (uniform exit)
+  skinny_wgrad_body<DY_SKINNY>(bt.dy[b], bt.x[b], m, n, k, bt.partial[b]);
+}
 extern "C" int32_t u3d_skinny_wgrad_chunks(int32_t m) { return u3d_cdiv(m > 0 ? m : 1, SK_ROWS); }
+extern "C" int32_t u3d_skinny_wgrad_batched(const void* const* dy, const void* const* x, float* const* partial, const int32_t* n,
+                                            const int32_t* k, int32_t count, int32_t m, int32_t dy_skinny, u3d_stream s) {
+  U3D_REQUIRE(dy && x && partial && n && k && count > 0 && count <= SKB_MAX && m > 0, U3D_ERR_ARG);
+  SkinnyBatch bt;
+  int wide = 0;
+  for (int i = 0; i < count; ++i) {
+    U3D_REQUIRE(dy[i] && x[i] && partial[i] && n[i] > 0 && k[i] > 0 && (dy_skinny ? n[i] : k[i]) <= SK_MAX, U3D_ERR_ARG);
+    bt.dy[i] = (const u16*)dy[i]; bt.x[i] = (const u16*)x[i]; bt.partial[i] = partial[i]; bt.n[i] = n[i]; bt.k[i] = k[i];
+    const int w = dy_skinny ? k[i] : n[i];
+    if (w > wide) wide = w;
+  }
+  const dim3 grid(u3d_skinny_wgrad_chunks(m), u3d_cdiv(wide, 256), count);
+  if (dy_skinny) hipLaunchKernelGGL(k_skinny_wgrad_b<true>, grid, dim3(256), 0, s, bt, m);
+  else hipLaunchKernelGGL(k_skinny_wgrad_b<false>, grid, dim3(256), 0, s, bt, m);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
 extern "C" int32_t u3d_skinny_wgrad_bf16(const void* dy, const void* x, int32_t m, int32_t n, int32_t k, float* partial, u3d_stream s) {
   U3D_REQUIRE(dy && x && partial && m > 0 && n > 0 && k > 0, U3D_ERR_ARG);
   if (n > SK_MAX && k > SK_MAX) return U3D_ERR_UNSUPPORTED;

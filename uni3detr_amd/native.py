@@ -121,6 +121,7 @@ _SIGS = {
     "u3d_wgrad_batched_bf16": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _L, _P]),
     "u3d_skinny_wgrad_chunks": (_I, [_I]),
     "u3d_skinny_wgrad_bf16": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "u3d_skinny_wgrad_batched": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "u3d_colsum_batched_workspace": (_L, [_I, _I, _I]),
     "u3d_colsum_batched": (_I, [_P, _P, _I, _I, _I, _I, _P, _L, _P]),
     "u3d_layernorm_blocks": (_I, [_I]),
@@ -851,6 +852,24 @@ def skinny_wgrad_partial(dy2, x2):
     partial = torch.empty((chunks, n * k), dtype=torch.float32, device=dy2.device)
     _check(lib().u3d_skinny_wgrad_bf16(_ptr(dy2), _ptr(x2), m, n, k, _ptr(partial), _stream()), "skinny_wgrad_bf16")
     return partial
+
+
+def skinny_wgrad_partial_batched(dys, xs):
+    """The same for a list of (dy2 [m, n_i], x2 [m, k_i]) pairs over the same m rows: one launch per skinny side (<= 32 products each).
+    -> list of f32 [chunks, n_i*k_i] partials, in input order."""
+    m = dys[0].shape[0]
+    chunks = int(lib().u3d_skinny_wgrad_chunks(m))
+    outs = [torch.empty((chunks, d.shape[1] * x.shape[1]), dtype=torch.float32, device=d.device) for d, x in zip(dys, xs)]
+    for dy_skinny in (1, 0):
+        sel = [i for i, (d, x) in enumerate(zip(dys, xs)) if (d.shape[1] <= x.shape[1]) == bool(dy_skinny)]
+        for o in range(0, len(sel), 32):
+            ii = sel[o:o + 32]
+            n = (C.c_int32 * len(ii))(*[dys[i].shape[1] for i in ii])
+            k = (C.c_int32 * len(ii))(*[xs[i].shape[1] for i in ii])
+            _check(lib().u3d_skinny_wgrad_batched(_ptr_array([dys[i] for i in ii]), _ptr_array([xs[i] for i in ii]),
+                                                  _ptr_array([outs[i] for i in ii]), n, k, len(ii), m, dy_skinny, _stream()),
+                   "skinny_wgrad_batched")
+    return outs
 
 
 def cast_bf16(src, dst):

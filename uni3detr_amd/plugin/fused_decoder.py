@@ -304,12 +304,11 @@ class FusedLayerFn(torch.autograd.Function):
                 dw, db = new(n, k), new(n)
             single = _Deferred.uses.get(id(w), 0) == 1
             if i in _NARROW:
-                part = nv.skinny_wgrad_partial(dy, xin)
                 if deferred_ok and single:
-                    _Deferred.sum_items.append((part, w))
+                    _Deferred.skinny.append((dy, xin, w))        # the product itself waits for the flush: one launch for all layers
                     _Deferred.sum_items.append((dy, b))
                 else:
-                    sums_now += [(part, dw.view(-1)), (dy, db)]
+                    sums_now += [(nv.skinny_wgrad_partial(dy, xin), dw.view(-1)), (dy, db)]
             elif deferred_ok and single:
                 _Deferred.items.append((dy, xin, id(w), r0, r0 + rows_, True))
             else:
@@ -334,12 +333,12 @@ class FusedLayerFn(torch.autograd.Function):
         # attention_weights (256 -> 1) and the position encoder's first layer (3 -> 256): skinny products
         for dy, xin, mod in ((Gv("WL", 1), S("QP", 256), sp.attw), (Gv("P0", 256), ref.to(bf), sp.pe0)):
             dw, db = new(*mod.weight.shape), new(mod.bias.shape[0])
-            part = nv.skinny_wgrad_partial(dy, xin.contiguous())
             if deferred_ok and _Deferred.uses.get(id(mod.weight), 0) == 1:
                 _Deferred.params[id(mod.weight)] = (mod.weight, mod.bias)
-                _Deferred.sum_items += [(part, mod.weight), (dy, mod.bias)]
+                _Deferred.skinny.append((dy, xin.contiguous(), mod.weight))
+                _Deferred.sum_items.append((dy, mod.bias))
             else:
-                sums_now += [(part, dw.view(-1)), (dy, db)]
+                sums_now += [(nv.skinny_wgrad_partial(dy, xin.contiguous()), dw.view(-1)), (dy, db)]
             grads += [dw, db]
         for (n, k), lst in wgrad_now.items():
             nv.wgrad_batched([a for a, _, _ in lst], [b_ for _, b_, _ in lst], [c for _, _, c in lst])

@@ -114,6 +114,7 @@ class _Deferred:
     active = False
     items = []          # (dy2 [M,N], x2 [M,K], weight id, first row, last row, has_bias)
     sum_items = []      # (matrix [rows, C] f32, parameter): parameter.grad <- column sums
+    skinny = []         # (dy2 [M,n], x2 [M,k], weight) with min(n, k) <= 16: all products of a step in one launch per skinny side
     uses = {}           # id(weight) -> number of forward uses in this step
     params = {}         # id(weight) -> (weight, bias)
 
@@ -125,6 +126,14 @@ def reset_param_uses():
 def flush_deferred():
     items, _Deferred.items = _Deferred.items, []
     sums, _Deferred.sum_items = _Deferred.sum_items, []
+    skinny, _Deferred.skinny = _Deferred.skinny, []
+    if skinny:
+        by_m = {}
+        for it in skinny:
+            by_m.setdefault(it[0].shape[0], []).append(it)
+        for lst in by_m.values():
+            parts = nv.skinny_wgrad_partial_batched([d for d, _, _ in lst], [x for _, x, _ in lst])
+            sums = sums + [(p_, w_) for p_, (_, _, w_) in zip(parts, lst)]
     groups, bgroups = {}, {}
     for mat, param in sums:                   # column sums of a [rows, C] matrix into param.grad (LayerNorm dgamma / dbeta, skinny dW / db)
         if param.grad is None or param.grad.dtype != torch.float32 or not param.grad.is_contiguous() or param.grad.numel() != mat.shape[1]:
@@ -151,12 +160,12 @@ import contextlib as _contextlib
 @_contextlib.contextmanager
 def deferred_param_grads():
     prev = _Deferred.active
-    _Deferred.active, _Deferred.items, _Deferred.sum_items = True, [], []
+    _Deferred.active, _Deferred.items, _Deferred.sum_items, _Deferred.skinny = True, [], [], []
     try:
         yield
         flush_deferred()
     finally:
-        _Deferred.active, _Deferred.items, _Deferred.sum_items = prev, [], []
+        _Deferred.active, _Deferred.items, _Deferred.sum_items, _Deferred.skinny = prev, [], [], []
 
 
 def _linear_backward(dy2, x2, wc, need_dx, need_dw, need_db, xdtype, defer=None, dw_out=None, db_out=None):
