@@ -124,9 +124,12 @@ def reset_param_uses():
 
 
 def flush_deferred():
+    """Returns everything the launches read (operands of the queued products): a caller that runs the flush on a side stream keeps
+    it alive until the streams are joined."""
     items, _Deferred.items = _Deferred.items, []
     sums, _Deferred.sum_items = _Deferred.sum_items, []
     skinny, _Deferred.skinny = _Deferred.skinny, []
+    keep = (items, sums, skinny)
     if skinny:
         by_m = {}
         for it in skinny:
@@ -152,6 +155,7 @@ def flush_deferred():
         nv.wgrad_batched([a for a, _, _ in g], [b for _, b, _ in g], [c for _, _, c in g])
     for g in bgroups.values():
         nv.colsum_batched([a for a, _ in g], [b for _, b in g])
+    return keep
 
 
 import contextlib as _contextlib
