@@ -44,6 +44,11 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #ifndef DIR_WAVES_PER_SIMD
 #define DIR_WAVES_PER_SIMD 2
 #endif
+#ifndef DIR_SPLIT_64
+#define DIR_SPLIT_64 0    /* 1: 64 -> 64 layers as two 64 -> 32 launches.  Measured SLOWER on the 207 k-row level (17.5 of 27 neighbours
+                             exist there: 2 x 78 us against 73 us on the LDS-DMA tiled kernel - each half gathers all 64 input channels
+                             again and the level is bound by real L2 -> L1 bytes, not by empty slots) */
+#endif
 #ifndef DIR_SCHED_BARRIER
 #define DIR_SCHED_BARRIER 1 /* pin the step's three phases (LDS requests | MFMAs | gathers): hipcc otherwise sinks the requests to their uses */
 #endif
@@ -62,7 +67,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 //   * weight fragments and permuted indices are requested one offset ahead (LDS round trips are not hidden by two waves per SIMD).
 template <int KS, int WN, bool W_KMAJOR, int NW, int P>
 __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr, int ld,
-                                                  u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap, int cin, int cout) {
+                                                  u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap, int cin, int cout,
+                                                  int co0) {
+  // cout = channels of a row of `out` (and of the weight tensor); this launch computes the COUT = 16 * WN columns from co0 on
+  // (a 64 -> 64 layer is two launches of the 64 -> 32 kernel: the weights of 27 x 64 x 64 do not fit LDS, those of one half do)
   static_assert(DIR_K % P == 0, "operand register sets are indexed statically");
   constexpr int NT = NW * 64;
   constexpr int KP = KS * 32;                 // padded reduction length
@@ -166,10 +174,11 @@ __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, co
     wv_[j] = (u32x4){0u, 0u, 0u, 0u};
     if constexpr (W_KMAJOR) {                 // global [27][cin][cout]: 16-byte pieces along n
       const int kap = i / (KP * (COUT / 8)), r = i % (KP * (COUT / 8)), k = r / (COUT / 8), n0 = (r % (COUT / 8)) * 8;
-      if (i < TOTAL && k < cin) wv_[j] = *(const u32x4*)(w + ((long long)kap * cin + k) * cout + n0);
+      if (i < TOTAL && k < cin) wv_[j] = *(const u32x4*)(w + ((long long)kap * cin + k) * cout + co0 + n0);
     } else {                                  // global [27][cout][cin]: rows as they are
       const int row = i / (KP / 8), k0 = (i % (KP / 8)) * 8;
-      if (i < TOTAL && k0 < cin) wv_[j] = *(const u32x4*)(w + (long long)row * cin + k0);
+      const long long grow = (long long)(row / COUT) * cout + co0 + row % COUT;
+      if (i < TOTAL && k0 < cin) wv_[j] = *(const u32x4*)(w + grow * cin + k0);
     }
   }
   int mcur = row_mask(tile), mnxt = row_mask(tile + stride);
@@ -234,9 +243,9 @@ __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, co
 #pragma unroll
           for (int b = 0; b < WN; ++b) {
 #if !(defined(DIR_EXP) && (DIR_EXP & 8))                        /* timing experiment (wrong results): nothing stored except by the last tile */
-            if (m < n_out) *(bf16x4*)(out + (long long)m * cout + b * 16 + g * 4) = __builtin_convertvector(acc[a][b], bf16x4);
+            if (m < n_out) *(bf16x4*)(out + (long long)m * cout + co0 + b * 16 + g * 4) = __builtin_convertvector(acc[a][b], bf16x4);
 #else
-            if (m < n_out && tile + stride >= slab_end) *(bf16x4*)(out + (long long)m * cout + b * 16 + g * 4) = __builtin_convertvector(acc[a][b], bf16x4);
+            if (m < n_out && tile + stride >= slab_end) *(bf16x4*)(out + (long long)m * cout + co0 + b * 16 + g * 4) = __builtin_convertvector(acc[a][b], bf16x4);
 #endif
             acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
@@ -270,8 +279,8 @@ __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, co
 
 #define U3D_DIRECT_KERNEL(NAME, KS, WN, KM, NW, P)                                                                                    \
   __global__ __launch_bounds__(NW * 64, DIR_WAVES_PER_SIMD) void NAME(const u16* in, const u16* w, const int* nbr, int ld, u16* out, const int* n_out_dev, \
-                                                  int n_out_cap, int cin, int cout) {                                              \
-    igemm_direct_body<KS, WN, KM, NW, P>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout);                                          \
+                                                  int n_out_cap, int cin, int cout, int co0) {                                     \
+    igemm_direct_body<KS, WN, KM, NW, P>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, co0);                                     \
   }
 // name: k_igemm_direct_<cin_pad>x<cout>_<k|n>: k = weights [27][cin][cout] (forward), n = [27][cout][cin] (dgrad)
 U3D_DIRECT_KERNEL(k_igemm_direct_32x16_k, 1, 1, true, DIR_NW_A, DIR_P1)
@@ -285,14 +294,20 @@ U3D_DIRECT_KERNEL(k_igemm_direct_64x16_n, 2, 1, false, DIR_NW_A, DIR_P2)
 U3D_DIRECT_KERNEL(k_igemm_direct_64x32_k, 2, 2, true, DIR_NW_B, DIR_P2)
 U3D_DIRECT_KERNEL(k_igemm_direct_64x32_n, 2, 2, false, DIR_NW_B, DIR_P2)
 
-typedef void (*direct_kernel_t)(const u16*, const u16*, const int*, int, u16*, const int*, int, int, int);
+typedef void (*direct_kernel_t)(const u16*, const u16*, const int*, int, u16*, const int*, int, int, int, int);
 
 // 0 = launched, U3D_ERR_UNSUPPORTED = shape not served here (caller falls through to the tiled kernels)
 int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev, int n_out_cap,
                             int cin, int cout, int kvol, int transpose_w, hipStream_t s) {
-  if (kvol != DIR_K || !nbr || (cin != 16 && cin != 32 && cin != 64) || (cout != 16 && cout != 32 && cout != 64) || (cin == 64 && cout == 64))
+  if (kvol != DIR_K || !nbr || (cin != 16 && cin != 32 && cin != 64) || (cout != 16 && cout != 32 && cout != 64))
     return U3D_ERR_UNSUPPORTED;
+#if !DIR_SPLIT_64
+  if (cin == 64 && cout == 64) return U3D_ERR_UNSUPPORTED;
+#endif
   const int ks = cin > 32 ? 2 : 1, kp = ks * 32;
+  const int cout_total = cout;
+  const int halves = (cin == 64 && cout == 64) ? 2 : 1;          // 64 -> 64: two launches over 32 output columns each
+  if (halves == 2) cout = 32;
   const size_t lds = (size_t)DIR_K * cout * (kp + 8) * 2;
   if (lds > 160 * 1024) return U3D_ERR_UNSUPPORTED;
   direct_kernel_t kern = nullptr;
@@ -330,6 +345,8 @@ int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, i
   const int need = u3d_cdiv(ntiles, nw);
   if (grid > need) grid = need;
   grid = (grid + 7) / 8 * 8;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin, cout);
+  for (int h = 0; h < halves; ++h)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin,
+                       cout_total, h * 32);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
 }
