@@ -451,12 +451,17 @@ def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False, tag=None)
     return out
 
 
-def spconv_wgrad(inp, dout, nbr, n_out_dev, kvol, out_oik=False):
-    """-> f32 [K, Cin, Cout]; with out_oik (bf16 second-generation path only): [Cout, Cin, K] (nn.Conv3d's layout)."""
+def spconv_wgrad(inp, dout, nbr, n_out_dev, kvol, out_oik=False, out=None):
+    """-> f32 [K, Cin, Cout]; with out_oik (bf16 second-generation path only): [Cout, Cin, K] (nn.Conv3d's layout).
+    out: contiguous f32 tensor of kvol*cin*cout elements to write into (bf16 path) - returned viewed in the result's shape."""
     cin, cout, n_out = inp.shape[1], dout.shape[1], dout.shape[0]
     v2 = bool(inp.dtype == torch.bfloat16 and USE_IGEMM_V2 and cin % 16 == 0 and cout % 16 == 0)
     assert v2 or not out_oik, "out_oik needs the bf16 implicit-GEMM weight-gradient path"
-    dw = torch.empty((cout, cin, kvol) if out_oik else (kvol, cin, cout), dtype=torch.float32, device=inp.device)
+    shape = (cout, cin, kvol) if out_oik else (kvol, cin, cout)
+    if out is not None and v2 and out.is_contiguous() and out.dtype == torch.float32 and out.numel() == kvol * cin * cout:
+        dw = out.view(shape)
+    else:
+        dw = torch.empty(shape, dtype=torch.float32, device=inp.device)
     t = TIMER
     meta = None
     if t is not None and t.mode == "census":

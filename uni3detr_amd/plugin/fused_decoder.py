@@ -289,6 +289,14 @@ class FusedLayerFn(torch.autograd.Function):
         wgrad_now = {}              # (n, k) -> list of (dy, x, out)
         sums_now = []               # (matrix, out vector)
         new = lambda *shape: torch.empty(shape, dtype=f32, device=dev)
+
+        def slot(param, deferred):
+            """Gradient tensor handed to autograd for `param`: under TrainStep, when the value is written later by the flush (so
+            nothing else accumulates into it), the parameter's own slice of the flat gradient buffer - the step's packing copy then
+            has nothing to move for it; else a fresh tensor."""
+            v = getattr(param, "_u3d_grad_view", None) if deferred else None
+            # (a fresh alias: AccumulateGrad keeps an incoming tensor as .grad only if nobody else holds that tensor object)
+            return v.view(v.shape) if (v is not None and v.dtype == f32 and v.is_contiguous()) else new(*param.shape)
         inproj_dw = inproj_db = None
         for i, (w, r0, rows_, b) in enumerate(sp.lin):
             if i not in pairs:                                   # query_scale in the first layer: unused
@@ -298,10 +306,12 @@ class FusedLayerFn(torch.autograd.Function):
             n, k = rows_, w.shape[1]
             if i in (nv.DL_INQK, nv.DL_INV):
                 if inproj_dw is None:
-                    inproj_dw, inproj_db = new(*w.shape), new(w.shape[0])
+                    dfr = deferred_ok and _Deferred.uses.get(id(w), 0) == 1
+                    inproj_dw, inproj_db = slot(w, dfr), slot(b, dfr)
                 dw, db = inproj_dw[r0:r0 + rows_], inproj_db[r0:r0 + rows_]
             else:
-                dw, db = new(n, k), new(n)
+                dfr = deferred_ok and _Deferred.uses.get(id(w), 0) == 1
+                dw, db = slot(w, dfr), slot(b, dfr)
             single = _Deferred.uses.get(id(w), 0) == 1
             if i in _NARROW:
                 if deferred_ok and single:
@@ -323,7 +333,8 @@ class FusedLayerFn(torch.autograd.Function):
         lnp = nv.slot_view(grad, go["LNP"], nv.DL_NLN * 2 * d_blocks(M), 256, f32)
         nb = d_blocks(M)
         for j, nmod in enumerate(sp.ln):
-            dg, db = new(256), new(256)
+            dfr = deferred_ok and _Deferred.uses.get(id(nmod.weight), 0) == 1
+            dg, db = slot(nmod.weight, dfr), slot(nmod.bias, dfr)
             mg, mb = lnp[(2 * j) * nb:(2 * j + 1) * nb], lnp[(2 * j + 1) * nb:(2 * j + 2) * nb]
             if deferred_ok and _Deferred.uses.get(id(nmod.weight), 0) == 1:
                 _Deferred.sum_items += [(mg, nmod.weight), (mb, nmod.bias)]
@@ -332,7 +343,8 @@ class FusedLayerFn(torch.autograd.Function):
             grads += [dg, db]
         # attention_weights (256 -> 1) and the position encoder's first layer (3 -> 256): skinny products
         for dy, xin, mod in ((Gv("WL", 1), S("QP", 256), sp.attw), (Gv("P0", 256), ref.to(bf), sp.pe0)):
-            dw, db = new(*mod.weight.shape), new(mod.bias.shape[0])
+            dfr = deferred_ok and _Deferred.uses.get(id(mod.weight), 0) == 1
+            dw, db = slot(mod.weight, dfr), slot(mod.bias, dfr)
             if deferred_ok and _Deferred.uses.get(id(mod.weight), 0) == 1:
                 _Deferred.params[id(mod.weight)] = (mod.weight, mod.bias)
                 _Deferred.skinny.append((dy, xin.contiguous(), mod.weight))

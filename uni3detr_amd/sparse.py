@@ -129,6 +129,7 @@ class _SparseConv(torch.autograd.Function):
         nmajor = NMAJOR_FWD and bf16 and ((cin % 64 == 0 and cout % 64 == 0) or narrow)
         kio, koi = conv_weights(weight, layout, feats.dtype, want_koi=nmajor)
         ctx.geom, ctx.layout = geom, layout
+        ctx.grad_view = getattr(weight, "_u3d_grad_view", None)      # TrainStep: this parameter's slice of the flat gradient buffer
         ctx.save_for_backward(feats, kio)
         ctx.kio_shape, ctx.wdtype = kio_shape, weight.dtype
         nbr = geom.nbr_fwd if kio.shape[0] > 1 else None
@@ -168,11 +169,17 @@ class _SparseConv(torch.autograd.Function):
         def weight_grad():
             nbr = g.nbr_fwd if kvol > 1 else None
             cin_w, cout_w = wc.shape[1], wc.shape[2]
-            if (ctx.layout == "oidhw" and feats.dtype == torch.bfloat16 and nv.USE_IGEMM_V2 and cin_w % 16 == 0 and cout_w % 16 == 0
-                    and ctx.wdtype == torch.float32):
-                # the reduction stage writes nn.Conv3d's own [Cout,Cin,kD,kH,kW] layout: autograd keeps the tensor as the gradient
+            v2 = feats.dtype == torch.bfloat16 and nv.USE_IGEMM_V2 and cin_w % 16 == 0 and cout_w % 16 == 0 and ctx.wdtype == torch.float32
+            # the reduction stage can write the parameter's own layout straight into its slice of the flat gradient buffer (out=):
+            # autograd keeps that view as .grad and the step's packing copy has nothing to move for this parameter
+            gv = ctx.grad_view if (v2 and ctx.grad_view is not None and ctx.grad_view.is_contiguous()
+                                   and ctx.grad_view.dtype == torch.float32) else None
+            if ctx.layout == "oidhw" and v2:
+                # nn.Conv3d's own [Cout,Cin,kD,kH,kW] layout: autograd keeps the tensor as the gradient
                 ks = ctx.kio_shape
-                dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol, out_oik=True).view(ks[4], ks[3], ks[0], ks[1], ks[2])
+                dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol, out_oik=True, out=gv).view(ks[4], ks[3], ks[0], ks[1], ks[2])
+            elif ctx.layout == "dhwio" and v2:
+                dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol, out=gv).view(ctx.kio_shape)
             else:
                 dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol).reshape(ctx.kio_shape).to(ctx.wdtype)
                 if ctx.layout == "oidhw":

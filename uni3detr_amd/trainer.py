@@ -51,6 +51,9 @@ class TrainStep:
         for p, o in zip(self.params, self.offsets):
             self.views.append(self.flat_grad[o:o + p.numel()].view_as(p))
             p.grad = self.views[-1]
+            # conv weight gradients are reduced straight into this view (sparse._SparseConv.backward): the packing copy below then
+            # only moves the small tensors
+            p._u3d_grad_view = self.views[-1]
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, tuple(betas), eps
         self.flat_update = flat_update
         self.check_every, self._steps_since_check, self.recaptures = check_every, 0, 0
@@ -206,7 +209,7 @@ class TrainStep:
             if p.grad is None:
                 missing.append(v)
                 self._grad_missing[i] = True
-            else:
+            elif p.grad.data_ptr() != v.data_ptr():          # (already in place: written there by the producing kernel)
                 dst.append(v); src.append(p.grad)
             p.grad = v
         torch._foreach_copy_(dst, src)
@@ -244,7 +247,7 @@ class TrainStep:
             if p.grad is None:
                 missing.append(v)
                 self._grad_missing[lo + i] = True
-            else:
+            elif p.grad.data_ptr() != v.data_ptr():          # (already in place: written there by the producing kernel)
                 dst.append(v); src.append(p.grad)
             p.grad = v
         if dst:
