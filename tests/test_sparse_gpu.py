@@ -620,3 +620,26 @@ def test_lattice_window_kernel_equals_table_kernel(cuda, kd, dims, cin, cout):
         got_d = nv.lattice_conv(dy, w2, B, dims, kd, transposed=True)
         assert got_d is not None and torch.equal(got_d, ref_d)
     assert nv.lattice_conv(x[:, :32].contiguous(), koi[:, :, :32].contiguous(), B, dims, kd) is None     # Cin % 64 != 0: not served
+
+
+def test_subm_transposed_table_is_the_reversed_forward_table(cuda):
+    """native.RevNbr: the input gradient of a SubM layer reads the forward table with the 27 offsets reversed instead of building
+    the transposed table (sparse.Level.subm_tables).  Pinned here against the table the builder produces in transposed mode, on a
+    ragged multi-scene level, and through the dgrad itself (bf16 direct kernel + f32 first-generation kernel)."""
+    import torch
+    from uni3detr_amd import native as nv
+    from uni3detr_amd import sparse as sp
+    torch.manual_seed(3)
+    dims = (16, 40, 36)
+    coors = torch.unique(torch.stack([torch.randint(0, 3, (6000,)), torch.randint(0, dims[0], (6000,)), torch.randint(0, dims[1], (6000,)),
+                                      torch.randint(0, dims[2], (6000,))], 1), dim=0).int().cuda()
+    lvl, _ = sp.level_from_coors(coors, 3, dims)
+    fwd = lvl.grid.nbr_table(lvl.coords, lvl.n_dev, sp.K3, sp.S1, sp.P1, 0)
+    bwd = lvl.grid.nbr_table(lvl.coords, lvl.n_dev, sp.K3, sp.S1, sp.P1, 1)
+    assert torch.equal(bwd[:, :lvl.n], fwd.flip(0)[:, :lvl.n])
+    for dt, cin, cout in ((torch.bfloat16, 32, 32), (torch.bfloat16, 64, 64), (torch.float32, 16, 16)):
+        dy = torch.randn(lvl.n, cout, device="cuda").to(dt)
+        w = (torch.randn(27, cin, cout, device="cuda") * 0.1).to(dt)
+        a = nv.spconv_fwd(dy, w, bwd, lvl.n_dev, lvl.n, cin, transpose_w=True)
+        b = nv.spconv_fwd(dy, w, nv.RevNbr(fwd), lvl.n_dev, lvl.n, cin, transpose_w=True)
+        assert torch.equal(a, b), (dt, cin, cout)

@@ -91,7 +91,8 @@ def main():
             err = (got - exp).abs().max().item() / max(1.0, exp.abs().max().item())
             mi = min(g.n_in, 8192)
             gd = nv.spconv_fwd(dy, w, g.nbr_bwd, g.n_in_dev, g.n_in, ci, transpose_w=True)[:mi].float()
-            ed = ref_fwd(dy, w.transpose(1, 2), g.nbr_bwd, mi)
+            nb = g.nbr_bwd.t.flip(0) if isinstance(g.nbr_bwd, nv.RevNbr) else g.nbr_bwd
+            ed = ref_fwd(dy, w.transpose(1, 2), nb, mi)
             errd = (gd - ed).abs().max().item() / max(1.0, ed.abs().max().item())
             gw = nv.spconv_wgrad(x, dy, g.nbr_fwd, g.n_out_dev, 27)
             errw = 0.0

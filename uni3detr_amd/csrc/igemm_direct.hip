@@ -90,8 +90,12 @@ __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, co
   const int stride = wg_per_xcd * NW;
   int tile = xcd * slab + slot * NW + wv;
 
-  const __amdgpu_buffer_rsrc_t nbr_rs = __builtin_amdgcn_make_buffer_rsrc((void*)nbr, 0, 0x7FFFFFFC, 0x00020000);
-  const unsigned ld4 = (unsigned)ld * 4u;
+  // ld < 0: the table is read in REVERSED offset order (row 26 - q for offset q; `nbr` then points at table row 26) - the transposed
+  // table of a submanifold convolution is its forward table with the offsets reversed, so the input gradient needs no table of its own
+  const bool rev = ld < 0;
+  const __amdgpu_buffer_rsrc_t nbr_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(rev ? nbr + (long long)(DIR_K - 1) * ld : nbr), 0, 0x7FFFFFFC, 0x00020000);
+  const unsigned ld4 = (unsigned)(rev ? -ld : ld) * 4u;
+#define DIR_ROW(q) ((unsigned)(rev ? DIR_K - 1 - (q) : (q)) * ld4)
   auto row_off = [&](int t) -> unsigned {                       // byte offset of this lane's row of tile t in one table row (clamped)
     return (unsigned)max(0, min(t * 64 + lane, n_out - 1)) * 4u;
   };
@@ -103,7 +107,7 @@ __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, co
   {
     const unsigned r0 = row_off(tile);
 #pragma unroll
-    for (int q = 0; q < DIR_K; ++q) X[q] = __builtin_amdgcn_raw_buffer_load_b32(nbr_rs, r0, (unsigned)q * ld4, 0);
+    for (int q = 0; q < DIR_K; ++q) X[q] = __builtin_amdgcn_raw_buffer_load_b32(nbr_rs, r0, DIR_ROW(q), 0);
   }
 
   // 2 GB bound: every real row offset is below it, (-1 << shift) | part is above it (hardware zero fill)
@@ -189,7 +193,7 @@ __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, co
   for (int p = 0; p < P; ++p) {
     permute(p, mcur, pi[0]);
     issue(pi[0], A[p]);
-    X[p] = __builtin_amdgcn_raw_buffer_load_b32(nbr_rs, roff1, (unsigned)p * ld4, 0);
+    X[p] = __builtin_amdgcn_raw_buffer_load_b32(nbr_rs, roff1, DIR_ROW(p), 0);
   }
   permute(P % DIR_K, mcur, pi[0]);
 #pragma unroll
@@ -259,7 +263,7 @@ __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, co
       const int q = (s + P) % DIR_K;
       issue(pi[cur], A[s % P]);
 #if !(defined(DIR_EXP) && (DIR_EXP & 4))                        /* timing experiment (wrong results): indices never reloaded */
-      X[q] = __builtin_amdgcn_raw_buffer_load_b32(nbr_rs, (s + P >= DIR_K) ? roff2 : roff1, (unsigned)q * ld4, 0);
+      X[q] = __builtin_amdgcn_raw_buffer_load_b32(nbr_rs, (s + P >= DIR_K) ? roff2 : roff1, DIR_ROW(q), 0);
 #endif
     }
     // 27 steps: what the last step left in slot 1 is what step 0 of the next tile reads from slot 0

@@ -422,22 +422,47 @@ def bn_finalize_partials(stats, tile_rows, n_dev, n_cap, eps, momentum, running_
     return mean, invstd
 
 
+class RevNbr:
+    """A neighbour table read with its offsets in REVERSED order (row K-1-k for offset k): what the transposed table of a
+    submanifold convolution is - voxel j is the neighbour of m at offset +d exactly when m is the neighbour of j at -d, and the
+    3x3x3 offsets are enumerated symmetrically.  Handed to the kernels as a pointer to the last table row with a negative row
+    stride: the input gradient of a SubM layer needs no table of its own (4 table builds per step less)."""
+
+    def __init__(self, table):
+        self.t = table
+        self.shape = table.shape
+
+    def ptr_ld(self):
+        k, ld = self.t.shape
+        return C.c_void_p(self.t.data_ptr() + (k - 1) * ld * 4), -ld
+
+
+def _nbr_ptr_ld(nbr):
+    if nbr is None:
+        return _ptr(None), 0
+    if isinstance(nbr, RevNbr):
+        return nbr.ptr_ld()
+    return _ptr(nbr), nbr.shape[1]
+
+
 def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False, tag=None):
-    """out[m] = sum_k in[nbr[k][m]] @ W[k]; w: [K, Cin_w, Cout_w] contiguous. Returns [n_out, cout]."""
+    """out[m] = sum_k in[nbr[k][m]] @ W[k]; w: [K, Cin_w, Cout_w] contiguous. Returns [n_out, cout].  nbr may be a RevNbr."""
     kvol = w.shape[0]
     cin = inp.shape[1]
     out = torch.empty((n_out, cout), dtype=inp.dtype, device=inp.device)
-    ld = nbr.shape[1] if nbr is not None else 0
+    nbr_p, ld = _nbr_ptr_ld(nbr)
+    if isinstance(nbr, RevNbr):
+        nbr = nbr.t.flip(0) if (TIMER is not None and TIMER.mode == "census") else None      # only the census counts pairs from it
     t = TIMER
     e0 = t.begin() if t is not None else None
     rc = -2
     if inp.dtype == torch.bfloat16 and USE_IGEMM_V2:
-        rc = lib().u3d_igemm_fwd_bf16(_ptr(inp), _ptr(w), _ptr(nbr), ld, _ptr(out), _ptr(n_out_dev), n_out, cin, cout, kvol,
+        rc = lib().u3d_igemm_fwd_bf16(_ptr(inp), _ptr(w), nbr_p, ld, _ptr(out), _ptr(n_out_dev), n_out, cin, cout, kvol,
                                       1 if transpose_w else 0, _stream())
         if rc not in (0, -2):
             _check(rc, "igemm_fwd_bf16")
     if rc == -2:      # shape served by the first-generation kernel (small channel counts, f32)
-        _check(lib().u3d_spconv_fwd(_ptr(inp), _ptr(w), _ptr(nbr), ld, _ptr(out), _ptr(n_out_dev), n_out, cin, cout, kvol,
+        _check(lib().u3d_spconv_fwd(_ptr(inp), _ptr(w), nbr_p, ld, _ptr(out), _ptr(n_out_dev), n_out, cin, cout, kvol,
                                     1 if transpose_w else 0, dtype_code(inp), _stream()), "spconv_fwd")
     if t is not None:
         meta = None

@@ -27,7 +27,8 @@ class Level:
     def subm_tables(self):
         if self._subm is None:
             fwd = self.grid.nbr_table(self.coords, self.n_dev, K3, S1, P1, 0)
-            bwd = self.grid.nbr_table(self.coords, self.n_dev, K3, S1, P1, 1)
+            # the transposed table of a SubM layer = the forward table with the offsets reversed (native.RevNbr): not built
+            bwd = nv.RevNbr(fwd) if REV_SUBM_TABLE else self.grid.nbr_table(self.coords, self.n_dev, K3, S1, P1, 1)
             self._subm = (fwd, bwd)
         return self._subm
 
@@ -79,6 +80,7 @@ def strided_level(lvl, ksize, stride, pad, capacity=None):
     return out, ConvGeom(fwd, bwd, lvl.n, lvl.n_dev, n_out, out.n_dev)
 
 
+REV_SUBM_TABLE = os.environ.get("U3D_REV_SUBM_TABLE", "1") == "1"
 LATTICE_KERNEL = os.environ.get("U3D_LATTICE_KERNEL", "0") == "1"      # 27-offset dense convs on u3d_igemm_lattice_bf16 (measured on par: off)
 STRIDED_DGRAD_SPLIT = os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
 NMAJOR_FWD = os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
