@@ -154,6 +154,12 @@ int32_t u3d_spconv_fwd(const void* in, const void* w, const int32_t* nbr, int32_
 int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,
                            const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
                            int32_t transpose_w, u3d_stream s);
+/* out = conv(in) + addend in one pass (addend bf16, out's shape): the input gradient of a residual block's first conv with the
+ * residual branch's gradient summed in by the epilogue (ref: SparseBasicBlock's `out += identity`, mmdet3d; autograd adds the two
+ * gradients with a separate element-wise kernel).  U3D_ERR_UNSUPPORTED for shapes without that epilogue: the caller adds. */
+int32_t u3d_igemm_fwd_add_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, const void* addend, void* out,
+                               const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
+                               int32_t transpose_w, u3d_stream s);
 /* nn.Linear on rows with the same kernel: out[M,N] = act(x[M,K] @ W[N,K]^T + bias); bf16 x/W/out, f32 bias (may be NULL),
  * relu != 0 applies max(.,0).  (ref: the Linear layers of models/utils/uni3detr_transformer.py:18-30,142-143,248-260 and
  * models/dense_heads/uni3detr_head.py:365-387.)  U3D_ERR_UNSUPPORTED unless K % 64 == 0 and N % 64 == 0. */

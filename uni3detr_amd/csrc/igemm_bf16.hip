@@ -26,7 +26,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define IGEMM_DIRECT 1     /* narrow sparse levels on the direct-operand kernel (igemm_direct.hip); 0: the tiled BK = 32 kernels below */
 #endif
 int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev, int n_out_cap,
-                            int cin, int cout, int kvol, int transpose_w, hipStream_t s);
+                            int cin, int cout, int kvol, int transpose_w, hipStream_t s, const void* addend = nullptr);
 #ifndef IGEMM_SMALL_PF
 #define IGEMM_SMALL_PF 1   /* stages of operand loads in flight in the 16/32-channel kernels (1: the wide layers' one-stage pipeline) */
 #endif
@@ -1141,7 +1141,7 @@ extern "C" int32_t u3d_linear_bf16(const void* x, const void* w, const float* bi
   if (n % 256 == 0 && wg256 >= 128) return launch_igemm_glds<GLDS256_CFG>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
   if (n % 128 == 0 && (long long)u3d_cdiv(m_cap, 256) * (n / 128) >= 128)
     return launch_igemm_glds<4, 2, 4, 4>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
-  return launch_igemm_glds<4, 1, 2, 4>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu);
+  return launch_igemm_glds<4, 1, 2, 4>(x, w, nullptr, 0, out, m_dev, m_cap, k, n, 1, s, bias, relu ? 1 : 0);
 }
 
 // row-tile height of the n-major (LDS-DMA) kernel u3d_igemm_fwd_stats_bf16 would launch for this shape; 0 = not served by it
@@ -1288,6 +1288,31 @@ __global__ __launch_bounds__(1024) void k_conv_in_reduce(const float* __restrict
   }
 }
 static inline bool convin_shape(int cin, int cout, int kvol) { return cin == CONVIN_CIN && cout == CONVIN_COUT && kvol >= 1 && kvol <= CONVIN_MAXK; }
+
+// out = conv(in) + addend (bf16, out's shape) in one pass - the input gradient of a residual block's first conv with the residual
+// branch's gradient summed in by the epilogue.  Shapes: the direct-operand kernels (16/32/64 channels, 27 offsets) and the n-major
+// LDS-DMA kernels with 128 x 128 / 128 x 64 tiles (transpose_w != 0, cin % 64 == 0); anything else: U3D_ERR_UNSUPPORTED (the caller adds).
+extern "C" int32_t u3d_igemm_fwd_add_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, const void* addend, void* out,
+                                          const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
+                                          int32_t transpose_w, u3d_stream s) {
+  U3D_REQUIRE(in && w && out && addend && n_out_dev && nbr, U3D_ERR_ARG);
+  if (n_out_cap <= 0) return U3D_OK;
+#if IGEMM_DIRECT
+  {
+    const int rc = u3d_launch_igemm_direct(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, transpose_w, s, addend);
+    if (rc != U3D_ERR_UNSUPPORTED) return rc;
+  }
+#endif
+#if IGEMM_GLDS
+  if (transpose_w && cin % 64 == 0 && cout % 64 == 0) {
+    const long long wg256 = (long long)u3d_cdiv(n_out_cap, 256) * (cout / 256 > 0 ? cout / 256 : 1);
+    if (cout % 256 == 0 && wg256 >= 128) return U3D_ERR_UNSUPPORTED;                 // the 256 x 256 kernel has no addend path
+    if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, (const float*)addend, 2);
+    return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, (const float*)addend, 2);
+  }
+#endif
+  return U3D_ERR_UNSUPPORTED;
+}
 
 extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,
                                       const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,

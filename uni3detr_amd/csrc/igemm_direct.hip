@@ -68,7 +68,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 template <int KS, int WN, bool W_KMAJOR, int NW, int P>
 __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr, int ld,
                                                   u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap, int cin, int cout,
-                                                  int co0) {
+                                                  int co0, const u16* __restrict__ addend) {
   // cout = channels of a row of `out` (and of the weight tensor); this launch computes the COUT = 16 * WN columns from co0 on
   // (a 64 -> 64 layer is two launches of the 64 -> 32 kernel: the weights of 27 x 64 x 64 do not fit LDS, those of one half do)
   static_assert(DIR_K % P == 0, "operand register sets are indexed statically");
@@ -247,7 +247,12 @@ __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, co
 #pragma unroll
           for (int b = 0; b < WN; ++b) {
 #if !(defined(DIR_EXP) && (DIR_EXP & 8))                        /* timing experiment (wrong results): nothing stored except by the last tile */
-            if (m < n_out) *(bf16x4*)(out + (long long)m * cout + co0 + b * 16 + g * 4) = __builtin_convertvector(acc[a][b], bf16x4);
+            if (m < n_out) {
+              f32x4 v = acc[a][b];
+              // addend (nullable): a bf16 tensor of out's shape summed in before the rounding (the residual branch's gradient)
+              if (addend) v += __builtin_convertvector(*(const bf16x4*)(addend + (long long)m * cout + co0 + b * 16 + g * 4), f32x4);
+              *(bf16x4*)(out + (long long)m * cout + co0 + b * 16 + g * 4) = __builtin_convertvector(v, bf16x4);
+            }
 #else
             if (m < n_out && tile + stride >= slab_end) *(bf16x4*)(out + (long long)m * cout + co0 + b * 16 + g * 4) = __builtin_convertvector(acc[a][b], bf16x4);
 #endif
@@ -283,8 +288,8 @@ __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, co
 
 #define U3D_DIRECT_KERNEL(NAME, KS, WN, KM, NW, P)                                                                                    \
   __global__ __launch_bounds__(NW * 64, DIR_WAVES_PER_SIMD) void NAME(const u16* in, const u16* w, const int* nbr, int ld, u16* out, const int* n_out_dev, \
-                                                  int n_out_cap, int cin, int cout, int co0) {                                     \
-    igemm_direct_body<KS, WN, KM, NW, P>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, co0);                                     \
+                                                  int n_out_cap, int cin, int cout, int co0, const u16* addend) {                  \
+    igemm_direct_body<KS, WN, KM, NW, P>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, co0, addend);                             \
   }
 // name: k_igemm_direct_<cin_pad>x<cout>_<k|n>: k = weights [27][cin][cout] (forward), n = [27][cout][cin] (dgrad)
 U3D_DIRECT_KERNEL(k_igemm_direct_32x16_k, 1, 1, true, DIR_NW_A, DIR_P1)
@@ -298,11 +303,11 @@ U3D_DIRECT_KERNEL(k_igemm_direct_64x16_n, 2, 1, false, DIR_NW_A, DIR_P2)
 U3D_DIRECT_KERNEL(k_igemm_direct_64x32_k, 2, 2, true, DIR_NW_B, DIR_P2)
 U3D_DIRECT_KERNEL(k_igemm_direct_64x32_n, 2, 2, false, DIR_NW_B, DIR_P2)
 
-typedef void (*direct_kernel_t)(const u16*, const u16*, const int*, int, u16*, const int*, int, int, int, int);
+typedef void (*direct_kernel_t)(const u16*, const u16*, const int*, int, u16*, const int*, int, int, int, int, const u16*);
 
 // 0 = launched, U3D_ERR_UNSUPPORTED = shape not served here (caller falls through to the tiled kernels)
 int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev, int n_out_cap,
-                            int cin, int cout, int kvol, int transpose_w, hipStream_t s) {
+                            int cin, int cout, int kvol, int transpose_w, hipStream_t s, const void* addend) {
   if (kvol != DIR_K || !nbr || (cin != 16 && cin != 32 && cin != 64) || (cout != 16 && cout != 32 && cout != 64))
     return U3D_ERR_UNSUPPORTED;
 #if !DIR_SPLIT_64
@@ -351,6 +356,6 @@ int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, i
   grid = (grid + 7) / 8 * 8;
   for (int h = 0; h < halves; ++h)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin,
-                       cout_total, h * 32);
+                       cout_total, h * 32, (const u16*)addend);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
 }

@@ -90,6 +90,7 @@ _SIGS = {
     "u3d_spconv_wgrad_workspace": (_L, [_I, _I, _I, _I]),
     "u3d_spconv_wgrad": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "u3d_igemm_fwd_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "u3d_igemm_fwd_add_bf16": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "u3d_linear_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "u3d_igemm_wgrad_bf16_workspace": (_L, [_I, _I, _I, _I]),
     "u3d_igemm_wgrad_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
@@ -445,8 +446,9 @@ def _nbr_ptr_ld(nbr):
     return _ptr(nbr), nbr.shape[1]
 
 
-def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False, tag=None):
-    """out[m] = sum_k in[nbr[k][m]] @ W[k]; w: [K, Cin_w, Cout_w] contiguous. Returns [n_out, cout].  nbr may be a RevNbr."""
+def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False, tag=None, addend=None):
+    """out[m] = sum_k in[nbr[k][m]] @ W[k]; w: [K, Cin_w, Cout_w] contiguous. Returns [n_out, cout].  nbr may be a RevNbr.
+    addend (bf16 [n_out, cout], optional): summed into the result - by the kernel's epilogue where it has one, else afterwards."""
     kvol = w.shape[0]
     cin = inp.shape[1]
     out = torch.empty((n_out, cout), dtype=inp.dtype, device=inp.device)
@@ -456,7 +458,15 @@ def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False, tag=None)
     t = TIMER
     e0 = t.begin() if t is not None else None
     rc = -2
-    if inp.dtype == torch.bfloat16 and USE_IGEMM_V2:
+    if addend is not None and inp.dtype == torch.bfloat16 and USE_IGEMM_V2 and ld != 0 and addend.dtype == torch.bfloat16 \
+            and addend.shape == out.shape and addend.is_contiguous():
+        rc = lib().u3d_igemm_fwd_add_bf16(_ptr(inp), _ptr(w), nbr_p, ld, _ptr(addend), _ptr(out), _ptr(n_out_dev), n_out, cin, cout, kvol,
+                                          1 if transpose_w else 0, _stream())
+        if rc not in (0, -2):
+            _check(rc, "igemm_fwd_add_bf16")
+        if rc == 0:
+            addend = None                      # already in
+    if rc == -2 and inp.dtype == torch.bfloat16 and USE_IGEMM_V2:
         rc = lib().u3d_igemm_fwd_bf16(_ptr(inp), _ptr(w), nbr_p, ld, _ptr(out), _ptr(n_out_dev), n_out, cin, cout, kvol,
                                       1 if transpose_w else 0, _stream())
         if rc not in (0, -2):
@@ -473,6 +483,8 @@ def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False, tag=None)
                         bytes=inp.shape[0] * cin * s + n_out * cout * s + 8 * pairs + kvol * cin * cout * s,
                         flops=2 * pairs * cin * cout)
         t.end(tag or ("spconv_dgrad" if transpose_w else "spconv_fwd"), e0, meta)
+    if addend is not None:
+        out += addend
     return out
 
 

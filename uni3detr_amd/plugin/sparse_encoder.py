@@ -7,6 +7,8 @@ Parameter names follow the reference checkpoints: `conv_i
 """
 import math
 
+import os
+
 import torch
 from torch import nn
 
@@ -56,6 +58,9 @@ class SparseBasicBlock(nn.Module):
         self.bn1 = _bn(norm_cfg, planes)
         self.conv2 = SparseConvWeight(planes, planes, (3, 3, 3), subm=True, padding=(1, 1, 1))
         self.bn2 = _bn(norm_cfg, planes)
+
+
+RESIDUAL_FUSION = os.environ.get("U3D_RESIDUAL_FUSION", "1") == "1"
 
 
 @MIDDLE_ENCODERS.register_module()
@@ -117,8 +122,11 @@ class SparseEncoderHD(nn.Module):
 
     def _block(self, blk, x, lvl):
         geom = sp.subm_geom(lvl)
-        o = sp.conv_bn(x, blk.conv1.weight, geom, blk.bn1, lvl.n_dev, None, True)
-        return sp.conv_bn(o, blk.conv2.weight, geom, blk.bn2, lvl.n_dev, x, True)
+        # bf16 training: the identity's gradient is summed into conv1's input gradient by that kernel's epilogue (sp.ResidualToken)
+        tok = sp.ResidualToken() if (RESIDUAL_FUSION and x.dtype == torch.bfloat16 and x.requires_grad and torch.is_grad_enabled()
+                                     and blk.bn1.training) else None
+        o = sp.conv_bn(x, blk.conv1.weight, geom, blk.bn1, lvl.n_dev, None, True, res_take=tok)
+        return sp.conv_bn(o, blk.conv2.weight, geom, blk.bn2, lvl.n_dev, x, True, res_give=tok)
 
     def forward(self, voxel_features, coors, batch_size):
         """voxel_features [N,C], coors int [N,4] (b,z,y,x), batch_size -> [B, C_out, D, H, W] (ref :106-138)."""

@@ -33,6 +33,16 @@ class Level:
         return self._subm
 
 
+class ResidualToken:
+    """Side channel between the two autograd nodes of a residual block (ref: mmdet3d SparseBasicBlock, `out += identity`): the
+    BatchNorm that adds the identity deposits the identity branch's gradient here in ITS backward, and the block's first conv - whose
+    backward runs later, and whose input IS the identity - sums it into its input gradient in the kernel epilogue
+    (u3d_igemm_fwd_add_bf16).  Autograd would add the two gradients with a separate element-wise pass over both tensors."""
+
+    def __init__(self):
+        self.dres = None
+
+
 class ConvGeom:
     """Tables of one convolution instance: forward (output-stationary), transposed (input-stationary), sizes."""
 
@@ -116,7 +126,7 @@ def wgrad_side_stream():
 
 class _SparseConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, weight, geom, layout, want_stats=False):
+    def forward(ctx, feats, weight, geom, layout, want_stats=False, res_token=None):
         # weight: the PARAMETER in its checkpoint layout: "dhwio" [kD,kH,kW,Cin,Cout] (mmcv spconv-1.x) or "oidhw" (nn.Conv3d)
         # want_stats: also return the per-row-tile BatchNorm statistics of the output (empty tensor when the kernel serving this
         # shape does not produce them) - second, non-differentiable output
@@ -131,6 +141,7 @@ class _SparseConv(torch.autograd.Function):
         nmajor = NMAJOR_FWD and bf16 and ((cin % 64 == 0 and cout % 64 == 0) or narrow)
         kio, koi = conv_weights(weight, layout, feats.dtype, want_koi=nmajor)
         ctx.geom, ctx.layout = geom, layout
+        ctx.res_token = res_token
         ctx.grad_view = getattr(weight, "_u3d_grad_view", None)      # TrainStep: this parameter's slice of the flat gradient buffer
         ctx.save_for_backward(feats, kio)
         ctx.kio_shape, ctx.wdtype = kio_shape, weight.dtype
@@ -162,7 +173,7 @@ class _SparseConv(torch.autograd.Function):
         feats, wc = ctx.saved_tensors
         g = ctx.geom
         if dout is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         dout = dout.contiguous()
         kvol = wc.shape[0]
         din = dw = None
@@ -209,29 +220,37 @@ class _SparseConv(torch.autograd.Function):
                 if LATTICE_KERNEL and g.lattice is not None and g.lattice[2] == 3 and dout.dtype == torch.bfloat16:
                     din = nv.lattice_conv(dout, wc, g.lattice[0], g.lattice[1], g.lattice[2], transposed=True)
                 if din is None:
-                    din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True)
-        return din, dw, None, None, None
+                    tok = ctx.res_token
+                    add = tok.dres if tok is not None else None
+                    if tok is not None:
+                        tok.dres = None
+                    din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True, addend=add)
+        elif ctx.res_token is not None:
+            ctx.res_token.dres = None
+        return din, dw, None, None, None, None
 
 
 def sparse_conv(feats, weight, geom, layout="dhwio"):
     """weight: conv PARAMETER in checkpoint layout ("dhwio" = [kD,kH,kW,Cin,Cout]; "oidhw" = nn.Conv3d's [Cout,Cin,kD,kH,kW])."""
-    return _SparseConv.apply(feats, weight, geom, layout)
+    return _SparseConv.apply(feats, weight, geom, layout, False, None)
 
 
 FUSED_CONV_STATS = os.environ.get("U3D_FUSED_CONV_STATS", "1") == "1"
 
 
-def conv_bn(feats, weight, geom, bn, n_dev, residual=None, relu=True, layout="dhwio", post_add=None):
+def conv_bn(feats, weight, geom, bn, n_dev, residual=None, relu=True, layout="dhwio", post_add=None, res_take=None, res_give=None):
     """conv -> BatchNorm rows (+ residual) (+ ReLU).  In training the conv's epilogue already reduces the BatchNorm statistics per row
     tile where its kernel supports it (bf16, channels % 64 == 0): the separate statistics pass over the conv output disappears."""
     if FUSED_CONV_STATS and bn.training and feats.dtype == torch.bfloat16 and feats.is_cuda:
-        y, stats = _SparseConv.apply(feats, weight, geom, layout, True)
+        # res_take: this conv's input is the identity of a residual block - its backward sums the token's gradient into the input
+        # gradient; res_give: this BatchNorm adds that identity - its backward leaves the identity's gradient in the token
+        y, stats = _SparseConv.apply(feats, weight, geom, layout, True, res_take)
         if stats.numel():
             tr = getattr(stats, "_u3d_tile_rows", None)
             if tr is None:                      # attribute lost on the way through autograd: recover it from the shape
                 tr = 128 if (y.shape[0] + 127) // 128 == stats.shape[0] else 256
-            return _BNRows.apply(y, bn.weight, bn.bias, residual, n_dev, bn, relu, True, stats, tr, None, post_add)
-        return bn_rows(y, bn, n_dev, residual, relu, None, post_add)
+            return _BNRows.apply(y, bn.weight, bn.bias, residual, n_dev, bn, relu, True, stats, tr, None, post_add, res_give)
+        return _BNRows.apply(y, bn.weight, bn.bias, residual, n_dev, bn, relu, bn.training, None, 0, None, post_add, res_give)
     return bn_rows(sparse_conv(feats, weight, geom, layout), bn, n_dev, residual, relu, None, post_add)
 
 
@@ -239,7 +258,7 @@ class _BNRows(torch.autograd.Function):
     """BatchNorm1d over active rows (+ residual) (+ ReLU), training or eval statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, n_dev, bn, relu, training, stats=None, tile_rows=0, row_map=None, post_add=None):
+    def forward(ctx, x, gamma, beta, residual, n_dev, bn, relu, training, stats=None, tile_rows=0, row_map=None, post_add=None, res_token=None):
         n = x.shape[0]
         if training and stats is not None:
             mean, invstd = nv.bn_finalize_partials(stats, tile_rows, n_dev, n, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
@@ -262,6 +281,7 @@ class _BNRows(torch.autograd.Function):
         ctx.pdtype = gamma.dtype
         ctx.row_map = row_map
         ctx.has_post = post_add is not None
+        ctx.res_token = res_token if residual is not None else None
         return y
 
     @staticmethod
@@ -277,13 +297,15 @@ class _BNRows(torch.autograd.Function):
             dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, ctx.relu, ctx.n_dev, ctx.has_res, beta, ctx.row_map)
         if ctx.pdtype != torch.float32:
             s32 = s32.to(ctx.pdtype)
+        if ctx.res_token is not None and dres is not None:
+            ctx.res_token.dres, dres = dres, None            # picked up by the block's first conv (ResidualToken)
         # post_add enters y by a plain sum: its gradient is dy itself (no launch)
-        return dx, s32[1], s32[0], dres, None, None, None, None, None, None, None, (dy if ctx.has_post else None)
+        return dx, s32[1], s32[0], dres, None, None, None, None, None, None, None, (dy if ctx.has_post else None), None
 
 
 def bn_rows(x, bn, n_dev, residual=None, relu=True, row_map=None, post_add=None):
     """row_map: the output (and its gradient) use a permuted row order, y[row_map[r]] = bn(x[r]) - see u3d_bn_apply."""
-    return _BNRows.apply(x, bn.weight, bn.bias, residual, n_dev, bn, relu, bn.training, None, 0, row_map, post_add)
+    return _BNRows.apply(x, bn.weight, bn.bias, residual, n_dev, bn, relu, bn.training, None, 0, row_map, post_add, None)
 
 
 class _ToDense(torch.autograd.Function):
