@@ -643,3 +643,96 @@ def test_subm_transposed_table_is_the_reversed_forward_table(cuda):
         a = nv.spconv_fwd(dy, w, bwd, lvl.n_dev, lvl.n, cin, transpose_w=True)
         b = nv.spconv_fwd(dy, w, nv.RevNbr(fwd), lvl.n_dev, lvl.n, cin, transpose_w=True)
         assert torch.equal(a, b), (dt, cin, cout)
+
+
+def _level(seed=5, n_pts=9000, batch=3, dims=(16, 40, 36)):
+    import torch
+    from uni3detr_amd import sparse as sp
+    torch.manual_seed(seed)
+    coors = torch.unique(torch.stack([torch.randint(0, batch, (n_pts,)), torch.randint(0, dims[0], (n_pts,)),
+                                      torch.randint(0, dims[1], (n_pts,)), torch.randint(0, dims[2], (n_pts,))], 1), dim=0).int().cuda()
+    lvl, _ = sp.level_from_coors(coors, batch, dims)
+    return lvl, lvl.grid.nbr_table(lvl.coords, lvl.n_dev, sp.K3, sp.S1, sp.P1, 0)
+
+
+def _ref_conv(x, w, nbr, n):
+    import torch
+    out = torch.zeros(n, w.shape[2], dtype=torch.float32, device=x.device)
+    xf = torch.cat([x.float(), torch.zeros(1, x.shape[1], device=x.device)])
+    for k in range(w.shape[0]):
+        idx = nbr[k, :n].long()
+        idx = torch.where(idx < 0, torch.full_like(idx, x.shape[0]), idx)
+        out += xf[idx] @ w[k].float()
+    return out
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64)])
+def test_narrow_weight_gradient_kernel_matches_f32_reference(cuda, cin, cout):
+    """wgrad_narrow.hip (9 waves x 3 offsets, stationary dout tile): every offset's dW against an f32 gather-matmul, both output
+    layouts, with a device-side row count BELOW the capacity (rows past it hold garbage and must not be read as data) and with zero rows."""
+    import torch
+    from uni3detr_amd import native as nv
+    lvl, nbr = _level()
+    n = lvl.n
+    torch.manual_seed(cin + cout)
+    x = torch.randn(n, cin, device="cuda").bfloat16()
+    dy = torch.randn(n, cout, device="cuda").bfloat16()
+    xf = torch.cat([x.float(), torch.zeros(1, cin, device="cuda")])
+    exp = []
+    for k in range(27):
+        idx = nbr[k, :n].long()
+        idx = torch.where(idx < 0, torch.full_like(idx, n), idx)
+        exp.append(xf[idx].t() @ dy.float())
+    exp = torch.stack(exp)                                                       # [27, cin, cout]
+    got = nv.spconv_wgrad(x, dy, nbr, lvl.n_dev, 27)
+    scale = exp.abs().max()
+    assert (got - exp).abs().max() / scale < 2e-5                                # bf16 products are exact in f32; only the summation order differs
+    got_oik = nv.spconv_wgrad(x, dy, nbr, lvl.n_dev, 27, out_oik=True)
+    assert torch.equal(got_oik, got.permute(2, 1, 0).contiguous())
+    # fewer live rows than the tensors hold: NaN in the dead rows must not reach the result
+    m = n - 777
+    cnt = nv.count_tensor(m, x.device)
+    x2, dy2 = x.clone(), dy.clone()
+    x2[m:] = float("nan"); dy2[m:] = float("nan")
+    nb2 = nbr.clone()
+    nb2[:, :m][nb2[:, :m] >= m] = -1                                             # a live row never points at a dead one in the real tables
+    exp2 = torch.stack([torch.cat([x2[:m].float(), torch.zeros(1, cin, device="cuda")])[torch.where(nb2[k, :m] < 0, torch.full_like(nb2[k, :m], m), nb2[k, :m]).long()].t()
+                        @ dy2[:m].float() for k in range(27)])
+    got2 = nv.spconv_wgrad(x2, dy2, nb2, cnt, 27)
+    assert torch.isfinite(got2).all() and (got2 - exp2).abs().max() / exp2.abs().max() < 2e-5
+    assert (nv.spconv_wgrad(x, dy, nbr, nv.count_tensor(0, x.device), 27) == 0).all()
+    assert torch.equal(nv.spconv_wgrad(x, dy, nbr, lvl.n_dev, 27), got)         # deterministic
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (16, 32), (64, 32), (64, 64), (128, 128)])
+def test_input_gradient_with_addend_epilogue(cuda, cin, cout):
+    """u3d_igemm_fwd_add_bf16 (direct-operand kernels and the 128-row LDS-DMA tiles): conv + addend rounded once == f32 reference."""
+    import torch
+    from uni3detr_amd import native as nv
+    lvl, nbr = _level(seed=9)
+    n = lvl.n
+    torch.manual_seed(cin * 3 + cout)
+    dy = torch.randn(n, cin, device="cuda").bfloat16()
+    w = (torch.randn(27, cout, cin, device="cuda") * 0.1).bfloat16()           # n-major [K][Cout_gemm][Cin_gemm] as the dgrad passes it
+    add = torch.randn(n, cout, device="cuda").bfloat16()
+    got = nv.spconv_fwd(dy, w, nbr, lvl.n_dev, n, cout, transpose_w=True, addend=add).float()
+    exp = _ref_conv(dy, w.transpose(1, 2), nbr, n) + add.float()
+    assert (got - exp).abs().max() / exp.abs().max() < 1e-2
+    plain = nv.spconv_fwd(dy, w, nbr, lvl.n_dev, n, cout, transpose_w=True).float()
+    assert ((plain + add.float()) - got).abs().max() / exp.abs().max() < 1.6e-2   # the two-pass form rounds twice
+
+
+def test_skinny_weight_gradients_batched_equal_single_launches(cuda):
+    import torch
+    from uni3detr_amd import native as nv
+    torch.manual_seed(0)
+    m = 7200
+    shapes = [(8, 256), (10, 256), (1, 256), (1, 256), (256, 3), (256, 3)]
+    dys = [torch.randn(m, n, device="cuda").bfloat16() for n, _ in shapes]
+    xs = [torch.randn(m, k, device="cuda").bfloat16() for _, k in shapes]
+    parts = nv.skinny_wgrad_partial_batched(dys, xs)
+    for d, x, p in zip(dys, xs, parts):
+        assert torch.equal(p, nv.skinny_wgrad_partial(d, x))
+        dw = p.sum(0).view(d.shape[1], x.shape[1])
+        ref = d.float().t() @ x.float()
+        assert (dw - ref).abs().max() / ref.abs().max() < 1e-4
