@@ -62,6 +62,59 @@ __global__ void k_bitgrid_mark_strided(BitGridDev g, unsigned long long* words, 
   }
 }
 
+// The same marking with the atomics aggregated per workgroup.  Rows are in block-major order, so the 256 voxels of a workgroup
+// come from a handful of 4x4x4 input blocks and their (up to 27 each) targets fall into a few dozen output WORDS: the plain kernel
+// sends 0.4-1.1 M global atomics per launch, most of them onto words another lane is hitting too (60-99 us, the cost IS the L2
+// atomic unit).  Here every target first goes into a small open-addressing table in LDS (key = word index: ds_cmpst; bits: ds_or),
+// and only the table's occupied slots go to global memory - one atomic per distinct word and workgroup.  A full table (never seen
+// on real levels) falls back to the direct global atomic.
+#define MK_SLOTS 512
+__global__ __launch_bounds__(256) void k_bitgrid_mark_strided_agg(BitGridDev g, unsigned long long* words, const int4* __restrict__ coors,
+                                                                  const int* __restrict__ n_dev, int n_cap, Conv3 cv) {
+  __shared__ unsigned long long keys[MK_SLOTS];        // word index + 1 (0 = empty)
+  __shared__ unsigned long long bits[MK_SLOTS];
+  for (int i = threadIdx.x; i < MK_SLOTS; i += 256) { keys[i] = 0ull; bits[i] = 0ull; }
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = min(*n_dev, n_cap);
+  if (i < n) {
+    const int4 c = coors[i];
+    for (int kz = 0; kz < cv.k[0]; ++kz) {
+      const int tz = c.y + cv.p[0] - kz;
+      if (tz < 0 || tz % cv.s[0]) continue;
+      const int oz = tz / cv.s[0];
+      if (oz >= g.Dz) continue;
+      for (int ky = 0; ky < cv.k[1]; ++ky) {
+        const int ty = c.z + cv.p[1] - ky;
+        if (ty < 0 || ty % cv.s[1]) continue;
+        const int oy = ty / cv.s[1];
+        if (oy >= g.Dy) continue;
+        for (int kx = 0; kx < cv.k[2]; ++kx) {
+          const int tx = c.w + cv.p[2] - kx;
+          if (tx < 0 || tx % cv.s[2]) continue;
+          const int ox = tx / cv.s[2];
+          if (ox >= g.Dx) continue;
+          const unsigned long long w = (unsigned long long)u3d_word_index(g, c.x, oz, oy, ox);
+          const unsigned long long bit = 1ull << u3d_bit_index(g, c.x, oz, oy, ox);
+          unsigned h = (unsigned)((w * 0x9E3779B97F4A7C15ull) >> 55) & (MK_SLOTS - 1);
+          bool done = false;
+          for (int probe = 0; probe < 16 && !done; ++probe) {
+            const unsigned long long prev = atomicCAS(&keys[h], 0ull, w + 1ull);
+            if (prev == 0ull || prev == w + 1ull) { atomicOr(&bits[h], bit); done = true; }
+            else h = (h + 1) & (MK_SLOTS - 1);
+          }
+          if (!done) atomicOr(&words[w], bit);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < MK_SLOTS; j += 256) {
+    const unsigned long long k = keys[j];
+    if (k) atomicOr(&words[k - 1ull], bits[j]);
+  }
+}
+
 extern "C" int32_t u3d_bitgrid_mark_strided(const u3d_bitgrid* g, const int32_t* in_coors, const int32_t* n_dev,
                                             int32_t n_cap, const int32_t ksize[3], const int32_t stride[3],
                                             const int32_t pad[3], u3d_stream s) {
@@ -70,8 +123,16 @@ extern "C" int32_t u3d_bitgrid_mark_strided(const u3d_bitgrid* g, const int32_t*
   Conv3 cv;
   for (int i = 0; i < 3; ++i) { cv.k[i] = ksize[i]; cv.s[i] = stride[i]; cv.p[i] = pad[i]; U3D_REQUIRE(stride[i] > 0 && ksize[i] > 0, U3D_ERR_ARG); }
   BitGridDev d = u3d_make_grid(g);
+#ifndef BITGRID_MARK_AGG
+#define BITGRID_MARK_AGG 1
+#endif
+#if BITGRID_MARK_AGG
+  hipLaunchKernelGGL(k_bitgrid_mark_strided_agg, dim3(u3d_cdiv(n_cap, 256)), dim3(256), 0, s, d,
+                     (unsigned long long*)g->words, (const int4*)in_coors, n_dev, n_cap, cv);
+#else
   hipLaunchKernelGGL(k_bitgrid_mark_strided, dim3(u3d_cdiv(n_cap, 256)), dim3(256), 0, s, d,
                      (unsigned long long*)g->words, (const int4*)in_coors, n_dev, n_cap, cv);
+#endif
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
