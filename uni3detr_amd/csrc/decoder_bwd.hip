@@ -359,6 +359,9 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
       f32x4 ds;
 #pragma unroll
       for (int j = 0; j < 4; ++j) ds[j] = dc_round(dgt[j] * gate);
+      float dsc[4];                                                  // the same d(sample) values, channel j*64 + lane
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dsc[j] = dc_round(G[row * DC_TS + j * 64 + lane] * gate);
       DcCorners tc;
       dc_corners(misc + row * DC_MISC_LD, min(gr, M - 1) / dm.qps, dm.dz, dm.dy, dm.dx, tc);
       float gx = 0.f, gy = 0.f, gz = 0.f;
@@ -366,9 +369,12 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
 #pragma unroll
         for (int c = 0; c < 8; ++c)
           if (tc.row[c] >= 0) {
-            float* dvp = dvalue + (size_t)tc.row[c] * DC_C + lane * 4;
+            // lane l adds channels l, l + 64, l + 128, l + 192: one atomic instruction then covers 64 CONSECUTIVE floats (two cache
+            // lines) - with the MFMA-side mapping (channels 4l .. 4l+3) each of the four instructions touched all eight lines of
+            // the row, and the L2 atomic unit works a line at a time (125 of this kernel's 316 us were these atomics)
+            float* dvr = dvalue + (size_t)tc.row[c] * DC_C + lane;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(dvp + j, tc.w[c] * ds[j]);
+            for (int j = 0; j < 4; ++j) atomicAdd(dvr + j * 64, tc.w[c] * dsc[j]);
             if (dm.need_dref) {
               const f32x4 val = dc_unpack4(*(const u16x4*)(value + (size_t)tc.row[c] * DC_C + lane * 4));
               const float dot = val[0] * ds[0] + val[1] * ds[1] + val[2] * ds[2] + val[3] * ds[3];
