@@ -129,12 +129,35 @@ __global__ __launch_bounds__(256) void k_col_stats_vec(const T* __restrict__ x, 
       }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * ncol; i += 256) {
-      int which = i / ncol, col = i % ncol;
-      if (cb * V + col < c) {
+    // sum over the rl row lanes in a FIXED order.  Narrow tensors (16 / 32 channels: rl = 64 ... 128) used to leave this to 2*ncol
+    // threads walking rl values each (~8 k clk for 32 outputs: these launches took 12-17 us whatever their bytes); now NP threads
+    // per output take every NP-th row lane, and the NP sums are added in order
+    const int NP = rl >= 32 ? 8 : 1;                  // wide tensors (rl <= 16): the short walk is cheaper than a second LDS stage + its footprint
+    if (NP > 1) {
+      double* red2 = red + 2 * rl * ncol;             // [NP][2*ncol]
+      for (int i = threadIdx.x; i < 2 * ncol * NP; i += 256) {
+        const int o = i % (2 * ncol), pp = i / (2 * ncol), which = o / ncol, col = o % ncol;
         double a = 0.0;
-        for (int j = 0; j < rl; ++j) a += red[(which * rl + j) * ncol + col];
-        partial[((long long)blockIdx.x * 2 + which) * c + cb * V + col] = a;
+        for (int j = pp; j < rl; j += NP) a += red[(which * rl + j) * ncol + col];
+        red2[pp * 2 * ncol + o] = a;
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < 2 * ncol; i += 256) {
+        const int which = i / ncol, col = i % ncol;
+        if (cb * V + col < c) {
+          double a = 0.0;
+          for (int pp = 0; pp < NP; ++pp) a += red2[pp * 2 * ncol + i];
+          partial[((long long)blockIdx.x * 2 + which) * c + cb * V + col] = a;
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < 2 * ncol; i += 256) {
+        int which = i / ncol, col = i % ncol;
+        if (cb * V + col < c) {
+          double a = 0.0;
+          for (int j = 0; j < rl; ++j) a += red[(which * rl + j) * ncol + col];
+          partial[((long long)blockIdx.x * 2 + which) * c + cb * V + col] = a;
+        }
       }
     }
     __syncthreads();
@@ -255,7 +278,7 @@ static int run_stats(const void* x, const void* dy, const void* y, const float* 
   if (dtype == U3D_F32) {
     if (c % 4 == 0 && pal) {
       int cw = (c / 4) < 256 ? (c / 4) : 256; int rl = 256 / cw;
-      size_t lds = (size_t)2 * rl * cw * 4 * sizeof(double);
+      size_t lds = (size_t)2 * (rl + (rl >= 32 ? 8 : 0)) * cw * 4 * sizeof(double);
       hipLaunchKernelGGL((k_col_stats_vec<float, MODE>), dim3(nb), dim3(256), lds, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws, row_map, rpb);
     } else {
       hipLaunchKernelGGL((k_col_stats<float, MODE>), dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)dy, (const float*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws, rpb);
@@ -263,7 +286,7 @@ static int run_stats(const void* x, const void* dy, const void* y, const float* 
   } else if (dtype == U3D_BF16) {
     if (c % 8 == 0 && pal) {
       int cw = (c / 8) < 256 ? (c / 8) : 256; int rl = 256 / cw;
-      size_t lds = (size_t)2 * rl * cw * 8 * sizeof(double);
+      size_t lds = (size_t)2 * (rl + (rl >= 32 ? 8 : 0)) * cw * 8 * sizeof(double);
       hipLaunchKernelGGL((k_col_stats_vec<u16, MODE>), dim3(nb), dim3(256), lds, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws, row_map, rpb);
     } else {
       hipLaunchKernelGGL((k_col_stats<u16, MODE>), dim3(nb), dim3(256), 0, s, (const u16*)x, (const u16*)dy, (const u16*)y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, (double*)ws, rpb);
@@ -546,7 +569,7 @@ extern "C" int32_t u3d_bn_forward_stats(const void* x, const int32_t* n_dev, int
     const int v = f32 ? 4 : 8;
     if (c % v == 0) {
       int cw = (c / v) < 256 ? (c / v) : 256; int rl = 256 / cw;
-      size_t lds = (size_t)2 * rl * cw * v * sizeof(double);
+      size_t lds = (size_t)2 * (rl + (rl >= 32 ? 8 : 0)) * cw * v * sizeof(double);
       if (f32) hipLaunchKernelGGL((k_col_stats_vec<float, 0>), dim3(nb), dim3(256), lds, s, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace, (const int*)nullptr, rpb);
       else hipLaunchKernelGGL((k_col_stats_vec<u16, 0>), dim3(nb), dim3(256), lds, s, (const u16*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_dev, n_cap, c, (double*)workspace, (const int*)nullptr, rpb);
     } else {
