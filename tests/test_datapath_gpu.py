@@ -182,3 +182,53 @@ def test_full_size_batch_properties(cuda):
     lo, hi = np.array(RANGE[:3], np.float32), np.array(RANGE[3:], np.float32)
     assert s.shape == (160000, 4) and (s[:, :3] > lo).all() and (s[:, :3] < hi).all()
     assert len(np.unique(s[:20000], axis=0)) == 20000
+
+
+def test_device_pipeline_feeds_the_captured_training_step(cuda):
+    """The flow INTEGRATION.md describes: raw scenes -> device pipeline (flip / rot-scale / range filter / PointSample) -> set_batch ->
+    graph replay, with a different augmented batch every iteration (ref: extra_tools/train.py:204-254 with the config's train_pipeline)."""
+    import copy
+    import projects.mmdet3d_plugin  # noqa: F401
+    from uni3detr_amd import datapath as dp
+    from uni3detr_amd.configs.sunrgbd import model as MODEL_CFG
+    from uni3detr_amd.registry import build_model
+    from uni3detr_amd.synth import room_scene
+    from uni3detr_amd.trainer import TrainStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = build_model(copy.deepcopy(MODEL_CFG)).to(dev).train().set_precision("bf16")
+    pipe = dp.DevicePipeline([
+        dict(type="RandomFlip3D", sync_2d=False, flip_ratio_bev_horizontal=0.5),
+        dict(type="GlobalRotScaleTrans", rot_range=[-0.523599, 0.523599], scale_ratio_range=[0.85, 1.15], shift_height=True),
+        dict(type="PointsRangeFilter", point_cloud_range=RANGE),
+        dict(type="PointSample", num_points=12000),
+    ])
+
+    def raw(i):                                            # two raw scenes of different sizes (30 k / 42 k points) + their boxes
+        P, G, L = [], [], []
+        for j, n in enumerate((30000, 42000)):
+            p, g, l = room_scene(100 * i + j, n)
+            gb = torch.from_numpy(g).clone()
+            gb[:, 2] -= gb[:, 5] / 2
+            P.append(torch.from_numpy(p).to(dev)); G.append(gb.to(dev)); L.append(torch.from_numpy(l).to(dev))
+        return P, G, L
+
+    def batch(i):
+        P, G, L = raw(i)
+        b = pipe(dp.pack_batch(P, G))
+        return dp.unpack_batch(b, L), b
+
+    (p0, g0, l0), b0 = batch(0)
+    assert [int(p.shape[0]) for p in p0] == [12000, 12000] and all(int(g.tensor.shape[0]) == 8 for g in g0)
+    ts = TrainStep(model, p0, g0, l0, graph=True, lr=1e-4)
+    ts.capture(batches=[(p0, g0, l0), batch(1)[0]])
+    losses, angles = [], [b0["pcd_rotation_angle"].copy()]
+    for i in range(2, 5):
+        (p, g, l), b = batch(i)
+        angles.append(b["pcd_rotation_angle"].copy())
+        ts.set_batch(p, g, l)
+        losses.append(float(ts.step()))
+    assert all(np.isfinite(v) and 0 < v < 1e4 for v in losses), losses
+    assert len({tuple(np.round(a, 6)) for a in angles}) == len(angles)            # a new draw every iteration
+    assert ts.recaptures == 0

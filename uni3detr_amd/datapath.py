@@ -201,3 +201,21 @@ def pack_batch(points, gt_bboxes_3d=None, box_type_3d="Depth", height_dim=3):
         batch["gt_bboxes_3d"] = (torch.cat([g.float() for g in gt_bboxes_3d]).contiguous() if sum(gl)
                                  else torch.zeros((0, dim), dtype=torch.float32, device=dev))
     return batch
+
+
+def unpack_batch(batch, labels=None):
+    """batch dict -> (points list, Boxes3D list[, labels list]) as `Uni3DETR.forward_train` / `TrainStep.set_batch` take them
+    (views of the packed tensors: no copies)."""
+    from .plugin.structures import Boxes3D
+    off = batch["scene_off"].tolist()
+    pts = [batch["points"][off[b]:off[b + 1]] for b in range(len(off) - 1)]
+    if "count" in batch:
+        cnt = batch["count"].tolist()
+        pts = [p[:c] for p, c in zip(pts, cnt)]
+    out = [pts]
+    if "gt_bboxes_3d" in batch:
+        go = batch["gt_off"].tolist()
+        out.append([Boxes3D(batch["gt_bboxes_3d"][go[b]:go[b + 1]]) for b in range(len(go) - 1)])
+    if labels is not None:
+        out.append(labels)
+    return tuple(out)
