@@ -736,3 +736,37 @@ def test_skinny_weight_gradients_batched_equal_single_launches(cuda):
         dw = p.sum(0).view(d.shape[1], x.shape[1])
         ref = d.float().t() @ x.float()
         assert (dw - ref).abs().max() / ref.abs().max() < 1e-4
+
+
+def test_conv_weight_gradient_in_flat_view_and_shared_weight(cuda):
+    """TrainStep hands every parameter a view of the flat gradient buffer (`_u3d_grad_view`): a conv writes its weight gradient
+    there in place when the weight is used ONCE in the step; a weight used twice must fall back to fresh tensors (autograd adds them)."""
+    import torch
+    from uni3detr_amd import sparse as sp
+    lvl, _ = _level(seed=11, n_pts=4000)
+    geom = sp.subm_geom(lvl)
+    torch.manual_seed(1)
+    x = torch.randn(lvl.n, 32, device="cuda").bfloat16().requires_grad_(True)
+    w = torch.nn.Parameter(torch.randn(3, 3, 3, 32, 32, device="cuda") * 0.05)
+    flat = torch.zeros(w.numel() + 64, device="cuda")
+    w._u3d_grad_view = flat[64:].view_as(w)
+    # single use: the gradient IS the view
+    sp.reset_conv_uses()
+    y = sp.sparse_conv(x, w, geom)
+    y.float().square().sum().backward()
+    assert w.grad.data_ptr() == w._u3d_grad_view.data_ptr()
+    g1 = w.grad.clone()
+    assert torch.equal(flat[64:].view_as(w), g1) and (flat[:64] == 0).all()
+    # two uses in one step: grad = sum of both, not an aliased overwrite
+    w.grad = None; x.grad = None
+    flat.zero_()
+    sp.reset_conv_uses()
+    y2 = sp.sparse_conv(sp.sparse_conv(x, w, geom), w, geom)
+    y2.float().square().sum().backward()
+    got = w.grad.clone()
+    w.grad = None; x.grad = None
+    del w._u3d_grad_view
+    sp.reset_conv_uses()
+    y3 = sp.sparse_conv(sp.sparse_conv(x, w, geom), w, geom)
+    y3.float().square().sum().backward()
+    assert torch.equal(got, w.grad)

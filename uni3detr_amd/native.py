@@ -347,24 +347,35 @@ class KernelTimer:
         self.targets, self.per_step, self.counter, self.marks = set(targets), per_step, 0, {}
 
     def begin(self):
+        if self.mode == "off":
+            return None
         if self.mode == "mark":
             i = self.counter % self.per_step if self.per_step else self.counter
             self.counter += 1
             if i not in self.targets:
                 return None
-            e = ExternalEvent()
-            e.record()
+            try:
+                e = ExternalEvent()
+                e.record()
+            except U3DError:                  # no event-record nodes on this runtime: keep the capture alive, time nothing
+                self.mode, self.marks = "off", {}
+                return None
             return (i, e)
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         return e
 
     def end(self, tag, e0, meta=None):
+        if self.mode == "off":
+            return
         if self.mode == "mark":
             if e0 is not None:
-                e1 = ExternalEvent()
-                e1.record()
-                self.marks[e0[0]] = (tag, e0[1], e1)          # the latest recording wins: the captured one
+                try:
+                    e1 = ExternalEvent()
+                    e1.record()
+                    self.marks[e0[0]] = (tag, e0[1], e1)      # the latest recording wins: the captured one
+                except U3DError:
+                    self.mode, self.marks = "off", {}
             return
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()

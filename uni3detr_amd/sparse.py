@@ -124,6 +124,13 @@ def wgrad_side_stream():
         _WG["pending"].clear()
 
 
+_CONV_USES = {}          # id(conv weight) -> forward uses since reset_conv_uses() (TrainStep resets it at the top of every step)
+
+
+def reset_conv_uses():
+    _CONV_USES.clear()
+
+
 class _SparseConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, weight, geom, layout, want_stats=False, res_token=None):
@@ -142,7 +149,11 @@ class _SparseConv(torch.autograd.Function):
         kio, koi = conv_weights(weight, layout, feats.dtype, want_koi=nmajor)
         ctx.geom, ctx.layout = geom, layout
         ctx.res_token = res_token
-        ctx.grad_view = getattr(weight, "_u3d_grad_view", None)      # TrainStep: this parameter's slice of the flat gradient buffer
+        # TrainStep: this parameter's slice of the flat gradient buffer - written in place by the backward ONLY if this is the
+        # weight's single use in the step (a weight used twice gets two gradients that autograd must add: it may not alias them)
+        _CONV_USES[id(weight)] = _CONV_USES.get(id(weight), 0) + 1
+        ctx.weight_id = id(weight)
+        ctx.grad_view = getattr(weight, "_u3d_grad_view", None)
         ctx.save_for_backward(feats, kio)
         ctx.kio_shape, ctx.wdtype = kio_shape, weight.dtype
         nbr = geom.nbr_fwd if kio.shape[0] > 1 else None
@@ -186,7 +197,7 @@ class _SparseConv(torch.autograd.Function):
             # the reduction stage can write the parameter's own layout straight into its slice of the flat gradient buffer (out=):
             # autograd keeps that view as .grad and the step's packing copy has nothing to move for this parameter
             gv = ctx.grad_view if (v2 and ctx.grad_view is not None and ctx.grad_view.is_contiguous()
-                                   and ctx.grad_view.dtype == torch.float32) else None
+                                   and ctx.grad_view.dtype == torch.float32 and _CONV_USES.get(ctx.weight_id, 0) == 1) else None
             if ctx.layout == "oidhw" and v2:
                 # nn.Conv3d's own [Cout,Cin,kD,kH,kW] layout: autograd keeps the tensor as the gradient
                 ks = ctx.kio_shape

@@ -156,6 +156,7 @@ class TrainStep:
     def _stage1(self):
         m = self.model
         _T.reset_param_uses()
+        _sp.reset_conv_uses()
         with m.shadow_scope():
             feat, fps = m.extract_pts_feat(self.pts)
             if EARLY_FLUSH and torch.is_tensor(feat) and feat.requires_grad:
