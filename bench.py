@@ -267,11 +267,29 @@ def main():
                 for i, ms in mark_ms.items():
                     calls[i]["ms_eager"] = calls[i]["ms"]
                     calls[i]["ms"] = ms
-                j = max(mark_ms, key=lambda i: mark_ms[i])
-                timing = f"hip event-record nodes inside the replayed hipGraph, mean of {MARK_REPLAYS} replays"
+                # the marked launches are the heaviest shape (equal flops) of TWO kernels: k_igemm_glds (forward / input gradient)
+                # and k_igemm_wgrad_glds.  The dominant kernel is the one with more time per step over all of its launches; it is
+                # priced at the AVERAGE duration of its marked launches (the contract's "average launch duration"); the slowest
+                # marked launch of either kernel is reported beside it
+                def klass(x):
+                    return "wgrad" if "wgrad" in x["tag"] else "fwd"
+                tot = {}
+                for x in calls:
+                    if x.get("v2"):
+                        tot[klass(x)] = tot.get(klass(x), 0.0) + x["ms"]
+                dom = max(tot, key=tot.get)
+                mine = [i for i in mark_ms if klass(calls[i]) == dom] or list(mark_ms)
+                j = max(mine, key=lambda i: mark_ms[i])
+                dom_mean_ms = float(np.mean([mark_ms[i] for i in mine]))
+                timing = (f"hip event-record nodes inside the replayed hipGraph, mean over the {len(mine)} launches of this shape per step "
+                          f"x {MARK_REPLAYS} replays")
             else:
                 j = int(np.argmax([x["ms"] for x in calls]))
-            h = calls[j]
+                dom_mean_ms = None
+            h = dict(calls[j])
+            slowest_ms = max(mark_ms.values()) if mark_ms else h["ms"]
+            if dom_mean_ms is not None:
+                h["ms"] = dom_mean_ms
             ai = h["flops"] / h["bytes"]
             peak_tf = MFMA_PEAK_TF[out["dtype"]]
             if ai > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
@@ -288,6 +306,7 @@ def main():
                           f"Cin={h['cin']}, Cout={h['cout']}, K={h['kvol']}, pairs={h['pairs']}]",
                 "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
                 "launch_ms": h["ms"], "launch_timing": timing,
+                "frac_slowest_marked_launch": (h["flops"] / (slowest_ms * 1e-3) / 1e12 / peak if bound == "mfma" else None),
                 "frac_mean_of_heaviest_launches": (float(np.mean([h["flops"] / (ms * 1e-3) / 1e12 for ms in mark_ms.values()])) / peak if mark_ms else None),
                 "heaviest_launches_ms": ({calls[i]["tag"] + f"#{i}": round(ms, 4) for i, ms in sorted(mark_ms.items())} if mark_ms else None),
                 "algorithmic_bytes": h["bytes"], "flops": h["flops"], "arithmetic_intensity": ai,
