@@ -668,6 +668,228 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
 #include "glds_epilogue.inc"
 }
 
+// =============================================================================================
+// 256 x 256 tile, EIGHT-PHASE schedule (two k-tiles of 64 = one trip through both LDS buffers; 4 phases per k-tile).
+//
+// igemm_glds_body walks all eight waves through a k-tile together: 24 fragment reads, 8 LDS-DMA instructions and 64 MFMAs per wave
+// between two __syncthreads() that drain vmcnt - the two waves of a SIMD are always in the same part of the stage, and the LDS-DMA
+// instructions (the 35 % its ablation prices) sit among the MFMAs of the wave that issues them.  Here (the schedule the CDNA4
+// guide's 256^2 template describes) a k-tile is four PHASES of 16 MFMAs (one 64 x 32 quadrant of the wave's 128 x 64 block, both
+// k-steps), each phase = a LOAD segment (the phase's fragment reads + 2 LDS-DMA instructions of the next k-tile + a COUNTED vmcnt
+// wait) | s_barrier | an MFMA segment (16 MFMAs at raised priority) | s_barrier, and the two wave rows (wm = 0 / 1: one wave of
+// each per SIMD) run ONE barrier apart: while one wave of a SIMD is in its MFMA segment its partner is in its load segment.
+//
+// LDS image of a k-tile = four 16 KiB pieces, each exactly what one load segment reads: A0 / A1 = the first / second 64 rows of
+// BOTH wave rows, B0 / B1 = the first / second 32 columns of all four wave columns.  Phase p reads: 1: A0 + B0, 2: B1, 3: A1, 4: -
+// (B0 stays in registers for the last quadrant) and requests for the NEXT k-tile: 1: A0, 2: B0, 3: B1, 4: A1 (+ the gather
+// indices two k-tiles ahead, requested first thing in phase 1 and consumed at the end of phase 4).  vmcnt is in order, so
+// "everything up to piece X has landed" is one count: at the end of the load segments 1 and 2 exactly 8 younger requests are
+// allowed in flight (2 pieces x 2 + 4 index loads), at the end of segment 4 four (B1, A1) - which retires B1 / A1 /
+// A0 + B0 one barrier before their first reader - two barriers for the wave row that runs behind.  Nothing waits for vmcnt(0)
+// inside the loop.  Rows / swizzle / fragment layout / epilogue as igemm_glds_body.
+// =============================================================================================
+#ifndef IGEMM_GLDS8
+#define IGEMM_GLDS8 1
+#endif
+#ifndef GLDS8_PRIO
+#define GLDS8_PRIO 1
+#endif
+__device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
+                                                 int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
+                                                 int cin, int cout, int kvol, const float* __restrict__ bias, int relu,
+                                                 double* __restrict__ stats) {
+  constexpr int WAVES_M = 2, WAVES_N = 4, WM = 8, WN = 4, NW = 8;
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int PIECE = 128 * BK;                         // elements of one piece (16 KiB)
+  constexpr int STAGE_ELEMS = 4 * PIECE;                  // A0 | A1 | B0 | B1
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+
+  const int n_out = min(*n_out_dev, n_out_cap);
+  const int ntile = gridDim.x;
+  const int xq = ntile >> 3, xr = ntile & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+  const int m0 = tile * BM;
+  if (m0 >= n_out) return;
+  const int col0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+  const int nstage = kvol * (cin / BK);
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, -1, 0x00020000);
+  const unsigned row_bytes = (unsigned)cin * 2u;
+  // loader role: LDS-DMA instruction u (0 / 1) of this wave fills piece rows (wv*2+u)*8 .. +7; lane = (row in group, 16-byte slot)
+  const int lrow = lane >> 3, lslot = lane & 7;
+  unsigned a_part16[2], w_voff[2][2];                     // [u], [piece t][u]
+  int arow[2][2];                                         // tile row of (piece s, u)
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = (wv * 2 + u) * 8 + lrow;                // piece row 0..127
+    a_part16[u] = (unsigned)(lslot ^ ((r >> 1) & 7)) * 16u;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      arow[sp][u] = (r < 64) ? sp * 64 + r : 128 + sp * 64 + (r - 64);
+      const int tc = (r >> 5) * 64 + sp * 32 + (r & 31);  // piece B_sp row r = tile column tc
+      w_voff[sp][u] = (col0 + tc < cout) ? (unsigned)((col0 + tc) * cin + (lslot ^ ((r >> 1) & 7)) * 8) * 2u : 0xFFFFFFFFu;
+    }
+  }
+  int idx_cur[2][2], idx_nxt[2][2];
+  // (needs a neighbour table: the plain GEMM callers, nbr == nullptr, stay on igemm_glds_body)
+  int mcl[2][2];
+#pragma unroll
+  for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + arow[sp][u];
+      mcl[sp][u] = m < n_out ? m : n_out - 1;
+      idx_nxt[sp][u] = mcl[sp][u];
+    }
+  // the loads must land in the loop-carried registers themselves: a copy at the loop's back edge needs the value, i.e. a
+  // vmcnt(0) per k-tile (what hipcc emitted with a select or a branch "nbr ? load : m" between the load and the variable)
+  // Requested at the top of phase 1 and consumed at the end of phase 4 of the SAME loop trip: a load pending across the back
+  // edge made hipcc copy the register there, i.e. wait vmcnt(0) once per k-tile.  Between the request and advance_idx() lie
+  // exactly the 8 LDS-DMA requests of the trip: the wait hipcc inserts for the indices is the vmcnt(8) the schedule wants.
+  auto load_idx_next = [&](int stage) {
+    const int* row = nbr + (long long)(stage % kvol) * ld;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) idx_nxt[sp][u] = row[mcl[sp][u]];
+  };
+  auto advance_idx = [&]() {
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) idx_cur[sp][u] = (m0 + arow[sp][u] < n_out) ? idx_nxt[sp][u] : -1;
+  };
+  auto issue_a = [&](int st, int buf, int sp) {           // piece A_sp of k-tile st
+    const unsigned soff = (unsigned)((st / kvol) * BK) * 2u;
+    u16* dst = smem + buf * STAGE_ELEMS + sp * PIECE + wv * 1024;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const unsigned voff = idx_cur[sp][u] >= 0 ? (unsigned)idx_cur[sp][u] * row_bytes + a_part16[u] : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void_ptr)(dst + u * 512), 16, voff, soff, 0, 0);
+    }
+  };
+  auto issue_b = [&](int st, int buf, int sp) {           // piece B_sp of k-tile st
+    const unsigned soff = (unsigned)((st % kvol) * cin * cout + (st / kvol) * BK) * 2u;
+    u16* dst = smem + buf * STAGE_ELEMS + (2 + sp) * PIECE + wv * 1024;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_ptr)(dst + u * 512), 16, w_voff[sp][u], soff, 0, 0);
+  };
+  const int g = lane >> 4, li = lane & 15, fsw = (lane >> 1) & 7;
+  int foff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) foff[ks] = ((ks * 4 + g) ^ fsw) << 3;
+  typedef const volatile s16x8 __attribute__((address_space(3))) * lds_vptr;
+  auto frag = [&](const u16* rowp, int ks) {
+    s16x8 v = *(lds_vptr)(rowp + foff[ks]);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  bf16x8 af[4][2], bf[2][2][2];                           // A: [row block][k-step] of the current half; B: [half][col block][k-step]
+#define G8_READ_A(BUF, SP)                                                                                   \
+  {                                                                                                          \
+    const u16* A_ = smem + (BUF) * STAGE_ELEMS + (SP) * PIECE + (wm * 64 + li) * BK;                         \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                          \
+      af[a][0] = frag(A_ + a * 16 * BK, 0);                                                                  \
+      af[a][1] = frag(A_ + a * 16 * BK, 1);                                                                  \
+    }                                                                                                        \
+  }
+#define G8_READ_B(BUF, SP)                                                                                   \
+  {                                                                                                          \
+    const u16* B_ = smem + (BUF) * STAGE_ELEMS + (2 + (SP)) * PIECE + (wn * 32 + li) * BK;                   \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                          \
+      bf[SP][b][0] = frag(B_ + b * 16 * BK, 0);                                                              \
+      bf[SP][b][1] = frag(B_ + b * 16 * BK, 1);                                                              \
+    }                                                                                                        \
+  }
+#define G8_MMA(SA, SB)                                                                                       \
+  {                                                                                                          \
+    __builtin_amdgcn_s_setprio(GLDS8_PRIO);                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                          \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                        \
+          acc[(SA) * 4 + a][(SB) * 2 + b] =                                                                  \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[SB][b][ks], af[a][ks], acc[(SA) * 4 + a][(SB) * 2 + b], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+  }
+#define G8_BAR()                                  \
+  {                                               \
+    __builtin_amdgcn_sched_barrier(0);            \
+    __builtin_amdgcn_s_barrier();                 \
+    __builtin_amdgcn_sched_barrier(0);            \
+  }
+#define G8_VMCNT8() __builtin_amdgcn_s_waitcnt(0x0F78)    /* vmcnt(8): expcnt / lgkmcnt untouched */
+
+  // prologue: indices of k-tiles 0, 1, 2; all four pieces of k-tile 0; everything landed before the first read
+  load_idx_next(0);
+  advance_idx();
+  issue_a(0, 0, 0); issue_b(0, 0, 0); issue_b(0, 0, 1); issue_a(0, 0, 1);
+  load_idx_next(1 < nstage ? 1 : 0);
+  advance_idx();
+  __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+  G8_BAR();
+  if (wm == 1) G8_BAR();                                  // the second wave row runs one barrier behind the first
+  for (int st = 0; st < nstage; ++st) {
+    const int buf = st & 1;
+    const int nx = st + 1 < nstage ? st + 1 : st;         // past the end: a harmless re-fetch into the buffer nobody reads again
+    // ---- phase 1: quadrant (rows 0-63, cols 0-31)
+    load_idx_next(st + 2 < nstage ? st + 2 : nstage - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    G8_READ_B(buf, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    G8_READ_A(buf, 0)
+    issue_a(nx, buf ^ 1, 0);
+    G8_VMCNT8();                                          // B1 of this k-tile has landed (every wave's share after the barrier)
+    G8_BAR();
+    G8_MMA(0, 0)
+    G8_BAR();
+    // ---- phase 2: (rows 0-63, cols 32-63)
+    G8_READ_B(buf, 1)
+    issue_b(nx, buf ^ 1, 0);
+    G8_VMCNT8();                                          // A1 of this k-tile
+    G8_BAR();
+    G8_MMA(0, 1)
+    G8_BAR();
+    // ---- phase 3: (rows 64-127, cols 32-63)
+    G8_READ_A(buf, 1)
+    issue_b(nx, buf ^ 1, 1);
+    G8_BAR();
+    G8_MMA(1, 1)
+    G8_BAR();
+    // ---- phase 4: (rows 64-127, cols 0-31): B0 is still in registers
+    issue_a(nx, buf ^ 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    advance_idx();                                        // (hipcc waits vmcnt(8) here: the indices requested in phase 1)
+    __builtin_amdgcn_s_waitcnt(0x0F74);                   // vmcnt(4): A0 and B0 of the next k-tile
+    G8_BAR();
+    G8_MMA(1, 0)
+    G8_BAR();
+  }
+  if (wm == 0) G8_BAR();                                  // same number of barriers for both wave rows
+  __builtin_amdgcn_s_waitcnt(0x0F70);                     // the tail's re-fetch requests: landed before the epilogue reuses the buffers
+  __syncthreads();
+#undef G8_READ_A
+#undef G8_READ_B
+#undef G8_MMA
+#undef G8_BAR
+#undef G8_VMCNT8
+#include "glds_epilogue.inc"
+}
+__global__ __launch_bounds__(512) void k_igemm_glds8_256x256(const u16* in, const u16* w, const int* nbr, int ld, u16* out,
+                                                             const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,
+                                                             const float* bias, int relu, double* stats) {
+  igemm_glds8_body(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats);
+}
+
 // concrete kernels (a __global__ TEMPLATE with this body lost its host stub under hipcc 7.2: undefined symbol at load time)
 #define U3D_GLDS_KERNEL(NAME, A, B, C, D)                                                                                        \
   __global__ __launch_bounds__(A* B * 64) void NAME(const u16* in, const u16* w, const int* nbr, int ld, u16* out,               \
@@ -691,7 +913,7 @@ static int launch_igemm_glds(const void* in, const void* w, const int32_t* nbr, 
                              double* stats = nullptr) {
   constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
   constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;        // 256 x 256: 128 KiB
-  glds_kernel_t kern = (BM == 256 && BN == 256) ? k_igemm_glds_256x256
+  glds_kernel_t kern = (BM == 256 && BN == 256) ? ((IGEMM_GLDS8 && nbr) ? k_igemm_glds8_256x256 : k_igemm_glds_256x256)
                        : (BM == 256 ? k_igemm_glds_256x128 : (BN == 128 ? k_igemm_glds_128x128 : k_igemm_glds_128x64));
   if (lds > 64 * 1024) U3D_ALLOW_LDS(kern, lds);      // one call site per template instantiation: per-kernel, per-device
   dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
