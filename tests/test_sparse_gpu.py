@@ -770,3 +770,38 @@ def test_conv_weight_gradient_in_flat_view_and_shared_weight(cuda):
     y3 = sp.sparse_conv(sp.sparse_conv(x, w, geom), w, geom)
     y3.float().square().sum().backward()
     assert torch.equal(got, w.grad)
+
+
+def test_eight_phase_kernel_bit_identical_to_the_128_tile_kernel_and_stable_under_load(cuda):
+    """The 256 x 256 eight-phase kernel (counted vmcnt, raw barriers, wave rows one barrier apart: a schedule whose failure mode is a RARE
+    stale tile) against the 128 x 128-tile kernel with its one __syncthreads() per k-tile, at the full size of the dominant layer and on a
+    ragged row count: both feed the MFMAs the same k-groups in the same order, so every element must be BIT-identical - any tile read
+    before its LDS-DMA landed shows up as a difference.  Then 24 more launches while a second stream saturates HBM (load latencies move):
+    every result equal to the first."""
+    torch.manual_seed(11)
+    B, dims, C, ks = 8, (15, 40, 40), 256, (3, 3, 3)
+    n_full = B * dims[0] * dims[1] * dims[2]
+    nbr = nv.dense_nbr_table(B, dims, dims, ks, (1, 1, 1), (1, 1, 1), 0, cuda)
+    x = (torch.randn(n_full, C, device=cuda) * 0.5).bfloat16()
+    koi = (torch.randn(27, C, C, device=cuda) * 0.03).bfloat16()          # n-major [K][Cout][Cin]
+    halves = [koi[:, :128].contiguous(), koi[:, 128:].contiguous()]       # Cout = 128: served by the 128 x 128 tiles
+    for n in (n_full, n_full - 4321):                                     # the second: a partial last tile, rows past n never written
+        nd = nv.count_tensor(n, cuda)
+        y = nv.spconv_fwd(x, koi, nbr, nd, n_full, C, transpose_w=True, tag="spconv_fwd")
+        lo = nv.spconv_fwd(x, halves[0], nbr, nd, n_full, 128, transpose_w=True, tag="spconv_fwd")
+        hi = nv.spconv_fwd(x, halves[1], nbr, nd, n_full, 128, transpose_w=True, tag="spconv_fwd")
+        assert torch.equal(y[:n, :128], lo[:n]) and torch.equal(y[:n, 128:], hi[:n])
+    nd = nv.count_tensor(n_full, cuda)
+    first = nv.spconv_fwd(x, koi, nbr, nd, n_full, C, transpose_w=True, tag="spconv_fwd")
+    side = torch.cuda.Stream()
+    hog_a = torch.empty(256 << 20, dtype=torch.uint8, device=cuda)
+    hog_b = torch.empty_like(hog_a)
+    stop = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        for _ in range(60):
+            hog_b.copy_(hog_a, non_blocking=True)
+        stop.record()
+    for i in range(24):
+        again = nv.spconv_fwd(x, koi, nbr, nd, n_full, C, transpose_w=True, tag="spconv_fwd")
+        assert torch.equal(again, first), i
+    stop.synchronize()

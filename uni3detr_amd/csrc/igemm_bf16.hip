@@ -694,6 +694,12 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
 #ifndef GLDS8_PRIO
 #define GLDS8_PRIO 1
 #endif
+#ifndef GLDS8_BALANCE
+#define GLDS8_BALANCE 1     /* the next k-tile's first A half is read in phase 4 (second register set): 4 / 4 / 8 / 8 fragment reads per segment */
+#endif
+#ifndef GLDS8_STAGGER
+#define GLDS8_STAGGER 1     /* 0 (experiment): both wave rows in the same segment at the same time */
+#endif
 __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
                                                  int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
                                                  int cin, int cout, int kvol, const float* __restrict__ bias, int relu,
@@ -794,13 +800,19 @@ __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, con
     s16x8 v = *(lds_vptr)(rowp + foff[ks]);
     return __builtin_bit_cast(bf16x8, v);
   };
-  bf16x8 af[4][2], bf[2][2][2];                           // A: [row block][k-step] of the current half; B: [half][col block][k-step]
+#if GLDS8_BALANCE
+  bf16x8 af2[2][4][2], bf[2][2][2];                       // A: [half][row block][k-step]; B: [half][col block][k-step]
+#define G8_AF(SP) af2[SP]
+#else
+  bf16x8 af1[4][2], bf[2][2][2];                          // A: [row block][k-step] of the current half; B: [half][col block][k-step]
+#define G8_AF(SP) af1
+#endif
 #define G8_READ_A(BUF, SP)                                                                                   \
   {                                                                                                          \
     const u16* A_ = smem + (BUF) * STAGE_ELEMS + (SP) * PIECE + (wm * 64 + li) * BK;                         \
     _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                          \
-      af[a][0] = frag(A_ + a * 16 * BK, 0);                                                                  \
-      af[a][1] = frag(A_ + a * 16 * BK, 1);                                                                  \
+      G8_AF(SP)[a][0] = frag(A_ + a * 16 * BK, 0);                                                           \
+      G8_AF(SP)[a][1] = frag(A_ + a * 16 * BK, 1);                                                           \
     }                                                                                                        \
   }
 #define G8_READ_B(BUF, SP)                                                                                   \
@@ -818,7 +830,7 @@ __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, con
       _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                          \
         _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                        \
           acc[(SA) * 4 + a][(SB) * 2 + b] =                                                                  \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[SB][b][ks], af[a][ks], acc[(SA) * 4 + a][(SB) * 2 + b], 0, 0, 0); \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[SB][b][ks], G8_AF(SA)[a][ks], acc[(SA) * 4 + a][(SB) * 2 + b], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                           \
   }
 #define G8_BAR()                                  \
@@ -837,7 +849,10 @@ __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, con
   advance_idx();
   __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
   G8_BAR();
-  if (wm == 1) G8_BAR();                                  // the second wave row runs one barrier behind the first
+#if GLDS8_BALANCE
+  G8_READ_A(0, 0)                                         // phase 4 reads the NEXT k-tile's first row half: the first one here
+#endif
+  if (GLDS8_STAGGER && wm == 1) G8_BAR();                 // the second wave row runs one barrier behind the first
   for (int st = 0; st < nstage; ++st) {
     const int buf = st & 1;
     const int nx = st + 1 < nstage ? st + 1 : st;         // past the end: a harmless re-fetch into the buffer nobody reads again
@@ -845,8 +860,10 @@ __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, con
     load_idx_next(st + 2 < nstage ? st + 2 : nstage - 1);
     __builtin_amdgcn_sched_barrier(0);
     G8_READ_B(buf, 0)
+#if !GLDS8_BALANCE
     __builtin_amdgcn_sched_barrier(0);
     G8_READ_A(buf, 0)
+#endif
     issue_a(nx, buf ^ 1, 0);
     G8_VMCNT8();                                          // B1 of this k-tile has landed (every wave's share after the barrier)
     G8_BAR();
@@ -862,10 +879,16 @@ __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, con
     // ---- phase 3: (rows 64-127, cols 32-63)
     G8_READ_A(buf, 1)
     issue_b(nx, buf ^ 1, 1);
+#if GLDS8_BALANCE
+    __builtin_amdgcn_s_waitcnt(0x0F74);                   // vmcnt(4): A0 of the next k-tile (read in phase 4)
+#endif
     G8_BAR();
     G8_MMA(1, 1)
     G8_BAR();
     // ---- phase 4: (rows 64-127, cols 0-31): B0 is still in registers
+#if GLDS8_BALANCE
+    G8_READ_A(buf ^ 1, 0)                                 // 12 / 4 / 8 / 0 reads per segment -> 4 / 4 / 8 / 8
+#endif
     issue_a(nx, buf ^ 1, 1);
     __builtin_amdgcn_sched_barrier(0);
     advance_idx();                                        // (hipcc waits vmcnt(8) here: the indices requested in phase 1)
@@ -874,9 +897,10 @@ __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, con
     G8_MMA(1, 0)
     G8_BAR();
   }
-  if (wm == 0) G8_BAR();                                  // same number of barriers for both wave rows
+  if (GLDS8_STAGGER && wm == 0) G8_BAR();                 // same number of barriers for both wave rows
   __builtin_amdgcn_s_waitcnt(0x0F70);                     // the tail's re-fetch requests: landed before the epilogue reuses the buffers
   __syncthreads();
+#undef G8_AF
 #undef G8_READ_A
 #undef G8_READ_B
 #undef G8_MMA
