@@ -772,7 +772,7 @@ def test_conv_weight_gradient_in_flat_view_and_shared_weight(cuda):
     assert torch.equal(got, w.grad)
 
 
-def test_eight_phase_kernel_bit_identical_to_the_128_tile_kernel_and_stable_under_load(cuda):
+def test_eight_phase_kernels_against_the_128_tile_kernels_and_stable_under_load(cuda):
     """The 256 x 256 eight-phase kernel (counted vmcnt, raw barriers, wave rows one barrier apart: a schedule whose failure mode is a RARE
     stale tile) against the 128 x 128-tile kernel with its one __syncthreads() per k-tile, at the full size of the dominant layer and on a
     ragged row count: both feed the MFMAs the same k-groups in the same order, so every element must be BIT-identical - any tile read
@@ -805,3 +805,14 @@ def test_eight_phase_kernel_bit_identical_to_the_128_tile_kernel_and_stable_unde
         again = nv.spconv_fwd(x, koi, nbr, nd, n_full, C, transpose_w=True, tag="spconv_fwd")
         assert torch.equal(again, first), i
     stop.synchronize()
+    # the weight gradient on the same schedule (k_igemm_wgrad_glds8_256) against the 128-tile kernel (dout cut into two 128-channel
+    # halves), full and ragged row counts: the row split of the two plans differs, so f32 sums agree to rounding only - a single stale
+    # 64-row tile of the 3000 would be ~3e-4 of the scale
+    dy = (torch.randn(n_full, C, device=cuda) * 0.5).bfloat16()
+    dys = [dy[:, :128].contiguous(), dy[:, 128:].contiguous()]
+    for n in (n_full, n_full - 4321):
+        nd = nv.count_tensor(n, cuda)
+        dw = nv.spconv_wgrad(x, dy, nbr, nd, 27)
+        ref = torch.cat([nv.spconv_wgrad(x, d, nbr, nd, 27) for d in dys], dim=2)
+        assert (dw - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+        assert torch.equal(nv.spconv_wgrad(x, dy, nbr, nd, 27), dw)

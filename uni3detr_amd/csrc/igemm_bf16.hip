@@ -1828,6 +1828,31 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_wgrad(const u16
       }
 }
 
+// Workgroup (blockIdx.x, blockIdx.y) -> the (row split, offset) it works on.  The `kvol` workgroups of one row split read the
+// same `dout` rows and (offset-shifted) the same input rows, at about the same time: on ONE XCD they are fetched into that L2 once
+// and hit by the other offsets; dealt round-robin over the XCDs (hardware order: linear id % 8) every L2 streams the whole of both
+// tensors.  XCD x takes the splits x, x + 8, ... of the first 8 * floor(nsplit / 8); the workgroups of the remaining splits are
+// dealt round-robin (they keep every CU busy: 27 offsets x 9 splits = 243 workgroups, 8 of the 9 splits L2-local).
+#ifndef WGRAD_XCD_SPLITS
+#define WGRAD_XCD_SPLITS 1
+#endif
+__device__ __forceinline__ void wgrad_xcd_remap(int& split, int& kap, int nsplit, int kvol) {
+#if WGRAD_XCD_SPLITS
+  if (nsplit >= 8 && gridDim.z == 1) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7, slot = lin >> 3;
+    const int q8 = nsplit >> 3, aligned = q8 * kvol;      // slots of the XCD-local part
+    if (slot < aligned) {
+      split = xcd + 8 * (slot / kvol);
+      kap = slot % kvol;
+    } else {
+      const int rem = (slot - aligned) * 8 + xcd;
+      split = 8 * q8 + rem / kvol;
+      kap = rem % kvol;
+    }
+  }
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight gradient with LDS-DMA staging: both stage tiles ([64 rows][TM] gathered input rows, [64 rows][TN] dout rows) go global ->
 // LDS with `buffer_load_dwordx4 ... lds`, lane-linear, unpadded.  Transpose reads of an unpadded tile would put the 8 rows of a
@@ -1851,7 +1876,9 @@ __device__ __forceinline__ void igemm_wgrad_glds_body(const u16* __restrict__ in
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
 
   const int n_out = min(*n_out_dev, n_out_cap);
-  const int nsplit = gridDim.x, split = blockIdx.x, kap = kap_override >= 0 ? kap_override : (int)blockIdx.y;
+  const int nsplit = gridDim.x;
+  int split = blockIdx.x, kap = kap_override >= 0 ? kap_override : (int)blockIdx.y;
+  if (kap_override < 0) wgrad_xcd_remap(split, kap, nsplit, kvol);
   const int ci0 = (blockIdx.z / co_blocks) * TM, co0 = (blockIdx.z % co_blocks) * TN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2005,6 +2032,221 @@ __device__ __forceinline__ void igemm_wgrad_glds_body(const u16* __restrict__ in
       *(f32x4*)(p + (long long)ci * cout + co) = acc[a][b];
     }
 }
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 weight-gradient tile on the EIGHT-PHASE schedule of igemm_glds8_body (same segments, counts and barriers; read that
+// comment first).  What differs: the reduction index is the output ROW (64 per k-tile), both operands are [64 rows][256 channels]
+// tiles read with transpose reads, and a k-tile's four 16 KiB pieces are COLUMN ranges: A0 / A1 = the first / second 64 input
+// channels of both wave rows (128 columns, 256 B per row), D0 / D1 = the first / second 32 output channels of all four wave
+// columns.  One LDS-DMA instruction = 4 rows x 256 B; 16-column tile T of piece row r sits at position T ^ (r & 7).  The two A
+// pieces gather the SAME 64 rows: two index registers per lane.  Needs a neighbour table (the batched linear-layer form stays on
+// igemm_wgrad_glds_body).
+// ---------------------------------------------------------------------------------------------
+#ifndef IGEMM_WGRAD_GLDS8
+#define IGEMM_WGRAD_GLDS8 1
+#endif
+__device__ __forceinline__ void igemm_wgrad_glds8_body(const u16* __restrict__ in, const u16* __restrict__ dout,
+                                                       const int* __restrict__ nbr, int ld, float* __restrict__ partial,
+                                                       const int* __restrict__ n_out_dev, int n_out_cap, int cin, int cout, int kvol,
+                                                       int co_blocks) {
+  constexpr int WAVES_N = 4, WM = 8, WN = 4, RK = 64;
+  constexpr int PC = 128;                                  // columns of a piece
+  constexpr int PIECE = RK * PC, STAGE_ELEMS = 4 * PIECE;  // A0 | A1 | D0 | D1
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+
+  const int n_out = min(*n_out_dev, n_out_cap);
+  const int nsplit = gridDim.x;
+  int split = blockIdx.x, kap = (int)blockIdx.y;
+  wgrad_xcd_remap(split, kap, nsplit, kvol);
+  const int ci0 = (blockIdx.z / co_blocks) * 256, co0 = (blockIdx.z % co_blocks) * 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = (n_out + RK - 1) / RK;
+  const int per = (ntiles + nsplit - 1) / nsplit;
+  const int t_begin = split * per, t_end = min(ntiles, t_begin + per);
+  const int nstage = t_end - t_begin;
+
+  const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc((void*)dout, 0, -1, 0x00020000);
+  const unsigned in_row_bytes = (unsigned)cin * 2u, d_row_bytes = (unsigned)cout * 2u;
+  // loader role: instruction u (0 / 1) of this wave fills piece rows (wv*2+u)*4 .. +3; lane = (row in group, 16-byte slot of 16)
+  const int lrow = lane >> 4, lslot = lane & 15;
+  int prow[2];
+  unsigned a_col[2][2], d_col[2][2];                       // [piece][u]: byte offset of this lane's 16 bytes inside a source row
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = (wv * 2 + u) * 4 + lrow;
+    prow[u] = r;
+    const int chunk = lslot ^ ((r & 7) << 1);              // 8-column chunk of the piece this slot receives (tile T = chunk >> 1 swizzled)
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      const int ca = (chunk < 8) ? sp * 64 + chunk * 8 : 128 + sp * 64 + (chunk - 8) * 8;          // piece column -> input channel
+      a_col[sp][u] = (unsigned)(ci0 + ca) * 2u;
+      const int pc = chunk * 8;                                                                     // piece column 0..127
+      const int cd = (pc >> 5) * 64 + sp * 32 + (pc & 31);                                          // -> output channel
+      d_col[sp][u] = (unsigned)(co0 + cd) * 2u;
+    }
+  }
+  const int* nrow = nbr + (long long)kap * ld;
+  int idx_cur[2], idx_nxt[2];
+  auto load_idx_next = [&](int t) {                        // t: row tile (clamped by the caller)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = t * RK + prow[u];
+      idx_nxt[u] = nrow[m < n_out ? m : n_out - 1];
+    }
+  };
+  auto advance_idx = [&](int t) {                          // indices of row tile t; -1 = zero row (past the end / missing neighbour)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) idx_cur[u] = (t < t_end && t * RK + prow[u] < n_out) ? idx_nxt[u] : -1;
+  };
+#ifndef W8_EXP
+#define W8_EXP 0   /* timing experiments only (wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads in the loop, 4 no wave-row offset */
+#endif
+  bool in_loop = false;
+  auto issue_a = [&](int buf, int sp) {                    // piece A_sp of the row tile idx_cur describes
+    if ((W8_EXP & 1) && in_loop) return;
+    u16* dst = smem + buf * STAGE_ELEMS + sp * PIECE + wv * 1024;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const unsigned voff = idx_cur[u] >= 0 ? (unsigned)idx_cur[u] * in_row_bytes + a_col[sp][u] : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void_ptr)(dst + u * 512), 16, voff, 0, 0, 0);
+    }
+  };
+  auto issue_d = [&](int t, int buf, int sp) {
+    if ((W8_EXP & 1) && in_loop) return;
+    u16* dst = smem + buf * STAGE_ELEMS + (2 + sp) * PIECE + wv * 1024;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = t * RK + prow[u];
+      const unsigned voff = (t < t_end && m < n_out) ? (unsigned)m * d_row_bytes + d_col[sp][u] : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rs, (lds_void_ptr)(dst + u * 512), 16, voff, 0, 0, 0);
+    }
+  };
+  // reader role: transpose-read fragments; this lane's rows are k0 + 4g + j (+16): y = (4g + j) & 7
+  const int g = lane >> 4, L = lane & 15, j = L >> 2, q = L & 3;
+  const int y = (4 * g + j) & 7;
+  auto trf = [&](const u16* piece, int k0, int T) {
+    const u16* p0 = piece + (k0 + 4 * g + j) * PC + ((T ^ y) << 4) + 4 * q;
+    s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(p0));
+    s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(p0 + 16 * PC));
+    s16x8 v = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  bf16x8 af[2][4][2], df[2][2][2];                         // A: [half][ci block][k-step]; D: [half][co block][k-step]
+#define W8_READ_A(BUF, SP)                                                                       \
+  if (!((W8_EXP & 2) && in_loop)) {                                                              \
+    const u16* A_ = smem + (BUF) * STAGE_ELEMS + (SP) * PIECE;                                   \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                              \
+      af[SP][a][0] = trf(A_, 0, wm * 4 + a);                                                     \
+      af[SP][a][1] = trf(A_, 32, wm * 4 + a);                                                    \
+    }                                                                                            \
+  }
+#define W8_READ_D(BUF, SP)                                                                       \
+  if (!((W8_EXP & 2) && in_loop)) {                                                              \
+    const u16* D_ = smem + (BUF) * STAGE_ELEMS + (2 + (SP)) * PIECE;                             \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                              \
+      df[SP][b][0] = trf(D_, 0, wn * 2 + b);                                                     \
+      df[SP][b][1] = trf(D_, 32, wn * 2 + b);                                                    \
+    }                                                                                            \
+  }
+#define W8_MMA(SA, SB)                                                                           \
+  {                                                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                             \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                              \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                            \
+          acc[(SA) * 4 + a][(SB) * 2 + b] =                                                      \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[SB][b][ks], af[SA][a][ks], acc[(SA) * 4 + a][(SB) * 2 + b], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                               \
+  }
+#define W8_BAR()                                  \
+  {                                               \
+    __builtin_amdgcn_sched_barrier(0);            \
+    __builtin_amdgcn_s_barrier();                 \
+    __builtin_amdgcn_sched_barrier(0);            \
+  }
+  if (nstage > 0) {
+    // prologue: row tile t_begin complete in buffer 0, its first A half in registers, indices of t_begin + 1 current
+    load_idx_next(t_begin);
+    advance_idx(t_begin);
+    issue_a(0, 0); issue_d(t_begin, 0, 0); issue_d(t_begin, 0, 1); issue_a(0, 1);
+    load_idx_next(t_begin + 1);
+    advance_idx(t_begin + 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+    W8_BAR();
+    W8_READ_A(0, 0)
+    if (!(W8_EXP & 4) && wm == 1) W8_BAR();                // the second wave row runs one barrier behind the first
+#if W8_EXP & 2
+    W8_READ_A(0, 1) W8_READ_D(0, 0) W8_READ_D(0, 1)
+#endif
+    in_loop = true;
+    for (int st = 0; st < nstage; ++st) {
+      const int buf = st & 1, t = t_begin + st;
+      // ---- phase 1: (ci 0-63, co 0-31); requests: indices of t + 2, piece A0 of t + 1
+      load_idx_next(t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      W8_READ_D(buf, 0)
+      issue_a(buf ^ 1, 0);
+      __builtin_amdgcn_s_waitcnt(0x0F76);                  // vmcnt(6) = A1 + 2 indices + A0': D1 of this row tile has landed
+      W8_BAR();
+      W8_MMA(0, 0)
+      W8_BAR();
+      // ---- phase 2: (ci 0-63, co 32-63)
+      W8_READ_D(buf, 1)
+      issue_d(t + 1, buf ^ 1, 0);
+      __builtin_amdgcn_s_waitcnt(0x0F76);                  // vmcnt(6) = 2 indices + A0' + D0': A1 of this row tile
+      W8_BAR();
+      W8_MMA(0, 1)
+      W8_BAR();
+      // ---- phase 3: (ci 64-127, co 32-63)
+      W8_READ_A(buf, 1)
+      issue_d(t + 1, buf ^ 1, 1);
+      __builtin_amdgcn_s_waitcnt(0x0F74);                  // vmcnt(4): the indices and A0 of the next row tile
+      W8_BAR();
+      W8_MMA(1, 1)
+      W8_BAR();
+      // ---- phase 4: (ci 64-127, co 0-31): D0 is still in registers; the next row tile's first A half is read here
+      W8_READ_A(buf ^ 1, 0)
+      issue_a(buf ^ 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      advance_idx(t + 2);
+      __builtin_amdgcn_s_waitcnt(0x0F74);                  // vmcnt(4): D0 of the next row tile
+      W8_BAR();
+      W8_MMA(1, 0)
+      W8_BAR();
+    }
+    if (!(W8_EXP & 4) && wm == 0) W8_BAR();
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // the tail's zero-fill requests
+  }
+#undef W8_READ_A
+#undef W8_READ_D
+#undef W8_MMA
+#undef W8_BAR
+  float* p = partial + ((long long)split * kvol + kap) * cin * cout;
+  const int li = lane & 15;
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b) {
+      const int ci = ci0 + (wm * WM + a) * 16 + li;
+      const int co = co0 + (wn * WN + b) * 16 + 4 * g;
+      *(f32x4*)(p + (long long)ci * cout + co) = acc[a][b];
+    }
+}
+__global__ __launch_bounds__(512) void k_igemm_wgrad_glds8_256(const u16* in, const u16* dout, const int* nbr, int ld, float* partial,
+                                                               const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,
+                                                               int co_blocks) {
+  igemm_wgrad_glds8_body(in, dout, nbr, ld, partial, n_out_dev, n_out_cap, cin, cout, kvol, co_blocks);
+}
+
 #define U3D_WGRAD_GLDS_KERNEL(NAME, A, B, C, D)                                                                                   \
   __global__ __launch_bounds__(A* B * 64) void NAME(const u16* in, const u16* dout, const int* nbr, int ld, float* partial,        \
                                                     const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol, int co_blocks) { \
@@ -2174,11 +2416,13 @@ static int launch_igemm_wgrad(const void* in, const void* dout, const int32_t* n
 #endif
 static int launch_igemm_wgrad_glds(int tile, const void* in, const void* dout, const int32_t* nbr, int ld, float* partial,
                                    const int32_t* n_out_dev, int n_out_cap, int cin, int cout, int kvol, const WgPlan& p, hipStream_t s) {
-  wgrad_glds_kernel_t kern = tile == 256 ? k_igemm_wgrad_glds_256 : (tile == 128 ? k_igemm_wgrad_glds_128 : k_igemm_wgrad_glds_64);
+  wgrad_glds_kernel_t kern = tile == 256 ? ((IGEMM_WGRAD_GLDS8 && nbr) ? k_igemm_wgrad_glds8_256 : k_igemm_wgrad_glds_256)
+                                         : (tile == 128 ? k_igemm_wgrad_glds_128 : k_igemm_wgrad_glds_64);
   const int nthreads = tile == 256 ? 512 : 256;
   const size_t lds = 2 * (size_t)(64 * tile + 64 * tile) * 2;
   if (lds > 64 * 1024) {                       // one per-device mask per kernel
-    if (tile == 256) U3D_ALLOW_LDS(k_igemm_wgrad_glds_256, lds);
+    if (tile == 256 && IGEMM_WGRAD_GLDS8 && nbr) U3D_ALLOW_LDS(k_igemm_wgrad_glds8_256, lds);
+    else if (tile == 256) U3D_ALLOW_LDS(k_igemm_wgrad_glds_256, lds);
     else if (tile == 128) U3D_ALLOW_LDS(k_igemm_wgrad_glds_128, lds);
     else U3D_ALLOW_LDS(k_igemm_wgrad_glds_64, lds);
   }
