@@ -816,3 +816,40 @@ def test_eight_phase_kernels_against_the_128_tile_kernels_and_stable_under_load(
         ref = torch.cat([nv.spconv_wgrad(x, d, nbr, nd, 27) for d in dys], dim=2)
         assert (dw - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
         assert torch.equal(nv.spconv_wgrad(x, dy, nbr, nd, 27), dw)
+
+
+@pytest.mark.parametrize("cin,ks", [(64, (1, 1, 1)), (64, (3, 3, 3)), (128, (1, 3, 3)), (192, (3, 1, 1)), (256, (1, 1, 3))])
+def test_eight_phase_kernel_short_and_odd_reductions(cuda, cin, ks):
+    """The eight-phase kernel's prologue / tail on short reductions (1, 2, 3, 27 ... k-tiles: odd and even counts, a single one), forward
+    and transposed (reversed-table) use, ragged row count: bit-identical to the 128-tile kernel on every element."""
+    from uni3detr_amd.plugin import dense as dn
+    torch.manual_seed(cin + sum(ks))
+    B, dims, C = 8, (6, 30, 28), 256                       # 40 320 rows: 158 row tiles of 256 -> the 256 x 256 kernel is dispatched
+    pad = tuple(k // 2 for k in ks)
+    geom, _ = dn.Lattice.conv(cuda, B, dims, ks, (1, 1, 1), pad)
+    n_full = B * dims[0] * dims[1] * dims[2]
+    kv = ks[0] * ks[1] * ks[2]
+    x = (torch.randn(n_full, cin, device=cuda) * 0.5).bfloat16()
+    w = (torch.randn(kv, C, cin, device=cuda) * 0.05).bfloat16()          # n-major [K][Cout][Cin]
+    halves = [w[:, :128].contiguous(), w[:, 128:].contiguous()]
+    ident = torch.arange(n_full, device=cuda, dtype=torch.int32).view(1, n_full)      # 1x1x1: an explicit table (None = the table-less kernel)
+    tables = (ident, ident) if kv == 1 else (geom.nbr_fwd, geom.nbr_bwd)
+    for nbr in tables:
+        for n in (n_full, n_full - 777):
+            nd = nv.count_tensor(n, cuda)
+            y = nv.spconv_fwd(x, w, nbr, nd, n_full, C, transpose_w=True, tag="spconv_fwd")
+            lo = nv.spconv_fwd(x, halves[0], nbr, nd, n_full, 128, transpose_w=True, tag="spconv_fwd")
+            hi = nv.spconv_fwd(x, halves[1], nbr, nd, n_full, 128, transpose_w=True, tag="spconv_fwd")
+            assert torch.equal(y[:n, :128], lo[:n]) and torch.equal(y[:n, 128:], hi[:n])
+    # and against f32 on a sample of rows (both kernels could share a mistake)
+    nbr = tables[0]
+    nbt = nbr.t if isinstance(nbr, nv.RevNbr) else nbr
+    rows = torch.cat([torch.arange(0, 200, device=cuda), torch.arange(n_full - 200, n_full, device=cuda)])
+    y = nv.spconv_fwd(x, w, nbr, nv.count_tensor(n_full, cuda), n_full, C, transpose_w=True, tag="spconv_fwd")
+    xf = torch.cat([x.float(), torch.zeros(1, cin, device=cuda)])
+    exp = torch.zeros(rows.numel(), C, device=cuda)
+    for k in range(kv):
+        idx = nbt[k, rows].long()
+        idx = torch.where(idx < 0, torch.full_like(idx, n_full), idx)
+        exp += xf[idx] @ w[k].float().t()
+    assert (y[rows].float() - exp).abs().max().item() <= 1.5e-2 * max(1e-3, exp.abs().max().item())

@@ -51,9 +51,6 @@ int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, i
 #ifndef GLDS_PIPE
 #define GLDS_PIPE 0     /* 1: unit-level fragment pipeline in the LDS-DMA forward/dgrad kernels (igemm_glds_body); measured time-neutral */
 #endif
-#ifndef IGEMM_PP
-#define IGEMM_PP 0       /* 1: 256x256 tiles run the experimental ping-pong kernel (k_igemm_pp; measured on par with k_igemm_fwd<2,4,8,4>: DESIGN.md) */
-#endif
 #ifndef IGEMM_STORE_KS
 #define IGEMM_STORE_KS 0   /* k-step after which the next stage's registers are written to LDS (0: mid-stage, 1: end of stage) */
 #endif
@@ -1115,265 +1112,8 @@ extern "C" int32_t u3d_igemm_lattice_bf16(const void* in, const void* w, void* o
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
 }
 
-// =============================================================================================
-// forward / dgrad, "ping-pong" schedule for the 256 x 256 tile (the layers that dominate the step).
-//
-// In k_igemm_fwd all eight waves walk through the same phases together: everybody reads LDS (matrix pipe idle), then everybody
-// issues MFMAs (LDS idle) - SQ counters put the matrix pipe at ~35 % busy with neither LDS nor L2 saturated.  Here the two waves
-// that share a SIMD (wave w and w+4) are always in OPPOSITE phases, separated by workgroup barriers:
-//      phase 2s   : group 0 issues the 32 MFMAs of stage s        | group 1: LDS stores, global loads, fragment reads
-//      phase 2s+1 : group 0: LDS stores, global loads, frag reads | group 1 issues the 32 MFMAs of stage s
-// so every SIMD's matrix pipe always has one wave feeding it while its partner uses the LDS / vector-memory / VALU pipes.
-// Stage = 32 reduction elements (one MFMA k-step): the fragments of a whole stage are held in registers across the barrier.
-// LDS ring of two stages; group 0 stores its half of stage t's tile in phase 2t-3, group 1 in phase 2t-2; group 0 reads the
-// stage-t fragments in phase 2t-1, group 1 in phase 2t (every reader/writer pair is separated by a barrier).
-// Barriers are bare s_barrier + lgkmcnt(0): global loads stay in flight across them (issued two phases before their LDS store).
-// =============================================================================================
-#ifndef PP_SCHED
-#define PP_SCHED 1
-#endif
-#ifndef PP_PRIO
-#define PP_PRIO 0
-#endif
-#ifndef PP_EXP
-#define PP_EXP 0   /* timing experiments only: 1 no global loads, 2 + no LDS stores, 3 + no fragment reads */
-#endif
-#define PP_BARRIER()                                                        \
-  do {                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                      \
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         \
-    __builtin_amdgcn_sched_barrier(0);                                      \
-  } while (0)
-
-template <bool W_KMAJOR>
-__global__ __launch_bounds__(512) void k_igemm_pp(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
-                                                  int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
-                                                  int cin, int cout, int kvol, const float* __restrict__ bias, int relu) {
-  constexpr int NT = 512, WM = 8, WN = 4, WAVES_N = 4;
-  constexpr int BM = 256, BN = 256, BK = 32;
-  constexpr int LDA = BK + 8;                           // 20-dword row stride: the 16 rows x 2 k-groups of a b64 fragment read tile all 64 banks
-  constexpr int LDW = W_KMAJOR ? BN + 16 : BK + 8;
-  constexpr int A_ELEMS = BM * LDA;
-  constexpr int W_ELEMS = W_KMAJOR ? BK * LDW : BN * LDW;
-  constexpr int STAGE_ELEMS = A_ELEMS + W_ELEMS;
-  constexpr int A_SEGS = BM * (BK / 8) / NT;            // 2
-  constexpr int W_SEGS = BK * BN / 8 / NT;              // 2
-  constexpr int A_ROW_STEP = NT / (BK / 8);             // 128
-  extern __shared__ __attribute__((aligned(16))) u16 smem[];
-
-  const int n_out = min(*n_out_dev, n_out_cap);
-  const int ntile = gridDim.x;
-  const int xq = ntile >> 3, xr = ntile & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
-  const int m0 = tile * BM;
-  if (m0 >= n_out) return;
-  const int col0 = blockIdx.y * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int grp = wv >> 2;                              // waves w and w+4 share a SIMD: one of each group per SIMD
-  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
-  const int nchunk = cin / BK;
-  const int T = kvol * nchunk;
-
-  f32x4 acc[WM][WN];
-#pragma unroll
-  for (int a = 0; a < WM; ++a)
-#pragma unroll
-    for (int b = 0; b < WN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, -1, 0x00020000);
-  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, -1, 0x00020000);
-  const unsigned row_bytes = (unsigned)cin * 2u;
-  const int a_part = tid % (BK / 8), a_row0 = tid / (BK / 8);
-  const unsigned a_part16 = (unsigned)a_part * 16u;
-  unsigned w_voff[W_SEGS];
-  int w_lds[W_SEGS];
-#pragma unroll
-  for (int u = 0; u < W_SEGS; ++u) {
-    int sgi = tid + u * NT;
-    if (W_KMAJOR) {
-      int k = sgi / (BN / 8), part = sgi % (BN / 8);
-      w_voff[u] = (unsigned)(k * cout + col0 + part * 8) * 2u;
-      w_lds[u] = k * LDW + part * 8;
-    } else {
-      int n = sgi / (BK / 8), part = sgi % (BK / 8);
-      w_voff[u] = (unsigned)((col0 + n) * cin + part * 8) * 2u;
-      w_lds[u] = n * LDW + part * 8;
-    }
-  }
-
-  u32x4 ra[A_SEGS], rw[W_SEGS];
-  int idx_nxt[A_SEGS];
-  bf16x8 af[WM], bfr[WN];
-
-  // stage st = (offset st / nchunk, chunk st % nchunk): the neighbour indices change every nchunk stages only
-  auto load_idx = [&](int st) {
-    const int kap = min(st, T - 1) / nchunk;
-#pragma unroll
-    for (int u = 0; u < A_SEGS; ++u) {
-      int m = m0 + a_row0 + u * A_ROW_STEP;
-      int mc = m < n_out ? m : n_out - 1;
-      idx_nxt[u] = nbr ? nbr[(long long)kap * ld + mc] : mc;          // raw: masked at use (see k_igemm_fwd)
-    }
-  };
-  // global -> registers for stage st (uses the indices fetched by the previous call), then fetch the indices of stage st+1
-  auto issue = [&](int st) {
-    const int sc = min(st, T - 1);
-    const int kap = sc / nchunk, c0 = (sc % nchunk) * BK;
-    const unsigned a_soff = (unsigned)c0 * 2u;
-#pragma unroll
-    for (int u = 0; u < A_SEGS; ++u) {
-      const bool ok = idx_nxt[u] >= 0 && (m0 + a_row0 + u * A_ROW_STEP < n_out);
-      unsigned voff = ok ? (unsigned)idx_nxt[u] * row_bytes + a_part16 : 0xFFFFFFFFu;
-      ra[u] = __builtin_amdgcn_raw_buffer_load_b128(in_rs, voff, a_soff, 0);
-    }
-    const unsigned w_soff = W_KMAJOR ? (unsigned)((kap * cin + c0) * cout) * 2u : (unsigned)(kap * cin * cout + c0) * 2u;
-#pragma unroll
-    for (int u = 0; u < W_SEGS; ++u) rw[u] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_voff[u], w_soff, 0);
-    load_idx(st + 1);
-  };
-  auto store = [&](int buf) {
-    u16* Ab = smem + buf * STAGE_ELEMS;
-    u16* Wb = Ab + A_ELEMS;
-#pragma unroll
-    for (int u = 0; u < A_SEGS; ++u) *(u32x4*)(Ab + (a_row0 + u * A_ROW_STEP) * LDA + a_part * 8) = ra[u];
-#pragma unroll
-    for (int u = 0; u < W_SEGS; ++u) *(u32x4*)(Wb + w_lds[u]) = rw[u];
-  };
-  auto read_frags = [&](int buf) {
-    const u16* A = smem + buf * STAGE_ELEMS;
-    const u16* W = A + A_ELEMS;
-#pragma unroll
-    for (int a = 0; a < WM; ++a) af[a] = direct_frag(A, LDA, (wm * WM + a) * 16, 0, lane);
-#pragma unroll
-    for (int b = 0; b < WN; ++b)
-      bfr[b] = W_KMAJOR ? tr_frag(W, LDW, 0, (wn * WN + b) * 16, lane) : direct_frag(W, LDW, (wn * WN + b) * 16, 0, lane);
-  };
-  auto compute = [&]() {
-#if PP_PRIO
-    __builtin_amdgcn_s_setprio(PP_PRIO);
-#endif
-#pragma unroll
-    for (int b = 0; b < WN; ++b)
-#pragma unroll
-      for (int a = 0; a < WM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
-#if PP_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-  };
-
-  // compute phase: the 32 MFMAs of the stage in registers, with this wave's LDS stores (tile half fetched two phases ago) and
-  // the global loads of the tile after it spread between them - a wave issues in order, so memory instructions placed between
-  // two MFMAs cost the matrix pipe nothing while a block of them in front of the barrier would.
-  auto compute_and_stage = [&](int store_buf, int issue_st) {
-    compute();
-#if PP_EXP < 2
-    store(store_buf);
-#endif
-#if PP_EXP < 1
-    issue(issue_st);
-#endif
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);      // MFMA
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // DS write
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-  };
-
-  // ---- prologue (all waves): stage 0 complete in buffer 0; stage 1: group 1's half in buffer 1, group 0's half in registers
-  //   group 0, phase 2s  : MFMA(s), store own half of stage s+1 -> buf (s+1)&1, fetch stage s+2   | group 1: fragments of stage s
-  //   group 0, phase 2s+1: fragments of stage s+1                                                  | group 1: MFMA(s), store own half
-  //                                                                                                  of stage s+2 -> buf s&1, fetch s+3
-  load_idx(0);
-  issue(0);
-  store(0);
-  issue(1);
-#if PP_SCHED == 2
-  if (grp == 0) {
-    PP_BARRIER();
-    read_frags(0);
-    for (int s = 0; s < T; ++s) {
-      compute_and_stage((s + 1) & 1, s + 2);
-      PP_BARRIER();
-      read_frags((s + 1) & 1);
-      PP_BARRIER();
-    }
-  } else {
-    store(1);
-    issue(2);
-    PP_BARRIER();
-    for (int s = 0; s < T; ++s) {
-      read_frags(s & 1);
-      PP_BARRIER();
-      compute_and_stage(s & 1, s + 3);
-      PP_BARRIER();
-    }
-  }
-#else
-  // schedule 1: the load phase does everything but the MFMAs.  group 0 stores its half of stage t in phase 2t-3, group 1 in 2t-2.
-  if (grp == 0) {
-    store(1);
-    issue(2);                                           // stored in phase 1
-    PP_BARRIER();
-    read_frags(0);
-    for (int s = 0; s < T; ++s) {
-      compute();                                        // phase 2s
-      PP_BARRIER();
-      store(s & 1);                                     // phase 2s+1: this group's half of stage s+2 (buffer of stage s: last read in phase 2s)
-      issue(s + 3);
-      read_frags((s + 1) & 1);
-      PP_BARRIER();
-    }
-  } else {
-    PP_BARRIER();
-    for (int s = 0; s < T; ++s) {
-      store((s + 1) & 1);                               // phase 2s: this group's half of stage s+1
-      issue(s + 2);
-      read_frags(s & 1);
-      PP_BARRIER();
-      compute();                                        // phase 2s+1
-      PP_BARRIER();
-    }
-  }
-#endif
-  // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + r
-  const int li = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int a = 0; a < WM; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int m = m0 + (wm * WM + a) * 16 + g * 4 + r;
-      if (m >= n_out) continue;
-#pragma unroll
-      for (int b = 0; b < WN; ++b) {
-        int col = col0 + (wn * WN + b) * 16 + li;
-        float v = acc[a][b][r];
-        if (bias) v += bias[col];
-        if (relu) v = fmaxf(v, 0.f);
-        out[(long long)m * cout + col] = f2bf(v);
-      }
-    }
-}
-
-template <bool WK>
-static int launch_igemm_pp(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev,
-                           int n_out_cap, int cin, int cout, int kvol, hipStream_t s, const float* bias = nullptr, int relu = 0) {
-  constexpr int BM = 256, BN = 256, BK = 32;
-  constexpr int LDA = BK + 8, LDW = WK ? BN + 16 : BK + 8;
-  constexpr size_t lds = 2 * (size_t)(BM * LDA + (WK ? BK * LDW : BN * LDW)) * 2;
-  auto kern = k_igemm_pp<WK>;
-  if (lds > 64 * 1024) U3D_ALLOW_LDS(kern, lds);      // one call site per template instantiation: per-kernel, per-device
-  dim3 grid(u3d_cdiv(n_out_cap, BM), cout / BN);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin, cout,
-                     kvol, bias, relu);
-  return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
-}
+// (The register-staged "ping-pong" kernel of round 1 - two wave groups in opposite phases, measured on par with k_igemm_fwd -
+//  was removed when igemm_glds8_body took that idea to the LDS-DMA kernels; DESIGN.md 3.1 keeps its numbers.)
 
 // Dense layer on rows: out[M,N] = act(x[M,K] @ W[N,K]^T + bias) — nn.Linear layout, bf16 in/out, f32 accumulate/bias.
 // Small M (decoder: B*900 rows): 128x64 tiles so that a few hundred workgroups exist.
@@ -1611,11 +1351,6 @@ extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32
     if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
     if (cout % 64 == 0) return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
   }
-#endif
-#if IGEMM_PP
-  if (cout % 256 == 0)                                              // 256 x 256, ping-pong schedule
-    return transpose_w ? launch_igemm_pp<false>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s)
-                       : launch_igemm_pp<true>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
 #endif
   if (cout % 256 == 0 && wg256 < 128) { IG_CASE(4, 2, 4, 4) }       // measured: 94 workgroups (N=12000, 512 ch) 0.136 -> 0.100 ms;
                                                                     // 188 workgroups (N=48000, 256 ch) stay faster on 256 x 256
