@@ -853,3 +853,35 @@ def test_eight_phase_kernel_short_and_odd_reductions(cuda, cin, ks):
         idx = torch.where(idx < 0, torch.full_like(idx, n_full), idx)
         exp += xf[idx] @ w[k].float().t()
     assert (y[rows].float() - exp).abs().max().item() <= 1.5e-2 * max(1e-3, exp.abs().max().item())
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_second3d_branch_input_gradients_summed_by_the_convs(cuda, precision):
+    """SECOND3D (is_cascade=False): the three branches' input gradients are summed by the first convs' backward launches
+    (sp.FanoutToken + addend epilogue, 256 x 256 eight-phase kernel included) - same gradients as autograd's own sums."""
+    from uni3detr_amd.plugin import dense as dn
+    torch.manual_seed(2)
+    B, C = 8, 256
+    net = dn.SECOND3D(in_channels=[C, C, C], out_channels=[128, 256, 256], layer_nums=[1, 1, 1], layer_strides=[1, 2, 4], is_cascade=False,
+                      conv_cfg=dict(type="Conv3d", kernel=(1, 3, 3), bias=False)).to(cuda).train()
+    dt = torch.bfloat16 if precision == "bf16" else torch.float32
+    x0 = (torch.randn(B, 15, 40, 40, C, device=cuda) * 0.5).to(dt).permute(0, 4, 1, 2, 3)      # channels_last_3d volume
+    res = {}
+    for fused in (True, False):
+        dn.FANOUT_FUSION = fused
+        try:
+            for p_ in net.parameters():
+                p_.grad = None
+            x = x0.clone().requires_grad_(True)
+            outs = net(x)
+            torch.manual_seed(5)
+            loss = sum((o.float() * torch.randn_like(o.float())).sum() for o in outs)
+            loss.backward()
+            res[fused] = (x.grad.float().clone(), [p_.grad.clone() for p_ in net.parameters()])
+        finally:
+            dn.FANOUT_FUSION = True
+    a, b = res[True], res[False]
+    tol = 2e-2 if precision == "bf16" else 1e-5
+    assert (a[0] - b[0]).abs().max().item() <= tol * b[0].abs().max().item()
+    for u, v in zip(a[1], b[1]):
+        assert (u - v).abs().max().item() <= tol * max(1e-6, v.abs().max().item())

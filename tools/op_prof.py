@@ -55,6 +55,13 @@ def main():
         for (key, name), (cnt, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:110]:
             print(f"{t:8.0f} us {cnt:4d}x  {name:28s} {key}")
         return
+    if "--aten" in sys.argv:                       # only the ATen launches, grouped by input shapes
+        rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and (e.self_device_time_total or 0) > 0]
+        rows.sort(key=lambda e: -e.self_device_time_total)
+        print(f"aten launches: {sum(e.count for e in rows)}, {sum(e.self_device_time_total for e in rows):.0f} us")
+        for e in rows[:80]:
+            print(f"{e.self_device_time_total:8.0f} us {e.count:4d}x  {e.key:26s} {str(e.input_shapes)[:150]}")
+        return
     print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=50,
                                                               max_shapes_column_width=70))
 

@@ -662,7 +662,9 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
     __syncthreads();                                    // also drains this wave's LDS-DMA (vmcnt) before anyone reads the next buffer
   }
 #endif
+#define GLDS_EPI_ADDEND (BM != 256 || BN != 256)
 #include "glds_epilogue.inc"
+#undef GLDS_EPI_ADDEND
 }
 
 // =============================================================================================
@@ -903,7 +905,9 @@ __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, con
 #undef G8_MMA
 #undef G8_BAR
 #undef G8_VMCNT8
+#define GLDS_EPI_ADDEND 1
 #include "glds_epilogue.inc"
+#undef GLDS_EPI_ADDEND
 }
 __global__ __launch_bounds__(512) void k_igemm_glds8_256x256(const u16* in, const u16* w, const int* nbr, int ld, u16* out,
                                                              const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,
@@ -1087,7 +1091,9 @@ __device__ __forceinline__ void igemm_lattice_body(const u16* __restrict__ in, c
     }
     __syncthreads();
   }
+#define GLDS_EPI_ADDEND 0
 #include "glds_epilogue.inc"
+#undef GLDS_EPI_ADDEND
 }
 
 __global__ __launch_bounds__(512) void k_igemm_lattice_256x256(const u16* in, const u16* w, u16* out, int n_rows, int cin, int cout, LatGeom lg,
@@ -1277,7 +1283,7 @@ static inline bool convin_shape(int cin, int cout, int kvol) { return cin == CON
 
 // out = conv(in) + addend (bf16, out's shape) in one pass - the input gradient of a residual block's first conv with the residual
 // branch's gradient summed in by the epilogue.  Shapes: the direct-operand kernels (16/32/64 channels, 27 offsets) and the n-major
-// LDS-DMA kernels with 128 x 128 / 128 x 64 tiles (transpose_w != 0, cin % 64 == 0); anything else: U3D_ERR_UNSUPPORTED (the caller adds).
+// LDS-DMA kernels (transpose_w != 0, cin % 64 == 0; 256 x 256 tiles: the eight-phase kernel only); anything else: U3D_ERR_UNSUPPORTED (the caller adds).
 extern "C" int32_t u3d_igemm_fwd_add_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, const void* addend, void* out,
                                           const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
                                           int32_t transpose_w, u3d_stream s) {
@@ -1292,7 +1298,10 @@ extern "C" int32_t u3d_igemm_fwd_add_bf16(const void* in, const void* w, const i
 #if IGEMM_GLDS
   if (transpose_w && cin % 64 == 0 && cout % 64 == 0) {
     const long long wg256 = (long long)u3d_cdiv(n_out_cap, 256) * (cout / 256 > 0 ? cout / 256 : 1);
-    if (cout % 256 == 0 && wg256 >= 128) return U3D_ERR_UNSUPPORTED;                 // the 256 x 256 kernel has no addend path
+    if (cout % 256 == 0 && wg256 >= 128) {                                            // 256 x 256: the eight-phase kernel's epilogue takes the addend
+      if (!(IGEMM_GLDS8 && nbr)) return U3D_ERR_UNSUPPORTED;
+      return launch_igemm_glds<GLDS256_CFG>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, (const float*)addend, 2);
+    }
     if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, (const float*)addend, 2);
     return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, (const float*)addend, 2);
   }

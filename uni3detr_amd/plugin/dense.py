@@ -113,11 +113,11 @@ def to_volume(rows, B, dims):
     return rows.view(B, *dims, rows.shape[1]).permute(0, 4, 1, 2, 3)
 
 
-def conv_bn_relu(rows, B, dims, conv, bn, post_add=None):
+def conv_bn_relu(rows, B, dims, conv, bn, post_add=None, fan_token=None):
     ks, st, pd = tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding)
     geom, dims_out = Lattice.conv(rows.device, B, dims, ks, st, pd)
     # nn.Conv3d layout [Cout,Cin,kd,kh,kw] (re-laid-out by the shadow set); BatchNorm statistics come out of the conv's epilogue
-    return sp.conv_bn(rows, conv.weight, geom, bn, geom.n_out_dev, None, True, "oidhw", post_add), dims_out
+    return sp.conv_bn(rows, conv.weight, geom, bn, geom.n_out_dev, None, True, "oidhw", post_add, fan_token=fan_token), dims_out
 
 
 def deconv_bn_relu(rows, B, dims, deconv, bn, post_add=None):
@@ -136,6 +136,9 @@ def deconv_bn_relu(rows, B, dims, deconv, bn, post_add=None):
         return sp.bn_rows(y, bn, n_dev, None, True, row_map=inv, post_add=post_add), dims_out
     y = _GatherBijection.apply(y, idx, inv)
     return sp.bn_rows(y, bn, n_dev, None, True, post_add=post_add), dims_out
+
+
+FANOUT_FUSION = os.environ.get("U3D_FANOUT_FUSION", "1") == "1"
 
 
 @BACKBONES.register_module()
@@ -162,10 +165,10 @@ class SECOND3D(nn.Module):
         self.blocks = nn.ModuleList(blocks)
 
     @staticmethod
-    def _run_block(blk, rows, B, dims):
+    def _run_block(blk, rows, B, dims, fan=None):
         mods = list(blk)
         for j in range(0, len(mods), 3):
-            rows, dims = conv_bn_relu(rows, B, dims, mods[j], mods[j + 1])
+            rows, dims = conv_bn_relu(rows, B, dims, mods[j], mods[j + 1], fan_token=fan if j == 0 else None)
         return rows, dims
 
     def forward(self, x):
@@ -183,7 +186,9 @@ class SECOND3D(nn.Module):
         if not PARALLEL_BRANCHES or torch.cuda.is_current_stream_capturing():
             # measured: inside the captured step the fork/join costs more than it gains (56.1 vs 54.4 ms) — the 256x256-tile
             # kernels own a CU's LDS, so branches cannot co-reside; streams only pay off against eager-mode launch gaps
-            seq = [self._run_block(blk, rows, B, dims) for blk in self.blocks]
+            # the branches' input gradients are summed by the first convs' own backward launches (sp.FanoutToken), not by autograd
+            fan = sp.FanoutToken(len(self.blocks)) if (FANOUT_FUSION and rows.requires_grad and len(self.blocks) > 1) else None
+            seq = [self._run_block(blk, rows, B, dims, fan) for blk in self.blocks]
             return tuple(to_volume(r, B, d) for r, d in seq)
         cur = torch.cuda.current_stream()
         while len(_BRANCH_STREAMS) < len(self.blocks) - 1:

@@ -43,6 +43,26 @@ class ResidualToken:
         self.dres = None
 
 
+class FanoutToken:
+    """Side channel between the first convs of `n` branches that take the SAME input (SECOND3D with is_cascade=False): autograd
+    would add their input gradients with n - 1 element-wise passes over the full tensor.  Instead each conv's backward adds what the
+    branches before it left here (kernel epilogue, u3d_igemm_fwd_add_bf16) and keeps the partial sum; only the last one hands the
+    total to autograd, the others return no gradient for the input."""
+
+    def __init__(self, n):
+        self.n = self.remaining = n
+        self.acc = None
+
+    def step(self, din):
+        """din already contains self.acc.  -> what this conv returns to autograd for its input."""
+        self.remaining -= 1
+        if self.remaining > 0:
+            self.acc = din
+            return None
+        self.acc, self.remaining = None, self.n
+        return din
+
+
 class ConvGeom:
     """Tables of one convolution instance: forward (output-stationary), transposed (input-stationary), sizes."""
 
@@ -133,7 +153,7 @@ def reset_conv_uses():
 
 class _SparseConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, weight, geom, layout, want_stats=False, res_token=None):
+    def forward(ctx, feats, weight, geom, layout, want_stats=False, res_token=None, fan_token=None):
         # weight: the PARAMETER in its checkpoint layout: "dhwio" [kD,kH,kW,Cin,Cout] (mmcv spconv-1.x) or "oidhw" (nn.Conv3d)
         # want_stats: also return the per-row-tile BatchNorm statistics of the output (empty tensor when the kernel serving this
         # shape does not produce them) - second, non-differentiable output
@@ -141,6 +161,8 @@ class _SparseConv(torch.autograd.Function):
         bf16 = feats.dtype == torch.bfloat16
         kio_shape = weight.shape if layout == "dhwio" else tuple(weight.shape[i] for i in (2, 3, 4, 1, 0))
         cin, cout = kio_shape[3], kio_shape[4]
+        if feats.shape[1] != cin:               # the kernels take the channel counts from the weight: a mismatch would read out of bounds
+            raise ValueError(f"sparse conv: input has {feats.shape[1]} channels, weight expects {cin}")
         # n-major forward weights: the LDS-DMA kernels (channels % 64) and the direct-operand kernel of the narrow 27-offset levels
         # (igemm_direct.hip stages [K][Cout][Cin] rows as they are; the k-major layout costs it a transposing prologue)
         kv = kio_shape[0] * kio_shape[1] * kio_shape[2]
@@ -149,6 +171,7 @@ class _SparseConv(torch.autograd.Function):
         kio, koi = conv_weights(weight, layout, feats.dtype, want_koi=nmajor)
         ctx.geom, ctx.layout = geom, layout
         ctx.res_token = res_token
+        ctx.fan_token = fan_token if (fan_token is not None and feats.requires_grad) else None
         # TrainStep: this parameter's slice of the flat gradient buffer - written in place by the backward ONLY if this is the
         # weight's single use in the step (a weight used twice gets two gradients that autograd must add: it may not alias them)
         _CONV_USES[id(weight)] = _CONV_USES.get(id(weight), 0) + 1
@@ -184,7 +207,7 @@ class _SparseConv(torch.autograd.Function):
         feats, wc = ctx.saved_tensors
         g = ctx.geom
         if dout is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         dout = dout.contiguous()
         kvol = wc.shape[0]
         din = dw = None
@@ -222,47 +245,61 @@ class _SparseConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             nbr = g.nbr_bwd if kvol > 1 else None
             cin, cout = wc.shape[1], wc.shape[2]
+            fan = ctx.fan_token
+            facc = fan.acc if fan is not None else None          # partial sum of the branches that ran before this one
             if (STRIDED_DGRAD_SPLIT and g.strided and kvol > 1 and dout.dtype == torch.bfloat16 and cout % 64 == 0
                     and (kvol * cin) % 64 == 0 and g.n_out * STRIDED_SPLIT_MIN_RATIO <= g.n_in):      # stride 4: 15/16 of the direct dgrad's MFMAs hit zero rows
                 prod = nv.linear_bf16(dout, wc.view(kvol * cin, cout), None, False)      # [n_out, K*Cin]
                 din = nv.tap_gather_sum(prod, nbr, g.n_in_dev, g.n_in, cin, kvol)
+                if facc is not None:
+                    din += facc
             else:
                 din = None
                 if LATTICE_KERNEL and g.lattice is not None and g.lattice[2] == 3 and dout.dtype == torch.bfloat16:
                     din = nv.lattice_conv(dout, wc, g.lattice[0], g.lattice[1], g.lattice[2], transposed=True)
+                    if facc is not None:
+                        din += facc
                 if din is None:
                     tok = ctx.res_token
                     add = tok.dres if tok is not None else None
                     if tok is not None:
                         tok.dres = None
+                    if add is not None and facc is not None:
+                        add = add + facc
+                    elif facc is not None:
+                        add = facc
                     din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True, addend=add)
+            if fan is not None:
+                din = fan.step(din)
         elif ctx.res_token is not None:
             ctx.res_token.dres = None
-        return din, dw, None, None, None, None
+        return din, dw, None, None, None, None, None
 
 
-def sparse_conv(feats, weight, geom, layout="dhwio"):
+def sparse_conv(feats, weight, geom, layout="dhwio", fan_token=None):
     """weight: conv PARAMETER in checkpoint layout ("dhwio" = [kD,kH,kW,Cin,Cout]; "oidhw" = nn.Conv3d's [Cout,Cin,kD,kH,kW])."""
-    return _SparseConv.apply(feats, weight, geom, layout, False, None)
+    return _SparseConv.apply(feats, weight, geom, layout, False, None, fan_token)
 
 
 FUSED_CONV_STATS = os.environ.get("U3D_FUSED_CONV_STATS", "1") == "1"
 
 
-def conv_bn(feats, weight, geom, bn, n_dev, residual=None, relu=True, layout="dhwio", post_add=None, res_take=None, res_give=None):
+def conv_bn(feats, weight, geom, bn, n_dev, residual=None, relu=True, layout="dhwio", post_add=None, res_take=None, res_give=None,
+            fan_token=None):
     """conv -> BatchNorm rows (+ residual) (+ ReLU).  In training the conv's epilogue already reduces the BatchNorm statistics per row
     tile where its kernel supports it (bf16, channels % 64 == 0): the separate statistics pass over the conv output disappears."""
     if FUSED_CONV_STATS and bn.training and feats.dtype == torch.bfloat16 and feats.is_cuda:
         # res_take: this conv's input is the identity of a residual block - its backward sums the token's gradient into the input
         # gradient; res_give: this BatchNorm adds that identity - its backward leaves the identity's gradient in the token
-        y, stats = _SparseConv.apply(feats, weight, geom, layout, True, res_take)
+        # fan_token: this conv is one of several that take the same input (FanoutToken)
+        y, stats = _SparseConv.apply(feats, weight, geom, layout, True, res_take, fan_token)
         if stats.numel():
             tr = getattr(stats, "_u3d_tile_rows", None)
             if tr is None:                      # attribute lost on the way through autograd: recover it from the shape
                 tr = 128 if (y.shape[0] + 127) // 128 == stats.shape[0] else 256
             return _BNRows.apply(y, bn.weight, bn.bias, residual, n_dev, bn, relu, True, stats, tr, None, post_add, res_give)
         return _BNRows.apply(y, bn.weight, bn.bias, residual, n_dev, bn, relu, bn.training, None, 0, None, post_add, res_give)
-    return bn_rows(sparse_conv(feats, weight, geom, layout), bn, n_dev, residual, relu, None, post_add)
+    return bn_rows(sparse_conv(feats, weight, geom, layout, fan_token), bn, n_dev, residual, relu, None, post_add)
 
 
 class _BNRows(torch.autograd.Function):
