@@ -75,8 +75,10 @@ def main():
         pairs = int((nbr[:, :n] >= 0).sum())
         flops = 2.0 * pairs * cin * cout
         byt = n * cin * 2 + n * cout * 2 + 8 * pairs + kvol * cin * cout * 2
+        koi = w.transpose(1, 2).contiguous()             # n-major [K][Cout][Cin]: what the training step's forward passes (sparse._SparseConv)
         passes = {
-            "fwd": lambda: nv.spconv_fwd(nxt()[0], w, nbr, nd, n, cout),
+            "fwd": lambda: nv.spconv_fwd(nxt()[0], koi, nbr, nd, n, cout, transpose_w=True, tag="spconv_fwd"),
+            "fwd_k": lambda: nv.spconv_fwd(nxt()[0], w, nbr, nd, n, cout),         # k-major weights: the inference / first-generation path
             "dgrad": lambda: nv.spconv_fwd(nxt()[1], w, nbr_b, nd, n, cin, transpose_w=True),
             "wgrad": lambda: nv.spconv_wgrad(*nxt(), nbr, nd, kvol),
         }
