@@ -420,6 +420,11 @@ int32_t u3d_cast_bf16(const float* src, void* dst, int64_t n, u3d_stream s);
 int32_t u3d_permute_block_elems(void);
 int32_t u3d_permute_bf16_batched(const void* src, void* dst, const u3d_permute_desc* descs_dev, const int32_t* blocks_dev,
                                  int32_t nblocks, u3d_stream s);
+/* The same re-layout through a 32 x 32 x K LDS tile for descriptors whose source is contiguous along k (stride_k == 1, one of
+ * stride_r / stride_c == K = n / (rows * cols) <= max_k <= 32, rows % 32 == cols % 32 == 0, even src_off): coalesced reads of
+ * nn.Conv3d's [Cout][Cin][K] weights.  tiles_dev: int32 [ntiles][4] = (descriptor index, first row, first column, 0). */
+int32_t u3d_permute_bf16_tiled(const void* src, void* dst, const u3d_permute_desc* descs_dev, const int32_t* tiles_dev,
+                               int32_t ntiles, int32_t max_k, u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * Test-time post-processing.

@@ -159,6 +159,8 @@ def test_flat_parameter_shadows_equal_per_tensor_casts(cuda):
             assert kio.is_contiguous() and koi.is_contiguous()
             n_conv += 1
     assert n_lin > 50 and n_conv > 30 and layouts == {"dhwio", "oidhw"}
+    # nn.Conv3d's weights (k-contiguous source) go through the LDS-tiled kernel, the rest through the element-wise one
+    assert sh._plan[4] > 0 and sh._plan[2] > 0
 
 
 @pytest.mark.parametrize("graph", [False, True])

@@ -192,6 +192,54 @@ __global__ __launch_bounds__(256) void k_permute_bf16(const u16* __restrict__ sr
   }
 }
 
+// The same re-layout for descriptors whose SOURCE is contiguous along k (stride_k == 1: nn.Conv3d's [Cout][Cin][K], 50 of the 55 M
+// shadow elements of the SUN RGB-D model): k_permute_bf16 gathers them 2 bytes at a time, 54 bytes apart.  Here a workgroup takes a
+// 32 x 32 (row, column) tile with all K offsets: for each index of the slow source dimension that is ONE contiguous run of 32 * K
+// elements - read coalesced into LDS as [outer][inner][k], written back as 16-byte pieces of dst[k][row][col ...].
+#define PT_TILE 32
+__global__ __launch_bounds__(256) void k_permute_k1_tiled(const u16* __restrict__ src, u16* __restrict__ dst,
+                                                          const u3d_permute_desc* __restrict__ descs, const int4* __restrict__ tiles) {
+  extern __shared__ __attribute__((aligned(16))) u16 pt_lds[];
+  const int4 t = tiles[blockIdx.x];
+  const u3d_permute_desc d = descs[t.x];
+  const int r0 = t.y, c0 = t.z, rc = d.rows * d.cols, K = d.n / rc;
+  const bool c_inner = d.stride_c == K;                    // the column index is the fast source dimension (else the row index)
+  const long long so = c_inner ? d.stride_r : d.stride_c;  // stride of the slow one
+  const int outer0 = c_inner ? r0 : c0, inner0 = c_inner ? c0 : r0;
+  const int run = PT_TILE * K, run2 = run >> 1;            // elements / dwords of one contiguous run
+  const u16* base = src + d.src_off + (long long)outer0 * so + (long long)inner0 * K;
+  unsigned* l32 = (unsigned*)pt_lds;
+  for (int i = threadIdx.x; i < PT_TILE * run2; i += 256) {
+    const int o = i / run2, j = i - o * run2;
+    l32[i] = *(const unsigned*)(base + (long long)o * so + 2 * j);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * PT_TILE * (PT_TILE / 8); i += 256) {
+    const int c8 = i & 3, r = (i >> 2) & (PT_TILE - 1), k = i >> 7;
+    u16 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c8 * 8 + j;
+      v[j] = pt_lds[(c_inner ? r : c) * run + (c_inner ? c : r) * K + k];
+    }
+    const uint4 w = {(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16), (unsigned)v[4] | ((unsigned)v[5] << 16),
+                     (unsigned)v[6] | ((unsigned)v[7] << 16)};
+    *(uint4*)(dst + d.dst_off + (long long)k * rc + (long long)(r0 + r) * d.cols + c0 + c8 * 8) = w;
+  }
+}
+// tiles_dev: int32 [ntiles][4] = (descriptor, first row, first column, 0); descriptors must have stride_k == 1, rows % 32 == 0,
+// cols % 32 == 0, one of stride_r / stride_c == K (= n / (rows * cols)) <= max_k <= 32, even src_off, dst_off % 8 == 0
+extern "C" int32_t u3d_permute_bf16_tiled(const void* src, void* dst, const u3d_permute_desc* descs_dev, const int32_t* tiles_dev,
+                                          int32_t ntiles, int32_t max_k, u3d_stream s) {
+  U3D_REQUIRE(src && dst && descs_dev && tiles_dev && ntiles >= 0 && max_k >= 1 && max_k <= 32 && ((uintptr_t)dst & 15) == 0
+              && ((uintptr_t)src & 3) == 0, U3D_ERR_ARG);
+  if (ntiles == 0) return U3D_OK;
+  hipLaunchKernelGGL(k_permute_k1_tiled, dim3(ntiles), dim3(256), (size_t)PT_TILE * PT_TILE * max_k * 2, s, (const u16*)src, (u16*)dst,
+                     descs_dev, (const int4*)tiles_dev);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
 extern "C" int32_t u3d_cast_bf16(const float* src, void* dst, int64_t n, u3d_stream s) {
   U3D_REQUIRE(src && dst && n >= 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, U3D_ERR_ARG);
   if (n == 0) return U3D_OK;

@@ -138,6 +138,7 @@ _SIGS = {
     "u3d_sine_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "u3d_cast_bf16": (_I, [_P, _P, _L, _P]),
     "u3d_permute_block_elems": (_I, []),
+    "u3d_permute_bf16_tiled": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "u3d_permute_bf16_batched": (_I, [_P, _P, _P, _P, _I, _P]),
     "u3d_adamw_workspace": (_L, [_L]),
     "u3d_adamw_step": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _L, _P]),
@@ -936,25 +937,40 @@ PERMUTE_DESC_DTYPE = [("src_off", "<i8"), ("dst_off", "<i8"), ("n", "<i4"), ("ro
                       ("stride_k", "<i8"), ("stride_r", "<i8"), ("stride_c", "<i8")]          # = struct u3d_permute_desc
 
 
+PERMUTE_TILED = os.environ.get("U3D_PERMUTE_TILED", "1") == "1"
+
+
 def permute_plan(descs, device):
-    """descs: list of dicts with the u3d_permute_desc fields -> (descs_dev uint8, blocks_dev int32 [nblocks, 2], nblocks)."""
+    """descs: list of dicts with the u3d_permute_desc fields -> plan for permute_bf16_batched: descriptors whose source is contiguous
+    along k go to the LDS-tiled kernel (u3d_permute_bf16_tiled), the rest to the element-wise one."""
     import numpy as np
     arr = np.zeros(len(descs), dtype=PERMUTE_DESC_DTYPE)
     per = int(lib().u3d_permute_block_elems())
-    blocks = []
+    blocks, tiles, max_k = [], [], 1
     for i, d in enumerate(descs):
         for k, v in d.items():
             arr[i][k] = v
         assert d["dst_off"] % 8 == 0
-        blocks += [(i, o) for o in range(0, d["n"], per)]
+        kk = d["n"] // (d["rows"] * d["cols"])
+        if (PERMUTE_TILED and d["stride_k"] == 1 and d["rows"] % 32 == 0 and d["cols"] % 32 == 0 and kk <= 32 and d["src_off"] % 2 == 0
+                and kk * d["rows"] * d["cols"] == d["n"] and kk in (d["stride_r"], d["stride_c"])
+                and (d["stride_r"] == kk * d["cols"] or d["stride_c"] == kk * d["rows"])):
+            tiles += [(i, r, c, 0) for r in range(0, d["rows"], 32) for c in range(0, d["cols"], 32)]
+            max_k = max(max_k, kk)
+        else:
+            blocks += [(i, o) for o in range(0, d["n"], per)]
     descs_dev = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).to(device)
     blocks_dev = torch.tensor(blocks, dtype=torch.int32).reshape(-1, 2).to(device)
-    return descs_dev, blocks_dev, len(blocks)
+    tiles_dev = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 4).to(device)
+    return descs_dev, blocks_dev, len(blocks), tiles_dev, len(tiles), max_k
 
 
 def permute_bf16_batched(src, dst, plan):
-    descs_dev, blocks_dev, nblocks = plan
-    _check(lib().u3d_permute_bf16_batched(_ptr(src), _ptr(dst), _ptr(descs_dev), _ptr(blocks_dev), nblocks, _stream()), "permute_bf16_batched")
+    descs_dev, blocks_dev, nblocks, tiles_dev, ntiles, max_k = plan
+    if nblocks:
+        _check(lib().u3d_permute_bf16_batched(_ptr(src), _ptr(dst), _ptr(descs_dev), _ptr(blocks_dev), nblocks, _stream()), "permute_bf16_batched")
+    if ntiles:
+        _check(lib().u3d_permute_bf16_tiled(_ptr(src), _ptr(dst), _ptr(descs_dev), _ptr(tiles_dev), ntiles, max_k, _stream()), "permute_bf16_tiled")
     return dst
 
 
