@@ -179,6 +179,10 @@ int32_t u3d_igemm_lattice_bf16(const void* in, const void* w, void* out, int32_t
  * u3d_bn_finalize_partials; saves the separate statistics pass over the conv output (ref: conv -> BatchNorm pairs of
  * sparse_encoder_hd.py:71-104 and second_3d.py:52-76). */
 int32_t u3d_igemm_fwd_stats_tile_rows(int32_t n_out_cap, int32_t cin, int32_t cout);
+/* Number of partials [blocks][2][Cout] u3d_igemm_fwd_stats_bf16 writes for this shape (0: not served).  The direct-operand kernels of
+ * the narrow 27-offset levels (Cin, Cout in {16, 32, 64}, not 64 -> 64) write one partial per WAVE of their persistent grid:
+ * u3d_igemm_fwd_stats_tile_rows is 0 for them and u3d_bn_finalize_partials takes rows_per_block = 0 (= every partial counts). */
+int32_t u3d_igemm_fwd_stats_blocks(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol);
 int32_t u3d_igemm_fwd_stats_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,
                                  const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
                                  double* stats, u3d_stream s);

@@ -472,7 +472,9 @@ def test_strided_dgrad_split_path_matches_conv3d(cuda, stride, cout):
     assert (got[True] - got[False]).abs().max().item() <= 2e-2 * scale
 
 
-@pytest.mark.parametrize("cin,cout,B,dims", [(64, 64, 2, (5, 12, 10)), (128, 256, 3, (4, 11, 9)), (256, 256, 8, (15, 40, 40))])
+@pytest.mark.parametrize("cin,cout,B,dims", [(64, 64, 2, (5, 12, 10)), (128, 256, 3, (4, 11, 9)), (256, 256, 8, (15, 40, 40)),
+                                             (32, 32, 3, (7, 13, 11)), (16, 32, 2, (5, 12, 10)), (64, 32, 2, (6, 9, 14)), (32, 16, 4, (9, 20, 17)),
+                                             (64, 16, 1, (3, 5, 4))])
 def test_conv_epilogue_bn_statistics_match_separate_pass(cuda, cin, cout, B, dims):
     """conv -> BatchNorm with the statistics reduced in the conv epilogue (u3d_igemm_fwd_stats_bf16 + u3d_bn_finalize_partials) equals
     the conv followed by the stand-alone statistics pass: outputs, running statistics, and the backward through both."""

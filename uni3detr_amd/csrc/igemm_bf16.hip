@@ -26,7 +26,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define IGEMM_DIRECT 1     /* narrow sparse levels on the direct-operand kernel (igemm_direct.hip); 0: the tiled BK = 32 kernels below */
 #endif
 int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev, int n_out_cap,
-                            int cin, int cout, int kvol, int transpose_w, hipStream_t s, const void* addend = nullptr);
+                            int cin, int cout, int kvol, int transpose_w, hipStream_t s, const void* addend = nullptr,
+                            double* stats = nullptr, int* stats_blocks = nullptr);
 #ifndef IGEMM_SMALL_PF
 #define IGEMM_SMALL_PF 1   /* stages of operand loads in flight in the 16/32-channel kernels (1: the wide layers' one-stage pipeline) */
 #endif
@@ -1145,10 +1146,33 @@ extern "C" int32_t u3d_igemm_fwd_stats_tile_rows(int32_t n_out_cap, int32_t cin,
 }
 // forward with n-major weights w[kappa][cout][cin] that also leaves the per-row-tile BatchNorm statistics of the (bf16-rounded)
 // output: stats f64 [ceil(n_out_cap / tile_rows)][2][cout] = (sum, sum of squares) per tile and column
+// number of statistics partials u3d_igemm_fwd_stats_bf16 writes for this shape (0: not served).  LDS-DMA kernels: one per row tile
+// (ceil(n_out_cap / u3d_igemm_fwd_stats_tile_rows)); direct-operand kernels of the narrow 27-offset levels: one per WAVE of their
+// persistent grid - u3d_igemm_fwd_stats_tile_rows is 0 there and u3d_bn_finalize_partials takes rows_per_block = 0 ("all of them")
+#ifndef DIRECT_STATS
+#define DIRECT_STATS 1
+#endif
+extern "C" int32_t u3d_igemm_fwd_stats_blocks(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol) {
+#if IGEMM_DIRECT && DIRECT_STATS
+  if (n_out_cap > 0) {
+    int nb = 0;
+    if (u3d_launch_igemm_direct(nullptr, nullptr, (const int32_t*)16, 1, nullptr, nullptr, n_out_cap, cin, cout, kvol, 1, nullptr, nullptr, nullptr, &nb) == U3D_OK)
+      return nb;
+  }
+#endif
+  const int tr = u3d_igemm_fwd_stats_tile_rows(n_out_cap, cin, cout);
+  return tr ? u3d_cdiv(n_out_cap, tr) : 0;
+}
 extern "C" int32_t u3d_igemm_fwd_stats_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,
                                             const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
                                             double* stats, u3d_stream s) {
   U3D_REQUIRE(in && w && out && n_out_dev && stats && (nbr || kvol == 1), U3D_ERR_ARG);
+#if IGEMM_DIRECT && DIRECT_STATS
+  {
+    const int rc = u3d_launch_igemm_direct(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, 1, s, nullptr, stats);
+    if (rc != U3D_ERR_UNSUPPORTED) return rc;
+  }
+#endif
   const int tr = u3d_igemm_fwd_stats_tile_rows(n_out_cap, cin, cout);
   if (tr == 0) return U3D_ERR_UNSUPPORTED;
   if (tr == 256) return launch_igemm_glds<GLDS256_CFG>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);

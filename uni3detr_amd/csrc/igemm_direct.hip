@@ -65,10 +65,14 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 //     rows past n_out (and tiles past this wave's slab) get -1 by OR-ing a per-tile lane mask into the index BEFORE it is permuted;
 //   * index loads are buffer loads: per-tile row offset in a VGPR, the offset's table row as the scalar offset;
 //   * weight fragments and permuted indices are requested one offset ahead (LDS round trips are not hidden by two waves per SIMD).
-template <int KS, int WN, bool W_KMAJOR, int NW, int P>
+template <int KS, int WN, bool W_KMAJOR, int NW, int P, bool STATS = false>
 __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr, int ld,
                                                   u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap, int cin, int cout,
-                                                  int co0, const u16* __restrict__ addend) {
+                                                  int co0, const u16* __restrict__ addend, double* __restrict__ stats) {
+  // stats (STATS instantiations: the n-major kernels with <= 32 output columns - 32 more accumulator registers spill the 64-column
+  // ones): BatchNorm statistics of the rounded output, one partial per WAVE: f64 [gridDim.x * NW][2][cout] = column sums
+  // and sums of squares over the rows this wave wrote (f32 per lane over its ~20 rows, 16 lanes by shuffles at the end, f64 from
+  // there on) - u3d_bn_finalize_partials with rows_per_block = 0 adds them up; waves without tiles write zeros.
   // cout = channels of a row of `out` (and of the weight tensor); this launch computes the COUT = 16 * WN columns from co0 on
   // (a 64 -> 64 layer is two launches of the 64 -> 32 kernel: the weights of 27 x 64 x 64 do not fit LDS, those of one half do)
   static_assert(DIR_K % P == 0, "operand register sets are indexed statically");
@@ -121,6 +125,9 @@ __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, co
   for (int a = 0; a < DIR_WM; ++a) perm[a] = (a * 16 + li) * 4;
 
   f32x4 acc[DIR_WM][WN];
+  f32x4 cs[WN], cq[WN];
+#pragma unroll
+  for (int b = 0; b < WN; ++b) { cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
   for (int a = 0; a < DIR_WM; ++a)
 #pragma unroll
@@ -211,7 +218,14 @@ __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, co
     }
   }
   __syncthreads();
-  if (tile >= slab_end) return;
+  if (tile >= slab_end) {                                       // no tile for this wave (its statistics partial must still read as zero)
+    if constexpr (STATS) {
+      double* p = stats + ((long long)blockIdx.x * NW + wv) * 2 * cout + co0;
+      if (lane < 2 * COUT) p[(lane / COUT) * cout + lane % COUT] = 0.0;
+      if (2 * COUT > 64 && lane + 64 < 2 * COUT) p[((lane + 64) / COUT) * cout + (lane + 64) % COUT] = 0.0;
+    }
+    return;
+  }
   make_wb();
   read_w(0, wf[0]);
 
@@ -251,7 +265,13 @@ __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, co
               f32x4 v = acc[a][b];
               // addend (nullable): a bf16 tensor of out's shape summed in before the rounding (the residual branch's gradient)
               if (addend) v += __builtin_convertvector(*(const bf16x4*)(addend + (long long)m * cout + co0 + b * 16 + g * 4), f32x4);
-              *(bf16x4*)(out + (long long)m * cout + co0 + b * 16 + g * 4) = __builtin_convertvector(v, bf16x4);
+              const bf16x4 o = __builtin_convertvector(v, bf16x4);
+              *(bf16x4*)(out + (long long)m * cout + co0 + b * 16 + g * 4) = o;
+              if constexpr (STATS) {                            // of the ROUNDED values: what the BatchNorm behind this conv reads
+                const f32x4 vr = __builtin_convertvector(o, f32x4);
+                cs[b] += vr;
+                cq[b] += vr * vr;
+              }
             }
 #else
             if (m < n_out && tile + stride >= slab_end) *(bf16x4*)(out + (long long)m * cout + co0 + b * 16 + g * 4) = __builtin_convertvector(acc[a][b], bf16x4);
@@ -284,12 +304,27 @@ __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, co
     roff2 = row_off(tile + 3 * stride);
     make_wb();
   }
+  if constexpr (STATS) {
+    double* p = stats + ((long long)blockIdx.x * NW + wv) * 2 * cout + co0;
+#pragma unroll
+    for (int b = 0; b < WN; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = cs[b][r], s2 = cq[b][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (li == 0) {
+          p[b * 16 + g * 4 + r] = (double)s1;
+          p[cout + b * 16 + g * 4 + r] = (double)s2;
+        }
+      }
+  }
 }
 
 #define U3D_DIRECT_KERNEL(NAME, KS, WN, KM, NW, P)                                                                                    \
   __global__ __launch_bounds__(NW * 64, DIR_WAVES_PER_SIMD) void NAME(const u16* in, const u16* w, const int* nbr, int ld, u16* out, const int* n_out_dev, \
-                                                  int n_out_cap, int cin, int cout, int co0, const u16* addend) {                  \
-    igemm_direct_body<KS, WN, KM, NW, P>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, co0, addend);                             \
+                                                  int n_out_cap, int cin, int cout, int co0, const u16* addend, double* stats) {   \
+    igemm_direct_body<KS, WN, KM, NW, P>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, co0, addend, stats);                      \
   }
 // name: k_igemm_direct_<cin_pad>x<cout>_<k|n>: k = weights [27][cin][cout] (forward), n = [27][cout][cin] (dgrad)
 U3D_DIRECT_KERNEL(k_igemm_direct_32x16_k, 1, 1, true, DIR_NW_A, DIR_P1)
@@ -303,11 +338,23 @@ U3D_DIRECT_KERNEL(k_igemm_direct_64x16_n, 2, 1, false, DIR_NW_A, DIR_P2)
 U3D_DIRECT_KERNEL(k_igemm_direct_64x32_k, 2, 2, true, DIR_NW_B, DIR_P2)
 U3D_DIRECT_KERNEL(k_igemm_direct_64x32_n, 2, 2, false, DIR_NW_B, DIR_P2)
 
-typedef void (*direct_kernel_t)(const u16*, const u16*, const int*, int, u16*, const int*, int, int, int, int, const u16*);
+#define U3D_DIRECT_KERNEL_S(NAME, KS, WN, NW, P)                                                                                     \
+  __global__ __launch_bounds__(NW * 64, DIR_WAVES_PER_SIMD) void NAME(const u16* in, const u16* w, const int* nbr, int ld, u16* out, const int* n_out_dev, \
+                                                  int n_out_cap, int cin, int cout, int co0, const u16* addend, double* stats) {   \
+    igemm_direct_body<KS, WN, false, NW, P, true>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, co0, addend, stats);              \
+  }
+U3D_DIRECT_KERNEL_S(k_igemm_direct_32x16_ns, 1, 1, DIR_NW_A, DIR_P1)
+U3D_DIRECT_KERNEL_S(k_igemm_direct_32x32_ns, 1, 2, DIR_NW_A, DIR_P1)
+U3D_DIRECT_KERNEL_S(k_igemm_direct_64x16_ns, 2, 1, DIR_NW_A, DIR_P2)
+U3D_DIRECT_KERNEL_S(k_igemm_direct_64x32_ns, 2, 2, DIR_NW_B, DIR_P2)
+
+typedef void (*direct_kernel_t)(const u16*, const u16*, const int*, int, u16*, const int*, int, int, int, int, const u16*, double*);
 
 // 0 = launched, U3D_ERR_UNSUPPORTED = shape not served here (caller falls through to the tiled kernels)
 int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev, int n_out_cap,
-                            int cin, int cout, int kvol, int transpose_w, hipStream_t s, const void* addend) {
+                            int cin, int cout, int kvol, int transpose_w, hipStream_t s, const void* addend, double* stats,
+                            int* stats_blocks) {
+  // stats_blocks != nullptr: a QUERY - nothing is launched, *stats_blocks = number of per-wave statistics partials a launch writes
   if (kvol != DIR_K || !nbr || (cin != 16 && cin != 32 && cin != 64) || (cout != 16 && cout != 32 && cout != 64))
     return U3D_ERR_UNSUPPORTED;
 #if !DIR_SPLIT_64
@@ -334,7 +381,14 @@ int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, i
   DIR_PICK(2, 32, k_igemm_direct_64x32_k, k_igemm_direct_64x32_n, DIR_NW_B)
 #undef DIR_PICK
   if (!kern) return U3D_ERR_UNSUPPORTED;
-  if (n_out_cap <= 0) return U3D_OK;
+  if (stats || stats_blocks) {                                   // statistics epilogue: n-major kernels with <= 32 output columns
+    if (halves == 2 || !transpose_w || cout > 32) return U3D_ERR_UNSUPPORTED;
+    if (ks == 1 && cout == 16) { kern = k_igemm_direct_32x16_ns; U3D_ALLOW_LDS(k_igemm_direct_32x16_ns, lds); }
+    if (ks == 1 && cout == 32) { kern = k_igemm_direct_32x32_ns; U3D_ALLOW_LDS(k_igemm_direct_32x32_ns, lds); }
+    if (ks == 2 && cout == 16) { kern = k_igemm_direct_64x16_ns; U3D_ALLOW_LDS(k_igemm_direct_64x16_ns, lds); }
+    if (ks == 2 && cout == 32) { kern = k_igemm_direct_64x32_ns; U3D_ALLOW_LDS(k_igemm_direct_64x32_ns, lds); }
+  }
+  if (n_out_cap <= 0) { if (stats_blocks) *stats_blocks = 0; return U3D_OK; }
   // persistent grid: as many workgroups as fit on the chip at once (LDS-limited), a multiple of 8 (one share per XCD), and no
   // more than there are tiles
   static int cu_count[64] = {0};                           // per device, read once (plain host query, legal during stream capture)
@@ -354,8 +408,9 @@ int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, i
   const int need = u3d_cdiv(ntiles, nw);
   if (grid > need) grid = need;
   grid = (grid + 7) / 8 * 8;
+  if (stats_blocks) { *stats_blocks = grid * nw; return U3D_OK; }
   for (int h = 0; h < halves; ++h)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin,
-                       cout_total, h * 32, (const u16*)addend);
+                       cout_total, h * 32, (const u16*)addend, stats);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
 }

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_col_stats_final(const double* _
                                                                  int rows_per_block) {
   __shared__ double red[FIN_LANES][16];
   const int n = min(*n_dev, n_cap);
-  int used = (n + rows_per_block - 1) / rows_per_block;
+  int used = rows_per_block > 0 ? (n + rows_per_block - 1) / rows_per_block : nblocks;     // 0: every partial counts (per-wave partials)
   if (used > nblocks) used = nblocks;
   const int col0 = blockIdx.x * 8;
   fin_reduce(partial, used, c, col0, red);
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bn_final_finalize(const double*
   __shared__ double red[FIN_LANES][16];
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
   const int n = min(*n_dev, n_cap);
-  int used = (n + rows_per_block - 1) / rows_per_block;
+  int used = rows_per_block > 0 ? (n + rows_per_block - 1) / rows_per_block : nblocks;     // 0: every partial counts (per-wave partials)
   if (used > nblocks) used = nblocks;
   const int col0 = blockIdx.x * 8;
   fin_reduce(partial, used, c, col0, red);
@@ -587,7 +587,7 @@ extern "C" int32_t u3d_bn_forward_stats(const void* x, const int32_t* n_dev, int
 extern "C" int32_t u3d_bn_finalize_partials(const double* partial, int32_t nblocks, int32_t rows_per_block, const int32_t* n_dev,
                                             int32_t n_cap, int32_t c, float eps, float momentum, float* running_mean,
                                             float* running_var, int64_t* num_batches, float* mean, float* invstd, u3d_stream s) {
-  U3D_REQUIRE(partial && n_dev && mean && invstd && c > 0 && nblocks >= 0 && rows_per_block > 0 && (!running_mean || running_var), U3D_ERR_ARG);
+  U3D_REQUIRE(partial && n_dev && mean && invstd && c > 0 && nblocks >= 0 && rows_per_block >= 0 && (!running_mean || running_var), U3D_ERR_ARG);
   hipLaunchKernelGGL(k_bn_final_finalize, dim3(u3d_cdiv(c, 8)), dim3(FIN_THREADS), 0, s, partial, nblocks, rows_per_block, n_dev, n_cap, c, eps, momentum,
                      running_mean, running_var, (long long*)num_batches, mean, invstd);
   U3D_CHECK_LAUNCH();

@@ -90,6 +90,7 @@ _SIGS = {
     "u3d_spconv_wgrad_workspace": (_L, [_I, _I, _I, _I]),
     "u3d_spconv_wgrad": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "u3d_igemm_fwd_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "u3d_igemm_fwd_stats_blocks": (_I, [_I, _I, _I, _I]),
     "u3d_igemm_fwd_add_bf16": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "u3d_linear_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "u3d_igemm_wgrad_bf16_workspace": (_L, [_I, _I, _I, _I]),
@@ -405,11 +406,13 @@ def spconv_fwd_stats(inp, w_nmajor, nbr, n_out_dev, n_out, cout):
     cin, kvol = inp.shape[1], w_nmajor.shape[0]
     if inp.dtype != torch.bfloat16 or not USE_IGEMM_V2:
         return None
-    tr = int(lib().u3d_igemm_fwd_stats_tile_rows(n_out, cin, cout))
-    if tr == 0:
+    nblocks = int(lib().u3d_igemm_fwd_stats_blocks(n_out, cin, cout, kvol)) if (nbr is not None or kvol == 1) else 0
+    if nblocks == 0:
         return None
+    # 0 for the direct-operand kernels of the narrow levels: per-wave partials, all of them count (rows_per_block = 0 downstream)
+    tr = int(lib().u3d_igemm_fwd_stats_tile_rows(n_out, cin, cout))
+    assert tr == 0 or nblocks == (n_out + tr - 1) // tr
     out = torch.empty((n_out, cout), dtype=inp.dtype, device=inp.device)
-    nblocks = (n_out + tr - 1) // tr
     stats = torch.empty((nblocks, 2, cout), dtype=torch.float64, device=inp.device)
     ld = nbr.shape[1] if nbr is not None else 0
     t = TIMER
@@ -524,8 +527,16 @@ def spconv_wgrad(inp, dout, nbr, n_out_dev, kvol, out_oik=False, out=None):
         ws = torch.empty(wsb, dtype=torch.uint8, device=inp.device)
         ld = nbr.shape[1] if nbr is not None else 0
         e0 = t.begin() if t is not None else None
-        _check(lib().u3d_igemm_wgrad_bf16(_ptr(inp), _ptr(dout), _ptr(nbr), ld, _ptr(dw), _ptr(n_out_dev), n_out, cin, cout, kvol,
-                                          1 if out_oik else 0, _ptr(ws), wsb, _stream()), "igemm_wgrad_bf16")
+        rc = lib().u3d_igemm_wgrad_bf16(_ptr(inp), _ptr(dout), _ptr(nbr), ld, _ptr(dw), _ptr(n_out_dev), n_out, cin, cout, kvol,
+                                        1 if out_oik else 0, _ptr(ws), wsb, _stream())
+        if rc != -2:
+            _check(rc, "igemm_wgrad_bf16")
+            if t is not None:
+                t.end("spconv_wgrad", e0, meta)
+            return dw
+        # a channel pair the implicit-GEMM weight-gradient kernels do not serve (e.g. 32 -> 16): the first-generation kernel below
+        gen = spconv_wgrad_generic(inp, dout, nbr, n_out_dev, kvol)
+        dw.copy_(gen.permute(2, 1, 0) if out_oik else gen)
         if t is not None:
             t.end("spconv_wgrad", e0, meta)
         return dw
@@ -537,6 +548,18 @@ def spconv_wgrad(inp, dout, nbr, n_out_dev, kvol, out_oik=False, out=None):
                                   dtype_code(inp), _ptr(ws), wsb, _stream()), "spconv_wgrad")
     if t is not None:
         t.end("spconv_wgrad", e0, meta)
+    return dw
+
+
+def spconv_wgrad_generic(inp, dout, nbr, n_out_dev, kvol):
+    """First-generation weight gradient (any channel counts, f32 or bf16): f32 [K, Cin, Cout]."""
+    cin, cout, n_out = inp.shape[1], dout.shape[1], dout.shape[0]
+    dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=inp.device)
+    wsb = int(lib().u3d_spconv_wgrad_workspace(n_out, cin, cout, kvol))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=inp.device)
+    ld = nbr.shape[1] if nbr is not None else 0
+    _check(lib().u3d_spconv_wgrad(_ptr(inp), _ptr(dout), _ptr(nbr), ld, _ptr(dw), _ptr(n_out_dev), n_out, cin, cout, kvol,
+                                  dtype_code(inp), _ptr(ws), wsb, _stream()), "spconv_wgrad")
     return dw
 
 
