@@ -183,6 +183,10 @@ int32_t u3d_igemm_fwd_stats_tile_rows(int32_t n_out_cap, int32_t cin, int32_t co
  * the narrow 27-offset levels (Cin, Cout in {16, 32, 64}, not 64 -> 64) write one partial per WAVE of their persistent grid:
  * u3d_igemm_fwd_stats_tile_rows is 0 for them and u3d_bn_finalize_partials takes rows_per_block = 0 (= every partial counts). */
 int32_t u3d_igemm_fwd_stats_blocks(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol);
+/* Rows per partial (= rows_per_block of u3d_bn_finalize_partials) for a conv with a neighbour table and kvol offsets: like
+ * u3d_igemm_fwd_stats_tile_rows, but aware of the kernels whose choice depends on the reduction length (256 x 128 eight-phase tiles
+ * for long reductions); 0 = per-wave partials / shape not served. */
+int32_t u3d_igemm_fwd_stats_rows(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol);
 int32_t u3d_igemm_fwd_stats_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,
                                  const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
                                  double* stats, u3d_stream s);

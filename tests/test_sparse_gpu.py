@@ -474,7 +474,7 @@ def test_strided_dgrad_split_path_matches_conv3d(cuda, stride, cout):
 
 @pytest.mark.parametrize("cin,cout,B,dims", [(64, 64, 2, (5, 12, 10)), (128, 256, 3, (4, 11, 9)), (256, 256, 8, (15, 40, 40)),
                                              (32, 32, 3, (7, 13, 11)), (16, 32, 2, (5, 12, 10)), (64, 32, 2, (6, 9, 14)), (32, 16, 4, (9, 20, 17)),
-                                             (64, 16, 1, (3, 5, 4))])
+                                             (64, 16, 1, (3, 5, 4)), (512, 512, 8, (15, 10, 10))])
 def test_conv_epilogue_bn_statistics_match_separate_pass(cuda, cin, cout, B, dims):
     """conv -> BatchNorm with the statistics reduced in the conv epilogue (u3d_igemm_fwd_stats_bf16 + u3d_bn_finalize_partials) equals
     the conv followed by the stand-alone statistics pass: outputs, running statistics, and the backward through both."""
@@ -887,3 +887,40 @@ def test_second3d_branch_input_gradients_summed_by_the_convs(cuda, precision):
     assert (a[0] - b[0]).abs().max().item() <= tol * b[0].abs().max().item()
     for u, v in zip(a[1], b[1]):
         assert (u - v).abs().max().item() <= tol * max(1e-6, v.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,ks,n_cut", [(512, (1, 3, 3), 0), (512, (1, 3, 3), 333), (256, (3, 3, 3), 0), (384, (1, 3, 3), 77)])
+def test_eight_phase_256x128_kernel_bit_identical_to_the_128_tile_kernel(cuda, cin, ks, n_cut):
+    """k_igemm_glds8_256x128 (three stage buffers, two groups of four waves one barrier apart; dispatched on long reductions with 128-wide
+    column tiles: the 12 000-row 512-channel layers) against the 128 x 128-tile kernel, which still serves each 128-column slice on its
+    own (too few workgroups for the dispatch rule): bit-identical, ragged row count, forward and reversed tables, odd k-tile counts;
+    plus the addend epilogue and 16 launches under HBM load."""
+    from uni3detr_amd.plugin import dense as dn
+    torch.manual_seed(cin + ks[0])
+    B, dims, C = 8, (15, 10, 10), 512
+    pad = tuple(k // 2 for k in ks)
+    geom, _ = dn.Lattice.conv(cuda, B, dims, ks, (1, 1, 1), pad)
+    n_full = B * dims[0] * dims[1] * dims[2]
+    kv = ks[0] * ks[1] * ks[2]
+    x = (torch.randn(n_full, cin, device=cuda) * 0.5).bfloat16()
+    w = (torch.randn(kv, C, cin, device=cuda) * 0.05).bfloat16()
+    n = n_full - n_cut
+    nd = nv.count_tensor(n, cuda)
+    for nbr in (geom.nbr_fwd, geom.nbr_bwd):
+        y = nv.spconv_fwd(x, w, nbr, nd, n_full, C, transpose_w=True, tag="spconv_fwd")
+        for q in range(4):
+            ref = nv.spconv_fwd(x, w[:, q * 128:(q + 1) * 128].contiguous(), nbr, nd, n_full, 128, transpose_w=True, tag="spconv_fwd")
+            assert torch.equal(y[:n, q * 128:(q + 1) * 128], ref[:n]), q
+    add = torch.randn(n_full, C, device=cuda).bfloat16()
+    ya = nv.spconv_fwd(x, w, geom.nbr_fwd, nd, n_full, C, transpose_w=True, addend=add)
+    yp = nv.spconv_fwd(x, w, geom.nbr_fwd, nd, n_full, C, transpose_w=True)
+    assert ((yp.float() + add.float())[:n] - ya.float()[:n]).abs().max().item() <= 1.6e-2 * ya.float()[:n].abs().max().item()
+    side = torch.cuda.Stream()
+    hog_a = torch.empty(256 << 20, dtype=torch.uint8, device=cuda)
+    hog_b = torch.empty_like(hog_a)
+    with torch.cuda.stream(side):
+        for _ in range(30):
+            hog_b.copy_(hog_a, non_blocking=True)
+    for i in range(16):
+        assert torch.equal(nv.spconv_fwd(x, w, geom.nbr_fwd, nd, n_full, C, transpose_w=True, tag="spconv_fwd")[:n], yp[:n]), i
+    torch.cuda.synchronize()

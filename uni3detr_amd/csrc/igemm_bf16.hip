@@ -916,6 +916,238 @@ __global__ __launch_bounds__(512) void k_igemm_glds8_256x256(const u16* in, cons
   igemm_glds8_body(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats);
 }
 
+// =============================================================================================
+// 256 x 128 tile on the same idea, for LONG reductions with 128-column output tiles (the 12 000-row 512-channel layers: 72 k-tiles per
+// tile; they ran on 128 x 128 tiles, two independent workgroups per CU whose relative phase nobody controls).  Eight waves = two
+// GROUPS of four (waves w and w + 4 share a SIMD): group g owns rows g*128 .. +127 as 2 x 2 waves of 64 x 64, both groups share the
+// weight tile (1.5 x the LDS-DMA bytes per MFMA of the 256 x 256 tile instead of 2 x) and run one barrier apart.  A k-tile is only
+// TWO phases of 16 MFMAs here (column halves of the wave's block), so two stage buffers would leave a request one phase to land:
+// THREE buffers (3 x 48 KiB), k-tile st + 2 requested during k-tile st.  Pieces: A0 / A1 = the rows of group 0 / 1 (16 KiB),
+// B0 / B1 = the first / second 32 columns of both wave columns (8 KiB).  Per trip: segment 1 reads B0 + B1 and requests A(st+2)
+// (+ the gather indices of st + 3), segment 2 reads the NEXT k-tile's A (second register set) and requests B(st+2); one counted
+// wait per segment, vmcnt(10) both times (what is younger than the piece that must have landed: 2 + 4 + 4 and 4 + 4 + 2 requests).
+// Not for short reductions: with 18 k-tiles per tile a quarter of a workgroup's life is prologue + epilogue, which a second
+// resident workgroup hides and this 144 KiB one cannot (measured on par there).
+// =============================================================================================
+#ifndef IGEMM_GLDS8N
+#define IGEMM_GLDS8N 1
+#endif
+__device__ __forceinline__ void igemm_glds8n_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
+                                                  int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
+                                                  int cin, int cout, int kvol, const float* __restrict__ bias, int relu,
+                                                  double* __restrict__ stats) {
+  constexpr int WAVES_M = 4, WAVES_N = 2, WM = 4, WN = 4, NW = 8;
+  constexpr int BM = 256, BN = 128, BK = 64;
+  constexpr int APIECE = 128 * BK, BPIECE = 64 * BK;
+  constexpr int STAGE_ELEMS = 2 * APIECE + 2 * BPIECE;    // A0 | A1 | B0 | B1 = 48 KiB
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+
+  const int n_out = min(*n_out_dev, n_out_cap);
+  const int ntile = gridDim.x;
+  const int xq = ntile >> 3, xr = ntile & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+  const int m0 = tile * BM;
+  if (m0 >= n_out) return;
+  const int col0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wv >> 2, wm = wv >> 1, wn = wv & 1;     // wm = grp*2 + (row half inside the group): the epilogue's row-block index
+  const int nstage = kvol * (cin / BK);
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int b = 0; b < WN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, -1, 0x00020000);
+  const unsigned row_bytes = (unsigned)cin * 2u;
+  const int lrow = lane >> 3, lslot = lane & 7;
+  // A piece g: 16 instructions, this wave issues u = 0 / 1: piece rows (wv*2+u)*8 + lrow = tile rows g*128 + ...
+  // B piece t:  8 instructions, this wave issues one: piece row wv*8 + lrow = tile column (r>>5)*64 + t*32 + (r&31)
+  unsigned a_part16[2], w_voff[2];
+  int arow[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = (wv * 2 + u) * 8 + lrow;
+    a_part16[u] = (unsigned)(lslot ^ ((r >> 1) & 7)) * 16u;
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) arow[gp][u] = gp * 128 + r;
+  }
+  {
+    const int r = wv * 8 + lrow;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int tc = (r >> 5) * 64 + t * 32 + (r & 31);
+      w_voff[t] = (col0 + tc < cout) ? (unsigned)((col0 + tc) * cin + (lslot ^ ((r >> 1) & 7)) * 8) * 2u : 0xFFFFFFFFu;
+    }
+  }
+  int idx_cur[2][2], idx_nxt[2][2], mcl[2][2];
+#pragma unroll
+  for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + arow[gp][u];
+      mcl[gp][u] = m < n_out ? m : n_out - 1;
+      idx_nxt[gp][u] = mcl[gp][u];
+    }
+  auto load_idx_next = [&](int stage) {                   // requested and consumed inside one loop trip (see igemm_glds8_body)
+    const int* row = nbr + (long long)(stage % kvol) * ld;
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) idx_nxt[gp][u] = row[mcl[gp][u]];
+  };
+  auto advance_idx = [&]() {
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) idx_cur[gp][u] = (m0 + arow[gp][u] < n_out) ? idx_nxt[gp][u] : -1;
+  };
+  auto issue_a = [&](int st, int sl) {                    // both A pieces of k-tile st into stage slot sl (rows idx_cur describes)
+    const unsigned soff = (unsigned)((st / kvol) * BK) * 2u;
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      u16* dst = smem + sl * STAGE_ELEMS + gp * APIECE + wv * 1024;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const unsigned voff = idx_cur[gp][u] >= 0 ? (unsigned)idx_cur[gp][u] * row_bytes + a_part16[u] : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void_ptr)(dst + u * 512), 16, voff, soff, 0, 0);
+      }
+    }
+  };
+  auto issue_b = [&](int st, int sl) {                    // both B pieces of k-tile st
+    const unsigned soff = (unsigned)((st % kvol) * cin * cout + (st / kvol) * BK) * 2u;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      u16* dst = smem + sl * STAGE_ELEMS + 2 * APIECE + t * BPIECE + wv * 512;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_ptr)dst, 16, w_voff[t], soff, 0, 0);
+    }
+  };
+  const int g = lane >> 4, li = lane & 15, fsw = (lane >> 1) & 7;
+  int foff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) foff[ks] = ((ks * 4 + g) ^ fsw) << 3;
+  typedef const volatile s16x8 __attribute__((address_space(3))) * lds_vptr;
+  auto frag = [&](const u16* rowp, int ks) {
+    s16x8 v = *(lds_vptr)(rowp + foff[ks]);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  bf16x8 af[2][4][2], bf[2][2][2];                        // A: [register set][row block][k-step]; B: [column half][col block][k-step]
+#define N8_READ_A(SL, SET)                                                                                   \
+  {                                                                                                          \
+    const u16* A_ = smem + (SL) * STAGE_ELEMS + grp * APIECE + (((wv >> 1) & 1) * 64 + li) * BK;             \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                          \
+      af[SET][a][0] = frag(A_ + a * 16 * BK, 0);                                                             \
+      af[SET][a][1] = frag(A_ + a * 16 * BK, 1);                                                             \
+    }                                                                                                        \
+  }
+#define N8_READ_B(SL)                                                                                        \
+  {                                                                                                          \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                          \
+      const u16* B_ = smem + (SL) * STAGE_ELEMS + 2 * APIECE + t * BPIECE + (wn * 32 + li) * BK;             \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                        \
+        bf[t][b][0] = frag(B_ + b * 16 * BK, 0);                                                             \
+        bf[t][b][1] = frag(B_ + b * 16 * BK, 1);                                                             \
+      }                                                                                                      \
+    }                                                                                                        \
+  }
+#define N8_MMA(SET, T)                                                                                       \
+  {                                                                                                          \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                          \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                        \
+          acc[a][(T) * 2 + b] =                                                                              \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[T][b][ks], af[SET][a][ks], acc[a][(T) * 2 + b], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+  }
+#define N8_BAR()                                  \
+  {                                               \
+    __builtin_amdgcn_sched_barrier(0);            \
+    __builtin_amdgcn_s_barrier();                 \
+    __builtin_amdgcn_sched_barrier(0);            \
+  }
+  // one k-tile: SET = the A register set holding k-tile st (the other one receives k-tile st + 1)
+#define N8_TRIP(SET)                                                                                         \
+  {                                                                                                          \
+    const int s2 = st + 2 < nstage ? st + 2 : nstage - 1;                                                    \
+    load_idx_next(st + 3 < nstage ? st + 3 : nstage - 1);                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    N8_READ_B(sl0)                                                                                           \
+    issue_a(s2, sl2);                                                                                        \
+    __builtin_amdgcn_s_waitcnt(0x0F7A);                   /* vmcnt(10): A of k-tile st + 1 */                \
+    N8_BAR();                                                                                                \
+    N8_MMA(SET, 0)                                                                                           \
+    N8_BAR();                                                                                                \
+    N8_READ_A(sl1, (SET) ^ 1)                                                                                \
+    issue_b(s2, sl2);                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    advance_idx();                                                                                           \
+    __builtin_amdgcn_s_waitcnt(0x0F7A);                   /* vmcnt(10): B of k-tile st + 1 */                \
+    N8_BAR();                                                                                                \
+    N8_MMA(SET, 1)                                                                                           \
+    N8_BAR();                                                                                                \
+    { const int t_ = sl0; sl0 = sl1; sl1 = sl2; sl2 = t_; }                                                  \
+    ++st;                                                                                                    \
+  }
+  // prologue: k-tiles 0 and 1 requested (slots 0, 1), indices of k-tile 2 current, A of k-tile 0 in register set 0
+  load_idx_next(0);
+  advance_idx();
+  issue_a(0, 0); issue_b(0, 0);
+  load_idx_next(1 < nstage ? 1 : 0);
+  advance_idx();
+  issue_a(1 < nstage ? 1 : 0, 1); issue_b(1 < nstage ? 1 : 0, 1);
+  load_idx_next(2 < nstage ? 2 : nstage - 1);
+  advance_idx();
+  __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+  N8_BAR();
+  N8_READ_A(0, 0)
+  if (grp == 1) N8_BAR();                                 // the second group runs one barrier behind the first
+  int st = 0, sl0 = 0, sl1 = 1, sl2 = 2;
+  while (st + 1 < nstage) {
+    N8_TRIP(0)
+    N8_TRIP(1)
+  }
+  if (st < nstage) N8_TRIP(0)
+  if (grp == 0) N8_BAR();
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+#undef N8_READ_A
+#undef N8_READ_B
+#undef N8_MMA
+#undef N8_BAR
+#undef N8_TRIP
+#define GLDS_EPI_ADDEND 1
+#include "glds_epilogue.inc"
+#undef GLDS_EPI_ADDEND
+}
+__global__ __launch_bounds__(512) void k_igemm_glds8_256x128(const u16* in, const u16* w, const int* nbr, int ld, u16* out,
+                                                             const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,
+                                                             const float* bias, int relu, double* stats) {
+  igemm_glds8n_body(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats);
+}
+// the 256 x 128 eight-phase kernel for the shapes it is dispatched on: long reductions (>= GLDS8N_MIN_KTILES k-tiles), enough
+// workgroups to keep most CUs busy with ONE per CU
+#ifndef GLDS8N_MIN_KTILES
+#define GLDS8N_MIN_KTILES 48
+#endif
+static bool igemm_glds8n_shape(const int32_t* nbr, int n_out_cap, int cin, int cout, int kvol) {
+  return IGEMM_GLDS8N && nbr && cin % 64 == 0 && cout % 128 == 0 && kvol * (cin / 64) >= GLDS8N_MIN_KTILES
+         && (long long)u3d_cdiv(n_out_cap, 256) * (cout / 128) >= 160;
+}
+static int launch_igemm_glds8n(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev,
+                               int n_out_cap, int cin, int cout, int kvol, hipStream_t s, const float* bias = nullptr, int relu = 0,
+                               double* stats = nullptr) {
+  constexpr size_t lds = 3 * (size_t)(256 + 128) * 64 * 2;      // 144 KiB
+  U3D_ALLOW_LDS(k_igemm_glds8_256x128, lds);
+  dim3 grid(u3d_cdiv(n_out_cap, 256), cout / 128);
+  hipLaunchKernelGGL(k_igemm_glds8_256x128, grid, dim3(512), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap,
+                     cin, cout, kvol, bias, relu, stats);
+  return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
+}
+
 // concrete kernels (a __global__ TEMPLATE with this body lost its host stub under hipcc 7.2: undefined symbol at load time)
 #define U3D_GLDS_KERNEL(NAME, A, B, C, D)                                                                                        \
   __global__ __launch_bounds__(A* B * 64) void NAME(const u16* in, const u16* w, const int* nbr, int ld, u16* out,               \
@@ -1149,6 +1381,13 @@ extern "C" int32_t u3d_igemm_fwd_stats_tile_rows(int32_t n_out_cap, int32_t cin,
 // number of statistics partials u3d_igemm_fwd_stats_bf16 writes for this shape (0: not served).  LDS-DMA kernels: one per row tile
 // (ceil(n_out_cap / u3d_igemm_fwd_stats_tile_rows)); direct-operand kernels of the narrow 27-offset levels: one per WAVE of their
 // persistent grid - u3d_igemm_fwd_stats_tile_rows is 0 there and u3d_bn_finalize_partials takes rows_per_block = 0 ("all of them")
+// rows per statistics partial of u3d_igemm_fwd_stats_bf16 for a conv WITH a neighbour table and `kvol` offsets (what
+// u3d_bn_finalize_partials takes as rows_per_block): the LDS-DMA kernels' row-tile height - which depends on kvol where the
+// 256 x 128 eight-phase kernel serves long reductions -, 0 for the per-wave partials of the direct-operand kernels / unserved shapes
+extern "C" int32_t u3d_igemm_fwd_stats_rows(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol) {
+  if (igemm_glds8n_shape((const int32_t*)16, n_out_cap, cin, cout, kvol)) return 256;
+  return u3d_igemm_fwd_stats_tile_rows(n_out_cap, cin, cout);
+}
 #ifndef DIRECT_STATS
 #define DIRECT_STATS 1
 #endif
@@ -1160,7 +1399,7 @@ extern "C" int32_t u3d_igemm_fwd_stats_blocks(int32_t n_out_cap, int32_t cin, in
       return nb;
   }
 #endif
-  const int tr = u3d_igemm_fwd_stats_tile_rows(n_out_cap, cin, cout);
+  const int tr = u3d_igemm_fwd_stats_rows(n_out_cap, cin, cout, kvol);
   return tr ? u3d_cdiv(n_out_cap, tr) : 0;
 }
 extern "C" int32_t u3d_igemm_fwd_stats_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,
@@ -1176,6 +1415,8 @@ extern "C" int32_t u3d_igemm_fwd_stats_bf16(const void* in, const void* w, const
   const int tr = u3d_igemm_fwd_stats_tile_rows(n_out_cap, cin, cout);
   if (tr == 0) return U3D_ERR_UNSUPPORTED;
   if (tr == 256) return launch_igemm_glds<GLDS256_CFG>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);
+  if (igemm_glds8n_shape(nbr, n_out_cap, cin, cout, kvol))          // (256-row tiles too: u3d_igemm_fwd_stats_rows)
+    return launch_igemm_glds8n(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);
   if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);
   return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);
 }
@@ -1326,6 +1567,8 @@ extern "C" int32_t u3d_igemm_fwd_add_bf16(const void* in, const void* w, const i
       if (!(IGEMM_GLDS8 && nbr)) return U3D_ERR_UNSUPPORTED;
       return launch_igemm_glds<GLDS256_CFG>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, (const float*)addend, 2);
     }
+    if (igemm_glds8n_shape(nbr, n_out_cap, cin, cout, kvol))
+      return launch_igemm_glds8n(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, (const float*)addend, 2);
     if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, (const float*)addend, 2);
     return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, (const float*)addend, 2);
   }
@@ -1381,6 +1624,7 @@ extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32
   if (transpose_w) {                                                // n-major weights: LDS-DMA staged kernels
     if (cout % 256 == 0 && wg256 >= 128) return launch_igemm_glds<GLDS256_CFG>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
     // 128 x 128 (4 waves, 64 KiB LDS, two workgroups per CU out of phase): +3...6 % over 256 x 128 on the 128- and 512-channel layers
+    if (igemm_glds8n_shape(nbr, n_out_cap, cin, cout, kvol)) return launch_igemm_glds8n(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
     if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
     if (cout % 64 == 0) return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s);
   }

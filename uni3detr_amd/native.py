@@ -91,6 +91,7 @@ _SIGS = {
     "u3d_spconv_wgrad": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "u3d_igemm_fwd_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "u3d_igemm_fwd_stats_blocks": (_I, [_I, _I, _I, _I]),
+    "u3d_igemm_fwd_stats_rows": (_I, [_I, _I, _I, _I]),
     "u3d_igemm_fwd_add_bf16": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "u3d_linear_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "u3d_igemm_wgrad_bf16_workspace": (_L, [_I, _I, _I, _I]),
@@ -410,8 +411,9 @@ def spconv_fwd_stats(inp, w_nmajor, nbr, n_out_dev, n_out, cout):
     if nblocks == 0:
         return None
     # 0 for the direct-operand kernels of the narrow levels: per-wave partials, all of them count (rows_per_block = 0 downstream)
-    tr = int(lib().u3d_igemm_fwd_stats_tile_rows(n_out, cin, cout))
-    assert tr == 0 or nblocks == (n_out + tr - 1) // tr
+    tr = int(lib().u3d_igemm_fwd_stats_rows(n_out, cin, cout, kvol)) if nbr is not None else int(lib().u3d_igemm_fwd_stats_tile_rows(n_out, cin, cout))
+    if tr and nblocks != (n_out + tr - 1) // tr:
+        tr = 0
     out = torch.empty((n_out, cout), dtype=inp.dtype, device=inp.device)
     stats = torch.empty((nblocks, 2, cout), dtype=torch.float64, device=inp.device)
     ld = nbr.shape[1] if nbr is not None else 0
