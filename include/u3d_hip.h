@@ -409,6 +409,14 @@ int32_t u3d_adamw_set_hyper(float* state, float lr, float beta1, float beta2, fl
                             u3d_stream s);
 int32_t u3d_adamw_step_state(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
                              const uint8_t* skip, void* workspace, int64_t workspace_bytes, u3d_stream s);
+/* u3d_adamw_step_state with a HOLD flag: hold (nullable) -> one device float; > 0 makes this step a no-op (parameters, moments and
+ * the step count untouched; state[11] = 1, state[12] += 1 = held steps so far).  Static-shape training (hipGraph replay over
+ * capacity-sized sparse levels) uses it so that a batch that overflowed a level - on ANY rank: the flag rides in the job's
+ * positive-count all-reduce - never trains on truncated levels; the host reads state[12] now and then and re-captures. */
+int32_t u3d_adamw_step_hold(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                            const uint8_t* skip, const float* hold, void* workspace, int64_t workspace_bytes, u3d_stream s);
+/* flag[0] = number of i < n (n <= 8) with *counts[i] > caps[i]; counts: HOST array of device pointers, caps: HOST array */
+int32_t u3d_capacity_flag(const int32_t* const* counts, const int32_t* caps, int32_t n, float* flag, u3d_stream s);
 int32_t u3d_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                        float beta2, float eps, float weight_decay, float max_norm, float* state, void* workspace,
                        int64_t workspace_bytes, u3d_stream s);
@@ -505,6 +513,9 @@ typedef struct u3d_declayer_dims {
   int32_t layer;        /* dropout stream id */
   float p_attn, p_drop; /* dropout probabilities: attention weights | the four residual / FFN sites (0 = off) */
   float ln_eps;
+  int32_t dtype;        /* U3D_BF16: bf16 activations / weights / slots, v_mfma_f32_16x16x32_bf16 (throughput mode);
+                           U3D_F32: f32 everywhere, exact v_mfma_f32_16x16x4_f32 (parity mode) - the SAME kernels, instantiated on the
+                           element type; every `void*` operand / slot below then holds f32 and xc may alias x */
 } u3d_declayer_dims;
 /* forward-save slots (row matrices [m, cols]); u3d_decoder_layer_slots fills byte offsets (U3D_DS_COUNT + 1 entries, last = total) */
 enum {
@@ -520,10 +531,12 @@ enum {
   U3D_DG_QS2, U3D_DG_QS1, U3D_DG_RAW, U3D_DG_RPH2, U3D_DG_RPH1, U3D_DG_LNP, U3D_DG_DU1, U3D_DG_DPOSA, U3D_DG_SINE,
   U3D_DG_COUNT
 };
-int32_t u3d_decoder_layer_slots(int32_t m, int32_t ncls, int32_t code, int64_t* save_off, int64_t* grad_off);
-int32_t u3d_decoder_layer_blocks(int32_t m);   /* workgroups of the row-chain kernels = rows of every U3D_DG_LNP partial matrix */
+int32_t u3d_decoder_layer_slots(int32_t m, int32_t ncls, int32_t code, int64_t* save_off, int64_t* grad_off);      /* = _dt(.., U3D_BF16, ..) */
+int32_t u3d_decoder_layer_slots_dt(int32_t m, int32_t ncls, int32_t code, int32_t dtype, int64_t* save_off, int64_t* grad_off);
+int32_t u3d_decoder_layer_blocks(int32_t m);   /* workgroups of the row-chain kernels = rows of every U3D_DG_LNP partial matrix (bf16) */
+int32_t u3d_decoder_layer_blocks_dt(int32_t m, int32_t dtype);   /* rows per workgroup: 32 (U3D_BF16) / 16 (U3D_F32) */
 /* ROW PADDING: every row matrix this layer WRITES (x_out, xc_out, reg_out, cls_out, iou_out, dx, dref and all slots) must hold
- * u3d_decoder_layer_blocks(m) * 32 rows; rows >= m receive values nobody reads.  Matrices it only READS (x, xc, ref, dx_out, dreg,
+ * u3d_decoder_layer_blocks_dt(m, dtype) * (32 | 16) rows; rows >= m receive values nobody reads.  Matrices it only READS (x, xc, ref, dx_out, dreg,
  * dcls, diou) have m rows.  (The row kernels contain no branch on the row index: see csrc/decoder_common.h.) */
 /* x f32 [m,256] layer input, xc its bf16 copy, ref f32 [m,3] logits, value bf16 rows, rng: device uint64 seed.
  * Outputs: x_out f32 / xc_out bf16 [m,256], reg_out f32 [m,code], cls_out f32 [m,ncls], iou_out f32 [m]; save: the slot buffer. */
@@ -543,6 +556,11 @@ int32_t u3d_mha_fwd(const void* qk, const void* v, int32_t m, int32_t nq, float 
                     float* lse, u3d_stream s);
 int32_t u3d_mha_bwd(const void* qk, const void* v, const void* o, const void* d_o, const float* lse, int32_t m, int32_t nq,
                     float p_attn, int32_t layer, const uint64_t* rng, void* dqk, void* dv, u3d_stream s);
+/* the same kernels on either element type (dtype U3D_BF16 | U3D_F32: all matrices then f32, exact-f32 MFMA) */
+int32_t u3d_mha_fwd_dt(const void* qk, const void* v, int32_t m, int32_t nq, float p_attn, int32_t layer, const uint64_t* rng, void* o,
+                       float* lse, int32_t dtype, u3d_stream s);
+int32_t u3d_mha_bwd_dt(const void* qk, const void* v, const void* o, const void* d_o, const float* lse, int32_t m, int32_t nq,
+                       float p_attn, int32_t layer, const uint64_t* rng, void* dqk, void* dv, int32_t dtype, u3d_stream s);
 /* Refresh of the bf16 weight copies the fused layer reads: for each descriptor dst[n][k] = bf16(src[n][k]) (rows n >= N zero up to
  * n_pad) and dst_t[k][n] = the transpose with n_pad_t columns.  descs in device memory; one launch for all linears of all layers. */
 typedef struct u3d_wpack_desc {
@@ -550,6 +568,8 @@ typedef struct u3d_wpack_desc {
   int32_t n, k, n_pad, n_pad_t;
 } u3d_wpack_desc;
 int32_t u3d_wpack_bf16(const u3d_wpack_desc* descs_dev, int32_t count, int32_t max_elems, u3d_stream s);
+/* dtype U3D_F32: the same copies in f32 (zero-padded rows / transposes of the f32 masters) for the parity-mode instantiation */
+int32_t u3d_wpack(const u3d_wpack_desc* descs_dev, int32_t count, int32_t max_elems, int32_t dtype, u3d_stream s);
 /* keep-mask of the layer's dropout sites as bytes (testing aid): site 0..3 = out_proj, output_proj, FFN hidden, FFN out over
  * [m, cols]; site 4 = attention weights over [m*8, nq] (row = (group*8 + head)*nq + query). */
 int32_t u3d_dropout_mask(const uint64_t* rng, int32_t layer, int32_t site, int64_t n, float p, uint8_t* keep, u3d_stream s);

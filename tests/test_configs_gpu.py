@@ -109,6 +109,7 @@ def test_head_variants_match_reference_golden(cuda, name):
     feats = seeded_input(name + ".pts_feats", (B, C, D, H, W), seed, -0.5, 1.0).clamp_min(0).to(cuda).requires_grad_(True)
     fps = seeded_input(name + ".fpsbpts", (B, 2 * nq, 3), seed, 0.0, 1.0).to(cuda)
     outs = head(feats, None, fps)
+    assert head.transformer.decoder._fused_et == torch.float32      # the f32 instantiation of the fused HIP decoder kernels
     for key, oname in (("_cls", "all_cls_scores"), ("_box", "all_bbox_preds"), ("_iou", "all_iou_preds")):
         ref = torch.from_numpy(z[name + key])
         assert outs[oname].shape == ref.shape

@@ -32,6 +32,31 @@ def no_dropout(model):
     return model
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def no_vendor_gemm():
+    """Fails the test if the code inside reaches a vendor GEMM / attention entry point (F.linear -> hipBLASLt, SDPA -> AOTriton, mm,
+    addmm, bmm): the 1e-3 reference parity must be earned by the hand-written decoder kernels the benchmark runs."""
+    import torch.nn.functional as F
+
+    def boom(name):
+        def f(*a, **k):
+            raise AssertionError(f"vendor kernel entry point reached: {name}")
+        return f
+    saved = [(F, "linear", F.linear), (F, "scaled_dot_product_attention", F.scaled_dot_product_attention), (torch, "mm", torch.mm),
+             (torch, "addmm", torch.addmm), (torch, "bmm", torch.bmm), (torch, "matmul", torch.matmul),
+             (torch.Tensor, "__matmul__", torch.Tensor.__matmul__), (torch, "_addmm_activation", torch._addmm_activation)]
+    for mod, name, _ in saved:
+        setattr(mod, name, boom(name))
+    try:
+        yield
+    finally:
+        for mod, name, fn in saved:
+            setattr(mod, name, fn)
+
+
 def seeded_model(cuda, seed, prefix_strip=""):
     model = build_model(MODEL_CFG)
     sd = {k: seeded_tensor(k[len(prefix_strip):] if k.startswith(prefix_strip) else k, tuple(v.shape), seed) for k, v in model.state_dict().items()}
@@ -47,7 +72,9 @@ def test_head_forward_loss_backward_match_reference_golden(cuda):
     head = no_dropout(head).to(cuda).train()
     feats = seeded_input("pts_feats", (2, 256, 15, 40, 40), seed, -0.5, 1.0).clamp_min(0).to(cuda).requires_grad_(True)
     fps = seeded_input("fpsbpts", (2, 600, 3), seed, 0.0, 1.0).to(cuda)
-    outs = head(feats, None, fps)
+    with no_vendor_gemm():            # the decoder / head run on the f32 instantiation of the fused HIP kernels, not on ATen
+        outs = head(feats, None, fps)
+    assert head.transformer.decoder._fused_et == torch.float32
     for k, name in (("cls", "all_cls_scores"), ("box", "all_bbox_preds"), ("iou", "all_iou_preds")):
         ref = torch.from_numpy(z[k])
         err = (outs[name].detach().cpu() - ref).abs().max().item()
@@ -62,7 +89,8 @@ def test_head_forward_loss_backward_match_reference_golden(cuda):
     for name, val in zip(z["loss_names"], z["loss_values"]):
         got = float(losses[str(name)])
         assert abs(got - val) <= 1e-3 * max(1.0, abs(val)), (name, got, val)
-    sum(losses.values()).backward()
+    with no_vendor_gemm():
+        sum(losses.values()).backward()
     g = feats.grad.reshape(-1)[::997].cpu().numpy()
     np.testing.assert_allclose(g, z["feats_grad_sub"], rtol=5e-3, atol=5e-5)
     pg = {k: float(p.grad.norm()) for k, p in head.named_parameters() if p.grad is not None}
@@ -78,8 +106,9 @@ def test_head_eval_layout_matches_reference_golden(cuda):
     head = head.to(cuda).eval()
     feats = seeded_input("pts_feats", (1, 256, 15, 40, 40), seed, -0.5, 1.0).clamp_min(0).to(cuda)
     fps = seeded_input("fpsbpts", (1, 600, 3), seed, 0.0, 1.0).to(cuda)
-    with torch.no_grad():
+    with torch.no_grad(), no_vendor_gemm():
         outs = head(feats, None, fps, rand_points=torch.from_numpy(z["rand_points"]).to(cuda))
+    assert head.transformer.decoder._fused_et == torch.float32
     assert outs["all_cls_scores"].shape == (3, 1, 1200, 10)
     for k, name in (("cls", "all_cls_scores"), ("box", "all_bbox_preds"), ("iou", "all_iou_preds")):
         assert (outs[name].cpu() - torch.from_numpy(z[k])).abs().max().item() <= 1e-3 * max(1.0, float(np.abs(z[k]).max()))

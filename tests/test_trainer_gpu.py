@@ -255,3 +255,73 @@ def test_captured_step_follows_lr_schedule_and_new_batches(cuda):
     assert not torch.equal(w.detach(), w0)                                      # (a) and now they move
     with pytest.raises(ValueError):
         ts.set_batch([pts[0][:100], pts[1]], gts, labels)
+
+
+def test_capacity_overflow_holds_the_update_and_recaptures_collectively(cuda):
+    """VERDICT r2 / ADVICE: a sparse level that outgrows its captured capacity must neither train on truncated levels nor be handled
+    by one rank alone.  The device computes the flag inside G1, it rides in the positive-count all-reduce, G3 holds the update when it
+    is set; every `check_every` steps the (rank-identical) held-step counter triggers recapture(), which tears the process group down
+    through pg_hooks, captures, and creates it again.  One rank + a gloo group exercises exactly that code path."""
+    import os
+    import socket
+    import torch.distributed as dist
+    pts, gts, labels = _data(cuda)
+    # the same scenes squeezed to a fifth of their extent: far fewer occupied voxels on every strided level -> small capacities
+    ctr = torch.tensor([0.0, 3.0, -0.7, 0.0], device=cuda)
+    small = [(p - ctr) * torch.tensor([0.2, 0.2, 0.2, 1.0], device=cuda) + ctr for p in pts]
+    m = _model(cuda)
+    gen = [0]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+
+    def setup():
+        store = dist.TCPStore("127.0.0.1", port + gen[0], 1, True)
+        gen[0] += 1
+        dist.init_process_group("gloo", store=store, rank=0, world_size=1)
+
+    def teardown():
+        dist.destroy_process_group()
+    ts = TrainStep(m, small, gts, labels, graph=True, lr=1e-3, capacity_margin=1.0, check_every=3, pg_hooks=(teardown, setup))
+    ts.capture(batches=[(small, gts, labels)])
+    setup()
+    try:
+        ts.enable_dist()
+        with pytest.raises(RuntimeError):
+            ts.capture()                                   # a capture under a live process group is refused, not attempted
+        w = m.pts_bbox_head.cls_branches[0][0].weight
+        ts.step()
+        assert ts.held_steps() == 0
+        w0 = w.detach().clone()
+        ts.set_batch(pts, gts, labels)                     # the real scenes overflow the squeezed scenes' capacities
+        ts.step(); ts.step()
+        assert ts.held_steps() == 2 and torch.equal(w.detach(), w0)      # both updates were held: nothing trained on truncated levels
+        with pytest.raises(RuntimeError):
+            ts.check_capacities()
+        ts.step()                                          # check_every reached: collective re-capture, then a real step
+        assert ts.recaptures == 1 and ts.dist_on and dist.is_initialized()
+        assert ts.held_steps() == 0 and not torch.equal(w.detach(), w0)
+        ts.check_capacities()
+        assert float(ts.opt_state[0]) == 2.0               # optimizer step count: 1 before the overflow + 1 after; held steps not counted
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_optimizer_state_round_trip(cuda):
+    """resume_from (ref: extra_tools/train.py:141-142): flat AdamW moments / step count exported and re-imported bit for bit."""
+    pts, gts, labels = _data(cuda)
+    m = _model(cuda)
+    ts = TrainStep(m, pts, gts, labels, graph=False, lr=1e-3)
+    for _ in range(2):
+        ts.step()
+    sd = ts.optimizer_state_dict()
+    msd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    l3 = float(ts.step())
+    m2 = _model(cuda, msd)
+    ts2 = TrainStep(m2, pts, gts, labels, graph=False, lr=1e-3)
+    ts2.load_optimizer_state_dict(sd)
+    assert float(ts2.opt_state[0]) == 2.0
+    l3b = float(ts2.step())
+    assert abs(l3 - l3b) <= 1e-3 * abs(l3), (l3, l3b)
+    a = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    b = torch.cat([p.detach().reshape(-1) for p in m2.parameters()])
+    assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())

@@ -1,10 +1,17 @@
-// Building blocks of the fused decoder-layer kernels (decoder.hip, decoder_bwd.hip): a 32-row block of the layer state lives in LDS
+// Building blocks of the fused decoder-layer kernels (decoder.hip, decoder_bwd.hip): a block of rows of the layer state lives in LDS
 // through a whole chain of GEMMs / LayerNorms; weights stream from L2 straight into MFMA fragments (each wave owns 64 output
 // columns, so no two waves share a weight row and LDS staging of the weights would buy nothing).
 //
-// MFMA orientation: D^T = W . X^T, i.e. a-operand = weight rows (lane l: row n = l&15, 8 consecutive k at (l>>4)*8), b-operand =
-// activation rows from LDS (lane l: row m = l&15, same 8 k) -> a lane ends up with 4 CONSECUTIVE output columns of one row:
-// 8-byte bf16 / 16-byte f32 accesses in every epilogue.
+// Every kernel is a template over an ELEMENT TRAIT E - the storage type of activations / weights / slots and the MFMA that consumes
+// them - and is instantiated twice:
+//   EB  bf16 storage, v_mfma_f32_16x16x32_bf16, 32 rows per workgroup            (throughput mode, U3D_BF16)
+//   EF  f32 storage,  v_mfma_f32_16x16x4_f32 (bitwise an fma chain), 16 rows     (parity mode, U3D_F32: the 1e-3 reference goldens)
+// Same source, same launch structure, same slot layout (element size aside): what the parity tests exercise IS the benchmarked code.
+//
+// MFMA orientation: D^T = W . X^T, i.e. a-operand = weight rows (lane l: row n = l&15, one 16-byte chunk of k at chunk (l>>4)),
+// b-operand = activation rows from LDS (lane l: row m = l&15, same chunk) -> a lane ends up with 4 CONSECUTIVE output columns of
+// one row: 8-byte bf16 / 16-byte f32 accesses in every epilogue.  A 16-byte chunk is 8 bf16 (one 16x16x32 MFMA) or 4 f32 (four
+// 16x16x4 MFMAs, MFMA j taking element j of every lane's chunk: the reduction index is permuted identically in both operands).
 #pragma once
 #include "common.h"
 
@@ -15,41 +22,101 @@ typedef unsigned short u16;
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
-#define DC_BM 32              /* rows per workgroup */
 #define DC_THREADS 256
 #define DC_C 256              /* embed dim */
 #define DC_FF 512             /* FFN hidden */
 #define DC_TS 260             /* row stride (floats) of the f32 tiles: 8-lane store groups land on distinct banks */
 #define DC_NHEAD 8
 #define DC_HD 32
-
-// LDS map (bytes) of the row-chain kernels
-#define DC_OFF_A0 0                                  /* bf16 [32][512] */
-#define DC_OFF_A1 (DC_OFF_A0 + DC_BM * 512 * 2)      /* bf16 [32][512] */
-#define DC_OFF_A2 (DC_OFF_A1 + DC_BM * 512 * 2)      /* bf16 [32][256] */
-#define DC_OFF_F (DC_OFF_A2 + DC_BM * 256 * 2)       /* f32 [32][260] */
-#define DC_OFF_G (DC_OFF_F + DC_BM * DC_TS * 4)      /* f32 [32][260] */
-#define DC_MISC_LD 48                                 /* floats per row of the misc tile: [0,16) scalars, [16,48) narrow gradients */
-#define DC_OFF_MISC (DC_OFF_G + DC_BM * DC_TS * 4)   /* f32 [32][48] */
-#define DC_LDS_BYTES (DC_OFF_MISC + DC_BM * DC_MISC_LD * 4)
+#define DC_MISC_LD 48         /* floats per row of the misc tile: [0,16) scalars, [16,48) narrow gradients */
 
 __device__ __forceinline__ float dc_bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
 __device__ __forceinline__ u16 dc_f2bf(float f) {
   __bf16 h = (__bf16)f;
   return __builtin_bit_cast(u16, h);
 }
-__device__ __forceinline__ float dc_round(float f) { return dc_bf2f(dc_f2bf(f)); }      // value after a bf16 store
-__device__ __forceinline__ u16x4 dc_pack4(f32x4 v) { return __builtin_bit_cast(u16x4, __builtin_convertvector(v, bf16x4)); }
-__device__ __forceinline__ f32x4 dc_unpack4(u16x4 v) {
-  f32x4 r = {dc_bf2f(v[0]), dc_bf2f(v[1]), dc_bf2f(v[2]), dc_bf2f(v[3])};
-  return r;
-}
-__device__ __forceinline__ f32x4 dc_round4(f32x4 v) { return dc_unpack4(dc_pack4(v)); }
 __device__ __forceinline__ float dc_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
 
-// element offset of (row, col) in a bf16 activation tile whose rows hold `ldk` elements: the 16-byte chunk index is XORed with
-// row & 15, so the ds_read_b128 of one MFMA operand (16 rows x one chunk column per 16-lane group) touches all 64 banks once
-__device__ __forceinline__ int dc_aoff(int row, int col, int ldk) { return row * ldk + ((((col >> 3) ^ (row & 15)) << 3) | (col & 7)); }
+// ---- element traits -----------------------------------------------------------------------------------------------------------
+struct EB {                    // bf16 storage
+  typedef u16 T;
+  typedef u16x4 V4;            // 4 consecutive elements (a lane's share of one MFMA output row)
+  typedef u16x8 VC;            // one 16-byte chunk
+  static constexpr int CH = 8;        // elements per 16-byte chunk
+  static constexpr int BM = 32;       // rows per workgroup of the row-chain kernels
+  static constexpr int MT = 2;        // 16-row MFMA tiles per workgroup
+  static constexpr int KSTEP = 32;    // reduction elements per dc_gemm step (4 chunk columns, one per 16-lane group)
+  static constexpr int DT = U3D_BF16;
+  static constexpr int MHA_KC = 128;  // keys per LDS chunk of the attention kernels
+  __device__ static __forceinline__ float to_f(T v) { return dc_bf2f(v); }
+  __device__ static __forceinline__ T from_f(float f) { return dc_f2bf(f); }
+  __device__ static __forceinline__ float round(float f) { return dc_bf2f(dc_f2bf(f)); }         // value after a store in T
+  __device__ static __forceinline__ V4 pack4(f32x4 v) { return __builtin_bit_cast(u16x4, __builtin_convertvector(v, bf16x4)); }
+  __device__ static __forceinline__ f32x4 unpack4(V4 v) {
+    f32x4 r = {dc_bf2f(v[0]), dc_bf2f(v[1]), dc_bf2f(v[2]), dc_bf2f(v[3])};
+    return r;
+  }
+  __device__ static __forceinline__ f32x4 round4(f32x4 v) { return unpack4(pack4(v)); }
+  // transcendentals: the hardware approximations (v_exp_f32 / v_rsq_f32, ~1 ulp) - far below bf16 storage rounding
+  __device__ static __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+  __device__ static __forceinline__ float sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+  __device__ static __forceinline__ float rsqrt(float x) { return rsqrtf(x); }
+  __device__ static __forceinline__ VC zero_chunk() { return (VC){0, 0, 0, 0, 0, 0, 0, 0}; }
+  __device__ static __forceinline__ float chunk_elem(const VC& v, int e) { return dc_bf2f(v[e]); }
+  // acc += sum over the chunk's reduction elements of w . a
+  __device__ static __forceinline__ void mma(const VC& w, const VC& a, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+  }
+};
+struct EF {                    // f32 storage, exact-f32 MFMA
+  typedef float T;
+  typedef f32x4 V4;
+  typedef f32x4 VC;
+  static constexpr int CH = 4;
+  static constexpr int BM = 16;
+  static constexpr int MT = 1;
+  static constexpr int KSTEP = 16;
+  static constexpr int DT = U3D_F32;
+  static constexpr int MHA_KC = 64;
+  __device__ static __forceinline__ float to_f(T v) { return v; }
+  __device__ static __forceinline__ T from_f(float f) { return f; }
+  __device__ static __forceinline__ float round(float f) { return f; }
+  __device__ static __forceinline__ V4 pack4(f32x4 v) { return v; }
+  __device__ static __forceinline__ f32x4 unpack4(V4 v) { return v; }
+  __device__ static __forceinline__ f32x4 round4(f32x4 v) { return v; }
+  // parity mode: correctly rounded library functions (the softmax backward multiplies p by a difference of near-equal terms, which
+  // amplifies a 1-ulp error in p into 1e-4 of the gradient)
+  __device__ static __forceinline__ float exp2(float x) { return exp2f(x); }
+  __device__ static __forceinline__ float sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+  __device__ static __forceinline__ float rsqrt(float x) { return 1.f / sqrtf(x); }
+  __device__ static __forceinline__ VC zero_chunk() { return (VC){0.f, 0.f, 0.f, 0.f}; }
+  __device__ static __forceinline__ float chunk_elem(const VC& v, int e) { return v[e]; }
+  __device__ static __forceinline__ void mma(const VC& w, const VC& a, f32x4& acc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], a[j], acc, 0, 0, 0);
+  }
+};
+
+// LDS map (bytes) of the row-chain kernels
+template <typename E>
+struct DcLds {
+  static constexpr int ES = (int)sizeof(typename E::T);
+  static constexpr int A0 = 0;                                /* T [BM][512] */
+  static constexpr int A1 = A0 + E::BM * 512 * ES;            /* T [BM][512] */
+  static constexpr int A2 = A1 + E::BM * 512 * ES;            /* T [BM][256] */
+  static constexpr int F = A2 + E::BM * 256 * ES;             /* f32 [BM][260] */
+  static constexpr int G = F + E::BM * DC_TS * 4;             /* f32 [BM][260] */
+  static constexpr int MISC = G + E::BM * DC_TS * 4;          /* f32 [BM][48] */
+  static constexpr int BYTES = MISC + E::BM * DC_MISC_LD * 4;
+};
+static_assert(DcLds<EB>::BYTES <= 160 * 1024 && DcLds<EF>::BYTES <= 160 * 1024, "row-chain tiles must fit the CU's LDS");
+
+// element offset of (row, col) in an activation tile whose rows hold `ldk` elements: the 16-byte chunk index is XORed with
+// row & 15, so the ds_read_b128 of one MFMA operand (16 rows x one chunk column per 16-lane group) spreads over the banks
+template <typename E>
+__device__ __forceinline__ int dc_aoff(int row, int col, int ldk) {
+  return row * ldk + ((((col / E::CH) ^ (row & 15)) * E::CH) | (col % E::CH));
+}
 
 // ---- dropout: keep decision of element idx at (layer, site); identical in forward and backward ----------------------------
 struct DcRng { unsigned lo, hi; };
@@ -79,7 +146,7 @@ struct DcDrop {
   }
 };
 
-// ---- the block GEMM: acc[mt][nt] (+)= X[32 rows] . W[NT*16 rows]^T over K ---------------------------------------------------
+// ---- the block GEMM: acc[mt][nt] (+)= X[BM rows] . W[NT*16 rows]^T over K ---------------------------------------------------
 // A: LDS activation tile (ldk = K); W: global weight rows, already offset to the wave's first output column.
 // The weight fragments of DC_PF k-steps are requested in ONE burst and consumed behind sched_barriers: left alone, hipcc's
 // scheduler sinks each load to just before its MFMA (2-3 loads in flight per wave), and with one wave per SIMD every k-step then
@@ -93,51 +160,55 @@ constexpr int dc_burst(int ks, int want) {          // largest divisor of ks tha
     if (ks % d == 0) b = d;
   return b;
 }
-template <int K, int NT>
-__device__ __forceinline__ void dc_gemm(const u16* A, const u16* __restrict__ W, f32x4 (&acc)[2][NT], int lane) {
-  constexpr int KS = K / 32;
+template <typename E, int K, int NT>
+__device__ __forceinline__ void dc_gemm(const typename E::T* A, const typename E::T* __restrict__ W, f32x4 (&acc)[E::MT][NT], int lane) {
+  typedef typename E::T T;
+  typedef typename E::VC VC;
+  constexpr int KS = K / E::KSTEP;
   constexpr int PF = dc_burst(KS, DC_PF);
+  static_assert((K / E::CH) % 16 == 0, "the chunk swizzle permutes aligned groups of 16 chunks");
   const int r16 = lane & 15, kq = lane >> 4;
-  const u16* wp[NT];
+  const T* wp[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) wp[nt] = W + (size_t)(nt * 16 + r16) * K + kq * 8;
-  const u16* ap0 = A + r16 * K;
-  const u16* ap1 = A + (16 + r16) * K;
+  for (int nt = 0; nt < NT; ++nt) wp[nt] = W + (size_t)(nt * 16 + r16) * K + kq * E::CH;
+  const T* ap[E::MT];
+#pragma unroll
+  for (int mt = 0; mt < E::MT; ++mt) ap[mt] = A + (mt * 16 + r16) * K;
 #pragma unroll
   for (int kb = 0; kb < KS; kb += PF) {
-    bf16x8 wf[PF][NT];
+    VC wf[PF][NT];
 #pragma unroll
     for (int p = 0; p < PF; ++p)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wf[p][nt] = *(const bf16x8*)(wp[nt] + (kb + p) * 32);
+      for (int nt = 0; nt < NT; ++nt) wf[p][nt] = *(const VC*)(wp[nt] + (kb + p) * E::KSTEP);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      const int ch = (((kb + p) * 4 + kq) ^ r16) << 3;
-      const bf16x8 a0 = *(const bf16x8*)(ap0 + ch);
-      const bf16x8 a1 = *(const bf16x8*)(ap1 + ch);
+      const int ch = (((kb + p) * 4 + kq) ^ r16) * E::CH;
+      VC a[E::MT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[p][nt], a0, acc[0][nt], 0, 0, 0);
-        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[p][nt], a1, acc[1][nt], 0, 0, 0);
-      }
+      for (int mt = 0; mt < E::MT; ++mt) a[mt] = *(const VC*)(ap[mt] + ch);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < E::MT; ++mt) E::mma(wf[p][nt], a[mt], acc[mt][nt]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// y[32 rows][ncol0 .. ncol0 + NT*16) = X . W^T; epi(row, col, v) gets 4 consecutive columns col..col+3 of row `row`
-template <int K, int NT, typename Epi>
-__device__ __forceinline__ void dc_linear(const u16* A, const u16* __restrict__ W, int ncol0, int lane, Epi epi) {
-  f32x4 acc[2][NT];
+// y[BM rows][ncol0 .. ncol0 + NT*16) = X . W^T; epi(row, col, v) gets 4 consecutive columns col..col+3 of row `row`
+template <typename E, int K, int NT, typename Epi>
+__device__ __forceinline__ void dc_linear(const typename E::T* A, const typename E::T* __restrict__ W, int ncol0, int lane, Epi epi) {
+  f32x4 acc[E::MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < E::MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  dc_gemm<K, NT>(A, W + (size_t)ncol0 * K, acc, lane);
+  dc_gemm<E, K, NT>(A, W + (size_t)ncol0 * K, acc, lane);
   const int r16 = lane & 15, kq = lane >> 4;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < E::MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) epi(mt * 16 + r16, ncol0 + nt * 16 + kq * 4, acc[mt][nt]);
 }
@@ -153,8 +224,8 @@ __device__ __forceinline__ f32x4 dc_relu4(f32x4 v) {
 
 // ---- control flow discipline -------------------------------------------------------------------------------------------------
 // Every loop below has a trip count the compiler can see is the same for all lanes (DC_FOR_TID), and no branch depends on the row
-// index: row matrices owned by this library (save / gradient slots, outputs) hold whole 32-row blocks (u3d_decoder_layer_blocks(m)
-// * 32 rows), caller-owned inputs of m rows are read through a clamped row index.  Reason: hipcc (ROCm 7.2) was seen to place
+// index: row matrices owned by this library (save / gradient slots, outputs) hold whole BM-row blocks (u3d_decoder_layer_blocks_dt(m)
+// * BM rows), caller-owned inputs of m rows are read through a clamped row index.  Reason: hipcc (ROCm 7.2) was seen to place
 // register-allocator copies (v_accvgpr_write) in the exit block of an exec-masked `for (i = tid; i < N; i += 256)` loop AHEAD of the
 // `s_or_b64 exec` that restores the lane mask - the copies ran with EXEC = 0 and the "saved" LDS addresses were garbage afterwards
 // (tools/check_exec_restore.py scans the ISA for that pattern; tests/test_build_cpu.py runs it).
@@ -162,35 +233,37 @@ __device__ __forceinline__ f32x4 dc_relu4(f32x4 v) {
 __device__ __forceinline__ int dc_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // ---- tile movers ------------------------------------------------------------------------------------------------------------
-// global bf16 rows [.., ld] (columns [0, K)) -> activation tile (ldk = K).  CLAMP: the source has only M rows (rows >= M re-read row M-1)
-template <int K, bool CLAMP>
-__device__ __forceinline__ void dc_load_a(u16* A, const u16* __restrict__ src, int ld, int row0, int M, int tid) {
-  constexpr int CPR = K / 8;
-  static_assert((DC_BM * CPR) % DC_THREADS == 0, "tile chunks must split evenly over the workgroup");
-  DC_FOR_TID(c, DC_BM * CPR) {
+// global rows [.., ld] (columns [0, K)) -> activation tile (ldk = K).  CLAMP: the source has only M rows (rows >= M re-read row M-1)
+template <typename E, int K, bool CLAMP>
+__device__ __forceinline__ void dc_load_a(typename E::T* A, const typename E::T* __restrict__ src, int ld, int row0, int M, int tid) {
+  typedef typename E::VC VC;
+  constexpr int CPR = K / E::CH;
+  static_assert((E::BM * CPR) % DC_THREADS == 0, "tile chunks must split evenly over the workgroup");
+  DC_FOR_TID(c, E::BM * CPR) {
     const int row = c / CPR, ch = c % CPR;
     const int gr = CLAMP ? min(row0 + row, M - 1) : row0 + row;
-    *(u16x8*)(A + dc_aoff(row, ch * 8, K)) = *(const u16x8*)(src + (size_t)gr * ld + ch * 8);
+    *(VC*)(A + dc_aoff<E>(row, ch * E::CH, K)) = *(const VC*)(src + (size_t)gr * ld + ch * E::CH);
   }
 }
-// activation tile -> global bf16 rows (padded destination)
-template <int K>
-__device__ __forceinline__ void dc_store_a(const u16* A, u16* __restrict__ dst, int ld, int row0, int tid) {
-  constexpr int CPR = K / 8;
-  DC_FOR_TID(c, DC_BM * CPR) {
+// activation tile -> global rows (padded destination)
+template <typename E, int K>
+__device__ __forceinline__ void dc_store_a(const typename E::T* A, typename E::T* __restrict__ dst, int ld, int row0, int tid) {
+  typedef typename E::VC VC;
+  constexpr int CPR = K / E::CH;
+  DC_FOR_TID(c, E::BM * CPR) {
     const int row = c / CPR, ch = c % CPR;
-    *(u16x8*)(dst + (size_t)(row0 + row) * ld + ch * 8) = *(const u16x8*)(A + dc_aoff(row, ch * 8, K));
+    *(VC*)(dst + (size_t)(row0 + row) * ld + ch * E::CH) = *(const VC*)(A + dc_aoff<E>(row, ch * E::CH, K));
   }
 }
 // f32 tile (stride DC_TS) <- global f32 rows [M, 256]: rows >= M are zero (ZERO_TAIL, gradients) or repeat row M-1 (inputs);
 // src == nullptr (uniform) fills zeros
-template <bool ZERO_TAIL>
+template <typename E, bool ZERO_TAIL>
 __device__ __forceinline__ void dc_load_f(float* T, const float* __restrict__ src, int row0, int M, int tid) {
   if (src == nullptr) {
-    DC_FOR_TID(c, DC_BM * 64) *(f32x4*)(T + (c >> 6) * DC_TS + (c & 63) * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    DC_FOR_TID(c, E::BM * 64) *(f32x4*)(T + (c >> 6) * DC_TS + (c & 63) * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
     return;
   }
-  DC_FOR_TID(c, DC_BM * 64) {
+  DC_FOR_TID(c, E::BM * 64) {
     const int row = c >> 6, q = c & 63;
     f32x4 v = *(const f32x4*)(src + (size_t)min(row0 + row, M - 1) * DC_C + q * 4);
     if (ZERO_TAIL) {
@@ -201,48 +274,54 @@ __device__ __forceinline__ void dc_load_f(float* T, const float* __restrict__ sr
   }
 }
 // padded workspace rows -> tile / tile -> padded rows
+template <typename E>
 __device__ __forceinline__ void dc_load_f_rows(float* T, const float* __restrict__ src, int row0, int tid) {
-  DC_FOR_TID(c, DC_BM * 64) *(f32x4*)(T + (c >> 6) * DC_TS + (c & 63) * 4) = *(const f32x4*)(src + (size_t)(row0 + (c >> 6)) * DC_C + (c & 63) * 4);
+  DC_FOR_TID(c, E::BM * 64) *(f32x4*)(T + (c >> 6) * DC_TS + (c & 63) * 4) = *(const f32x4*)(src + (size_t)(row0 + (c >> 6)) * DC_C + (c & 63) * 4);
 }
+template <typename E>
 __device__ __forceinline__ void dc_store_f(const float* T, float* __restrict__ dst, int row0, int tid) {
-  DC_FOR_TID(c, DC_BM * 64) *(f32x4*)(dst + (size_t)(row0 + (c >> 6)) * DC_C + (c & 63) * 4) = *(const f32x4*)(T + (c >> 6) * DC_TS + (c & 63) * 4);
+  DC_FOR_TID(c, E::BM * 64) *(f32x4*)(dst + (size_t)(row0 + (c >> 6)) * DC_C + (c & 63) * 4) = *(const f32x4*)(T + (c >> 6) * DC_TS + (c & 63) * 4);
 }
 
-// ---- LayerNorm over the 256 columns of an f32 tile: wave w owns rows 8w..8w+7, a lane 4 consecutive columns ------------------
+// ---- LayerNorm over the 256 columns of an f32 tile: wave w owns rows RPW*w .. RPW*w + RPW-1, a lane 4 consecutive columns ------
+template <typename E>
 struct DcLnOut {
-  float* tile;        // f32 tile to receive y (may alias the input tile), or null
-  u16* a; int a_ldk;  // activation tile to receive bf16(y), or null
-  float* g32;         // global f32 [M,256], or null
-  u16* g16;           // global bf16 [M,256], or null
-  float* mr;          // global f32 [M,16]: (mean, rstd) at columns 2*idx, 2*idx+1 (saved for the backward), or null
+  float* tile;                 // f32 tile to receive y (may alias the input tile), or null
+  typename E::T* a; int a_ldk; // activation tile to receive T(y), or null
+  float* g32;                  // global f32 [M,256], or null
+  typename E::T* g16;          // global T [M,256], or null
+  float* mr;                   // global f32 [M,16]: (mean, rstd) at columns 2*idx, 2*idx+1 (saved for the backward), or null
   int mr_idx;
-  bool round_out;     // y rounded through bf16 before it is used as f32 (outputs that are bf16 tensors in the layer-by-layer formulation)
-  float* gpre;        // global f32 [M,256] to receive the INPUT rows (saved for the backward), or null
+  bool round_out;              // y rounded through T before it is used as f32 (outputs that are T tensors in the layer-by-layer formulation)
+  float* gpre;                 // global f32 [M,256] to receive the INPUT rows (saved for the backward), or null
 };
+template <typename E>
 __device__ __forceinline__ void dc_layernorm(const float* T, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                             bool relu, const DcLnOut& o, int row0, int wave, int lane) {
+                                             bool relu, const DcLnOut<E>& o, int row0, int wave, int lane) {
+  typedef typename E::V4 V4;
+  constexpr int RPW = E::BM / 4;
   const f32x4 ga = *(const f32x4*)(gamma + lane * 4), be = *(const f32x4*)(beta + lane * 4);
 #pragma unroll 2
-  for (int rr = 0; rr < 8; ++rr) {
-    const int row = wave * 8 + rr;
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = wave * RPW + rr;
     const f32x4 v = *(const f32x4*)(T + row * DC_TS + lane * 4);
     const float mu = u3d_wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / DC_C);
     const f32x4 d = {v[0] - mu, v[1] - mu, v[2] - mu, v[3] - mu};
-    const float rs = rsqrtf(u3d_wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / DC_C) + eps);
+    const float rs = E::rsqrt(u3d_wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / DC_C) + eps);
     f32x4 y;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       y[j] = d[j] * rs * ga[j] + be[j];
       if (relu) y[j] = fmaxf(y[j], 0.f);
     }
-    const u16x4 yb = dc_pack4(y);
-    if (o.round_out) y = dc_unpack4(yb);
+    const V4 yb = E::pack4(y);
+    if (o.round_out) y = E::unpack4(yb);
     const size_t grow = (size_t)(row0 + row);
     if (o.gpre) *(f32x4*)(o.gpre + grow * DC_C + lane * 4) = v;
     if (o.tile) *(f32x4*)(o.tile + row * DC_TS + lane * 4) = y;
-    if (o.a) *(u16x4*)(o.a + dc_aoff(row, lane * 4, o.a_ldk)) = yb;
+    if (o.a) *(V4*)(o.a + dc_aoff<E>(row, lane * 4, o.a_ldk)) = yb;
     if (o.g32) *(f32x4*)(o.g32 + grow * DC_C + lane * 4) = y;
-    if (o.g16) *(u16x4*)(o.g16 + grow * DC_C + lane * 4) = yb;
+    if (o.g16) *(V4*)(o.g16 + grow * DC_C + lane * 4) = yb;
     if (o.mr) {                       // every lane stores the same two values: no lane-dependent branch
       o.mr[grow * 16 + 2 * o.mr_idx] = mu;
       o.mr[grow * 16 + 2 * o.mr_idx + 1] = rs;
@@ -253,8 +332,9 @@ __device__ __forceinline__ void dc_layernorm(const float* T, const float* __rest
 // ---- trilinear corner setup (F.grid_sample, align_corners=False, zeros padding; grid = (sigmoid(ref) - 0.5) * 2) --------------
 struct DcCorners { int row[8]; float w[8], dwx[8], dwy[8], dwz[8]; };
 // ref3: the three reference-point logits of ONE query, identical in all lanes -> row ids are made wave-uniform (scalar branches)
+template <typename E>
 __device__ __forceinline__ void dc_corners(const float* ref3, int b, int D, int H, int W, DcCorners& tc) {
-  const float gx = (dc_sigmoid(ref3[0]) - 0.5f) * 2.f, gy = (dc_sigmoid(ref3[1]) - 0.5f) * 2.f, gz = (dc_sigmoid(ref3[2]) - 0.5f) * 2.f;
+  const float gx = (E::sigmoid(ref3[0]) - 0.5f) * 2.f, gy = (E::sigmoid(ref3[1]) - 0.5f) * 2.f, gz = (E::sigmoid(ref3[2]) - 0.5f) * 2.f;
   const float ix = ((gx + 1.f) * W - 1.f) * 0.5f, iy = ((gy + 1.f) * H - 1.f) * 0.5f, iz = ((gz + 1.f) * D - 1.f) * 0.5f;
   const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
   const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
@@ -278,13 +358,109 @@ __device__ __forceinline__ void dc_corners(const float* ref3, int b, int D, int 
 #ifndef DC_POISON_LDS
 #define DC_POISON_LDS 0
 #endif
+template <typename E>
 __device__ __forceinline__ void dc_poison_lds(unsigned char* lds, int tid) {
 #if DC_POISON_LDS == 1
-  for (int i = tid; i < DC_LDS_BYTES / 4; i += DC_THREADS) ((unsigned*)lds)[i] = 0xFFFFFFFFu;
+  for (int i = tid; i < DcLds<E>::BYTES / 4; i += DC_THREADS) ((unsigned*)lds)[i] = 0xFFFFFFFFu;
   __syncthreads();
 #elif DC_POISON_LDS == 2
   __syncthreads();
 #elif DC_POISON_LDS == 3
-  for (int i = tid; i < DC_LDS_BYTES / 4; i += DC_THREADS) ((unsigned*)lds)[i] = 0xFFFFFFFFu;
+  for (int i = tid; i < DcLds<E>::BYTES / 4; i += DC_THREADS) ((unsigned*)lds)[i] = 0xFFFFFFFFu;
 #endif
 }
+
+// ablation hook (tools/dec_bench.py): -DDC_ABL_NOFRAGSTORE drops the MFMA-fragment-layout global stores (timing experiments only)
+#ifdef DC_ABL_NOFRAGSTORE
+#define DC_FRAG_STORE(stmt)
+#else
+#define DC_FRAG_STORE(stmt) stmt
+#endif
+
+// ---- slot geometry shared by the forward and the backward translation units ---------------------------------------------------------
+__host__ static inline int dc_esize(int dtype) { return dtype == U3D_BF16 ? 2 : 4; }
+__host__ static inline int dc_bm(int dtype) { return dtype == U3D_BF16 ? EB::BM : EF::BM; }
+
+// ---- attention building blocks (k_mha_fwd in decoder.hip, k_mha_bwd_* in decoder_bwd.hip) -----------------------------------------
+// A head slice of a row is 32 elements = NP 16-byte parts.  Row-major LDS copies [key][32] are swizzled per key; the transposed
+// copies [d][key] have a padded row stride.
+template <typename E>
+struct Mha {
+  typedef typename E::T T;
+  typedef typename E::VC VC;
+  static constexpr int KC = E::MHA_KC;
+  static constexpr int NP = DC_HD / E::CH;       // parts per row: 4 (bf16) / 8 (f32)
+  static constexpr int TLD = KC + 8;             // row stride of a transposed copy [32][KC]
+  __device__ static __forceinline__ int koff(int key, int part) {
+    if constexpr (E::CH == 8) return key * 32 + (((part ^ ((-(key >> 2)) & 3)) & 3) << 3);
+    else return key * 32 + (((part ^ key) & 7) << 2);
+  }
+  // stage KC rows (head slice) of a row matrix into LDS: row-major swizzled copy and/or the transpose [32][TLD]
+  __device__ static __forceinline__ void stage(const T* __restrict__ src, int ld, long long base_row, int first, int nvalid, T* rowmajor,
+                                               T* transposed, int tid) {
+    DC_FOR_TID(c, KC * NP) {
+      const int key = c / NP, part = c % NP;
+      VC v = E::zero_chunk();
+      if (first + key < nvalid) v = *(const VC*)(src + (base_row + first + key) * ld + part * E::CH);
+      if (rowmajor) *(VC*)(rowmajor + koff(key, part)) = v;
+      if (transposed) {
+#pragma unroll
+        for (int e = 0; e < E::CH; ++e) transposed[(part * E::CH + e) * TLD + key] = v[e];
+      }
+    }
+  }
+  // a lane's share of a 32-element row as the b-operand of the score product (lane: row l&15, 16-lane group kq)
+  struct RowFrag { VC c[NP / 4]; };
+  __device__ static __forceinline__ RowFrag zero_frag() {
+    RowFrag f;
+#pragma unroll
+    for (int j = 0; j < NP / 4; ++j) f.c[j] = E::zero_chunk();
+    return f;
+  }
+  __device__ static __forceinline__ RowFrag load_frag(const T* __restrict__ row32, int kq) {       // from global: row32 -> the head slice
+    RowFrag f;
+#pragma unroll
+    for (int j = 0; j < NP / 4; ++j) f.c[j] = *(const VC*)(row32 + (j * 4 + kq) * E::CH);
+    return f;
+  }
+  __device__ static __forceinline__ float dot(const RowFrag& a, const RowFrag& b) {               // partial dot over this lane's elements
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP / 4; ++j)
+#pragma unroll
+      for (int e = 0; e < E::CH; ++e) d += E::chunk_elem(a.c[j], e) * E::chunk_elem(b.c[j], e);
+    return d;
+  }
+  // S^T tile [16 keys][16 queries] = R[16 rows of the row-major LDS copy starting at row0] . frag^T
+  __device__ static __forceinline__ f32x4 scores(const T* rowmajor, int row0, int r16, int kq, const RowFrag& f) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NP / 4; ++j) E::mma(*(const VC*)(rowmajor + koff(row0 + r16, j * 4 + kq)), f.c[j], acc);
+    return acc;
+  }
+  // acc[dt] += Tt[dt*16 .. +16)[keys of the tile pair tp] . P^T: p0 / p1 = the lane's 4 values (keys kq*4 + r) of tiles 2tp, 2tp+1
+  __device__ static __forceinline__ void pv(const T* Tt, int tp, int r16, int kq, f32x4 p0, f32x4 p1, f32x4 (&acc)[2]) {
+    if constexpr (E::CH == 8) {
+      const u16x4 a4 = EB::pack4(p0), b4 = EB::pack4(p1);
+      const u16x8 pb = {a4[0], a4[1], a4[2], a4[3], b4[0], b4[1], b4[2], b4[3]};
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const u16* vp = (const u16*)Tt + (dt * 16 + r16) * TLD + tp * 32 + kq * 4;
+        const u16x4 v0 = *(const u16x4*)vp, v1 = *(const u16x4*)(vp + 16);
+        const u16x8 vb = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vb), __builtin_bit_cast(bf16x8, pb), acc[dt], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f32x4 p = u ? p1 : p0;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const f32x4 v = *(const f32x4*)((const float*)Tt + (dt * 16 + r16) * TLD + (tp * 2 + u) * 16 + kq * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j], p[j], acc[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+};

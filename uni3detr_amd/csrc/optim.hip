@@ -35,12 +35,16 @@ __global__ __launch_bounds__(OPT_BLOCK) void k_sumsq_partial(const float* __rest
 
 // state (16 floats): [0] step count (as float, like torch's capturable AdamW), [1] clip coefficient, [2] 1 - beta1^t, [3] 1 - beta2^t,
 //        [4] total gradient norm (for logging); hyper-parameters, read by the kernels at run time so that a captured graph follows a
-//        learning-rate / momentum schedule: [5] lr, [6] beta1, [7] beta2, [8] eps, [9] weight decay, [10] max_norm (<= 0: no clipping)
+//        learning-rate / momentum schedule: [5] lr, [6] beta1, [7] beta2, [8] eps, [9] weight decay, [10] max_norm (<= 0: no clipping);
+//        [11] hold flag of THIS step (copied from the caller's device flag: > 0 = leave parameters, moments and the step count alone),
+//        [12] number of held steps so far (read by the host every N steps: a capacity overflow somewhere in the job)
 __global__ void k_adamw_set_hyper(float* __restrict__ state, float lr, float beta1, float beta2, float eps, float wd, float max_norm) {
   if (threadIdx.x == 0) { state[5] = lr; state[6] = beta1; state[7] = beta2; state[8] = eps; state[9] = wd; state[10] = max_norm; }
 }
-__global__ __launch_bounds__(256) void k_adamw_prepare(const double* __restrict__ partial, int nb, float* __restrict__ state) {
+__global__ __launch_bounds__(256) void k_adamw_prepare(const double* __restrict__ partial, int nb, float* __restrict__ state,
+                                                       const float* __restrict__ hold) {
   const float max_norm = state[10], beta1 = state[6], beta2 = state[7];
+  const bool held = hold != nullptr && *hold > 0.f;          // uniform
   double s = 0.0;
   for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
   s = u3d_wave_sum_d(s);
@@ -53,6 +57,12 @@ __global__ __launch_bounds__(256) void k_adamw_prepare(const double* __restrict_
     if (max_norm > 0.f) {
       coef = max_norm / ((float)tot + 1e-6f);              // torch.nn.utils.clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
       coef = coef < 1.f ? coef : 1.f;
+    }
+    state[11] = held ? 1.f : 0.f;
+    state[4] = (float)tot;
+    if (held) {
+      state[12] += 1.f;
+      return;
     }
     float t = state[0] + 1.f;
     state[0] = t;
@@ -70,6 +80,7 @@ __global__ __launch_bounds__(256) void k_adamw_prepare(const double* __restrict_
 __global__ __launch_bounds__(OPT_BLOCK) void k_adamw_flat(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, long long n, const float* __restrict__ state,
                                                           const unsigned char* __restrict__ skip) {
+  if (state[11] > 0.f) return;                            // held step (uniform): see k_adamw_prepare
   const float coef = state[1], bc1 = state[2], bc2 = state[3];
   const float lr = state[5], beta1 = state[6], beta2 = state[7], eps = state[8], wd = state[9];
   const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2), decay = 1.f - lr * wd;
@@ -121,16 +132,42 @@ extern "C" int32_t u3d_adamw_set_hyper(float* state, float lr, float beta1, floa
   return U3D_OK;
 }
 
-extern "C" int32_t u3d_adamw_step_state(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
-                                        const uint8_t* skip, void* workspace, int64_t workspace_bytes, u3d_stream s) {
+extern "C" int32_t u3d_adamw_step_hold(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                                       const uint8_t* skip, const float* hold, void* workspace, int64_t workspace_bytes, u3d_stream s) {
   U3D_REQUIRE(param && grad && exp_avg && exp_avg_sq && state && workspace && n >= 0, U3D_ERR_ARG);
   U3D_REQUIRE(workspace_bytes >= u3d_adamw_workspace(n), U3D_ERR_WORKSPACE);
   U3D_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0, U3D_ERR_ARG);
   const int nb = u3d_cdiv(n > 0 ? n : 1, OPT_ELEMS_PER_BLOCK);
   hipLaunchKernelGGL(k_sumsq_partial, dim3(nb), dim3(OPT_BLOCK), 0, s, grad, (long long)n, (double*)workspace);
-  hipLaunchKernelGGL(k_adamw_prepare, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, state);
+  hipLaunchKernelGGL(k_adamw_prepare, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, state, hold);
   if (n > 0)
     hipLaunchKernelGGL(k_adamw_flat, dim3(nb), dim3(OPT_BLOCK), 0, s, param, grad, exp_avg, exp_avg_sq, (long long)n, (const float*)state, skip);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+extern "C" int32_t u3d_adamw_step_state(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* state,
+                                        const uint8_t* skip, void* workspace, int64_t workspace_bytes, u3d_stream s) {
+  return u3d_adamw_step_hold(param, grad, exp_avg, exp_avg_sq, n, state, skip, nullptr, workspace, workspace_bytes, s);
+}
+
+// flag[0] = number of sparse levels whose device-side row count exceeds its capacity.  counts: HOST array of n (<= 8) device pointers
+// to int32 counts, caps: HOST int32 [n] (both travel as kernel arguments: a captured launch keeps them).  The trainer all-reduces
+// the flag together with the positive counts and hands it to u3d_adamw_step_hold.
+struct CapArgs { const int* cnt[8]; int cap[8]; int n; };
+__global__ void k_capacity_flag(CapArgs a, float* __restrict__ flag) {
+  if (threadIdx.x == 0) {
+    int over = 0;
+    for (int i = 0; i < a.n; ++i) over += *a.cnt[i] > a.cap[i] ? 1 : 0;
+    *flag = (float)over;
+  }
+}
+extern "C" int32_t u3d_capacity_flag(const int32_t* const* counts, const int32_t* caps, int32_t n, float* flag, u3d_stream s) {
+  U3D_REQUIRE(flag && n >= 0 && n <= 8 && (n == 0 || (counts && caps)), U3D_ERR_ARG);
+  CapArgs a;
+  a.n = n;
+  for (int i = 0; i < 8; ++i) { a.cnt[i] = i < n ? (const int*)counts[i] : nullptr; a.cap[i] = i < n ? caps[i] : 0; }
+  for (int i = 0; i < n; ++i) U3D_REQUIRE(a.cnt[i], U3D_ERR_ARG);
+  hipLaunchKernelGGL(k_capacity_flag, dim3(1), dim3(64), 0, s, a, flag);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

@@ -43,7 +43,7 @@ class DecLayerParams(C.Structure):
 class DecLayerDims(C.Structure):
     """u3d_declayer_dims."""
     _fields_ = [(n, C.c_int32) for n in ("m", "nq", "qps", "batch", "dz", "dy", "dx", "ncls", "code", "has_qs", "need_dref", "layer")] + \
-               [("p_attn", C.c_float), ("p_drop", C.c_float), ("ln_eps", C.c_float)]
+               [("p_attn", C.c_float), ("p_drop", C.c_float), ("ln_eps", C.c_float), ("dtype", C.c_int32)]
 
 
 class WPackDesc(C.Structure):
@@ -146,6 +146,8 @@ _SIGS = {
     "u3d_adamw_step": (_I, [_P, _P, _P, _P, _L, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _L, _P]),
     "u3d_adamw_set_hyper": (_I, [_P] + [C.c_float] * 6 + [_P]),
     "u3d_adamw_step_state": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _L, _P]),
+    "u3d_adamw_step_hold": (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _P, _L, _P]),
+    "u3d_capacity_flag": (_I, [_P, _P, _I, _P, _P]),
     "u3d_gather_rows": (_I, [_P, _P, _I, _I, _P, _P]),
     "u3d_soft_nms": (_I, [_P, _P, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P]),
     "u3d_box_merge_workspace": (_L, [_I]),
@@ -157,6 +159,11 @@ _SIGS = {
     "u3d_mha_fwd": (_I, [_P, _P, _I, _I, C.c_float, _I, _P, _P, _P, _P]),
     "u3d_mha_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, C.c_float, _I, _P, _P, _P, _P]),
     "u3d_wpack_bf16": (_I, [_P, _I, _I, _P]),
+    "u3d_wpack": (_I, [_P, _I, _I, _I, _P]),
+    "u3d_decoder_layer_slots_dt": (_I, [_I, _I, _I, _I, _P, _P]),
+    "u3d_decoder_layer_blocks_dt": (_I, [_I, _I]),
+    "u3d_mha_fwd_dt": (_I, [_P, _P, _I, _I, C.c_float, _I, _P, _P, _P, _I, _P]),
+    "u3d_mha_bwd_dt": (_I, [_P, _P, _P, _P, _P, _I, _I, C.c_float, _I, _P, _P, _P, _I, _P]),
     "u3d_dropout_mask": (_I, [_P, _I, _I, _L, C.c_float, _P, _P]),
     "u3d_scatter_rows": (_I, [_P, _P, _I, _I, _P, _P]),
 }
@@ -819,13 +826,22 @@ def adamw_set_hyper(state, lr, betas, eps, weight_decay, max_norm):
     _check(lib().u3d_adamw_set_hyper(_ptr(state), lr, betas[0], betas[1], eps, weight_decay, float(max_norm), _stream()), "adamw_set_hyper")
 
 
-def adamw_step_state(param, grad, exp_avg, exp_avg_sq, state, skip=None, workspace=None):
-    """clip + AdamW with the hyper-parameters taken from `state` (see adamw_set_hyper); skip: uint8 per 64-element chunk or None."""
+def adamw_step_state(param, grad, exp_avg, exp_avg_sq, state, skip=None, workspace=None, hold=None):
+    """clip + AdamW with the hyper-parameters taken from `state` (see adamw_set_hyper); skip: uint8 per 64-element chunk or None;
+    hold: one device float or None - > 0 turns the step into a no-op and counts it in state[12] (capacity overflow somewhere)."""
     n = param.numel()
     wsb = int(lib().u3d_adamw_workspace(n))
     ws = workspace if workspace is not None else torch.empty(wsb, dtype=torch.uint8, device=param.device)
-    _check(lib().u3d_adamw_step_state(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, _ptr(state), _ptr(skip), _ptr(ws),
-                                      ws.numel(), _stream()), "adamw_step_state")
+    _check(lib().u3d_adamw_step_hold(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, _ptr(state), _ptr(skip), _ptr(hold),
+                                     _ptr(ws), ws.numel(), _stream()), "adamw_step_hold")
+
+
+def capacity_flag(counts, caps, flag):
+    """flag[0] <- number of levels with counts[i][0] > caps[i] (counts: list of device int32 tensors, caps: python ints)."""
+    n = len(counts)
+    assert n == len(caps) and n <= 8 and flag.dtype == torch.float32
+    _check(lib().u3d_capacity_flag(_ptr_array(counts), (C.c_int32 * max(n, 1))(*[int(c) for c in caps]), n, _ptr(flag), _stream()),
+           "capacity_flag")
 
 
 def tap_gather_sum(p, nbr, n_dev, n, c, kvol):
@@ -1059,16 +1075,26 @@ def sine_embed_bwd(logits, dim_t, dout):
 # fused decoder layer (csrc/decoder.hip, csrc/decoder_bwd.hip)
 # --------------------------------------------------------------------------------------------------
 _SLOT_CACHE = {}
+DT_F32, DT_BF16 = 0, 1                 # include/u3d_hip.h: enum { U3D_F32 = 0, U3D_BF16 = 1 }
 
 
-def decoder_layer_slots(m, ncls, code):
+def dt_code(dtype):
+    """torch dtype of the decoder's element type -> U3D_* code."""
+    if dtype == torch.bfloat16:
+        return DT_BF16
+    if dtype == torch.float32:
+        return DT_F32
+    raise U3DError(f"fused decoder: unsupported element type {dtype}")
+
+
+def decoder_layer_slots(m, ncls, code, dtype=torch.bfloat16):
     """(save_off, grad_off): dicts slot name -> byte offset, plus "_total"."""
-    key = (m, ncls, code)
+    key = (m, ncls, code, dtype)
     r = _SLOT_CACHE.get(key)
     if r is None:
         so = (C.c_int64 * (len(DS_NAMES) + 1))()
         go = (C.c_int64 * (len(DG_NAMES) + 1))()
-        _check(lib().u3d_decoder_layer_slots(m, ncls, code, so, go), "decoder_layer_slots")
+        _check(lib().u3d_decoder_layer_slots_dt(m, ncls, code, dt_code(dtype), so, go), "decoder_layer_slots")
         r = ({**{n: int(so[i]) for i, n in enumerate(DS_NAMES)}, "_total": int(so[len(DS_NAMES)])},
              {**{n: int(go[i]) for i, n in enumerate(DG_NAMES)}, "_total": int(go[len(DG_NAMES)])})
         _SLOT_CACHE[key] = r
@@ -1081,17 +1107,26 @@ def slot_view(buf, off, rows, cols, dtype):
     return buf[off:off + nbytes].view(dtype).view(rows, cols)
 
 
-def decoder_rows(m):
-    """rows every buffer owned by the fused layer holds: m rounded up to whole 32-row blocks (the kernels never branch on the row)."""
-    return int(lib().u3d_decoder_layer_blocks(m)) * 32
+def decoder_blocks(m, dtype=torch.bfloat16):
+    """workgroups of the row-chain kernels = rows of every LayerNorm partial matrix"""
+    return int(lib().u3d_decoder_layer_blocks_dt(m, dt_code(dtype)))
+
+
+def decoder_rows(m, dtype=torch.bfloat16):
+    """rows every buffer owned by the fused layer holds: m rounded up to whole row blocks (32 rows in bf16, 16 in f32: the kernels
+    never branch on the row)."""
+    return decoder_blocks(m, dtype) * (32 if dtype == torch.bfloat16 else 16)
 
 
 def decoder_layer_fwd(params, dims, x, xc, ref, value_rows, rng, save):
+    """xc / value_rows / the slots are in the element type dims.dtype names (bf16 | f32); in f32 mode xc_out IS x_out."""
     m, code, ncls = dims.m, dims.code, dims.ncls
-    mp = decoder_rows(m)
+    et = torch.bfloat16 if dims.dtype == DT_BF16 else torch.float32
+    assert xc.dtype == et and value_rows.dtype == et and x.dtype == torch.float32
+    mp = decoder_rows(m, et)
     dev = x.device
     x_out = torch.empty((mp, 256), dtype=torch.float32, device=dev)
-    xc_out = torch.empty((mp, 256), dtype=torch.bfloat16, device=dev)
+    xc_out = torch.empty((mp, 256), dtype=torch.bfloat16, device=dev) if et == torch.bfloat16 else x_out
     reg = torch.empty((mp, code), dtype=torch.float32, device=dev)
     cls = torch.empty((mp, ncls), dtype=torch.float32, device=dev)
     iou = torch.empty((mp,), dtype=torch.float32, device=dev)
@@ -1103,7 +1138,7 @@ def decoder_layer_fwd(params, dims, x, xc, ref, value_rows, rng, save):
 
 def decoder_layer_bwd(params, dims, x, xc, ref, value_rows, rng, xc_out, save, dx_out, dreg, dcls, diou, dvalue, grad):
     m = dims.m
-    mp = decoder_rows(m)
+    mp = decoder_rows(m, torch.bfloat16 if dims.dtype == DT_BF16 else torch.float32)
     dx = torch.empty((mp, 256), dtype=torch.float32, device=ref.device)
     dref = torch.empty((mp, 3), dtype=torch.float32, device=ref.device) if dims.need_dref else None
     _check(lib().u3d_decoder_layer_bwd(C.byref(params), C.byref(dims), _ptr(x), _ptr(xc), _ptr(ref), _ptr(value_rows), _ptr(rng),
@@ -1113,24 +1148,31 @@ def decoder_layer_bwd(params, dims, x, xc, ref, value_rows, rng, xc_out, save, d
 
 
 def mha_fwd(qk, v, nq, p_attn=0.0, layer=0, rng=None):
-    """qk bf16 [m,512] (q | k), v bf16 [m,256] -> (o bf16 [m,256], lse f32 [m,8] in log2 units)."""
+    """qk [m,512] (q | k), v [m,256] (both bf16 or both f32) -> (o [m,256] same type, lse f32 [m,8] in log2 units)."""
     m = qk.shape[0]
-    o = torch.empty((m, 256), dtype=torch.bfloat16, device=qk.device)
+    assert qk.dtype == v.dtype and qk.is_contiguous() and v.is_contiguous()
+    o = torch.empty((m, 256), dtype=qk.dtype, device=qk.device)
     lse = torch.empty((m, 8), dtype=torch.float32, device=qk.device)
-    _check(lib().u3d_mha_fwd(_ptr(qk), _ptr(v), m, nq, p_attn, layer, _ptr(rng), _ptr(o), _ptr(lse), _stream()), "mha_fwd")
+    _check(lib().u3d_mha_fwd_dt(_ptr(qk), _ptr(v), m, nq, p_attn, layer, _ptr(rng), _ptr(o), _ptr(lse), dt_code(qk.dtype), _stream()),
+           "mha_fwd")
     return o, lse
 
 
 def mha_bwd(qk, v, o, d_o, lse, nq, p_attn=0.0, layer=0, rng=None):
     m = qk.shape[0]
+    assert qk.dtype == v.dtype == o.dtype == d_o.dtype
     dqk, dv = torch.empty_like(qk), torch.empty_like(v)
-    _check(lib().u3d_mha_bwd(_ptr(qk), _ptr(v), _ptr(o), _ptr(d_o), _ptr(lse), m, nq, p_attn, layer, _ptr(rng), _ptr(dqk), _ptr(dv),
-                             _stream()), "mha_bwd")
+    _check(lib().u3d_mha_bwd_dt(_ptr(qk), _ptr(v), _ptr(o), _ptr(d_o), _ptr(lse), m, nq, p_attn, layer, _ptr(rng), _ptr(dqk), _ptr(dv),
+                                dt_code(qk.dtype), _stream()), "mha_bwd")
     return dqk, dv
 
 
+def wpack(descs_dev, count, max_elems, dtype=torch.bfloat16):
+    _check(lib().u3d_wpack(_ptr(descs_dev), count, max_elems, dt_code(dtype), _stream()), "wpack")
+
+
 def wpack_bf16(descs_dev, count, max_elems):
-    _check(lib().u3d_wpack_bf16(_ptr(descs_dev), count, max_elems, _stream()), "wpack_bf16")
+    wpack(descs_dev, count, max_elems, torch.bfloat16)
 
 
 def dropout_mask(rng, layer, site, n, p):

@@ -1,6 +1,10 @@
-"""Fused bf16 decoder path: every decoder layer (+ the reference-point / query-scale MLPs in front of it and the reg / cls / iou
+"""Fused decoder path: every decoder layer (+ the reference-point / query-scale MLPs in front of it and the reg / cls / iou
 branches behind it) is ONE C-ABI call forward and one backward (u3d_decoder_layer_fwd / _bwd: csrc/decoder.hip, decoder_bwd.hip) -
 own MFMA row-chain kernels and own attention kernels; no torch GEMM / SDPA / element-wise launch in between.
+
+Two instantiations of the SAME kernels (csrc/decoder_common.h, element traits EB / EF): bf16 storage + v_mfma_f32_16x16x32_bf16 in
+throughput mode (bf16 autocast), f32 storage + exact v_mfma_f32_16x16x4_f32 in parity mode (`set_precision('fp32')`): the 1e-3
+reference-golden tests run the kernels the benchmark runs.
 
 ref: projects/mmdet3d_plugin/models/utils/uni3detr_transformer.py:145-212 (decoder loop), :271-360 (UniCrossAtten),
 models/dense_heads/uni3detr_head.py:367-387, 470-490 (branches; the box decode stays in Uni3DETRHead.forward).
@@ -112,12 +116,13 @@ class FusedDecoder:
     def __init__(self, decoder, reg_branches, cls_branches, iou_branches):
         self.decoder = decoder
         self.specs = [LayerSpec(decoder, i, reg_branches[i], cls_branches[i], iou_branches[i]) for i in range(decoder.num_layers)]
-        self._key = None
+        self._states = {}              # element type -> _State
+        self.params = None
         self.rng = None
         self._dim_t = None
 
     # ---- weight copies ---------------------------------------------------------------------------------------------------
-    def _build(self, dev):
+    def _build(self, dev, et):
         uniq = {}                      # (id(weight), first row) -> (w, r0, rows)
         for sp in self.specs:
             for i, (w, r0, rows, _) in enumerate(sp.lin):
@@ -131,30 +136,32 @@ class FusedDecoder:
             plan[key] = (total, total + n_pad * k, n_pad, n_pad_t)
             total += n_pad * k + k * n_pad_t
             total = (total + 127) // 128 * 128
-        self.wbuf = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+        st = _State()
+        st.wbuf = torch.zeros(total, dtype=et, device=dev)
+        es = st.wbuf.element_size()
         descs = (nv.WPackDesc * len(uniq))()
-        self._views = {}
+        views = {}
         max_elems = 1
         for j, (key, (w, r0, rows, narrow)) in enumerate(uniq.items()):
             k = w.shape[1]
             o, ot, n_pad, n_pad_t = plan[key]
             d = descs[j]
             d.src = w.data_ptr() + r0 * k * 4
-            d.dst = self.wbuf.data_ptr() + o * 2
-            d.dst_t = self.wbuf.data_ptr() + ot * 2
+            d.dst = st.wbuf.data_ptr() + o * es
+            d.dst_t = st.wbuf.data_ptr() + ot * es
             d.n, d.k, d.n_pad, d.n_pad_t = rows, k, n_pad, n_pad_t
-            self._views[key] = (d.dst, d.dst_t)
+            views[key] = (d.dst, d.dst_t)
             max_elems = max(max_elems, n_pad * k, k * n_pad_t)
-        self._ndesc, self._max_elems = len(uniq), max_elems
-        self._descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        st.ndesc, st.max_elems = len(uniq), max_elems
+        st.descs_dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
         if self._dim_t is None or self._dim_t.device != dev:
             d = torch.arange(128, dtype=torch.float32, device=dev)
             self._dim_t = 10000 ** (2 * torch.div(d, 2, rounding_mode="floor") / 128)
-        self.params = []
+        st.params = []
         for sp in self.specs:
             p = nv.DecLayerParams()
             for i, (w, r0, rows, b) in enumerate(sp.lin):
-                dst, dst_t = self._views[(id(w), r0)]
+                dst, dst_t = views[(id(w), r0)]
                 p.w[i], p.wt[i] = dst, dst_t
                 p.b[i] = b.data_ptr() + r0 * 4
             for i, n in enumerate(sp.ln):
@@ -162,9 +169,10 @@ class FusedDecoder:
             p.attw_w, p.attw_b = sp.attw.weight.data_ptr(), sp.attw.bias.data_ptr()
             p.pe0_w, p.pe0_b = sp.pe0.weight.data_ptr(), sp.pe0.bias.data_ptr()
             p.dim_t = self._dim_t.data_ptr()
-            self.params.append(p)
+            st.params.append(p)
         if self.rng is None or self.rng.device != dev:
             self.rng = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFF], dtype=torch.int64, device=dev)
+        return st
 
     def xyz_cols(self, dev):
         """code columns of the (x, y, z) offsets (ref :194-202), cached on the device: no host-to-device copy inside a graph capture"""
@@ -173,51 +181,73 @@ class FusedDecoder:
             c = self._cols = torch.tensor([0, 1, 4], device=dev)
         return c
 
-    def refresh(self, dev):
-        """bf16 copies of the current master weights (one launch); rebuilt when a parameter moved (e.g. into the trainer's flat buffer)."""
+    def refresh(self, dev, et=torch.bfloat16):
+        """Copies of the current master weights in the element type `et` (one launch); rebuilt when a parameter moved (e.g. into the
+        trainer's flat buffer).  bf16: rounded copies; f32: the zero-padded / transposed layouts the kernels read."""
         key = (str(dev),) + tuple(t.data_ptr() for sp in self.specs for t in sp.tensors())
-        if key != self._key:
-            self._build(dev)
-            self._key = key
-        nv.wpack_bf16(self._descs_dev, self._ndesc, self._max_elems)
+        st = self._states.get(et)
+        if st is None or st.key != key:
+            st = self._states[et] = self._build(dev, et)
+            st.key = key
+        self.params = st.params
+        nv.wpack(st.descs_dev, st.ndesc, st.max_elems, et)
+        return st
+
+
+class _State:
+    """weight copies + parameter blocks of one element type"""
+    key = None
+
+
+def element_type(decoder, query, value, reg_branches, head_branches):
+    """torch dtype the fused kernels run this call in (bf16 under bf16 autocast, f32 for plain f32 tensors), or None when the fused
+    path does not cover it."""
+    if not (ENABLED and query.is_cuda):
+        return None
+    if reg_branches is None or head_branches is None or value.dim() != 5 or value.shape[1] != 256 or query.shape[-1] != 256:
+        return None
+    if len(reg_branches) != decoder.num_layers or len({id(m) for m in reg_branches}) != decoder.num_layers:
+        return None
+    if torch.is_autocast_enabled():
+        return torch.bfloat16 if torch.get_autocast_dtype("cuda") == torch.bfloat16 else None
+    return torch.float32 if (query.dtype == torch.float32 and value.dtype == torch.float32) else None
 
 
 def eligible(decoder, query, value, reg_branches, head_branches):
-    if not (ENABLED and query.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
-        return False
-    if reg_branches is None or head_branches is None or value.dim() != 5 or value.shape[1] != 256 or query.shape[-1] != 256:
-        return False
-    if len(reg_branches) != decoder.num_layers or len({id(m) for m in reg_branches}) != decoder.num_layers:
-        return False
-    return True
+    return element_type(decoder, query, value, reg_branches, head_branches) is not None
 
 
 class FusedLayerFn(torch.autograd.Function):
-    """One decoder layer.  Inputs: x f32 [M,256]; xc bf16 copy of x or None; ref f32 [M,3] logits; rows bf16 [B*D*H*W,256]; meta."""
+    """One decoder layer.  Inputs: x f32 [M,256]; xc = x in the element type (bf16 copy, or None: made here; f32 mode: x itself);
+    ref f32 [M,3] logits; rows [B*D*H*W,256] in the element type; meta = (FusedDecoder, layer, dims, accum[, element type])."""
 
     @staticmethod
     def forward(ctx, x, xc, ref, rows, meta, *ptensors):
-        fd, lid, dims_t, accum = meta
+        fd, lid, dims_t, accum = meta[:4]
+        et = meta[4] if len(meta) > 4 else torch.bfloat16
         sp = fd.specs[lid]
         B, qps, nq, D, H, W = dims_t
         M = x.shape[0]
         x = x.contiguous()
-        xc = x.to(torch.bfloat16) if xc is None else xc
+        xc = x if et == torch.float32 else (x.to(et) if xc is None else xc)
         ref = ref.contiguous().float()
+        assert rows.dtype == et and rows.is_contiguous()
         d = nv.DecLayerDims()
         d.m, d.nq, d.qps, d.batch, d.dz, d.dy, d.dx = M, nq, qps, B, D, H, W
         d.ncls, d.code, d.has_qs, d.need_dref, d.layer = sp.ncls, sp.code, int(lid > 0), 0, lid
+        d.dtype = nv.dt_code(et)
         train = fd.decoder.training
         d.p_attn = sp.p_attn if train else 0.0
         d.p_drop = sp.p_drop if train else 0.0
         d.ln_eps = float(sp.ln[0].eps)
-        so, go = nv.decoder_layer_slots(M, sp.ncls, sp.code)
+        so, go = nv.decoder_layer_slots(M, sp.ncls, sp.code, et)
         save = torch.empty(so["_total"], dtype=torch.uint8, device=x.device)
         if POISON:
             save.fill_(255)
-        x_out, xc_out, reg, cls, iou = nv.decoder_layer_fwd(fd.params[lid], d, x, xc, ref, rows, fd.rng, save)
+        params = fd._states[et].params[lid]
+        x_out, xc_out, reg, cls, iou = nv.decoder_layer_fwd(params, d, x, xc, ref, rows, fd.rng, save)
         ctx.save_for_backward(x, xc, ref, rows, xc_out, save)
-        ctx.meta, ctx.dims = meta, d
+        ctx.meta, ctx.dims, ctx.et, ctx.params = meta, d, et, params
         ctx.wids = []
         from .transformer import _Deferred
         for w, r0, rows_, b in sp.lin:
@@ -228,19 +258,23 @@ class FusedLayerFn(torch.autograd.Function):
             _Deferred.uses[id(t)] = _Deferred.uses.get(id(t), 0) + 1
         for n in sp.ln:
             _Deferred.uses[id(n.weight)] = _Deferred.uses.get(id(n.weight), 0) + 1
-        ctx.mark_non_differentiable(xc_out)
-        return x_out, xc_out, reg, cls, iou
+        # f32 mode: the layer state IS its own compute copy (xc_out aliases x_out inside): hand autograd an empty stand-in instead of
+        # two outputs over one storage; the next layer takes its x as xc
+        xc_ret = xc_out if et == torch.bfloat16 else x_out.new_empty(0)
+        ctx.mark_non_differentiable(xc_ret)
+        return x_out, xc_ret, reg, cls, iou
 
     @staticmethod
     def backward(ctx, dx_out, _dxc, dreg, dcls, diou):
         from .transformer import _Deferred
         x, xc, ref, rows, xc_out, save = ctx.saved_tensors
-        fd, lid, dims_t, accum = ctx.meta
+        fd, lid, dims_t, accum = ctx.meta[:4]
+        et = ctx.et
         sp, d = fd.specs[lid], ctx.dims
         M = x.shape[0]
         dev = x.device
         d.need_dref = int(ctx.needs_input_grad[2])
-        so, go = nv.decoder_layer_slots(M, sp.ncls, sp.code)
+        so, go = nv.decoder_layer_slots(M, sp.ncls, sp.code, et)
         grad = torch.empty(go["_total"], dtype=torch.uint8, device=dev)
         if POISON:
             grad.fill_(255)
@@ -254,7 +288,7 @@ class FusedLayerFn(torch.autograd.Function):
             dvalue = accum.buf
         else:
             dvalue = torch.zeros(rows.shape, dtype=torch.float32, device=dev)
-        dx, dref = nv.decoder_layer_bwd(fd.params[lid], d, x, xc, ref, rows, fd.rng, xc_out, save, dx_out, dreg, dcls, diou, dvalue, grad)
+        dx, dref = nv.decoder_layer_bwd(ctx.params, d, x, xc, ref, rows, fd.rng, xc_out, save, dx_out, dreg, dcls, diou, dvalue, grad)
         if DEBUG_KEEP is not None:
             DEBUG_KEEP.append(grad)
         drows = None
@@ -265,9 +299,9 @@ class FusedLayerFn(torch.autograd.Function):
                 accum.buf = None
         elif want_dv:
             drows = dvalue.to(rows.dtype)
-        bf, f32 = torch.bfloat16, torch.float32
-        S = lambda name, cols, dt=bf: nv.slot_view(save, so[name], M, cols, dt)
-        Gv = lambda name, cols, dt=bf: nv.slot_view(grad, go[name], M, cols, dt)
+        f32 = torch.float32
+        S = lambda name, cols, dt=et: nv.slot_view(save, so[name], M, cols, dt)
+        Gv = lambda name, cols, dt=et: nv.slot_view(grad, go[name], M, cols, dt)
         if d.need_dref:      # the sine-embedding path of the reference-point gradient (ref_point_head's input)
             dref = dref + nv.sine_embed_bwd(ref, fd._dim_t, Gv("SINE", 384))
         # ---- parameter gradients: (dY, X) per linear --------------------------------------------------------------------------
@@ -284,7 +318,9 @@ class FusedLayerFn(torch.autograd.Function):
         }
         if lid > 0:
             pairs.update({nv.DL_QS0: (Gv("QS1", 256), xc), nv.DL_QS1: (Gv("QS2", 256), S("QS1", 256)), nv.DL_QS2: (Gv("QS", 256), S("QS2", 256))})
-        deferred_ok = _Deferred.active
+        # the deferred / batched parameter-gradient launches are bf16 kernels; parity mode computes every product right here on the
+        # exact-f32 weight-gradient kernel (u3d_spconv_wgrad, one offset)
+        deferred_ok = _Deferred.active and et == torch.bfloat16
         grads = []
         wgrad_now = {}              # (n, k) -> list of (dy, x, out)
         sums_now = []               # (matrix, out vector)
@@ -297,6 +333,13 @@ class FusedLayerFn(torch.autograd.Function):
             v = getattr(param, "_u3d_grad_view", None) if deferred else None
             # (a fresh alias: AccumulateGrad keeps an incoming tensor as .grad only if nobody else holds that tensor object)
             return v.view(v.shape) if (v is not None and v.dtype == f32 and v.is_contiguous()) else new(*param.shape)
+
+        def skinny_now(dy, xin, dw):
+            """dW = dY^T X for a product with a side <= 16, written into dw ([n, k] view)"""
+            if et == torch.bfloat16:
+                sums_now.append((nv.skinny_wgrad_partial(dy, xin), dw.view(-1)))
+            else:
+                dw.copy_(_wgrad_f32(dy, xin))
         inproj_dw = inproj_db = None
         for i, (w, r0, rows_, b) in enumerate(sp.lin):
             if i not in pairs:                                   # query_scale in the first layer: unused
@@ -318,11 +361,15 @@ class FusedLayerFn(torch.autograd.Function):
                     _Deferred.skinny.append((dy, xin, w))        # the product itself waits for the flush: one launch for all layers
                     _Deferred.sum_items.append((dy, b))
                 else:
-                    sums_now += [(nv.skinny_wgrad_partial(dy, xin), dw.view(-1)), (dy, db)]
+                    skinny_now(dy, xin, dw)
+                    sums_now.append((dy, db))
             elif deferred_ok and single:
                 _Deferred.items.append((dy, xin, id(w), r0, r0 + rows_, True))
-            else:
+            elif et == torch.bfloat16:
                 wgrad_now.setdefault((n, k), []).append((dy, xin, dw))
+                sums_now.append((dy, db))
+            else:
+                dw.copy_(_wgrad_f32(dy, xin))
                 sums_now.append((dy, db))
             if i == nv.DL_INV:
                 grads += []                                      # in_proj weight / bias were emitted with INQK
@@ -330,8 +377,8 @@ class FusedLayerFn(torch.autograd.Function):
                 grads += [inproj_dw, inproj_db]
             else:
                 grads += [dw, db]
-        lnp = nv.slot_view(grad, go["LNP"], nv.DL_NLN * 2 * d_blocks(M), 256, f32)
-        nb = d_blocks(M)
+        nb = nv.decoder_blocks(M, et)
+        lnp = nv.slot_view(grad, go["LNP"], nv.DL_NLN * 2 * nb, 256, f32)
         for j, nmod in enumerate(sp.ln):
             dfr = deferred_ok and _Deferred.uses.get(id(nmod.weight), 0) == 1
             dg, db = slot(nmod.weight, dfr), slot(nmod.bias, dfr)
@@ -342,7 +389,7 @@ class FusedLayerFn(torch.autograd.Function):
                 sums_now += [(mg, dg), (mb, db)]
             grads += [dg, db]
         # attention_weights (256 -> 1) and the position encoder's first layer (3 -> 256): skinny products
-        for dy, xin, mod in ((Gv("WL", 1), S("QP", 256), sp.attw), (Gv("P0", 256), ref.to(bf), sp.pe0)):
+        for dy, xin, mod in ((Gv("WL", 1), S("QP", 256), sp.attw), (Gv("P0", 256), ref.to(et), sp.pe0)):
             dfr = deferred_ok and _Deferred.uses.get(id(mod.weight), 0) == 1
             dw, db = slot(mod.weight, dfr), slot(mod.bias, dfr)
             if deferred_ok and _Deferred.uses.get(id(mod.weight), 0) == 1:
@@ -350,7 +397,8 @@ class FusedLayerFn(torch.autograd.Function):
                 _Deferred.skinny.append((dy, xin.contiguous(), mod.weight))
                 _Deferred.sum_items.append((dy, mod.bias))
             else:
-                sums_now += [(nv.skinny_wgrad_partial(dy, xin.contiguous()), dw.view(-1)), (dy, db)]
+                skinny_now(dy, xin.contiguous(), dw)
+                sums_now.append((dy, db))
             grads += [dw, db]
         for (n, k), lst in wgrad_now.items():
             nv.wgrad_batched([a for a, _, _ in lst], [b_ for _, b_, _ in lst], [c for _, _, c in lst])
@@ -363,8 +411,18 @@ class FusedLayerFn(torch.autograd.Function):
         return (dx, None, dref, drows, None) + tuple(grads)
 
 
-def d_blocks(m):
-    return int(nv.lib().u3d_decoder_layer_blocks(m))
+def _wgrad_f32(dy, xin):
+    """dY^T X for f32 [M, n] / [M, k] on the exact-f32 MFMA weight-gradient kernel (u3d_spconv_wgrad, one offset): f32 [n, k].
+    The kernel wants channel counts that are multiples of 4: narrow sides (1, 3, 10 columns) are zero-padded."""
+    n, k = dy.shape[1], xin.shape[1]
+    pad = lambda t: t if t.shape[1] % 4 == 0 else torch.nn.functional.pad(t, (0, 4 - t.shape[1] % 4))
+    dyp, xp = pad(dy).contiguous(), pad(xin).contiguous()
+    md = nv.count_tensor(dy.shape[0], dy.device)
+    return nv.spconv_wgrad(dyp, xp, None, md, 1).view(dyp.shape[1], xp.shape[1])[:n, :k]
+
+
+def d_blocks(m, et=torch.bfloat16):
+    return nv.decoder_blocks(m, et)
 
 
 def tensor_list(sp):
@@ -380,16 +438,17 @@ def tensor_list(sp):
     return out
 
 
-def run(fd, query, ref_logits, value, group):
-    """query [B,N,256] f32, ref_logits [B,N,3], value [B,256,D,H,W] -> per-layer lists (states [B,N,256] f32, refs, reg, cls, iou)."""
+def run(fd, query, ref_logits, value, group, et=torch.bfloat16):
+    """query [B,N,256] f32, ref_logits [B,N,3], value [B,256,D,H,W] -> per-layer lists (states [B,N,256] f32, refs, reg, cls, iou).
+    et: element type of the kernels (bf16: throughput mode; f32: parity mode)."""
     from .transformer import ValueGradAccum
     B, N, Cc = query.shape
     _, _, D, H, W = value.shape
     rows = value.permute(0, 2, 3, 4, 1).reshape(-1, Cc)
-    rows = rows if rows.dtype == torch.bfloat16 else rows.to(torch.bfloat16)
+    rows = rows if rows.dtype == et else rows.to(et)
     rows = rows if rows.is_contiguous() else rows.contiguous()
     dev = query.device
-    fd.refresh(dev)
+    fd.refresh(dev, et)
     if fd.decoder.training:
         fd.rng.add_(0x9E3779B1)                         # new dropout stream every step (captured: advances on every graph replay)
     L = fd.decoder.num_layers
@@ -401,7 +460,7 @@ def run(fd, query, ref_logits, value, group):
     cols = None
     for lid in range(L):
         sp = fd.specs[lid]
-        meta = (fd, lid, (B, N, group, D, H, W), accum)
+        meta = (fd, lid, (B, N, group, D, H, W), accum, et)
         x, xc, reg, cls, iou = FusedLayerFn.apply(x, xc, ref, rows, meta, *tensor_list(sp))
         if cols is None:
             cols = fd.xyz_cols(dev)

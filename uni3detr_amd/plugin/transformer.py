@@ -702,10 +702,11 @@ class Uni3DETRTransformerDecoder(nn.Module):
         self._xyz_cols = None
 
     def _fused_decoder(self, query, value, reg_branches):
-        """The FusedDecoder serving this call, or None (fp32 mode, CPU, a layout the fused kernels do not cover)."""
+        """The FusedDecoder serving this call, or None (CPU, a layout the fused kernels do not cover)."""
         from . import fused_decoder as _fdm
         hb = getattr(self, "_head_branches", None)
-        if not _fdm.eligible(self, query, value, reg_branches, hb):
+        self._fused_et = _fdm.element_type(self, query, value, reg_branches, hb)
+        if self._fused_et is None:
             return None
         key = (tuple(id(m) for m in reg_branches), tuple(id(m) for m in hb[0]), tuple(id(m) for m in hb[1]))
         cached = getattr(self, "_fused_cache", None)
@@ -722,9 +723,10 @@ class Uni3DETRTransformerDecoder(nn.Module):
         self._cls_outputs = self._iou_outputs = None
         fd = self._fused_decoder(query, value, reg_branches)
         if fd is not None:
-            # bf16 throughput mode: every layer is one fused HIP call each way (plugin/fused_decoder.py; u3d_decoder_layer_fwd/_bwd)
+            # every layer is one fused HIP call each way (plugin/fused_decoder.py; u3d_decoder_layer_fwd/_bwd): the bf16 instantiation
+            # under bf16 autocast (throughput mode), the exact-f32 instantiation of the same kernels for f32 tensors (parity mode)
             from . import fused_decoder as _fdm
-            states, refs, regs, clss, ious = _fdm.run(fd, query, ref_logits, value, group)
+            states, refs, regs, clss, ious = _fdm.run(fd, query, ref_logits, value, group, self._fused_et)
             self._reg_outputs, self._cls_outputs, self._iou_outputs, self._states_c = regs, clss, ious, None
             if self.return_intermediate:
                 return torch.stack(states), torch.stack(refs)

@@ -10,7 +10,12 @@ step consists of (host enqueue time ≈ GPU time in eager mode):
          G2b = the sparse encoder's backward underneath it, then the all-reduce of the encoder's small slice)
     G3  gradient clipping + fused AdamW
 The sparse levels run in static-shape mode (capacity-sized tensors, device-side row counts; uni3detr_amd/sparse.py), so the
-captured launches are valid for any batch whose level sizes fit the capacities; `check_capacities()` verifies that.
+captured launches are valid for any batch whose level sizes fit the capacities.  A batch that does NOT fit is handled on the device and
+collectively: G1 ends with a capacity flag (u3d_capacity_flag), the flag travels in the positive-count all-reduce (so every rank sees
+the job-wide value) and G3's update is held when it is set (u3d_adamw_step_hold) - no rank ever trains on truncated levels, and the
+ranks cannot diverge.  Every `check_every` steps the host reads the held-step counter (identical on all ranks) and re-captures with more
+room: on one rank directly; with a live process group through `pg_hooks` (tear the group down, capture, create it again - capture and
+RCCL do not mix on this stack), or it raises on ALL ranks when no hooks were given.
 """
 import os
 
@@ -29,8 +34,13 @@ EARLY_FLUSH = os.environ.get("U3D_EARLY_FLUSH", "0") == "1"
 class TrainStep:
     def __init__(self, model, points, gt_bboxes_3d, gt_labels_3d, lr=1e-4, weight_decay=0.01, max_norm=10.0, graph=True,
                  capacity_margin=1.25, flat_update=True, overlap_reduce=False, betas=(0.9, 0.999), eps=1e-8, gt_capacity=64,
-                 check_every=50):
+                 check_every=50, pg_hooks=None):
+        """pg_hooks: (teardown, setup) callables that destroy / re-create the default process group; needed only for a collective
+        re-capture after a capacity overflow on a multi-rank run (bench.py passes them)."""
         self.model = model
+        self.pg_hooks = pg_hooks
+        self._capture_batches = None
+        self._msg = None
         self._flush_stream, self._flush_keep = None, None
         self.dev = next(model.parameters()).device
         self.dist_on = dist.is_available() and dist.is_initialized()
@@ -149,6 +159,10 @@ class TrainStep:
         if self.flat_update:
             nv.adamw_set_hyper(self.opt_state, self.lr, self.betas, self.eps, self.weight_decay, self.max_norm)
         elif self.opt is not None:
+            if self._graphs is not None and (lr is not None or betas is not None or weight_decay is not None):
+                # torch's capturable AdamW bakes lr / betas / decay into the captured launches as host scalars
+                raise RuntimeError("graph=True with flat_update=False cannot follow a schedule: the captured torch.optim step ignores "
+                                   "param_groups edits; use flat_update=True (device-side hyper-parameters)")
             for g in self.opt.param_groups:
                 g["lr"], g["betas"], g["weight_decay"] = self.lr, self.betas, self.weight_decay
 
@@ -168,7 +182,19 @@ class TrainStep:
             with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
                 self._outs = m.pts_bbox_head(feat, None, fps)
         self._T = m.pts_bbox_head.loss_targets(self.gts, None, self._outs)
-        self._num_pos = self._T["num_pos"].clone()
+        # the step's collective message: [L positive counts | capacity flag].  The flag (levels over capacity, this rank) is computed on
+        # the device from the counts the encoder just produced: no host read
+        npos = self._T["num_pos"]
+        L = npos.numel()
+        self._msg = torch.empty(L + 1, dtype=torch.float32, device=npos.device)
+        self._msg[:L].copy_(npos)
+        enc = getattr(m, "pts_middle_encoder", None)
+        caps = getattr(enc, "level_capacities", None) if enc is not None else None
+        if caps is not None and m.static_shapes:
+            nv.capacity_flag(list(enc.last_level_counts[1:1 + len(caps)]), caps, self._msg[L:])
+        else:
+            self._msg[L:].zero_()
+        self._num_pos = self._msg[:L]
 
     def _early_flush(self, grad):
         if _T._Deferred.active and (_T._Deferred.items or _T._Deferred.sum_items or _T._Deferred.skinny):
@@ -186,9 +212,11 @@ class TrainStep:
             self._flush_keep = None
 
     def _reduce_num_pos(self):
+        """ONE small all-reduce per step: the mean positive counts (ref: reduce_mean in uni3detr_head.py:658-664, 680-681) and, in the
+        same message, the job-wide capacity flag (> 0 on every rank iff any rank overflowed)."""
         if self.dist_on:
-            self._num_pos.div_(self.world)
-            dist.all_reduce(self._num_pos)
+            self._msg.div_(self.world)
+            dist.all_reduce(self._msg)
 
     def _stage2(self):
         # .grad = None: autograd hands each parameter its gradient tensor as is (no per-parameter "grad += new" launch, ~270 of
@@ -308,7 +336,8 @@ class TrainStep:
 
     def _stage3(self):
         if self.flat_update:
-            nv.adamw_step_state(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.opt_state, self._skip, self._opt_ws)
+            nv.adamw_step_state(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.opt_state, self._skip, self._opt_ws,
+                                 hold=None if self._msg is None else self._msg[-1:])
             return
         torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, foreach=True)
         self.opt.step()
@@ -318,11 +347,34 @@ class TrainStep:
             self.exp_avg.zero_()
             self.exp_avg_sq.zero_()
             self.opt_state[:5].zero_()            # step count and derived values; the hyper-parameter slots stay
+            self.opt_state[11:13].zero_()         # hold flag / held-step counter
             return
         for st in self.opt.state.values():
             for v in st.values():
                 if torch.is_tensor(v):
                     v.zero_()
+
+    # ---- optimizer state export / import (ref: the runner's resume_from, extra_tools/train.py:141-142) -------------------------------
+    def optimizer_state_dict(self):
+        """Flat AdamW state as a dict of CPU tensors (per-parameter views are recoverable through `offsets`)."""
+        if not self.flat_update:
+            return dict(kind="torch", state=self.opt.state_dict())
+        return dict(kind="flat", exp_avg=self.exp_avg.cpu(), exp_avg_sq=self.exp_avg_sq.cpu(), opt_state=self.opt_state.cpu(),
+                    offsets=list(self.offsets), numels=[p.numel() for p in self.params],
+                    skip=None if self._skip is None else self._skip.cpu())
+
+    def load_optimizer_state_dict(self, sd):
+        if sd.get("kind") == "torch":
+            self.opt.load_state_dict(sd["state"])
+            return
+        if list(sd["offsets"]) != list(self.offsets) or list(sd["numels"]) != [p.numel() for p in self.params]:
+            raise ValueError("optimizer state was saved for a different parameter layout")
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"]); self.opt_state.copy_(sd["opt_state"])
+        self.opt_state[11:13].zero_()
+        if sd.get("skip") is not None:
+            self._skip = sd["skip"].to(self.dev)
+            self._skip_known = True
+        self.set_hyper()
 
     def eager_step(self):
         self._stage1(); self._reduce_num_pos()
@@ -354,6 +406,9 @@ class TrainStep:
         snap = dict(model=self.snapshot())
         if self.flat_update:
             snap.update(m=self.exp_avg.clone(), v=self.exp_avg_sq.clone(), st=self.opt_state.clone())
+        else:       # torch.optim.AdamW: moments and step counters of every parameter that has state already
+            snap["opt"] = {i: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in self.opt.state.get(p, {}).items()}
+                           for i, p in enumerate(self.params)}
         return snap
 
     def restore_full(self, snap):
@@ -363,7 +418,15 @@ class TrainStep:
             if self.flat_update:
                 self.exp_avg.copy_(snap["m"]); self.exp_avg_sq.copy_(snap["v"]); self.opt_state.copy_(snap["st"])
             else:
-                self._reset_opt_state()
+                # in place (a captured optimizer step holds these addresses); state created after the snapshot goes back to zero
+                for i, p in enumerate(self.params):
+                    cur, old = self.opt.state.get(p, {}), snap["opt"].get(i, {})
+                    for k, v in cur.items():
+                        if torch.is_tensor(v):
+                            if k in old:
+                                v.copy_(old[k])
+                            else:
+                                v.zero_()
 
     def snapshot(self):
         return [t.detach().clone() for t in list(self.model.parameters()) + list(self.model.buffers())]
@@ -406,6 +469,11 @@ class TrainStep:
         keep_state: weights, BatchNorm statistics and optimizer state are restored afterwards - the measuring / warm-up iterations
         are real optimizer steps and must not count as training."""
         assert self.graph
+        if self.dist_on:
+            raise RuntimeError("capture() with a live process group: hipGraph capture and RCCL do not mix on this stack (see "
+                               "enable_dist); use recapture(), which tears the group down through pg_hooks first")
+        if batches is not None:
+            self._capture_batches = batches
         snap = self.snapshot_full() if keep_state else None
         counts, caps = self.measure_capacities(batches)
         s = torch.cuda.Stream()
@@ -417,7 +485,7 @@ class TrainStep:
         torch.cuda.synchronize()
         # drop the eager iteration's activations / autograd graph BEFORE capturing: releasing them from inside a capture
         # (when the attributes are re-assigned) tears down autograd nodes mid-capture and crashes hipStreamEndCapture
-        self._outs = self._T = self._num_pos = self._losses = self.loss = None
+        self._outs = self._T = self._num_pos = self._msg = self._losses = self.loss = None
         self._gx = None
         self.model._encoder_out = self.model._encoder_cut = None
         self.model.pts_bbox_head._loss_total = None
@@ -455,19 +523,52 @@ class TrainStep:
         self._steps_since_check = 0
         return counts, caps
 
+    def held_steps(self):
+        """Steps whose update was held because a sparse level overflowed somewhere in the job (one small device-to-host read;
+        identical on every rank: the flag is all-reduced before the update)."""
+        if not self.flat_update:
+            return 0
+        return int(self.opt_state[12].item())
+
+    def recapture(self):
+        """Collective re-capture with more room (every rank calls it at the same step: the decision comes from the all-reduced
+        counter).  With a live process group the group is torn down first and re-created afterwards through `pg_hooks`: capture and
+        RCCL do not mix (enable_dist).  Weights, BatchNorm statistics and optimizer state are put back (capture keep_state=True), so
+        replicas stay identical without a broadcast."""
+        was_dist = self.dist_on
+        if was_dist:
+            if self.pg_hooks is None:
+                raise RuntimeError("sparse level overflow on a multi-rank run and no pg_hooks=(teardown, setup) to re-capture with: "
+                                   "capture with a larger capacity_margin or more representative `batches`")
+            if self._work is not None:
+                self._work.wait(); self._work = None
+            torch.cuda.synchronize()
+            dist.barrier()
+            self.pg_hooks[0]()
+            self.dist_on = False
+        self.capacity_margin *= 1.5
+        self.recaptures += 1
+        held = self.held_steps()
+        import sys
+        print(f"[TrainStep] {held} step(s) held by a sparse-level capacity overflow; re-capturing with margin "
+              f"{self.capacity_margin:.2f} (re-capture #{self.recaptures})", file=sys.stderr, flush=True)
+        self.capture(batches=self._capture_batches)
+        if self.flat_update:
+            self.opt_state[11:13].zero_()
+        if was_dist:
+            self.pg_hooks[1]()
+            self.dist_on = dist.is_available() and dist.is_initialized()
+            self.world = dist.get_world_size() if self.dist_on else 1
+
     def step(self):
         if self._graphs is None:
             return self.eager_step()
         if self.check_every and self._steps_since_check >= self.check_every:
-            # a level that outgrew its capacity would silently drop voxels: read the device-side counts every `check_every` steps
-            # (one small device-to-host copy) and re-capture with room to spare when one is exceeded
+            # held steps = a level outgrew its capacity on some rank (the device already refused to train on it, on every rank):
+            # one small device-to-host read every `check_every` steps, then a collective re-capture with room to spare
             self._steps_since_check = 0
-            try:
-                self.check_capacities()
-            except RuntimeError:
-                self.capacity_margin *= 1.5
-                self.recaptures += 1
-                self.capture()
+            if self.held_steps() > 0:
+                self.recapture()
         self._steps_since_check += 1
         g1, g2, g2b, g3 = self._graphs
         g1.replay()
