@@ -478,7 +478,7 @@ int32_t u3d_box_merge(const float* boxes, const int32_t* labels, int32_t n, floa
  * (u3d_wgrad_batched_bf16 / u3d_skinny_wgrad_bf16 / u3d_colsum_batched).  Slot offsets: u3d_decoder_layer_slots().
  * Dropout: counter-based (hash of seed, layer, site, element index); the backward regenerates the masks from the same seed.
  * ---------------------------------------------------------------------------------------------- */
-enum {  /* wide linears: w bf16 [N(pad)][K] (nn.Linear layout), wt bf16 [K][N(pad)] (dgrad), b f32 [N] */
+enum {  /* wide linears: w = [N(pad)][K] (nn.Linear's matrix) and wt = [K][N(pad)] (dgrad), both in u3d_wpack's fragment order; b f32 [N] */
   U3D_DL_RPH0, U3D_DL_RPH1, U3D_DL_RPH2,      /* ref_point_head 384->256->256->256 */
   U3D_DL_QS0, U3D_DL_QS1, U3D_DL_QS2,         /* query_scale 256->256->256->256 (layers > 0) */
   U3D_DL_INQK, U3D_DL_INV,                    /* in_proj rows [0,512) and [512,768) */
@@ -486,7 +486,7 @@ enum {  /* wide linears: w bf16 [N(pad)][K] (nn.Linear layout), wt bf16 [K][N(pa
   U3D_DL_OPROJ,                               /* UniCrossAtten.output_proj */
   U3D_DL_PE1,                                 /* position_encoder[3] */
   U3D_DL_FFN0, U3D_DL_FFN1,                   /* 256->512, 512->256 */
-  U3D_DL_REG0, U3D_DL_REG1, U3D_DL_REG2,      /* REG2 / CLS2 / IOU2: N <= 32, w padded to 64 rows, wt to 32 columns */
+  U3D_DL_REG0, U3D_DL_REG1, U3D_DL_REG2,      /* REG2 / CLS2 / IOU2: N <= 32, w padded to 64 rows, wt = ROW-MAJOR [K][32] (t_plain) */
   U3D_DL_CLS0, U3D_DL_CLS1, U3D_DL_CLS2,
   U3D_DL_IOU0, U3D_DL_IOU1, U3D_DL_IOU2,
   U3D_DL_NLIN
@@ -561,11 +561,15 @@ int32_t u3d_mha_fwd_dt(const void* qk, const void* v, int32_t m, int32_t nq, flo
                        float* lse, int32_t dtype, u3d_stream s);
 int32_t u3d_mha_bwd_dt(const void* qk, const void* v, const void* o, const void* d_o, const float* lse, int32_t m, int32_t nq,
                        float p_attn, int32_t layer, const uint64_t* rng, void* dqk, void* dv, int32_t dtype, u3d_stream s);
-/* Refresh of the bf16 weight copies the fused layer reads: for each descriptor dst[n][k] = bf16(src[n][k]) (rows n >= N zero up to
- * n_pad) and dst_t[k][n] = the transpose with n_pad_t columns.  descs in device memory; one launch for all linears of all layers. */
+/* Refresh of the weight copies the fused layer reads: for each descriptor dst = bf16(src [n][k]) (rows n >= N zero up to n_pad) and
+ * dst_t = its transpose [k][n_pad_t], both stored in MFMA FRAGMENT ORDER: block (16-row tile, 32-element k-step) = 64 x 16 bytes in
+ * lane order (lane = kq * 16 + row, 8 consecutive k each), blocks of a tile consecutive - one wave load of a weight fragment is
+ * 1 KiB contiguous.  descs in device memory; one launch for all linears of all layers. */
 typedef struct u3d_wpack_desc {
   const float* src; void* dst; void* dst_t;
-  int32_t n, k, n_pad, n_pad_t;
+  int32_t n, k, n_pad, n_pad_t;   /* n_pad % 16 == 0, k % 32 == 0 (bf16) / % 16 (f32); packed transposes: k % 16 == 0, n_pad_t % 32 == 0 */
+  int32_t t_plain;                /* 1: dst_t stays row-major [k][n_pad_t] (the <= 32-column final layers); 0: fragment order */
+  int32_t reserved;
 } u3d_wpack_desc;
 int32_t u3d_wpack_bf16(const u3d_wpack_desc* descs_dev, int32_t count, int32_t max_elems, u3d_stream s);
 /* dtype U3D_F32: the same copies in f32 (zero-padded rows / transposes of the f32 masters) for the parity-mode instantiation */

@@ -9,6 +9,14 @@
 // Each row kernel keeps its 32 rows in LDS from the first GEMM to the last; only what the backward needs goes to HBM.
 #include "decoder_common.h"
 
+#ifdef DC_PHASE_TIMING       /* tools/dec_bench.py: shader-clock stamps of ONE workgroup at the phase boundaries of k_dec_post */
+__device__ unsigned long long dc_dbg_fwd[64];
+#define DC_MARK(id) do { if (blockIdx.x == 7 && threadIdx.x == 0) dc_dbg_fwd[id] = __builtin_readcyclecounter(); } while (0)
+extern "C" int32_t u3d_debug_fwd_times(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dc_dbg_fwd), 64 * 8) == hipSuccess ? 0 : -1; }
+#else
+#define DC_MARK(id)
+#endif
+
 template <typename E>
 struct DcPtrs {            // forward-save slot pointers (device), resolved on the host from the slot offsets
   typedef typename E::T T;
@@ -97,22 +105,36 @@ static DcPtrs<E> dc_resolve(void* save, int m) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// weight packing: f32 master -> T [n_pad][k] and its transpose [k][n_pad_t] (T = bf16: rounded copies; T = f32: padded copies)
+// weight packing: f32 master -> T [n_pad][k] and its transpose [k][n_pad_t] (T = bf16: rounded copies; T = f32: padded copies), both in
+// the MFMA FRAGMENT ORDER dc_gemm reads (decoder_common.h); t_plain keeps the transpose row-major
 // ---------------------------------------------------------------------------------------------------------------------------
 template <typename E>
 __global__ __launch_bounds__(256) void k_wpack(const u3d_wpack_desc* __restrict__ descs) {
   typedef typename E::T T;
   const u3d_wpack_desc d = descs[blockIdx.y];
-  const int total = d.n_pad * d.k;
+  constexpr int WBLK = 64 * E::CH;
+  // dst: W [n_pad][k] in fragment order - block (tile = n / 16, ks = k / KSTEP) holds lane l = kq * 16 + r16 -> elements
+  // W[tile * 16 + r16][ks * KSTEP + kq * CH + e]
+  const int total = d.n_pad * d.k, KS = d.k / E::KSTEP;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int n = i / d.k, k = i % d.k;
+    const int e = i % E::CH, l = (i / E::CH) & 63, blk = i / WBLK, ks = blk % KS, tile = blk / KS;
+    const int n = tile * 16 + (l & 15), k = ks * E::KSTEP + (l >> 4) * E::CH + e;
     ((T*)d.dst)[i] = n < d.n ? E::from_f(d.src[(size_t)n * d.k + k]) : E::from_f(0.f);
   }
   if (d.dst_t) {
     const int tt = d.k * d.n_pad_t;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < tt; i += gridDim.x * 256) {
-      const int k = i / d.n_pad_t, n = i % d.n_pad_t;
-      ((T*)d.dst_t)[i] = n < d.n ? E::from_f(d.src[(size_t)n * d.k + k]) : E::from_f(0.f);
+    if (d.t_plain) {                                   // [k][n_pad_t] row-major (narrow final layers: read by plain VALU code)
+      for (int i = blockIdx.x * 256 + threadIdx.x; i < tt; i += gridDim.x * 256) {
+        const int k = i / d.n_pad_t, n = i % d.n_pad_t;
+        ((T*)d.dst_t)[i] = n < d.n ? E::from_f(d.src[(size_t)n * d.k + k]) : E::from_f(0.f);
+      }
+    } else {                                           // W^T [k][n_pad_t] in fragment order (rows = k, reduction index = n)
+      const int KST = d.n_pad_t / E::KSTEP;
+      for (int i = blockIdx.x * 256 + threadIdx.x; i < tt; i += gridDim.x * 256) {
+        const int e = i % E::CH, l = (i / E::CH) & 63, blk = i / WBLK, ks = blk % KST, tile = blk / KST;
+        const int k = tile * 16 + (l & 15), n = ks * E::KSTEP + (l >> 4) * E::CH + e;
+        ((T*)d.dst_t)[i] = n < d.n ? E::from_f(d.src[(size_t)n * d.k + k]) : E::from_f(0.f);
+      }
     }
   }
 }
@@ -177,71 +199,78 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_pre(u3d_declayer_params P, u
     *(VC*)(S.sine + (size_t)(row0 + row) * 384 + col0) = v;
   }
   __syncthreads();
-  // linear + ReLU into an activation tile and its save slot
-  auto relu_to = [&](T* dst, T* gsave, const float* bias) {
+  // Every linear's output lands in an LDS activation tile; what the backward (or the attention kernel) needs in HBM is stored FROM
+  // THE TILE after the barrier, 16 bytes per lane over whole 512-byte rows (dc_store_a).  Stores straight from the MFMA fragments
+  // (8 bytes per lane, 16 rows per instruction) were store-issue bound: ~3-4 k clocks of a 10 k-clock linear (tools/dec_bench.py).
+  auto relu_to = [&](T* dst, const float* bias) {
     return [=](int row, int col, f32x4 v) {
-      const V4 o = E::pack4(dc_relu4(v + dc_bias4(bias, col)));
-      *(V4*)(dst + dc_aoff<E>(row, col, DC_C)) = o;
-      DC_FRAG_STORE(*(V4*)(gsave + (size_t)(row0 + row) * DC_C + col) = o;)
+      *(V4*)(dst + dc_aoff<E>(row, col, DC_C)) = E::pack4(dc_relu4(v + dc_bias4(bias, col)));
     };
   };
-  dc_linear<E, 384, 4>(A0, (const T*)P.w[U3D_DL_RPH0], wave * 64, lane, relu_to(A1, S.rph1, P.b[U3D_DL_RPH0]));
+  auto lin_to = [&](T* dst, const float* bias) {
+    return [=](int row, int col, f32x4 v) { *(V4*)(dst + dc_aoff<E>(row, col, DC_C)) = E::pack4(v + dc_bias4(bias, col)); };
+  };
+  T* A1b = A1 + BM * DC_C;
+  dc_linear<E, 384, 4>(A0, (const T*)P.w[U3D_DL_RPH0], wave * 64, lane, relu_to(A1, P.b[U3D_DL_RPH0]));
   __syncthreads();
-  dc_linear<E, 256, 4>(A1, (const T*)P.w[U3D_DL_RPH1], wave * 64, lane, relu_to(A0, S.rph2, P.b[U3D_DL_RPH1]));
+  dc_store_a<E, 256>(A1, S.rph1, DC_C, row0, tid);
+  dc_linear<E, 256, 4>(A1, (const T*)P.w[U3D_DL_RPH1], wave * 64, lane, relu_to(A0, P.b[U3D_DL_RPH1]));
   __syncthreads();
+  dc_store_a<E, 256>(A0, S.rph2, DC_C, row0, tid);
   // raw = ref_point_head's output -> A2; it is the position embedding itself in the first layer
-  {
-    const float* bias = P.b[U3D_DL_RPH2];
-    T* gsave = dm.has_qs ? S.raw : S.pos;
-    dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_RPH2], wave * 64, lane, [=](int row, int col, f32x4 v) {
-      const V4 o = E::pack4(v + dc_bias4(bias, col));
-      *(V4*)(A2 + dc_aoff<E>(row, col, DC_C)) = o;
-      DC_FRAG_STORE(*(V4*)(gsave + (size_t)(row0 + row) * DC_C + col) = o;)
-    });
-  }
+  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_RPH2], wave * 64, lane, lin_to(A2, P.b[U3D_DL_RPH2]));
   __syncthreads();
+  dc_store_a<E, 256>(A2, dm.has_qs ? S.raw : S.pos, DC_C, row0, tid);
   dc_load_a<E, 256, true>(A0, xc, DC_C, row0, M, tid);           // x: input of query_scale and of the value projection
   __syncthreads();
   if (dm.has_qs) {
-    dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_QS0], wave * 64, lane, relu_to(A1, S.qs1, P.b[U3D_DL_QS0]));
+    dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_QS0], wave * 64, lane, relu_to(A1, P.b[U3D_DL_QS0]));
     __syncthreads();
+    dc_store_a<E, 256>(A1, S.qs1, DC_C, row0, tid);
     // A0 still holds x (the value projection needs it): the second hidden layer goes to the second BM x 256 half of A1
-    T* A1b = A1 + BM * DC_C;
-    dc_linear<E, 256, 4>(A1, (const T*)P.w[U3D_DL_QS1], wave * 64, lane, relu_to(A1b, S.qs2, P.b[U3D_DL_QS1]));
+    dc_linear<E, 256, 4>(A1, (const T*)P.w[U3D_DL_QS1], wave * 64, lane, relu_to(A1b, P.b[U3D_DL_QS1]));
     __syncthreads();
+    dc_store_a<E, 256>(A1b, S.qs2, DC_C, row0, tid);
     const float* bias = P.b[U3D_DL_QS2];
-    // pos = query_scale(x) * raw (both T tensors in the layer-by-layer formulation) -> A2 in place (same element, same lane)
+    // pos = query_scale(x) * raw (both T tensors in the layer-by-layer formulation) -> A2 in place (same element, same lane);
+    // the scale itself -> first half of A1 (free: its reader, the linear before, finished at the barrier)
     dc_linear<E, 256, 4>(A1b, (const T*)P.w[U3D_DL_QS2], wave * 64, lane, [=](int row, int col, f32x4 v) {
       const V4 q = E::pack4(v + dc_bias4(bias, col));
-      T* ap = A2 + dc_aoff<E>(row, col, DC_C);
-      const f32x4 raw = E::unpack4(*(const V4*)ap);
-      const V4 p = E::pack4(E::unpack4(q) * raw);
-      *(V4*)ap = p;
-      DC_FRAG_STORE(*(V4*)(S.qs + (size_t)(row0 + row) * DC_C + col) = q;)
-      DC_FRAG_STORE(*(V4*)(S.pos + (size_t)(row0 + row) * DC_C + col) = p;)
+      const int ao = dc_aoff<E>(row, col, DC_C);
+      const f32x4 raw = E::unpack4(*(const V4*)(A2 + ao));
+      *(V4*)(A2 + ao) = E::pack4(E::unpack4(q) * raw);
+      *(V4*)(A1 + ao) = q;
     });
     __syncthreads();
+    dc_store_a<E, 256>(A1, S.qs, DC_C, row0, tid);
+    dc_store_a<E, 256>(A2, S.pos, DC_C, row0, tid);
   }
-  // q = k input: x + pos -> A1
+  // q = k input: x + pos -> A1b (free in both paths)
   DC_FOR_TID(c, BM * (DC_C / E::CH)) {
-    const int off = c * E::CH;                              // A0, A1, A2 share one (row, chunk) permutation at ldk = 256
+    const int off = c * E::CH;                              // the tiles share one (row, chunk) permutation at ldk = 256
     const VC a = *(const VC*)(A0 + off), p = *(const VC*)(A2 + off);
     VC r;
 #pragma unroll
     for (int e = 0; e < E::CH; ++e) r[e] = E::from_f(E::to_f(a[e]) + E::to_f(p[e]));
-    *(VC*)(A1 + off) = r;
+    *(VC*)(A1b + off) = r;
   }
   __syncthreads();
-  dc_store_a<E, 256>(A1, S.qkin, DC_C, row0, tid);
-  // in-projection: (q | k) = A1 . Wqk^T + b, v = A0 . Wv^T + b -> HBM (the attention kernel regroups rows by (group, head))
-  auto to_global = [&](T* dst, int ld, const float* bias) {
-    return [=](int row, int col, f32x4 v) {
-      DC_FRAG_STORE(*(V4*)(dst + (size_t)(row0 + row) * ld + col) = E::pack4(v + dc_bias4(bias, col));)
-    };
-  };
-  dc_linear<E, 256, 4>(A1, (const T*)P.w[U3D_DL_INQK], wave * 64, lane, to_global(S.qk, 512, P.b[U3D_DL_INQK]));
-  dc_linear<E, 256, 4>(A1, (const T*)P.w[U3D_DL_INQK], 256 + wave * 64, lane, to_global(S.qk, 512, P.b[U3D_DL_INQK]));
-  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_INV], wave * 64, lane, to_global(S.v, 256, P.b[U3D_DL_INV]));
+  dc_store_a<E, 256>(A1b, S.qkin, DC_C, row0, tid);
+  // in-projection: q = A1b . Wq^T + b -> A1, k -> A2 (pos is saved), v = A0 . Wv^T + b -> A1b; each block leaves for HBM from its tile
+  // (the attention kernel regroups rows by (group, head))
+  dc_linear<E, 256, 4>(A1b, (const T*)P.w[U3D_DL_INQK], wave * 64, lane, lin_to(A1, P.b[U3D_DL_INQK]));
+  {
+    const float* bias = P.b[U3D_DL_INQK];
+    dc_linear<E, 256, 4>(A1b, (const T*)P.w[U3D_DL_INQK], 256 + wave * 64, lane, [=](int row, int col, f32x4 v) {
+      *(V4*)(A2 + dc_aoff<E>(row, col - 256, DC_C)) = E::pack4(v + dc_bias4(bias, col));
+    });
+  }
+  __syncthreads();
+  dc_store_a<E, 256>(A1, S.qk, 512, row0, tid);
+  dc_store_a<E, 256>(A2, S.qk + 256, 512, row0, tid);
+  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_INV], wave * 64, lane, lin_to(A1b, P.b[U3D_DL_INV]));
+  __syncthreads();
+  dc_store_a<E, 256>(A1b, S.v, DC_C, row0, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -380,6 +409,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post(u3d_declayer_params P, 
   dc_poison_lds<E>(lds, tid);
   DcDrop drop = {dc_rng_load(rng), dc_thresh(dm.p_drop), dc_inv_keep(dm.p_drop), dm.layer};
 
+  DC_MARK(0);
   dc_load_a<E, 256, true>(A0, S.o, DC_C, row0, M, tid);           // the attention kernel writes m rows only: padded rows repeat row m-1 (finite)
   dc_load_f<E, false>(F, x, row0, M, tid);
   dc_load_a<E, 256, false>(A2, S.pos, DC_C, row0, M, tid);
@@ -397,42 +427,69 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post(u3d_declayer_params P, 
       *(f32x4*)fp = *(const f32x4*)fp + v;
     };
   };
+  DC_MARK(1);
   dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_OUTP], wave * 64, lane, add_to_F(P.b[U3D_DL_OUTP], 0));
   __syncthreads();
+  DC_MARK(2);
   {
-    DcLnOut<E> o = {F, A0, DC_C, nullptr, nullptr, S.mr, U3D_DLN_1, false, S.u1};
+    DcLnOut<E> o = {F, A0, DC_C, nullptr, nullptr, S.mr, U3D_DLN_1, false, S.u1, nullptr};
     dc_layernorm<E>(F, P.ln_g[U3D_DLN_1], P.ln_b[U3D_DLN_1], dm.ln_eps, false, o, row0, wave, lane);
   }
   __syncthreads();
-  // cross "attention": gate = sigmoid(attention_weights(x1 + pos)), one trilinear sample of the value volume per query
+  DC_MARK(3);
+  // cross "attention": gate = sigmoid(attention_weights(x1 + pos)), one trilinear sample of the value volume per query.
+  // The 8 corner rows of GRP queries are requested together (8 * GRP row loads of 512 B in flight per wave) before any of them is
+  // used: one query at a time, every query waited out a full miss latency (phase stamps: 82 k clocks = 21 % of the kernel).
+  // Out-of-volume corners load row 0 with weight 0: no branch between the loads.
   {
     const f32x4 aw = *(const f32x4*)(P.attw_w + lane * 4);
     const float ab = P.attw_b[0];
-#pragma unroll 2
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int row = wave * RPW + rr;
-      const size_t gr = (size_t)(row0 + row);
-      const int ao = dc_aoff<E>(row, lane * 4, DC_C);
-      const f32x4 x1 = E::unpack4(*(const V4*)(A0 + ao)), pp = E::unpack4(*(const V4*)(A2 + ao));
-      const V4 qpb = E::pack4(x1 + pp);
-      const f32x4 qp = E::unpack4(qpb);
-      *(V4*)(S.qp + gr * DC_C + lane * 4) = qpb;
-      const float wl = E::round(u3d_wave_sum(qp[0] * aw[0] + qp[1] * aw[1] + qp[2] * aw[2] + qp[3] * aw[3]) + ab);
-      const float gate = E::round(E::sigmoid(wl));
-      S.mr[gr * 16 + 14] = wl;                     // all lanes, same value
-      DcCorners tc;
-      dc_corners<E>(misc + row * DC_MISC_LD, min(row0 + row, M - 1) / dm.qps, dm.dz, dm.dy, dm.dx, tc);
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int GRP = 4;
+    static_assert(RPW % GRP == 0, "rows per wave must split into gather groups");
+#pragma unroll 1
+    for (int r0g = 0; r0g < RPW; r0g += GRP) {
+      V4 cv[GRP][8];
+      float cw[GRP][8];
+#ifndef DC_ABL_NOGATHER
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (tc.row[c] >= 0) acc += tc.w[c] * E::unpack4(*(const V4*)(value + (size_t)tc.row[c] * DC_C + lane * 4));
-      const V4 sb = E::pack4(acc);
-      const V4 gb = E::pack4(E::unpack4(sb) * gate);
-      *(V4*)(A1 + ao) = gb;
-      *(V4*)(S.samp + gr * DC_C + lane * 4) = sb;
-      *(V4*)(S.gated + gr * DC_C + lane * 4) = gb;
+      for (int g = 0; g < GRP; ++g) {
+        const int row = wave * RPW + r0g + g;
+        DcCorners tc;
+        dc_corners<E>(misc + row * DC_MISC_LD, min(row0 + row, M - 1) / dm.qps, dm.dz, dm.dy, dm.dx, tc);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int vr = max(tc.row[c], 0);                  // scalar
+          cw[g][c] = tc.row[c] >= 0 ? tc.w[c] : 0.f;
+          cv[g][c] = *(const V4*)(value + (size_t)vr * DC_C + lane * 4);
+        }
+      }
+#endif
+#pragma unroll
+      for (int g = 0; g < GRP; ++g) {
+        const int row = wave * RPW + r0g + g;
+        const size_t gr = (size_t)(row0 + row);
+        const int ao = dc_aoff<E>(row, lane * 4, DC_C);
+        const f32x4 x1 = E::unpack4(*(const V4*)(A0 + ao)), pp = E::unpack4(*(const V4*)(A2 + ao));
+        const V4 qpb = E::pack4(x1 + pp);
+        const f32x4 qp = E::unpack4(qpb);
+        *(V4*)(S.qp + gr * DC_C + lane * 4) = qpb;
+        const float wl = E::round(dc_wave_sum(qp[0] * aw[0] + qp[1] * aw[1] + qp[2] * aw[2] + qp[3] * aw[3]) + ab);
+        const float gate = E::round(E::sigmoid(wl));
+        S.mr[gr * 16 + 14] = wl;                     // all lanes, same value
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#ifndef DC_ABL_NOGATHER
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc += cw[g][c] * E::unpack4(cv[g][c]);
+#endif
+        const V4 sb = E::pack4(acc);
+        const V4 gb = E::pack4(E::unpack4(sb) * gate);
+        *(V4*)(A1 + ao) = gb;
+        *(V4*)(S.samp + gr * DC_C + lane * 4) = sb;
+        *(V4*)(S.gated + gr * DC_C + lane * 4) = gb;
+      }
     }
   }
+  DC_MARK(4);
   // position encoder, first layer (3 -> 256): plain VALU into G
   {
     const int col = tid;
@@ -444,23 +501,24 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post(u3d_declayer_params P, 
     }
   }
   __syncthreads();
+  DC_MARK(5);
   dc_linear<E, 256, 4>(A1, (const T*)P.w[U3D_DL_OPROJ], wave * 64, lane, add_to_F(P.b[U3D_DL_OPROJ], 1));
   {
-    DcLnOut<E> o = {nullptr, A0, DC_C, nullptr, S.peh0, S.mr, U3D_DLN_PE0, false, nullptr};
+    DcLnOut<E> o = {nullptr, A0, DC_C, nullptr, S.peh0, S.mr, U3D_DLN_PE0, false, nullptr, nullptr};
     dc_layernorm<E>(G, P.ln_g[U3D_DLN_PE0], P.ln_b[U3D_DLN_PE0], dm.ln_eps, true, o, row0, wave, lane);   // overwrites A0 (x1: no longer needed)
   }
   __syncthreads();
+  DC_MARK(6);
   {
     const float* bias = P.b[U3D_DL_PE1];
     dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_PE1], wave * 64, lane, [=](int row, int col, f32x4 v) {
-      const V4 ub = E::pack4(v + dc_bias4(bias, col));
-      *(f32x4*)(G + row * DC_TS + col) = E::unpack4(ub);
-      DC_FRAG_STORE(*(V4*)(S.upe1 + (size_t)(row0 + row) * DC_C + col) = ub;)
+      *(f32x4*)(G + row * DC_TS + col) = E::round4(v + dc_bias4(bias, col));       // saved by the LayerNorm below (its input rows)
     });
   }
   __syncthreads();
+  DC_MARK(7);
   {
-    DcLnOut<E> o = {G, nullptr, 0, nullptr, nullptr, S.mr, U3D_DLN_PE1, true, nullptr};
+    DcLnOut<E> o = {G, nullptr, 0, nullptr, nullptr, S.mr, U3D_DLN_PE1, true, nullptr, S.upe1};
     dc_layernorm<E>(G, P.ln_g[U3D_DLN_PE1], P.ln_b[U3D_DLN_PE1], dm.ln_eps, true, o, row0, wave, lane);
   }
   __syncthreads();
@@ -469,11 +527,13 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post(u3d_declayer_params P, 
     *(f32x4*)(F + o) = *(const f32x4*)(F + o) + *(const f32x4*)(G + o);
   }
   __syncthreads();
+  DC_MARK(8);
   {
-    DcLnOut<E> o = {F, A0, DC_C, nullptr, S.x2c, S.mr, U3D_DLN_2, false, S.u2};
+    DcLnOut<E> o = {F, A0, DC_C, nullptr, S.x2c, S.mr, U3D_DLN_2, false, S.u2, nullptr};
     dc_layernorm<E>(F, P.ln_g[U3D_DLN_2], P.ln_b[U3D_DLN_2], dm.ln_eps, false, o, row0, wave, lane);
   }
   __syncthreads();
+  DC_MARK(9);
   // FFN
   {
     const float* bias = P.b[U3D_DL_FFN0];
@@ -481,25 +541,26 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post(u3d_declayer_params P, 
       v = E::round4(dc_relu4(v + dc_bias4(bias, col)));
       const V4 hb = E::pack4(drop.apply(v, 2, (unsigned)((row0 + row) * DC_FF + col)));
       *(V4*)(A1 + dc_aoff<E>(row, col, DC_FF)) = hb;
-      DC_FRAG_STORE(*(V4*)(S.ffh + (size_t)(row0 + row) * DC_FF + col) = hb;)
     };
     dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_FFN0], wave * 64, lane, ffh);
     dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_FFN0], 256 + wave * 64, lane, ffh);
   }
   __syncthreads();
+  DC_MARK(10);
+  dc_store_a<E, 512>(A1, S.ffh, DC_FF, row0, tid);
   dc_linear<E, 512, 4>(A1, (const T*)P.w[U3D_DL_FFN1], wave * 64, lane, add_to_F(P.b[U3D_DL_FFN1], 3));
   __syncthreads();
+  DC_MARK(11);
   {
-    DcLnOut<E> o = {nullptr, A2, DC_C, x_out, xc_out, S.mr, U3D_DLN_3, false, S.u3};
+    DcLnOut<E> o = {nullptr, A2, DC_C, x_out, xc_out, S.mr, U3D_DLN_3, false, S.u3, nullptr};
     dc_layernorm<E>(F, P.ln_g[U3D_DLN_3], P.ln_b[U3D_DLN_3], dm.ln_eps, false, o, row0, wave, lane);
   }
   __syncthreads();
+  DC_MARK(12);
   // branches on the layer state x3 (A2)
-  auto relu_to = [&](T* dst, T* gsave, const float* bias) {
+  auto relu_to = [&](T* dst, const float* bias) {         // the slot copy leaves from the tile after the barrier (see k_dec_pre)
     return [=](int row, int col, f32x4 v) {
-      const V4 o = E::pack4(dc_relu4(v + dc_bias4(bias, col)));
-      *(V4*)(dst + dc_aoff<E>(row, col, DC_C)) = o;
-      DC_FRAG_STORE(*(V4*)(gsave + (size_t)(row0 + row) * DC_C + col) = o;)
+      *(V4*)(dst + dc_aoff<E>(row, col, DC_C)) = E::pack4(dc_relu4(v + dc_bias4(bias, col)));
     };
   };
   auto narrow_out = [&](float* dst, int n, const float* bias) {     // final layer of a branch: n <= 32 real columns of the 64 computed
@@ -510,39 +571,63 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post(u3d_declayer_params P, 
     };
   };
   T* A1b = A1 + BM * DC_C;
-  dc_linear<E, 256, 4>(A2, (const T*)P.w[U3D_DL_REG0], wave * 64, lane, relu_to(A0, S.r1, P.b[U3D_DL_REG0]));
+#ifdef DC_PHASE_TIMING
+  {     // one linear taken apart: burst + MFMAs | epilogue | barrier
+    DC_MARK(20);
+    f32x4 acc[E::MT][4];
+#pragma unroll
+    for (int mt = 0; mt < E::MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dc_gemm<E, 256, 4>(A2, (const T*)P.w[U3D_DL_REG0] + (size_t)(wave * 64) * 256, acc, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    DC_MARK(21);
+    auto epi = relu_to(A0, P.b[U3D_DL_REG0]);
+#pragma unroll
+    for (int mt = 0; mt < E::MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) epi(mt * 16 + (lane & 15), wave * 64 + nt * 16 + (lane >> 4) * 4, acc[mt][nt]);
+    __builtin_amdgcn_sched_barrier(0);
+    DC_MARK(22);
+    __syncthreads();
+    DC_MARK(23);
+  }
+#else
+  dc_linear<E, 256, 4>(A2, (const T*)P.w[U3D_DL_REG0], wave * 64, lane, relu_to(A0, P.b[U3D_DL_REG0]));
   __syncthreads();
-  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_REG1], wave * 64, lane, relu_to(A1, S.r2, P.b[U3D_DL_REG1]));
+#endif
+  dc_store_a<E, 256>(A0, S.r1, DC_C, row0, tid);
+  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_REG1], wave * 64, lane, relu_to(A1, P.b[U3D_DL_REG1]));
   __syncthreads();
+  dc_store_a<E, 256>(A1, S.r2, DC_C, row0, tid);
   dc_linear<E, 256, 1>(A1, (const T*)P.w[U3D_DL_REG2], wave * 16, lane, narrow_out(reg_out, dm.code, P.b[U3D_DL_REG2]));
-  dc_linear<E, 256, 4>(A2, (const T*)P.w[U3D_DL_IOU0], wave * 64, lane, relu_to(A0, S.i1, P.b[U3D_DL_IOU0]));
+  dc_linear<E, 256, 4>(A2, (const T*)P.w[U3D_DL_IOU0], wave * 64, lane, relu_to(A0, P.b[U3D_DL_IOU0]));
   __syncthreads();
-  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_IOU1], wave * 64, lane, relu_to(A1b, S.i2, P.b[U3D_DL_IOU1]));
+  dc_store_a<E, 256>(A0, S.i1, DC_C, row0, tid);
+  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_IOU1], wave * 64, lane, relu_to(A1b, P.b[U3D_DL_IOU1]));
   __syncthreads();
+  dc_store_a<E, 256>(A1b, S.i2, DC_C, row0, tid);
   dc_linear<E, 256, 1>(A1b, (const T*)P.w[U3D_DL_IOU2], wave * 16, lane, narrow_out(iou_out, 1, P.b[U3D_DL_IOU2]));
-  // cls: Linear -> LN -> ReLU twice, then the class logits
-  auto to_G = [&](T* gsave, const float* bias) {
-    return [=](int row, int col, f32x4 v) {
-      const V4 ub = E::pack4(v + dc_bias4(bias, col));
-      *(f32x4*)(G + row * DC_TS + col) = E::unpack4(ub);
-      DC_FRAG_STORE(*(V4*)(gsave + (size_t)(row0 + row) * DC_C + col) = ub;)
-    };
+  // cls: Linear -> LN -> ReLU twice, then the class logits (each linear's output is saved by the LayerNorm that reads it)
+  auto to_G = [&](const float* bias) {
+    return [=](int row, int col, f32x4 v) { *(f32x4*)(G + row * DC_TS + col) = E::round4(v + dc_bias4(bias, col)); };
   };
-  dc_linear<E, 256, 4>(A2, (const T*)P.w[U3D_DL_CLS0], wave * 64, lane, to_G(S.uc1, P.b[U3D_DL_CLS0]));
+  dc_linear<E, 256, 4>(A2, (const T*)P.w[U3D_DL_CLS0], wave * 64, lane, to_G(P.b[U3D_DL_CLS0]));
   __syncthreads();
   {
-    DcLnOut<E> o = {nullptr, A0, DC_C, nullptr, S.c1, S.mr, U3D_DLN_C1, false, nullptr};
+    DcLnOut<E> o = {nullptr, A0, DC_C, nullptr, S.c1, S.mr, U3D_DLN_C1, false, nullptr, S.uc1};
     dc_layernorm<E>(G, P.ln_g[U3D_DLN_C1], P.ln_b[U3D_DLN_C1], dm.ln_eps, true, o, row0, wave, lane);
   }
   __syncthreads();
-  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_CLS1], wave * 64, lane, to_G(S.uc2, P.b[U3D_DL_CLS1]));
+  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_CLS1], wave * 64, lane, to_G(P.b[U3D_DL_CLS1]));
   __syncthreads();
   {
-    DcLnOut<E> o = {nullptr, A1, DC_C, nullptr, S.c2, S.mr, U3D_DLN_C2, false, nullptr};
+    DcLnOut<E> o = {nullptr, A1, DC_C, nullptr, S.c2, S.mr, U3D_DLN_C2, false, nullptr, S.uc2};
     dc_layernorm<E>(G, P.ln_g[U3D_DLN_C2], P.ln_b[U3D_DLN_C2], dm.ln_eps, true, o, row0, wave, lane);
   }
   __syncthreads();
   dc_linear<E, 256, 1>(A1, (const T*)P.w[U3D_DL_CLS2], wave * 16, lane, narrow_out(cls_out, dm.ncls, P.b[U3D_DL_CLS2]));
+  DC_MARK(14);
 }
 
 static int32_t dc_check(const u3d_declayer_params* p, const u3d_declayer_dims* d) {

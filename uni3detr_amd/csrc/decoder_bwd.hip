@@ -9,6 +9,14 @@
 #define DC_PF 4      /* weight-prefetch burst (k-steps): the backward row kernels carry more live state per lane than the forward ones */
 #include "decoder_common.h"
 
+#ifdef DC_PHASE_TIMING       /* tools/dec_bench.py: shader-clock stamps of ONE workgroup at the phase boundaries of k_dec_post_bwd */
+__device__ unsigned long long dc_dbg_bwd[64];
+#define DC_MARK(id) do { if (blockIdx.x == 7 && threadIdx.x == 0) dc_dbg_bwd[id] = __builtin_readcyclecounter(); } while (0)
+extern "C" int32_t u3d_debug_bwd_times(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dc_dbg_bwd), 64 * 8) == hipSuccess ? 0 : -1; }
+#else
+#define DC_MARK(id)
+#endif
+
 template <typename E>
 struct DcSave {            // forward-save slots (read-only here)
   typedef typename E::T T;
@@ -110,8 +118,8 @@ __device__ __forceinline__ void dc_layernorm_bwd(const float* T, LoadU load_u, c
       dg[j] += dy[j] * xh[j];
       db[j] += dy[j];
     }
-    s1 = u3d_wave_sum(s1) * (1.f / DC_C);
-    s2 = u3d_wave_sum(s2) * (1.f / DC_C);
+    s1 = dc_wave_sum(s1) * (1.f / DC_C);
+    s2 = dc_wave_sum(s2) * (1.f / DC_C);
     f32x4 du;
 #pragma unroll
     for (int j = 0; j < 4; ++j) du[j] = rs * (dxh[j] - s1 - xh[j] * s2);
@@ -155,60 +163,81 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
   float* misc = (float*)(lds + L::MISC);
   float* red = (float*)(A1 + BM * DC_C);               // LayerNorm partial reduce scratch: second half of A1 (free whenever it is used)
   static_assert(BM * DC_C * sizeof(T) >= 4 * 2 * DC_C * 4, "LayerNorm reduce scratch must fit the second half of A1");
-  (void)A2;
+  // narrow output gradients [BM][32] (zero-padded) as an MFMA operand: rows of NLD elements in the A2 region (unused otherwise here);
+  // the 80-byte (bf16) / 160-byte (f32) row stride spreads the 16 rows of a fragment read over all banks
+  constexpr int NLD = 40;
+  T* Dn = A2;
+  static_assert(BM * NLD <= BM * DC_C, "narrow-gradient tile must fit the A2 region");
   const int tid = threadIdx.x, lane = tid & 63, wave = dc_wave_id();
   const int row0 = blockIdx.x * BM, M = dm.m, nb = Gd.nb;
   dc_poison_lds<E>(lds, tid);
   DcDrop drop = {dc_rng_load(rng), dc_thresh(dm.p_drop), dc_inv_keep(dm.p_drop), dm.layer};
 
+  DC_MARK(0);
   dc_load_f<E, true>(F, dx_out, row0, M, tid);         // F = gradient w.r.t. the layer output x3 (zero when dx_out is null, zero past row m)
   {
     const int row = (tid >> 3) & (BM - 1), j = tid & 7;      // reference-point logits, slots 3..7 unused
     misc[row * DC_MISC_LD + j] = ref[(size_t)min(row0 + row, M - 1) * 3 + min(j, 2)];
   }
-  // narrow gradient [BM][n] (f32, m rows) -> misc columns 16.., plus its T copy (padded rows) for the caller's weight gradient
+  // narrow gradient [BM][n] (f32, m rows) -> the Dn tile (T, zero-padded to 32 columns), plus its T copy (padded rows) for the
+  // caller's weight gradient
   auto load_narrow = [&](const float* src, int n, T* gcopy) {
     DC_FOR_TID(i, BM * 32) {
       const int row = i >> 5, j = i & 31;
       const float raw = src[(size_t)min(row0 + row, M - 1) * n + min(j, n - 1)];      // always in range: selects below, no branch
       const float vr = row0 + row < M ? raw : 0.f;                                     // value of column min(j, n-1)
       gcopy[(size_t)(row0 + row) * n + min(j, n - 1)] = E::from_f(vr);                 // lanes j >= n repeat column n-1's store
-      misc[row * DC_MISC_LD + 16 + j] = E::round(j < n ? vr : 0.f);
+      Dn[row * NLD + j] = E::from_f(j < n ? vr : 0.f);
     }
   };
-  // dX[row][col] = sum_j dY[row][j] * W[j][col] for a final branch layer (n <= 32 rows of the padded weight), masked by the
-  // saved ReLU output `mask_src` when given; result (T) -> activation tile `dst` + global slot, or -> tile G (f32) when dst is null
-  auto narrow_dgrad = [&](const T* w, int n, const T* mask_src, T* dst, T* gslot) {
-    const int col = tid;
-    float wc[32];
+  // dX [BM][256] = dY [BM][32] . W [32][256] for a final branch layer on the matrix pipe (one 32-deep reduction: wt = W^T in fragment
+  // order, 16 tiles of one / two k-steps), masked by the saved ReLU output `mask_src` when given; result (T) -> activation tile `dst`
+  // (its slot copy leaves from the tile after the barrier), or -> tile G (f32) when dst is null.
+  // (As plain VALU code - 32 x 32 multiply-adds per thread and row-at-a-time 2-byte stores - this step cost 25-30 k clocks, a
+  // quarter of each branch's backward: tools/dec_bench.py phase stamps.)
+  auto narrow_dgrad = [&](const T* wt, const T* mask_src, T* dst) {
+    typedef typename E::VC VC;
+    constexpr int KSN = 32 / E::KSTEP, WBLK = 64 * E::CH;
+    const int r16 = lane & 15, kq = lane >> 4;
+    f32x4 acc[E::MT][4];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) wc[j] = j < n ? E::to_f(w[j * DC_C + col]) : 0.f;
-    for (int row = 0; row < BM; ++row) {
-      float acc = 0.f;
+    for (int mt = 0; mt < E::MT; ++mt)
 #pragma unroll
-      for (int j = 0; j < 32; ++j) acc += misc[row * DC_MISC_LD + 16 + j] * wc[j];
-      if (mask_src) {
-        const float y = E::to_f(mask_src[(size_t)(row0 + row) * DC_C + col]);
-        acc = y > 0.f ? acc : 0.f;
-      }
-      const T ab = E::from_f(acc);
-      if (dst) {
-        dst[dc_aoff<E>(row, col, DC_C)] = ab;
-        gslot[(size_t)(row0 + row) * DC_C + col] = ab;
-      } else {
-        G[row * DC_TS + col] = E::to_f(ab);
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KSN; ++ks) {
+      VC a[E::MT];
+#pragma unroll
+      for (int mt = 0; mt < E::MT; ++mt) a[mt] = *(const VC*)(Dn + (mt * 16 + r16) * NLD + (ks * 4 + kq) * E::CH);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const VC wf = *(const VC*)(wt + (size_t)((wave * 4 + nt) * KSN + ks) * WBLK + lane * E::CH);
+#pragma unroll
+        for (int mt = 0; mt < E::MT; ++mt) E::mma(wf, a[mt], acc[mt][nt]);
       }
     }
+#pragma unroll
+    for (int mt = 0; mt < E::MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int row = mt * 16 + r16, col = wave * 64 + nt * 16 + kq * 4;
+        f32x4 v = acc[mt][nt];
+        if (mask_src) {
+          const V4 y = *(const V4*)(mask_src + (size_t)(row0 + row) * DC_C + col);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = E::to_f(y[r]) > 0.f ? v[r] : 0.f;
+        }
+        if (dst) *(V4*)(dst + dc_aoff<E>(row, col, DC_C)) = E::pack4(v);
+        else *(f32x4*)(G + row * DC_TS + col) = E::round4(v);
+      }
   };
   // dgrad GEMM epilogues
-  auto masked_to = [&](T* dst, T* gslot, const T* mask_src) {          // (dY W) * [saved ReLU output > 0] -> tile + slot
+  auto masked_to = [&](T* dst, const T* mask_src) {          // (dY W) * [saved ReLU output > 0] -> tile (slot copy: dc_store_a)
     return [=](int row, int col, f32x4 v) {
       const V4 y = *(const V4*)(mask_src + (size_t)(row0 + row) * DC_C + col);
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = E::to_f(y[r]) > 0.f ? v[r] : 0.f;
-      const V4 o = E::pack4(v);
-      *(V4*)(dst + dc_aoff<E>(row, col, DC_C)) = o;
-      DC_FRAG_STORE(*(V4*)(gslot + (size_t)(row0 + row) * DC_C + col) = o;)
+      *(V4*)(dst + dc_aoff<E>(row, col, DC_C)) = E::pack4(v);
     };
   };
   auto acc_to_F = [&]() {
@@ -227,10 +256,11 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
     return [=](int row, int gr) { return *(const f32x4*)(src + (size_t)gr * DC_C + lane * 4); };
   };
 
+  DC_MARK(1);
   // ---- cls branch --------------------------------------------------------------------------------------------------------
   load_narrow(dcls, dm.ncls, Gd.clso);
   __syncthreads();
-  narrow_dgrad((const T*)P.w[U3D_DL_CLS2], dm.ncls, nullptr, nullptr, nullptr);          // -> G
+  narrow_dgrad((const T*)P.wt[U3D_DL_CLS2], nullptr, nullptr);          // -> G
   __syncthreads();
   {
     DcLnBwdOut<E> o = {nullptr, A0, Gd.c2u};
@@ -246,30 +276,38 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
   }
   dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_CLS0], wave * 64, lane, acc_to_F());
   __syncthreads();
+  DC_MARK(2);
   // ---- iou branch ----------------------------------------------------------------------------------------------------------
   load_narrow(diou, 1, Gd.iouo);
   __syncthreads();
-  narrow_dgrad((const T*)P.w[U3D_DL_IOU2], 1, S.i2, A0, Gd.i2);
+  narrow_dgrad((const T*)P.wt[U3D_DL_IOU2], S.i2, A0);
   __syncthreads();
-  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_IOU1], wave * 64, lane, masked_to(A1, Gd.i1, S.i1));
+  dc_store_a<E, 256>(A0, Gd.i2, DC_C, row0, tid);
+  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_IOU1], wave * 64, lane, masked_to(A1, S.i1));
   __syncthreads();
+  dc_store_a<E, 256>(A1, Gd.i1, DC_C, row0, tid);
   dc_linear<E, 256, 4>(A1, (const T*)P.wt[U3D_DL_IOU0], wave * 64, lane, acc_to_F());
   __syncthreads();
+  DC_MARK(3);
   // ---- reg branch ----------------------------------------------------------------------------------------------------------
   load_narrow(dreg, dm.code, Gd.rego);
   __syncthreads();
-  narrow_dgrad((const T*)P.w[U3D_DL_REG2], dm.code, S.r2, A0, Gd.r2);
+  narrow_dgrad((const T*)P.wt[U3D_DL_REG2], S.r2, A0);
   __syncthreads();
-  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_REG1], wave * 64, lane, masked_to(A1, Gd.r1, S.r1));
+  dc_store_a<E, 256>(A0, Gd.r2, DC_C, row0, tid);
+  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_REG1], wave * 64, lane, masked_to(A1, S.r1));
   __syncthreads();
+  dc_store_a<E, 256>(A1, Gd.r1, DC_C, row0, tid);
   dc_linear<E, 256, 4>(A1, (const T*)P.wt[U3D_DL_REG0], wave * 64, lane, acc_to_F());
   __syncthreads();
+  DC_MARK(4);
   // ---- LN3 -> du3 (F) -------------------------------------------------------------------------------------------------------
   {
     DcLnBwdOut<E> o = {F, nullptr, nullptr};
     dc_layernorm_bwd<E>(F, u_f32(S.u3), S.mr, U3D_DLN_3, P.ln_g[U3D_DLN_3], P.ln_b[U3D_DLN_3], false, o, Gd.lnp, U3D_DLN_3, nb, red, row0,
                         wave, lane, tid);
   }
+  DC_MARK(5);
   // ---- FFN -----------------------------------------------------------------------------------------------------------------
   // dY of a residual branch: dropout mask of the forward applied to the residual-stream gradient, T -> tile + slot
   auto branch_grad = [&](int site, T* dst, T* gslot) {
@@ -279,7 +317,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
       v = drop.apply(v, site, (unsigned)((row0 + row) * DC_C + col));
       const V4 o = E::pack4(v);
       *(V4*)(dst + dc_aoff<E>(row, col, DC_C)) = o;
-      DC_FRAG_STORE(*(V4*)(gslot + (size_t)(row0 + row) * DC_C + col) = o;)
+      *(V4*)(gslot + (size_t)(row0 + row) * DC_C + col) = o;           // whole rows, 8 / 16 bytes per lane: coalesced as it is
     }
   };
   branch_grad(3, A0, Gd.f);
@@ -292,20 +330,22 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
       for (int r = 0; r < 4; ++r) v[r] = E::to_f(y[r]) > 0.f ? E::round(v[r]) * ik : 0.f;     // kept & positive <=> saved value > 0
       const V4 o = E::pack4(v);
       *(V4*)(A1 + dc_aoff<E>(row, col, DC_FF)) = o;
-      DC_FRAG_STORE(*(V4*)(Gd.ffh + (size_t)(row0 + row) * DC_FF + col) = o;)
     };
     dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_FFN1], wave * 64, lane, dh);
     dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_FFN1], 256 + wave * 64, lane, dh);
   }
   __syncthreads();
+  dc_store_a<E, 512>(A1, Gd.ffh, DC_FF, row0, tid);
   dc_linear<E, 512, 4>(A1, (const T*)P.wt[U3D_DL_FFN0], wave * 64, lane, acc_to_F());
   __syncthreads();
+  DC_MARK(6);
   // ---- LN2 -> du2 (F) -------------------------------------------------------------------------------------------------------
   {
     DcLnBwdOut<E> o = {F, nullptr, nullptr};
     dc_layernorm_bwd<E>(F, u_f32(S.u2), S.mr, U3D_DLN_2, P.ln_g[U3D_DLN_2], P.ln_b[U3D_DLN_2], false, o, Gd.lnp, U3D_DLN_2, nb, red, row0,
                         wave, lane, tid);
   }
+  DC_MARK(7);
   // ---- position encoder ---------------------------------------------------------------------------------------------------
   DC_FOR_TID(c, BM * 64) {                                       // its output was a T tensor: the gradient arrives rounded
     const int o = (c >> 6) * DC_TS + (c & 63) * 4;
@@ -344,17 +384,19 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
         const f32x4 d = E::round4(*(const f32x4*)(G + row * DC_TS + lane * 4));
         float g3[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) g3[k] = u3d_wave_sum(d[0] * w[0][k] + d[1] * w[1][k] + d[2] * w[2][k] + d[3] * w[3][k]);
+        for (int k = 0; k < 3; ++k) g3[k] = dc_wave_sum(d[0] * w[0][k] + d[1] * w[1][k] + d[2] * w[2][k] + d[3] * w[3][k]);
         misc[row * DC_MISC_LD + 8 + (lane & 3)] = (lane & 3) == 0 ? g3[0] : ((lane & 3) == 1 ? g3[1] : g3[2]);   // misc[8..10]: running dref of the row (every lane stores; slot 11 is a dummy)
       }
     }
   }
   __syncthreads();
+  DC_MARK(8);
   // ---- output_proj, gate, trilinear scatter ------------------------------------------------------------------------------------
   branch_grad(1, A0, Gd.out);
   __syncthreads();
   dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_OPROJ], wave * 64, lane, to_G());      // d(gated) (T tensor)
   __syncthreads();
+  DC_MARK(9);
   {
     const f32x4 aw = *(const f32x4*)(P.attw_w + lane * 4);
 #pragma unroll 2
@@ -365,7 +407,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
       const f32x4 samp = E::unpack4(*(const V4*)(S.samp + (size_t)gr * DC_C + lane * 4));
       const float wl = S.mr[(size_t)gr * 16 + 14];
       const float gate = E::round(E::sigmoid(wl));
-      float dw = u3d_wave_sum(dgt[0] * samp[0] + dgt[1] * samp[1] + dgt[2] * samp[2] + dgt[3] * samp[3]);
+      float dw = dc_wave_sum(dgt[0] * samp[0] + dgt[1] * samp[1] + dgt[2] * samp[2] + dgt[3] * samp[3]);
       const float sg = E::sigmoid(wl);
       const float dwl = E::round(E::round(dw) * sg * (1.f - sg));
       Gd.wl[gr] = E::from_f(dwl);                                    // all lanes, same value
@@ -386,6 +428,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
       DcCorners tc;
       dc_corners<E>(misc + row * DC_MISC_LD, min(gr, M - 1) / dm.qps, dm.dz, dm.dy, dm.dx, tc);
       float gx = 0.f, gy = 0.f, gz = 0.f;
+#ifndef DC_ABL_NOGATHER
       if (ok) {
 #pragma unroll
         for (int c = 0; c < 8; ++c)
@@ -403,8 +446,9 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
             }
           }
       }
+#endif
       if (dm.need_dref) {
-        gx = u3d_wave_sum(gx); gy = u3d_wave_sum(gy); gz = u3d_wave_sum(gz);
+        gx = dc_wave_sum(gx); gy = dc_wave_sum(gy); gz = dc_wave_sum(gz);
         {                                        // every lane stores component lane % 3 (same address -> same value): no lane branch
           const float* r3 = misc + row * DC_MISC_LD;
           const int k = lane % 3;
@@ -416,6 +460,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
     }
   }
   __syncthreads();
+  DC_MARK(10);
   // ---- LN1 -> du1 (F): gradient of the residual stream at the layer input, and of the attention output -------------------------
   {
     DcLnBwdOut<E> o = {F, nullptr, nullptr};
@@ -426,8 +471,11 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
   branch_grad(0, A0, Gd.o2);
   __syncthreads();
   dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_OUTP], wave * 64, lane, [=](int row, int col, f32x4 v) {
-    DC_FRAG_STORE(*(V4*)(Gd.d_o + (size_t)(row0 + row) * DC_C + col) = E::pack4(v);)
+    *(V4*)(A1 + dc_aoff<E>(row, col, DC_C)) = E::pack4(v);              // A1 is free by now: d(attention output) leaves from the tile
   });
+  __syncthreads();
+  dc_store_a<E, 256>(A1, Gd.d_o, DC_C, row0, tid);
+  DC_MARK(11);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -651,14 +699,12 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_pre_bwd(u3d_declayer_params 
       *(f32x4*)fp = *(const f32x4*)fp + E::round4(v);
     };
   };
-  auto masked_to = [&](T* dst, T* gslot, const T* mask_src) {
+  auto masked_to = [&](T* dst, const T* mask_src) {          // (dY W) * [saved ReLU output > 0] -> tile (slot copy: dc_store_a)
     return [=](int row, int col, f32x4 v) {
       const V4 y = *(const V4*)(mask_src + (size_t)(row0 + row) * DC_C + col);
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = E::to_f(y[r]) > 0.f ? v[r] : 0.f;
-      const V4 o = E::pack4(v);
-      *(V4*)(dst + dc_aoff<E>(row, col, DC_C)) = o;
-      DC_FRAG_STORE(*(V4*)(gslot + (size_t)(row0 + row) * DC_C + col) = o;)
+      *(V4*)(dst + dc_aoff<E>(row, col, DC_C)) = E::pack4(v);
     };
   };
   // gradient w.r.t. the q = k input (x + pos) -> G; it reaches x (F) and pos
@@ -691,17 +737,21 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_pre_bwd(u3d_declayer_params 
   __syncthreads();
   T* A1b = A1 + BM * DC_C;
   if (dm.has_qs) {
-    dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_QS2], wave * 64, lane, masked_to(A1, Gd.qs2, S.qs2));
+    dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_QS2], wave * 64, lane, masked_to(A1, S.qs2));
     __syncthreads();
-    dc_linear<E, 256, 4>(A1, (const T*)P.wt[U3D_DL_QS1], wave * 64, lane, masked_to(A1b, Gd.qs1, S.qs1));
+    dc_store_a<E, 256>(A1, Gd.qs2, DC_C, row0, tid);
+    dc_linear<E, 256, 4>(A1, (const T*)P.wt[U3D_DL_QS1], wave * 64, lane, masked_to(A1b, S.qs1));
     __syncthreads();
+    dc_store_a<E, 256>(A1b, Gd.qs1, DC_C, row0, tid);
     dc_linear<E, 256, 4>(A1b, (const T*)P.wt[U3D_DL_QS0], wave * 64, lane, acc_to_F());
     __syncthreads();
   }
-  dc_linear<E, 256, 4>(A2, (const T*)P.wt[U3D_DL_RPH2], wave * 64, lane, masked_to(A0, Gd.rph2, S.rph2));
+  dc_linear<E, 256, 4>(A2, (const T*)P.wt[U3D_DL_RPH2], wave * 64, lane, masked_to(A0, S.rph2));
   __syncthreads();
-  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_RPH1], wave * 64, lane, masked_to(A1, Gd.rph1, S.rph1));
+  dc_store_a<E, 256>(A0, Gd.rph2, DC_C, row0, tid);
+  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_RPH1], wave * 64, lane, masked_to(A1, S.rph1));
   __syncthreads();
+  dc_store_a<E, 256>(A1, Gd.rph1, DC_C, row0, tid);
   if (dm.need_dref) {      // gradient w.r.t. the sine embedding [BM][384] -> slot (u3d_sine_embed_bwd turns it into d(logits))
     auto to_sine = [=](int row, int col, f32x4 v) { *(V4*)(Gd.sine + (size_t)(row0 + row) * 384 + col) = E::pack4(v); };
     dc_linear<E, 256, 4>(A1, (const T*)P.wt[U3D_DL_RPH0], wave * 64, lane, to_sine);
@@ -718,7 +768,7 @@ static int32_t dcb_check(const u3d_declayer_params* p, const u3d_declayer_dims* 
   for (int i = 0; i < U3D_DL_NLIN; ++i) {
     if (!d->has_qs && (i == U3D_DL_QS0 || i == U3D_DL_QS1 || i == U3D_DL_QS2)) continue;
     U3D_REQUIRE(p->w[i], U3D_ERR_ARG);
-    if (i != U3D_DL_REG2 && i != U3D_DL_CLS2 && i != U3D_DL_IOU2) U3D_REQUIRE(p->wt[i], U3D_ERR_ARG);
+    U3D_REQUIRE(p->wt[i], U3D_ERR_ARG);
   }
   for (int i = 0; i < U3D_DL_NLN; ++i) U3D_REQUIRE(p->ln_g[i] && p->ln_b[i], U3D_ERR_ARG);
   U3D_REQUIRE(p->attw_w && p->pe0_w && p->pe0_b && p->dim_t, U3D_ERR_ARG);

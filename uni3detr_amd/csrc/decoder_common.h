@@ -37,6 +37,25 @@ __device__ __forceinline__ u16 dc_f2bf(float f) {
 }
 __device__ __forceinline__ float dc_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// ---- wave reduction on the DPP network --------------------------------------------------------------------------------------------
+// u3d_wave_sum (common.h) is six dependent __shfl_xor = ds_bpermute_b32 round trips through the LDS crossbar (~100+ clocks each): a
+// LayerNorm row (two dependent sums) cost ~1.4 k clocks - the phase stamps of tools/dec_bench.py put the seven LayerNorms of
+// k_dec_post at 23 % of the kernel.  The same sum on the VALU's data-parallel primitives: quad permutes, row mirrors and the two
+// row broadcasts (6 dependent v_add_f32 with DPP modifiers), the total read from lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dc_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float dc_wave_sum(float v) {
+  v += dc_dpp<0xB1, 0xF>(v);        // quad_perm [1,0,3,2]
+  v += dc_dpp<0x4E, 0xF>(v);        // quad_perm [2,3,0,1]
+  v += dc_dpp<0x141, 0xF>(v);       // row_half_mirror
+  v += dc_dpp<0x140, 0xF>(v);       // row_mirror: every lane of a 16-lane row now holds the row's sum
+  v += dc_dpp<0x142, 0xA>(v);       // row_bcast:15 into rows 1 and 3
+  v += dc_dpp<0x143, 0xC>(v);       // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // ---- element traits -----------------------------------------------------------------------------------------------------------
 struct EB {                    // bf16 storage
   typedef u16 T;
@@ -147,7 +166,7 @@ struct DcDrop {
 };
 
 // ---- the block GEMM: acc[mt][nt] (+)= X[BM rows] . W[NT*16 rows]^T over K ---------------------------------------------------
-// A: LDS activation tile (ldk = K); W: global weight rows, already offset to the wave's first output column.
+// A: LDS activation tile (ldk = K); W: global weights, fragment-packed, already offset to the wave's first 16-row tile.
 // The weight fragments of DC_PF k-steps are requested in ONE burst and consumed behind sched_barriers: left alone, hipcc's
 // scheduler sinks each load to just before its MFMA (2-3 loads in flight per wave), and with one wave per SIMD every k-step then
 // waits out a full L2 round trip (measured: 13 us per 256x256 stage, 4x the burst schedule).
@@ -167,10 +186,18 @@ __device__ __forceinline__ void dc_gemm(const typename E::T* A, const typename E
   constexpr int KS = K / E::KSTEP;
   constexpr int PF = dc_burst(KS, DC_PF);
   static_assert((K / E::CH) % 16 == 0, "the chunk swizzle permutes aligned groups of 16 chunks");
+#ifdef DC_ABL_NOGEMM
+  return;
+#endif
   const int r16 = lane & 15, kq = lane >> 4;
+  // weights are FRAGMENT-PACKED (u3d_wpack): block (16-row tile, k-step) = 64 lanes x 16 bytes in lane order, so one wave load is
+  // 1 KiB contiguous (8 cache lines).  Row-major weights made every 16-lane group of a dwordx4 load touch 16 different lines - the
+  // vector L1 then serialised ~64 tag lookups per instruction and the row kernels ran at ~8 B/clk/CU of weight stream
+  // (phase stamps: 16 k clocks per 256 x 256 linear against 1.1 k clocks of MFMAs).
+  constexpr int WBLK = 64 * E::CH;                   // elements per (tile, k-step) block
   const T* wp[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) wp[nt] = W + (size_t)(nt * 16 + r16) * K + kq * E::CH;
+  for (int nt = 0; nt < NT; ++nt) wp[nt] = W + (size_t)nt * KS * WBLK + lane * E::CH;
   const T* ap[E::MT];
 #pragma unroll
   for (int mt = 0; mt < E::MT; ++mt) ap[mt] = A + (mt * 16 + r16) * K;
@@ -180,7 +207,7 @@ __device__ __forceinline__ void dc_gemm(const typename E::T* A, const typename E
 #pragma unroll
     for (int p = 0; p < PF; ++p)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wf[p][nt] = *(const VC*)(wp[nt] + (kb + p) * E::KSTEP);
+      for (int nt = 0; nt < NT; ++nt) wf[p][nt] = *(const VC*)(wp[nt] + (kb + p) * WBLK);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
@@ -294,6 +321,7 @@ struct DcLnOut {
   int mr_idx;
   bool round_out;              // y rounded through T before it is used as f32 (outputs that are T tensors in the layer-by-layer formulation)
   float* gpre;                 // global f32 [M,256] to receive the INPUT rows (saved for the backward), or null
+  typename E::T* gpre16;       // global T [M,256] to receive the INPUT rows (values that are already T-representable), or null
 };
 template <typename E>
 __device__ __forceinline__ void dc_layernorm(const float* T, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -305,9 +333,9 @@ __device__ __forceinline__ void dc_layernorm(const float* T, const float* __rest
   for (int rr = 0; rr < RPW; ++rr) {
     const int row = wave * RPW + rr;
     const f32x4 v = *(const f32x4*)(T + row * DC_TS + lane * 4);
-    const float mu = u3d_wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / DC_C);
+    const float mu = dc_wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / DC_C);
     const f32x4 d = {v[0] - mu, v[1] - mu, v[2] - mu, v[3] - mu};
-    const float rs = E::rsqrt(u3d_wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / DC_C) + eps);
+    const float rs = E::rsqrt(dc_wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / DC_C) + eps);
     f32x4 y;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -318,6 +346,7 @@ __device__ __forceinline__ void dc_layernorm(const float* T, const float* __rest
     if (o.round_out) y = E::unpack4(yb);
     const size_t grow = (size_t)(row0 + row);
     if (o.gpre) *(f32x4*)(o.gpre + grow * DC_C + lane * 4) = v;
+    if (o.gpre16) *(V4*)(o.gpre16 + grow * DC_C + lane * 4) = E::pack4(v);
     if (o.tile) *(f32x4*)(o.tile + row * DC_TS + lane * 4) = y;
     if (o.a) *(V4*)(o.a + dc_aoff<E>(row, lane * 4, o.a_ldk)) = yb;
     if (o.g32) *(f32x4*)(o.g32 + grow * DC_C + lane * 4) = y;

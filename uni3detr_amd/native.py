@@ -49,7 +49,7 @@ class DecLayerDims(C.Structure):
 class WPackDesc(C.Structure):
     """u3d_wpack_desc."""
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_t", C.c_void_p), ("n", C.c_int32), ("k", C.c_int32),
-                ("n_pad", C.c_int32), ("n_pad_t", C.c_int32)]
+                ("n_pad", C.c_int32), ("n_pad_t", C.c_int32), ("t_plain", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None

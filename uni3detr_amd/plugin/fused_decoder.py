@@ -150,6 +150,7 @@ class FusedDecoder:
             d.dst = st.wbuf.data_ptr() + o * es
             d.dst_t = st.wbuf.data_ptr() + ot * es
             d.n, d.k, d.n_pad, d.n_pad_t = rows, k, n_pad, n_pad_t
+            d.t_plain = 0                 # every transpose in fragment order (the narrow ones feed the MFMA narrow-dgrad step)
             views[key] = (d.dst, d.dst_t)
             max_elems = max(max_elems, n_pad * k, k * n_pad_t)
         st.ndesc, st.max_elems = len(uniq), max_elems
