@@ -25,14 +25,32 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks (no 2:1 sparsity)
 
 
+# BASELINE.json configs[1..4]: scenes per GPU and points per scene of the synthetic clouds (the room generator scaled to
+# each configuration's range; nuScenes = 10 sweeps, 5 point features, 2 scenes per GPU)
+WORKLOADS = {
+    "sunrgbd": dict(batch=8, points=20000, file="uni3detr_sunrgbd.py", baseline="configs[1]"),
+    "scannet_large": dict(batch=4, points=100000, file="uni3detr_scannet_large.py", baseline="configs[2]"),
+    "kitti_3classes": dict(batch=4, points=18000, file="uni3detr_kitti_3classes.py", baseline="configs[3]"),
+    "nuscenes": dict(batch=2, points=250000, file="uni3detr_nuscenes.py", baseline="configs[4]"),
+}
+
+
+def workload_cfg(name):
+    import copy
+    from uni3detr_amd.configs import variants
+    return copy.deepcopy(getattr(variants, name))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batches", type=int, default=16, help="distinct synthetic batches rotated through the timed steps")
-    ap.add_argument("--batch", type=int, default=8, help="scenes per GPU")
-    ap.add_argument("--points", type=int, default=20000)
+    ap.add_argument("--config", default="sunrgbd", choices=sorted(WORKLOADS),
+                    help="shipped configuration to run (BASELINE.json configs[1..4]); the headline metric is quoted on sunrgbd")
+    ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (default: the workload's)")
+    ap.add_argument("--points", type=int, default=None, help="points per scene (default: the workload's)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -40,12 +58,18 @@ def parse():
     return ap.parse_args()
 
 
-def make_batch(rank, B, npts, dev, index=0):
+def make_batch(rank, B, npts, dev, index=0, cfg=None):
     from uni3detr_amd.plugin.structures import Boxes3D
-    from uni3detr_amd.synth import room_scene
+    from uni3detr_amd.synth import SUNRGBD_RANGE, room_scene
+    rng_range = tuple(cfg["pts_voxel_layer"]["point_cloud_range"]) if cfg is not None else SUNRGBD_RANGE
+    nfeat = cfg["pts_middle_encoder"]["in_channels"] if cfg is not None else 4
+    ncls = cfg["pts_bbox_head"]["num_classes"] if cfg is not None else 10
     pts, gts, labels = [], [], []
     for i in range(B):
-        p, g, l = room_scene((index * 64 + rank) * B + i, npts)
+        p, g, l = room_scene((index * 64 + rank) * B + i, npts, pc_range=rng_range)
+        if nfeat > 4:                                    # nuScenes: (x, y, z, intensity, sweep time) - the two extras as zeros
+            p = np.concatenate([p, np.zeros((p.shape[0], nfeat - 4), np.float32)], 1)
+        l = l % ncls
         gb = torch.from_numpy(g).clone()
         gb[:, 2] -= gb[:, 5] / 2
         pts.append(torch.from_numpy(p).to(dev))
@@ -94,6 +118,9 @@ def cpu_baseline(npts, budget_s=25.0):
 
 def main():
     args = parse()
+    wl = WORKLOADS[args.config]
+    args.batch = wl["batch"] if args.batch is None else args.batch
+    args.points = wl["points"] if args.points is None else args.points
     import faulthandler
     # watchdog: a hung collective / kernel must not burn the whole GPU slot — dump all stacks and exit
     faulthandler.dump_traceback_later(int(os.environ.get("U3D_WATCHDOG_S", "900")), exit=True)
@@ -117,18 +144,18 @@ def main():
 
     import projects.mmdet3d_plugin  # noqa: F401
     from uni3detr_amd import native as nv
-    from uni3detr_amd.configs.sunrgbd import model as MODEL_CFG
     from uni3detr_amd.registry import build_model
+    MODEL_CFG = workload_cfg(args.config)
     nv.lib()                                            # fail loudly if the HIP library is absent
 
     torch.manual_seed(1234)
     model = build_model(MODEL_CFG).to(dev).train()      # constructor-default init == what the shipped flow trains from
     model.set_precision(args.precision)
     from uni3detr_amd.trainer import TrainStep
-    data = make_batch(rank, args.batch, args.points, dev)
+    data = make_batch(rank, args.batch, args.points, dev, cfg=MODEL_CFG)
     # the timed steps rotate through `--batches` distinct batches, resident in HBM and pre-packed; each step copies the next one into
     # the static input buffers (TrainStep.set_batch: device-to-device) - every sparse level sees changing row counts
-    rot = [data] + [make_batch(rank, args.batch, args.points, dev, index=j) for j in range(1, max(1, args.batches))]
+    rot = [data] + [make_batch(rank, args.batch, args.points, dev, index=j, cfg=MODEL_CFG) for j in range(1, max(1, args.batches))]
     # two-phase backward: for N > 1 the flat-gradient all-reduce of the head / decoder / dense-stack slice rides under the encoder's
     # backward; the split itself is free (25.34 vs 25.44 ms on one GPU), so N = 1 runs the same schedule
     overlap = os.environ.get("U3D_OVERLAP_REDUCE", "1") == "1"
@@ -232,14 +259,16 @@ def main():
         raise SystemExit(f"bench: training diverged (loss = {loss_val}) — a throughput number for a broken step would be meaningless")
 
     if rank == 0:
+        nq_cfg = int(MODEL_CFG["pts_bbox_head"]["num_query"])
         scenes = world * args.batch * args.steps
         out = {
-            "metric": "scenes/sec (fwd+bwd) SUN-RGB-D 20k pts, 300 queries", "value": scenes / dt, "unit": "scenes/s",
+            "metric": ("scenes/sec (fwd+bwd) SUN-RGB-D 20k pts, 300 queries" if args.config == "sunrgbd" else
+                       f"scenes/sec (fwd+bwd) {args.config} {args.points} pts, {nq_cfg} queries"), "value": scenes / dt, "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "uni3detr_sunrgbd.py (BASELINE configs[1]): train step fwd+loss+bwd+clip+AdamW, "
-                                   f"{args.batch} scenes/GPU x {args.points} pts, 300 queries x 3 groups, random-init weights",
+            "config": {"workload": f"{wl['file']} (BASELINE {wl['baseline']}): train step fwd+loss+bwd+clip+AdamW, "
+                                   f"{args.batch} scenes/GPU x {args.points} pts, {nq_cfg} queries x 3 groups, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss_val,
                        "launch_mode": launch_mode if launch_mode != "hipGraph" else (("hipGraph x4 (fwd+match | loss+bwd head/dense [all-reduce A overlaps] | bwd encoder | clip+AdamW)" if ts.overlap else "hipGraph x3 (fwd+match | loss+bwd | clip+AdamW)") + ", static-shape sparse levels"),
                        "sparse_level_capacities": caps, "rotating_batches": len(rot), "recaptures": int(getattr(ts, "recaptures", 0))},
@@ -319,7 +348,7 @@ def main():
             }
             if os.environ.get("U3D_BENCH_DUMP_CALLS"):
                 json.dump(calls, open(os.environ["U3D_BENCH_DUMP_CALLS"], "w"))
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.config == "sunrgbd":      # the CPU leg is quoted on the headline workload only
             faulthandler.cancel_dump_traceback_later()       # CPU leg: no GPU work can hang here
             out["cpu_baseline"] = cpu_baseline(args.points)
             if args.precision == "bf16":

@@ -199,6 +199,34 @@ def gen_decode(ns):
     print("coder_decode:", [int(out[f"s{si}_b0_scores"].shape[0]) for si in range(len(settings))])
 
 
+def gen_extra(ns):
+    """The registry names no shipped config selects, where the reference implements the arithmetic itself: get_rdiou
+    (core/bbox/util.py:104-153), RDIoUCost / SoftFocalLossCost (match_cost.py:69-128), RDIoULoss (rdiouloss.py:13-91)."""
+    rng = np.random.default_rng(SEED + 9)
+    Q, G, C = 40, 7, 10
+
+    def boxes(n):
+        return torch.from_numpy(np.concatenate([rng.uniform(-3, 3, (n, 3)), rng.normal(0, 0.6, (n, 3)), rng.uniform(-3.1, 3.1, (n, 1))], 1)
+                                .astype(np.float32))
+    p, g = boxes(Q), boxes(G)
+    p[0, 3] = 3.0                                             # exp(3) > 10: the clamp of the first box's extents
+    u, r = ns.util.get_rdiou(p.unsqueeze(1), g.unsqueeze(0))
+    cost = ns.match_cost.RDIoUCost(weight=1.7)(p, g)
+    cls = torch.from_numpy(rng.normal(-1, 2, (Q, C)).astype(np.float32))
+    labels = torch.from_numpy(rng.integers(0, C, G))
+    iou = torch.from_numpy(rng.uniform(0, 1, (Q, C)).astype(np.float32))
+    sfc = ns.match_cost.SoftFocalLossCost(weight=2.0)(cls, labels, iou)
+    a, b = boxes(Q), boxes(Q)
+    w = torch.from_numpy((rng.uniform(0, 1, (Q, 7)) < 0.6).astype(np.float32))
+    a.requires_grad_(True)
+    loss = ns.losses.RDIoULoss(loss_weight=1.2)(a, b, w, avg_factor=5.0)
+    loss.backward()
+    np.savez_compressed(os.path.join(OUT, "extra_costs.npz"), p=p.numpy(), g=g.numpy(), u=u.numpy(), rdiou=r.numpy(), rdiou_cost=cost.numpy(),
+                        cls=cls.numpy(), labels=labels.numpy(), iou=iou.numpy(), soft_focal_cost=sfc.numpy(), a=a.detach().numpy(), b=b.numpy(),
+                        w=w.numpy(), rdiou_loss=float(loss), rdiou_loss_grad=a.grad.numpy())
+    print("extra_costs:", tuple(cost.shape), float(loss))
+
+
 def main():
     if not rs.available():
         sys.exit("reference tree not available: goldens can only be generated in the build container")
@@ -209,6 +237,7 @@ def main():
     gen_head_eval(ns)
     gen_decode(ns)
     gen_head_variants(ns)
+    gen_extra(ns)
 
 
 if __name__ == "__main__":

@@ -325,8 +325,11 @@ def head_forward(sd, pre, pts_feats, fpsbpts, cfg, rand_points=None):
 # ==================================================================================================
 def normalize_bbox(b):
     rot = -b[..., 6:7] - math.pi / 2
-    return torch.cat([b[..., 0:1], b[..., 1:2], (b[..., 4:5] + 1e-5).log(), (b[..., 3:4] + 1e-5).log(), b[..., 2:3],
-                      (b[..., 5:6] + 1e-5).log(), rot.sin(), rot.cos()], -1)
+    cols = [b[..., 0:1], b[..., 1:2], (b[..., 4:5] + 1e-5).log(), (b[..., 3:4] + 1e-5).log(), b[..., 2:3],
+            (b[..., 5:6] + 1e-5).log(), rot.sin(), rot.cos()]
+    if b.shape[-1] > 7:                      # velocity pair appended as is (core/bbox/util.py:32-37)
+        cols += [b[..., 7:8], b[..., 8:9]]
+    return torch.cat(cols, -1)
 
 
 def denormalize_bbox(n):
@@ -341,8 +344,8 @@ def match_cost(cls_pred, bbox_pred, gt, labels, cfg):
     neg = -(1 - p + 1e-12).log() * (1 - a) * p.pow(g)
     pos = -(p + 1e-12).log() * a * (1 - p).pow(g)
     c_cls = (pos[:, labels] - neg[:, labels]) * cfg["cost_cls"]
-    c_reg = torch.cdist(bbox_pred[:, :8], normalize_bbox(gt)[:, :8], p=1) * cfg["cost_reg"]
-    c_iou = (1 - ob.bbox_overlaps_nearest_3d(denormalize_bbox(bbox_pred), gt)) * cfg["cost_iou"]
+    c_reg = torch.cdist(bbox_pred[:, :8], normalize_bbox(gt[:, :7])[:, :8], p=1) * cfg["cost_reg"]
+    c_iou = (1 - ob.bbox_overlaps_nearest_3d(denormalize_bbox(bbox_pred), gt[:, :7])) * cfg["cost_iou"]
     return c_cls + c_reg + c_iou
 
 
@@ -363,10 +366,15 @@ def assign(cls_pred, bbox_pred, gt, labels, cfg):
 
 
 def loss_single(cls, box, iou_pred, gts, labels, cfg):
-    """loss_single (uni3detr_head.py:617-698) for one decoder layer; world size 1."""
+    """loss_single (uni3detr_head.py:617-698) for one decoder layer; world size 1.
+    Target width: 7 columns, or 9 when the box code has 10 entries (nuScenes) - the reference's `[..., :7]` slice (:557) cannot
+    feed its own 10-column L1 (:684-687), so uni3detr_nuscenes.py does not train as shipped; this follows the commented-out upstream
+    `[..., :9]` line above it, with zero velocities for 7-column GT (same choice as the product: plugin/head.py gt_dim)."""
     B, Q, C = cls.shape
     lab_t = torch.full((B * Q,), C, dtype=torch.long)
-    tgt = torch.zeros(B * Q, 7)
+    gd = 9 if box.shape[-1] >= 10 else 7
+    gts = [F.pad(g[:, :gd], (0, gd - min(gd, g.shape[1]))) for g in gts]
+    tgt = torch.zeros(B * Q, gd)
     wgt = torch.zeros(B * Q, box.shape[-1])
     npos = 0
     assigned = []
@@ -407,7 +415,7 @@ def loss_single(cls, box, iou_pred, gts, labels, cfg):
     else:
         l_iou = b3d.sum() * wgt.sum()
     l_iou = l_iou + ((1 - iou_z) * wgt[:, 0]).sum() / npos_c
-    iou_true = ob.bbox_overlaps_3d_aligned(b3d.detach(), tgt)
+    iou_true = ob.bbox_overlaps_3d_aligned(b3d.detach(), tgt[:, :7])
     l_ioup = (F.binary_cross_entropy_with_logits(iou_pred.reshape(-1), iou_true, reduction="none") * wgt[:, 0]).sum() / npos_c * 1.2
     return (l_cls, l_box, l_iou, l_ioup), assigned
 

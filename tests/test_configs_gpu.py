@@ -1,6 +1,8 @@
 """GPU: the other shipped configurations (BASELINE.json configs[2..4]) build from the reference config files when present
 (else from restated key numbers), run one training step on scaled synthetic clouds and produce finite losses and gradients.
-nuScenes is shape-only for the forward (its loss path is inconsistent upstream: SURVEY.md App. D-15)."""
+nuScenes (BASELINE configs[4]: 2 scenes, 2700 training queries, code size 10) trains too: the reference's own target line slices to 7
+columns and cannot feed its 10-column L1, so the step follows the commented-out upstream `[..., :9]` semantics
+with zero velocities for 7-column GT (plugin/head.py gt_dim; oracle/model.py loss_single makes the same choice and pins it)."""
 import os
 
 import numpy as np
@@ -34,7 +36,8 @@ def _scene(i, n, rng_range, nfeat):
     return torch.from_numpy(p), gb, torch.from_numpy(l)
 
 
-@pytest.mark.parametrize("name,npts,bf16", [("kitti_3classes", 20000, True), ("scannet_large", 60000, True), ("sunrgbd", 20000, True)])
+@pytest.mark.parametrize("name,npts,bf16", [("kitti_3classes", 20000, True), ("scannet_large", 60000, True), ("sunrgbd", 20000, True),
+                                            ("nuscenes", 60000, True)])
 def test_config_trains_one_step(cuda, name, npts, bf16):
     cfg = _cfg(name)
     model = build_model(cfg).to(cuda).train()
@@ -131,7 +134,7 @@ def test_head_variants_match_reference_golden(cuda, name):
             assert abs(pg[str(k)] - ref) <= 2e-3 * max(ref, 1e-3) + 1e-5, (k, pg[str(k)], ref)
 
 
-@pytest.mark.parametrize("name,npts,with_loss", [("scannet_large", 100000, True), ("kitti_3classes", 18000, False), ("nuscenes", 250000, False)])
+@pytest.mark.parametrize("name,npts,with_loss", [("scannet_large", 100000, True), ("kitti_3classes", 18000, False), ("nuscenes", 250000, True)])
 def test_full_forward_matches_cpu_oracle_other_configs(cuda, name, npts, with_loss):
     """fp32 mode, ONE scene at the configuration's real point count (ScanNet-large ~100 k points, dynamic voxelization, 32-channel base /
     512-channel dense input; KITTI 18 000 sampled points; nuScenes 10 sweeps ~250 k points, 90 000-voxel cap, 2700 queries, code size

@@ -178,3 +178,31 @@ def test_checkpoint_round_trip_incl_spconv2_layout(tmp_path, spconv2):
     bad["pts_bbox_head.tgt_embed.weight"] = torch.zeros(5, 5)
     with pytest.raises(RuntimeError, match="shape mismatch"):
         load_checkpoint(b, dict(state_dict=bad))
+
+
+def test_unselected_registry_names_match_reference_goldens():
+    """RDIoULoss / RDIoUCost / SoftFocalLossCost / get_rdiou (no shipped config selects them) against vectors produced by the reference's
+    own files (oracle/make_golden.py gen_extra); AxisAlignedIoU3DCost / RotatedIoU3DCost build from the registry."""
+    import numpy as np
+    import torch
+    from uni3detr_amd.plugin import extra_costs as X
+    from uni3detr_amd.registry import LOSSES, MATCH_COST
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "extra_costs.npz"))
+    t = lambda k: torch.from_numpy(z[k])
+    u, r = X.get_rdiou(t("p").unsqueeze(1), t("g").unsqueeze(0))
+    assert torch.allclose(u, t("u"), rtol=1e-5, atol=1e-6) and torch.allclose(r, t("rdiou"), rtol=1e-5, atol=1e-7)
+    cost = MATCH_COST.build(dict(type="RDIoUCost", weight=1.7))(t("p"), t("g"))
+    assert torch.allclose(cost, t("rdiou_cost"), rtol=1e-5, atol=1e-6)
+    sfc = MATCH_COST.build(dict(type="SoftFocalLossCost", weight=2.0))(t("cls"), t("labels"), t("iou"))
+    assert torch.allclose(sfc, t("soft_focal_cost"), rtol=1e-5, atol=1e-6)
+    a = t("a").requires_grad_(True)
+    loss = LOSSES.build(dict(type="RDIoULoss", loss_weight=1.2))(a, t("b"), t("w"), avg_factor=5.0)
+    assert abs(float(loss) - float(z["rdiou_loss"])) <= 1e-5 * abs(float(z["rdiou_loss"]))
+    loss.backward()
+    assert torch.allclose(a.grad, t("rdiou_loss_grad"), rtol=1e-4, atol=1e-6)
+    # axis-aligned IoU cost: closed form on unit cubes shifted by half an edge -> IoU = 0.5 / 1.5
+    aa = MATCH_COST.build(dict(type="AxisAlignedIoU3DCost", weight=2.0))
+    b0 = torch.tensor([[0.0, 0, 0, 1, 1, 1]])
+    b1 = torch.tensor([[0.5, 0, 0, 1.5, 1, 1], [2.0, 2, 2, 3, 3, 3]])
+    assert torch.allclose(aa(b0, b1), torch.tensor([[-2.0 / 3.0, 0.0]]), atol=1e-6)
+    assert MATCH_COST.build(dict(type="RotatedIoU3DCost", weight=1.0)).weight == 1.0

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_pre(u3d_declayer_params P, u
   T* A1 = (T*)(lds + L::A1);
   T* A2 = (T*)(lds + L::A2);
   const int tid = threadIdx.x, lane = tid & 63, wave = dc_wave_id();
+  const int wv = (wave + (int)(blockIdx.x >> 3)) & 3;      // which 64 output columns this wave computes: rotated per workgroup (see dc_gemm)
   const int row0 = blockIdx.x * BM, M = dm.m;
   dc_poison_lds<E>(lds, tid);
   // sine embedding of the reference points -> A0 (ldk 384), saved for the first GEMM's weight gradient
@@ -211,30 +212,30 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_pre(u3d_declayer_params P, u
     return [=](int row, int col, f32x4 v) { *(V4*)(dst + dc_aoff<E>(row, col, DC_C)) = E::pack4(v + dc_bias4(bias, col)); };
   };
   T* A1b = A1 + BM * DC_C;
-  dc_linear<E, 384, 4>(A0, (const T*)P.w[U3D_DL_RPH0], wave * 64, lane, relu_to(A1, P.b[U3D_DL_RPH0]));
+  dc_linear<E, 384, 4>(A0, (const T*)P.w[U3D_DL_RPH0], wv * 64, lane, relu_to(A1, P.b[U3D_DL_RPH0]));
   __syncthreads();
   dc_store_a<E, 256>(A1, S.rph1, DC_C, row0, tid);
-  dc_linear<E, 256, 4>(A1, (const T*)P.w[U3D_DL_RPH1], wave * 64, lane, relu_to(A0, P.b[U3D_DL_RPH1]));
+  dc_linear<E, 256, 4>(A1, (const T*)P.w[U3D_DL_RPH1], wv * 64, lane, relu_to(A0, P.b[U3D_DL_RPH1]));
   __syncthreads();
   dc_store_a<E, 256>(A0, S.rph2, DC_C, row0, tid);
   // raw = ref_point_head's output -> A2; it is the position embedding itself in the first layer
-  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_RPH2], wave * 64, lane, lin_to(A2, P.b[U3D_DL_RPH2]));
+  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_RPH2], wv * 64, lane, lin_to(A2, P.b[U3D_DL_RPH2]));
   __syncthreads();
   dc_store_a<E, 256>(A2, dm.has_qs ? S.raw : S.pos, DC_C, row0, tid);
   dc_load_a<E, 256, true>(A0, xc, DC_C, row0, M, tid);           // x: input of query_scale and of the value projection
   __syncthreads();
   if (dm.has_qs) {
-    dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_QS0], wave * 64, lane, relu_to(A1, P.b[U3D_DL_QS0]));
+    dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_QS0], wv * 64, lane, relu_to(A1, P.b[U3D_DL_QS0]));
     __syncthreads();
     dc_store_a<E, 256>(A1, S.qs1, DC_C, row0, tid);
     // A0 still holds x (the value projection needs it): the second hidden layer goes to the second BM x 256 half of A1
-    dc_linear<E, 256, 4>(A1, (const T*)P.w[U3D_DL_QS1], wave * 64, lane, relu_to(A1b, P.b[U3D_DL_QS1]));
+    dc_linear<E, 256, 4>(A1, (const T*)P.w[U3D_DL_QS1], wv * 64, lane, relu_to(A1b, P.b[U3D_DL_QS1]));
     __syncthreads();
     dc_store_a<E, 256>(A1b, S.qs2, DC_C, row0, tid);
     const float* bias = P.b[U3D_DL_QS2];
     // pos = query_scale(x) * raw (both T tensors in the layer-by-layer formulation) -> A2 in place (same element, same lane);
     // the scale itself -> first half of A1 (free: its reader, the linear before, finished at the barrier)
-    dc_linear<E, 256, 4>(A1b, (const T*)P.w[U3D_DL_QS2], wave * 64, lane, [=](int row, int col, f32x4 v) {
+    dc_linear<E, 256, 4>(A1b, (const T*)P.w[U3D_DL_QS2], wv * 64, lane, [=](int row, int col, f32x4 v) {
       const V4 q = E::pack4(v + dc_bias4(bias, col));
       const int ao = dc_aoff<E>(row, col, DC_C);
       const f32x4 raw = E::unpack4(*(const V4*)(A2 + ao));
@@ -258,17 +259,17 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_pre(u3d_declayer_params P, u
   dc_store_a<E, 256>(A1b, S.qkin, DC_C, row0, tid);
   // in-projection: q = A1b . Wq^T + b -> A1, k -> A2 (pos is saved), v = A0 . Wv^T + b -> A1b; each block leaves for HBM from its tile
   // (the attention kernel regroups rows by (group, head))
-  dc_linear<E, 256, 4>(A1b, (const T*)P.w[U3D_DL_INQK], wave * 64, lane, lin_to(A1, P.b[U3D_DL_INQK]));
+  dc_linear<E, 256, 4>(A1b, (const T*)P.w[U3D_DL_INQK], wv * 64, lane, lin_to(A1, P.b[U3D_DL_INQK]));
   {
     const float* bias = P.b[U3D_DL_INQK];
-    dc_linear<E, 256, 4>(A1b, (const T*)P.w[U3D_DL_INQK], 256 + wave * 64, lane, [=](int row, int col, f32x4 v) {
+    dc_linear<E, 256, 4>(A1b, (const T*)P.w[U3D_DL_INQK], 256 + wv * 64, lane, [=](int row, int col, f32x4 v) {
       *(V4*)(A2 + dc_aoff<E>(row, col - 256, DC_C)) = E::pack4(v + dc_bias4(bias, col));
     });
   }
   __syncthreads();
   dc_store_a<E, 256>(A1, S.qk, 512, row0, tid);
   dc_store_a<E, 256>(A2, S.qk + 256, 512, row0, tid);
-  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_INV], wave * 64, lane, lin_to(A1b, P.b[U3D_DL_INV]));
+  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_INV], wv * 64, lane, lin_to(A1b, P.b[U3D_DL_INV]));
   __syncthreads();
   dc_store_a<E, 256>(A1b, S.v, DC_C, row0, tid);
 }
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post(u3d_declayer_params P, 
   float* G = (float*)(lds + L::G);
   float* misc = (float*)(lds + L::MISC);
   const int tid = threadIdx.x, lane = tid & 63, wave = dc_wave_id();
+  const int wv = (wave + (int)(blockIdx.x >> 3)) & 3;      // which 64 output columns this wave computes: rotated per workgroup (see dc_gemm)
   const int row0 = blockIdx.x * BM, M = dm.m;
   dc_poison_lds<E>(lds, tid);
   DcDrop drop = {dc_rng_load(rng), dc_thresh(dm.p_drop), dc_inv_keep(dm.p_drop), dm.layer};
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post(u3d_declayer_params P, 
     };
   };
   DC_MARK(1);
-  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_OUTP], wave * 64, lane, add_to_F(P.b[U3D_DL_OUTP], 0));
+  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_OUTP], wv * 64, lane, add_to_F(P.b[U3D_DL_OUTP], 0));
   __syncthreads();
   DC_MARK(2);
   {
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post(u3d_declayer_params P, 
   }
   __syncthreads();
   DC_MARK(5);
-  dc_linear<E, 256, 4>(A1, (const T*)P.w[U3D_DL_OPROJ], wave * 64, lane, add_to_F(P.b[U3D_DL_OPROJ], 1));
+  dc_linear<E, 256, 4>(A1, (const T*)P.w[U3D_DL_OPROJ], wv * 64, lane, add_to_F(P.b[U3D_DL_OPROJ], 1));
   {
     DcLnOut<E> o = {nullptr, A0, DC_C, nullptr, S.peh0, S.mr, U3D_DLN_PE0, false, nullptr, nullptr};
     dc_layernorm<E>(G, P.ln_g[U3D_DLN_PE0], P.ln_b[U3D_DLN_PE0], dm.ln_eps, true, o, row0, wave, lane);   // overwrites A0 (x1: no longer needed)
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post(u3d_declayer_params P, 
   DC_MARK(6);
   {
     const float* bias = P.b[U3D_DL_PE1];
-    dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_PE1], wave * 64, lane, [=](int row, int col, f32x4 v) {
+    dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_PE1], wv * 64, lane, [=](int row, int col, f32x4 v) {
       *(f32x4*)(G + row * DC_TS + col) = E::round4(v + dc_bias4(bias, col));       // saved by the LayerNorm below (its input rows)
     });
   }
@@ -542,13 +544,13 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post(u3d_declayer_params P, 
       const V4 hb = E::pack4(drop.apply(v, 2, (unsigned)((row0 + row) * DC_FF + col)));
       *(V4*)(A1 + dc_aoff<E>(row, col, DC_FF)) = hb;
     };
-    dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_FFN0], wave * 64, lane, ffh);
-    dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_FFN0], 256 + wave * 64, lane, ffh);
+    dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_FFN0], wv * 64, lane, ffh);
+    dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_FFN0], 256 + wv * 64, lane, ffh);
   }
   __syncthreads();
   DC_MARK(10);
   dc_store_a<E, 512>(A1, S.ffh, DC_FF, row0, tid);
-  dc_linear<E, 512, 4>(A1, (const T*)P.w[U3D_DL_FFN1], wave * 64, lane, add_to_F(P.b[U3D_DL_FFN1], 3));
+  dc_linear<E, 512, 4>(A1, (const T*)P.w[U3D_DL_FFN1], wv * 64, lane, add_to_F(P.b[U3D_DL_FFN1], 3));
   __syncthreads();
   DC_MARK(11);
   {
@@ -579,54 +581,54 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post(u3d_declayer_params P, 
     for (int mt = 0; mt < E::MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    dc_gemm<E, 256, 4>(A2, (const T*)P.w[U3D_DL_REG0] + (size_t)(wave * 64) * 256, acc, lane);
+    dc_gemm<E, 256, 4>(A2, (const T*)P.w[U3D_DL_REG0] + (size_t)(wv * 64) * 256, acc, lane);
     __builtin_amdgcn_sched_barrier(0);
     DC_MARK(21);
     auto epi = relu_to(A0, P.b[U3D_DL_REG0]);
 #pragma unroll
     for (int mt = 0; mt < E::MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) epi(mt * 16 + (lane & 15), wave * 64 + nt * 16 + (lane >> 4) * 4, acc[mt][nt]);
+      for (int nt = 0; nt < 4; ++nt) epi(mt * 16 + (lane & 15), wv * 64 + nt * 16 + (lane >> 4) * 4, acc[mt][nt]);
     __builtin_amdgcn_sched_barrier(0);
     DC_MARK(22);
     __syncthreads();
     DC_MARK(23);
   }
 #else
-  dc_linear<E, 256, 4>(A2, (const T*)P.w[U3D_DL_REG0], wave * 64, lane, relu_to(A0, P.b[U3D_DL_REG0]));
+  dc_linear<E, 256, 4>(A2, (const T*)P.w[U3D_DL_REG0], wv * 64, lane, relu_to(A0, P.b[U3D_DL_REG0]));
   __syncthreads();
 #endif
   dc_store_a<E, 256>(A0, S.r1, DC_C, row0, tid);
-  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_REG1], wave * 64, lane, relu_to(A1, P.b[U3D_DL_REG1]));
+  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_REG1], wv * 64, lane, relu_to(A1, P.b[U3D_DL_REG1]));
   __syncthreads();
   dc_store_a<E, 256>(A1, S.r2, DC_C, row0, tid);
-  dc_linear<E, 256, 1>(A1, (const T*)P.w[U3D_DL_REG2], wave * 16, lane, narrow_out(reg_out, dm.code, P.b[U3D_DL_REG2]));
-  dc_linear<E, 256, 4>(A2, (const T*)P.w[U3D_DL_IOU0], wave * 64, lane, relu_to(A0, P.b[U3D_DL_IOU0]));
+  dc_linear<E, 256, 1>(A1, (const T*)P.w[U3D_DL_REG2], wv * 16, lane, narrow_out(reg_out, dm.code, P.b[U3D_DL_REG2]));
+  dc_linear<E, 256, 4>(A2, (const T*)P.w[U3D_DL_IOU0], wv * 64, lane, relu_to(A0, P.b[U3D_DL_IOU0]));
   __syncthreads();
   dc_store_a<E, 256>(A0, S.i1, DC_C, row0, tid);
-  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_IOU1], wave * 64, lane, relu_to(A1b, P.b[U3D_DL_IOU1]));
+  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_IOU1], wv * 64, lane, relu_to(A1b, P.b[U3D_DL_IOU1]));
   __syncthreads();
   dc_store_a<E, 256>(A1b, S.i2, DC_C, row0, tid);
-  dc_linear<E, 256, 1>(A1b, (const T*)P.w[U3D_DL_IOU2], wave * 16, lane, narrow_out(iou_out, 1, P.b[U3D_DL_IOU2]));
+  dc_linear<E, 256, 1>(A1b, (const T*)P.w[U3D_DL_IOU2], wv * 16, lane, narrow_out(iou_out, 1, P.b[U3D_DL_IOU2]));
   // cls: Linear -> LN -> ReLU twice, then the class logits (each linear's output is saved by the LayerNorm that reads it)
   auto to_G = [&](const float* bias) {
     return [=](int row, int col, f32x4 v) { *(f32x4*)(G + row * DC_TS + col) = E::round4(v + dc_bias4(bias, col)); };
   };
-  dc_linear<E, 256, 4>(A2, (const T*)P.w[U3D_DL_CLS0], wave * 64, lane, to_G(P.b[U3D_DL_CLS0]));
+  dc_linear<E, 256, 4>(A2, (const T*)P.w[U3D_DL_CLS0], wv * 64, lane, to_G(P.b[U3D_DL_CLS0]));
   __syncthreads();
   {
     DcLnOut<E> o = {nullptr, A0, DC_C, nullptr, S.c1, S.mr, U3D_DLN_C1, false, nullptr, S.uc1};
     dc_layernorm<E>(G, P.ln_g[U3D_DLN_C1], P.ln_b[U3D_DLN_C1], dm.ln_eps, true, o, row0, wave, lane);
   }
   __syncthreads();
-  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_CLS1], wave * 64, lane, to_G(P.b[U3D_DL_CLS1]));
+  dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_CLS1], wv * 64, lane, to_G(P.b[U3D_DL_CLS1]));
   __syncthreads();
   {
     DcLnOut<E> o = {nullptr, A1, DC_C, nullptr, S.c2, S.mr, U3D_DLN_C2, false, nullptr, S.uc2};
     dc_layernorm<E>(G, P.ln_g[U3D_DLN_C2], P.ln_b[U3D_DLN_C2], dm.ln_eps, true, o, row0, wave, lane);
   }
   __syncthreads();
-  dc_linear<E, 256, 1>(A1, (const T*)P.w[U3D_DL_CLS2], wave * 16, lane, narrow_out(cls_out, dm.ncls, P.b[U3D_DL_CLS2]));
+  dc_linear<E, 256, 1>(A1, (const T*)P.w[U3D_DL_CLS2], wv * 16, lane, narrow_out(cls_out, dm.ncls, P.b[U3D_DL_CLS2]));
   DC_MARK(14);
 }
 

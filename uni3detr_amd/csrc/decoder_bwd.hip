@@ -169,6 +169,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
   T* Dn = A2;
   static_assert(BM * NLD <= BM * DC_C, "narrow-gradient tile must fit the A2 region");
   const int tid = threadIdx.x, lane = tid & 63, wave = dc_wave_id();
+  const int wv = (wave + (int)(blockIdx.x >> 3)) & 3;      // which 64 output columns this wave computes: rotated per workgroup (see dc_gemm)
   const int row0 = blockIdx.x * BM, M = dm.m, nb = Gd.nb;
   dc_poison_lds<E>(lds, tid);
   DcDrop drop = {dc_rng_load(rng), dc_thresh(dm.p_drop), dc_inv_keep(dm.p_drop), dm.layer};
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
       for (int mt = 0; mt < E::MT; ++mt) a[mt] = *(const VC*)(Dn + (mt * 16 + r16) * NLD + (ks * 4 + kq) * E::CH);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const VC wf = *(const VC*)(wt + (size_t)((wave * 4 + nt) * KSN + ks) * WBLK + lane * E::CH);
+        const VC wf = *(const VC*)(wt + (size_t)((wv * 4 + nt) * KSN + ks) * WBLK + lane * E::CH);
 #pragma unroll
         for (int mt = 0; mt < E::MT; ++mt) E::mma(wf, a[mt], acc[mt][nt]);
       }
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
     for (int mt = 0; mt < E::MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const int row = mt * 16 + r16, col = wave * 64 + nt * 16 + kq * 4;
+        const int row = mt * 16 + r16, col = wv * 64 + nt * 16 + kq * 4;
         f32x4 v = acc[mt][nt];
         if (mask_src) {
           const V4 y = *(const V4*)(mask_src + (size_t)(row0 + row) * DC_C + col);
@@ -267,14 +268,14 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
     dc_layernorm_bwd<E>(G, u_elem(S.uc2), S.mr, U3D_DLN_C2, P.ln_g[U3D_DLN_C2], P.ln_b[U3D_DLN_C2], true, o, Gd.lnp, U3D_DLN_C2, nb, red, row0,
                         wave, lane, tid);
   }
-  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_CLS1], wave * 64, lane, to_G());
+  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_CLS1], wv * 64, lane, to_G());
   __syncthreads();
   {
     DcLnBwdOut<E> o = {nullptr, A0, Gd.c1u};
     dc_layernorm_bwd<E>(G, u_elem(S.uc1), S.mr, U3D_DLN_C1, P.ln_g[U3D_DLN_C1], P.ln_b[U3D_DLN_C1], true, o, Gd.lnp, U3D_DLN_C1, nb, red, row0,
                         wave, lane, tid);
   }
-  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_CLS0], wave * 64, lane, acc_to_F());
+  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_CLS0], wv * 64, lane, acc_to_F());
   __syncthreads();
   DC_MARK(2);
   // ---- iou branch ----------------------------------------------------------------------------------------------------------
@@ -283,10 +284,10 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
   narrow_dgrad((const T*)P.wt[U3D_DL_IOU2], S.i2, A0);
   __syncthreads();
   dc_store_a<E, 256>(A0, Gd.i2, DC_C, row0, tid);
-  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_IOU1], wave * 64, lane, masked_to(A1, S.i1));
+  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_IOU1], wv * 64, lane, masked_to(A1, S.i1));
   __syncthreads();
   dc_store_a<E, 256>(A1, Gd.i1, DC_C, row0, tid);
-  dc_linear<E, 256, 4>(A1, (const T*)P.wt[U3D_DL_IOU0], wave * 64, lane, acc_to_F());
+  dc_linear<E, 256, 4>(A1, (const T*)P.wt[U3D_DL_IOU0], wv * 64, lane, acc_to_F());
   __syncthreads();
   DC_MARK(3);
   // ---- reg branch ----------------------------------------------------------------------------------------------------------
@@ -295,10 +296,10 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
   narrow_dgrad((const T*)P.wt[U3D_DL_REG2], S.r2, A0);
   __syncthreads();
   dc_store_a<E, 256>(A0, Gd.r2, DC_C, row0, tid);
-  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_REG1], wave * 64, lane, masked_to(A1, S.r1));
+  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_REG1], wv * 64, lane, masked_to(A1, S.r1));
   __syncthreads();
   dc_store_a<E, 256>(A1, Gd.r1, DC_C, row0, tid);
-  dc_linear<E, 256, 4>(A1, (const T*)P.wt[U3D_DL_REG0], wave * 64, lane, acc_to_F());
+  dc_linear<E, 256, 4>(A1, (const T*)P.wt[U3D_DL_REG0], wv * 64, lane, acc_to_F());
   __syncthreads();
   DC_MARK(4);
   // ---- LN3 -> du3 (F) -------------------------------------------------------------------------------------------------------
@@ -331,12 +332,12 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
       const V4 o = E::pack4(v);
       *(V4*)(A1 + dc_aoff<E>(row, col, DC_FF)) = o;
     };
-    dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_FFN1], wave * 64, lane, dh);
-    dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_FFN1], 256 + wave * 64, lane, dh);
+    dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_FFN1], wv * 64, lane, dh);
+    dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_FFN1], 256 + wv * 64, lane, dh);
   }
   __syncthreads();
   dc_store_a<E, 512>(A1, Gd.ffh, DC_FF, row0, tid);
-  dc_linear<E, 512, 4>(A1, (const T*)P.wt[U3D_DL_FFN0], wave * 64, lane, acc_to_F());
+  dc_linear<E, 512, 4>(A1, (const T*)P.wt[U3D_DL_FFN0], wv * 64, lane, acc_to_F());
   __syncthreads();
   DC_MARK(6);
   // ---- LN2 -> du2 (F) -------------------------------------------------------------------------------------------------------
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
     dc_layernorm_bwd<E>(G, u_elem(S.upe1), S.mr, U3D_DLN_PE1, P.ln_g[U3D_DLN_PE1], P.ln_b[U3D_DLN_PE1], true, o, Gd.lnp, U3D_DLN_PE1, nb, red,
                         row0, wave, lane, tid);
   }
-  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_PE1], wave * 64, lane, to_G());
+  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_PE1], wv * 64, lane, to_G());
   __syncthreads();
   {
     // the first position-encoder layer's output is recomputed from the reference point (3 -> 256)
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
   // ---- output_proj, gate, trilinear scatter ------------------------------------------------------------------------------------
   branch_grad(1, A0, Gd.out);
   __syncthreads();
-  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_OPROJ], wave * 64, lane, to_G());      // d(gated) (T tensor)
+  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_OPROJ], wv * 64, lane, to_G());      // d(gated) (T tensor)
   __syncthreads();
   DC_MARK(9);
   {
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
   dc_store_f<E>(F, Gd.du1, row0, tid);
   branch_grad(0, A0, Gd.o2);
   __syncthreads();
-  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_OUTP], wave * 64, lane, [=](int row, int col, f32x4 v) {
+  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_OUTP], wv * 64, lane, [=](int row, int col, f32x4 v) {
     *(V4*)(A1 + dc_aoff<E>(row, col, DC_C)) = E::pack4(v);              // A1 is free by now: d(attention output) leaves from the tile
   });
   __syncthreads();
@@ -684,6 +685,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_pre_bwd(u3d_declayer_params 
   float* F = (float*)(lds + L::F);
   float* G = (float*)(lds + L::G);
   const int tid = threadIdx.x, lane = tid & 63, wave = dc_wave_id();
+  const int wv = (wave + (int)(blockIdx.x >> 3)) & 3;      // which 64 output columns this wave computes: rotated per workgroup (see dc_gemm)
   const int row0 = blockIdx.x * BM, M = dm.m;
   dc_poison_lds<E>(lds, tid);
 
@@ -708,9 +710,9 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_pre_bwd(u3d_declayer_params 
     };
   };
   // gradient w.r.t. the q = k input (x + pos) -> G; it reaches x (F) and pos
-  dc_linear<E, 512, 4>(A1, (const T*)P.wt[U3D_DL_INQK], wave * 64, lane,
+  dc_linear<E, 512, 4>(A1, (const T*)P.wt[U3D_DL_INQK], wv * 64, lane,
                        [=](int row, int col, f32x4 v) { *(f32x4*)(G + row * DC_TS + col) = E::round4(v); });
-  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_INV], wave * 64, lane, acc_to_F());
+  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_INV], wv * 64, lane, acc_to_F());
   __syncthreads();
   // dpos = d(q=k input) + gate path (post kernel); x gets d(q=k input) too.  d(raw), d(query_scale output) by the product rule.
   DC_FOR_TID(c, BM * 64) {
@@ -737,25 +739,25 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_pre_bwd(u3d_declayer_params 
   __syncthreads();
   T* A1b = A1 + BM * DC_C;
   if (dm.has_qs) {
-    dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_QS2], wave * 64, lane, masked_to(A1, S.qs2));
+    dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_QS2], wv * 64, lane, masked_to(A1, S.qs2));
     __syncthreads();
     dc_store_a<E, 256>(A1, Gd.qs2, DC_C, row0, tid);
-    dc_linear<E, 256, 4>(A1, (const T*)P.wt[U3D_DL_QS1], wave * 64, lane, masked_to(A1b, S.qs1));
+    dc_linear<E, 256, 4>(A1, (const T*)P.wt[U3D_DL_QS1], wv * 64, lane, masked_to(A1b, S.qs1));
     __syncthreads();
     dc_store_a<E, 256>(A1b, Gd.qs1, DC_C, row0, tid);
-    dc_linear<E, 256, 4>(A1b, (const T*)P.wt[U3D_DL_QS0], wave * 64, lane, acc_to_F());
+    dc_linear<E, 256, 4>(A1b, (const T*)P.wt[U3D_DL_QS0], wv * 64, lane, acc_to_F());
     __syncthreads();
   }
-  dc_linear<E, 256, 4>(A2, (const T*)P.wt[U3D_DL_RPH2], wave * 64, lane, masked_to(A0, S.rph2));
+  dc_linear<E, 256, 4>(A2, (const T*)P.wt[U3D_DL_RPH2], wv * 64, lane, masked_to(A0, S.rph2));
   __syncthreads();
   dc_store_a<E, 256>(A0, Gd.rph2, DC_C, row0, tid);
-  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_RPH1], wave * 64, lane, masked_to(A1, S.rph1));
+  dc_linear<E, 256, 4>(A0, (const T*)P.wt[U3D_DL_RPH1], wv * 64, lane, masked_to(A1, S.rph1));
   __syncthreads();
   dc_store_a<E, 256>(A1, Gd.rph1, DC_C, row0, tid);
   if (dm.need_dref) {      // gradient w.r.t. the sine embedding [BM][384] -> slot (u3d_sine_embed_bwd turns it into d(logits))
     auto to_sine = [=](int row, int col, f32x4 v) { *(V4*)(Gd.sine + (size_t)(row0 + row) * 384 + col) = E::pack4(v); };
-    dc_linear<E, 256, 4>(A1, (const T*)P.wt[U3D_DL_RPH0], wave * 64, lane, to_sine);
-    dc_linear<E, 256, 2>(A1, (const T*)P.wt[U3D_DL_RPH0], 256 + wave * 32, lane, to_sine);
+    dc_linear<E, 256, 4>(A1, (const T*)P.wt[U3D_DL_RPH0], wv * 64, lane, to_sine);
+    dc_linear<E, 256, 2>(A1, (const T*)P.wt[U3D_DL_RPH0], 256 + wv * 32, lane, to_sine);
   }
   dc_store_f<E>(F, dx, row0, tid);
 }

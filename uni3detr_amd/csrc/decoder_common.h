@@ -201,17 +201,30 @@ __device__ __forceinline__ void dc_gemm(const typename E::T* A, const typename E
   const T* ap[E::MT];
 #pragma unroll
   for (int mt = 0; mt < E::MT; ++mt) ap[mt] = A + (mt * 16 + r16) * K;
+  // k-steps are walked from a per-workgroup starting point: every workgroup of a launch streams the SAME weight matrix at about the
+  // same time, and in lock step they all queue on the one or two L2 channels that hold the current lines
+#ifndef DC_NO_KROT
+  const int rot = (int)(blockIdx.x % KS);
+#else
+  const int rot = 0;
+#endif
 #pragma unroll
   for (int kb = 0; kb < KS; kb += PF) {
     VC wf[PF][NT];
+    int kk[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      kk[p] = kb + p + rot;
+      kk[p] = kk[p] >= KS ? kk[p] - KS : kk[p];
+    }
 #pragma unroll
     for (int p = 0; p < PF; ++p)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wf[p][nt] = *(const VC*)(wp[nt] + (kb + p) * WBLK);
+      for (int nt = 0; nt < NT; ++nt) wf[p][nt] = *(const VC*)(wp[nt] + kk[p] * WBLK);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      const int ch = (((kb + p) * 4 + kq) ^ r16) * E::CH;
+      const int ch = ((kk[p] * 4 + kq) ^ r16) * E::CH;
       VC a[E::MT];
 #pragma unroll
       for (int mt = 0; mt < E::MT; ++mt) a[mt] = *(const VC*)(ap[mt] + ch);

@@ -212,22 +212,36 @@ class Uni3DETRHead(nn.Module):
         return torch.stack((b[..., 0] - b[..., 3] / 2, b[..., 1] - b[..., 4] / 2, b[..., 2] - b[..., 5] / 2,
                             b[..., 0] + b[..., 3] / 2, b[..., 1] + b[..., 4] / 2, b[..., 2] + b[..., 5] / 2), dim=-1)
 
+    @property
+    def gt_dim(self):
+        """Columns of a regression target: 7 (x, y, z, dx, dy, dz, yaw), or 9 with the velocity pair when the box code has 10 entries
+        (nuScenes).  The reference slices its targets to 7 columns (`zeros_like(bbox_pred)[..., :7]`, uni3detr_head.py:557; the
+        upstream `[..., :9]` line sits commented out right above it) and then feeds them to a 10-column L1 loss and a 10-entry
+        code_weights vector (uni3detr_head.py:684-687) - with code_size 10 that is a shape error for 7- and 9-column GT alike, i.e.
+        uni3detr_nuscenes.py does not train as shipped.  The target here is as wide as the code asks (the upstream DETR3D semantics the
+        file derives from); 7-column GT gets zero velocities."""
+        return 9 if int(self.code_size) >= 10 else 7
+
     def _pack_gts(self, gt_bboxes_list, gt_labels_list, device):
-        if isinstance(gt_bboxes_list, dict):       # pre-packed static buffers: dict(gt [cap,7] gravity-centre, labels int32 [cap], gt_off int32 [B+1], gmax int)
+        if isinstance(gt_bboxes_list, dict):       # pre-packed static buffers: dict(gt [cap,gt_dim] gravity-centre, labels int32 [cap], gt_off int32 [B+1], gmax int)
             d = gt_bboxes_list
             return d["gt"], d["labels"], d["gt_off"], int(d["gmax"])
+        gd = self.gt_dim
         gts = []
         for g in gt_bboxes_list:
             if hasattr(g, "gravity_center"):
                 g = torch.cat((g.gravity_center, g.tensor[:, 3:]), dim=1)
-            gts.append(g.to(device=device, dtype=torch.float32))
+            g = g.to(device=device, dtype=torch.float32)[:, :gd]
+            if g.shape[1] < gd:
+                g = torch.nn.functional.pad(g, (0, gd - g.shape[1]))
+            gts.append(g)
         lens = [int(g.shape[0]) for g in gts]
         off = [0]
         for n in lens:
             off.append(off[-1] + n)
-        gt = torch.cat(gts) if sum(lens) else torch.zeros((0, 7), device=device)
+        gt = torch.cat(gts) if sum(lens) else torch.zeros((0, gd), device=device)
         labels = torch.cat([l.to(device) for l in gt_labels_list]).int() if sum(lens) else torch.zeros((0,), dtype=torch.int32, device=device)
-        return gt[:, :7].contiguous(), labels.contiguous(), torch.tensor(off, dtype=torch.int32, device=device), max(lens) if lens else 0
+        return gt.contiguous(), labels.contiguous(), torch.tensor(off, dtype=torch.int32, device=device), max(lens) if lens else 0
 
     def pack_gts(self, gt_bboxes_list, gt_labels_list, device):
         """Pack a batch's GTs once (static input buffers for hipGraph replay); pass the result as `gt_bboxes_3d`."""
@@ -242,7 +256,8 @@ class Uni3DETRHead(nn.Module):
         L, B, Q, C = cls_all.shape
         dev = cls_all.device
         gt, labels, gt_off, gmax = self._pack_gts(gt_bboxes_list, gt_labels_list, dev)
-        asg = self.assigner.assign_batched(cls_all, box_all, gt, labels, gt_off, gmax, self.num_query).long()   # [L,B,Q]
+        gt7 = gt if gt.shape[1] == 7 else gt[:, :7].contiguous()          # matching sees the 7 geometric columns (ref: match_cost.py:19-30, 91-97)
+        asg = self.assigner.assign_batched(cls_all, box_all, gt7, labels, gt_off, gmax, self.num_query).long()   # [L,B,Q]
         pos = asg > 0
         w = pos.to(torch.float32)
         if gt.shape[0]:
@@ -250,7 +265,7 @@ class Uni3DETRHead(nn.Module):
             tgt = gt[gidx] * w.unsqueeze(-1)                                           # zeros for background rows
             lab = torch.where(pos, labels.long()[gidx], torch.full_like(asg, C))
         else:
-            tgt = box_all.new_zeros((L, B, Q, 7))
+            tgt = box_all.new_zeros((L, B, Q, gt.shape[1]))
             lab = torch.full_like(asg, C)
         return dict(asg=asg, w=w, tgt=tgt, lab=lab, num_pos=layer_sums(w))
 
