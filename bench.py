@@ -325,15 +325,34 @@ def main():
                 ach, peak, unit, bound = h["flops"] / (h["ms"] * 1e-3) / 1e12, peak_tf, "TFLOP/s", "mfma"
             else:
                 ach, peak, unit, bound = h["bytes"] / (h["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
-            traffic = None
+            # HBM bytes per launch from the PMC passes of THIS build (profiles/pmc_traffic.json, tools/pmc_step.sh + pmc_to_json.py):
+            # the entry must name the launched symbol at the launched grid and come from the same kernel source, else null
+            is_wgrad = "wgrad" in h["tag"]
+            sym = (("k_igemm_wgrad_glds8_256" if is_wgrad else "k_igemm_glds8_256x256") if h.get("v2") else
+                   ("k_spconv_wgrad" if is_wgrad else "k_spconv_fwd"))
+            traffic, traffic_note, pmc = None, None, None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(out["dtype"], {}).get("heaviest_launch_hbm_bytes")
+                import hashlib
+                pmc = json.load(open(tpath))
+                srcf = os.path.join(ROOT, "uni3detr_amd", "csrc", "igemm_bf16.hip")
+                cur = hashlib.sha256(open(srcf, "rb").read()).hexdigest()[:16] if os.path.exists(srcf) else None
+                grid = (-(-h["n_out"] // 256)) * (-(-h["cout"] // 256)) * 512
+                ent = pmc.get("kernels", {}).get(f"{sym}@{grid}") if not is_wgrad else None
+                if is_wgrad:
+                    cands = [v for k, v in pmc.get("kernels", {}).items() if k.startswith(sym + "@") and "hbm_read_bytes" in v]
+                    ent = max(cands, key=lambda v: v["hbm_read_bytes"]) if cands else None
+                if pmc.get("source_sha16", {}).get("igemm_bf16.hip") != cur:
+                    traffic_note = "profiles/pmc_traffic.json was taken on a different igemm_bf16.hip: refused"
+                elif ent is None or "hbm_read_bytes" not in ent or "hbm_write_bytes" not in ent:
+                    traffic_note = f"no counter entry for {sym}"
+                else:
+                    traffic = ent["hbm_read_bytes"] + ent["hbm_write_bytes"]
+                    traffic_note = f"{pmc.get('tag')}: {sym}, FETCH_SIZE x 2 + WRITE_SIZE per launch, L2 hit {ent.get('l2_hit_rate')}"
             out["roofline"] = {
-                "kernel": (("k_igemm_wgrad_glds" if "wgrad" in h["tag"] else "k_igemm_glds") if h.get("v2") else
-                           ("k_spconv_wgrad" if "wgrad" in h["tag"] else "k_spconv_fwd")) + f" [{h['tag']}, {h['kind']} lattice, N={h['n_out']}, "
+                "kernel": sym + f" [{h['tag']}, {h['kind']} lattice, N={h['n_out']}, "
                           f"Cin={h['cin']}, Cout={h['cout']}, K={h['kvol']}, pairs={h['pairs']}]",
-                "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
+                "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_note,
                 "launch_ms": h["ms"], "launch_timing": timing,
                 "frac_slowest_marked_launch": (h["flops"] / (slowest_ms * 1e-3) / 1e12 / peak if bound == "mfma" else None),
                 "frac_mean_of_heaviest_launches": (float(np.mean([h["flops"] / (ms * 1e-3) / 1e12 for ms in mark_ms.values()])) / peak if mark_ms else None),
@@ -346,6 +365,24 @@ def main():
                 "dense_stack_convs": agg(lambda x: x["kind"] == "dense"),
                 "hbm_peak_GBps": HBM_PEAK_GBS,
             }
+            # the north_star's two named fractions, first-class: SubMConv3d forward vs the HBM roofline (algorithmic bytes / time of the
+            # 27-offset submanifold launches, from this run's per-launch events) and the decoder attention kernels' MFMA utilisation
+            # (counter-side: profiles/pmc_traffic.json of this build; null when no current counter pass exists)
+            sub = out["roofline"]["submconv3d_sparse_fwd"]
+            out["roofline"]["submconv3d_hbm_frac"] = sub["GBps"] / HBM_PEAK_GBS if sub["ms_per_step"] else None
+            dec_src = None
+            if pmc is not None:
+                import hashlib
+                ok = all(pmc.get("source_sha16", {}).get(f) == hashlib.sha256(open(os.path.join(ROOT, "uni3detr_amd", "csrc", f), "rb").read()).hexdigest()[:16]
+                         for f in ("decoder.hip", "decoder_bwd.hip", "decoder_common.h"))
+                att = {k.split("@")[0]: v.get("mfma_util") for k, v in pmc.get("kernels", {}).items() if k.startswith("k_mha_")}
+                if ok and att:
+                    out["roofline"]["decoder_attention_mfma_util"] = att
+                    dec_src = pmc.get("tag")
+                    rowk = {k.split("@")[0]: v.get("mfma_util") for k, v in pmc.get("kernels", {}).items() if k.startswith("k_dec_")}
+                    out["roofline"]["decoder_row_kernels_mfma_util"] = rowk
+            if dec_src is None:
+                out["roofline"]["decoder_attention_mfma_util"] = None
             if os.environ.get("U3D_BENCH_DUMP_CALLS"):
                 json.dump(calls, open(os.environ["U3D_BENCH_DUMP_CALLS"], "w"))
         if not args.no_cpu_baseline and world == 1 and args.config == "sunrgbd":      # the CPU leg is quoted on the headline workload only

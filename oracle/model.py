@@ -392,7 +392,7 @@ def loss_single(cls, box, iou_pred, gts, labels, cfg):
     box = box.reshape(-1, box.shape[-1])
     ntgt = normalize_bbox(tgt)
     b3d = denormalize_bbox(box)
-    iou_bev = ob.bbox_overlaps_nearest_3d(b3d, tgt, is_aligned=True)
+    iou_bev = ob.bbox_overlaps_nearest_3d(b3d, tgt[:, :7], is_aligned=True)
     z1, z2 = b3d[:, 2] - b3d[:, 5] / 2, b3d[:, 2] + b3d[:, 5] / 2
     z3, z4 = tgt[:, 2] - tgt[:, 5] / 2, tgt[:, 2] + tgt[:, 5] / 2
     iou_z = torch.max(torch.min(z2, z4) - torch.max(z1, z3), torch.zeros_like(z1)) / (torch.max(z2, z4) - torch.min(z1, z3))
