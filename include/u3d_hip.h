@@ -575,8 +575,9 @@ int32_t u3d_wpack_bf16(const u3d_wpack_desc* descs_dev, int32_t count, int32_t m
 /* dtype U3D_F32: the same copies in f32 (zero-padded rows / transposes of the f32 masters) for the parity-mode instantiation */
 int32_t u3d_wpack(const u3d_wpack_desc* descs_dev, int32_t count, int32_t max_elems, int32_t dtype, u3d_stream s);
 /* keep-mask of the layer's dropout sites as bytes (testing aid): site 0..3 = out_proj, output_proj, FFN hidden, FFN out over
- * [m, cols]; site 4 = attention weights over [m*8, nq] (row = (group*8 + head)*nq + query). */
-int32_t u3d_dropout_mask(const uint64_t* rng, int32_t layer, int32_t site, int64_t n, float p, uint8_t* keep, u3d_stream s);
+ * [m, 256 | 512], linear element index (cols = 0); site 4 = attention weights over [m*8, nq] (row = (group*8 + head)*nq + query):
+ * pass cols = nq (rows are padded to an even length in the generator's index space).  p is honoured to 2^-16. */
+int32_t u3d_dropout_mask(const uint64_t* rng, int32_t layer, int32_t site, int64_t n, float p, int32_t cols, uint8_t* keep, u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * On-device training data path.  Replaces, for a packed batch that already sits in HBM, the DataLoader-worker

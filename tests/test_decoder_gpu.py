@@ -71,7 +71,7 @@ def test_mha_dropout_uses_the_published_mask(cuda):
     rng = torch.tensor([0x1234567], dtype=torch.int64, device=cuda)
     qk = torch.randn(m, 512, device=cuda).to(torch.bfloat16)
     v = torch.randn(m, 256, device=cuda).to(torch.bfloat16)
-    keep = nv.dropout_mask(rng, layer, 4, groups * 8 * nq * nq, p)
+    keep = nv.dropout_mask(rng, layer, 4, groups * 8 * nq * nq, p, cols=nq)
     rate = float(keep.float().mean())
     assert abs(rate - 0.9) < 5e-3, rate
     o, lse = nv.mha_fwd(qk, v, nq, p, layer, rng)
@@ -84,7 +84,7 @@ def test_mha_dropout_uses_the_published_mask(cuda):
     assert rel(dqk, qf.grad) < 2e-2 and rel(dv, vf.grad) < 2e-2, (rel(dqk, qf.grad), rel(dv, vf.grad))
     # another seed -> another mask
     rng2 = rng + 0x9E3779B1
-    assert float((nv.dropout_mask(rng2, layer, 4, 100000, p) != keep[:100000]).float().mean()) > 0.1
+    assert float((nv.dropout_mask(rng2, layer, 4, 100000, p, cols=nq)[:90000] != keep[:90000]).float().mean()) > 0.1
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -279,7 +279,7 @@ def _grad_compare(cuda, lid, p_on):
         G8 = (M // dims[2]) * 8
         masks = {0: nv.dropout_mask(fd.rng, lid, 0, M * 256, p[1]).view(M, 256), 1: nv.dropout_mask(fd.rng, lid, 1, M * 256, p[1]).view(M, 256),
                  2: nv.dropout_mask(fd.rng, lid, 2, M * 512, p[1]).view(M, 512), 3: nv.dropout_mask(fd.rng, lid, 3, M * 256, p[1]).view(M, 256),
-                 4: nv.dropout_mask(fd.rng, lid, 4, G8 * dims[2] * dims[2], p[0])}
+                 4: nv.dropout_mask(fd.rng, lid, 4, G8 * dims[2] * dims[2], p[0], cols=dims[2])}
     so, go = nv.decoder_layer_slots(M, sp.ncls, sp.code)
     kact = {n: nv.slot_view(save, so[n], M, SLOT_COLS.get(n, 256), torch.bfloat16) for n in ("RPH1", "RPH2", "QS1", "QS2", "R1", "R2", "I1", "I2", "FFH", "PEH0", "C1", "C2")}
     upe1 = nv.slot_view(save, so["UPE1"], M, 256, torch.bfloat16).float()
@@ -430,7 +430,7 @@ def test_mha_f32_dropout_uses_the_same_mask_as_bf16(cuda):
     m = nq * groups
     rng = torch.tensor([0x7654321], dtype=torch.int64, device=cuda)
     qk, v = torch.randn(m, 512, device=cuda), torch.randn(m, 256, device=cuda)
-    keep = nv.dropout_mask(rng, layer, 4, groups * 8 * nq * nq, p)
+    keep = nv.dropout_mask(rng, layer, 4, groups * 8 * nq * nq, p, cols=nq)
     o, lse = nv.mha_fwd(qk, v, nq, p, layer, rng)
     qf, vf = qk.clone().requires_grad_(True), v.clone().requires_grad_(True)
     ref = attn_ref(qf, vf, nq, keep, p)
@@ -495,7 +495,7 @@ def test_fused_layer_f32_gradients_match_f32_restatement(cuda, exact, lid, p_on)
         G8 = (M // dims[2]) * 8
         masks = {0: nv.dropout_mask(fd.rng, lid, 0, M * 256, p[1]).view(M, 256), 1: nv.dropout_mask(fd.rng, lid, 1, M * 256, p[1]).view(M, 256),
                  2: nv.dropout_mask(fd.rng, lid, 2, M * 512, p[1]).view(M, 512), 3: nv.dropout_mask(fd.rng, lid, 3, M * 256, p[1]).view(M, 256),
-                 4: nv.dropout_mask(fd.rng, lid, 4, G8 * dims[2] * dims[2], p[0])}
+                 4: nv.dropout_mask(fd.rng, lid, 4, G8 * dims[2] * dims[2], p[0], cols=dims[2])}
     with torch.no_grad():
         t = restate(sp, lid, x, ref, rows_f, dims, masks, p)          # the restatement's OWN ReLU decisions
     for name, o in (("x_out", x_out), ("reg", reg), ("cls", cls), ("iou", iou)):

@@ -152,16 +152,20 @@ extern "C" int32_t u3d_wpack_bf16(const u3d_wpack_desc* descs_dev, int32_t count
   return u3d_wpack(descs_dev, count, max_elems, U3D_BF16, s);
 }
 
-__global__ void k_dropout_mask(const unsigned long long* rng, int layer, int site, long long n, unsigned thresh, unsigned char* keep) {
+__global__ void k_dropout_mask(const unsigned long long* rng, int layer, int site, long long n, unsigned thresh, int cols, unsigned char* keep) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  keep[i] = thresh == 0u ? 1 : (dc_keep(dc_rng_load(rng), dc_site_key(layer, site), (unsigned)i, thresh) ? 1 : 0);
+  // cols > 0: element i is (row i / cols, column i % cols) of a matrix whose rows are padded to an even length in index space (the
+  // attention weights, dc_att_idx)
+  const unsigned idx = cols > 0 ? dc_att_idx((unsigned)(i / cols), (unsigned)(i % cols), (unsigned)(cols + 1) & ~1u) : (unsigned)i;
+  keep[i] = thresh == 0u ? 1 : (dc_keep(dc_rng_load(rng), dc_site_key(layer, site), idx, thresh) ? 1 : 0);
 }
-extern "C" int32_t u3d_dropout_mask(const uint64_t* rng, int32_t layer, int32_t site, int64_t n, float p, uint8_t* keep, u3d_stream s) {
-  U3D_REQUIRE(rng && keep && n >= 0 && p >= 0.f && p < 1.f, U3D_ERR_ARG);
+extern "C" int32_t u3d_dropout_mask(const uint64_t* rng, int32_t layer, int32_t site, int64_t n, float p, int32_t cols, uint8_t* keep,
+                                    u3d_stream s) {
+  U3D_REQUIRE(rng && keep && n >= 0 && p >= 0.f && p < 1.f && cols >= 0, U3D_ERR_ARG);
   if (n == 0) return U3D_OK;
   hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned long long*)rng, layer, site,
-                     (long long)n, dc_thresh(p), keep);
+                     (long long)n, dc_thresh(p), (int)cols, keep);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
@@ -275,91 +279,104 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_pre(u3d_declayer_params P, u
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// k_mha_fwd: grid (ceil(nq/64), groups*8), 4 waves x 16 queries.  Scores are computed transposed (S^T = K Q^T) so that a lane
+// k_mha_fwd: grid (ceil(nq / 128), groups*8), 4 waves.  A workgroup stages a chunk of keys / values of its (group, head) ONCE and walks
+// NQI = 2 tiles of 64 queries over it (wave w: 16 queries of each).  Scores are computed transposed (S^T = K Q^T) so that a lane
 // owns ONE query (column) and 4 keys per tile: the softmax statistics are per-lane scalars, and the exponentials of two
-// consecutive tiles are exactly the reduction elements of the P.V MFMA's b-operand (V^T from LDS as the a-operand with the
-// same key permutation) - probabilities never leave registers.  lse is kept in log2 units.
+// consecutive tiles are exactly the reduction elements of the P.V MFMA's b-operand; its a-operand V^T comes out of the row-major V
+// image through transpose reads - probabilities never leave registers, nothing is transposed in LDS.  lse is kept in log2 units.
 // ---------------------------------------------------------------------------------------------------------------------------
 template <typename E>
-__global__ __launch_bounds__(256) void k_mha_fwd(const typename E::T* __restrict__ qk, const typename E::T* __restrict__ vv, int nq,
-                                                 float scale_log2, unsigned thresh, float inv_keep, int layer,
-                                                 const unsigned long long* __restrict__ rng, typename E::T* __restrict__ o,
-                                                 float* __restrict__ lse) {
+__global__ __launch_bounds__(256, 2) void k_mha_fwd(const typename E::T* __restrict__ qk, const typename E::T* __restrict__ vv, int nq, int qt_per_wg,
+                                                    float scale_log2, unsigned thresh, float inv_keep, int layer,
+                                                    const unsigned long long* __restrict__ rng, typename E::T* __restrict__ o,
+                                                    float* __restrict__ lse) {
   typedef typename E::T T;
   typedef typename E::V4 V4;
   typedef Mha<E> H;
   constexpr int KC = H::KC;
-  __shared__ __attribute__((aligned(16))) T Ks[KC * 32];
-  __shared__ __attribute__((aligned(16))) T Vt[32 * H::TLD];
+  __shared__ __attribute__((aligned(16))) T Ks[H::RM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T Vs[H::TR ? H::RM_ELEMS : 8];
+  __shared__ __attribute__((aligned(16))) T Vt[H::TP_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
   const int bh = blockIdx.y, g = bh >> 3, h = bh & 7;
   const long long base = (long long)g * nq;
-  const int q = blockIdx.x * 64 + wave * 16 + r16;
+  const unsigned nq_pad = (unsigned)(nq + 1) & ~1u;
   const DcRng rg = dc_rng_load(rng);
   const unsigned key_site = dc_site_key(layer, 4);
-  typename H::RowFrag qf = H::zero_frag();
-  if (q < nq) qf = H::load_frag(qk + (base + q) * 512 + h * DC_HD, kq);
-  f32x4 oacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  float m_run = -INFINITY, l_run = 0.f;
-  for (int kc0 = 0; kc0 < nq; kc0 += KC) {
-    __syncthreads();
-    H::stage(qk + 256 + h * DC_HD, 512, base, kc0, nq, Ks, nullptr, tid);
-    H::stage(vv + h * DC_HD, 256, base, kc0, nq, nullptr, Vt, tid);
-    __syncthreads();
-    const int nkeys = min(KC, nq - kc0);
-    const int ntile = (nkeys + 15) >> 4;
-    f32x4 s[KC / 16];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < KC / 16; ++t) {
-      s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      if (t < ntile) {
-        f32x4 a = H::scores(Ks, t * 16, r16, kq, qf);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = t * 16 + kq * 4 + r;
-          a[r] = key < nkeys ? a[r] * scale_log2 : -INFINITY;
-          mx = fmaxf(mx, a[r]);
-        }
-        s[t] = a;
+  const bool one_chunk = nq <= KC;                       // the whole group is resident: staged once, every query tile walks it
+  for (int qt = 0; qt < qt_per_wg; ++qt) {
+    const int q0 = (blockIdx.x * qt_per_wg + qt) * 64;
+    if (q0 >= nq) break;                                 // uniform
+    const int q = q0 + wave * 16 + r16;
+    typename H::RowFrag qf = H::zero_frag();
+    if (q < nq) qf = H::load_frag(qk + (base + q) * 512 + h * DC_HD, kq);
+    f32x4 oacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float m_run = -INFINITY, l_run = 0.f;                // running maximum of the RAW scores (the scale is positive)
+    const unsigned row = (unsigned)(bh * nq + q);
+    for (int kc0 = 0; kc0 < nq; kc0 += KC) {
+      if (qt == 0 || !one_chunk) {
+        __syncthreads();
+        H::stage(qk + 256 + h * DC_HD, 512, base, kc0, nq, Ks, nullptr, tid);
+        H::stage(vv + h * DC_HD, 256, base, kc0, nq, H::TR ? Vs : nullptr, Vt, tid);
+        __syncthreads();
       }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float corr = E::exp2(m_run - m_new);            // first chunk: exp2(-inf) = 0
-    l_run *= corr;
-    oacc[0] *= corr; oacc[1] *= corr;
-    m_run = m_new;
+      const int nkeys = min(KC, nq - kc0);
+      const int ntile = (nkeys + 15) >> 4;
+      f32x4 s[KC / 16];
+      float mx = -INFINITY;
 #pragma unroll
-    for (int tp = 0; tp < KC / 32; ++tp) {
-      if (tp * 2 < ntile) {
-        f32x4 p0, p1;
+      for (int t = 0; t < KC / 16; ++t) {
+        s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (t < ntile) {
+          f32x4 a = H::scores(Ks, t * 16, r16, kq, qf);
+          if (t == ntile - 1) {                          // only the last tile can hold keys past the group (zero rows in the image)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          p0[r] = E::exp2(s[2 * tp][r] - m_new);
-          p1[r] = E::exp2(s[2 * tp + 1][r] - m_new);
-          l_run += p0[r] + p1[r];
+            for (int r = 0; r < 4; ++r) a[r] = t * 16 + kq * 4 + r < nkeys ? a[r] : -INFINITY;
+          }
+          mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
+          s[t] = a;
         }
-        if (thresh) {
-          const unsigned rowidx = (unsigned)(((long long)bh * nq + q) * nq + kc0);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float corr = E::exp2((m_run - m_new) * scale_log2);            // first chunk: exp2(-inf) = 0
+      const float neg_m = -m_new * scale_log2;
+      l_run *= corr;
+      oacc[0] *= corr; oacc[1] *= corr;
+      m_run = m_new;
+#pragma unroll
+      for (int tp = 0; tp < KC / 32; ++tp) {
+        if (tp * 2 < ntile) {
+          f32x4 p0, p1;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            p0[r] = dc_keep(rg, key_site, rowidx + (2 * tp) * 16 + kq * 4 + r, thresh) ? p0[r] * inv_keep : 0.f;
-            p1[r] = dc_keep(rg, key_site, rowidx + (2 * tp + 1) * 16 + kq * 4 + r, thresh) ? p1[r] * inv_keep : 0.f;
+            p0[r] = E::exp2(fmaf(s[2 * tp][r], scale_log2, neg_m));
+            p1[r] = E::exp2(fmaf(s[2 * tp + 1][r], scale_log2, neg_m));
+            l_run += p0[r] + p1[r];
           }
+          if (thresh) {
+            bool k0[4], k1[4];
+            dc_keep4(rg, key_site, dc_att_idx(row, (unsigned)(kc0 + (2 * tp) * 16 + kq * 4), nq_pad), thresh, k0);
+            dc_keep4(rg, key_site, dc_att_idx(row, (unsigned)(kc0 + (2 * tp + 1) * 16 + kq * 4), nq_pad), thresh, k1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              p0[r] *= k0[r] ? inv_keep : 0.f;
+              p1[r] *= k1[r] ? inv_keep : 0.f;
+            }
+          }
+          H::pv(Vs, Vt, tp, r16, kq, p0, p1, oacc);
         }
-        H::pv(Vt, tp, r16, kq, p0, p1, oacc);
       }
     }
-  }
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
-  if (q < nq) {
-    const float inv = 1.f / l_run;
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (q < nq) {
+      const float inv = 1.f / l_run;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) *(V4*)(o + (base + q) * DC_C + h * DC_HD + dt * 16 + kq * 4) = E::pack4(oacc[dt] * inv);
-    if (kq == 0) lse[(base + q) * DC_NHEAD + h] = m_run + log2f(l_run);
+      for (int dt = 0; dt < 2; ++dt) *(V4*)(o + (base + q) * DC_C + h * DC_HD + dt * 16 + kq * 4) = E::pack4(oacc[dt] * inv);
+      if (kq == 0) lse[(base + q) * DC_NHEAD + h] = m_run * scale_log2 + log2f(l_run);
+    }
   }
 }
 
@@ -368,15 +385,17 @@ extern "C" int32_t u3d_mha_fwd_dt(const void* qk, const void* v, int32_t m, int3
   U3D_REQUIRE(qk && v && o && lse && m > 0 && nq > 0 && m % nq == 0 && p_attn >= 0.f && p_attn < 1.f, U3D_ERR_ARG);
   U3D_REQUIRE(p_attn == 0.f || rng, U3D_ERR_ARG);
   U3D_REQUIRE(dtype == U3D_BF16 || dtype == U3D_F32, U3D_ERR_ARG);
-  U3D_REQUIRE((long long)(m / nq) * DC_NHEAD * nq * nq < (1ll << 32), U3D_ERR_UNSUPPORTED);
+  U3D_REQUIRE((long long)(m / nq) * DC_NHEAD * nq * (nq + 1) < (1ll << 32), U3D_ERR_UNSUPPORTED);
   const float scale_log2 = 1.4426950408889634f / sqrtf((float)DC_HD);
-  const dim3 grid(u3d_cdiv(nq, 64), (m / nq) * DC_NHEAD);
-  if (dtype == U3D_BF16)
-    hipLaunchKernelGGL(k_mha_fwd<EB>, grid, dim3(256), 0, s, (const u16*)qk, (const u16*)v, nq, scale_log2, dc_thresh(p_attn),
-                       dc_inv_keep(p_attn), layer, (const unsigned long long*)rng, (u16*)o, lse);
-  else
-    hipLaunchKernelGGL(k_mha_fwd<EF>, grid, dim3(256), 0, s, (const float*)qk, (const float*)v, nq, scale_log2, dc_thresh(p_attn),
-                       dc_inv_keep(p_attn), layer, (const unsigned long long*)rng, (float*)o, lse);
+  if (dtype == U3D_BF16) {
+    const int qt = mha_tiles_per_wg<EB>(nq);
+    hipLaunchKernelGGL(k_mha_fwd<EB>, dim3(u3d_cdiv(nq, 64 * qt), (m / nq) * DC_NHEAD), dim3(256), 0, s, (const u16*)qk, (const u16*)v, nq, qt,
+                       scale_log2, dc_thresh(p_attn), dc_inv_keep(p_attn), layer, (const unsigned long long*)rng, (u16*)o, lse);
+  } else {
+    const int qt = mha_tiles_per_wg<EF>(nq);
+    hipLaunchKernelGGL(k_mha_fwd<EF>, dim3(u3d_cdiv(nq, 64 * qt), (m / nq) * DC_NHEAD), dim3(256), 0, s, (const float*)qk, (const float*)v, nq,
+                       qt, scale_log2, dc_thresh(p_attn), dc_inv_keep(p_attn), layer, (const unsigned long long*)rng, (float*)o, lse);
+  }
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

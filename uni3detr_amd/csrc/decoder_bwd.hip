@@ -482,161 +482,180 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
 // ---------------------------------------------------------------------------------------------------------------------------
 // attention backward
 // ---------------------------------------------------------------------------------------------------------------------------
-// dQ: a lane owns one query (column of the transposed score tiles), loops over all keys of its group
+// dQ: a lane owns one query (column of the transposed score tiles); the workgroup walks its query tiles over the staged key chunk
 template <typename E>
-__global__ __launch_bounds__(256) void k_mha_bwd_dq(const typename E::T* __restrict__ qk, const typename E::T* __restrict__ vv,
-                                                    const typename E::T* __restrict__ o, const typename E::T* __restrict__ d_o,
-                                                    const float* __restrict__ lse, int nq, float scale_log2, float scale, unsigned thresh,
-                                                    float inv_keep, int layer, const unsigned long long* __restrict__ rng,
-                                                    typename E::T* __restrict__ dqk) {
+__global__ __launch_bounds__(256, 2) void k_mha_bwd_dq(const typename E::T* __restrict__ qk, const typename E::T* __restrict__ vv,
+                                                       const typename E::T* __restrict__ o, const typename E::T* __restrict__ d_o,
+                                                       const float* __restrict__ lse, int nq, int qt_per_wg, float scale_log2, float scale,
+                                                       unsigned thresh, float inv_keep, int layer, const unsigned long long* __restrict__ rng,
+                                                       typename E::T* __restrict__ dqk) {
   typedef typename E::T T;
   typedef typename E::V4 V4;
   typedef Mha<E> H;
   constexpr int KC = H::KC;
-  __shared__ __attribute__((aligned(16))) T Ks[KC * 32];
-  __shared__ __attribute__((aligned(16))) T Vs[KC * 32];
-  __shared__ __attribute__((aligned(16))) T Kt[32 * H::TLD];
+  __shared__ __attribute__((aligned(16))) T Ks[H::RM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T Vs[H::RM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T Kt[H::TP_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
   const int bh = blockIdx.y, g = bh >> 3, h = bh & 7;
   const long long base = (long long)g * nq;
-  const int q = blockIdx.x * 64 + wave * 16 + r16;
-  const bool qok = q < nq;
+  const unsigned nq_pad = (unsigned)(nq + 1) & ~1u;
   const DcRng rg = dc_rng_load(rng);
   const unsigned key_site = dc_site_key(layer, 4);
-  typename H::RowFrag qf = H::zero_frag(), dof = H::zero_frag();
-  float Dq = 0.f, lq = 0.f;
-  if (qok) {
-    qf = H::load_frag(qk + (base + q) * 512 + h * DC_HD, kq);
-    dof = H::load_frag(d_o + (base + q) * DC_C + h * DC_HD, kq);
-    Dq = H::dot(dof, H::load_frag(o + (base + q) * DC_C + h * DC_HD, kq));
-    lq = lse[(base + q) * DC_NHEAD + h];
-  }
-  Dq += __shfl_xor(Dq, 16, 64);
-  Dq += __shfl_xor(Dq, 32, 64);
-  f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  for (int kc0 = 0; kc0 < nq; kc0 += KC) {
-    __syncthreads();
-    H::stage(qk + 256 + h * DC_HD, 512, base, kc0, nq, Ks, Kt, tid);
-    H::stage(vv + h * DC_HD, 256, base, kc0, nq, Vs, nullptr, tid);
-    __syncthreads();
-    const int nkeys = min(KC, nq - kc0);
-    const int ntile = (nkeys + 15) >> 4;
+  const bool one_chunk = nq <= KC;
+  for (int qt = 0; qt < qt_per_wg; ++qt) {
+    const int q0 = (blockIdx.x * qt_per_wg + qt) * 64;
+    if (q0 >= nq) break;                                 // uniform
+    const int q = q0 + wave * 16 + r16;
+    const bool qok = q < nq;
+    typename H::RowFrag qf = H::zero_frag(), dof = H::zero_frag();
+    float Dq = 0.f, lq = INFINITY;                       // a query past the group: exp2(-inf) = 0 everywhere (its lanes are never stored)
+    if (qok) {
+      qf = H::load_frag(qk + (base + q) * 512 + h * DC_HD, kq);
+      dof = H::load_frag(d_o + (base + q) * DC_C + h * DC_HD, kq);
+      Dq = H::dot(dof, H::load_frag(o + (base + q) * DC_C + h * DC_HD, kq));
+      lq = lse[(base + q) * DC_NHEAD + h];
+    }
+    Dq += __shfl_xor(Dq, 16, 64);
+    Dq += __shfl_xor(Dq, 32, 64);
+    f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const unsigned row = (unsigned)(bh * nq + q);
+    for (int kc0 = 0; kc0 < nq; kc0 += KC) {
+      if (qt == 0 || !one_chunk) {
+        __syncthreads();
+        H::stage(qk + 256 + h * DC_HD, 512, base, kc0, nq, Ks, Kt, tid);
+        H::stage(vv + h * DC_HD, 256, base, kc0, nq, Vs, nullptr, tid);
+        __syncthreads();
+      }
+      const int nkeys = min(KC, nq - kc0);
+      const int ntile = (nkeys + 15) >> 4;
+#pragma unroll 2
+      for (int tp = 0; tp < KC / 32; ++tp) {
+        if (tp * 2 < ntile) {
+          f32x4 dsv[2];
 #pragma unroll
-    for (int tp = 0; tp < KC / 32; ++tp) {
-      if (tp * 2 < ntile) {
-        f32x4 dsv[2];
+          for (int u = 0; u < 2; ++u) {
+            const int t = tp * 2 + u;
+            const f32x4 s = H::scores(Ks, t * 16, r16, kq, qf);
+            f32x4 dp = H::scores(Vs, t * 16, r16, kq, dof);
+            f32x4 p;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int t = tp * 2 + u;
-          const f32x4 s = H::scores(Ks, t * 16, r16, kq, qf);
-          f32x4 dp = H::scores(Vs, t * 16, r16, kq, dof);
+            for (int r = 0; r < 4; ++r) p[r] = E::exp2(fmaf(s[r], scale_log2, -lq));
+            if (t >= ntile - 1) {                         // keys past the group (zero rows of the image): only the last tile (pair)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = t * 16 + kq * 4 + r;
-            const float p = (key < nkeys && qok) ? E::exp2(s[r] * scale_log2 - lq) : 0.f;
-            if (thresh) {
-              const unsigned idx = (unsigned)(((long long)bh * nq + q) * nq + kc0 + key);
-              dp[r] = dc_keep(rg, key_site, idx, thresh) ? dp[r] * inv_keep : 0.f;
+              for (int r = 0; r < 4; ++r) p[r] = t * 16 + kq * 4 + r < nkeys ? p[r] : 0.f;
             }
-            dsv[u][r] = p * (dp[r] - Dq) * scale;
+            if (thresh) {
+              bool keep[4];
+              dc_keep4(rg, key_site, dc_att_idx(row, (unsigned)(kc0 + t * 16 + kq * 4), nq_pad), thresh, keep);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) dp[r] *= keep[r] ? inv_keep : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dsv[u][r] = p[r] * (dp[r] - Dq) * scale;
           }
+          H::pv(Ks, Kt, tp, r16, kq, dsv[0], dsv[1], dq);
         }
-        H::pv(Kt, tp, r16, kq, dsv[0], dsv[1], dq);
       }
     }
-  }
-  if (qok) {
+    if (qok) {
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) *(V4*)(dqk + (base + q) * 512 + h * DC_HD + dt * 16 + kq * 4) = E::pack4(dq[dt]);
+      for (int dt = 0; dt < 2; ++dt) *(V4*)(dqk + (base + q) * 512 + h * DC_HD + dt * 16 + kq * 4) = E::pack4(dq[dt]);
+    }
   }
 }
 
-// dK, dV: a lane owns one key, loops over all queries of its group
+// dK, dV: a lane owns one key; the workgroup walks its key tiles over the staged query chunk.  No masks: a key lane past the group is
+// never stored, and a query row past the group carries lse = +inf (probability 0).
 template <typename E>
-__global__ __launch_bounds__(256) void k_mha_bwd_dkv(const typename E::T* __restrict__ qk, const typename E::T* __restrict__ vv,
-                                                     const typename E::T* __restrict__ o, const typename E::T* __restrict__ d_o,
-                                                     const float* __restrict__ lse, int nq, float scale_log2, float scale, unsigned thresh,
-                                                     float inv_keep, int layer, const unsigned long long* __restrict__ rng,
-                                                     typename E::T* __restrict__ dqk, typename E::T* __restrict__ dv) {
+__global__ __launch_bounds__(256, 2) void k_mha_bwd_dkv(const typename E::T* __restrict__ qk, const typename E::T* __restrict__ vv,
+                                                        const typename E::T* __restrict__ o, const typename E::T* __restrict__ d_o,
+                                                        const float* __restrict__ lse, int nq, int kt_per_wg, float scale_log2, float scale,
+                                                        unsigned thresh, float inv_keep, int layer, const unsigned long long* __restrict__ rng,
+                                                        typename E::T* __restrict__ dqk, typename E::T* __restrict__ dv) {
   typedef typename E::T T;
   typedef typename E::V4 V4;
   typedef typename E::VC VC;
   typedef Mha<E> H;
-  constexpr int KC = H::KC;
-  __shared__ __attribute__((aligned(16))) T Qs[KC * 32];
-  __shared__ __attribute__((aligned(16))) T Os[KC * 32];        // dO rows
-  __shared__ __attribute__((aligned(16))) T Qt[32 * H::TLD];
-  __shared__ __attribute__((aligned(16))) T Ot[32 * H::TLD];    // dO^T
+  constexpr int KC = H::KC, NP = H::NP;
+  __shared__ __attribute__((aligned(16))) T Qs[H::RM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T Os[H::RM_ELEMS];        // dO rows
+  __shared__ __attribute__((aligned(16))) T Qt[H::TP_ELEMS];
+  __shared__ __attribute__((aligned(16))) T Ot[H::TP_ELEMS];        // dO^T (EF)
   __shared__ float lse_s[KC], D_s[KC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
   const int bh = blockIdx.y, g = bh >> 3, h = bh & 7;
   const long long base = (long long)g * nq;
-  const int key = blockIdx.x * 64 + wave * 16 + r16;
-  const bool kok = key < nq;
+  const unsigned nq_pad = (unsigned)(nq + 1) & ~1u;
   const DcRng rg = dc_rng_load(rng);
   const unsigned key_site = dc_site_key(layer, 4);
-  typename H::RowFrag kf = H::zero_frag(), vf = H::zero_frag();
-  if (kok) {
-    kf = H::load_frag(qk + (base + key) * 512 + 256 + h * DC_HD, kq);
-    vf = H::load_frag(vv + (base + key) * DC_C + h * DC_HD, kq);
-  }
-  f32x4 dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dvv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  constexpr int NP = H::NP;
-  for (int qc0 = 0; qc0 < nq; qc0 += KC) {
-    __syncthreads();
-    H::stage(qk + h * DC_HD, 512, base, qc0, nq, Qs, Qt, tid);
-    H::stage(d_o + h * DC_HD, 256, base, qc0, nq, Os, Ot, tid);
-    DC_FOR_TID(c, KC * NP) {                                // D[q] = dO[q] . O[q] over this head's 32 columns; lse[q]
-      const int qq = c / NP, part = c % NP;
-      float d = 0.f;
-      if (qc0 + qq < nq) {
-        const VC a = *(const VC*)(d_o + (base + qc0 + qq) * DC_C + h * DC_HD + part * E::CH);
-        const VC b = *(const VC*)(o + (base + qc0 + qq) * DC_C + h * DC_HD + part * E::CH);
-#pragma unroll
-        for (int e = 0; e < E::CH; ++e) d += E::chunk_elem(a, e) * E::chunk_elem(b, e);
-      }
-#pragma unroll
-      for (int sh = 1; sh < NP; sh <<= 1) d += __shfl_xor(d, sh, 64);
-      if (part == 0) {
-        D_s[qq] = d;
-        lse_s[qq] = qc0 + qq < nq ? lse[(base + qc0 + qq) * DC_NHEAD + h] : 0.f;
-      }
+  const bool one_chunk = nq <= KC;
+  for (int kt = 0; kt < kt_per_wg; ++kt) {
+    const int k0 = (blockIdx.x * kt_per_wg + kt) * 64;
+    if (k0 >= nq) break;                                 // uniform
+    const int key = k0 + wave * 16 + r16;
+    const bool kok = key < nq;
+    typename H::RowFrag kf = H::zero_frag(), vf = H::zero_frag();
+    if (kok) {
+      kf = H::load_frag(qk + (base + key) * 512 + 256 + h * DC_HD, kq);
+      vf = H::load_frag(vv + (base + key) * DC_C + h * DC_HD, kq);
     }
-    __syncthreads();
-    const int nqs = min(KC, nq - qc0);
-    const int ntile = (nqs + 15) >> 4;
+    f32x4 dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dvv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int qc0 = 0; qc0 < nq; qc0 += KC) {
+      if (kt == 0 || !one_chunk) {
+        __syncthreads();
+        H::stage(qk + h * DC_HD, 512, base, qc0, nq, Qs, Qt, tid);
+        H::stage(d_o + h * DC_HD, 256, base, qc0, nq, Os, Ot, tid);
+        DC_FOR_TID(c, KC * NP) {                                // D[q] = dO[q] . O[q] over this head's 32 columns; lse[q]
+          const int qq = c / NP, part = c % NP;
+          float d = 0.f;
+          if (qc0 + qq < nq) {
+            const VC a = *(const VC*)(d_o + (base + qc0 + qq) * DC_C + h * DC_HD + part * E::CH);
+            const VC b = *(const VC*)(o + (base + qc0 + qq) * DC_C + h * DC_HD + part * E::CH);
 #pragma unroll
-    for (int tp = 0; tp < KC / 32; ++tp) {
-      if (tp * 2 < ntile) {
-        f32x4 pd[2], dsv[2];
+            for (int e = 0; e < E::CH; ++e) d += E::chunk_elem(a, e) * E::chunk_elem(b, e);
+          }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int t = tp * 2 + u;
-          const f32x4 s = H::scores(Qs, t * 16, r16, kq, kf);
-          const f32x4 dp = H::scores(Os, t * 16, r16, kq, vf);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int qq = t * 16 + kq * 4 + r;
-            const float p = (qq < nqs && kok) ? E::exp2(s[r] * scale_log2 - lse_s[qq]) : 0.f;
-            float keepf = 1.f;
-            if (thresh) {
-              const unsigned idx = (unsigned)(((long long)bh * nq + qc0 + qq) * nq + key);
-              keepf = dc_keep(rg, key_site, idx, thresh) ? inv_keep : 0.f;
-            }
-            pd[u][r] = p * keepf;
-            dsv[u][r] = p * (dp[r] * keepf - D_s[qq]) * scale;
+          for (int sh = 1; sh < NP; sh <<= 1) d += __shfl_xor(d, sh, 64);
+          if (part == 0) {
+            D_s[qq] = d;
+            lse_s[qq] = qc0 + qq < nq ? lse[(base + qc0 + qq) * DC_NHEAD + h] : INFINITY;
           }
         }
-        H::pv(Ot, tp, r16, kq, pd[0], pd[1], dvv);
-        H::pv(Qt, tp, r16, kq, dsv[0], dsv[1], dk);
+        __syncthreads();
+      }
+      const int nqs = min(KC, nq - qc0);
+      const int ntile = (nqs + 15) >> 4;
+#pragma unroll 2
+      for (int tp = 0; tp < KC / 32; ++tp) {
+        if (tp * 2 < ntile) {
+          f32x4 pd[2], dsv[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int t = tp * 2 + u;
+            const f32x4 s = H::scores(Qs, t * 16, r16, kq, kf);
+            const f32x4 dp = H::scores(Os, t * 16, r16, kq, vf);
+            const f32x4 l4 = *(const f32x4*)(lse_s + t * 16 + kq * 4), D4 = *(const f32x4*)(D_s + t * 16 + kq * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = E::exp2(fmaf(s[r], scale_log2, -l4[r]));
+              float keepf = 1.f;
+              if (thresh) keepf = dc_keep(rg, key_site, dc_att_idx((unsigned)(bh * nq + qc0 + t * 16 + kq * 4 + r), (unsigned)key, nq_pad), thresh) ? inv_keep : 0.f;
+              pd[u][r] = p * keepf;
+              dsv[u][r] = p * (dp[r] * keepf - D4[r]) * scale;
+            }
+          }
+          H::pv(Os, Ot, tp, r16, kq, pd[0], pd[1], dvv);
+          H::pv(Qs, Qt, tp, r16, kq, dsv[0], dsv[1], dk);
+        }
       }
     }
-  }
-  if (kok) {
+    if (kok) {
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      *(V4*)(dqk + (base + key) * 512 + 256 + h * DC_HD + dt * 16 + kq * 4) = E::pack4(dk[dt]);
-      *(V4*)(dv + (base + key) * DC_C + h * DC_HD + dt * 16 + kq * 4) = E::pack4(dvv[dt]);
+      for (int dt = 0; dt < 2; ++dt) {
+        *(V4*)(dqk + (base + key) * 512 + 256 + h * DC_HD + dt * 16 + kq * 4) = E::pack4(dk[dt]);
+        *(V4*)(dv + (base + key) * DC_C + h * DC_HD + dt * 16 + kq * 4) = E::pack4(dvv[dt]);
+      }
     }
   }
 }
@@ -646,10 +665,11 @@ static void mha_bwd_launch(const void* qk, const void* v, const void* o, const v
                            float p_attn, int32_t layer, const uint64_t* rng, void* dqk, void* dv, u3d_stream s) {
   typedef typename E::T T;
   const float scale = 1.f / sqrtf((float)DC_HD), scale_log2 = 1.4426950408889634f * scale;
-  const dim3 grid(u3d_cdiv(nq, 64), (m / nq) * DC_NHEAD);
-  hipLaunchKernelGGL(k_mha_bwd_dq<E>, grid, dim3(256), 0, s, (const T*)qk, (const T*)v, (const T*)o, (const T*)d_o, lse, nq, scale_log2,
+  const int qt = mha_tiles_per_wg<E>(nq);
+  const dim3 grid(u3d_cdiv(nq, 64 * qt), (m / nq) * DC_NHEAD);
+  hipLaunchKernelGGL(k_mha_bwd_dq<E>, grid, dim3(256), 0, s, (const T*)qk, (const T*)v, (const T*)o, (const T*)d_o, lse, nq, qt, scale_log2,
                      scale, dc_thresh(p_attn), dc_inv_keep(p_attn), layer, (const unsigned long long*)rng, (T*)dqk);
-  hipLaunchKernelGGL(k_mha_bwd_dkv<E>, grid, dim3(256), 0, s, (const T*)qk, (const T*)v, (const T*)o, (const T*)d_o, lse, nq, scale_log2,
+  hipLaunchKernelGGL(k_mha_bwd_dkv<E>, grid, dim3(256), 0, s, (const T*)qk, (const T*)v, (const T*)o, (const T*)d_o, lse, nq, qt, scale_log2,
                      scale, dc_thresh(p_attn), dc_inv_keep(p_attn), layer, (const unsigned long long*)rng, (T*)dqk, (T*)dv);
 }
 extern "C" int32_t u3d_mha_bwd_dt(const void* qk, const void* v, const void* o, const void* d_o, const float* lse, int32_t m, int32_t nq,
@@ -657,7 +677,7 @@ extern "C" int32_t u3d_mha_bwd_dt(const void* qk, const void* v, const void* o, 
   U3D_REQUIRE(qk && v && o && d_o && lse && dqk && dv && m > 0 && nq > 0 && m % nq == 0 && p_attn >= 0.f && p_attn < 1.f, U3D_ERR_ARG);
   U3D_REQUIRE(p_attn == 0.f || rng, U3D_ERR_ARG);
   U3D_REQUIRE(dtype == U3D_BF16 || dtype == U3D_F32, U3D_ERR_ARG);
-  U3D_REQUIRE((long long)(m / nq) * DC_NHEAD * nq * nq < (1ll << 32), U3D_ERR_UNSUPPORTED);
+  U3D_REQUIRE((long long)(m / nq) * DC_NHEAD * nq * (nq + 1) < (1ll << 32), U3D_ERR_UNSUPPORTED);
   if (dtype == U3D_BF16) mha_bwd_launch<EB>(qk, v, o, d_o, lse, m, nq, p_attn, layer, rng, dqk, dv, s);
   else mha_bwd_launch<EF>(qk, v, o, d_o, lse, m, nq, p_attn, layer, rng, dqk, dv, s);
   U3D_CHECK_LAUNCH();

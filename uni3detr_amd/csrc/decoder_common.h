@@ -66,7 +66,7 @@ struct EB {                    // bf16 storage
   static constexpr int MT = 2;        // 16-row MFMA tiles per workgroup
   static constexpr int KSTEP = 32;    // reduction elements per dc_gemm step (4 chunk columns, one per 16-lane group)
   static constexpr int DT = U3D_BF16;
-  static constexpr int MHA_KC = 128;  // keys per LDS chunk of the attention kernels
+  static constexpr int MHA_KC = 320;  // rows per LDS chunk of the attention kernels: a 300-query group is ONE chunk
   __device__ static __forceinline__ float to_f(T v) { return dc_bf2f(v); }
   __device__ static __forceinline__ T from_f(float f) { return dc_f2bf(f); }
   __device__ static __forceinline__ float round(float f) { return dc_bf2f(dc_f2bf(f)); }         // value after a store in T
@@ -138,6 +138,10 @@ __device__ __forceinline__ int dc_aoff(int row, int col, int ldk) {
 }
 
 // ---- dropout: keep decision of element idx at (layer, site); identical in forward and backward ----------------------------
+// One 32-bit hash word serves TWO neighbouring elements (idx >> 1 selects the word, idx & 1 its 16-bit half; keep <=> half >= p * 2^16,
+// i.e. p is honoured to 2^-16).  The attention kernels hash every score element: with a word per element and four 32-bit multiplies
+// per word the hashing cost three times the softmax itself (quarter-rate v_mul_lo_u32).  Attention rows are padded to an even length
+// in index space (dc_att_idx) so that the 4 consecutive keys a lane owns always start on a pair boundary.
 struct DcRng { unsigned lo, hi; };
 __device__ __forceinline__ DcRng dc_rng_load(const unsigned long long* p) {
   const unsigned long long v = p ? *p : 0ull;
@@ -145,22 +149,34 @@ __device__ __forceinline__ DcRng dc_rng_load(const unsigned long long* p) {
   return r;
 }
 __device__ __forceinline__ unsigned dc_site_key(int layer, int site) { return (unsigned)(layer * 8 + site + 1) * 0x85EBCA77u; }
-__device__ __forceinline__ bool dc_keep(DcRng g, unsigned site_key, unsigned idx, unsigned thresh) {
-  unsigned h = idx * 0x9E3779B1u + (g.lo ^ site_key);
-  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-  h ^= g.hi; h *= 0x9E3779B1u; h ^= h >> 15;
-  return (h >> 8) >= thresh;                       // thresh = p * 2^24
+__device__ __forceinline__ unsigned dc_hash_pair(DcRng g, unsigned site_key, unsigned pair) {
+  unsigned h = pair * 0x9E3779B1u + (g.lo ^ site_key);
+  h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13; h ^= g.hi; h *= 0xC2B2AE3Du; h ^= h >> 16;
+  return h;
 }
-__host__ __device__ static inline unsigned dc_thresh(float p) { return p <= 0.f ? 0u : (unsigned)(p * 16777216.0f); }
+__device__ __forceinline__ bool dc_keep_half(unsigned word, unsigned odd, unsigned thresh) { return ((word >> (odd * 16u)) & 0xFFFFu) >= thresh; }
+__device__ __forceinline__ bool dc_keep(DcRng g, unsigned site_key, unsigned idx, unsigned thresh) {
+  return dc_keep_half(dc_hash_pair(g, site_key, idx >> 1), idx & 1u, thresh);
+}
+// keep decisions of 4 consecutive elements idx0 .. idx0+3, idx0 EVEN: two hash words
+__device__ __forceinline__ void dc_keep4(DcRng g, unsigned site_key, unsigned idx0, unsigned thresh, bool (&k)[4]) {
+  const unsigned w0 = dc_hash_pair(g, site_key, idx0 >> 1), w1 = dc_hash_pair(g, site_key, (idx0 >> 1) + 1u);
+  k[0] = dc_keep_half(w0, 0u, thresh); k[1] = dc_keep_half(w0, 1u, thresh);
+  k[2] = dc_keep_half(w1, 0u, thresh); k[3] = dc_keep_half(w1, 1u, thresh);
+}
+// index of attention weight (row = (group * 8 + head) * nq + query, key): rows of nq_pad = nq rounded up to even
+__device__ __forceinline__ unsigned dc_att_idx(unsigned row, unsigned key, unsigned nq_pad) { return row * nq_pad + key; }
+__host__ __device__ static inline unsigned dc_thresh(float p) { return p <= 0.f ? 0u : (unsigned)(p * 65536.0f); }
 __host__ __device__ static inline float dc_inv_keep(float p) { return p <= 0.f ? 1.f : 1.f / (1.f - p); }
 
 struct DcDrop {
   DcRng rng; unsigned thresh; float inv_keep; int layer;
-  __device__ __forceinline__ f32x4 apply(f32x4 v, int site, unsigned idx0) const {     // 4 consecutive elements idx0..idx0+3
+  __device__ __forceinline__ f32x4 apply(f32x4 v, int site, unsigned idx0) const {     // 4 consecutive elements idx0..idx0+3, idx0 % 4 == 0
     if (thresh == 0u) return v;
-    const unsigned key = dc_site_key(layer, site);
+    bool k[4];
+    dc_keep4(rng, dc_site_key(layer, site), idx0, thresh, k);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = dc_keep(rng, key, idx0 + r, thresh) ? v[r] * inv_keep : 0.f;
+    for (int r = 0; r < 4; ++r) v[r] = k[r] ? v[r] * inv_keep : 0.f;
     return v;
   }
 };
@@ -424,30 +440,42 @@ __host__ static inline int dc_esize(int dtype) { return dtype == U3D_BF16 ? 2 : 
 __host__ static inline int dc_bm(int dtype) { return dtype == U3D_BF16 ? EB::BM : EF::BM; }
 
 // ---- attention building blocks (k_mha_fwd in decoder.hip, k_mha_bwd_* in decoder_bwd.hip) -----------------------------------------
-// A head slice of a row is 32 elements = NP 16-byte parts.  Row-major LDS copies [key][32] are swizzled per key; the transposed
-// copies [d][key] have a padded row stride.
+// A head slice of a row is 32 elements = NP 16-byte parts.  A chunk of KC rows is staged in LDS row-major.
+//   EB: rows of RS = 48 elements (96 bytes): the 16 rows of a ds_read_b128 fragment and the 4 x 4 blocks of a ds_read_b64_tr_b16
+//       transpose read both land on distinct banks, so ONE image serves as row operand (scores) and as transposed operand (the
+//       products that reduce over the rows) - no transposed copy, no 2-byte LDS stores.  KC = 320: the 300 keys of a SUN RGB-D /
+//       ScanNet / KITTI group are one chunk (one staging round, no running-max rescale).
+//   EF: f32 has no transpose read: swizzled 32-element rows plus an explicit transposed copy [32][KC + 8]; KC = 64.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 template <typename E>
 struct Mha {
   typedef typename E::T T;
   typedef typename E::VC VC;
+  static constexpr bool TR = E::CH == 8;         // hardware transpose reads available (16-bit elements)
   static constexpr int KC = E::MHA_KC;
   static constexpr int NP = DC_HD / E::CH;       // parts per row: 4 (bf16) / 8 (f32)
-  static constexpr int TLD = KC + 8;             // row stride of a transposed copy [32][KC]
-  __device__ static __forceinline__ int koff(int key, int part) {
-    if constexpr (E::CH == 8) return key * 32 + (((part ^ ((-(key >> 2)) & 3)) & 3) << 3);
-    else return key * 32 + (((part ^ key) & 7) << 2);
+  static constexpr int RS = TR ? 48 : 32;        // row stride (elements) of a row-major image
+  static constexpr int TLD = KC + 8;             // row stride of a transposed copy [32][KC] (EF only)
+  static constexpr int RM_ELEMS = KC * RS;       // elements of a row-major image
+  static constexpr int TP_ELEMS = TR ? 8 : 32 * TLD;     // elements of a transposed copy (EB: a stub, never touched)
+  __device__ static __forceinline__ int roff(int row, int part) {
+    if constexpr (TR) return row * RS + part * 8;
+    else return row * 32 + (((part ^ row) & 7) << 2);
   }
-  // stage KC rows (head slice) of a row matrix into LDS: row-major swizzled copy and/or the transpose [32][TLD]
+  // stage KC rows (head slice) of a row matrix into LDS: the row-major image and (EF) the transposed copy
   __device__ static __forceinline__ void stage(const T* __restrict__ src, int ld, long long base_row, int first, int nvalid, T* rowmajor,
                                                T* transposed, int tid) {
     DC_FOR_TID(c, KC * NP) {
       const int key = c / NP, part = c % NP;
       VC v = E::zero_chunk();
       if (first + key < nvalid) v = *(const VC*)(src + (base_row + first + key) * ld + part * E::CH);
-      if (rowmajor) *(VC*)(rowmajor + koff(key, part)) = v;
-      if (transposed) {
+      if (rowmajor) *(VC*)(rowmajor + roff(key, part)) = v;
+      if constexpr (!TR) {
+        if (transposed) {
 #pragma unroll
-        for (int e = 0; e < E::CH; ++e) transposed[(part * E::CH + e) * TLD + key] = v[e];
+          for (int e = 0; e < E::CH; ++e) transposed[(part * E::CH + e) * TLD + key] = v[e];
+        }
       }
     }
   }
@@ -473,32 +501,40 @@ struct Mha {
       for (int e = 0; e < E::CH; ++e) d += E::chunk_elem(a.c[j], e) * E::chunk_elem(b.c[j], e);
     return d;
   }
-  // S^T tile [16 keys][16 queries] = R[16 rows of the row-major LDS copy starting at row0] . frag^T
+  // S^T tile [16 rows of the image starting at row0][16 columns of f] = R . frag^T
   __device__ static __forceinline__ f32x4 scores(const T* rowmajor, int row0, int r16, int kq, const RowFrag& f) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < NP / 4; ++j) E::mma(*(const VC*)(rowmajor + koff(row0 + r16, j * 4 + kq)), f.c[j], acc);
+    for (int j = 0; j < NP / 4; ++j) E::mma(*(const VC*)(rowmajor + roff(row0 + r16, j * 4 + kq)), f.c[j], acc);
     return acc;
   }
-  // acc[dt] += Tt[dt*16 .. +16)[keys of the tile pair tp] . P^T: p0 / p1 = the lane's 4 values (keys kq*4 + r) of tiles 2tp, 2tp+1
-  __device__ static __forceinline__ void pv(const T* Tt, int tp, int r16, int kq, f32x4 p0, f32x4 p1, f32x4 (&acc)[2]) {
-    if constexpr (E::CH == 8) {
+  // acc[dt] += X^T[dt*16 .. +16)[rows of the tile pair tp] . P^T: p0 / p1 = the lane's 4 values (rows kq*4 + r) of tiles 2tp, 2tp+1.
+  // EB: X = the row-major image (transpose reads); EF: X = the transposed copy.
+  __device__ static __forceinline__ void pv(const T* rowmajor, const T* transposed, int tp, int r16, int kq, f32x4 p0, f32x4 p1,
+                                            f32x4 (&acc)[2]) {
+    if constexpr (TR) {
+      (void)transposed;
       const u16x4 a4 = EB::pack4(p0), b4 = EB::pack4(p1);
       const u16x8 pb = {a4[0], a4[1], a4[2], a4[3], b4[0], b4[1], b4[2], b4[3]};
+      // 8 reduction values per lane: rows tp*32 + 4*kq + {0..3} and + 16 of column dt*16 + r16 (the order p0 | p1 has)
+      const int j = r16 >> 2, q = r16 & 3;
+      const u16* p0a = (const u16*)rowmajor + (tp * 32 + 4 * kq + j) * RS + 4 * q;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const u16* vp = (const u16*)Tt + (dt * 16 + r16) * TLD + tp * 32 + kq * 4;
-        const u16x4 v0 = *(const u16x4*)vp, v1 = *(const u16x4*)(vp + 16);
-        const u16x8 vb = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+        const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0a + dt * 16));
+        const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0a + dt * 16 + 16 * RS));
+        const s16x8 vb = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
         acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vb), __builtin_bit_cast(bf16x8, pb), acc[dt], 0, 0, 0);
       }
     } else {
+      (void)rowmajor;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const f32x4 p = u ? p1 : p0;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const f32x4 v = *(const f32x4*)((const float*)Tt + (dt * 16 + r16) * TLD + (tp * 2 + u) * 16 + kq * 4);
+          const f32x4 v = *(const f32x4*)((const float*)transposed + (dt * 16 + r16) * TLD + (tp * 2 + u) * 16 + kq * 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j], p[j], acc[dt], 0, 0, 0);
         }
@@ -506,3 +542,9 @@ struct Mha {
     }
   }
 };
+
+// query / key tiles (64 rows) one workgroup walks: up to 3 when a group fits one staged chunk (5 tiles of a 300-query group -> two
+// workgroups of 3 + 2 tiles, every workgroup resident in one round), else one (chunks are re-staged per tile)
+template <typename E>
+static inline int mha_tiles_per_wg(int nq) { return nq <= Mha<E>::KC ? 3 : 1; }
+

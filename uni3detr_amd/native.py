@@ -164,7 +164,7 @@ _SIGS = {
     "u3d_decoder_layer_blocks_dt": (_I, [_I, _I]),
     "u3d_mha_fwd_dt": (_I, [_P, _P, _I, _I, C.c_float, _I, _P, _P, _P, _I, _P]),
     "u3d_mha_bwd_dt": (_I, [_P, _P, _P, _P, _P, _I, _I, C.c_float, _I, _P, _P, _P, _I, _P]),
-    "u3d_dropout_mask": (_I, [_P, _I, _I, _L, C.c_float, _P, _P]),
+    "u3d_dropout_mask": (_I, [_P, _I, _I, _L, C.c_float, _I, _P, _P]),
     "u3d_scatter_rows": (_I, [_P, _P, _I, _I, _P, _P]),
 }
 
@@ -1175,9 +1175,10 @@ def wpack_bf16(descs_dev, count, max_elems):
     wpack(descs_dev, count, max_elems, torch.bfloat16)
 
 
-def dropout_mask(rng, layer, site, n, p):
+def dropout_mask(rng, layer, site, n, p, cols=0):
+    """keep mask (bytes) of n elements of dropout site `site`; the attention site (4) takes cols = queries per group."""
     keep = torch.empty((n,), dtype=torch.uint8, device=rng.device)
-    _check(lib().u3d_dropout_mask(_ptr(rng), layer, site, n, p, _ptr(keep), _stream()), "dropout_mask")
+    _check(lib().u3d_dropout_mask(_ptr(rng), layer, site, n, p, int(cols), _ptr(keep), _stream()), "dropout_mask")
     return keep
 
 
