@@ -51,7 +51,8 @@ def parse():
                     help="shipped configuration to run (BASELINE.json configs[1..4]); the headline metric is quoted on sunrgbd")
     ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (default: the workload's)")
     ap.add_argument("--points", type=int, default=None, help="points per scene (default: the workload's)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "mixed"],
+                    help="bf16: BASELINE configs[1]; mixed: the reference's recipe (fp32 encoder + backbone, 16-bit neck + head); fp32: parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -266,7 +267,7 @@ def main():
                        f"scenes/sec (fwd+bwd) {args.config} {args.points} pts, {nq_cfg} queries"), "value": scenes / dt, "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp32": "f32", "mixed": "f32 encoder+backbone / bf16 neck+head"}[args.precision], "data": "synthetic",
             "config": {"workload": f"{wl['file']} (BASELINE {wl['baseline']}): train step fwd+loss+bwd+clip+AdamW, "
                                    f"{args.batch} scenes/GPU x {args.points} pts, {nq_cfg} queries x 3 groups, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss_val,
@@ -320,7 +321,7 @@ def main():
             if dom_mean_ms is not None:
                 h["ms"] = dom_mean_ms
             ai = h["flops"] / h["bytes"]
-            peak_tf = MFMA_PEAK_TF[out["dtype"]]
+            peak_tf = MFMA_PEAK_TF["bf16" if args.precision == "bf16" else "f32"]
             if ai > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
                 ach, peak, unit, bound = h["flops"] / (h["ms"] * 1e-3) / 1e12, peak_tf, "TFLOP/s", "mfma"
             else:

@@ -585,15 +585,16 @@ int32_t u3d_dropout_mask(const uint64_t* rng, int32_t layer, int32_t site, int64
  * GlobalRotScaleTrans -> PointsRangeFilter -> PointSample; the plugin's own UnifiedRandomFlip3D / UnifiedRotScaleTrans,
  * projects/mmdet3d_plugin/datasets/pipelines/transform_3d.py:325-589, apply the same geometry).  The random DRAWS stay with the
  * caller (host RNG, as in the reference): per-scene parameters arrive as f32 [batch][U3D_AUG_NPARAM] =
- * (flip_horizontal, flip_vertical, sin(angle), cos(angle), angle, scale).  coord: 0 = Depth boxes/points (SUN RGB-D, ScanNet),
+ * (flip_horizontal, flip_vertical, sin(angle), cos(angle), angle, scale, tx, ty, tz): flip -> rotate -> scale -> translate.  coord: 0 = Depth boxes/points (SUN RGB-D, ScanNet),
  * 1 = LiDAR (KITTI, nuScenes) - it selects which axis a horizontal / vertical flip mirrors.
  * ------------------------------------------------------------------------------------------------ */
-#define U3D_AUG_NPARAM 6
+#define U3D_AUG_NPARAM 9
 /* in place: points [n_total, feat] f32 (x, y, z, ...), scene b = rows scene_off[b] .. scene_off[b+1]); height_dim >= 3 scales that
  * attribute with the scene (shift_height=True), -1 = none */
 int32_t u3d_points_augment(float* points, const int32_t* scene_off, int32_t batch, int32_t n_total, int32_t feat, const float* params,
                            int32_t coord, int32_t height_dim, u3d_stream s);
-/* in place: boxes [n, box_dim] f32 (x, y, z, dx, dy, dz, yaw [, vx, vy]), box_dim 7 or 9, scene b = rows gt_off[b] .. gt_off[b+1]) */
+/* in place: boxes [n, box_dim] f32 (x, y, z, dx, dy, dz, yaw [, vx, vy]), box_dim 7 or 9, scene b = rows gt_off[b] .. gt_off[b+1]);
+ * velocities flip, rotate and scale with the frame */
 int32_t u3d_boxes_augment(float* boxes, const int32_t* gt_off, int32_t batch, int32_t n, int32_t box_dim, const float* params, int32_t coord,
                           u3d_stream s);
 /* PointsRangeFilter: the points of scene b with lo < (x, y, z) < hi (strict), in their original order, compacted to the front of the
@@ -607,6 +608,12 @@ int32_t u3d_points_range_filter(const float* points, const int32_t* scene_off, i
  * int32 [batch * num_points] = the chosen row within the scene (-1 for an empty scene). */
 int32_t u3d_point_sample(const float* points, const int32_t* scene_off, const int32_t* count, int32_t batch, int32_t feat, int32_t num_points,
                          const uint64_t* seed, float* out, int32_t* idx_out, u3d_stream s);
+
+/* ObjectRangeFilter (KITTI / nuScenes train pipelines; ref: projects/configs/uni3detr/uni3detr_kitti_3classes.py train_pipeline):
+ * in place, per scene, order kept: boxes whose BEV centre lies strictly inside bev_range4 = (x0, y0, x1, y1) (HOST array) move to the
+ * front of the scene's segment (labels int32, nullable, move with them), yaw wrapped into [-pi, pi); count[b] = survivors. */
+int32_t u3d_boxes_range_filter(float* boxes, int32_t* labels, const int32_t* gt_off, int32_t batch, int32_t box_dim,
+                               const float* bev_range4, int32_t* count, u3d_stream s);
 
 #ifdef __cplusplus
 }

@@ -55,23 +55,26 @@ def _flip_xy(coord, flip_h, flip_v, x, y):
     return x, y
 
 
-def augment_points(points, flip_h, flip_v, angle, scale, coord=DEPTH, height_dim=-1):
-    """One scene: flip -> rotate (row vector @ rot_mat_T) -> scale; the height attribute scales when shift_height=True (:411-415)."""
+def augment_points(points, flip_h, flip_v, angle, scale, coord=DEPTH, height_dim=-1, trans=(0.0, 0.0, 0.0)):
+    """One scene: flip -> rotate (row vector @ rot_mat_T) -> scale -> translate (mmdet3d GlobalRotScaleTrans order, recalled); the height
+    attribute scales when shift_height=True (:411-415)."""
     p = np.array(points, np.float32, copy=True)
     x, y = _flip_xy(coord, flip_h, flip_v, p[:, 0].copy(), p[:, 1].copy())
     s, c = np.float32(np.sin(np.float32(angle))), np.float32(np.cos(np.float32(angle)))
     sc = np.float32(scale)
-    p[:, 0] = (x * c - y * s) * sc
-    p[:, 1] = (x * s + y * c) * sc
-    p[:, 2] = p[:, 2] * sc
+    t = np.asarray(trans, np.float32)
+    p[:, 0] = (x * c - y * s) * sc + t[0]
+    p[:, 1] = (x * s + y * c) * sc + t[1]
+    p[:, 2] = p[:, 2] * sc + t[2]
     if height_dim >= 3:
         p[:, height_dim] = p[:, height_dim] * sc
     return p
 
 
-def augment_boxes(boxes, flip_h, flip_v, angle, scale, coord=DEPTH):
+def augment_boxes(boxes, flip_h, flip_v, angle, scale, coord=DEPTH, trans=(0.0, 0.0, 0.0)):
     """Boxes (x, y, z, dx, dy, dz, yaw [, vx, vy]): centres like points, sizes scale, yaw: Depth h-flip pi - yaw, v-flip -yaw;
-    LiDAR h-flip -yaw, v-flip pi - yaw; then + angle (mmdet3d v1.0 `rotate`, recalled); velocities rotate / flip, do not scale."""
+    LiDAR h-flip -yaw, v-flip pi - yaw; then + angle (mmdet3d v1.0 `rotate`, recalled); velocities flip / rotate and SCALE with the
+    frame (mmdet3d BaseInstance3DBoxes.scale: `tensor[:, :6] *= s; tensor[:, 7:] *= s`, recalled)."""
     b = np.array(boxes, np.float32, copy=True)
     if b.shape[0] == 0:
         return b
@@ -90,15 +93,28 @@ def augment_boxes(boxes, flip_h, flip_v, angle, scale, coord=DEPTH):
             yaw = -yaw + pi
     s, c = np.float32(np.sin(np.float32(angle))), np.float32(np.cos(np.float32(angle)))
     sc = np.float32(scale)
-    b[:, 0] = (x * c - y * s) * sc
-    b[:, 1] = (x * s + y * c) * sc
-    b[:, 2:6] = b[:, 2:6] * sc
+    t = np.asarray(trans, np.float32)
+    b[:, 0] = (x * c - y * s) * sc + t[0]
+    b[:, 1] = (x * s + y * c) * sc + t[1]
+    b[:, 2] = b[:, 2] * sc + t[2]
+    b[:, 3:6] = b[:, 3:6] * sc
     b[:, 6] = yaw + np.float32(angle)
     if b.shape[1] >= 9:
         vx, vy = _flip_xy(coord, flip_h, flip_v, b[:, 7].copy(), b[:, 8].copy())
-        b[:, 7] = vx * c - vy * s
-        b[:, 8] = vx * s + vy * c
+        b[:, 7] = (vx * c - vy * s) * sc
+        b[:, 8] = (vx * s + vy * c) * sc
     return b
+
+
+def object_range_filter(boxes, labels, pc_range):
+    """ObjectRangeFilter (mmdet3d, recalled): in_range_bev on the box centres (strict), labels follow, limit_yaw(0.5, 2 pi)."""
+    b = np.array(boxes, np.float32, copy=True)
+    x0, y0, x1, y1 = (np.float32(pc_range[i]) for i in (0, 1, 3, 4))
+    keep = (b[:, 0] > x0) & (b[:, 1] > y0) & (b[:, 0] < x1) & (b[:, 1] < y1)
+    b = b[keep]
+    two_pi = np.float32(6.283185307179586)
+    b[:, 6] = b[:, 6] - np.floor(b[:, 6] / two_pi + np.float32(0.5)) * two_pi
+    return b, np.asarray(labels)[keep]
 
 
 def range_filter(points, pc_range):

@@ -15,8 +15,9 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
-def bf16_deviation(device, B=2, npts=20000, seed=11):
-    """Returns dict: feature / logit relative L2 deviations, share of identical Hungarian assignments, worst relative loss deviation."""
+def bf16_deviation(device, B=2, npts=20000, seed=11, mode="bf16"):
+    """mode: "bf16" (throughput mode) or "mixed" (the reference's recipe: fp32 encoder + backbone, 16-bit neck + head).
+    Returns dict: feature / logit relative L2 deviations, share of identical Hungarian assignments, worst relative loss deviation."""
     import projects.mmdet3d_plugin  # noqa: F401
     from oracle import model as om
     from oracle.weights import seeded_tensor
@@ -34,7 +35,7 @@ def bf16_deviation(device, B=2, npts=20000, seed=11):
         if hasattr(m, "attn_drop"):
             m.attn_drop = 0.0
     model = model.to(device).train()
-    model.set_precision("bf16")
+    model.set_precision(mode)
     scenes = [room_scene(i, npts - 2500 * i) for i in range(B)]
     pts = [torch.from_numpy(s[0]) for s in scenes]
     gtb = []
@@ -63,6 +64,6 @@ def bf16_deviation(device, B=2, npts=20000, seed=11):
         "matched_assignments_identical_share": float((asg == aux["assigned"])[aux["assigned"] > 0].float().mean()),
         "loss_max_rel": max(abs(float(losses[k].detach()) - float(v)) / max(1.0, abs(float(v))) for k, v in ref_losses.items()),
         "loss_total_rel": abs(float(sum(losses.values()).detach()) - float(sum(ref_losses.values()))) / abs(float(sum(ref_losses.values()))),
-        "workload": f"{B} scenes x {npts} pts, seeded weights, dropout off",
+        "workload": f"{B} scenes x {npts} pts, seeded weights, dropout off", "mode": mode,
     }
     return out

@@ -46,13 +46,14 @@ def test_augment_points_and_boxes_match_oracle(cuda, coord, dim):
     sc = rng.uniform(0.85, 1.15, B).astype(np.float32)
     batch = dp.pack_batch([torch.from_numpy(p).cuda() for p in pts], [torch.from_numpy(b).cuda() for b in boxes],
                           box_type_3d="LiDAR" if coord == od.LIDAR else "Depth")
-    tab = np.stack([fh, fv, np.sin(ang), np.cos(ang), ang, sc], 1).astype(np.float32)
+    tr = rng.normal(0, 0.1, (B, 3)).astype(np.float32)                # GlobalRotScaleTrans translation_std (ScanNet configs)
+    tab = np.concatenate([np.stack([fh, fv, np.sin(ang), np.cos(ang), ang, sc], 1), tr], 1).astype(np.float32)
     tab = torch.from_numpy(tab).cuda()
     nv.points_augment(batch["points"], batch["scene_off"], tab, coord, 3)
     nv.boxes_augment(batch["gt_bboxes_3d"], batch["gt_off"], tab, coord)
     got_p, got_b = batch["points"].cpu().numpy(), batch["gt_bboxes_3d"].cpu().numpy()
-    exp_p = np.concatenate([od.augment_points(p, fh[i], fv[i], ang[i], sc[i], coord, 3) for i, p in enumerate(pts)])
-    exp_b = np.concatenate([od.augment_boxes(b, fh[i], fv[i], ang[i], sc[i], coord) for i, b in enumerate(boxes)])
+    exp_p = np.concatenate([od.augment_points(p, fh[i], fv[i], ang[i], sc[i], coord, 3, tr[i]) for i, p in enumerate(pts)])
+    exp_b = np.concatenate([od.augment_boxes(b, fh[i], fv[i], ang[i], sc[i], coord, tr[i]) for i, b in enumerate(boxes)])
     # f32 elementwise arithmetic on both sides; the device may contract a*b+c into an fma: 1 ulp of a coordinate of size <= 10
     np.testing.assert_allclose(got_p, exp_p, rtol=0, atol=2e-6)
     np.testing.assert_allclose(got_b, exp_b, rtol=0, atol=2e-6)
@@ -232,3 +233,39 @@ def test_device_pipeline_feeds_the_captured_training_step(cuda):
     assert all(np.isfinite(v) and 0 < v < 1e4 for v in losses), losses
     assert len({tuple(np.round(a, 6)) for a in angles}) == len(angles)            # a new draw every iteration
     assert ts.recaptures == 0
+
+
+
+def test_object_range_filter_on_device_and_all_shipped_pipelines_build(cuda):
+    """(a) ObjectRangeFilter runs after flip / rotation / scale in the KITTI / nuScenes pipelines, so it is a device transform
+    here: survivors (strict BEV range on the centres) keep their order, labels follow, yaw is wrapped into [-pi, pi) - against
+    oracle/datapath.py; (b) DevicePipeline builds the train AND test pipeline of every shipped configuration (CollectUnified3D,
+    ScanNet's translation_std, ...)."""
+    from uni3detr_amd import datapath as dp
+    rng = np.random.default_rng(77)
+    pc_range = [0, -40, -3, 70.4, 40, 1]
+    gcounts = [9, 0, 70, 1]                                            # a scene without boxes, one longer than a wave
+    boxes, labels = [], []
+    for n in gcounts:
+        b = np.concatenate([rng.uniform(-10, 80, (n, 1)), rng.uniform(-50, 50, (n, 1)), rng.uniform(-2, 0, (n, 1)), rng.uniform(0.5, 4, (n, 3)),
+                            rng.uniform(-7, 7, (n, 1)), rng.normal(0, 2, (n, 2))], 1).astype(np.float32)
+        boxes.append(b)
+        labels.append(rng.integers(0, 3, n).astype(np.int64))
+    pts = _scenes(rng, [100, 50, 80, 10])
+    batch = dp.pack_batch([torch.from_numpy(p).cuda() for p in pts], [torch.from_numpy(b).cuda() for b in boxes], box_type_3d="LiDAR",
+                          gt_labels_3d=[torch.from_numpy(l).cuda() for l in labels])
+    batch = dp.ObjectRangeFilter(pc_range)(batch)
+    _, gb, gl = dp.unpack_batch(batch)
+    for i in range(len(gcounts)):
+        eb, el = od.object_range_filter(boxes[i], labels[i], pc_range)
+        assert gb[i].tensor.shape[0] == eb.shape[0] and 0 <= eb.shape[0] <= gcounts[i]
+        np.testing.assert_allclose(gb[i].tensor.cpu().numpy(), eb, rtol=0, atol=2e-6)
+        assert np.array_equal(gl[i].cpu().numpy(), el)
+        if eb.shape[0]:
+            assert float(np.abs(eb[:, 6]).max()) <= np.pi + 1e-6
+    assert sum(int(c) for c in batch["gt_count"].tolist()) < sum(gcounts)          # something really was filtered
+    from uni3detr_amd.configs import pipelines as P
+    for name, cfg in P.SHIPPED.items():
+        for key in ("train_pipeline", "test_pipeline"):
+            pipe = dp.DevicePipeline(cfg[key])
+            assert pipe.transforms or key == "test_pipeline", (name, key)

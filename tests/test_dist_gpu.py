@@ -101,7 +101,10 @@ def test_world2_exchanged_gradient_is_the_mean_of_the_local_gradients(cuda, over
     for rank, err, differ, np_ok, norm in out:
         assert isinstance(err, float), err
         assert norm > 0 and differ > 1e-2                    # the two ranks' local gradients really are different ...
-        assert err < 1e-4, (rank, err)                       # ... and the exchanged one is their mean (f32 atomics reorder: 1e-4)
+        # ... and the exchanged one is their mean.  Two replays of the SAME bf16 step differ by ~1e-3 in relative L2 (the trilinear
+        # scatter's f32 atomics land in a different order, and a 1-ulp difference that crosses a bf16 rounding boundary is amplified by
+        # the backward of the dense stack); a wrong scale or a mis-sliced bucket - what this test is for - is an O(0.1 .. 1) error
+        assert err < 5e-3, (rank, err)
         assert np_ok
 
 

@@ -206,3 +206,21 @@ def test_unselected_registry_names_match_reference_goldens():
     b1 = torch.tensor([[0.5, 0, 0, 1.5, 1, 1], [2.0, 2, 2, 3, 3, 3]])
     assert torch.allclose(aa(b0, b1), torch.tensor([[-2.0 / 3.0, 0.0]]), atol=1e-6)
     assert MATCH_COST.build(dict(type="RotatedIoU3DCost", weight=1.0)).weight == 1.0
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/projects/configs/uni3detr"), reason="reference tree not present")
+def test_restated_pipelines_equal_the_shipped_config_files():
+    import glob
+    from uni3detr_amd.configs import pipelines as P
+    from uni3detr_amd.registry import Config
+    files = sorted(glob.glob("/root/reference/projects/configs/uni3detr/uni3detr_*.py"))
+    assert len(files) == len(P.SHIPPED) == 6
+    for f in files:
+        name = os.path.basename(f)[len("uni3detr_"):-3]
+        cfg = Config.fromfile(f)
+        for key in ("train_pipeline", "test_pipeline"):
+            ref, ours = getattr(cfg, key), P.SHIPPED[name][key]
+            assert [e["type"] for e in ref] == [e["type"] for e in ours], (name, key)
+            for r, o in zip(ref, ours):
+                for a, v in o.items():
+                    assert list(r[a]) == list(v) if isinstance(v, (list, tuple)) else r[a] == v, (name, key, a)

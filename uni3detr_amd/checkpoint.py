@@ -31,9 +31,23 @@ def convert_spconv_layout(name, t, want_shape):
     return None
 
 
-def load_checkpoint(model, checkpoint, map_location="cpu", strict=True):
-    """checkpoint: path | dict.  Returns the checkpoint dict (like mmcv).  Raises on unexpected / missing keys when strict."""
-    ck = torch.load(checkpoint, map_location=map_location, weights_only=False) if isinstance(checkpoint, (str, bytes)) else checkpoint
+def _load_file(path, map_location):
+    """Tensors-only unpickling first (a checkpoint from an untrusted source must not run code); checkpoints whose `meta` holds
+    arbitrary python objects (mmcv stores config text / env info: plain strings, but older runners pickled more) fall back to the
+    full unpickler, as the reference's torch.load does."""
+    try:
+        return torch.load(path, map_location=map_location, weights_only=True)
+    except Exception:                                     # noqa: BLE001 - any failure of the restricted unpickler
+        import warnings
+        warnings.warn(f"{path}: not loadable with weights_only=True; falling back to the full unpickler (trusted files only)")
+        return torch.load(path, map_location=map_location, weights_only=False)
+
+
+def load_checkpoint(model, checkpoint, map_location="cpu", strict=False):
+    """checkpoint: path | dict.  Returns the checkpoint dict (like mmcv).  strict=False is mmcv.runner.load_checkpoint's default (what
+    extra_tools/test.py:197 gets): missing / unexpected keys are REPORTED (meta['missing_keys'], meta['unexpected_keys'] and a
+    warning), not raised; shape mismatches always raise."""
+    ck = _load_file(checkpoint, map_location) if isinstance(checkpoint, (str, bytes)) else checkpoint
     sd = ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck
     own = model.state_dict()
     new, converted, bad_shape = collections.OrderedDict(), [], []
@@ -53,15 +67,21 @@ def load_checkpoint(model, checkpoint, map_location="cpu", strict=True):
     unexpected = [k for k in new if k not in own]
     if strict and (missing or unexpected):
         raise RuntimeError(f"load_checkpoint: missing keys {missing[:5]} unexpected keys {unexpected[:5]}")
+    if missing or unexpected:
+        import warnings
+        warnings.warn(f"load_checkpoint: {len(missing)} missing key(s) {missing[:5]}, {len(unexpected)} unexpected key(s) {unexpected[:5]}")
     model.load_state_dict(new, strict=False)
     if isinstance(ck, dict):
-        ck.setdefault("meta", {})["converted_sparse_weights"] = converted
+        meta = ck.setdefault("meta", {})
+        meta["converted_sparse_weights"] = converted
+        meta["missing_keys"], meta["unexpected_keys"] = missing, unexpected
     return ck
 
 
 def save_checkpoint(model, path, meta=None, optimizer_state=None, to_spconv2=False):
     """{'meta', 'state_dict' [, 'optimizer']} as the reference's runner writes it; to_spconv2 permutes the sparse conv weights to the
-    spconv 2.x layout."""
+    spconv 2.x layout.  optimizer_state: TrainStep.optimizer_state_dict() (flat AdamW moments + step count) for `resume_from`;
+    TrainStep.load_optimizer_state_dict(ck['optimizer']) puts it back."""
     sd = collections.OrderedDict()
     for k, v in model.state_dict().items():
         v = v.detach().cpu()

@@ -8,7 +8,8 @@
 //
 // Layout: points of all scenes packed [n_total, F] f32, scene b = rows scene_off[b] .. scene_off[b+1]); boxes packed [G, D]
 // (x, y, z, dx, dy, dz, yaw [, vx, vy]), scene b = rows gt_off[b] .. gt_off[b+1]).  Per-scene parameters: f32 [B][U3D_AUG_NPARAM]
-// = (flip_horizontal, flip_vertical, rot_sin, rot_cos, rot_angle, scale).  Everything is order-preserving and deterministic.
+// = (flip_horizontal, flip_vertical, rot_sin, rot_cos, rot_angle, scale, tx, ty, tz): flip -> rotate -> scale -> translate, the order of
+// mmdet3d's GlobalRotScaleTrans.  Everything is order-preserving and deterministic.
 #include "common.h"
 
 #define AUG_NP U3D_AUG_NPARAM
@@ -43,7 +44,7 @@ __global__ void k_points_augment(float* __restrict__ pts, const int* __restrict_
   // row vector times rot_mat_T = [[c, s, 0], [-s, c, 0], [0, 0, 1]] (transform_3d.py:380-383), then the uniform scale
   const float s = p[2], c = p[3], sc = p[5];
   const float xr = x * c - y * s, yr = x * s + y * c;
-  r[0] = xr * sc; r[1] = yr * sc; r[2] = z * sc;
+  r[0] = xr * sc + p[6]; r[1] = yr * sc + p[7]; r[2] = z * sc + p[8];      // translation last (GlobalRotScaleTrans translation_std, ScanNet configs)
   if (height_dim >= 3 && height_dim < feat) r[height_dim] *= sc;          // shift_height=True: the height attribute scales too (:411-415)
 }
 
@@ -62,15 +63,16 @@ __global__ void k_boxes_augment(float* __restrict__ boxes, const int* __restrict
   if (coord == 0) { if (fh) yaw = -yaw + PI; if (fv) yaw = -yaw; }
   else { if (fh) yaw = -yaw; if (fv) yaw = -yaw + PI; }
   const float s = p[2], c = p[3], sc = p[5];
-  r[0] = (x * c - y * s) * sc;
-  r[1] = (x * s + y * c) * sc;
-  r[2] *= sc; r[3] *= sc; r[4] *= sc; r[5] *= sc;
+  r[0] = (x * c - y * s) * sc + p[6];
+  r[1] = (x * s + y * c) * sc + p[7];
+  r[2] = r[2] * sc + p[8];
+  r[3] *= sc; r[4] *= sc; r[5] *= sc;
   r[6] = yaw + p[4];
-  if (dim >= 9) {                                                         // velocities rotate (and flip) with the frame, do not scale
+  if (dim >= 9) {      // velocities flip and rotate with the frame and SCALE with it (mmdet3d BaseInstance3DBoxes.scale: tensor[:, 7:] *= s, recalled)
     float vx = r[7], vy = r[8];
     dp_flip_xy(coord, fh, fv, vx, vy);
-    r[7] = vx * c - vy * s;
-    r[8] = vx * s + vy * c;
+    r[7] = (vx * c - vy * s) * sc;
+    r[8] = (vx * s + vy * c) * sc;
   }
 }
 
@@ -165,6 +167,37 @@ __global__ void k_point_sample(const float* __restrict__ pts, const int* __restr
   if (idx_out) idx_out[gi] = (int)j;
 }
 
+// ObjectRangeFilter (mmdet3d, recalled: keep boxes whose BEV centre lies strictly inside (x0, y0, x1, y1) = in_range_bev, then
+// limit_yaw(offset 0.5, period 2 pi): yaw -= floor(yaw / 2pi + 0.5) * 2pi).  One wave per scene compacts the survivors (order kept) to
+// the front of the scene's own segment of boxes / labels; count[b] = survivors.  Segments longer than 64 boxes are walked in chunks.
+__global__ __launch_bounds__(64) void k_boxes_range_filter(float* __restrict__ boxes, int* __restrict__ labels, const int* __restrict__ gt_off, int dim,
+                                                           float x0, float y0, float x1, float y1, int* __restrict__ count) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int r0 = gt_off[b], r1 = gt_off[b + 1];
+  int base = 0;
+  for (int c0 = r0; c0 < r1; c0 += 64) {
+    const int i = c0 + lane;
+    float v[9];
+    int lab = 0;
+    bool keep = false;
+    if (i < r1) {
+      for (int f = 0; f < dim; ++f) v[f] = boxes[(long long)i * dim + f];
+      lab = labels ? labels[i] : 0;
+      keep = v[0] > x0 && v[1] > y0 && v[0] < x1 && v[1] < y1;
+      const float TWO_PI = 6.283185307179586f;
+      v[6] = v[6] - floorf(v[6] / TWO_PI + 0.5f) * TWO_PI;
+    }
+    const unsigned long long m = __ballot(keep);          // every lane has read its row before any lane writes (one wave, in order)
+    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep) {
+      for (int f = 0; f < dim; ++f) boxes[(long long)(r0 + pos) * dim + f] = v[f];
+      if (labels) labels[r0 + pos] = lab;
+    }
+    base += __popcll(m);
+  }
+  if (lane == 0) count[b] = base;
+}
+
 extern "C" int32_t u3d_points_augment(float* points, const int32_t* scene_off, int32_t batch, int32_t n_total, int32_t feat,
                                       const float* params, int32_t coord, int32_t height_dim, u3d_stream s) {
   U3D_REQUIRE(points && scene_off && params && batch > 0 && feat >= 3 && (coord == 0 || coord == 1), U3D_ERR_ARG);
@@ -195,6 +228,14 @@ extern "C" int32_t u3d_point_sample(const float* points, const int32_t* scene_of
   const long long total = (long long)batch * num_points;
   hipLaunchKernelGGL(k_point_sample, dim3(u3d_cdiv(total, 256)), dim3(256), 0, s, points, scene_off, count, batch, feat, num_points,
                      (const unsigned long long*)seed, out, idx_out);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+extern "C" int32_t u3d_boxes_range_filter(float* boxes, int32_t* labels, const int32_t* gt_off, int32_t batch, int32_t box_dim,
+                                          const float* bev_range4, int32_t* count, u3d_stream s) {
+  U3D_REQUIRE(boxes && gt_off && bev_range4 && count && batch > 0 && (box_dim == 7 || box_dim == 9), U3D_ERR_ARG);
+  hipLaunchKernelGGL(k_boxes_range_filter, dim3(batch), dim3(64), 0, s, boxes, labels, gt_off, box_dim, bev_range4[0], bev_range4[1],
+                     bev_range4[2], bev_range4[3], count);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

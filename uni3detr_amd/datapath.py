@@ -26,21 +26,22 @@ def _coord(batch):
 
 
 def _params(batch):
-    """Device parameter table [B,6] = (flip_h, flip_v, sin, cos, angle, scale) from the draws recorded in the batch dict."""
+    """Device parameter table [B,9] = (flip_h, flip_v, sin, cos, angle, scale, tx, ty, tz) from the draws recorded in the batch dict."""
     B = batch["scene_off"].numel() - 1
     fh = np.asarray(batch.get("pcd_horizontal_flip", np.zeros(B, bool)), np.float32)
     fv = np.asarray(batch.get("pcd_vertical_flip", np.zeros(B, bool)), np.float32)
     ang = np.asarray(batch.get("pcd_rotation_angle", np.zeros(B)), np.float32)
     sc = np.asarray(batch.get("pcd_scale_factor", np.ones(B)), np.float32)
-    tab = np.stack([fh, fv, np.sin(ang), np.cos(ang), ang, sc], 1).astype(np.float32)
+    tr = np.asarray(batch.get("pcd_trans", np.zeros((B, 3))), np.float32).reshape(B, 3)
+    tab = np.concatenate([np.stack([fh, fv, np.sin(ang), np.cos(ang), ang, sc], 1), tr], 1).astype(np.float32)
     return torch.from_numpy(tab).to(batch["points"].device)
 
 
-def _apply(batch, fh, fv, ang, sc, height_dim):
+def _apply(batch, fh, fv, ang, sc, height_dim, trans=None):
     """One launch over the points (+ one over the boxes) for the given per-scene draws; identity entries cost nothing extra."""
     B = batch["scene_off"].numel() - 1
     tmp = dict(scene_off=batch["scene_off"], points=batch["points"], pcd_horizontal_flip=fh, pcd_vertical_flip=fv,
-               pcd_rotation_angle=ang, pcd_scale_factor=sc)
+               pcd_rotation_angle=ang, pcd_scale_factor=sc, pcd_trans=np.zeros((B, 3), np.float32) if trans is None else trans)
     tab = _params(tmp)
     coord = _coord(batch)
     nv.points_augment(batch["points"], batch["scene_off"], tab, coord, height_dim)
@@ -93,30 +94,37 @@ class UnifiedRandomFlip3D(RandomFlip3D):
 
 @PIPELINES.register_module()
 class GlobalRotScaleTrans:
-    """ref: mmdet3d GlobalRotScaleTrans as configured at uni3detr_sunrgbd.py:164-168; translation_std = 0 in every shipped config
-    (a non-zero value raises)."""
+    """ref: mmdet3d GlobalRotScaleTrans as configured at uni3detr_sunrgbd.py:164-168 and, with translation_std = [.1, .1, .1], in the
+    two ScanNet configs (uni3detr_scannet.py / uni3detr_scannet_large.py train_pipeline): rotate -> scale -> translate, the translation
+    one normal draw per axis and scene added to the points and to the box centres (upstream `_trans_bbox_points`, recalled)."""
 
     def __init__(self, rot_range=(-0.78539816, 0.78539816), scale_ratio_range=(0.95, 1.05), translation_std=(0, 0, 0), shift_height=False):
         if not isinstance(rot_range, (list, tuple, np.ndarray)):
             rot_range = [-rot_range, rot_range]
-        if np.any(np.asarray(translation_std, np.float32) != 0):
-            raise NotImplementedError("translation_std != 0 is not used by any shipped Uni3DETR config")
+        if not isinstance(translation_std, (list, tuple, np.ndarray)):
+            translation_std = [translation_std] * 3
+        assert len(translation_std) == 3 and all(t >= 0 for t in translation_std), "invalid translation_std"
+        self.translation_std = np.asarray(translation_std, np.float32)
         self.rot_range, self.scale_ratio_range, self.shift_height = list(rot_range), list(scale_ratio_range), shift_height
 
     def __call__(self, batch):
         B = batch["scene_off"].numel() - 1
-        if "pcd_rotation_angle" not in batch:        # per sample: rotation first, then scale (transform_3d.py:456-460)
-            ang, sc = np.zeros(B, np.float32), np.ones(B, np.float32)
+        if "pcd_rotation_angle" not in batch:        # per sample: rotation first, then scale, then translation (transform_3d.py:456-460)
+            ang, sc, tr = np.zeros(B, np.float32), np.ones(B, np.float32), np.zeros((B, 3), np.float32)
             for b in range(B):
                 ang[b] = np.random.uniform(self.rot_range[0], self.rot_range[1])
                 sc[b] = np.random.uniform(self.scale_ratio_range[0], self.scale_ratio_range[1])
+                if np.any(self.translation_std != 0):
+                    tr[b] = np.random.normal(scale=self.translation_std, size=3)
             batch["pcd_rotation_angle"] = ang
             batch.setdefault("pcd_scale_factor", sc)
+            batch.setdefault("pcd_trans", tr)
         ang = np.asarray(batch["pcd_rotation_angle"], np.float32)
         sc = np.asarray(batch.get("pcd_scale_factor", np.ones(B)), np.float32)
+        tr = np.asarray(batch.get("pcd_trans", np.zeros((B, 3))), np.float32).reshape(B, 3)
         hd = int(batch.get("height_dim", 3)) if self.shift_height else -1
         batch.setdefault("transformation_3d_flow", []).extend(["R", "S", "T"])
-        return _apply(batch, np.zeros(B, bool), np.zeros(B, bool), ang, sc, hd)
+        return _apply(batch, np.zeros(B, bool), np.zeros(B, bool), ang, sc, hd, tr)
 
 
 @PIPELINES.register_module()
@@ -164,8 +172,44 @@ class PointSample:
         return batch
 
 
-_PASSTHROUGH = {"LoadPointsFromFile", "LoadAnnotations3D", "DefaultFormatBundle3D", "Collect3D", "LoadPointsFromMultiSweeps",
-                "ObjectRangeFilter", "ObjectNameFilter", "PointShuffle", "ObjectSample", "UnifiedObjectSample", "ObjectNoise"}
+@PIPELINES.register_module()
+class ObjectRangeFilter:
+    """ref: uni3detr_kitti_3classes.py / uni3detr_nuscenes.py train_pipeline (mmdet3d ObjectRangeFilter, recalled): ground-truth boxes
+    whose BEV centre left (x0, y0, x1, y1) after flip / rotation / scale are dropped together with their labels, yaw is wrapped into
+    [-pi, pi).  It runs AFTER the geometric augmentation, so with the augmentation on the device it has to be a device transform too:
+    per scene, in place, order kept; `gt_count` says how many rows at the front of every scene's segment are live."""
+
+    def __init__(self, point_cloud_range):
+        r = [float(v) for v in point_cloud_range]
+        self.bev_range = [r[0], r[1], r[3], r[4]]
+
+    def __call__(self, batch):
+        g = batch.get("gt_bboxes_3d")
+        if g is None:
+            return batch
+        lab = batch.get("gt_labels_3d")
+        if lab is not None and lab.dtype != torch.int32:
+            lab = batch["gt_labels_3d"] = lab.to(torch.int32)
+        batch["gt_count"] = nv.boxes_range_filter(g, lab, batch["gt_off"], self.bev_range)
+        return batch
+
+
+@PIPELINES.register_module()
+class MultiScaleFlipAug3D:
+    """Test-time wrapper (mmdet3d): one scale, no flip in the plugin's use - the inner transforms run as they are."""
+
+    def __init__(self, transforms, img_scale=None, pts_scale_ratio=1, flip=False, **kwargs):
+        if flip or (pts_scale_ratio not in (1, 1.0, [1], [1.0])):
+            raise NotImplementedError("test-time flips / point scaling are not used by any shipped Uni3DETR config")
+        self.inner = DevicePipeline(transforms)
+
+    def __call__(self, batch):
+        return self.inner(batch)
+
+
+_PASSTHROUGH = {"LoadPointsFromFile", "LoadAnnotations3D", "DefaultFormatBundle3D", "Collect3D", "CollectUnified3D", "LoadPointsFromMultiSweeps",
+                "ObjectNameFilter", "PointShuffle", "ObjectSample", "UnifiedObjectSample", "ObjectNoise", "NormalizePointsColor",
+                "LoadImageFromFile", "LoadMultiViewImageFromFiles"}
 
 
 class DevicePipeline:
@@ -188,8 +232,9 @@ class DevicePipeline:
         return batch
 
 
-def pack_batch(points, gt_bboxes_3d=None, box_type_3d="Depth", height_dim=3):
-    """list of per-scene [n_i,F] tensors (+ list of [g_i,7|9] box tensors) on one device -> the batch dict the transforms take."""
+def pack_batch(points, gt_bboxes_3d=None, box_type_3d="Depth", height_dim=3, gt_labels_3d=None):
+    """list of per-scene [n_i,F] tensors (+ list of [g_i,7|9] box tensors, + list of label tensors) on one device -> the batch dict
+    the transforms take."""
     dev = points[0].device
     lens = [int(p.shape[0]) for p in points]
     off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32), device=dev)
@@ -200,6 +245,9 @@ def pack_batch(points, gt_bboxes_3d=None, box_type_3d="Depth", height_dim=3):
         dim = gt_bboxes_3d[0].shape[1] if len(gt_bboxes_3d) else 7
         batch["gt_bboxes_3d"] = (torch.cat([g.float() for g in gt_bboxes_3d]).contiguous() if sum(gl)
                                  else torch.zeros((0, dim), dtype=torch.float32, device=dev))
+        if gt_labels_3d is not None:
+            batch["gt_labels_3d"] = (torch.cat([l.to(torch.int32) for l in gt_labels_3d]).contiguous() if sum(gl)
+                                     else torch.zeros((0,), dtype=torch.int32, device=dev))
     return batch
 
 
@@ -215,7 +263,10 @@ def unpack_batch(batch, labels=None):
     out = [pts]
     if "gt_bboxes_3d" in batch:
         go = batch["gt_off"].tolist()
-        out.append([Boxes3D(batch["gt_bboxes_3d"][go[b]:go[b + 1]]) for b in range(len(go) - 1)])
+        gc = batch["gt_count"].tolist() if "gt_count" in batch else [go[b + 1] - go[b] for b in range(len(go) - 1)]     # ObjectRangeFilter survivors
+        out.append([Boxes3D(batch["gt_bboxes_3d"][go[b]:go[b] + gc[b]]) for b in range(len(go) - 1)])
+        if labels is None and "gt_labels_3d" in batch:
+            labels = [batch["gt_labels_3d"][go[b]:go[b] + gc[b]].long() for b in range(len(go) - 1)]
     if labels is not None:
         out.append(labels)
     return tuple(out)

@@ -68,6 +68,7 @@ _SIGS = {
     "u3d_boxes_augment": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
     "u3d_points_range_filter": (_I, [_P, _P, _I, _I, C.POINTER(C.c_float), _P, _P, _P]),
     "u3d_point_sample": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "u3d_boxes_range_filter": (_I, [_P, _P, _P, _I, _I, C.POINTER(C.c_float), _P, _P]),
     "u3d_event_create": (_I, [C.POINTER(C.c_void_p)]),
     "u3d_event_record": (_I, [C.c_void_p, _I, _P]),
     "u3d_event_elapsed_ms": (_I, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
@@ -1185,11 +1186,12 @@ def dropout_mask(rng, layer, site, n, p, cols=0):
 # --------------------------------------------------------------------------------------------------
 # on-device data path
 # --------------------------------------------------------------------------------------------------
-AUG_NPARAM = 6
+AUG_NPARAM = 9
 
 
 def points_augment(points, scene_off, params, coord, height_dim=-1):
-    """In place on points [N,F] f32: per-scene flip -> rotation -> scale; params f32 [B,6] (flip_h, flip_v, sin, cos, angle, scale)."""
+    """In place on points [N,F] f32: per-scene flip -> rotation -> scale -> translation; params f32 [B,9]
+    (flip_h, flip_v, sin, cos, angle, scale, tx, ty, tz)."""
     assert points.dtype == torch.float32 and points.is_contiguous() and params.dtype == torch.float32 and params.shape[1] == AUG_NPARAM
     batch = scene_off.numel() - 1
     _check(lib().u3d_points_augment(_ptr(points), _ptr(scene_off), batch, points.shape[0], points.shape[1], _ptr(params.contiguous()),
@@ -1203,6 +1205,18 @@ def boxes_augment(boxes, gt_off, params, coord):
     _check(lib().u3d_boxes_augment(_ptr(boxes), _ptr(gt_off), batch, boxes.shape[0], boxes.shape[1], _ptr(params.contiguous()), int(coord),
                                    _stream()), "boxes_augment")
     return boxes
+
+
+def boxes_range_filter(boxes, labels, gt_off, bev_range):
+    """ObjectRangeFilter in place: (boxes, labels) of every scene compacted to the front of its segment -> count int32 [B]."""
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.shape[1] in (7, 9)
+    assert labels is None or (labels.dtype == torch.int32 and labels.is_contiguous())
+    batch = gt_off.numel() - 1
+    count = torch.empty((batch,), dtype=torch.int32, device=boxes.device)
+    rng = (C.c_float * 4)(*[float(v) for v in bev_range])
+    _check(lib().u3d_boxes_range_filter(_ptr(boxes), _ptr(labels), _ptr(gt_off), batch, boxes.shape[1], rng, _ptr(count), _stream()),
+           "boxes_range_filter")
+    return count
 
 
 def points_range_filter(points, scene_off, pc_range, out=None):

@@ -109,8 +109,14 @@ class Uni3DETR(nn.Module):
         return          # as the reference (ref :140-141): constructor-default init is what training really starts from
 
     def set_precision(self, mode):
-        assert mode in ("fp32", "bf16")
-        self.amp_dtype = torch.bfloat16 if mode == "bf16" else None
+        """'fp32': parity mode (exact-f32 MFMA everywhere); 'bf16': throughput mode (BASELINE configs[1]); 'mixed': the REFERENCE's
+        recipe - SparseEncoderHD and SECOND3D in fp32 (ref: sparse_encoder_hd.py:62-64 fp16_enabled=False, uni3detr.py:150-151; the
+        backbone is not wrapped in auto_fp16), neck + head in 16-bit (second3d_fpn.py:45 auto_fp16, uni3detr_sunrgbd.py:241
+        fp16 loss scaling): fp32-grade features at the price of running 2/3 of the convolution flops on the f32 matrix pipe (1/16
+        of the bf16 rate)."""
+        assert mode in ("fp32", "bf16", "mixed")
+        self.precision = mode
+        self.amp_dtype = None if mode == "fp32" else torch.bfloat16
         if self.pts_middle_encoder is not None:
             self.pts_middle_encoder.compute_dtype = torch.bfloat16 if mode == "bf16" else torch.float32
         return self
@@ -234,8 +240,10 @@ class Uni3DETR(nn.Module):
         amp = self.amp_dtype
         with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
             if self.with_pts_backbone:
-                x = self.pts_backbone(x)
+                x = self.pts_backbone(x)              # follows the dtype of its input rows: fp32 in 'mixed' mode (the encoder's dense())
             if self.with_pts_neck:
+                if getattr(self, "precision", None) == "mixed":
+                    x = tuple(t.to(torch.bfloat16) for t in x) if isinstance(x, (tuple, list)) else x.to(torch.bfloat16)
                 x = self.pts_neck(x)
         cur.wait_stream(side)
         for t in (cat, coors, voxel_off, scene_off):
