@@ -924,3 +924,83 @@ def test_eight_phase_256x128_kernel_bit_identical_to_the_128_tile_kernel(cuda, c
     for i in range(16):
         assert torch.equal(nv.spconv_fwd(x, w, geom.nbr_fwd, nd, n_full, C, transpose_w=True, tag="spconv_fwd")[:n], yp[:n]), i
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("seed,n_pts,dims,cut", [(5, 9000, (16, 40, 36), 0), (11, 60000, (12, 64, 64), 777), (3, 300, (8, 8, 8), 0)])
+def test_subm_halo_kernel_matches_the_table_kernels(cuda, seed, n_pts, dims, cut):
+    """subm_halo.hip (64 -> 64 SubM convs out of each tile's staged DISTINCT rows): the slot tables reproduce the neighbour table
+    exactly (integer work: bit-exact), and forward / statistics / input gradient with addend equal the f32 gather-matmul to bf16
+    rounding, with a device-side row count below the capacity (dead rows hold NaN), a dense level whose tiles exceed the staged-slot
+    budget (global-memory fall-back rows) and a level smaller than one tile."""
+    import torch
+    from uni3detr_amd import native as nv
+    lvl, nbr = _level(seed=seed, n_pts=n_pts, dims=dims)
+    n_cap = lvl.n
+    n = n_cap - cut
+    cnt = nv.count_tensor(n, "cuda") if cut else lvl.n_dev
+    nb = nbr.clone()
+    if cut:
+        nb[:, :n][nb[:, :n] >= n] = -1
+    halo = nv.SubmHalo(nb, cnt, n_cap)
+    # 1. integer work: tile_rows[tile][loc] == the table, slots sorted and distinct
+    T = halo.tiles
+    rows = halo.tile_rows.view(T, -1).long()
+    loc = (halo.loc.view(T, 27, 16, 8).long() & 0xffff).permute(0, 1, 3, 2).reshape(T, 27, 128)         # [tile][k][mt * 16 + r16]
+    tc = halo.tile_cnt.long()
+    assert int(tc.max()) <= 27 * 128 + 1 and int(loc.max()) < int(tc.max())
+    recon = torch.gather(rows, 1, loc.reshape(T, -1)).view(T, 27, 128).permute(1, 0, 2).reshape(27, -1)[:, :n]
+    assert torch.equal(recon.int(), nb[:, :n])
+    for t in (0, T // 2, T - 1):
+        r = rows[t, 1:int(tc[t])]
+        assert (r[1:] > r[:-1]).all()
+    # 2. forward + statistics, input gradient with addend
+    torch.manual_seed(seed)
+    x = torch.randn(n_cap, 64, device="cuda").bfloat16()
+    add = torch.randn(n_cap, 64, device="cuda").bfloat16()
+    if cut:
+        x[n:] = float("nan"); add[n:] = float("nan")
+    w = (torch.randn(27, 64, 64, device="cuda") * 0.1).bfloat16()               # n-major [K][out][reduction]
+    wp = nv.subm_halo_wpack(w)
+    y, stats, tr = nv.subm_halo_conv(x, wp, halo, want_stats=True)
+    exp = _ref_conv(x[:n], w.transpose(1, 2), nb, n)
+    sc = exp.abs().max()
+    assert torch.isfinite(y[:n]).all() and (y[:n].float() - exp).abs().max() / sc < 6e-3
+    assert tr == 128 and stats.shape == (T, 2, 64)
+    yf = y[:n].double()
+    assert (stats[:, 0].sum(0) - yf.sum(0)).abs().max() < 1e-3 * yf.abs().sum(0).max()
+    assert (stats[:, 1].sum(0) - (yf * yf).sum(0)).abs().max() < 1e-4 * (yf * yf).sum(0).max()
+    assert torch.equal(nv.subm_halo_conv(x, wp, halo)[:n], y[:n])                 # deterministic, statistics do not change the output
+    # offsets reversed == the transposed table (test_subm_transposed_table_is_the_reversed_forward_table)
+    g = nv.subm_halo_conv(x, wp, halo, krev=True, addend=add)
+    expg = _ref_conv(x[:n], w.transpose(1, 2), nb.flip(0), n) + add[:n].float()
+    assert (g[:n].float() - expg).abs().max() / expg.abs().max() < 6e-3
+    # against the LDS-DMA kernels on the same operands: same products, different f32 summation order -> one bf16 ulp at most
+    ref = nv.spconv_fwd(x, w, nb, cnt, n_cap, 64, transpose_w=True)[:n].float()
+    assert (y[:n].float() - ref).abs().max() / sc < 8e-3
+
+
+def test_subm_halo_used_by_the_64_channel_blocks(cuda):
+    """sparse._SparseConv routes 64 -> 64 SubM convs (forward, statistics epilogue, input gradient with the residual addend) through
+    the halo kernel; result and gradients equal the table path's to bf16 rounding."""
+    import torch
+    from uni3detr_amd import native as nv, sparse as sp
+    lvl, _ = _level(seed=7, n_pts=30000, dims=(12, 48, 48))
+    torch.manual_seed(1)
+    x0 = torch.randn(lvl.n, 64, device="cuda").bfloat16()
+    w0 = (torch.randn(3, 3, 3, 64, 64, device="cuda") * 0.05)
+    dy = torch.randn(lvl.n, 64, device="cuda").bfloat16()
+    res = {}
+    for on in (True, False):
+        sp.SUBM_HALO = on
+        try:
+            lv = sp.Level(lvl.grid, lvl.coords, lvl.n, lvl.n_dev)
+            x = x0.clone().requires_grad_(True)
+            w = w0.clone().requires_grad_(True)
+            y, st = sp._SparseConv.apply(x, w, sp.subm_geom(lv), "dhwio", True)
+            assert (lv._halo is not None) == on
+            y.backward(dy)
+            res[on] = (y.detach().float(), st.double().sum(0), x.grad.float(), w.grad.float())
+        finally:
+            sp.SUBM_HALO = True
+    for a, b, tol in zip(res[True], res[False], (8e-3, 1e-3, 8e-3, 1e-5)):
+        assert (a - b).abs().max() / b.abs().max() < tol

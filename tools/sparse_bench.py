@@ -25,22 +25,16 @@ def ref_fwd(x, w, nbr, n):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=30)
-    ap.add_argument("--only", default=None)
-    ap.add_argument("--check", action="store_true")
-    ap.add_argument("--batch", type=int, default=8)
-    a = ap.parse_args()
-    dev = torch.device("cuda:0")
+def build_jobs(batch, dev):
+    """[(name, cin, cout, ConvGeom)] of the bench workload's sparse levels."""
     import projects.mmdet3d_plugin  # noqa: F401
     from uni3detr_amd.configs.sunrgbd import model as MODEL_CFG
     from uni3detr_amd.registry import build_model
     model = build_model(MODEL_CFG).to(dev).train()
-    data = bench.make_batch(0, a.batch, 20000, dev)
+    data = bench.make_batch(0, batch, 20000, dev)
     coors = model.voxelize_batch(data["points"])[0]
     enc = model.pts_middle_encoder
-    lvl, _ = sp.level_from_coors(coors.int().contiguous(), a.batch, enc.sparse_shape)
+    lvl, _ = sp.level_from_coors(coors.int().contiguous(), batch, enc.sparse_shape)
     # (name, cin, cout, geom): the SubM convs of a level share one table; the strided conv into the next level has its own
     jobs = []
     cin = enc.base_channels
@@ -56,6 +50,18 @@ def main():
             jobs.append((f"L{i} down N={lvl.n}->{new.n}", cin, blocks[-1], geom))
             lvl = new
             cin = blocks[-1]
+    return jobs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--batch", type=int, default=8)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    jobs = build_jobs(a.batch, dev)
     torch.manual_seed(0)
     for name, ci, co, g in jobs:
         tagname = f"{name} {ci}->{co}"
@@ -72,6 +78,19 @@ def main():
             "dgrad": lambda: nv.spconv_fwd(dy, w, g.nbr_bwd, g.n_in_dev, g.n_in, ci, transpose_w=True),
             "wgrad": lambda: nv.spconv_wgrad(x, dy, g.nbr_fwd, g.n_out_dev, 27),
         }
+        if ci == 64 and co == 64 and g.level is not None:
+            halo = g.level.halo()
+            tc = halo.tile_cnt.float()
+            print(f"{tagname:34s} halo: {halo.tiles} tiles, distinct rows per tile mean {tc.mean().item():.0f} p50 {tc.median().item():.0f} "
+                  f"p90 {tc.quantile(0.9).item():.0f} max {tc.max().item():.0f}", flush=True)
+            wn = w.transpose(1, 2).contiguous()
+            passes["fwd_nmajor_stats"] = lambda: nv.spconv_fwd_stats(x, wn, g.nbr_fwd, g.n_out_dev, g.n_out, co)
+            passes["halo_build"] = lambda: nv.SubmHalo(g.nbr_fwd, g.n_out_dev, g.n_out)
+            wpf, wpb = nv.subm_halo_wpack(wn), nv.subm_halo_wpack(w)
+            passes["halo_wpack"] = lambda: nv.subm_halo_wpack(wn)
+            passes["halo_fwd"] = lambda: nv.subm_halo_conv(x, wpf, halo)
+            passes["halo_fwd_stats"] = lambda: nv.subm_halo_conv(x, wpf, halo, want_stats=True)
+            passes["halo_dgrad"] = lambda: nv.subm_halo_conv(dy, wpb, halo, krev=True)
         for pname, fn in passes.items():
             for _ in range(3):
                 fn()

@@ -1,0 +1,419 @@
+// Output-stationary "halo" kernel for the 64 -> 64 channel, 27-offset submanifold level (ref: sparse_encoder_hd.py:106-138, the
+// SparseBasicBlock convs of the stride-4 stage; spconv's SubMConv3d gathers each of the 27 offsets' rows again).
+//
+// The LDS-DMA implicit-GEMM kernel (igemm_bf16.hip) fetches, per 128-row output tile, 27 x 128 operand rows of 128 B through
+// 27 x 128 one-row DMA pieces: its time at this level (92 us for 211 k rows) is the issue cost of those pieces, not HBM and not
+// MFMA.  But rows are numbered in 4x4x4-block-major order, so the 27 x 128 table entries of a tile name
+// only ~250-450 DISTINCT rows (the tile's cells plus a one-cell shell).  This path
+//   1. k_halo_build  (once per level and step, shared by the level's 2 x 4 convs and their input gradients): per tile, the sorted
+//      distinct table entries (LDS bitmap) -> tile_rows[tile][slot] (slot 0 = the all-zero row), and the table rewritten as 16-bit
+//      LDS slots loc[tile][offset][row];
+//   2. k_subm_halo64: stage the tile's distinct rows ONCE (coalesced 16 B loads, 144 B LDS row stride), then run all 27 offsets
+//      out of LDS without a barrier: wave w takes offsets w, w+4, ... for the whole 128 x 64 tile (64 MFMAs per 16 LDS reads and 8
+//      weight-fragment loads - the split over offsets is what keeps LDS and L1 traffic 8 x below the MFMA time), and the four
+//      partial tiles are summed by a two-round reduce-scatter through the (by then dead) stage buffer.
+// The transposed table of a SubM layer is the forward one with the offsets reversed, so the same loc[] serves the input gradient
+// (krev: offset k reads loc[26 - k]).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define HL_T 128                 /* output rows per tile */
+#define HL_K 27
+#define HL_C 64
+#define HL_TRC 3460              /* tile_rows row length: 1 + 27 * 128 slots at most, padded to 16 B */
+#define HL_RS 72                 /* LDS row stride in elements: 144 B - consecutive slots land on distinct 4-bank groups */
+#ifndef HL_MAXS
+#define HL_MAXS 552              /* staged slots per tile (79.5 KB: two workgroups per CU); slots beyond are read from global memory */
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// table build
+// ---------------------------------------------------------------------------------------------------------------------------
+#ifdef HL_PHASE_TIMING       /* tools/halo_phase.py: shader-clock stamps of a few workgroups at the phase boundaries */
+__device__ unsigned long long hl_dbg[8 * 8];
+#define HL_MARK(id) do { if ((blockIdx.x & 255) == 7 && blockIdx.x < 8 * 256 && threadIdx.x == 0) hl_dbg[(blockIdx.x >> 8) * 8 + id] = __builtin_readcyclecounter(); } while (0)
+extern "C" int32_t u3d_debug_halo_times(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(hl_dbg), 64 * 8) == hipSuccess ? 0 : -1; }
+__device__ unsigned long long hb_dbg[8 * 8];
+#define HB_MARK(id) do { if ((blockIdx.x & 255) == 7 && blockIdx.x < 8 * 256 && threadIdx.x == 0) hb_dbg[(blockIdx.x >> 8) * 8 + id] = __builtin_readcyclecounter(); } while (0)
+extern "C" int32_t u3d_debug_halo_build_times(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(hb_dbg), 64 * 8) == hipSuccess ? 0 : -1; }
+#else
+#define HL_MARK(id)
+#define HB_MARK(id)
+#endif
+// Distinct rows of a tile, sorted, without sorting: the keys are row numbers < n_cap, so the tile marks them in an LDS BITMAP over
+// all rows (n_cap / 8 bytes; fire-and-forget ds_or), a popcount prefix over the bitmap words numbers the set bits in ascending
+// order, and an entry's slot is prefix[word] + popcount(bits below) + 1 - two LDS reads.  (A hash set + bitonic sort of the keys
+// took 44 us per level, a sort of the raw 27 x 128 entries 180 us; sorted slots keep the neighbours of consecutive rows on
+// consecutive LDS rows - conflict-free fragment reads in k_subm_halo64.)
+// dynamic LDS: bitmap u32 [W] | word prefix u16 [W] | part int [256], W = words rounded up to a multiple of 256
+__global__ __launch_bounds__(256) void k_halo_build(const int32_t* __restrict__ nbr, int ld, const int32_t* __restrict__ n_dev, int n_cap,
+                                                    int wpt, int32_t* __restrict__ tile_rows, u16* __restrict__ loc,
+                                                    int32_t* __restrict__ tile_cnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int W = wpt * 256;
+  unsigned* bits = (unsigned*)smem;
+  u16* wpre = (u16*)(bits + W);
+  int* part = (int*)(wpre + W);
+  const int tid = threadIdx.x, tile = blockIdx.x;
+  const int m0 = tile * HL_T;
+  const int n = min(*n_dev, n_cap);
+  HB_MARK(0);
+  // entry e of the tile in OUTPUT order (k, r16, mt): e = k * 128 + r16 * 8 + mt <-> row mt * 16 + r16; kept in registers
+  int gs[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    const int e = tid + i * 256;
+    const int k = e >> 7, r = (e & 7) * 16 + ((e >> 3) & 15);
+    gs[i] = (e < HL_K * HL_T && m0 + r < n) ? nbr[(long long)k * ld + m0 + r] : -1;
+  }
+  for (int i = tid; i < W; i += 256) bits[i] = 0u;
+  __syncthreads();
+  HB_MARK(1);
+#pragma unroll
+  for (int i = 0; i < 14; ++i)
+    if (gs[i] >= 0) atomicOr(&bits[gs[i] >> 5], 1u << (gs[i] & 31));
+  __syncthreads();
+  HB_MARK(2);
+  // thread t owns words [t * wpt, (t + 1) * wpt): popcount, block scan, per-word exclusive prefix
+  int c = 0;
+  for (int j = 0; j < wpt; ++j) c += __popc(bits[tid * wpt + j]);
+  part[tid] = c;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  const int total = part[255];
+  HB_MARK(3);
+  int32_t* tr = tile_rows + (long long)tile * HL_TRC;
+  if (tid == 0) { tile_cnt[tile] = total + 1; tr[0] = -1; }
+  int p = part[tid] - c;
+  for (int j = 0; j < wpt; ++j) {
+    const int wd = tid * wpt + j;
+    wpre[wd] = (u16)p;
+    p += __popc(bits[wd]);
+  }
+  __syncthreads();
+  // slot-parallel: the i-th set bit = (last word whose prefix is <= i - a non-empty word is the last of its run of equal
+  // prefixes -, bit of rank i - prefix in it).  A word-parallel loop over set bits ran 26 words x up to 32 bits with one lane live.
+  for (int i = tid; i < total; i += 256) {
+    int lo = 0, hi = W;                           // wpre[lo] <= i < wpre[hi] (wpre[W] = total)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)wpre[mid] <= i) lo = mid; else hi = mid;
+    }
+    unsigned v = bits[lo];
+    int k = i - (int)wpre[lo], pos = 0;
+#pragma unroll
+    for (int sh = 16; sh >= 1; sh >>= 1) {
+      const int cnt = __popc(v & ((1u << sh) - 1u));
+      if (k >= cnt) { k -= cnt; pos += sh; v >>= sh; }
+    }
+    tr[1 + i] = lo * 32 + pos;
+  }
+  __syncthreads();
+  HB_MARK(4);
+  u16* lp = loc + (long long)tile * HL_K * HL_T;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    const int e = tid + i * 256;
+    const int g = gs[i];
+    int slot = 0;
+    if (g >= 0) slot = wpre[g >> 5] + __popc(bits[g >> 5] & ((1u << (g & 31)) - 1u)) + 1;
+    if (e < HL_K * HL_T) lp[e] = (u16)slot;      // entry (r % 16) * 8 + r / 16 of (tile, k): a lane's 8 row blocks in one 16 B word
+  }
+  HB_MARK(5);
+}
+
+// weights n-major [27][64 n][64 k] -> MFMA fragment order [27][nt 4][ks 2][lane 64][8]: a wave's fragment load is 1 KB contiguous
+// (row-major fragments touch 16 half-used cache lines per load: the L1 tag rate, not the MFMAs, then bounds the kernel)
+// blockIdx.y: weight of a batch (srcs / dsts device pointer arrays), or src / dst themselves when the arrays are null
+__global__ __launch_bounds__(256) void k_halo_wpack(const u16* __restrict__ src, u16* __restrict__ dst, const u16* const* __restrict__ srcs,
+                                                    u16* const* __restrict__ dsts) {
+  if (srcs) { src = srcs[blockIdx.y]; dst = dsts[blockIdx.y]; }
+  const int c = blockIdx.x * 256 + threadIdx.x;   // 16 B chunk of dst
+  if (c >= HL_K * 512) return;
+  const int lane = c & 63, ks = (c >> 6) & 1, nt = (c >> 7) & 3, k = c >> 9;
+  *(u32x4*)(dst + (long long)c * 8) = *(const u32x4*)(src + k * 4096 + (nt * 16 + (lane & 15)) * 64 + ks * 32 + (lane >> 4) * 8);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// convolution
+// ---------------------------------------------------------------------------------------------------------------------------
+// sum over the 16 lanes of a DPP row (every lane gets it): 4 VALU ops - the statistics epilogue reduces 32 values per lane, which as
+// ds_bpermute shuffles cost the launch 9 us
+__device__ __forceinline__ float hl_row_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));      // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));     // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));     // row_mirror
+  return v;
+}
+
+__device__ __forceinline__ f32x4 hl_sel(bool c, f32x4 a, f32x4 b) {
+  f32x4 r;
+  r[0] = c ? a[0] : b[0]; r[1] = c ? a[1] : b[1]; r[2] = c ? a[2] : b[2]; r[3] = c ? a[3] : b[3];
+  return r;
+}
+
+// in/out/addend bf16 [n][64]; wgt: k_halo_wpack of bf16 [27][64 (n)][64 (reduction)]; stats f64 [tiles][2][64] or null
+__global__ __launch_bounds__(256, 2) void k_subm_halo64(const u16* __restrict__ in, const u16* __restrict__ wgt,
+                                                        const int32_t* __restrict__ tile_rows, const u16* __restrict__ loc,
+                                                        const int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ n_dev, int n_cap,
+                                                        int krev, const u16* __restrict__ addend, u16* __restrict__ out,
+                                                        double* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u16* xs = (u16*)smem;                           // [HL_MAXS][HL_RS]
+  const int tid = threadIdx.x, tile = blockIdx.x;
+  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int m0 = tile * HL_T;
+  HL_MARK(0);
+  const int n = min(*n_dev, n_cap);
+  if (m0 >= n) {
+    if (stats && tid < 2 * HL_C) stats[(long long)tile * 2 * HL_C + tid] = 0.0;
+    return;
+  }
+  const int32_t* rows_p = tile_rows + (long long)tile * HL_TRC;
+  const int nl = min(tile_cnt[tile], HL_MAXS);
+  // stage the distinct rows: 8 lanes x 16 B per row.  All of a thread's row indices are requested at once, then all of its rows:
+  // two memory round trips per 288 slots (a loop of index -> row -> store iterations spent 15 us per launch waiting in turn)
+#ifndef HL_ABL_NOSTAGE
+  {
+    const int part = tid & 7, sb = tid >> 3;
+    for (int base = 0; base < nl; base += 288) {
+      int idx[9];
+      u32x4 v[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int slot = base + sb + 32 * i;
+        idx[i] = (slot > 0 && slot < nl) ? rows_p[slot] : -1;
+      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        v[i] = (u32x4){0u, 0u, 0u, 0u};
+        if (idx[i] >= 0) v[i] = *(const u32x4*)(in + (long long)idx[i] * HL_C + part * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int slot = base + sb + 32 * i;
+        if (slot < nl) *(u32x4*)(xs + slot * HL_RS + part * 8) = v[i];
+      }
+    }
+  }
+#endif
+  HL_MARK(1);
+  __syncthreads();
+  HL_MARK(2);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const u16* locp = loc + (long long)tile * HL_K * HL_T + r16 * 8;
+  const u16* wl = wgt + lane * 8;                 // fragment-packed (k_halo_wpack)
+  const u16* xl = xs + kq * 8;
+
+  u16x8 sl = *(const u16x8*)(locp + (krev ? 26 - w : w) * HL_T);
+  bf16x8 wf[4][2];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    wf[b][0] = *(const bf16x8*)(wl + ((w * 4 + b) * 2 + 0) * 512);
+    wf[b][1] = *(const bf16x8*)(wl + ((w * 4 + b) * 2 + 1) * 512);
+  }
+  // FAST (every slot of the tile is staged - the normal case): straight-line LDS reads and MFMAs, no branch in the offset loop
+  // (a per-row-block "staged or global" branch made the compiler drain every outstanding load at each of the 8 row blocks)
+#ifdef HL_ABL_NOW
+#define HL_KN(k) w
+#else
+#define HL_KN(k) ((k) + 4 < HL_K ? (k) + 4 : (k))      /* next offset of this wave (the last one re-reads its own: hits L1) */
+#endif
+#ifdef HL_ABL_NOMFMA
+#define HL_MFMA(a, x0, x1) _Pragma("unroll") for (int b = 0; b < 4; ++b) { acc[a][b][0] += (float)x0[b] * (float)wf[b][0][0]; acc[a][b][1] += (float)x1[b] * (float)wf[b][1][1]; }
+#else
+#define HL_MFMA(a, x0, x1)                                                                              \
+  _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                        \
+    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][0], x0, acc[a][b], 0, 0, 0);              \
+    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][1], x1, acc[a][b], 0, 0, 0);              \
+  }
+#endif
+#ifdef HL_ABL_NOLDS
+#define HL_LOADX(FAST, s, x0, x1) { x0 = wf[0][0]; x1 = wf[1][1]; x0[0] = (__bf16)(float)(s); }
+#else
+#define HL_LOADX(FAST, s, x0, x1)                                                                       \
+  if (FAST || (s) < nl) {                                                                               \
+    x0 = *(const bf16x8*)(xl + (s) * HL_RS);                                                            \
+    x1 = *(const bf16x8*)(xl + (s) * HL_RS + 32);                                                       \
+  } else {                                                                                              \
+    const u16* g = in + (long long)rows_p[s] * HL_C + kq * 8;                                           \
+    x0 = *(const bf16x8*)g;                                                                             \
+    x1 = *(const bf16x8*)(g + 32);                                                                      \
+  }
+#endif
+// the next offset's weights and slots are requested at the top of the iteration (an L2 round trip is about one offset's MFMA
+// time), the operand rows of block a + 1 before the MFMAs of block a; scheduling barriers keep the compiler from sinking the
+// prefetches to where their registers are free (it then waited for them at the loop end) and from hoisting all 16 LDS reads
+#define HL_OFFSET_LOOP(FAST)                                                                            \
+  for (int k = w; k < HL_K; k += 4) {                                                                   \
+    const int kn = HL_KN(k);                                                                            \
+    const u16x8 sln = *(const u16x8*)(locp + (krev ? 26 - kn : kn) * HL_T);                             \
+    bf16x8 wn[4][2];                                                                                    \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                      \
+      wn[b][0] = *(const bf16x8*)(wl + ((kn * 4 + b) * 2 + 0) * 512);                                   \
+      wn[b][1] = *(const bf16x8*)(wl + ((kn * 4 + b) * 2 + 1) * 512);                                   \
+    }                                                                                                   \
+    bf16x8 x0, x1, y0, y1;                                                                              \
+    HL_LOADX(FAST, (int)sl[0], x0, x1)                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    _Pragma("unroll") for (int a = 0; a < 8; a += 2) {                                                   \
+      HL_LOADX(FAST, (int)sl[a + 1], y0, y1)                                                            \
+      HL_MFMA(a, x0, x1)                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                \
+      if (a + 2 < 8) { HL_LOADX(FAST, (int)sl[a + 2 < 8 ? a + 2 : 0], x0, x1) }                         \
+      HL_MFMA(a + 1, y0, y1)                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                \
+    }                                                                                                   \
+    sl = sln;                                                                                           \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) { wf[b][0] = wn[b][0]; wf[b][1] = wn[b][1]; }          \
+  }
+  if (tile_cnt[tile] <= HL_MAXS) { HL_OFFSET_LOOP(1) } else { HL_OFFSET_LOOP(0) }
+
+  // sum the four waves' partial tiles: reduce-scatter in two rounds through the stage buffer
+  f32x4* xb = (f32x4*)smem;
+  const bool h = w & 1, q = (w >> 1) & 1;
+  HL_MARK(3);
+  __syncthreads();                                // all waves are done reading the staged rows
+  f32x4 r4[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      xb[(w * 16 + i * 4 + b) * 64 + lane] = hl_sel(h, acc[i][b], acc[4 + i][b]);       // the half this wave gives away
+      r4[i][b] = hl_sel(h, acc[4 + i][b], acc[i][b]);
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) r4[i][b] += xb[((w ^ 1) * 16 + i * 4 + b) * 64 + lane];
+  __syncthreads();
+  f32x4 fin[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      xb[(w * 8 + j * 4 + b) * 64 + lane] = hl_sel(q, r4[j][b], r4[2 + j][b]);
+      fin[j][b] = hl_sel(q, r4[2 + j][b], r4[j][b]);
+    }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) fin[j][b] += xb[((w ^ 2) * 8 + j * 4 + b) * 64 + lane];
+
+  HL_MARK(4);
+  // epilogue: this wave owns row blocks mt = 4 h + 2 q + j, all 64 columns; fin[j][b][r] = C[row mt * 16 + r16][col b * 16 + 4 kq + r]
+  f32x4 cs[4], cq[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + (4 * (int)h + 2 * (int)q + j) * 16 + r16;
+    if (m >= n) continue;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = b * 16 + 4 * kq;
+      f32x4 v = fin[j][b];
+      if (addend) v += __builtin_convertvector(*(const bf16x4*)(addend + (long long)m * HL_C + col), f32x4);
+      const bf16x4 o = __builtin_convertvector(v, bf16x4);
+      *(bf16x4*)(out + (long long)m * HL_C + col) = o;
+      const f32x4 vr = __builtin_convertvector(o, f32x4);      // statistics of the ROUNDED values: what the BatchNorm behind reads
+      cs[b] += vr;
+      cq[b] += vr * vr;
+    }
+  }
+  HL_MARK(5);
+  if (stats) {
+    __syncthreads();                              // round-two buffers are dead
+    float* red = (float*)smem;                    // [4 waves][2][64]
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = hl_row_sum(cs[b][r]), s2 = hl_row_sum(cq[b][r]);
+        if (r16 == 0) {
+          red[(w * 2 + 0) * HL_C + b * 16 + 4 * kq + r] = s1;
+          red[(w * 2 + 1) * HL_C + b * 16 + 4 * kq + r] = s2;
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * HL_C) {
+      const int which = tid >> 6, cl = tid & 63;
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a += (double)red[(k * 2 + which) * HL_C + cl];
+      stats[((long long)tile * 2 + which) * HL_C + cl] = a;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// C ABI (include/u3d_hip.h)
+// ---------------------------------------------------------------------------------------------------------------------------
+extern "C" int32_t u3d_subm_halo_sizes(int32_t n_cap, int64_t* tile_rows_elems, int64_t* loc_elems, int32_t* tiles) {
+  U3D_REQUIRE(n_cap > 0 && tile_rows_elems && loc_elems && tiles, U3D_ERR_ARG);
+  const int t = u3d_cdiv(n_cap, HL_T);
+  *tiles = t;
+  *tile_rows_elems = (int64_t)t * HL_TRC;
+  *loc_elems = (int64_t)t * HL_K * HL_T;
+  return U3D_OK;
+}
+
+extern "C" int32_t u3d_subm_halo_build(const int32_t* nbr, int32_t ld, const int32_t* n_dev, int32_t n_cap, int32_t* tile_rows,
+                                       uint16_t* loc, int32_t* tile_cnt, u3d_stream s) {
+  U3D_REQUIRE(nbr && n_dev && tile_rows && loc && tile_cnt && n_cap > 0 && ld >= n_cap, U3D_ERR_ARG);
+  const int wpt = u3d_cdiv(u3d_cdiv(n_cap, 32), 256);
+  const int lds = wpt * 256 * 6 + 1024;
+  if (lds > 160 * 1024) return U3D_ERR_UNSUPPORTED;      // > 869 k rows: the row bitmap does not fit the LDS
+  U3D_ALLOW_LDS(k_halo_build, 160 * 1024);                // set once per device: the maximum, the launch asks for what n_cap needs
+  k_halo_build<<<u3d_cdiv(n_cap, HL_T), 256, lds, (hipStream_t)s>>>(nbr, ld, n_dev, n_cap, wpt, tile_rows, loc, tile_cnt);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+extern "C" int32_t u3d_subm_halo_wpack(const void* w_nmajor, void* w_packed, u3d_stream s) {
+  U3D_REQUIRE(w_nmajor && w_packed, U3D_ERR_ARG);
+  k_halo_wpack<<<u3d_cdiv(HL_K * 512, 256), 256, 0, (hipStream_t)s>>>((const u16*)w_nmajor, (u16*)w_packed, nullptr, nullptr);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+extern "C" int32_t u3d_subm_halo_wpack_batched(const void* const* srcs_dev, void* const* dsts_dev, int32_t n, u3d_stream s) {
+  U3D_REQUIRE(srcs_dev && dsts_dev && n >= 0, U3D_ERR_ARG);
+  if (n == 0) return U3D_OK;
+  k_halo_wpack<<<dim3(u3d_cdiv(HL_K * 512, 256), n), 256, 0, (hipStream_t)s>>>(nullptr, nullptr, (const u16* const*)srcs_dev, (u16* const*)dsts_dev);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+extern "C" int32_t u3d_subm_halo_conv64_bf16(const void* in, const void* w_packed, const int32_t* tile_rows, const uint16_t* loc,
+                                             const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, int32_t krev,
+                                             const void* addend, void* out, double* stats, u3d_stream s) {
+  U3D_REQUIRE(in && w_packed && tile_rows && loc && tile_cnt && n_dev && out && n_cap > 0, U3D_ERR_ARG);
+  const int lds = HL_MAXS * HL_RS * 2;
+  static_assert(HL_MAXS * HL_RS * 2 >= 4 * 16 * 64 * 16, "stage buffer holds the first reduce-scatter round");
+  U3D_ALLOW_LDS(k_subm_halo64, lds);
+  k_subm_halo64<<<u3d_cdiv(n_cap, HL_T), 256, lds, (hipStream_t)s>>>((const u16*)in, (const u16*)w_packed, tile_rows, loc, tile_cnt, n_dev,
+                                                                    n_cap, krev, (const u16*)addend, (u16*)out, stats);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}

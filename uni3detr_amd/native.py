@@ -106,6 +106,11 @@ _SIGS = {
     "u3d_bn_finalize_partials": (_I, [_P, _I, _I, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     "u3d_igemm_fwd_stats_tile_rows": (_I, [_I, _I, _I]),
     "u3d_igemm_fwd_stats_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "u3d_subm_halo_sizes": (_I, [_I, _P, _P, _P]),
+    "u3d_subm_halo_build": (_I, [_P, _I, _P, _I, _P, _P, _P, _P]),
+    "u3d_subm_halo_wpack": (_I, [_P, _P, _P]),
+    "u3d_subm_halo_wpack_batched": (_I, [_P, _P, _I, _P]),
+    "u3d_subm_halo_conv64_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "u3d_igemm_lattice_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "u3d_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     "u3d_bn_bwd_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P]),
@@ -437,6 +442,64 @@ def spconv_fwd_stats(inp, w_nmajor, nbr, n_out_dev, n_out, cout):
                         bytes=inp.shape[0] * cin * 2 + n_out * cout * 2 + 8 * pairs + kvol * cin * cout * 2, flops=2 * pairs * cin * cout)
         t.end("spconv_fwd", e0, meta)
     return out, stats, tr
+
+
+class SubmHalo:
+    """Per-tile distinct-row lists + 16-bit slot tables of one SubM level (u3d_subm_halo_build): built once per level and step from
+    the forward neighbour table, shared by all of the level's 64 -> 64 convs and (offsets reversed) their input gradients."""
+    TILE = 128
+
+    def __init__(self, nbr_fwd, n_dev, n_cap):
+        dev = nbr_fwd.device
+        a, b, t = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        _check(lib().u3d_subm_halo_sizes(n_cap, C.byref(a), C.byref(b), C.byref(t)), "subm_halo_sizes")
+        self.tiles, self.n_dev, self.n_cap, self.nbr = t.value, n_dev, n_cap, nbr_fwd
+        self.tile_rows = torch.empty((a.value,), dtype=torch.int32, device=dev)
+        self.loc = torch.empty((b.value,), dtype=torch.int16, device=dev)
+        self.tile_cnt = torch.empty((t.value,), dtype=torch.int32, device=dev)
+        _check(lib().u3d_subm_halo_build(_ptr(nbr_fwd), nbr_fwd.shape[1], _ptr(n_dev), n_cap, _ptr(self.tile_rows), _ptr(self.loc),
+                                         _ptr(self.tile_cnt), _stream()), "subm_halo_build")
+
+
+def subm_halo_wpack(w_nmajor, out=None):
+    """bf16 [27, 64 (out), 64 (reduction)] -> the MFMA fragment order u3d_subm_halo_conv64_bf16 reads (same shape and size)."""
+    assert w_nmajor.dtype == torch.bfloat16 and tuple(w_nmajor.shape) == (27, 64, 64) and w_nmajor.is_contiguous()
+    out = torch.empty_like(w_nmajor) if out is None else out
+    _check(lib().u3d_subm_halo_wpack(_ptr(w_nmajor), _ptr(out), _stream()), "subm_halo_wpack")
+    return out
+
+
+def subm_halo_wpack_plan(pairs, device):
+    """[(src, dst)] of [27, 64, 64] bf16 tensors -> plan for subm_halo_wpack_batched (device pointer arrays; the tensors must stay alive)."""
+    src = torch.tensor([a.data_ptr() for a, _ in pairs], dtype=torch.int64, device=device)
+    dst = torch.tensor([b.data_ptr() for _, b in pairs], dtype=torch.int64, device=device)
+    return src, dst, len(pairs), pairs
+
+
+def subm_halo_wpack_batched(plan):
+    _check(lib().u3d_subm_halo_wpack_batched(_ptr(plan[0]), _ptr(plan[1]), plan[2], _stream()), "subm_halo_wpack_batched")
+
+
+def subm_halo_conv(inp, w_packed, halo, krev=False, addend=None, want_stats=False, tag="spconv_fwd"):
+    """64 -> 64 channel, 27-offset SubM conv out of the tile's staged distinct rows (u3d_subm_halo_conv64_bf16).
+    w_packed: subm_halo_wpack of bf16 [27, 64 (out), 64 (reduction)].  -> out, or (out, stats f64 [tiles, 2, 64], 128) with want_stats."""
+    assert inp.dtype == torch.bfloat16 and inp.shape[1] == 64 and tuple(w_packed.shape) == (27, 64, 64) and inp.shape[0] == halo.n_cap
+    out = torch.empty_like(inp)
+    stats = torch.empty((halo.tiles, 2, 64), dtype=torch.float64, device=inp.device) if want_stats else None
+    t = TIMER
+    e0 = t.begin() if t is not None else None
+    _check(lib().u3d_subm_halo_conv64_bf16(_ptr(inp), _ptr(w_packed), _ptr(halo.tile_rows), _ptr(halo.loc), _ptr(halo.tile_cnt),
+                                           _ptr(halo.n_dev), halo.n_cap, int(krev), _ptr(addend), _ptr(out), _ptr(stats), _stream()),
+           "subm_halo_conv64_bf16")
+    if t is not None:
+        meta = None
+        if t.mode == "census":
+            n = halo.n_cap
+            pairs = int((halo.nbr[:, :n] >= 0).sum().item())
+            meta = dict(kind=CALL_KIND, v2=True, n_in=n, n_out=n, cin=64, cout=64, kvol=27, pairs=pairs,
+                        bytes=n * 64 * 2 * 2 + 8 * pairs + 27 * 64 * 64 * 2, flops=2 * pairs * 64 * 64)
+        t.end(tag, e0, meta)
+    return (out, stats, SubmHalo.TILE) if want_stats else out
 
 
 def bn_finalize_partials(stats, tile_rows, n_dev, n_cap, eps, momentum, running_mean=None, running_var=None, num_batches=None):

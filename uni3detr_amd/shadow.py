@@ -99,6 +99,16 @@ class ShadowSet:
                 K, co, ci = dims
                 koi = self.perm[d_koi["dst_off"]:d_koi["dst_off"] + p.numel()].view(K, co, ci)
             p._u3d_conv_shadow = [kio, koi, -1, layout]
+        # 64 -> 64 channel, 27-offset weights (the SubM blocks of the stride-4 stage): MFMA-fragment-packed copies of both layouts
+        # for the halo kernel (csrc/subm_halo.hip), all of them in ONE launch per refresh
+        pairs = []
+        for p in self.conv_params:
+            kio, koi = p._u3d_conv_shadow[0], p._u3d_conv_shadow[1]
+            if tuple(kio.shape) == (27, 64, 64):
+                pk = torch.empty((2, 27, 64, 64), dtype=torch.bfloat16, device=src.device)
+                pairs += [(koi, pk[0]), (kio, pk[1])]
+                p._u3d_halo_pack = [pk[0], pk[1], -1]
+        self._halo_plan = nv.subm_halo_wpack_plan(pairs, src.device) if pairs else None
         self._plan = nv.permute_plan(descs, src.device)
 
     def refresh(self):
@@ -106,10 +116,15 @@ class ShadowSet:
             from . import native as nv
             nv.cast_bf16(self.flat, self.flat_shadow)
             nv.permute_bf16_batched(self.flat_shadow, self.perm, self._plan)
+            if self._halo_plan is not None:
+                nv.subm_halo_wpack_batched(self._halo_plan)
             for p in self.params:
                 p._u3d_shadow[1] = p._version
             for p in self.conv_params:
                 p._u3d_conv_shadow[2] = p._version
+                hp = getattr(p, "_u3d_halo_pack", None)
+                if hp is not None:
+                    hp[2] = p._version
             return
         with torch.no_grad():
             if self.shadows:
@@ -131,6 +146,17 @@ class ShadowSet:
             yield self
         finally:
             _ACTIVE[0] = prev
+
+
+def halo_packs(p, kio, koi):
+    """(packed koi, packed kio or None) of a [27, 64, 64] conv weight for the halo kernel: the refresh's copies while the shadow set is
+    active and fresh, else packed on the spot (the transposed one only on demand: halo_pack_one)."""
+    if _ACTIVE[0]:
+        hp = getattr(p, "_u3d_halo_pack", None)
+        if hp is not None and hp[2] == p._version:
+            return hp[0], hp[1]
+    from . import native as nv
+    return nv.subm_halo_wpack(koi), None
 
 
 def compute_copy(p, dtype):

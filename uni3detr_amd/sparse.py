@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import native as nv
-from .shadow import conv_weights
+from .shadow import conv_weights, halo_packs
 
 K3, S1, P1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
 
@@ -23,6 +23,13 @@ class Level:
         self.grid, self.coords, self.n, self.n_dev = grid, coords, n, n_dev
         self.dims, self.batch = grid.dims, grid.batch
         self._subm = None
+        self._halo = None
+
+    def halo(self):
+        """Distinct-row lists of the 128-row tiles (native.SubmHalo) for the 64 -> 64 convs of this level: built on first use."""
+        if self._halo is None:
+            self._halo = nv.SubmHalo(self.subm_tables()[0], self.n_dev, self.n)
+        return self._halo
 
     def subm_tables(self):
         if self._subm is None:
@@ -72,6 +79,7 @@ class ConvGeom:
         self.n_in, self.n_in_dev, self.n_out, self.n_out_dev = n_in, n_in_dev, n_out, n_out_dev
         self.kind = kind            # "sparse" (encoder levels) or "dense" (SECOND3D/FPN lattice): bench.py tags timings with it
         self.lattice = None         # (batch, (D,H,W), kd) for a stride-1 "same" (kd,3,3) conv on a dense lattice (u3d_igemm_lattice_bf16)
+        self.level = None           # SubM convs: the Level (its halo() serves the 64 -> 64 convs, u3d_subm_halo_conv64_bf16)
 
 
 def level_from_coors(coors, batch, dims):
@@ -89,7 +97,9 @@ def level_from_coors(coors, batch, dims):
 
 def subm_geom(lvl):
     fwd, bwd = lvl.subm_tables()
-    return ConvGeom(fwd, bwd, lvl.n, lvl.n_dev, lvl.n, lvl.n_dev)
+    g = ConvGeom(fwd, bwd, lvl.n, lvl.n_dev, lvl.n, lvl.n_dev)
+    g.level = lvl
+    return g
 
 
 def strided_level(lvl, ksize, stride, pad, capacity=None):
@@ -111,6 +121,7 @@ def strided_level(lvl, ksize, stride, pad, capacity=None):
 
 
 REV_SUBM_TABLE = os.environ.get("U3D_REV_SUBM_TABLE", "1") == "1"
+SUBM_HALO = os.environ.get("U3D_SUBM_HALO", "1") == "1"       # 64 -> 64 SubM convs out of per-tile staged distinct rows (subm_halo.hip)
 LATTICE_KERNEL = os.environ.get("U3D_LATTICE_KERNEL", "0") == "1"      # 27-offset dense convs on u3d_igemm_lattice_bf16 (measured on par: off)
 STRIDED_DGRAD_SPLIT = os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
 NMAJOR_FWD = os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
@@ -182,6 +193,16 @@ class _SparseConv(torch.autograd.Function):
         nbr = geom.nbr_fwd if kio.shape[0] > 1 else None
         nv.CALL_KIND = geom.kind
         lat = geom.lattice if (LATTICE_KERNEL and nmajor and geom.lattice is not None and geom.lattice[2] == 3) else None
+        ctx.halo = (SUBM_HALO and REV_SUBM_TABLE and nmajor and geom.level is not None and kv == 27 and cin == 64 and cout == 64
+                    and geom.n_out >= 4096)
+        if ctx.halo:
+            pk_fwd, ctx.pk_bwd = halo_packs(weight, kio, koi)
+            if want_stats:
+                y, stats, tr = nv.subm_halo_conv(feats, pk_fwd, geom.level.halo(), want_stats=True)
+                stats._u3d_tile_rows = tr
+                ctx.mark_non_differentiable(stats)
+                return y, stats
+            return nv.subm_halo_conv(feats, pk_fwd, geom.level.halo())
         if want_stats:
             res = None
             if lat is not None:
@@ -268,7 +289,11 @@ class _SparseConv(torch.autograd.Function):
                         add = add + facc
                     elif facc is not None:
                         add = facc
-                    din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True, addend=add)
+                    if ctx.halo:
+                        pk = ctx.pk_bwd if ctx.pk_bwd is not None else nv.subm_halo_wpack(wc)
+                        din = nv.subm_halo_conv(dout, pk, g.level.halo(), krev=True, addend=add, tag="spconv_dgrad")
+                    else:
+                        din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True, addend=add)
             if fan is not None:
                 din = fan.step(din)
         elif ctx.res_token is not None:
