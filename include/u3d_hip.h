@@ -190,6 +190,27 @@ int32_t u3d_igemm_fwd_stats_rows(int32_t n_out_cap, int32_t cin, int32_t cout, i
 int32_t u3d_igemm_fwd_stats_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,
                                  const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
                                  double* stats, u3d_stream s);
+/* BatchNorm-BACKWARD statistics out of the input-gradient launch that writes the BatchNorm's dy (ref: the conv -> BatchNorm -> ReLU
+ * chains of sparse_encoder_hd.py:71-104 / second_3d.py:52-76; torch's batch_norm_backward makes a separate reduction pass over dy and
+ * x).  x: the BatchNorm's input (bf16 [n][C]); y: its output when the ReLU mask cannot be recomputed from x (residual layers), else
+ * NULL; mean/invstd (+ gamma/beta when relu and y == NULL) f32 [C].  The launch leaves, per row tile, sum(g) and sum(g * xhat) with
+ * g = dy under the ReLU mask: f64 [ceil(n/T)][2][C], T = u3d_igemm_fwd_stats_rows(...) (128 for the halo kernel), which
+ * u3d_bn_bwd_finalize_partials reduces to what u3d_bn_bwd_stats returns. */
+typedef struct {
+  const void* x;
+  const void* y;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  int32_t relu;
+  int32_t reserved;
+} u3d_bn_epi;
+int32_t u3d_igemm_dgrad_bnstats_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, const void* addend, void* out,
+                                     const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
+                                     const u3d_bn_epi* bn, double* stats, u3d_stream s);
+int32_t u3d_bn_bwd_finalize_partials(const double* partial, int32_t nblocks, int32_t rows_per_block, const int32_t* n_dev,
+                                     int32_t n_cap, int32_t c, double* sums, float* sums_f32, u3d_stream s);
 /* Output-stationary path of the 64 -> 64 channel, 27-offset submanifold convs (the stride-4 stage's SparseBasicBlocks, ref:
  * sparse_encoder_hd.py:106-138): rows are numbered in 4x4x4-block-major order, so the 27 x 128 table entries of a 128-row tile name
  * only a few hundred DISTINCT rows.  u3d_subm_halo_build (once per level and step) leaves, per tile, the sorted distinct rows
@@ -199,7 +220,8 @@ int32_t u3d_igemm_fwd_stats_bf16(const void* in, const void* w, const int32_t* n
  * u3d_subm_halo_conv64_bf16 then computes what u3d_igemm_fwd_bf16 (transpose_w = 1) /
  * u3d_igemm_fwd_add_bf16 / u3d_igemm_fwd_stats_bf16 compute from the table: in/out/addend bf16 [n][64]; w_packed =
  * u3d_subm_halo_wpack of the n-major bf16 weights [27][64][64] (MFMA fragment order, same size); krev != 0 reads the offsets reversed (the transposed table of a SubM layer: input gradients, pass [K][Cin][Cout]);
- * addend nullable; stats nullable f64 [tiles][2][64] (128 rows per partial, as u3d_bn_finalize_partials takes them). */
+ * addend nullable; stats nullable f64 [tiles][2][64] (128 rows per partial, as u3d_bn_finalize_partials takes them); bn nullable:
+ * with it the statistics are the BatchNorm-backward sums described at u3d_bn_epi above, instead of the output's own. */
 int32_t u3d_subm_halo_sizes(int32_t n_cap, int64_t* tile_rows_elems, int64_t* loc_elems, int32_t* tiles);
 int32_t u3d_subm_halo_build(const int32_t* nbr, int32_t ld, const int32_t* n_dev, int32_t n_cap, int32_t* tile_rows,
                             uint16_t* loc, int32_t* tile_cnt, u3d_stream s);
@@ -209,7 +231,7 @@ int32_t u3d_subm_halo_wpack(const void* w_nmajor, void* w_packed, u3d_stream s);
 int32_t u3d_subm_halo_wpack_batched(const void* const* srcs_dev, void* const* dsts_dev, int32_t n, u3d_stream s);
 int32_t u3d_subm_halo_conv64_bf16(const void* in, const void* w_packed, const int32_t* tile_rows, const uint16_t* loc,
                                   const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, int32_t krev,
-                                  const void* addend, void* out, double* stats, u3d_stream s);
+                                  const void* addend, void* out, double* stats, const u3d_bn_epi* bn, u3d_stream s);
 int64_t u3d_igemm_wgrad_bf16_workspace(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol);
 /* out_layout 0: dw [K][Cin][Cout] (spconv-1.x / this library's layout); 1: dw [Cout][Cin][K] (nn.Conv3d's [Cout,Cin,kD,kH,kW]). */
 int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const int32_t* nbr, int32_t ld, float* dw,

@@ -1004,3 +1004,54 @@ def test_subm_halo_used_by_the_64_channel_blocks(cuda):
             sp.SUBM_HALO = True
     for a, b, tol in zip(res[True], res[False], (8e-3, 1e-3, 8e-3, 1e-5)):
         assert (a - b).abs().max() / b.abs().max() < tol
+
+
+@pytest.mark.parametrize("c,n_pts,dims", [(64, 30000, (12, 48, 48)), (128, 30000, (12, 48, 48)), (256, 60000, (12, 64, 64))])
+def test_bn_backward_sums_from_the_consumers_dgrad_epilogue(cuda, c, n_pts, dims):
+    """sp.BnGradToken: conv -> BN -> ReLU -> [residual block: conv1 -> BN -> ReLU -> conv2 -> BN (+ identity) -> ReLU] -> conv -> BN.
+    With the fusion on, the BatchNorm-backward sums of three of the four BatchNorms come out of the consuming conv's input-gradient
+    epilogue (halo kernel at 64 channels, 128 x 128 LDS-DMA tiles at 128, the eight-phase 256 x 256 kernel at 256; one of them
+    through the residual block's addend epilogue, one with the mask read from y); gradients equal the separate-pass ones to
+    summation-order noise, and the statistics kernel is launched once instead of four times."""
+    import torch
+    from uni3detr_amd import native as nv, sparse as sp
+    lvl0, _ = _level(seed=21, n_pts=n_pts, dims=dims)
+    torch.manual_seed(c)
+    x0 = torch.randn(lvl0.n, c, device="cuda").bfloat16()
+    ws = [(torch.randn(3, 3, 3, c, c, device="cuda") * (0.6 / (27 * c) ** 0.5)) for _ in range(4)]
+    gb = [(torch.rand(c, device="cuda") + 0.5, torch.randn(c, device="cuda") * 0.3) for _ in range(4)]
+    dy = torch.randn(lvl0.n, c, device="cuda").bfloat16()
+    res, calls = {}, {}
+    real, default = nv.bn_bwd_stats, sp.BN_GRAD_FUSION
+    for on in (True, False):
+        sp.BN_GRAD_FUSION = on
+        cnt = [0]
+
+        def counted(*a, **k):
+            cnt[0] += 1
+            return real(*a, **k)
+        nv.bn_bwd_stats = counted
+        try:
+            lv = sp.Level(lvl0.grid, lvl0.coords, lvl0.n, lvl0.n_dev)
+            geom = sp.subm_geom(lv)
+            bns = [torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).cuda().train() for _ in range(4)]
+            for bn, (g_, b_) in zip(bns, gb):
+                bn.weight.data.copy_(g_); bn.bias.data.copy_(b_)
+            w = [t.clone().requires_grad_(True) for t in ws]
+            x = x0.clone().requires_grad_(True)
+            tA, mid, tB = sp.BnGradToken(), sp.BnGradToken(), sp.BnGradToken()
+            rt = sp.ResidualToken()
+            a = sp.conv_bn(x, w[0], geom, bns[0], lv.n_dev, None, True, bn_out=tA)
+            o = sp.conv_bn(a, w[1], geom, bns[1], lv.n_dev, None, True, res_take=rt, bn_in=tA, bn_out=mid)
+            b = sp.conv_bn(o, w[2], geom, bns[2], lv.n_dev, a, True, res_give=rt, bn_in=mid, bn_out=tB)
+            y = sp.conv_bn(b, w[3], geom, bns[3], lv.n_dev, None, True, bn_in=tB)
+            y.backward(dy)
+            res[on] = [x.grad.float()] + [t.grad.float() for t in w] + [p.grad.float() for bn in bns for p in (bn.weight, bn.bias)]
+            calls[on] = cnt[0]
+        finally:
+            sp.BN_GRAD_FUSION = default
+            nv.bn_bwd_stats = real
+    assert calls[False] == 4 and calls[True] == 1, calls
+    for i, (p, q) in enumerate(zip(res[True], res[False])):
+        assert torch.isfinite(p).all()
+        assert (p - q).abs().max() / q.abs().max() < 2e-2, (i, float((p - q).abs().max() / q.abs().max()))

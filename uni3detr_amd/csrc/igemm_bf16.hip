@@ -19,6 +19,15 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// BatchNorm-BACKWARD statistics in the epilogue of an input-gradient launch (glds_epilogue.inc; == u3d_bn_epi of the C ABI): the
+// tensor this launch writes is dy of the BatchNorm that produced the conv's input, so sum(g) and sum(g * xhat) (g = dy under the
+// ReLU mask) can leave per row tile with the store - the separate pass over dy and x (k_col_stats_vec) disappears.
+struct BnEpi {
+  const u16* x = nullptr;        // the BatchNorm's input (bf16 [n][C]); nullptr: off
+  const u16* y = nullptr;        // its output, for the ReLU mask of layers with a residual; nullptr: mask recomputed from x
+  const float *mean = nullptr, *invstd = nullptr, *gamma = nullptr, *beta = nullptr;
+  int relu = 0, pad = 0;
+};
 #ifndef IGEMM_SMALL_C
 #define IGEMM_SMALL_C 1
 #endif
@@ -418,7 +427,7 @@ template <int WAVES_M, int WAVES_N, int WM, int WN>
 __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
                                                 int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
                                                 int cin, int cout, int kvol, const float* __restrict__ bias, int relu,
-                                                double* __restrict__ stats) {
+                                                double* __restrict__ stats, const BnEpi bn) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, BK = 64;
   constexpr int A_ELEMS = BM * BK, W_ELEMS = BN * BK;   // unpadded tiles, 128 B per row
@@ -703,7 +712,7 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
 __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
                                                  int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
                                                  int cin, int cout, int kvol, const float* __restrict__ bias, int relu,
-                                                 double* __restrict__ stats) {
+                                                 double* __restrict__ stats, const BnEpi bn) {
   constexpr int WAVES_M = 2, WAVES_N = 4, WM = 8, WN = 4, NW = 8;
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int PIECE = 128 * BK;                         // elements of one piece (16 KiB)
@@ -912,8 +921,8 @@ __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, con
 }
 __global__ __launch_bounds__(512) void k_igemm_glds8_256x256(const u16* in, const u16* w, const int* nbr, int ld, u16* out,
                                                              const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,
-                                                             const float* bias, int relu, double* stats) {
-  igemm_glds8_body(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats);
+                                                             const float* bias, int relu, double* stats, BnEpi bn) {
+  igemm_glds8_body(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats, bn);
 }
 
 // =============================================================================================
@@ -935,7 +944,7 @@ __global__ __launch_bounds__(512) void k_igemm_glds8_256x256(const u16* in, cons
 __device__ __forceinline__ void igemm_glds8n_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
                                                   int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
                                                   int cin, int cout, int kvol, const float* __restrict__ bias, int relu,
-                                                  double* __restrict__ stats) {
+                                                  double* __restrict__ stats, const BnEpi bn) {
   constexpr int WAVES_M = 4, WAVES_N = 2, WM = 4, WN = 4, NW = 8;
   constexpr int BM = 256, BN = 128, BK = 64;
   constexpr int APIECE = 128 * BK, BPIECE = 64 * BK;
@@ -1125,8 +1134,8 @@ __device__ __forceinline__ void igemm_glds8n_body(const u16* __restrict__ in, co
 }
 __global__ __launch_bounds__(512) void k_igemm_glds8_256x128(const u16* in, const u16* w, const int* nbr, int ld, u16* out,
                                                              const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,
-                                                             const float* bias, int relu, double* stats) {
-  igemm_glds8n_body(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats);
+                                                             const float* bias, int relu, double* stats, BnEpi bn) {
+  igemm_glds8n_body(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats, bn);
 }
 // the 256 x 128 eight-phase kernel for the shapes it is dispatched on: long reductions (>= GLDS8N_MIN_KTILES k-tiles), enough
 // workgroups to keep most CUs busy with ONE per CU
@@ -1139,12 +1148,12 @@ static bool igemm_glds8n_shape(const int32_t* nbr, int n_out_cap, int cin, int c
 }
 static int launch_igemm_glds8n(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev,
                                int n_out_cap, int cin, int cout, int kvol, hipStream_t s, const float* bias = nullptr, int relu = 0,
-                               double* stats = nullptr) {
+                               double* stats = nullptr, const BnEpi bn = BnEpi{}) {
   constexpr size_t lds = 3 * (size_t)(256 + 128) * 64 * 2;      // 144 KiB
   U3D_ALLOW_LDS(k_igemm_glds8_256x128, lds);
   dim3 grid(u3d_cdiv(n_out_cap, 256), cout / 128);
   hipLaunchKernelGGL(k_igemm_glds8_256x128, grid, dim3(512), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap,
-                     cin, cout, kvol, bias, relu, stats);
+                     cin, cout, kvol, bias, relu, stats, bn);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
 }
 
@@ -1152,8 +1161,8 @@ static int launch_igemm_glds8n(const void* in, const void* w, const int32_t* nbr
 #define U3D_GLDS_KERNEL(NAME, A, B, C, D)                                                                                        \
   __global__ __launch_bounds__(A* B * 64) void NAME(const u16* in, const u16* w, const int* nbr, int ld, u16* out,               \
                                                     const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,            \
-                                                    const float* bias, int relu, double* stats) {                                \
-    igemm_glds_body<A, B, C, D>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats);                   \
+                                                    const float* bias, int relu, double* stats, BnEpi bn) {                      \
+    igemm_glds_body<A, B, C, D>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats, bn);               \
   }
 #define U3D_GLDS_KERNEL_X(NAME, ...) U3D_GLDS_KERNEL(NAME, __VA_ARGS__)
 U3D_GLDS_KERNEL_X(k_igemm_glds_256x256, GLDS256_CFG)
@@ -1163,12 +1172,12 @@ U3D_GLDS_KERNEL(k_igemm_glds_256x128, 4, 2, 4, 4)
 U3D_GLDS_KERNEL(k_igemm_glds_128x64, 4, 1, 2, 4)
 U3D_GLDS_KERNEL(k_igemm_glds_128x128, 2, 2, 4, 4)      /* 4 waves, 64 KiB LDS: two workgroups per CU run out of phase */
 #undef U3D_GLDS_KERNEL
-typedef void (*glds_kernel_t)(const u16*, const u16*, const int*, int, u16*, const int*, int, int, int, int, const float*, int, double*);
+typedef void (*glds_kernel_t)(const u16*, const u16*, const int*, int, u16*, const int*, int, int, int, int, const float*, int, double*, BnEpi);
 
 template <int WAVES_M, int WAVES_N, int WM, int WN>
 static int launch_igemm_glds(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev,
                              int n_out_cap, int cin, int cout, int kvol, hipStream_t s, const float* bias = nullptr, int relu = 0,
-                             double* stats = nullptr) {
+                             double* stats = nullptr, const BnEpi bn = BnEpi{}) {
   constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
   constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;        // 256 x 256: 128 KiB
   glds_kernel_t kern = (BM == 256 && BN == 256) ? ((IGEMM_GLDS8 && nbr) ? k_igemm_glds8_256x256 : k_igemm_glds_256x256)
@@ -1176,7 +1185,7 @@ static int launch_igemm_glds(const void* in, const void* w, const int32_t* nbr, 
   if (lds > 64 * 1024) U3D_ALLOW_LDS(kern, lds);      // one call site per template instantiation: per-kernel, per-device
   dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin,
-                     cout, kvol, bias, relu, stats);
+                     cout, kvol, bias, relu, stats, bn);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
 }
 
@@ -1197,6 +1206,7 @@ template <int WAVES_M, int WAVES_N, int WM, int WN>
 __device__ __forceinline__ void igemm_lattice_body(const u16* __restrict__ in, const u16* __restrict__ w, u16* __restrict__ out,
                                                    int n_rows, int cin, int cout, LatGeom lg, const float* __restrict__ bias, int relu,
                                                    double* __restrict__ stats) {
+  const BnEpi bn{};                              // (no BatchNorm-backward epilogue on this kernel: GLDS_EPI_ADDEND 0)
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, BK = 64;
   constexpr int WIN_ELEMS = LAT_WIN_ROWS * BK, W_ELEMS = BN * BK;
@@ -1574,6 +1584,42 @@ extern "C" int32_t u3d_igemm_fwd_add_bf16(const void* in, const void* w, const i
   }
 #endif
   return U3D_ERR_UNSUPPORTED;
+}
+
+// Input gradient (n-major weights [K][Cin][Cout] as the dgrad passes them) + optional addend + the BatchNorm-BACKWARD statistics of the
+// layer that produced the conv's input, per row tile: stats f64 [ceil(n_out_cap / T)][2][cout] = (sum g, sum g * xhat), T =
+// u3d_igemm_fwd_stats_rows(n_out_cap, cin, cout, kvol) (the dispatch below is u3d_igemm_fwd_stats_bf16's).  LDS-DMA kernels with the
+// addend epilogue only: U3D_ERR_UNSUPPORTED for the direct-operand shapes and the two-phase 256 x 256 kernel (the caller then runs
+// u3d_igemm_fwd_add_bf16 / u3d_igemm_fwd_bf16 and u3d_bn_bwd_stats).
+extern "C" int32_t u3d_igemm_dgrad_bnstats_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, const void* addend, void* out,
+                                                const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol,
+                                                const u3d_bn_epi* bn, double* stats, u3d_stream s) {
+  U3D_REQUIRE(in && w && out && n_out_dev && nbr && bn && bn->x && bn->mean && bn->invstd && stats, U3D_ERR_ARG);
+  U3D_REQUIRE(!bn->relu || bn->y || (bn->gamma && bn->beta), U3D_ERR_ARG);
+#if IGEMM_GLDS
+  if (n_out_cap <= 0 || cin % 64 != 0 || cout % 64 != 0) return U3D_ERR_UNSUPPORTED;
+#if IGEMM_DIRECT
+  if (u3d_launch_igemm_direct(nullptr, nullptr, (const int32_t*)16, 1, nullptr, nullptr, n_out_cap, cin, cout, kvol, 1, nullptr, nullptr, nullptr, nullptr)
+      != U3D_ERR_UNSUPPORTED) return U3D_ERR_UNSUPPORTED;                 // a direct-operand shape: its partial layout is per wave
+#endif
+  BnEpi e;
+  e.x = (const u16*)bn->x; e.y = (const u16*)bn->y; e.mean = bn->mean; e.invstd = bn->invstd; e.gamma = bn->gamma; e.beta = bn->beta;
+  e.relu = bn->relu;
+  const float* add = (const float*)addend;
+  const int fl = addend ? 2 : 0;
+  const int tr = u3d_igemm_fwd_stats_tile_rows(n_out_cap, cin, cout);
+  if (tr == 0) return U3D_ERR_UNSUPPORTED;
+  if (tr == 256) {
+    if (!(IGEMM_GLDS8 && nbr) || bn->y) return U3D_ERR_UNSUPPORTED;      // (mask from y: 128-row tiles only, glds_epilogue.inc)
+    return launch_igemm_glds<GLDS256_CFG>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, add, fl, stats, e);
+  }
+  if (igemm_glds8n_shape(nbr, n_out_cap, cin, cout, kvol))
+    return launch_igemm_glds8n(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, add, fl, stats, e);
+  if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, add, fl, stats, e);
+  return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, add, fl, stats, e);
+#else
+  return U3D_ERR_UNSUPPORTED;
+#endif
 }
 
 extern "C" int32_t u3d_igemm_fwd_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, void* out,

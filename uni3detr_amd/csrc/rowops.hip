@@ -309,6 +309,16 @@ extern "C" int32_t u3d_bn_bwd_stats(const void* dy, const void* y, const void* x
   return run_stats<1>(x, dy, y, mean, invstd, gamma, beta, relu, n_dev, n_cap, c, dtype, sums, workspace, workspace_bytes, s, row_map, sums_f32);
 }
 
+// stage 2 alone, for partial sums an input-gradient launch left in its epilogue (u3d_igemm_dgrad_bnstats_bf16 / the halo kernel)
+extern "C" int32_t u3d_bn_bwd_finalize_partials(const double* partial, int32_t nblocks, int32_t rows_per_block, const int32_t* n_dev,
+                                                int32_t n_cap, int32_t c, double* sums, float* sums_f32, u3d_stream s) {
+  U3D_REQUIRE(partial && n_dev && sums && nblocks > 0 && c > 0, U3D_ERR_ARG);
+  hipLaunchKernelGGL(k_col_stats_final, dim3(u3d_cdiv(c, 8)), dim3(FIN_THREADS), 0, (hipStream_t)s, partial, nblocks, n_dev, n_cap, c, sums, sums_f32,
+                     rows_per_block);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // column sums of a dense [n, C] matrix (bias gradients of the query decoder / head linears), f32 accumulation in a fixed
 // order: stage 1 = one workgroup per CS_ROWS rows -> partial[block][C]; stage 2 = one thread per column over the blocks.

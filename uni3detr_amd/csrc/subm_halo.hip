@@ -164,12 +164,19 @@ __device__ __forceinline__ f32x4 hl_sel(bool c, f32x4 a, f32x4 b) {
   return r;
 }
 
+// BatchNorm-backward statistics mode of the epilogue (== u3d_bn_epi; see glds_epilogue.inc / BnEpi in igemm_bf16.hip)
+struct HlBn {
+  const u16* x = nullptr; const u16* y = nullptr;
+  const float *mean = nullptr, *invstd = nullptr, *gamma = nullptr, *beta = nullptr;
+  int relu = 0, pad = 0;
+};
+
 // in/out/addend bf16 [n][64]; wgt: k_halo_wpack of bf16 [27][64 (n)][64 (reduction)]; stats f64 [tiles][2][64] or null
 __global__ __launch_bounds__(256, 2) void k_subm_halo64(const u16* __restrict__ in, const u16* __restrict__ wgt,
                                                         const int32_t* __restrict__ tile_rows, const u16* __restrict__ loc,
                                                         const int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ n_dev, int n_cap,
                                                         int krev, const u16* __restrict__ addend, u16* __restrict__ out,
-                                                        double* __restrict__ stats) {
+                                                        double* __restrict__ stats, const HlBn bn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u16* xs = (u16*)smem;                           // [HL_MAXS][HL_RS]
   const int tid = threadIdx.x, tile = blockIdx.x;
@@ -290,6 +297,22 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo64(const u16* __restrict__ 
   // sum the four waves' partial tiles: reduce-scatter in two rounds through the stage buffer
   f32x4* xb = (f32x4*)smem;
   const bool h = w & 1, q = (w >> 1) & 1;
+  // BatchNorm-backward statistics mode: this wave's x (and y) fragments of the rows it will own are requested before the
+  // reduce-scatter (8 B loads with a row stride: their latency hides behind the exchange)
+  bf16x4 xr[2][4], yr[2][4];
+  if (bn.x) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + (4 * (int)h + 2 * (int)q + j) * 16 + r16;
+      if (m >= n) continue;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const long long o_el = (long long)m * HL_C + b * 16 + 4 * kq;
+        xr[j][b] = *(const bf16x4*)(bn.x + o_el);
+        if (bn.y) yr[j][b] = *(const bf16x4*)(bn.y + o_el);
+      }
+    }
+  }
   HL_MARK(3);
   __syncthreads();                                // all waves are done reading the staged rows
   f32x4 r4[4][4];
@@ -337,8 +360,22 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo64(const u16* __restrict__ 
       const bf16x4 o = __builtin_convertvector(v, bf16x4);
       *(bf16x4*)(out + (long long)m * HL_C + col) = o;
       const f32x4 vr = __builtin_convertvector(o, f32x4);      // statistics of the ROUNDED values: what the BatchNorm behind reads
-      cs[b] += vr;
-      cq[b] += vr * vr;
+      if (bn.x) {                                              // input gradient: the BatchNorm-backward sums of the producing layer
+        const f32x4 xh = (__builtin_convertvector(xr[j][b], f32x4) - *(const f32x4*)(bn.mean + col)) * *(const f32x4*)(bn.invstd + col);
+        f32x4 gm = vr;
+        if (bn.relu) {
+          f32x4 yv;
+          if (bn.y) yv = __builtin_convertvector(yr[j][b], f32x4);
+          else yv = xh * *(const f32x4*)(bn.gamma + col) + *(const f32x4*)(bn.beta + col);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (!(yv[r] > 0.f)) gm[r] = 0.f;
+        }
+        cs[b] += gm;
+        cq[b] += gm * xh;
+      } else {
+        cs[b] += vr;
+        cq[b] += vr * vr;
+      }
     }
   }
   HL_MARK(5);
@@ -407,13 +444,16 @@ extern "C" int32_t u3d_subm_halo_wpack_batched(const void* const* srcs_dev, void
 
 extern "C" int32_t u3d_subm_halo_conv64_bf16(const void* in, const void* w_packed, const int32_t* tile_rows, const uint16_t* loc,
                                              const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, int32_t krev,
-                                             const void* addend, void* out, double* stats, u3d_stream s) {
+                                             const void* addend, void* out, double* stats, const u3d_bn_epi* bn, u3d_stream s) {
   U3D_REQUIRE(in && w_packed && tile_rows && loc && tile_cnt && n_dev && out && n_cap > 0, U3D_ERR_ARG);
+  U3D_REQUIRE(!bn || (stats && bn->x && bn->mean && bn->invstd && (!bn->relu || bn->y || (bn->gamma && bn->beta))), U3D_ERR_ARG);
+  HlBn e;
+  if (bn) { e.x = (const u16*)bn->x; e.y = (const u16*)bn->y; e.mean = bn->mean; e.invstd = bn->invstd; e.gamma = bn->gamma; e.beta = bn->beta; e.relu = bn->relu; }
   const int lds = HL_MAXS * HL_RS * 2;
   static_assert(HL_MAXS * HL_RS * 2 >= 4 * 16 * 64 * 16, "stage buffer holds the first reduce-scatter round");
   U3D_ALLOW_LDS(k_subm_halo64, lds);
   k_subm_halo64<<<u3d_cdiv(n_cap, HL_T), 256, lds, (hipStream_t)s>>>((const u16*)in, (const u16*)w_packed, tile_rows, loc, tile_cnt, n_dev,
-                                                                    n_cap, krev, (const u16*)addend, (u16*)out, stats);
+                                                                    n_cap, krev, (const u16*)addend, (u16*)out, stats, e);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

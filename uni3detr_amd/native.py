@@ -106,11 +106,13 @@ _SIGS = {
     "u3d_bn_finalize_partials": (_I, [_P, _I, _I, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     "u3d_igemm_fwd_stats_tile_rows": (_I, [_I, _I, _I]),
     "u3d_igemm_fwd_stats_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "u3d_igemm_dgrad_bnstats_bf16": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "u3d_bn_bwd_finalize_partials": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P]),
     "u3d_subm_halo_sizes": (_I, [_I, _P, _P, _P]),
     "u3d_subm_halo_build": (_I, [_P, _I, _P, _I, _P, _P, _P, _P]),
     "u3d_subm_halo_wpack": (_I, [_P, _P, _P]),
     "u3d_subm_halo_wpack_batched": (_I, [_P, _P, _I, _P]),
-    "u3d_subm_halo_conv64_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "u3d_subm_halo_conv64_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "u3d_igemm_lattice_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "u3d_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     "u3d_bn_bwd_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P]),
@@ -444,6 +446,58 @@ def spconv_fwd_stats(inp, w_nmajor, nbr, n_out_dev, n_out, cout):
     return out, stats, tr
 
 
+class BnEpi(C.Structure):
+    """u3d_bn_epi (include/u3d_hip.h): the BatchNorm whose dy an input-gradient launch writes."""
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("relu", C.c_int32), ("reserved", C.c_int32)]
+
+    @staticmethod
+    def of(x, y, mean, invstd, gamma, beta, relu):
+        p = lambda t: None if t is None else t.data_ptr()        # noqa: E731
+        return BnEpi(p(x), p(y), p(mean), p(invstd), p(gamma), p(beta), int(relu), 0)
+
+
+def spconv_dgrad_bnstats(dout, w_nmajor, nbr, n_dev, n, cout, addend, epi):
+    """Input gradient (weights [K, Cout_gemm, Cin_gemm] n-major as the dgrad passes them) + addend + per-row-tile BatchNorm-backward
+    sums of the layer that produced the conv's input (u3d_igemm_dgrad_bnstats_bf16).  -> (din, partial f64 [tiles, 2, cout],
+    tile_rows) or None when no kernel with that epilogue serves the shape."""
+    kvol, cin = w_nmajor.shape[0], dout.shape[1]
+    if dout.dtype != torch.bfloat16 or not USE_IGEMM_V2 or nbr is None:
+        return None
+    tr = int(lib().u3d_igemm_fwd_stats_rows(n, cin, cout, kvol))
+    if tr == 0:
+        return None
+    out = torch.empty((n, cout), dtype=dout.dtype, device=dout.device)
+    stats = torch.empty(((n + tr - 1) // tr, 2, cout), dtype=torch.float64, device=dout.device)
+    nbr_p, ld = _nbr_ptr_ld(nbr)
+    t = TIMER
+    e0 = t.begin() if t is not None else None
+    rc = lib().u3d_igemm_dgrad_bnstats_bf16(_ptr(dout), _ptr(w_nmajor), nbr_p, ld, _ptr(addend), _ptr(out), _ptr(n_dev), n, cin, cout, kvol,
+                                            C.byref(epi), _ptr(stats), _stream())
+    if rc == -2:
+        return None
+    _check(rc, "igemm_dgrad_bnstats_bf16")
+    if t is not None:
+        meta = None
+        if t.mode == "census":
+            tb = nbr.t.flip(0) if isinstance(nbr, RevNbr) else nbr
+            pairs = int((tb[:, :n] >= 0).sum().item())
+            meta = dict(kind=CALL_KIND, v2=True, n_in=dout.shape[0], n_out=n, cin=cin, cout=cout, kvol=kvol, pairs=pairs,
+                        bytes=dout.shape[0] * cin * 2 + n * cout * 2 + 8 * pairs + kvol * cin * cout * 2, flops=2 * pairs * cin * cout)
+        t.end("spconv_dgrad", e0, meta)
+    return out, stats, tr
+
+
+def bn_bwd_finalize_partials(partial, tile_rows, n_dev, n_cap):
+    """per-row-tile (sum g, sum g * xhat) -> what bn_bwd_stats(..., want_f32=True) returns."""
+    nb, _, c = partial.shape
+    sums = torch.empty((2, c), dtype=torch.float64, device=partial.device)
+    s32 = torch.empty((2, c), dtype=torch.float32, device=partial.device)
+    _check(lib().u3d_bn_bwd_finalize_partials(_ptr(partial), nb, tile_rows, _ptr(n_dev), n_cap, c, _ptr(sums), _ptr(s32), _stream()),
+           "bn_bwd_finalize_partials")
+    return sums, s32
+
+
 class SubmHalo:
     """Per-tile distinct-row lists + 16-bit slot tables of one SubM level (u3d_subm_halo_build): built once per level and step from
     the forward neighbour table, shared by all of the level's 64 -> 64 convs and (offsets reversed) their input gradients."""
@@ -480,7 +534,7 @@ def subm_halo_wpack_batched(plan):
     _check(lib().u3d_subm_halo_wpack_batched(_ptr(plan[0]), _ptr(plan[1]), plan[2], _stream()), "subm_halo_wpack_batched")
 
 
-def subm_halo_conv(inp, w_packed, halo, krev=False, addend=None, want_stats=False, tag="spconv_fwd"):
+def subm_halo_conv(inp, w_packed, halo, krev=False, addend=None, want_stats=False, tag="spconv_fwd", bn_epi=None):
     """64 -> 64 channel, 27-offset SubM conv out of the tile's staged distinct rows (u3d_subm_halo_conv64_bf16).
     w_packed: subm_halo_wpack of bf16 [27, 64 (out), 64 (reduction)].  -> out, or (out, stats f64 [tiles, 2, 64], 128) with want_stats."""
     assert inp.dtype == torch.bfloat16 and inp.shape[1] == 64 and tuple(w_packed.shape) == (27, 64, 64) and inp.shape[0] == halo.n_cap
@@ -489,7 +543,8 @@ def subm_halo_conv(inp, w_packed, halo, krev=False, addend=None, want_stats=Fals
     t = TIMER
     e0 = t.begin() if t is not None else None
     _check(lib().u3d_subm_halo_conv64_bf16(_ptr(inp), _ptr(w_packed), _ptr(halo.tile_rows), _ptr(halo.loc), _ptr(halo.tile_cnt),
-                                           _ptr(halo.n_dev), halo.n_cap, int(krev), _ptr(addend), _ptr(out), _ptr(stats), _stream()),
+                                           _ptr(halo.n_dev), halo.n_cap, int(krev), _ptr(addend), _ptr(out), _ptr(stats),
+                                           None if bn_epi is None else C.byref(bn_epi), _stream()),
            "subm_halo_conv64_bf16")
     if t is not None:
         meta = None

@@ -113,11 +113,12 @@ def to_volume(rows, B, dims):
     return rows.view(B, *dims, rows.shape[1]).permute(0, 4, 1, 2, 3)
 
 
-def conv_bn_relu(rows, B, dims, conv, bn, post_add=None, fan_token=None):
+def conv_bn_relu(rows, B, dims, conv, bn, post_add=None, fan_token=None, bn_in=None, bn_out=None):
     ks, st, pd = tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding)
     geom, dims_out = Lattice.conv(rows.device, B, dims, ks, st, pd)
     # nn.Conv3d layout [Cout,Cin,kd,kh,kw] (re-laid-out by the shadow set); BatchNorm statistics come out of the conv's epilogue
-    return sp.conv_bn(rows, conv.weight, geom, bn, geom.n_out_dev, None, True, "oidhw", post_add, fan_token=fan_token), dims_out
+    return sp.conv_bn(rows, conv.weight, geom, bn, geom.n_out_dev, None, True, "oidhw", post_add, fan_token=fan_token, bn_in=bn_in,
+                      bn_out=bn_out), dims_out
 
 
 def deconv_bn_relu(rows, B, dims, deconv, bn, post_add=None):
@@ -167,8 +168,11 @@ class SECOND3D(nn.Module):
     @staticmethod
     def _run_block(blk, rows, B, dims, fan=None):
         mods = list(blk)
-        for j in range(0, len(mods), 3):
-            rows, dims = conv_bn_relu(rows, B, dims, mods[j], mods[j + 1], fan_token=fan if j == 0 else None)
+        prev = None                     # inside a block every conv -> BN -> ReLU output has one consumer, the next conv: its input-gradient
+        for j in range(0, len(mods), 3):      # launch reduces that BatchNorm's backward sums (sp.BnGradToken); the block's output goes elsewhere
+            cur = sp.BnGradToken() if j + 3 < len(mods) else None
+            rows, dims = conv_bn_relu(rows, B, dims, mods[j], mods[j + 1], fan_token=fan if j == 0 else None, bn_in=prev, bn_out=cur)
+            prev = cur
         return rows, dims
 
     def forward(self, x):

@@ -107,7 +107,9 @@ class SparseEncoderHD(nn.Module):
         self.conv_out = SparseConvModule(cin, output_channels, (1, 1, 1), norm_cfg, stride=1, padding=0)
 
     # ------------------------------------------------------------------------------------------
-    def _module(self, m, x, lvl):
+    def _module(self, m, x, lvl, bn_in=None, bn_out=None):
+        """bn_in / bn_out (sp.BnGradToken): the BatchNorm that produced x hands its backward sums to this conv's input-gradient launch;
+        this module's BatchNorm fills bn_out for the next module.  Every module's output has exactly one consumer in forward()."""
         conv, bn = m[0], m[1]
         if conv.subm or conv.ksize == (1, 1, 1):
             geom = sp.subm_geom(lvl) if conv.ksize != (1, 1, 1) else sp.ConvGeom(None, None, lvl.n, lvl.n_dev, lvl.n, lvl.n_dev)
@@ -118,15 +120,19 @@ class SparseEncoderHD(nn.Module):
                 cap = self.level_capacities[len(self.last_level_counts) - 1]
             new, geom = sp.strided_level(lvl, conv.ksize, conv.stride, conv.padding, capacity=cap)
             self.last_level_counts.append(new.n_dev)
-        return sp.conv_bn(x, conv.weight, geom, bn, new.n_dev, None, True), new
+        return sp.conv_bn(x, conv.weight, geom, bn, new.n_dev, None, True, bn_in=bn_in, bn_out=bn_out), new
 
-    def _block(self, blk, x, lvl):
+    def _block(self, blk, x, lvl, bn_in=None, bn_out=None):
         geom = sp.subm_geom(lvl)
         # bf16 training: the identity's gradient is summed into conv1's input gradient by that kernel's epilogue (sp.ResidualToken)
         tok = sp.ResidualToken() if (RESIDUAL_FUSION and x.dtype == torch.bfloat16 and x.requires_grad and torch.is_grad_enabled()
                                      and blk.bn1.training) else None
-        o = sp.conv_bn(x, blk.conv1.weight, geom, blk.bn1, lvl.n_dev, None, True, res_take=tok)
-        return sp.conv_bn(o, blk.conv2.weight, geom, blk.bn2, lvl.n_dev, x, True, res_give=tok)
+        # x feeds conv1 AND the identity: conv1's input gradient is x's whole gradient only when the identity's is summed in by its
+        # epilogue (tok) - else autograd adds the two and the BatchNorm behind x keeps its own statistics pass
+        mid = sp.BnGradToken()
+        o = sp.conv_bn(x, blk.conv1.weight, geom, blk.bn1, lvl.n_dev, None, True, res_take=tok, bn_in=bn_in if tok is not None else None,
+                       bn_out=mid)
+        return sp.conv_bn(o, blk.conv2.weight, geom, blk.bn2, lvl.n_dev, x, True, res_give=tok, bn_in=mid, bn_out=bn_out)
 
     def forward(self, voxel_features, coors, batch_size):
         """voxel_features [N,C], coors int [N,4] (b,z,y,x), batch_size -> [B, C_out, D, H, W] (ref :106-138)."""
@@ -149,13 +155,16 @@ class SparseEncoderHD(nn.Module):
             x = x.to(self.compute_dtype)
         y = sp.sparse_conv(x, w_in, sp.subm_geom(lvl))
         x = sp.bn_rows(y, self.conv_input[1], lvl.n_dev, None, True)
+        prev = None                     # BnGradToken of the BatchNorm that produced x (each x below has ONE consumer: the next module)
         for stage in self.encoder_layers:
             for m in stage:
+                cur = sp.BnGradToken()
                 if isinstance(m, SparseBasicBlock):
-                    x = self._block(m, x, lvl)
+                    x = self._block(m, x, lvl, prev, cur)
                 else:
-                    x, lvl = self._module(m, x, lvl)
-        x, lvl = self._module(self.conv_out, x, lvl)
+                    x, lvl = self._module(m, x, lvl, prev, cur)
+                prev = cur
+        x, lvl = self._module(self.conv_out, x, lvl, prev, None)
         dense = sp.to_dense(x, lvl)
         if not self.keep_depth:
             dense = dense.sum(dim=2)

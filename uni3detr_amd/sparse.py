@@ -50,6 +50,25 @@ class ResidualToken:
         self.dres = None
 
 
+class BnGradToken:
+    """Side channel from a BatchNorm (+ ReLU) layer to the ONE conv that consumes its output (or, in a residual block, to the block's
+    first conv, whose input gradient already includes the identity branch's: ResidualToken): that conv's input-gradient launch writes
+    the BatchNorm's dy, so its epilogue reduces the BatchNorm-backward sums (sum g, sum g * xhat) per row tile on the way out
+    (u3d_igemm_dgrad_bnstats_bf16 / the halo kernel) and leaves them here; the BatchNorm's backward then skips its own pass over dy
+    and x (u3d_bn_bwd_stats).  The caller vouches that no other consumer of the BatchNorm's output contributes a gradient."""
+
+    def __init__(self):
+        self.epi = None          # native.BnEpi of the producing layer (+ the tensors it points at, kept alive)
+        self.keep = None
+        self.partial = None      # (f64 [tiles, 2, C], tile_rows) left by the consumer's backward
+        self.c = 0
+
+    def fill(self, x, y, mean, invstd, gamma, beta, relu):
+        self.keep = (x, y, mean, invstd, gamma, beta)
+        self.epi = nv.BnEpi.of(x, y, mean, invstd, gamma, beta, relu)
+        self.c = x.shape[1]
+
+
 class FanoutToken:
     """Side channel between the first convs of `n` branches that take the SAME input (SECOND3D with is_cascade=False): autograd
     would add their input gradients with n - 1 element-wise passes over the full tensor.  Instead each conv's backward adds what the
@@ -164,7 +183,7 @@ def reset_conv_uses():
 
 class _SparseConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, weight, geom, layout, want_stats=False, res_token=None, fan_token=None):
+    def forward(ctx, feats, weight, geom, layout, want_stats=False, res_token=None, fan_token=None, bn_in=None):
         # weight: the PARAMETER in its checkpoint layout: "dhwio" [kD,kH,kW,Cin,Cout] (mmcv spconv-1.x) or "oidhw" (nn.Conv3d)
         # want_stats: also return the per-row-tile BatchNorm statistics of the output (empty tensor when the kernel serving this
         # shape does not produce them) - second, non-differentiable output
@@ -183,6 +202,7 @@ class _SparseConv(torch.autograd.Function):
         ctx.geom, ctx.layout = geom, layout
         ctx.res_token = res_token
         ctx.fan_token = fan_token if (fan_token is not None and feats.requires_grad) else None
+        ctx.bn_in = bn_in if (BN_GRAD_FUSION and bn_in is not None and bn_in.epi is not None and bf16 and fan_token is None) else None
         # TrainStep: this parameter's slice of the flat gradient buffer - written in place by the backward ONLY if this is the
         # weight's single use in the step (a weight used twice gets two gradients that autograd must add: it may not alias them)
         _CONV_USES[id(weight)] = _CONV_USES.get(id(weight), 0) + 1
@@ -228,7 +248,7 @@ class _SparseConv(torch.autograd.Function):
         feats, wc = ctx.saved_tensors
         g = ctx.geom
         if dout is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         dout = dout.contiguous()
         kvol = wc.shape[0]
         din = dw = None
@@ -289,16 +309,28 @@ class _SparseConv(torch.autograd.Function):
                         add = add + facc
                     elif facc is not None:
                         add = facc
+                    bt = ctx.bn_in
+                    if bt is not None and (bt.c != cin or (add is not None and not (add.dtype == torch.bfloat16 and add.is_contiguous()))):
+                        bt = None
                     if ctx.halo:
                         pk = ctx.pk_bwd if ctx.pk_bwd is not None else nv.subm_halo_wpack(wc)
-                        din = nv.subm_halo_conv(dout, pk, g.level.halo(), krev=True, addend=add, tag="spconv_dgrad")
+                        if bt is not None:
+                            din, st, tr = nv.subm_halo_conv(dout, pk, g.level.halo(), krev=True, addend=add, want_stats=True, tag="spconv_dgrad",
+                                                            bn_epi=bt.epi)
+                            bt.partial = (st, tr)
+                        else:
+                            din = nv.subm_halo_conv(dout, pk, g.level.halo(), krev=True, addend=add, tag="spconv_dgrad")
                     else:
-                        din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True, addend=add)
+                        r = nv.spconv_dgrad_bnstats(dout, wc, nbr, g.n_in_dev, g.n_in, cin, add, bt.epi) if (bt is not None and kvol > 1) else None
+                        if r is not None:
+                            din, bt.partial = r[0], (r[1], r[2])
+                        else:
+                            din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True, addend=add)
             if fan is not None:
                 din = fan.step(din)
         elif ctx.res_token is not None:
             ctx.res_token.dres = None
-        return din, dw, None, None, None, None, None
+        return din, dw, None, None, None, None, None, None
 
 
 def sparse_conv(feats, weight, geom, layout="dhwio", fan_token=None):
@@ -306,25 +338,31 @@ def sparse_conv(feats, weight, geom, layout="dhwio", fan_token=None):
     return _SparseConv.apply(feats, weight, geom, layout, False, None, fan_token)
 
 
+# BatchNorm-backward sums out of the consumer's dgrad epilogue (BnGradToken).  Measured in the captured step: 24 of 45 statistics
+# passes disappear (-0.44 ms) but the fragment-shaped 8 B loads of x in the conv epilogues cost +0.85 ms (each (row block, column
+# block) iteration waits for its own loads): off until the epilogue stages the x tile through LDS with coalesced loads.
+BN_GRAD_FUSION = os.environ.get("U3D_BN_GRAD_FUSION", "0") == "1"
 FUSED_CONV_STATS = os.environ.get("U3D_FUSED_CONV_STATS", "1") == "1"
 
 
 def conv_bn(feats, weight, geom, bn, n_dev, residual=None, relu=True, layout="dhwio", post_add=None, res_take=None, res_give=None,
-            fan_token=None):
+            fan_token=None, bn_in=None, bn_out=None):
     """conv -> BatchNorm rows (+ residual) (+ ReLU).  In training the conv's epilogue already reduces the BatchNorm statistics per row
     tile where its kernel supports it (bf16, channels % 64 == 0): the separate statistics pass over the conv output disappears."""
     if FUSED_CONV_STATS and bn.training and feats.dtype == torch.bfloat16 and feats.is_cuda:
         # res_take: this conv's input is the identity of a residual block - its backward sums the token's gradient into the input
         # gradient; res_give: this BatchNorm adds that identity - its backward leaves the identity's gradient in the token
         # fan_token: this conv is one of several that take the same input (FanoutToken)
-        y, stats = _SparseConv.apply(feats, weight, geom, layout, True, res_take, fan_token)
+        # bn_in: BnGradToken of the BatchNorm that produced `feats`, when this conv's input gradient is that layer's whole dy;
+        # bn_out: token this call's BatchNorm fills for ITS consumer
+        y, stats = _SparseConv.apply(feats, weight, geom, layout, True, res_take, fan_token, bn_in)
         if stats.numel():
             tr = getattr(stats, "_u3d_tile_rows", None)
             if tr is None:                      # attribute lost on the way through autograd: recover it from the shape
                 nb = stats.shape[0]
                 tr = 128 if (y.shape[0] + 127) // 128 == nb else (256 if (y.shape[0] + 255) // 256 == nb else 0)
-            return _BNRows.apply(y, bn.weight, bn.bias, residual, n_dev, bn, relu, True, stats, tr, None, post_add, res_give)
-        return _BNRows.apply(y, bn.weight, bn.bias, residual, n_dev, bn, relu, bn.training, None, 0, None, post_add, res_give)
+            return _BNRows.apply(y, bn.weight, bn.bias, residual, n_dev, bn, relu, True, stats, tr, None, post_add, res_give, bn_out)
+        return _BNRows.apply(y, bn.weight, bn.bias, residual, n_dev, bn, relu, bn.training, None, 0, None, post_add, res_give, bn_out)
     return bn_rows(sparse_conv(feats, weight, geom, layout, fan_token), bn, n_dev, residual, relu, None, post_add)
 
 
@@ -332,7 +370,8 @@ class _BNRows(torch.autograd.Function):
     """BatchNorm1d over active rows (+ residual) (+ ReLU), training or eval statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, n_dev, bn, relu, training, stats=None, tile_rows=0, row_map=None, post_add=None, res_token=None):
+    def forward(ctx, x, gamma, beta, residual, n_dev, bn, relu, training, stats=None, tile_rows=0, row_map=None, post_add=None, res_token=None,
+                bn_tok=None):
         n = x.shape[0]
         if training and stats is not None:
             mean, invstd = nv.bn_finalize_partials(stats, tile_rows, n_dev, n, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
@@ -356,13 +395,24 @@ class _BNRows(torch.autograd.Function):
         ctx.row_map = row_map
         ctx.has_post = post_add is not None
         ctx.res_token = res_token if residual is not None else None
+        # BatchNorm-backward sums from the consumer's input-gradient launch (BnGradToken): training statistics, plain row order, bf16
+        ctx.bn_tok = None
+        if bn_tok is not None and training and row_map is None and post_add is None and x.dtype == torch.bfloat16 and x.is_cuda:
+            bn_tok.fill(x, None if ctx.remask else y, mean, invstd, g32, b32, relu)
+            ctx.bn_tok = bn_tok
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, mean, invstd, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
-        sums, s32 = nv.bn_bwd_stats(dy, y, x, mean, invstd, ctx.relu, ctx.n_dev, gamma, beta, ctx.row_map, want_f32=True)
+        tok, part = ctx.bn_tok, None
+        if tok is not None:
+            part, tok.partial, tok.epi, tok.keep = tok.partial, None, None, None
+        if part is not None:      # the conv that consumed this layer's output already reduced them per row tile on writing dy
+            sums, s32 = nv.bn_bwd_finalize_partials(part[0], part[1], ctx.n_dev, x.shape[0])
+        else:
+            sums, s32 = nv.bn_bwd_stats(dy, y, x, mean, invstd, ctx.relu, ctx.n_dev, gamma, beta, ctx.row_map, want_f32=True)
         if not ctx.training:
             # eval statistics are constants: dx = gamma*invstd*g
             zero = torch.zeros_like(sums)
@@ -374,7 +424,7 @@ class _BNRows(torch.autograd.Function):
         if ctx.res_token is not None and dres is not None:
             ctx.res_token.dres, dres = dres, None            # picked up by the block's first conv (ResidualToken)
         # post_add enters y by a plain sum: its gradient is dy itself (no launch)
-        return dx, s32[1], s32[0], dres, None, None, None, None, None, None, None, (dy if ctx.has_post else None), None
+        return dx, s32[1], s32[0], dres, None, None, None, None, None, None, None, (dy if ctx.has_post else None), None, None
 
 
 def bn_rows(x, bn, n_dev, residual=None, relu=True, row_map=None, post_add=None):
