@@ -28,6 +28,78 @@ struct BnEpi {
   const float *mean = nullptr, *invstd = nullptr, *gamma = nullptr, *beta = nullptr;
   int relu = 0, pad = 0;
 };
+// BatchNorm-backward sums of one BM x BN output tile whose rounded dy the epilogue left in LDS (16 B chunks, XOR-swizzled rows):
+// the per-tile form of k_col_stats_vec<., 1> (rowops.hip) - a thread owns 8 columns and every R-th row, x (and y for the mask of
+// layers with a residual) arrive by coalesced 16 B loads, the R row lanes are added in a fixed order, one f64 partial per
+// (tile, column) leaves.  It does not touch the accumulators (dead by then): a pass over the MFMA fragments cost the kernels their
+// register allocation (128 x 128 tiles: 180 -> 288 VGPRs; so did calling this out of line), and fragment-shaped 8 B global loads of
+// x made every (row block, column block) step wait for its own round trip (+35 us per launch).
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void bn_bwd_tile_sums(const BnEpi bn, u16* smem, int m0, int col0, int n_out, int cout, int tile,
+                                              double* __restrict__ stats, int tid) {
+  constexpr int CPR = BN / 8, SWZ = (CPR - 1) & 15, R = NT / CPR, ROWS = BM / R, BATCH = ROWS < 8 ? ROWS : 8;
+  static_assert(NT % CPR == 0 && BM % R == 0 && ROWS % BATCH == 0, "tile / thread mismatch");
+  const int cc = tid % CPR, r0 = tid / CPR;
+  const int col = col0 + cc * 8;
+  const bool from_y = bn.relu && bn.y, remask = bn.relu && !bn.y;
+  float s0[8], s1[8], mu[8], is[8], ga[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; ga[e] = 0.f; be[e] = 0.f; }
+  __syncthreads();                                      // every wave's dy fragments are in LDS
+  if (col < cout) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { mu[e] = bn.mean[col + e]; is[e] = bn.invstd[col + e]; }
+    if (remask) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ga[e] = bn.gamma[col + e]; be[e] = bn.beta[col + e]; }
+    }
+    for (int i0 = 0; i0 < ROWS; i0 += BATCH) {
+      bf16x8 xv[BATCH], yv[BATCH];
+#pragma unroll
+      for (int i = 0; i < BATCH; ++i) {
+        const int r = r0 + (i0 + i) * R;
+        const long long o = (long long)(m0 + r) * cout + col;
+        if (m0 + r < n_out) {
+          xv[i] = *(const bf16x8*)(bn.x + o);
+          if (from_y) yv[i] = *(const bf16x8*)(bn.y + o);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < BATCH; ++i) {
+        const int r = r0 + (i0 + i) * R;
+        if (m0 + r >= n_out) continue;
+        const bf16x8 dv = *(const bf16x8*)(smem + (r * CPR + (cc ^ (r & SWZ))) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = ((float)xv[i][e] - mu[e]) * is[e];
+          float gm = (float)dv[e];
+          const float yy = from_y ? (float)yv[i][e] : xh * ga[e] + be[e];
+          if (bn.relu && !(yy > 0.f)) gm = 0.f;
+          s0[e] += gm;
+          s1[e] += gm * xh;
+        }
+      }
+    }
+  }
+  __syncthreads();                                      // the dy tile is dead: the buffers take the row lanes' sums
+  float* red = (float*)smem;                            // [2][R][BN]
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[(0 * R + r0) * BN + cc * 8 + e] = s0[e];
+    red[(1 * R + r0) * BN + cc * 8 + e] = s1[e];
+  }
+  __syncthreads();
+  for (int t = tid; t < 2 * BN; t += NT) {
+    const int which = t / BN, cl = t % BN;
+    if (col0 + cl < cout) {
+      double a = 0.0;
+#pragma unroll 4
+      for (int k = 0; k < R; ++k) a += (double)red[(which * R + k) * BN + cl];
+      stats[((long long)tile * 2 + which) * cout + col0 + cl] = a;
+    }
+  }
+}
+
 #ifndef IGEMM_SMALL_C
 #define IGEMM_SMALL_C 1
 #endif
@@ -1610,7 +1682,7 @@ extern "C" int32_t u3d_igemm_dgrad_bnstats_bf16(const void* in, const void* w, c
   const int tr = u3d_igemm_fwd_stats_tile_rows(n_out_cap, cin, cout);
   if (tr == 0) return U3D_ERR_UNSUPPORTED;
   if (tr == 256) {
-    if (!(IGEMM_GLDS8 && nbr) || bn->y) return U3D_ERR_UNSUPPORTED;      // (mask from y: 128-row tiles only, glds_epilogue.inc)
+    if (!(IGEMM_GLDS8 && nbr)) return U3D_ERR_UNSUPPORTED;
     return launch_igemm_glds<GLDS256_CFG>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, add, fl, stats, e);
   }
   if (igemm_glds8n_shape(nbr, n_out_cap, cin, cout, kvol))

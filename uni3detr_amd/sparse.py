@@ -338,9 +338,11 @@ def sparse_conv(feats, weight, geom, layout="dhwio", fan_token=None):
     return _SparseConv.apply(feats, weight, geom, layout, False, None, fan_token)
 
 
-# BatchNorm-backward sums out of the consumer's dgrad epilogue (BnGradToken).  Measured in the captured step: 24 of 45 statistics
-# passes disappear (-0.44 ms) but the fragment-shaped 8 B loads of x in the conv epilogues cost +0.85 ms (each (row block, column
-# block) iteration waits for its own loads): off until the epilogue stages the x tile through LDS with coalesced loads.
+# BatchNorm-backward sums out of the consumer's dgrad epilogue (BnGradToken).  Measured in the captured step (profiles/
+# r03_bn_grad_fusion_diff.txt): 24 of the 45 statistics passes disappear (-0.47 ms of k_col_stats_vec), but the conv launches that
+# take them over grow by +0.44 ms (per-tile sums in a tail that runs at one or two workgroups per CU: its x loads and ~8 VALU ops per
+# element are exposed, where the separate pass streams at full occupancy), and k_bn_bwd_apply loses the L2 hits the statistics pass
+# left behind (+0.05 ms): 19.77 -> 19.85 ms per step.  Kept (parity-tested) but off.
 BN_GRAD_FUSION = os.environ.get("U3D_BN_GRAD_FUSION", "0") == "1"
 FUSED_CONV_STATS = os.environ.get("U3D_FUSED_CONV_STATS", "1") == "1"
 
