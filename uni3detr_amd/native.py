@@ -503,6 +503,8 @@ class SubmHalo:
     the forward neighbour table, shared by all of the level's 64 -> 64 convs and (offsets reversed) their input gradients."""
     TILE = 128
 
+    MAX_ROWS = 106 * 256 * 32       # u3d_subm_halo_build's LDS row bitmap: 6 B per 32 rows + 1 KiB within 160 KiB
+
     def __init__(self, nbr_fwd, n_dev, n_cap):
         dev = nbr_fwd.device
         a, b, t = C.c_int64(0), C.c_int64(0), C.c_int32(0)
@@ -511,8 +513,11 @@ class SubmHalo:
         self.tile_rows = torch.empty((a.value,), dtype=torch.int32, device=dev)
         self.loc = torch.empty((b.value,), dtype=torch.int16, device=dev)
         self.tile_cnt = torch.empty((t.value,), dtype=torch.int32, device=dev)
-        _check(lib().u3d_subm_halo_build(_ptr(nbr_fwd), nbr_fwd.shape[1], _ptr(n_dev), n_cap, _ptr(self.tile_rows), _ptr(self.loc),
-                                         _ptr(self.tile_cnt), _stream()), "subm_halo_build")
+        rc = lib().u3d_subm_halo_build(_ptr(nbr_fwd), nbr_fwd.shape[1], _ptr(n_dev), n_cap, _ptr(self.tile_rows), _ptr(self.loc),
+                                       _ptr(self.tile_cnt), _stream())
+        self.ok = rc != -2              # U3D_ERR_UNSUPPORTED: more rows than the LDS row bitmap holds - the caller keeps the table kernels
+        if self.ok:
+            _check(rc, "subm_halo_build")
 
 
 def subm_halo_wpack(w_nmajor, out=None):

@@ -28,8 +28,9 @@ class Level:
     def halo(self):
         """Distinct-row lists of the 128-row tiles (native.SubmHalo) for the 64 -> 64 convs of this level: built on first use."""
         if self._halo is None:
-            self._halo = nv.SubmHalo(self.subm_tables()[0], self.n_dev, self.n)
-        return self._halo
+            h = nv.SubmHalo(self.subm_tables()[0], self.n_dev, self.n) if self.n <= nv.SubmHalo.MAX_ROWS else None
+            self._halo = h if (h is not None and h.ok) else False      # False: too many rows for the build's LDS bitmap
+        return self._halo or None
 
     def subm_tables(self):
         if self._subm is None:
@@ -214,7 +215,7 @@ class _SparseConv(torch.autograd.Function):
         nv.CALL_KIND = geom.kind
         lat = geom.lattice if (LATTICE_KERNEL and nmajor and geom.lattice is not None and geom.lattice[2] == 3) else None
         ctx.halo = (SUBM_HALO and REV_SUBM_TABLE and nmajor and geom.level is not None and kv == 27 and cin == 64 and cout == 64
-                    and geom.n_out >= 4096)
+                    and geom.n_out >= 4096 and geom.level.halo() is not None)
         if ctx.halo:
             pk_fwd, ctx.pk_bwd = halo_packs(weight, kio, koi)
             if want_stats:
