@@ -55,6 +55,17 @@ def main():
         for (key, name), (cnt, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:110]:
             print(f"{t:8.0f} us {cnt:4d}x  {name:28s} {key}")
         return
+    if "--sums" in sys.argv:                       # the gradient sums the autograd engine issues itself: shapes + the node being evaluated
+        for e in prof.events():
+            t = getattr(e, "self_device_time_total", 0) or 0
+            if t <= 0 or e.name not in ("aten::add_", "aten::add"):
+                continue
+            chain, par = [], e.cpu_parent
+            while par is not None and len(chain) < 4:
+                chain.append(par.name.replace("autograd::engine::evaluate_function: ", "bwd:")[:60])
+                par = par.cpu_parent
+            print(f"{t:6.0f} us {e.name:12s} {str(e.input_shapes)[:70]:70s} <- {' <- '.join(chain)}")
+        return
     if "--aten" in sys.argv:                       # only the ATen launches, grouped by input shapes
         rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and (e.self_device_time_total or 0) > 0]
         rows.sort(key=lambda e: -e.self_device_time_total)
