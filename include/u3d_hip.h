@@ -382,6 +382,10 @@ int32_t u3d_nms3d(const float* boxes, const int32_t* labels, int32_t n, float th
  * for stride > 1 (ref: models/backbones/second_3d.py:52-76 first conv of each block). */
 int32_t u3d_tap_gather_sum(const void* p, const int32_t* nbr, int32_t ld, const int32_t* n_dev, int32_t n_cap, int32_t c,
                            int32_t kvol, int32_t dtype, void* out, u3d_stream s);
+/* ... + addend (nullable; out's shape and dtype): the input gradients the other branches of a shared input already summed
+ * (SECOND3D with is_cascade=False, ref: second_3d.py:89-114) - autograd's separate element-wise add over the full tensor disappears. */
+int32_t u3d_tap_gather_sum_add(const void* p, const int32_t* nbr, int32_t ld, const int32_t* n_dev, int32_t n_cap, int32_t c,
+                               int32_t kvol, int32_t dtype, const void* addend, void* out, u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension of a row matrix [n, C] (C <= 1024) with optional fused ReLU; input and output dtypes are

@@ -800,7 +800,8 @@ extern "C" int32_t u3d_from_dense(const void* dense, const int32_t* coors, const
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_tap_gather_sum(const T* __restrict__ p, const int* __restrict__ nbr, int ld,
-                                                        const int* __restrict__ n_dev, int n_cap, int c, int kvol, T* __restrict__ out) {
+                                                        const int* __restrict__ n_dev, int n_cap, int c, int kvol, T* __restrict__ out,
+                                                        const T* __restrict__ addend) {
   constexpr int V = VecOf<T>::N;
   const int n = min(*n_dev, n_cap), cv = c / V;
   const long long total = (long long)n * cv;
@@ -810,6 +811,7 @@ __global__ __launch_bounds__(256) void k_tap_gather_sum(const T* __restrict__ p,
     float acc[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    if (addend) load_vec<T>(addend + (long long)i * c + (long long)vc * V, acc);      // e.g. the other branches' input gradients (FanoutToken)
     for (int k = 0; k < kvol; ++k) {
       const int o = nbr[(long long)k * ld + i];
       if (o >= 0) {
@@ -824,14 +826,18 @@ __global__ __launch_bounds__(256) void k_tap_gather_sum(const T* __restrict__ p,
 }
 extern "C" int32_t u3d_tap_gather_sum(const void* p, const int32_t* nbr, int32_t ld, const int32_t* n_dev, int32_t n_cap, int32_t c,
                                       int32_t kvol, int32_t dtype, void* out, u3d_stream s) {
+  return u3d_tap_gather_sum_add(p, nbr, ld, n_dev, n_cap, c, kvol, dtype, nullptr, out, s);
+}
+extern "C" int32_t u3d_tap_gather_sum_add(const void* p, const int32_t* nbr, int32_t ld, const int32_t* n_dev, int32_t n_cap, int32_t c,
+                                          int32_t kvol, int32_t dtype, const void* addend, void* out, u3d_stream s) {
   U3D_REQUIRE(p && nbr && n_dev && out && c > 0 && kvol > 0, U3D_ERR_ARG);
   if (n_cap <= 0) return U3D_OK;
   if (dtype == U3D_BF16 && c % 8 == 0) {
     int g = ew_grid((long long)n_cap * (c / 8));
-    hipLaunchKernelGGL(k_tap_gather_sum<u16>, dim3(g), dim3(256), 0, s, (const u16*)p, nbr, ld, n_dev, n_cap, c, kvol, (u16*)out);
+    hipLaunchKernelGGL(k_tap_gather_sum<u16>, dim3(g), dim3(256), 0, s, (const u16*)p, nbr, ld, n_dev, n_cap, c, kvol, (u16*)out, (const u16*)addend);
   } else if (dtype == U3D_F32 && c % 4 == 0) {
     int g = ew_grid((long long)n_cap * (c / 4));
-    hipLaunchKernelGGL(k_tap_gather_sum<float>, dim3(g), dim3(256), 0, s, (const float*)p, nbr, ld, n_dev, n_cap, c, kvol, (float*)out);
+    hipLaunchKernelGGL(k_tap_gather_sum<float>, dim3(g), dim3(256), 0, s, (const float*)p, nbr, ld, n_dev, n_cap, c, kvol, (float*)out, (const float*)addend);
   } else return U3D_ERR_UNSUPPORTED;
   U3D_CHECK_LAUNCH();
   return U3D_OK;

@@ -128,6 +128,7 @@ _SIGS = {
     "u3d_nms3d": (_I, [_P, _P, _I, C.c_float, _P, _P, _L, _P]),
     "u3d_iou3d_rotated_aligned": (_I, [_P, _P, _I, _P, _P]),
     "u3d_tap_gather_sum": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
+    "u3d_tap_gather_sum_add": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
     "u3d_wgrad_batched_workspace": (_L, [_I, _I, _I, _I]),
     "u3d_wgrad_batched_bf16": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _L, _P]),
     "u3d_skinny_wgrad_chunks": (_I, [_I]),
@@ -968,11 +969,13 @@ def capacity_flag(counts, caps, flag):
            "capacity_flag")
 
 
-def tap_gather_sum(p, nbr, n_dev, n, c, kvol):
-    """din[i] = sum_k p[nbr[k][i], k*c:(k+1)*c] (f32 accumulate); p: [n_out, kvol*c]."""
+def tap_gather_sum(p, nbr, n_dev, n, c, kvol, addend=None):
+    """din[i] = sum_k p[nbr[k][i], k*c:(k+1)*c] (+ addend[i]) (f32 accumulate); p: [n_out, kvol*c]."""
     out = torch.empty((n, c), dtype=p.dtype, device=p.device)
-    _check(lib().u3d_tap_gather_sum(_ptr(p), _ptr(nbr), nbr.shape[1], _ptr(n_dev), n, c, kvol, dtype_code(p), _ptr(out), _stream()),
-           "tap_gather_sum")
+    if addend is not None:
+        assert addend.shape == out.shape and addend.dtype == out.dtype and addend.is_contiguous()
+    _check(lib().u3d_tap_gather_sum_add(_ptr(p), _ptr(nbr), nbr.shape[1], _ptr(n_dev), n, c, kvol, dtype_code(p), _ptr(addend), _ptr(out),
+                                        _stream()), "tap_gather_sum")
     return out
 
 

@@ -292,8 +292,9 @@ class _SparseConv(torch.autograd.Function):
             if (STRIDED_DGRAD_SPLIT and g.strided and kvol > 1 and dout.dtype == torch.bfloat16 and cout % 64 == 0
                     and (kvol * cin) % 64 == 0 and g.n_out * STRIDED_SPLIT_MIN_RATIO <= g.n_in):      # stride 4: 15/16 of the direct dgrad's MFMAs hit zero rows
                 prod = nv.linear_bf16(dout, wc.view(kvol * cin, cout), None, False)      # [n_out, K*Cin]
-                din = nv.tap_gather_sum(prod, nbr, g.n_in_dev, g.n_in, cin, kvol)
-                if facc is not None:
+                fa = facc if (facc is not None and facc.dtype == prod.dtype and facc.is_contiguous() and facc.shape == (g.n_in, cin)) else None
+                din = nv.tap_gather_sum(prod, nbr, g.n_in_dev, g.n_in, cin, kvol, addend=fa)      # the other branches' sum rides the gather
+                if facc is not None and fa is None:
                     din += facc
             else:
                 din = None
