@@ -160,7 +160,11 @@ def main():
     # two-phase backward: for N > 1 the flat-gradient all-reduce of the head / decoder / dense-stack slice rides under the encoder's
     # backward; the split itself is free (25.34 vs 25.44 ms on one GPU), so N = 1 runs the same schedule
     overlap = os.environ.get("U3D_OVERLAP_REDUCE", "1") == "1"
-    ts = TrainStep(model, data["points"], data["gt_bboxes_3d"], data["gt_labels_3d"], graph=not args.no_graph, overlap_reduce=overlap)
+    # a sparse level outgrowing its captured capacity on ANY rank holds the step on all ranks (the flag rides the positive-count
+    # all-reduce) and re-captures collectively: the process group is torn down for the capture and re-created afterwards
+    pg_hooks = ((lambda: dist.destroy_process_group()), init_pg) if use_dist else None
+    ts = TrainStep(model, data["points"], data["gt_bboxes_3d"], data["gt_labels_3d"], graph=not args.no_graph, overlap_reduce=overlap,
+                   pg_hooks=pg_hooks)
     caps = None
     launch_mode = "eager" if args.no_graph else "hipGraph"
     census, marker, mark_targets = None, None, []

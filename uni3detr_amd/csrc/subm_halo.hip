@@ -179,7 +179,15 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo64(const u16* __restrict__ 
                                                         double* __restrict__ stats, const HlBn bn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u16* xs = (u16*)smem;                           // [HL_MAXS][HL_RS]
-  const int tid = threadIdx.x, tile = blockIdx.x;
+  const int tid = threadIdx.x;
+#ifdef HL_NO_XCD_MAP
+  const int tile = blockIdx.x;
+#else
+  // workgroups go round-robin over the 8 XCDs: give each XCD a CONTIGUOUS range of tiles - neighbouring tiles share most of their
+  // halo rows, which then hit that XCD's L2 instead of being fetched once per XCD
+  const int xq = gridDim.x >> 3, xr = gridDim.x & 7, xcd = blockIdx.x & 7;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+#endif
   const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kq = lane >> 4;
   const int m0 = tile * HL_T;
