@@ -137,7 +137,7 @@ def strided_level(lvl, ksize, stride, pad, capacity=None):
     out = Level(g, g.coords(n_out), n_out, g.count_dev)
     fwd = lvl.grid.nbr_table(out.coords, out.n_dev, ksize, stride, pad, 0)
     bwd = g.nbr_table(lvl.coords, lvl.n_dev, ksize, stride, pad, 1)
-    return out, ConvGeom(fwd, bwd, lvl.n, lvl.n_dev, n_out, out.n_dev)
+    return out, ConvGeom(fwd, bwd, lvl.n, lvl.n_dev, n_out, out.n_dev, strided=True)
 
 
 REV_SUBM_TABLE = os.environ.get("U3D_REV_SUBM_TABLE", "1") == "1"
@@ -146,6 +146,7 @@ LATTICE_KERNEL = os.environ.get("U3D_LATTICE_KERNEL", "0") == "1"      # 27-offs
 STRIDED_DGRAD_SPLIT = os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
 NMAJOR_FWD = os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
 STRIDED_SPLIT_MIN_RATIO = int(os.environ.get("U3D_STRIDED_SPLIT_MIN_RATIO", "16"))
+STRIDED_SPLIT_SPARSE_RATIO = int(os.environ.get("U3D_STRIDED_SPLIT_SPARSE_RATIO", "16"))      # same threshold for the sparse levels' strided convs
 
 
 # Weight gradients on a side stream (opt-in, see wgrad_side_stream()): dW of a conv is off the backward's critical chain
@@ -290,7 +291,8 @@ class _SparseConv(torch.autograd.Function):
             fan = ctx.fan_token
             facc = fan.acc if fan is not None else None          # partial sum of the branches that ran before this one
             if (STRIDED_DGRAD_SPLIT and g.strided and kvol > 1 and dout.dtype == torch.bfloat16 and cout % 64 == 0
-                    and (kvol * cin) % 64 == 0 and g.n_out * STRIDED_SPLIT_MIN_RATIO <= g.n_in):      # stride 4: 15/16 of the direct dgrad's MFMAs hit zero rows
+                    and (kvol * cin) % 64 == 0
+                    and g.n_out * (STRIDED_SPLIT_SPARSE_RATIO if g.kind == "sparse" else STRIDED_SPLIT_MIN_RATIO) <= g.n_in):      # stride 4: 15/16 of the direct dgrad's MFMAs hit zero rows
                 prod = nv.linear_bf16(dout, wc.view(kvol * cin, cout), None, False)      # [n_out, K*Cin]
                 fa = facc if (facc is not None and facc.dtype == prod.dtype and facc.is_contiguous() and facc.shape == (g.n_in, cin)) else None
                 din = nv.tap_gather_sum(prod, nbr, g.n_in_dev, g.n_in, cin, kvol, addend=fa)      # the other branches' sum rides the gather
