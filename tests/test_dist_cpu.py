@@ -1,5 +1,7 @@
-"""CPU, world size 2, gloo: the N>1 specific host logic — the fused scalar all-reduces of the loss / log-vars and the DDP
-wrapping bench.py uses (gradient averaging with bucket views) on a CPU-runnable stand-in with the detector's call signature."""
+"""CPU, world size 2, gloo: the N>1 specific host logic - the fused scalar all-reduces of the loss / log-vars, and the reductions of
+uni3detr_amd.trainer.TrainStep as bench.py runs them for N > 1 (flat gradient buffer averaged in two buckets, the first one in
+flight under the second half of the backward; ONE small message per step carrying the positive counts and the capacity flag),
+called as unbound methods on a CPU stand-in that holds the attributes they touch."""
 import os
 import socket
 
@@ -36,30 +38,24 @@ def _worker(rank, world, port, q):
         assert abs(float(loss) - (1.0 + rank + 2.0 + 3.0 * (rank + 1))) < 1e-6            # local loss drives backward
         assert abs(float(logs["loss_cls"]) - 1.5) < 1e-6 and abs(float(logs["acc"]) - 5.0) < 1e-6
         assert abs(float(logs["loss"]) - (1.5 + 2.0 + 4.5)) < 1e-6
-        # (3) DDP exactly as bench.py wraps the detector (kwargs-only forward returning a loss dict)
-        class Toy(torch.nn.Module):
-            def __init__(self):
-                super().__init__()
-                self.a = torch.nn.Linear(4, 4)
-                self.b = torch.nn.Linear(4, 1)
-
-            def forward(self, return_loss=True, points=None, **kw):
-                return {"loss_x": self.b(torch.relu(self.a(points))).pow(2).mean()}
-        torch.manual_seed(0)
-        toy = Toy()
-        ref = Toy()
-        ref.load_state_dict(toy.state_dict())
-        net = torch.nn.parallel.DistributedDataParallel(toy, gradient_as_bucket_view=True, bucket_cap_mb=64, broadcast_buffers=False)
-        xs = [torch.arange(8.0).view(2, 4) * (r + 1) for r in range(world)]
-        net(return_loss=True, points=xs[rank])["loss_x"].backward()
-        exp = [torch.zeros_like(p) for p in ref.parameters()]
-        for r in range(world):
-            ref.zero_grad()
-            ref(points=xs[r])["loss_x"].backward()
-            for e, p in zip(exp, ref.parameters()):
-                e += p.grad / world
-        for e, p in zip(exp, toy.parameters()):
-            assert torch.allclose(p.grad, e, atol=1e-6)
+        # (3) TrainStep's own reductions (bench.py, N > 1): the flat gradient is averaged in two buckets - [enc_end:) asynchronously,
+        #     then [:enc_end) - and equals the mean of the ranks' local gradients element for element; the per-step message
+        #     averages the positive counts and turns ANY rank's capacity flag into a positive flag on every rank
+        from types import SimpleNamespace
+        from uni3detr_amd.trainer import TrainStep
+        g = torch.Generator().manual_seed(7)
+        local = [torch.randn(1000, generator=g) * (r + 1) for r in range(world)]
+        st = SimpleNamespace(dist_on=True, world=world, flat_grad=local[rank].clone(), enc_end=384, _work=None,
+                             _msg=torch.tensor([30.0, 20.0, 10.0, 1.0 if rank == 1 else 0.0]) * torch.tensor([rank + 1.0] * 3 + [1.0]))
+        TrainStep._reduce_grads_a(st)
+        assert st._work is not None
+        TrainStep._reduce_grads_b(st)
+        assert st._work is None and torch.allclose(st.flat_grad, sum(local) / world, atol=1e-6)
+        st2 = SimpleNamespace(dist_on=True, world=world, flat_grad=local[rank].clone())
+        TrainStep._reduce_grads(st2)
+        assert torch.allclose(st2.flat_grad, st.flat_grad, atol=1e-6)
+        TrainStep._reduce_num_pos(st)
+        assert torch.allclose(st._msg[:3], torch.tensor([45.0, 30.0, 15.0])) and float(st._msg[3]) > 0.0      # rank 1's overflow holds rank 0 too
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
@@ -67,7 +63,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_world2_gloo_scalar_reductions_and_ddp():
+def test_world2_gloo_scalar_reductions_and_trainstep_buckets():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
