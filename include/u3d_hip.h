@@ -231,7 +231,18 @@ int32_t u3d_subm_halo_wpack(const void* w_nmajor, void* w_packed, u3d_stream s);
 int32_t u3d_subm_halo_wpack_batched(const void* const* srcs_dev, void* const* dsts_dev, int32_t n, u3d_stream s);
 int32_t u3d_subm_halo_conv64_bf16(const void* in, const void* w_packed, const int32_t* tile_rows, const uint16_t* loc,
                                   const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, int32_t krev,
-                                  const void* addend, void* out, double* stats, const u3d_bn_epi* bn, u3d_stream s);
+                                  const void* addend, void* out, double* stats, const u3d_bn_epi* bn, int32_t max_slots,
+                                  u3d_stream s);
+/* Weight gradient of the same 64 -> 64 SubM layers from the same tables: dw f32 [27][64][64] (spconv-1.x layout) =
+ * sum over rows m of x[nbr_k(m)]^T dy[m]; x / dy bf16 [n][64].  Persistent workgroups, both MFMA operands by transpose reads out of
+ * the staged distinct rows / the dy tile, offsets split over four workgroup groups, one f32 partial per workgroup summed in a fixed
+ * order (deterministic).  workspace: u3d_subm_halo_wgrad64_workspace() bytes.  max_slots (both functions): 0 = the stage buffer's
+ * capacity; a lower value only forces the fall-back paths for tiles with more distinct rows (test hook).  Replaces u3d_igemm_wgrad_bf16 for this shape (ref: the
+ * weight half of spconv's indice_conv_backward for sparse_encoder_hd.py:106-138). */
+int64_t u3d_subm_halo_wgrad64_workspace(void);
+int32_t u3d_subm_halo_wgrad64_bf16(const void* x, const void* dy, const int32_t* tile_rows, const uint16_t* loc,
+                                   const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, float* dw, void* workspace,
+                                   int64_t workspace_bytes, int32_t max_slots, u3d_stream s);
 int64_t u3d_igemm_wgrad_bf16_workspace(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol);
 /* out_layout 0: dw [K][Cin][Cout] (spconv-1.x / this library's layout); 1: dw [Cout][Cin][K] (nn.Conv3d's [Cout,Cin,kD,kH,kW]). */
 int32_t u3d_igemm_wgrad_bf16(const void* in, const void* dout, const int32_t* nbr, int32_t ld, float* dw,

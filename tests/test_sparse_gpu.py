@@ -970,6 +970,10 @@ def test_subm_halo_kernel_matches_the_table_kernels(cuda, seed, n_pts, dims, cut
     assert (stats[:, 0].sum(0) - yf.sum(0)).abs().max() < 1e-3 * yf.abs().sum(0).max()
     assert (stats[:, 1].sum(0) - (yf * yf).sum(0)).abs().max() < 1e-4 * (yf * yf).sum(0).max()
     assert torch.equal(nv.subm_halo_conv(x, wp, halo)[:n], y[:n])                 # deterministic, statistics do not change the output
+    # rows beyond the staged slots are read from global memory (test hook: stage only 150 / 40 slots): same products, same order
+    assert int(halo.tile_cnt.max()) > 40
+    for ms in (150, 40):
+        assert torch.equal(nv.subm_halo_conv(x, wp, halo, max_slots=ms)[:n], y[:n]), ms
     # offsets reversed == the transposed table (test_subm_transposed_table_is_the_reversed_forward_table)
     g = nv.subm_halo_conv(x, wp, halo, krev=True, addend=add)
     expg = _ref_conv(x[:n], w.transpose(1, 2), nb.flip(0), n) + add[:n].float()
@@ -1055,3 +1059,41 @@ def test_bn_backward_sums_from_the_consumers_dgrad_epilogue(cuda, c, n_pts, dims
     for i, (p, q) in enumerate(zip(res[True], res[False])):
         assert torch.isfinite(p).all()
         assert (p - q).abs().max() / q.abs().max() < 2e-2, (i, float((p - q).abs().max() / q.abs().max()))
+
+
+@pytest.mark.parametrize("seed,n_pts,dims,cut", [(5, 9000, (16, 40, 36), 0), (11, 60000, (12, 64, 64), 777), (3, 300, (8, 8, 8), 0)])
+def test_subm_halo_weight_gradient(cuda, seed, n_pts, dims, cut):
+    """k_subm_halo_wgrad64 (both MFMA operands by transpose reads out of the tile's staged distinct rows / dy tile, offsets split
+    over four groups of persistent workgroups): every offset's dW against an f32 gather-matmul; a device-side row count below the
+    capacity with NaN in the dead rows; a dense level whose tiles exceed the stage buffer (the per-offset gather fall-back - checked
+    to be the case); a level smaller than one tile; zero rows; bitwise repeatable."""
+    import torch
+    from uni3detr_amd import native as nv
+    lvl, nbr = _level(seed=seed, n_pts=n_pts, dims=dims)
+    n_cap = lvl.n
+    n = n_cap - cut
+    cnt = nv.count_tensor(n, "cuda") if cut else lvl.n_dev
+    nb = nbr.clone()
+    if cut:
+        nb[:, :n][nb[:, :n] >= n] = -1
+    halo = nv.SubmHalo(nb, cnt, n_cap)
+    slots = 150 if cut else 0                                                     # test hook: tiles with more distinct rows take the fall-back path
+    assert not cut or int(halo.tile_cnt.max()) > slots
+    torch.manual_seed(seed)
+    x = torch.randn(n_cap, 64, device="cuda").bfloat16()
+    dy = torch.randn(n_cap, 64, device="cuda").bfloat16()
+    if cut:
+        x[n:] = float("nan"); dy[n:] = float("nan")
+    got = nv.subm_halo_wgrad(x, dy, halo, max_slots=slots)
+    xf = torch.cat([x[:n].float(), torch.zeros(1, 64, device="cuda")])
+    exp = torch.stack([xf[torch.where(nb[k, :n] < 0, torch.full_like(nb[k, :n], n), nb[k, :n]).long()].t() @ dy[:n].float() for k in range(27)])
+    assert torch.isfinite(got).all()
+    assert (got - exp).abs().max() / exp.abs().max() < 2e-5                       # bf16 products are exact in f32; only the summation order differs
+    ref = nv.spconv_wgrad(x, dy, nb, cnt, 27)
+    assert (got - ref).abs().max() / exp.abs().max() < 2e-5
+    assert torch.equal(nv.subm_halo_wgrad(x, dy, halo, max_slots=slots), got)      # deterministic
+    assert (nv.subm_halo_wgrad(x, dy, halo) - got).abs().max() / exp.abs().max() < 2e-5      # staged path == fall-back path
+    out = torch.empty(27 * 4096, device="cuda")
+    assert nv.subm_halo_wgrad(x, dy, halo, out=out, max_slots=slots).data_ptr() == out.data_ptr() and torch.equal(out.view(27, 64, 64), got)
+    zero = nv.SubmHalo(nb, nv.count_tensor(0, "cuda"), n_cap)
+    assert (nv.subm_halo_wgrad(x, dy, zero) == 0).all()

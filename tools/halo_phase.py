@@ -32,6 +32,20 @@ def main():
         if m[5]:
             print(f"build wg {r * 256 + 7}: start +{m[0] - buf[0]:>8d} | " + " | ".join(f"{nm} {m[i + 1] - m[i]:>6d}" for i, nm in enumerate(names)) + f" | total {m[5] - m[0]}")
     x = torch.randn(lvl.n, 64, device="cuda").bfloat16()
+    dyv = torch.randn(lvl.n, 64, device="cuda").bfloat16()
+    for _ in range(3):
+        nv.subm_halo_wgrad(x, dyv, halo)
+    torch.cuda.synchronize()
+    buf = (C.c_uint64 * 64)()
+    if nv.lib().u3d_debug_halo_wgrad_times(buf) == 0:
+        m = list(buf)
+        print(f"wgrad wg 7: prologue {m[1] - m[0]}")
+        it = 0
+        while 5 + it * 5 < 64 and m[5 + it * 5]:
+            b = 1 + it * 5
+            print(f"  tile {it}: wait+barrier {m[b + 1] - m[b]:>6d} | issue next {m[b + 2] - m[b + 1]:>6d} | dy fragments {m[b + 3] - m[b + 2]:>6d} | offsets {m[b + 4] - m[b + 3]:>6d}")
+            it += 1
+        print(f"  tail: wait {0} partial store {m[2 + it * 5] - m[1 + it * 5]}")
     w = nv.subm_halo_wpack((torch.randn(27, 64, 64, device="cuda") * 0.1).bfloat16())
     for stats in (False, True):
         for _ in range(3):

@@ -91,6 +91,7 @@ def main():
             passes["halo_fwd"] = lambda: nv.subm_halo_conv(x, wpf, halo)
             passes["halo_fwd_stats"] = lambda: nv.subm_halo_conv(x, wpf, halo, want_stats=True)
             passes["halo_dgrad"] = lambda: nv.subm_halo_conv(dy, wpb, halo, krev=True)
+            passes["halo_wgrad"] = lambda: nv.subm_halo_wgrad(x, dy, halo)
         for pname, fn in passes.items():
             for _ in range(3):
                 fn()

@@ -42,9 +42,13 @@ extern "C" int32_t u3d_debug_halo_times(uint64_t* out) { return hipMemcpyFromSym
 __device__ unsigned long long hb_dbg[8 * 8];
 #define HB_MARK(id) do { if ((blockIdx.x & 255) == 7 && blockIdx.x < 8 * 256 && threadIdx.x == 0) hb_dbg[(blockIdx.x >> 8) * 8 + id] = __builtin_readcyclecounter(); } while (0)
 extern "C" int32_t u3d_debug_halo_build_times(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(hb_dbg), 64 * 8) == hipSuccess ? 0 : -1; }
+__device__ unsigned long long hw_dbg[64];
+#define HW_MARK(id) do { if (blockIdx.x == 7 && threadIdx.x == 0 && (id) < 64) hw_dbg[id] = __builtin_readcyclecounter(); } while (0)
+extern "C" int32_t u3d_debug_halo_wgrad_times(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(hw_dbg), 64 * 8) == hipSuccess ? 0 : -1; }
 #else
 #define HL_MARK(id)
 #define HB_MARK(id)
+#define HW_MARK(id)
 #endif
 // Distinct rows of a tile, sorted, without sorting: the keys are row numbers < n_cap, so the tile marks them in an LDS BITMAP over
 // all rows (n_cap / 8 bytes; fire-and-forget ds_or), a popcount prefix over the bitmap words numbers the set bits in ascending
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo64(const u16* __restrict__ 
                                                         const int32_t* __restrict__ tile_rows, const u16* __restrict__ loc,
                                                         const int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ n_dev, int n_cap,
                                                         int krev, const u16* __restrict__ addend, u16* __restrict__ out,
-                                                        double* __restrict__ stats, const HlBn bn) {
+                                                        double* __restrict__ stats, const HlBn bn, int maxs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u16* xs = (u16*)smem;                           // [HL_MAXS][HL_RS]
   const int tid = threadIdx.x;
@@ -185,8 +189,8 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo64(const u16* __restrict__ 
 #else
   // workgroups go round-robin over the 8 XCDs: give each XCD a CONTIGUOUS range of tiles - neighbouring tiles share most of their
   // halo rows, which then hit that XCD's L2 instead of being fetched once per XCD
-  const int xq = gridDim.x >> 3, xr = gridDim.x & 7, xcd = blockIdx.x & 7;
-  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int tq = gridDim.x >> 3, trem = gridDim.x & 7, xcd = blockIdx.x & 7;
+  const int tile = (xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq) + (blockIdx.x >> 3);
 #endif
   const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kq = lane >> 4;
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo64(const u16* __restrict__ 
     return;
   }
   const int32_t* rows_p = tile_rows + (long long)tile * HL_TRC;
-  const int nl = min(tile_cnt[tile], HL_MAXS);
+  const int nl = min(tile_cnt[tile], maxs);      // staged slots (maxs <= HL_MAXS: the stage buffer; lower only as a test hook)
   // stage the distinct rows: 8 lanes x 16 B per row.  All of a thread's row indices are requested at once, then all of its rows:
   // two memory round trips per 288 slots (a loop of index -> row -> store iterations spent 15 us per launch waiting in turn)
 #ifndef HL_ABL_NOSTAGE
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo64(const u16* __restrict__ 
     sl = sln;                                                                                           \
     _Pragma("unroll") for (int b = 0; b < 4; ++b) { wf[b][0] = wn[b][0]; wf[b][1] = wn[b][1]; }          \
   }
-  if (tile_cnt[tile] <= HL_MAXS) { HL_OFFSET_LOOP(1) } else { HL_OFFSET_LOOP(0) }
+  if (tile_cnt[tile] <= maxs) { HL_OFFSET_LOOP(1) } else { HL_OFFSET_LOOP(0) }
 
   // sum the four waves' partial tiles: reduce-scatter in two rounds through the stage buffer
   f32x4* xb = (f32x4*)smem;
@@ -412,6 +416,209 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo64(const u16* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// weight gradient:  dW[k][ci][co] = sum over rows m of  x[nbr_k(m)][ci] * dy[m][co]
+// ---------------------------------------------------------------------------------------------------------------------------
+// The tiled kernel (k_igemm_wgrad_glds_64, 118 us) gathers 27 x 128 row pieces per tile through LDS-DMA like the forward did.  Here
+// the tile's distinct rows are staged once (same tables as the forward), the dy tile once, and BOTH MFMA operands come out of LDS
+// by transpose reads (ds_read_b64_tr_b16: the reduction index - the row - is the LDS row).  A transpose read takes a per-lane
+// address, so the operand of offset k is read straight from the halo rows at loc[k][m]: no gathered copy, no barrier per offset.
+//   * One persistent workgroup of EIGHT waves per CU; wave w owns input-channel block w & 3 (16 of the 64), all four output-channel
+//     blocks and 7 offsets (112 accumulator registers): the dy fragments (offset-independent) stay in registers for the tile, an
+//     offset costs one 16 B slot load, 8 transpose reads and 16 MFMAs.  A workgroup covers 14 offsets, so two GROUPS of workgroups
+//     walk the tiles (0-13 / 14-26: the rows are staged twice per launch, the second time from L2).
+//   * Staging is asynchronous: LDS-DMA (buffer_load ... lds, no staging registers - the accumulators leave none) into the OTHER of
+//     two stage buffers while the current tile is multiplied; the row indices of the tile after that are already in registers.  A
+//     first version that staged through registers between two barriers spent 20 k clocks per tile waiting for 4-5 dependent round
+//     trips against 1.8 k of MFMAs (108 us per launch: no better than the tiled kernel).
+//   * LDS-DMA writes lane-linearly (8 rows of 128 B per wave instruction), so rows are unpadded; the 16-byte pieces of a row are
+//     permuted on the SOURCE side (piece p of LDS row r lands in slot p ^ 2 * ((r >> 1) & 3), as wgrad_narrow.hip) so that the 16
+//     rows x 32 B of a transpose read spread over the banks.
+//   * One f32 partial [14][64][64] per workgroup, summed in workgroup order by k_halo_wgrad_reduce - deterministic.
+//   * Tiles whose distinct rows exceed a stage buffer (424 slots) gather each offset's 128 rows into it instead (plain loads, two
+//     barriers per offset; rare: a 128-row tile of block-major rows has 212-419 distinct rows on the bench scenes).
+#define HW_MAXS 424
+#define HW_G 2                   /* workgroup groups */
+#define HW_OPG 14                /* offsets per workgroup (two wave sets of 7) */
+#define HW_OPW 7                 /* offsets per wave */
+#define HW_XS (HW_MAXS * HL_C)   /* elements of the distinct-row stage */
+#define HW_BUF (HW_XS + HL_T * HL_C)
+#define HW_WGS 256               /* persistent workgroups: one per CU */
+typedef __attribute__((address_space(3))) void* hw_lds_ptr;
+
+__device__ __forceinline__ int hw_sw(int r) { return (r >> 1) & 3; }
+// transpose-read fragment of rows r0 + 4g + j and r1 + 4g + j (given as LDS row numbers ra, rb) at 16-column block `blk`
+__device__ __forceinline__ bf16x8 hw_trf(const u16* tile, int ra, int rb, int blk, int q) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const u16* p0 = tile + ra * HL_C + (((2 * blk + (q >> 1)) ^ (2 * hw_sw(ra))) * 8) + (q & 1) * 4;
+  const u16* p1 = tile + rb * HL_C + (((2 * blk + (q >> 1)) ^ (2 * hw_sw(rb))) * 8) + (q & 1) * 4;
+  const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p0);
+  const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p1);
+  const s16x8 v = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(512) void k_subm_halo_wgrad64(const u16* __restrict__ x, const u16* __restrict__ dy,
+                                                           const int32_t* __restrict__ tile_rows, const u16* __restrict__ loc,
+                                                           const int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ n_dev,
+                                                           int n_cap, float* __restrict__ partial, int maxs) {
+  extern __shared__ __attribute__((aligned(16))) u16 hsm[];          // [2][HW_BUF]: distinct rows [HW_MAXS][64] | dy tile [128][64]
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, L = lane & 15, j = L >> 2, q = L & 3;
+  const int cib = w & 3;                           // input-channel block of this wave
+  const int grp = blockIdx.x % HW_G, slotw = blockIdx.x / HW_G;
+  const int nslot = ((int)gridDim.x - grp + HW_G - 1) / HW_G;
+  const int kbase = grp * HW_OPG + (w >> 2) * HW_OPW;
+  const int n = min(*n_dev, n_cap);
+  const int ntiles = (n + HL_T - 1) / HL_T;
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, 0x80000000u, 0x00020000);
+
+  f32x4 acc[HW_OPW][4];
+#pragma unroll
+  for (int o = 0; o < HW_OPW; ++o)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[o][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int r16p = 4 * g + j;                      // this lane's row within a 16-row block of the transpose reads
+
+  // DMA roles: instruction a of this wave covers LDS rows (a * 8 + w) * 8 .. + 7 (8 waves interleave), lane -> row + lane / 8, piece slot lane % 8
+  constexpr int XI = (HW_MAXS / 8 + 7) / 8;        // distinct-row instructions per wave (424 rows = 53 groups of 8 rows: 7 per wave)
+  const int lrow = lane >> 3, lpc = lane & 7;
+  int idx[XI];                                     // row numbers of the NEXT tile to stage (-1: zero row / beyond the tile's count)
+  int cnt_nn = 0;                                  // ... and its number of distinct rows
+  auto load_idx = [&](int tile) {
+    const bool live = tile < ntiles;
+    const int cnt = live ? tile_cnt[tile] : 0;
+    cnt_nn = cnt;
+    const int32_t* rows_p = tile_rows + (long long)(live ? tile : 0) * HL_TRC;
+#pragma unroll
+    for (int a = 0; a < XI; ++a) {
+      const int slot = (a * 8 + w) * 8 + lrow;
+      idx[a] = (cnt <= maxs && slot > 0 && slot < cnt) ? rows_p[slot] : -1;
+    }
+  };
+  auto issue = [&](int tile, int buf, int cnt) {   // distinct rows (from idx[]) and the dy tile of `tile` -> stage buffer `buf`, asynchronously
+    u16* base = hsm + buf * HW_BUF;
+    const int nrow = cnt <= maxs ? cnt : 0;        // rows past the tile's count are never read: their 8-row groups are not fetched
+#pragma unroll                                     // (an LDS-DMA instruction costs the CU ~100-170 clocks whatever it carries)
+    for (int a = 0; a < XI; ++a) {
+      const int grp8 = a * 8 + w;                  // 8-row group
+      if (grp8 * 8 < nrow) {
+        const int slot = grp8 * 8 + lrow;
+        const unsigned voff = idx[a] >= 0 ? (unsigned)idx[a] * (unsigned)(HL_C * 2) + (unsigned)((lpc ^ (2 * hw_sw(slot))) * 16) : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (hw_lds_ptr)(base + grp8 * 512), 16, voff, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {                  // dy: 16 groups of 8 rows, two per wave; rows past n read as zeros
+      const int grp8 = a * 8 + w, r = grp8 * 8 + lrow, m = tile * HL_T + r;
+      const unsigned voff = (tile < ntiles && m < n) ? (unsigned)m * (unsigned)(HL_C * 2) + (unsigned)((lpc ^ (2 * hw_sw(r))) * 16) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rs, (hw_lds_ptr)(base + HW_XS + grp8 * 512), 16, voff, 0, 0, 0);
+    }
+  };
+
+  int cnt_next = 0;
+  HW_MARK(0);
+  if (slotw < ntiles) {
+    load_idx(slotw);
+    cnt_next = cnt_nn;
+    issue(slotw, 0, cnt_next);
+    load_idx(slotw + nslot);
+  }
+  int it = 0;
+  for (int tile = slotw; tile < ntiles; tile += nslot, ++it) {
+    const int buf = it & 1;
+    u16* xs = hsm + buf * HW_BUF;
+    const u16* dys = xs + HW_XS;
+    HW_MARK(1 + it * 5);
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's share of `tile` has landed, the next tile's indices are here
+    __syncthreads();                               // ... everybody's; and the other buffer's readers (previous tile) are done
+    HW_MARK(2 + it * 5);
+    const int cnt = cnt_next;                      // (read a tile ahead: a load here would stall the first transpose reads)
+    cnt_next = cnt_nn;
+    issue(tile + nslot, buf ^ 1, cnt_next);
+    load_idx(tile + 2 * nslot);
+    HW_MARK(3 + it * 5);
+    const bool fast = cnt <= maxs;                 // (maxs <= HW_MAXS: the stage buffer; lower only as a test hook)
+    const int32_t* rows_p = tile_rows + (long long)tile * HL_TRC;
+    bf16x8 bfr[4][4];                              // dy fragments [output-channel block][32-row block]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) bfr[c][mb] = hw_trf(dys, mb * 32 + r16p, mb * 32 + 16 + r16p, c, q);
+    __builtin_amdgcn_sched_barrier(0);
+    HW_MARK(4 + it * 5);
+    const u16* locp = loc + (long long)tile * HL_K * HL_T + r16p * 8;      // this lane's 8 slots of an offset: rows mt * 16 + r16p
+    u16x8 sl = *(const u16x8*)(locp + min(kbase, HL_K - 1) * HL_T);
+#pragma unroll
+    for (int o = 0; o < HW_OPW; ++o) {
+      const int k = kbase + o;
+      const bool live = k < HL_K;                  // (the last wave set has 6 offsets: its seventh step multiplies zero rows)
+      const u16x8 sln = *(const u16x8*)(locp + min(k + 1, HL_K - 1) * HL_T);
+      if (!fast) {                                 // rows of offsets (k of wave set 0, k of wave set 1) -> stage rows 0..127 / 128..255
+        __syncthreads();                           // the previous offset's reads are done
+        const int set = tid >> 8, t2 = tid & 255, m = t2 >> 1, half = t2 & 1;
+        const int kk = grp * HW_OPG + set * HW_OPW + o;
+        const int s = kk < HL_K ? loc[(long long)tile * HL_K * HL_T + kk * HL_T + (m & 15) * 8 + (m >> 4)] : 0;
+        const int row = set * 128 + m;
+        u32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (u32x4){0u, 0u, 0u, 0u};
+        if (s > 0) {
+          const u16* src = x + (long long)rows_p[s] * HL_C + half * 32;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = *(const u32x4*)(src + i * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(u32x4*)(xs + row * HL_C + (((half * 4 + i) ^ (2 * hw_sw(row))) * 8)) = v[i];
+        __syncthreads();
+      }
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const int sbase = (w >> 2) * 128;
+        const int s0 = fast ? (live ? (int)sl[2 * mb] : 0) : sbase + mb * 32 + r16p;
+        const int s1 = fast ? (live ? (int)sl[2 * mb + 1] : 0) : sbase + mb * 32 + 16 + r16p;
+        const bf16x8 a = hw_trf(xs, s0, s1, cib, q);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[o][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[c][mb], a, acc[o][c], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);           // (or every offset's transpose reads are hoisted to the top: 112 registers of operands)
+      sl = sln;
+    }
+    HW_MARK(5 + it * 5);
+  }
+  HW_MARK(1 + it * 5);
+  __builtin_amdgcn_s_waitcnt(0x0F70);              // (nothing of a DMA issued past the last tile may be in flight at exit)
+  // one partial per workgroup: acc[o][c][r] = dW[k = kbase + o][ci = cib * 16 + (lane & 15)][co = c * 16 + 4 * (lane >> 4) + r]
+  float* pp = partial + (long long)blockIdx.x * HW_OPG * HL_C * HL_C + (long long)((w >> 2) * HW_OPW) * HL_C * HL_C;
+#pragma unroll
+  for (int o = 0; o < HW_OPW; ++o)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *(f32x4*)(pp + o * HL_C * HL_C + (cib * 16 + L) * HL_C + c * 16 + 4 * g) = acc[o][c];
+  HW_MARK(2 + it * 5);
+}
+
+// dw[k][ci][co] = sum of the partials of the workgroups of group k / 14 in a FIXED order: thread (chunk c, element group) adds the
+// workgroups c, c + 8, ... of the group (independent loads, all in flight), the 8 chunk sums are then added in order through LDS
+// (one thread per element group walking 128 partials took 33 us for 59 MB)
+__global__ __launch_bounds__(256) void k_halo_wgrad_reduce(const float* __restrict__ partial, int nwg, float* __restrict__ dw) {
+  __shared__ f32x4 red[8][32];
+  const int el = threadIdx.x & 31, ch = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;                // f32x4 element group; 27 * 1024 of them, a multiple of 32
+  const int k = e / (HL_C * HL_C / 4), rest = e % (HL_C * HL_C / 4);
+  const int grp = k / HW_OPG, o = k % HW_OPG;
+  f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int wg = grp + ch * HW_G; wg < nwg; wg += 8 * HW_G) a += *(const f32x4*)(partial + ((long long)wg * HW_OPG + o) * HL_C * HL_C + rest * 4);
+  red[ch][el] = a;
+  __syncthreads();
+  if (ch == 0) {
+#pragma unroll
+    for (int c = 1; c < 8; ++c) a += red[c][el];
+    *(f32x4*)(dw + (long long)e * 4) = a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // C ABI (include/u3d_hip.h)
 // ---------------------------------------------------------------------------------------------------------------------------
 extern "C" int32_t u3d_subm_halo_sizes(int32_t n_cap, int64_t* tile_rows_elems, int64_t* loc_elems, int32_t* tiles) {
@@ -452,7 +659,8 @@ extern "C" int32_t u3d_subm_halo_wpack_batched(const void* const* srcs_dev, void
 
 extern "C" int32_t u3d_subm_halo_conv64_bf16(const void* in, const void* w_packed, const int32_t* tile_rows, const uint16_t* loc,
                                              const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, int32_t krev,
-                                             const void* addend, void* out, double* stats, const u3d_bn_epi* bn, u3d_stream s) {
+                                             const void* addend, void* out, double* stats, const u3d_bn_epi* bn, int32_t max_slots,
+                                             u3d_stream s) {
   U3D_REQUIRE(in && w_packed && tile_rows && loc && tile_cnt && n_dev && out && n_cap > 0, U3D_ERR_ARG);
   U3D_REQUIRE(!bn || (stats && bn->x && bn->mean && bn->invstd && (!bn->relu || bn->y || (bn->gamma && bn->beta))), U3D_ERR_ARG);
   HlBn e;
@@ -461,7 +669,29 @@ extern "C" int32_t u3d_subm_halo_conv64_bf16(const void* in, const void* w_packe
   static_assert(HL_MAXS * HL_RS * 2 >= 4 * 16 * 64 * 16, "stage buffer holds the first reduce-scatter round");
   U3D_ALLOW_LDS(k_subm_halo64, lds);
   k_subm_halo64<<<u3d_cdiv(n_cap, HL_T), 256, lds, (hipStream_t)s>>>((const u16*)in, (const u16*)w_packed, tile_rows, loc, tile_cnt, n_dev,
-                                                                    n_cap, krev, (const u16*)addend, (u16*)out, stats, e);
+                                                                    n_cap, krev, (const u16*)addend, (u16*)out, stats, e,
+                                                                    (max_slots > 0 && max_slots < HL_MAXS) ? max_slots : HL_MAXS);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+extern "C" int64_t u3d_subm_halo_wgrad64_workspace(void) { return (int64_t)HW_WGS * HW_OPG * HL_C * HL_C * 4; }
+
+extern "C" int32_t u3d_subm_halo_wgrad64_bf16(const void* x, const void* dy, const int32_t* tile_rows, const uint16_t* loc,
+                                              const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, float* dw, void* workspace,
+                                              int64_t workspace_bytes, int32_t max_slots, u3d_stream s) {
+  U3D_REQUIRE(x && dy && tile_rows && loc && tile_cnt && n_dev && dw && workspace && n_cap > 0, U3D_ERR_ARG);
+  U3D_REQUIRE(workspace_bytes >= u3d_subm_halo_wgrad64_workspace(), U3D_ERR_WORKSPACE);
+  if ((long long)n_cap * HL_C * 2 >= 0x7fffffffll) return U3D_ERR_UNSUPPORTED;      // 32-bit buffer offsets of the LDS-DMA
+  constexpr int lds = 2 * HW_BUF * 2;
+  static_assert(HW_MAXS >= 2 * HL_T && HW_MAXS % 8 == 0, "the per-offset fall-back stages 2 x 128 rows; whole 8-row DMA groups");
+  static_assert(lds <= 160 * 1024, "two stage buffers must fit the LDS");
+  U3D_ALLOW_LDS(k_subm_halo_wgrad64, lds);
+  int nwg = HW_G * u3d_cdiv(n_cap, HL_T);
+  if (nwg > HW_WGS) nwg = HW_WGS;
+  k_subm_halo_wgrad64<<<nwg, 512, lds, (hipStream_t)s>>>((const u16*)x, (const u16*)dy, tile_rows, loc, tile_cnt, n_dev, n_cap, (float*)workspace,
+                                                          (max_slots > 0 && max_slots < HW_MAXS) ? max_slots : HW_MAXS);
+  k_halo_wgrad_reduce<<<HL_K * HL_C * HL_C / 4 / 32, 256, 0, (hipStream_t)s>>>((const float*)workspace, nwg, dw);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

@@ -110,9 +110,11 @@ _SIGS = {
     "u3d_bn_bwd_finalize_partials": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P]),
     "u3d_subm_halo_sizes": (_I, [_I, _P, _P, _P]),
     "u3d_subm_halo_build": (_I, [_P, _I, _P, _I, _P, _P, _P, _P]),
+    "u3d_subm_halo_wgrad64_workspace": (_L, []),
+    "u3d_subm_halo_wgrad64_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _P]),
     "u3d_subm_halo_wpack": (_I, [_P, _P, _P]),
     "u3d_subm_halo_wpack_batched": (_I, [_P, _P, _I, _P]),
-    "u3d_subm_halo_conv64_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "u3d_subm_halo_conv64_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P]),
     "u3d_igemm_lattice_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "u3d_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     "u3d_bn_bwd_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P]),
@@ -521,6 +523,29 @@ class SubmHalo:
             _check(rc, "subm_halo_build")
 
 
+def subm_halo_wgrad(x, dy, halo, out=None, max_slots=0):
+    """dW f32 [27, 64, 64] of a 64 -> 64 SubM conv from the level's halo tables (u3d_subm_halo_wgrad64_bf16); out: contiguous f32
+    tensor of 27 * 64 * 64 elements to write into."""
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.shape == dy.shape == (halo.n_cap, 64)
+    dw = out.view(27, 64, 64) if (out is not None and out.is_contiguous() and out.dtype == torch.float32 and out.numel() == 27 * 4096) \
+        else torch.empty((27, 64, 64), dtype=torch.float32, device=x.device)
+    wsb = int(lib().u3d_subm_halo_wgrad64_workspace())
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    t = TIMER
+    e0 = t.begin() if t is not None else None
+    _check(lib().u3d_subm_halo_wgrad64_bf16(_ptr(x), _ptr(dy), _ptr(halo.tile_rows), _ptr(halo.loc), _ptr(halo.tile_cnt), _ptr(halo.n_dev),
+                                            halo.n_cap, _ptr(dw), _ptr(ws), wsb, int(max_slots), _stream()), "subm_halo_wgrad64_bf16")
+    if t is not None:
+        meta = None
+        if t.mode == "census":
+            n = halo.n_cap
+            pairs = int((halo.nbr[:, :n] >= 0).sum().item())
+            meta = dict(kind=CALL_KIND, v2=True, n_in=n, n_out=n, cin=64, cout=64, kvol=27, pairs=pairs,
+                        bytes=n * 64 * 2 * 2 + 8 * pairs + 27 * 64 * 64 * 4, flops=2 * pairs * 64 * 64)
+        t.end("spconv_wgrad", e0, meta)
+    return dw
+
+
 def subm_halo_wpack(w_nmajor, out=None):
     """bf16 [27, 64 (out), 64 (reduction)] -> the MFMA fragment order u3d_subm_halo_conv64_bf16 reads (same shape and size)."""
     assert w_nmajor.dtype == torch.bfloat16 and tuple(w_nmajor.shape) == (27, 64, 64) and w_nmajor.is_contiguous()
@@ -540,7 +565,7 @@ def subm_halo_wpack_batched(plan):
     _check(lib().u3d_subm_halo_wpack_batched(_ptr(plan[0]), _ptr(plan[1]), plan[2], _stream()), "subm_halo_wpack_batched")
 
 
-def subm_halo_conv(inp, w_packed, halo, krev=False, addend=None, want_stats=False, tag="spconv_fwd", bn_epi=None):
+def subm_halo_conv(inp, w_packed, halo, krev=False, addend=None, want_stats=False, tag="spconv_fwd", bn_epi=None, max_slots=0):
     """64 -> 64 channel, 27-offset SubM conv out of the tile's staged distinct rows (u3d_subm_halo_conv64_bf16).
     w_packed: subm_halo_wpack of bf16 [27, 64 (out), 64 (reduction)].  -> out, or (out, stats f64 [tiles, 2, 64], 128) with want_stats."""
     assert inp.dtype == torch.bfloat16 and inp.shape[1] == 64 and tuple(w_packed.shape) == (27, 64, 64) and inp.shape[0] == halo.n_cap
@@ -550,7 +575,7 @@ def subm_halo_conv(inp, w_packed, halo, krev=False, addend=None, want_stats=Fals
     e0 = t.begin() if t is not None else None
     _check(lib().u3d_subm_halo_conv64_bf16(_ptr(inp), _ptr(w_packed), _ptr(halo.tile_rows), _ptr(halo.loc), _ptr(halo.tile_cnt),
                                            _ptr(halo.n_dev), halo.n_cap, int(krev), _ptr(addend), _ptr(out), _ptr(stats),
-                                           None if bn_epi is None else C.byref(bn_epi), _stream()),
+                                           None if bn_epi is None else C.byref(bn_epi), int(max_slots), _stream()),
            "subm_halo_conv64_bf16")
     if t is not None:
         meta = None

@@ -142,6 +142,7 @@ def strided_level(lvl, ksize, stride, pad, capacity=None):
 
 REV_SUBM_TABLE = os.environ.get("U3D_REV_SUBM_TABLE", "1") == "1"
 SUBM_HALO = os.environ.get("U3D_SUBM_HALO", "1") == "1"       # 64 -> 64 SubM convs out of per-tile staged distinct rows (subm_halo.hip)
+HALO_WGRAD = os.environ.get("U3D_HALO_WGRAD", "1") == "1"     # ... and their weight gradients (k_subm_halo_wgrad64)
 LATTICE_KERNEL = os.environ.get("U3D_LATTICE_KERNEL", "0") == "1"      # 27-offset dense convs on u3d_igemm_lattice_bf16 (measured on par: off)
 STRIDED_DGRAD_SPLIT = os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
 NMAJOR_FWD = os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
@@ -268,6 +269,8 @@ class _SparseConv(torch.autograd.Function):
                 # nn.Conv3d's own [Cout,Cin,kD,kH,kW] layout: autograd keeps the tensor as the gradient
                 ks = ctx.kio_shape
                 dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol, out_oik=True, out=gv).view(ks[4], ks[3], ks[0], ks[1], ks[2])
+            elif ctx.layout == "dhwio" and v2 and ctx.halo and HALO_WGRAD:
+                dw = nv.subm_halo_wgrad(feats, dout, g.level.halo(), out=gv).view(ctx.kio_shape)
             elif ctx.layout == "dhwio" and v2:
                 dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol, out=gv).view(ctx.kio_shape)
             else:
