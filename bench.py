@@ -284,6 +284,15 @@ def main():
             assert len(durs) == per_step * ROOF_STEPS, (len(durs), per_step, ROOF_STEPS)
             per_call = np.array([d for _, d in durs]).reshape(ROOF_STEPS, per_step).mean(0)          # ms, averaged over the instrumented steps
             calls = [dict(m, tag=t, ms=float(per_call[i])) for i, (t, m) in enumerate(census)]
+            if os.environ.get("U3D_CONV_TABLE"):        # per-launch table of the conv launches of a step (shape, time): grouped, to stderr
+                grp = {}
+                for x in calls:
+                    k = (x["kind"], x["tag"], x["n_in"], x["n_out"], x["cin"], x["cout"], x["kvol"])
+                    g_ = grp.setdefault(k, [0, 0.0, 0.0])
+                    g_[0] += 1; g_[1] += x["ms"]; g_[2] += x["flops"]
+                for k, (cnt_, ms_, fl_) in sorted(grp.items(), key=lambda kv: -kv[1][1]):
+                    print(f"[conv] {k[0]:6s} {k[1]:13s} n_in {k[2]:7d} n_out {k[3]:7d} {k[4]:4d}->{k[5]:4d} K={k[6]:2d}  x{cnt_:2d}  {ms_ * 1e3:8.1f} us/step  "
+                          f"{ms_ / cnt_ * 1e3:7.1f} us each  {fl_ / ms_ / 1e9 if ms_ else 0:7.1f} TF/s", file=sys.stderr)
 
             def agg(sel):
                 c = [x for x in calls if sel(x)]
