@@ -1026,7 +1026,8 @@ def test_bn_backward_sums_from_the_consumers_dgrad_epilogue(cuda, c, n_pts, dims
     gb = [(torch.rand(c, device="cuda") + 0.5, torch.randn(c, device="cuda") * 0.3) for _ in range(4)]
     dy = torch.randn(lvl0.n, c, device="cuda").bfloat16()
     res, calls = {}, {}
-    real, default = nv.bn_bwd_stats, sp.BN_GRAD_FUSION
+    real, default, halo128 = nv.bn_bwd_stats, sp.BN_GRAD_FUSION, sp.HALO_128
+    sp.HALO_128 = False             # (the 128-channel case is about the LDS-DMA kernels' epilogue: the halo kernel for that width has none)
     for on in (True, False):
         sp.BN_GRAD_FUSION = on
         cnt = [0]
@@ -1054,6 +1055,7 @@ def test_bn_backward_sums_from_the_consumers_dgrad_epilogue(cuda, c, n_pts, dims
             calls[on] = cnt[0]
         finally:
             sp.BN_GRAD_FUSION = default
+            sp.HALO_128 = halo128 if not on else False
             nv.bn_bwd_stats = real
     assert calls[False] == 4 and calls[True] == 1, calls
     for i, (p, q) in enumerate(zip(res[True], res[False])):
@@ -1097,3 +1099,44 @@ def test_subm_halo_weight_gradient(cuda, seed, n_pts, dims, cut):
     assert nv.subm_halo_wgrad(x, dy, halo, out=out, max_slots=slots).data_ptr() == out.data_ptr() and torch.equal(out.view(27, 64, 64), got)
     zero = nv.SubmHalo(nb, nv.count_tensor(0, "cuda"), n_cap)
     assert (nv.subm_halo_wgrad(x, dy, zero) == 0).all()
+
+
+@pytest.mark.parametrize("seed,n_pts,dims,cut", [(5, 9000, (16, 40, 36), 0), (11, 60000, (12, 64, 64), 777)])
+def test_subm_halo_128_channel_kernel(cuda, seed, n_pts, dims, cut):
+    """k_subm_halo128 (128 -> 128 SubM convs: waves split the output columns, the 256-byte rows staged one 64-channel half at a time):
+    forward + per-tile statistics, input gradient (offsets reversed) with addend, the global-memory fall-back for rows past the staged
+    slots (max_slots hook), a device-side row count below the capacity with NaN in the dead rows; against the f32 gather-matmul and the
+    LDS-DMA tiled kernel."""
+    import torch
+    from uni3detr_amd import native as nv
+    lvl, nbr = _level(seed=seed, n_pts=n_pts, dims=dims)
+    n_cap = lvl.n
+    n = n_cap - cut
+    cnt = nv.count_tensor(n, "cuda") if cut else lvl.n_dev
+    nb = nbr.clone()
+    if cut:
+        nb[:, :n][nb[:, :n] >= n] = -1
+    halo = nv.SubmHalo(nb, cnt, n_cap)
+    torch.manual_seed(seed)
+    x = torch.randn(n_cap, 128, device="cuda").bfloat16()
+    add = torch.randn(n_cap, 128, device="cuda").bfloat16()
+    if cut:
+        x[n:] = float("nan"); add[n:] = float("nan")
+    w = (torch.randn(27, 128, 128, device="cuda") * 0.07).bfloat16()             # n-major [K][out][reduction]
+    wp = nv.subm_halo_wpack(w)
+    y, stats, tr = nv.subm_halo_conv(x, wp, halo, want_stats=True)
+    exp = _ref_conv(x[:n], w.transpose(1, 2), nb, n)
+    sc = exp.abs().max()
+    assert torch.isfinite(y[:n]).all() and (y[:n].float() - exp).abs().max() / sc < 6e-3
+    assert tr == 128 and stats.shape == (halo.tiles, 2, 128)
+    yf = y[:n].double()
+    assert (stats[:, 0].sum(0) - yf.sum(0)).abs().max() < 1e-3 * yf.abs().sum(0).max()
+    assert (stats[:, 1].sum(0) - (yf * yf).sum(0)).abs().max() < 1e-4 * (yf * yf).sum(0).max()
+    assert torch.equal(nv.subm_halo_conv(x, wp, halo)[:n], y[:n])
+    for ms in (150, 40):
+        assert torch.equal(nv.subm_halo_conv(x, wp, halo, max_slots=ms)[:n], y[:n]), ms
+    g = nv.subm_halo_conv(x, wp, halo, krev=True, addend=add)
+    expg = _ref_conv(x[:n], w.transpose(1, 2), nb.flip(0), n) + add[:n].float()
+    assert (g[:n].float() - expg).abs().max() / expg.abs().max() < 6e-3
+    ref = nv.spconv_fwd(x, w, nb, cnt, n_cap, 128, transpose_w=True)[:n].float()
+    assert (y[:n].float() - ref).abs().max() / sc < 8e-3

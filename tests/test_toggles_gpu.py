@@ -20,6 +20,8 @@ pytestmark = pytest.mark.gpu
 # (module, attribute, flipped value)
 TOGGLES = [
     ("uni3detr_amd.sparse", "SUBM_HALO", False),
+    ("uni3detr_amd.sparse", "HALO_WGRAD", False),
+    ("uni3detr_amd.sparse", "HALO_128", False),
     ("uni3detr_amd.sparse", "REV_SUBM_TABLE", False),
     ("uni3detr_amd.sparse", "STRIDED_DGRAD_SPLIT", False),
     ("uni3detr_amd.sparse", "NMAJOR_FWD", False),

@@ -92,6 +92,14 @@ def main():
             passes["halo_fwd_stats"] = lambda: nv.subm_halo_conv(x, wpf, halo, want_stats=True)
             passes["halo_dgrad"] = lambda: nv.subm_halo_conv(dy, wpb, halo, krev=True)
             passes["halo_wgrad"] = lambda: nv.subm_halo_wgrad(x, dy, halo)
+        if ci == 128 and co == 128 and g.level is not None and g.level.halo() is not None:
+            halo = g.level.halo()
+            wn = w.transpose(1, 2).contiguous()
+            wpf, wpb = nv.subm_halo_wpack(wn), nv.subm_halo_wpack(w)
+            passes["fwd_nmajor_stats"] = lambda: nv.spconv_fwd_stats(x, wn, g.nbr_fwd, g.n_out_dev, g.n_out, co)
+            passes["halo_fwd"] = lambda: nv.subm_halo_conv(x, wpf, halo)
+            passes["halo_fwd_stats"] = lambda: nv.subm_halo_conv(x, wpf, halo, want_stats=True)
+            passes["halo_dgrad"] = lambda: nv.subm_halo_conv(dy, wpb, halo, krev=True)
         for pname, fn in passes.items():
             for _ in range(3):
                 fn()

@@ -416,6 +416,166 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo64(const u16* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// 128 -> 128 channels (the stride-8 stage's SparseBasicBlocks, ~54 k rows): same tables, same staging, different split
+// ---------------------------------------------------------------------------------------------------------------------------
+// 128 x 128 accumulators do not fit a wave, so the four waves split the output COLUMNS (32 each: 64 accumulator registers) and every
+// wave walks all 27 offsets - no reduce-scatter; the price is that all four read the same operand rows from LDS (16 ds_read_b128
+// per 32 MFMAs).  The 256-byte rows are staged one 64-channel HALF at a time (the stage buffer and the 144 B row stride of the
+// 64-channel kernel: two workgroups per CU), and the accumulators run through both halves.  What this saves over the LDS-DMA tiled
+// kernel is the operand stream: per 128-row tile that kernel fills 27 x 128 rows x 256 B = 884 KB of rows next to the 884 KB of
+// weights, at the ~17 B/clk/CU fill rate that bounds it; here the rows are ~270 x 256 B = 69 KB.
+// weights: k_halo_wpack128 = [27][half][nt 8][ks 2][lane 64][8]
+__global__ __launch_bounds__(256) void k_halo_wpack128(const u16* __restrict__ src, u16* __restrict__ dst, const u16* const* __restrict__ srcs,
+                                                       u16* const* __restrict__ dsts) {
+  if (srcs) { src = srcs[blockIdx.y]; dst = dsts[blockIdx.y]; }
+  const int c = blockIdx.x * 256 + threadIdx.x;   // 16 B chunk of dst
+  if (c >= HL_K * 2048) return;
+  const int lane = c & 63, ks = (c >> 6) & 1, nt = (c >> 7) & 7, half = (c >> 10) & 1, k = c >> 11;
+  *(u32x4*)(dst + (long long)c * 8) = *(const u32x4*)(src + k * 16384 + (nt * 16 + (lane & 15)) * 128 + half * 64 + ks * 32 + (lane >> 4) * 8);
+}
+
+#define HL_C2 128
+__global__ __launch_bounds__(256, 2) void k_subm_halo128(const u16* __restrict__ in, const u16* __restrict__ wgt,
+                                                         const int32_t* __restrict__ tile_rows, const u16* __restrict__ loc,
+                                                         const int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ n_dev, int n_cap,
+                                                         int krev, const u16* __restrict__ addend, u16* __restrict__ out,
+                                                         double* __restrict__ stats, int maxs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u16* xs = (u16*)smem;                           // [HL_MAXS][HL_RS]: one 64-channel half of the distinct rows
+  const int tid = threadIdx.x;
+  const int tq = gridDim.x >> 3, trem = gridDim.x & 7, xcd = blockIdx.x & 7;      // XCD-contiguous tile ranges (k_subm_halo64)
+  const int tile = (xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq) + (blockIdx.x >> 3);
+  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int m0 = tile * HL_T;
+  const int n = min(*n_dev, n_cap);
+  if (m0 >= n) {
+    if (stats && tid < 2 * HL_C2) stats[(long long)tile * 2 * HL_C2 + tid] = 0.0;
+    return;
+  }
+  const int32_t* rows_p = tile_rows + (long long)tile * HL_TRC;
+  const int cnt = tile_cnt[tile];
+  const int nl = min(cnt, maxs);
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const u16* locp = loc + (long long)tile * HL_K * HL_T + r16 * 8;
+  const u16* xl = xs + kq * 8;
+
+#define H2_LOADX(FAST, s, x0, x1)                                                                       \
+  if (FAST || (s) < nl) {                                                                               \
+    x0 = *(const bf16x8*)(xl + (s) * HL_RS);                                                            \
+    x1 = *(const bf16x8*)(xl + (s) * HL_RS + 32);                                                       \
+  } else {                                                                                              \
+    const u16* g_ = in + (long long)rows_p[s] * HL_C2 + half * 64 + kq * 8;                             \
+    x0 = *(const bf16x8*)g_;                                                                            \
+    x1 = *(const bf16x8*)(g_ + 32);                                                                     \
+  }
+#define H2_MFMA(a, x0, x1)                                                                              \
+  _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                        \
+    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][0], x0, acc[a][b], 0, 0, 0);              \
+    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][1], x1, acc[a][b], 0, 0, 0);              \
+  }
+#define H2_WLOAD(dst, k)                                                                                \
+  _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                        \
+    dst[b][0] = *(const bf16x8*)(wl + ((long long)(k) * 32 + b * 2 + 0) * 512);                          \
+    dst[b][1] = *(const bf16x8*)(wl + ((long long)(k) * 32 + b * 2 + 1) * 512);                          \
+  }
+#define H2_OFFSET_LOOP(FAST)                                                                            \
+  for (int k = 0; k < HL_K; ++k) {                                                                      \
+    const int kn = k + 1 < HL_K ? k + 1 : k;                                                            \
+    const u16x8 sln = *(const u16x8*)(locp + (krev ? 26 - kn : kn) * HL_T);                             \
+    bf16x8 wn[2][2];                                                                                    \
+    H2_WLOAD(wn, kn)                                                                                    \
+    bf16x8 x0, x1, y0, y1;                                                                              \
+    H2_LOADX(FAST, (int)sl[0], x0, x1)                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    _Pragma("unroll") for (int a = 0; a < 8; a += 2) {                                                   \
+      H2_LOADX(FAST, (int)sl[a + 1], y0, y1)                                                            \
+      H2_MFMA(a, x0, x1)                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                \
+      if (a + 2 < 8) { H2_LOADX(FAST, (int)sl[a + 2 < 8 ? a + 2 : 0], x0, x1) }                         \
+      H2_MFMA(a + 1, y0, y1)                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                \
+    }                                                                                                   \
+    sl = sln;                                                                                           \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b) { wf[b][0] = wn[b][0]; wf[b][1] = wn[b][1]; }          \
+  }
+
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();                    // the first half's reads are done
+    {                                             // stage this 64-channel half of the distinct rows (k_subm_halo64's scheme)
+      const int part = tid & 7, sb = tid >> 3;
+      for (int base = 0; base < nl; base += 288) {
+        int idx[9];
+        u32x4 v[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const int slot = base + sb + 32 * i;
+          idx[i] = (slot > 0 && slot < nl) ? rows_p[slot] : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          v[i] = (u32x4){0u, 0u, 0u, 0u};
+          if (idx[i] >= 0) v[i] = *(const u32x4*)(in + (long long)idx[i] * HL_C2 + half * 64 + part * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const int slot = base + sb + 32 * i;
+          if (slot < nl) *(u32x4*)(xs + slot * HL_RS + part * 8) = v[i];
+        }
+      }
+    }
+    __syncthreads();
+    // weights of (offset k, this half, n-tiles 2w and 2w + 1): chunk ((k * 2 + half) * 8 + nt) * 2 + ks
+    const u16* wl = wgt + ((long long)(half * 8 + 2 * w) * 2) * 512 + lane * 8;
+    u16x8 sl = *(const u16x8*)(locp + (krev ? 26 : 0) * HL_T);
+    bf16x8 wf[2][2];
+    H2_WLOAD(wf, 0)
+    if (cnt <= maxs) { H2_OFFSET_LOOP(1) } else { H2_OFFSET_LOOP(0) }
+  }
+#undef H2_LOADX
+#undef H2_MFMA
+#undef H2_WLOAD
+#undef H2_OFFSET_LOOP
+
+  // epilogue: acc[a][b][r] = C[row a * 16 + r16][col (2w + b) * 16 + 4 kq + r]; this wave owns its 32 columns of all 128 rows
+  f32x4 cs[2], cq[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) { cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int m = m0 + a * 16 + r16;
+    if (m >= n) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = (2 * w + b) * 16 + 4 * kq;
+      f32x4 v = acc[a][b];
+      if (addend) v += __builtin_convertvector(*(const bf16x4*)(addend + (long long)m * HL_C2 + col), f32x4);
+      const bf16x4 o = __builtin_convertvector(v, bf16x4);
+      *(bf16x4*)(out + (long long)m * HL_C2 + col) = o;
+      const f32x4 vr = __builtin_convertvector(o, f32x4);      // statistics of the ROUNDED values
+      cs[b] += vr;
+      cq[b] += vr * vr;
+    }
+  }
+  if (stats) {                                    // a wave owns its columns: row sums by DPP, one f64 per (tile, column) straight out
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = hl_row_sum(cs[b][r]), s2 = hl_row_sum(cq[b][r]);
+        if (r16 == 0) {
+          const int col = (2 * w + b) * 16 + 4 * kq + r;
+          stats[((long long)tile * 2 + 0) * HL_C2 + col] = (double)s1;
+          stats[((long long)tile * 2 + 1) * HL_C2 + col] = (double)s2;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // weight gradient:  dW[k][ci][co] = sum over rows m of  x[nbr_k(m)][ci] * dy[m][co]
 // ---------------------------------------------------------------------------------------------------------------------------
 // The tiled kernel (k_igemm_wgrad_glds_64, 118 us) gathers 27 x 128 row pieces per tile through LDS-DMA like the forward did.  Here
@@ -692,6 +852,32 @@ extern "C" int32_t u3d_subm_halo_wgrad64_bf16(const void* x, const void* dy, con
   k_subm_halo_wgrad64<<<nwg, 512, lds, (hipStream_t)s>>>((const u16*)x, (const u16*)dy, tile_rows, loc, tile_cnt, n_dev, n_cap, (float*)workspace,
                                                           (max_slots > 0 && max_slots < HW_MAXS) ? max_slots : HW_MAXS);
   k_halo_wgrad_reduce<<<HL_K * HL_C * HL_C / 4 / 32, 256, 0, (hipStream_t)s>>>((const float*)workspace, nwg, dw);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+extern "C" int32_t u3d_subm_halo_wpack128(const void* w_nmajor, void* w_packed, u3d_stream s) {
+  U3D_REQUIRE(w_nmajor && w_packed, U3D_ERR_ARG);
+  k_halo_wpack128<<<u3d_cdiv(HL_K * 2048, 256), 256, 0, (hipStream_t)s>>>((const u16*)w_nmajor, (u16*)w_packed, nullptr, nullptr);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+extern "C" int32_t u3d_subm_halo_wpack128_batched(const void* const* srcs_dev, void* const* dsts_dev, int32_t n, u3d_stream s) {
+  U3D_REQUIRE(srcs_dev && dsts_dev && n >= 0, U3D_ERR_ARG);
+  if (n == 0) return U3D_OK;
+  k_halo_wpack128<<<dim3(u3d_cdiv(HL_K * 2048, 256), n), 256, 0, (hipStream_t)s>>>(nullptr, nullptr, (const u16* const*)srcs_dev, (u16* const*)dsts_dev);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+extern "C" int32_t u3d_subm_halo_conv128_bf16(const void* in, const void* w_packed, const int32_t* tile_rows, const uint16_t* loc,
+                                              const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, int32_t krev,
+                                              const void* addend, void* out, double* stats, int32_t max_slots, u3d_stream s) {
+  U3D_REQUIRE(in && w_packed && tile_rows && loc && tile_cnt && n_dev && out && n_cap > 0, U3D_ERR_ARG);
+  const int lds = HL_MAXS * HL_RS * 2;
+  U3D_ALLOW_LDS(k_subm_halo128, lds);
+  k_subm_halo128<<<u3d_cdiv(n_cap, HL_T), 256, lds, (hipStream_t)s>>>((const u16*)in, (const u16*)w_packed, tile_rows, loc, tile_cnt, n_dev, n_cap,
+                                                                     krev, (const u16*)addend, (u16*)out, stats,
+                                                                     (max_slots > 0 && max_slots < HL_MAXS) ? max_slots : HL_MAXS);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

@@ -101,14 +101,17 @@ class ShadowSet:
             p._u3d_conv_shadow = [kio, koi, -1, layout]
         # 64 -> 64 channel, 27-offset weights (the SubM blocks of the stride-4 stage): MFMA-fragment-packed copies of both layouts
         # for the halo kernel (csrc/subm_halo.hip), all of them in ONE launch per refresh
-        pairs = []
-        for p in self.conv_params:
-            kio, koi = p._u3d_conv_shadow[0], p._u3d_conv_shadow[1]
-            if tuple(kio.shape) == (27, 64, 64):
-                pk = torch.empty((2, 27, 64, 64), dtype=torch.bfloat16, device=src.device)
-                pairs += [(koi, pk[0]), (kio, pk[1])]
-                p._u3d_halo_pack = [pk[0], pk[1], -1]
-        self._halo_plan = nv.subm_halo_wpack_plan(pairs, src.device) if pairs else None
+        self._halo_plans = []
+        for c in (64, 128):
+            pairs = []
+            for p in self.conv_params:
+                kio, koi = p._u3d_conv_shadow[0], p._u3d_conv_shadow[1]
+                if tuple(kio.shape) == (27, c, c) and conv_layouts[p] == "dhwio":      # (the sparse encoder's weights: the dense stack never takes the halo path)
+                    pk = torch.empty((2, 27, c, c), dtype=torch.bfloat16, device=src.device)
+                    pairs += [(koi, pk[0]), (kio, pk[1])]
+                    p._u3d_halo_pack = [pk[0], pk[1], -1]
+            if pairs:
+                self._halo_plans.append(nv.subm_halo_wpack_plan(pairs, src.device))
         self._plan = nv.permute_plan(descs, src.device)
 
     def refresh(self):
@@ -116,8 +119,8 @@ class ShadowSet:
             from . import native as nv
             nv.cast_bf16(self.flat, self.flat_shadow)
             nv.permute_bf16_batched(self.flat_shadow, self.perm, self._plan)
-            if self._halo_plan is not None:
-                nv.subm_halo_wpack_batched(self._halo_plan)
+            for plan in self._halo_plans:
+                nv.subm_halo_wpack_batched(plan)
             for p in self.params:
                 p._u3d_shadow[1] = p._version
             for p in self.conv_params:
@@ -149,7 +152,7 @@ class ShadowSet:
 
 
 def halo_packs(p, kio, koi):
-    """(packed koi, packed kio or None) of a [27, 64, 64] conv weight for the halo kernel: the refresh's copies while the shadow set is
+    """(packed koi, packed kio or None) of a [27, 64, 64] / [27, 128, 128] conv weight for the halo kernels: the refresh's copies while the shadow set is
     active and fresh, else packed on the spot (the transposed one only on demand: halo_pack_one)."""
     if _ACTIVE[0]:
         hp = getattr(p, "_u3d_halo_pack", None)

@@ -143,6 +143,7 @@ def strided_level(lvl, ksize, stride, pad, capacity=None):
 REV_SUBM_TABLE = os.environ.get("U3D_REV_SUBM_TABLE", "1") == "1"
 SUBM_HALO = os.environ.get("U3D_SUBM_HALO", "1") == "1"       # 64 -> 64 SubM convs out of per-tile staged distinct rows (subm_halo.hip)
 HALO_WGRAD = os.environ.get("U3D_HALO_WGRAD", "1") == "1"     # ... and their weight gradients (k_subm_halo_wgrad64)
+HALO_128 = os.environ.get("U3D_HALO_128", "1") == "1"         # ... and the 128 -> 128 SubM convs (k_subm_halo128: forward / input gradient)
 LATTICE_KERNEL = os.environ.get("U3D_LATTICE_KERNEL", "0") == "1"      # 27-offset dense convs on u3d_igemm_lattice_bf16 (measured on par: off)
 STRIDED_DGRAD_SPLIT = os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
 NMAJOR_FWD = os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
@@ -216,8 +217,8 @@ class _SparseConv(torch.autograd.Function):
         nbr = geom.nbr_fwd if kio.shape[0] > 1 else None
         nv.CALL_KIND = geom.kind
         lat = geom.lattice if (LATTICE_KERNEL and nmajor and geom.lattice is not None and geom.lattice[2] == 3) else None
-        ctx.halo = (SUBM_HALO and REV_SUBM_TABLE and nmajor and geom.level is not None and kv == 27 and cin == 64 and cout == 64
-                    and geom.n_out >= 4096 and geom.level.halo() is not None)
+        ctx.halo = (SUBM_HALO and REV_SUBM_TABLE and nmajor and geom.level is not None and kv == 27 and cin == cout
+                    and (cin == 64 or (cin == 128 and HALO_128)) and geom.n_out >= 4096 and geom.level.halo() is not None)
         if ctx.halo:
             pk_fwd, ctx.pk_bwd = halo_packs(weight, kio, koi)
             if want_stats:
@@ -269,7 +270,7 @@ class _SparseConv(torch.autograd.Function):
                 # nn.Conv3d's own [Cout,Cin,kD,kH,kW] layout: autograd keeps the tensor as the gradient
                 ks = ctx.kio_shape
                 dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol, out_oik=True, out=gv).view(ks[4], ks[3], ks[0], ks[1], ks[2])
-            elif ctx.layout == "dhwio" and v2 and ctx.halo and HALO_WGRAD:
+            elif ctx.layout == "dhwio" and v2 and ctx.halo and HALO_WGRAD and cin_w == 64:
                 dw = nv.subm_halo_wgrad(feats, dout, g.level.halo(), out=gv).view(ctx.kio_shape)
             elif ctx.layout == "dhwio" and v2:
                 dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol, out=gv).view(ctx.kio_shape)
@@ -319,6 +320,8 @@ class _SparseConv(torch.autograd.Function):
                     bt = ctx.bn_in
                     if bt is not None and (bt.c != cin or (add is not None and not (add.dtype == torch.bfloat16 and add.is_contiguous()))):
                         bt = None
+                    if ctx.halo and cin != 64:
+                        bt = None                    # (the 128-channel halo kernel has no BatchNorm-backward epilogue)
                     if ctx.halo:
                         pk = ctx.pk_bwd if ctx.pk_bwd is not None else nv.subm_halo_wpack(wc)
                         if bt is not None:
