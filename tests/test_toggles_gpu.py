@@ -24,6 +24,7 @@ TOGGLES = [
     ("uni3detr_amd.sparse", "HALO_128", False),
     ("uni3detr_amd.sparse", "REV_SUBM_TABLE", False),
     ("uni3detr_amd.sparse", "STRIDED_DGRAD_SPLIT", False),
+    ("uni3detr_amd.sparse", "IM2COL_STRIDED", True),
     ("uni3detr_amd.sparse", "NMAJOR_FWD", False),
     ("uni3detr_amd.sparse", "FUSED_CONV_STATS", False),
     ("uni3detr_amd.sparse", "BN_GRAD_FUSION", True),

@@ -100,6 +100,14 @@ class ConvGeom:
         self.kind = kind            # "sparse" (encoder levels) or "dense" (SECOND3D/FPN lattice): bench.py tags timings with it
         self.lattice = None         # (batch, (D,H,W), kd) for a stride-1 "same" (kd,3,3) conv on a dense lattice (u3d_igemm_lattice_bf16)
         self.level = None           # SubM convs: the Level (its halo() serves the 64 -> 64 convs, u3d_subm_halo_conv64_bf16)
+        self._im2col = None
+
+    def im2col_index(self):
+        """int32 [n_out * K]: entry m * K + k = the input row of output row m at offset k (-1: none) - the forward table transposed,
+        what u3d_gather_rows takes to lay the operand rows of a strided conv out as contiguous rows of K * Cin elements."""
+        if self._im2col is None:
+            self._im2col = self.nbr_fwd[:, :self.n_out].t().contiguous().view(-1)
+        return self._im2col
 
 
 def level_from_coors(coors, batch, dims):
@@ -148,6 +156,12 @@ LATTICE_KERNEL = os.environ.get("U3D_LATTICE_KERNEL", "0") == "1"      # 27-offs
 STRIDED_DGRAD_SPLIT = os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
 NMAJOR_FWD = os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
 STRIDED_SPLIT_MIN_RATIO = int(os.environ.get("U3D_STRIDED_SPLIT_MIN_RATIO", "16"))
+# Stride-4 dense convs (SECOND3D's third branch: 192 000 -> 12 000 rows, 9 offsets): forward and weight gradient as im2col (one row
+# gather into contiguous rows of K * Cin) + plain GEMMs.  The table kernels gather cold 512-byte rows one 64-channel slice at a
+# time through LDS-DMA (forward 151 us, weight gradient 142 us in the eager per-launch table); the gathered matrix is 55 MB, and the
+# GEMMs over it take 50 + 52 us in isolation (tools/im2col_probe.py).  At stride 2 the matrix is 221 MB and its gather (110 us) eats
+# the gain.  In the captured step the swap LOSES 0.08 ms (same-box A/B, 3 x 100 steps: 19.32 -> 19.40 ms): off.
+IM2COL_STRIDED = os.environ.get("U3D_IM2COL_STRIDED", "0") == "1"
 STRIDED_SPLIT_SPARSE_RATIO = int(os.environ.get("U3D_STRIDED_SPLIT_SPARSE_RATIO", "16"))      # same threshold for the sparse levels' strided convs
 
 
@@ -212,10 +226,28 @@ class _SparseConv(torch.autograd.Function):
         _CONV_USES[id(weight)] = _CONV_USES.get(id(weight), 0) + 1
         ctx.weight_id = id(weight)
         ctx.grad_view = getattr(weight, "_u3d_grad_view", None)
-        ctx.save_for_backward(feats, kio)
         ctx.kio_shape, ctx.wdtype = kio_shape, weight.dtype
-        nbr = geom.nbr_fwd if kio.shape[0] > 1 else None
         nv.CALL_KIND = geom.kind
+        ctx.im2col = (IM2COL_STRIDED and nmajor and geom.strided and geom.kind == "dense" and kv > 1 and (kv * cin) % 64 == 0
+                      and geom.n_out * STRIDED_SPLIT_MIN_RATIO <= geom.n_in)
+        ctx.halo = False
+        if ctx.im2col:
+            cols = nv.gather_rows(feats, geom.im2col_index()).view(geom.n_out, kv * cin)
+            w2 = koi.permute(1, 0, 2).reshape(1, cout, kv * cin)                  # [Cout][K][Cin]: n-major for the K * Cin reduction
+            ctx.save_for_backward(cols, kio)          # the weight gradient reads the gathered matrix; the input gradient (split path) needs neither
+            res = nv.spconv_fwd_stats(cols, w2, None, geom.n_out_dev, geom.n_out, cout) if want_stats else None
+            if res is not None:
+                y, stats, tr = res
+                stats._u3d_tile_rows = tr
+            else:
+                y = nv.spconv_fwd(cols, w2, None, geom.n_out_dev, geom.n_out, cout, transpose_w=True, tag="spconv_fwd")
+                stats = torch.empty(0, dtype=torch.float64, device=feats.device)
+            if want_stats:
+                ctx.mark_non_differentiable(stats)
+                return y, stats
+            return y
+        ctx.save_for_backward(feats, kio)
+        nbr = geom.nbr_fwd if kio.shape[0] > 1 else None
         lat = geom.lattice if (LATTICE_KERNEL and nmajor and geom.lattice is not None and geom.lattice[2] == 3) else None
         ctx.halo = (SUBM_HALO and REV_SUBM_TABLE and nmajor and geom.level is not None and kv == 27 and cin == cout
                     and (cin == 64 or (cin == 128 and HALO_128)) and geom.n_out >= 4096 and geom.level.halo() is not None)
@@ -259,6 +291,9 @@ class _SparseConv(torch.autograd.Function):
         nv.CALL_KIND = g.kind
 
         def weight_grad():
+            if ctx.im2col:      # feats = the gathered matrix [n_out, K * Cin]: dW = cols^T dout, one offset
+                dwp = nv.spconv_wgrad(feats, dout, None, g.n_out_dev, 1).view(ctx.kio_shape).to(ctx.wdtype)
+                return dwp.permute(4, 3, 0, 1, 2) if ctx.layout == "oidhw" else dwp
             nbr = g.nbr_fwd if kvol > 1 else None
             cin_w, cout_w = wc.shape[1], wc.shape[2]
             v2 = feats.dtype == torch.bfloat16 and nv.USE_IGEMM_V2 and cin_w % 16 == 0 and cout_w % 16 == 0 and ctx.wdtype == torch.float32
