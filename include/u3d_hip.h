@@ -580,6 +580,8 @@ typedef struct u3d_declayer_dims {
   int32_t dtype;        /* U3D_BF16: bf16 activations / weights / slots, v_mfma_f32_16x16x32_bf16 (throughput mode);
                            U3D_F32: f32 everywhere, exact v_mfma_f32_16x16x4_f32 (parity mode) - the SAME kernels, instantiated on the
                            element type; every `void*` operand / slot below then holds f32 and xc may alias x */
+  int32_t dvalue_bf16;  /* backward, U3D_BF16 only: 1 = dvalue is a bf16 [rows][256] accumulator (packed bf16 atomics: two channels per
+                           atomic, no f32 volume to zero and to cast afterwards); 0 = f32 [rows][256] */
 } u3d_declayer_dims;
 /* forward-save slots (row matrices [m, cols]); u3d_decoder_layer_slots fills byte offsets (U3D_DS_COUNT + 1 entries, last = total) */
 enum {
@@ -613,7 +615,7 @@ int32_t u3d_decoder_layer_fwd(const u3d_declayer_params* p, const u3d_declayer_d
 int32_t u3d_decoder_layer_bwd(const u3d_declayer_params* p, const u3d_declayer_dims* d, const float* x, const void* xc,
                               const float* ref, const void* value, const uint64_t* rng, const void* xc_out, const void* save,
                               const float* dx_out, const float* dreg, const float* dcls, const float* diou, float* dx,
-                              float* dvalue, float* dref, void* grad, int64_t grad_bytes, u3d_stream s);
+                              void* dvalue, float* dref, void* grad, int64_t grad_bytes, u3d_stream s);
 /* Self-attention over groups on its own (the middle launch of the layer): q,k rows of qk [m,512] (q | k), v [m,256], 8 heads x 32;
  * o bf16 [m,256], lse f32 [m,8].  Backward: dqk [m,512], dv [m,256] bf16. */
 int32_t u3d_mha_fwd(const void* qk, const void* v, int32_t m, int32_t nq, float p_attn, int32_t layer, const uint64_t* rng, void* o,

@@ -35,6 +35,7 @@ TOGGLES = [
     ("uni3detr_amd.plugin.dense", "FUSED_UPSAMPLE_ORDER", False),
     ("uni3detr_amd.plugin.dense", "FUSED_LEVEL_SUM", False),
     ("uni3detr_amd.plugin.fused_decoder", "ENABLED", False),
+    ("uni3detr_amd.plugin.fused_decoder", "PK_SCATTER", False),
     ("uni3detr_amd.plugin.head", "FUSED_BOX_DECODE", False),
     ("uni3detr_amd.plugin.head", "FUSED_DET_LOSS", False),
     ("uni3detr_amd.plugin.transformer", "FUSED_LN", False),

@@ -149,7 +149,8 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
                                                              const unsigned long long* __restrict__ rng, DcSave<E> S, DcGrad<E> Gd,
                                                              const float* __restrict__ dx_out, const float* __restrict__ dreg,
                                                              const float* __restrict__ dcls, const float* __restrict__ diou,
-                                                             float* __restrict__ dvalue, float* __restrict__ dref) {
+                                                             void* __restrict__ dvalue_v, float* __restrict__ dref) {
+  float* const dvalue = (float*)dvalue_v;
   typedef typename E::T T;
   typedef typename E::V4 V4;
   typedef DcLds<E> L;
@@ -426,6 +427,9 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
       float dsc[4];                                                  // the same d(sample) values, channel j*64 + lane
 #pragma unroll
       for (int j = 0; j < 4; ++j) dsc[j] = E::round(G[row * DC_TS + j * 64 + lane] * gate);
+      float dsp[2][2];                                               // ... and as channel pairs (j*128 + 2*lane, + 1) for the packed bf16 atomics
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { dsp[j][0] = E::round(G[row * DC_TS + j * 128 + 2 * lane] * gate); dsp[j][1] = E::round(G[row * DC_TS + j * 128 + 2 * lane + 1] * gate); }
       DcCorners tc;
       dc_corners<E>(misc + row * DC_MISC_LD, min(gr, M - 1) / dm.qps, dm.dz, dm.dy, dm.dx, tc);
       float gx = 0.f, gy = 0.f, gz = 0.f;
@@ -437,9 +441,23 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_post_bwd(u3d_declayer_params
             // lane l adds channels l, l + 64, l + 128, l + 192: one atomic instruction then covers 64 CONSECUTIVE floats (two cache
             // lines) - with the MFMA-side mapping (channels 4l .. 4l+3) each of the four instructions touched all eight lines of
             // the row, and the L2 atomic unit works a line at a time (125 of this kernel's 316 us were these atomics)
-            float* dvr = dvalue + (size_t)tc.row[c] * DC_C + lane;
+            if (E::DT == U3D_BF16 && dm.dvalue_bf16) {
+              // bf16 accumulator: lane l adds the channel PAIRS (2l, 2l+1) and (128 + 2l, 128 + 2l + 1) - global_atomic_pk_add_bf16,
+              // 64 lanes x 4 B = 256 consecutive bytes per instruction, two instructions per corner instead of four, and the volume
+              // gradient needs neither a 196 MB f32 zero-fill nor a cast pass (a cell collects a handful of contributions at most)
+              typedef short s16x2 __attribute__((ext_vector_type(2)));
+              typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+              u16* dvp = (u16*)dvalue_v + (size_t)tc.row[c] * DC_C + 2 * lane;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(dvr + j * 64, tc.w[c] * dsc[j]);
+              for (int j = 0; j < 2; ++j) {
+                const bf16x2_t pv = {(__bf16)(tc.w[c] * dsp[j][0]), (__bf16)(tc.w[c] * dsp[j][1])};
+                __builtin_amdgcn_global_atomic_fadd_v2bf16((s16x2 __attribute__((address_space(1)))*)(dvp + j * 128), __builtin_bit_cast(s16x2, pv));
+              }
+            } else {
+              float* dvr = dvalue + (size_t)tc.row[c] * DC_C + lane;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) atomicAdd(dvr + j * 64, tc.w[c] * dsc[j]);
+            }
             if (dm.need_dref) {
               const f32x4 val = E::unpack4(*(const V4*)(value + (size_t)tc.row[c] * DC_C + lane * 4));
               const float dot = val[0] * ds[0] + val[1] * ds[1] + val[2] * ds[2] + val[3] * ds[3];
@@ -800,7 +818,7 @@ static int32_t dcb_check(const u3d_declayer_params* p, const u3d_declayer_dims* 
 template <typename E>
 static int32_t dcb_layer_bwd(const u3d_declayer_params* p, const u3d_declayer_dims* d, const float* ref, const void* value,
                              const uint64_t* rng, const void* save, const float* dx_out, const float* dreg, const float* dcls,
-                             const float* diou, float* dx, float* dvalue, float* dref, void* grad, int64_t grad_bytes, u3d_stream s) {
+                             const float* diou, float* dx, void* dvalue, float* dref, void* grad, int64_t grad_bytes, u3d_stream s) {
   typedef typename E::T T;
   int64_t total = 0;
   const DcGrad<E> G = dcb_resolve_grad<E>(grad, d->m, d->ncls, d->code, &total);
@@ -820,11 +838,12 @@ static int32_t dcb_layer_bwd(const u3d_declayer_params* p, const u3d_declayer_di
 extern "C" int32_t u3d_decoder_layer_bwd(const u3d_declayer_params* p, const u3d_declayer_dims* d, const float* x, const void* xc,
                                          const float* ref, const void* value, const uint64_t* rng, const void* xc_out, const void* save,
                                          const float* dx_out, const float* dreg, const float* dcls, const float* diou, float* dx,
-                                         float* dvalue, float* dref, void* grad, int64_t grad_bytes, u3d_stream s) {
+                                         void* dvalue, float* dref, void* grad, int64_t grad_bytes, u3d_stream s) {
   (void)x; (void)xc; (void)xc_out;
   int32_t rc = dcb_check(p, d);
   if (rc != U3D_OK) return rc;
   U3D_REQUIRE(ref && value && save && dreg && dcls && diou && dx && dvalue && grad, U3D_ERR_ARG);
+  U3D_REQUIRE(!d->dvalue_bf16 || d->dtype == U3D_BF16, U3D_ERR_ARG);
   U3D_REQUIRE(!d->need_dref || dref, U3D_ERR_ARG);
   U3D_REQUIRE((d->p_attn == 0.f && d->p_drop == 0.f) || rng, U3D_ERR_ARG);
   if (d->dtype == U3D_BF16)

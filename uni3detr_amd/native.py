@@ -43,7 +43,7 @@ class DecLayerParams(C.Structure):
 class DecLayerDims(C.Structure):
     """u3d_declayer_dims."""
     _fields_ = [(n, C.c_int32) for n in ("m", "nq", "qps", "batch", "dz", "dy", "dx", "ncls", "code", "has_qs", "need_dref", "layer")] + \
-               [("p_attn", C.c_float), ("p_drop", C.c_float), ("ln_eps", C.c_float), ("dtype", C.c_int32)]
+               [("p_attn", C.c_float), ("p_drop", C.c_float), ("ln_eps", C.c_float), ("dtype", C.c_int32), ("dvalue_bf16", C.c_int32)]
 
 
 class WPackDesc(C.Structure):
@@ -1304,7 +1304,10 @@ def decoder_layer_fwd(params, dims, x, xc, ref, value_rows, rng, save):
 
 
 def decoder_layer_bwd(params, dims, x, xc, ref, value_rows, rng, xc_out, save, dx_out, dreg, dcls, diou, dvalue, grad):
+    """dvalue: f32 [rows, 256] accumulator, or (bf16 kernels only) a bf16 one - packed bf16 atomics, see u3d_declayer_dims.dvalue_bf16."""
     m = dims.m
+    dims.dvalue_bf16 = 1 if dvalue.dtype == torch.bfloat16 else 0
+    assert dvalue.dtype == torch.float32 or dims.dtype == DT_BF16
     mp = decoder_rows(m, torch.bfloat16 if dims.dtype == DT_BF16 else torch.float32)
     dx = torch.empty((mp, 256), dtype=torch.float32, device=ref.device)
     dref = torch.empty((mp, 3), dtype=torch.float32, device=ref.device) if dims.need_dref else None

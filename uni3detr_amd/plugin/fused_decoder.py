@@ -22,6 +22,7 @@ from torch import nn
 from .. import native as nv
 
 ENABLED = os.environ.get("U3D_FUSED_DECODER", "1") == "1"
+PK_SCATTER = os.environ.get("U3D_PK_SCATTER", "1") == "1"      # trilinear scatter of the volume gradient with global_atomic_pk_add_bf16
 POISON = os.environ.get("U3D_DEC_POISON", "0") == "1"      # debugging: NaN-fill the workspaces (read-before-write shows up as NaN)
 DEBUG_KEEP = None          # tests: a list that receives every backward call's gradient workspace
 
@@ -283,12 +284,15 @@ class FusedLayerFn(torch.autograd.Function):
         dreg, dcls, diou = z(dreg, (M, sp.code)), z(dcls, (M, sp.ncls)), z(diou, (M,))
         dx_out = None if dx_out is None else dx_out.contiguous().float()
         want_dv = ctx.needs_input_grad[3]
+        # bf16 kernels: the volume gradient accumulates in bf16 through packed atomics (two channels per atomic; no f32 volume to zero and
+        # cast).  A cell collects a handful of contributions at most, each already rounded to bf16 on the way into the conv backward.
+        acc_dt = torch.bfloat16 if (PK_SCATTER and rows.dtype == torch.bfloat16) else torch.float32
         if accum is not None:
             if accum.buf is None:
-                accum.buf = torch.zeros(rows.shape, dtype=torch.float32, device=dev)
+                accum.buf = torch.zeros(rows.shape, dtype=acc_dt, device=dev)
             dvalue = accum.buf
         else:
-            dvalue = torch.zeros(rows.shape, dtype=torch.float32, device=dev)
+            dvalue = torch.zeros(rows.shape, dtype=acc_dt, device=dev)
         dx, dref = nv.decoder_layer_bwd(ctx.params, d, x, xc, ref, rows, fd.rng, xc_out, save, dx_out, dreg, dcls, diou, dvalue, grad)
         if DEBUG_KEEP is not None:
             DEBUG_KEEP.append(grad)
