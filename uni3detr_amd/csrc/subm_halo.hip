@@ -1,17 +1,20 @@
-// Output-stationary "halo" kernel for the 64 -> 64 channel, 27-offset submanifold level (ref: sparse_encoder_hd.py:106-138, the
-// SparseBasicBlock convs of the stride-4 stage; spconv's SubMConv3d gathers each of the 27 offsets' rows again).
+// Output-stationary "halo" kernels for the 64- and 128-channel, 27-offset submanifold levels (ref: sparse_encoder_hd.py:106-138, the
+// SparseBasicBlock convs of the stride-4 / stride-8 stages; spconv's SubMConv3d gathers each of the 27 offsets' rows again).
 //
-// The LDS-DMA implicit-GEMM kernel (igemm_bf16.hip) fetches, per 128-row output tile, 27 x 128 operand rows of 128 B through
-// 27 x 128 one-row DMA pieces: its time at this level (92 us for 211 k rows) is the issue cost of those pieces, not HBM and not
-// MFMA.  But rows are numbered in 4x4x4-block-major order, so the 27 x 128 table entries of a tile name
-// only ~250-450 DISTINCT rows (the tile's cells plus a one-cell shell).  This path
-//   1. k_halo_build  (once per level and step, shared by the level's 2 x 4 convs and their input gradients): per tile, the sorted
+// The LDS-DMA implicit-GEMM kernels (igemm_bf16.hip) fetch, per 128-row output tile, 27 x 128 operand rows through 27 x 128 one-row
+// DMA pieces, and the fill rate of that path is what bounds them.  But rows are numbered in 4x4x4-block-major
+// order, so the 27 x 128 table entries of a tile name only ~210-420 DISTINCT rows (the tile's cells plus a one-cell shell).  This file:
+//   1. k_halo_build  (once per level and step, shared by all of the level's convs and their gradients): per tile, the sorted
 //      distinct table entries (LDS bitmap) -> tile_rows[tile][slot] (slot 0 = the all-zero row), and the table rewritten as 16-bit
 //      LDS slots loc[tile][offset][row];
-//   2. k_subm_halo64: stage the tile's distinct rows ONCE (coalesced 16 B loads, 144 B LDS row stride), then run all 27 offsets
-//      out of LDS without a barrier: wave w takes offsets w, w+4, ... for the whole 128 x 64 tile (64 MFMAs per 16 LDS reads and 8
-//      weight-fragment loads - the split over offsets is what keeps LDS and L1 traffic 8 x below the MFMA time), and the four
-//      partial tiles are summed by a two-round reduce-scatter through the (by then dead) stage buffer.
+//   2. k_subm_halo64 (forward / input gradient, 64 channels): stage the tile's distinct rows ONCE (coalesced 16 B loads, 144 B LDS
+//      row stride), then run all 27 offsets out of LDS without a barrier: wave w takes offsets w, w+4, ... for the whole 128 x 64
+//      tile (64 MFMAs per 16 LDS reads and 8 weight-fragment loads), and the four partial tiles are summed by a two-round
+//      reduce-scatter through the (by then dead) stage buffer;
+//   3. k_subm_halo128 (forward / input gradient, 128 channels): waves split the output columns, rows staged one 64-channel half at
+//      a time;
+//   4. k_subm_halo_wgrad64 (weight gradient, 64 channels): both MFMA operands by transpose reads out of the staged rows / dy tile,
+//      persistent 8-wave workgroups, LDS-DMA double-buffered staging.
 // The transposed table of a SubM layer is the forward one with the offsets reversed, so the same loc[] serves the input gradient
 // (krev: offset k reads loc[26 - k]).
 #include "common.h"
