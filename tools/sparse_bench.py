@@ -78,6 +78,10 @@ def main():
             "dgrad": lambda: nv.spconv_fwd(dy, w, g.nbr_bwd, g.n_in_dev, g.n_in, ci, transpose_w=True),
             "wgrad": lambda: nv.spconv_wgrad(x, dy, g.nbr_fwd, g.n_out_dev, 27),
         }
+        if os.environ.get("HALO_STATS") and g.level is not None and ci == co:
+            h_ = nv.SubmHalo(g.nbr_fwd, g.n_out_dev, g.n_out)
+            tc_ = h_.tile_cnt.float()
+            print(f"{tagname:34s} halo stats: {h_.tiles} tiles, distinct rows per tile mean {tc_.mean().item():.0f} p90 {tc_.quantile(0.9).item():.0f} max {tc_.max().item():.0f}", flush=True)
         if ci == 64 and co == 64 and g.level is not None:
             halo = g.level.halo()
             tc = halo.tile_cnt.float()
