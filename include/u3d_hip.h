@@ -224,7 +224,7 @@ int32_t u3d_bn_bwd_finalize_partials(const double* partial, int32_t nblocks, int
  * with it the statistics are the BatchNorm-backward sums described at u3d_bn_epi above, instead of the output's own. */
 int32_t u3d_subm_halo_sizes(int32_t n_cap, int64_t* tile_rows_elems, int64_t* loc_elems, int32_t* tiles);
 int32_t u3d_subm_halo_build(const int32_t* nbr, int32_t ld, const int32_t* n_dev, int32_t n_cap, int32_t* tile_rows,
-                            uint16_t* loc, int32_t* tile_cnt, u3d_stream s);
+                            uint16_t* loc, int32_t* tile_cnt, int32_t kvol, u3d_stream s);
 int32_t u3d_subm_halo_wpack(const void* w_nmajor, void* w_packed, u3d_stream s);
 /* n weights in one launch: device arrays of n source / destination pointers (the per-step shadow refresh packs every 64 -> 64 SubM weight,
  * forward and transposed, at once). */
@@ -234,12 +234,15 @@ int32_t u3d_subm_halo_conv64_bf16(const void* in, const void* w_packed, const in
                                   const void* addend, void* out, double* stats, const u3d_bn_epi* bn, int32_t max_slots,
                                   u3d_stream s);
 /* The same for 128 -> 128 channels (the stride-8 stage): in/out/addend bf16 [n][128], w_packed = u3d_subm_halo_wpack128 of the n-major
- * bf16 weights [27][128][128]; stats f64 [tiles][2][128].  Tables from u3d_subm_halo_build (they do not depend on the channel count). */
-int32_t u3d_subm_halo_wpack128(const void* w_nmajor, void* w_packed, u3d_stream s);
-int32_t u3d_subm_halo_wpack128_batched(const void* const* srcs_dev, void* const* dsts_dev, int32_t n, u3d_stream s);
+ * bf16 weights [kvol][128][128]; stats f64 [tiles][2][128].  Tables from u3d_subm_halo_build (they do not depend on the channel count).
+ * kvol <= 27 offsets (the build takes the same kvol; loc keeps 27 slots per tile): 27 for the sparse SubM levels, 9 for the stride-1
+ * (1,3,3) convs of the dense stack (SECOND3D's 128-channel branch, ref: second_3d.py:52-76), whose tables are static - the transposed
+ * table of a stride-1 "same" conv on a lattice is the forward one reversed, exactly as for SubM. */
+int32_t u3d_subm_halo_wpack128(const void* w_nmajor, void* w_packed, int32_t kvol, u3d_stream s);
+int32_t u3d_subm_halo_wpack128_batched(const void* const* srcs_dev, void* const* dsts_dev, int32_t n, int32_t kvol, u3d_stream s);
 int32_t u3d_subm_halo_conv128_bf16(const void* in, const void* w_packed, const int32_t* tile_rows, const uint16_t* loc,
                                    const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, int32_t krev,
-                                   const void* addend, void* out, double* stats, int32_t max_slots, u3d_stream s);
+                                   const void* addend, void* out, double* stats, int32_t max_slots, int32_t kvol, u3d_stream s);
 /* Weight gradient of the same 64 -> 64 SubM layers from the same tables: dw f32 [27][64][64] (spconv-1.x layout) =
  * sum over rows m of x[nbr_k(m)]^T dy[m]; x / dy bf16 [n][64].  Persistent workgroups, both MFMA operands by transpose reads out of
  * the staged distinct rows / the dy tile, offsets split over four workgroup groups, one f32 partial per workgroup summed in a fixed

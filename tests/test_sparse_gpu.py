@@ -1140,3 +1140,47 @@ def test_subm_halo_128_channel_kernel(cuda, seed, n_pts, dims, cut):
     assert (g[:n].float() - expg).abs().max() / expg.abs().max() < 6e-3
     ref = nv.spconv_fwd(x, w, nb, cnt, n_cap, 128, transpose_w=True)[:n].float()
     assert (y[:n].float() - ref).abs().max() / sc < 8e-3
+
+
+def test_halo_kernel_on_the_dense_stacks_128_channel_convs(cuda):
+    """The stride-1 (1,3,3) 128 -> 128 convs of SECOND3D's first branch run the 128-channel halo kernel on the lattice's STATIC tables
+    (9 offsets): forward + statistics against the table kernel, and the input gradient through the reversed forward table against
+    the lattice's own transposed table - which it must equal entry for entry."""
+    import torch
+    from uni3detr_amd import native as nv, sparse as sp
+    from uni3detr_amd.plugin.dense import Lattice
+    B, dims = 2, (5, 24, 20)
+    geom, dims_out = Lattice.conv(torch.device("cuda"), B, dims, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    n = geom.n_out
+    assert dims_out == dims and geom.n_in == n and not geom.strided
+    assert torch.equal(geom.nbr_bwd[:, :n], geom.nbr_fwd.flip(0)[:, :n])        # transposed table == forward table reversed
+    halo = geom.halo()
+    assert halo is not None and halo.kvol == 9
+    torch.manual_seed(0)
+    x = torch.randn(n, 128, device="cuda").bfloat16()
+    w = (torch.randn(9, 128, 128, device="cuda") * 0.1).bfloat16()               # n-major [K][out][reduction]
+    wp = nv.subm_halo_wpack(w)
+    y, stats, tr = nv.subm_halo_conv(x, wp, halo, want_stats=True)
+    ref, rstats, rtr = nv.spconv_fwd_stats(x, w, geom.nbr_fwd, geom.n_out_dev, n, 128)
+    sc = ref.float().abs().max()
+    assert (y.float() - ref.float()).abs().max() / sc < 8e-3
+    assert (stats[:, 0].sum(0) - rstats[:, 0].sum(0)).abs().max() < 2e-2 * rstats[:, 0].sum(0).abs().max() + 1.0
+    g = nv.subm_halo_conv(x, wp, halo, krev=True)
+    gref = nv.spconv_fwd(x, w, geom.nbr_bwd, geom.n_in_dev, n, 128, transpose_w=True)
+    assert (g.float() - gref.float()).abs().max() / gref.float().abs().max() < 8e-3
+    # and through the autograd wrapper: same result and gradients as the table path
+    res = {}
+    w5 = (torch.randn(128, 128, 1, 3, 3, device="cuda") * 0.05)
+    dy = torch.randn(n, 128, device="cuda").bfloat16()
+    for on in (True, False):
+        sp.HALO_DENSE = on
+        try:
+            xi = x.clone().requires_grad_(True)
+            wi = w5.clone().requires_grad_(True)
+            yy, st = sp._SparseConv.apply(xi, wi, geom, "oidhw", True)
+            yy.backward(dy)
+            res[on] = (yy.detach().float(), xi.grad.float(), wi.grad.float())
+        finally:
+            sp.HALO_DENSE = False
+    for a, b, tol in zip(res[True], res[False], (8e-3, 8e-3, 1e-5)):
+        assert (a - b).abs().max() / b.abs().max() < tol

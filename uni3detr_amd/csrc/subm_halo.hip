@@ -59,8 +59,8 @@ extern "C" int32_t u3d_debug_halo_wgrad_times(uint64_t* out) { return hipMemcpyF
 // took 44 us per level, a sort of the raw 27 x 128 entries 180 us; sorted slots keep the neighbours of consecutive rows on
 // consecutive LDS rows - conflict-free fragment reads in k_subm_halo64.)
 // dynamic LDS: bitmap u32 [W] | word prefix u16 [W] | part int [256], W = words rounded up to a multiple of 256
-__global__ __launch_bounds__(256) void k_halo_build(const int32_t* __restrict__ nbr, int ld, const int32_t* __restrict__ n_dev, int n_cap,
-                                                    int wpt, int32_t* __restrict__ tile_rows, u16* __restrict__ loc,
+__global__ __launch_bounds__(256) void k_halo_build(const int32_t* __restrict__ nbr, int ld, int kvol, const int32_t* __restrict__ n_dev,
+                                                    int n_cap, int wpt, int32_t* __restrict__ tile_rows, u16* __restrict__ loc,
                                                     int32_t* __restrict__ tile_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int W = wpt * 256;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_halo_build(const int32_t* __restrict__ 
   for (int i = 0; i < 14; ++i) {
     const int e = tid + i * 256;
     const int k = e >> 7, r = (e & 7) * 16 + ((e >> 3) & 15);
-    gs[i] = (e < HL_K * HL_T && m0 + r < n) ? nbr[(long long)k * ld + m0 + r] : -1;
+    gs[i] = (e < kvol * HL_T && m0 + r < n) ? nbr[(long long)k * ld + m0 + r] : -1;      // (kvol <= 27 offsets; loc keeps 27 slots per tile)
   }
   for (int i = tid; i < W; i += 256) bits[i] = 0u;
   __syncthreads();
@@ -429,10 +429,10 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo64(const u16* __restrict__ 
 // weights, at the ~17 B/clk/CU fill rate that bounds it; here the rows are ~270 x 256 B = 69 KB.
 // weights: k_halo_wpack128 = [27][half][nt 8][ks 2][lane 64][8]
 __global__ __launch_bounds__(256) void k_halo_wpack128(const u16* __restrict__ src, u16* __restrict__ dst, const u16* const* __restrict__ srcs,
-                                                       u16* const* __restrict__ dsts) {
+                                                       u16* const* __restrict__ dsts, int kvol) {
   if (srcs) { src = srcs[blockIdx.y]; dst = dsts[blockIdx.y]; }
   const int c = blockIdx.x * 256 + threadIdx.x;   // 16 B chunk of dst
-  if (c >= HL_K * 2048) return;
+  if (c >= kvol * 2048) return;
   const int lane = c & 63, ks = (c >> 6) & 1, nt = (c >> 7) & 7, half = (c >> 10) & 1, k = c >> 11;
   *(u32x4*)(dst + (long long)c * 8) = *(const u32x4*)(src + k * 16384 + (nt * 16 + (lane & 15)) * 128 + half * 64 + ks * 32 + (lane >> 4) * 8);
 }
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo128(const u16* __restrict__
                                                          const int32_t* __restrict__ tile_rows, const u16* __restrict__ loc,
                                                          const int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ n_dev, int n_cap,
                                                          int krev, const u16* __restrict__ addend, u16* __restrict__ out,
-                                                         double* __restrict__ stats, int maxs) {
+                                                         double* __restrict__ stats, int maxs, int kvol) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u16* xs = (u16*)smem;                           // [HL_MAXS][HL_RS]: one 64-channel half of the distinct rows
   const int tid = threadIdx.x;
@@ -485,9 +485,9 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo128(const u16* __restrict__
     dst[b][1] = *(const bf16x8*)(wl + ((long long)(k) * 32 + b * 2 + 1) * 512);                          \
   }
 #define H2_OFFSET_LOOP(FAST)                                                                            \
-  for (int k = 0; k < HL_K; ++k) {                                                                      \
-    const int kn = k + 1 < HL_K ? k + 1 : k;                                                            \
-    const u16x8 sln = *(const u16x8*)(locp + (krev ? 26 - kn : kn) * HL_T);                             \
+  for (int k = 0; k < kvol; ++k) {                                                                      \
+    const int kn = k + 1 < kvol ? k + 1 : k;                                                            \
+    const u16x8 sln = *(const u16x8*)(locp + (krev ? kvol - 1 - kn : kn) * HL_T);                       \
     bf16x8 wn[2][2];                                                                                    \
     H2_WLOAD(wn, kn)                                                                                    \
     bf16x8 x0, x1, y0, y1;                                                                              \
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo128(const u16* __restrict__
     __syncthreads();
     // weights of (offset k, this half, n-tiles 2w and 2w + 1): chunk ((k * 2 + half) * 8 + nt) * 2 + ks
     const u16* wl = wgt + ((long long)(half * 8 + 2 * w) * 2) * 512 + lane * 8;
-    u16x8 sl = *(const u16x8*)(locp + (krev ? 26 : 0) * HL_T);
+    u16x8 sl = *(const u16x8*)(locp + (krev ? kvol - 1 : 0) * HL_T);
     bf16x8 wf[2][2];
     H2_WLOAD(wf, 0)
     if (cnt <= maxs) { H2_OFFSET_LOOP(1) } else { H2_OFFSET_LOOP(0) }
@@ -803,13 +803,13 @@ extern "C" int32_t u3d_subm_halo_sizes(int32_t n_cap, int64_t* tile_rows_elems, 
 }
 
 extern "C" int32_t u3d_subm_halo_build(const int32_t* nbr, int32_t ld, const int32_t* n_dev, int32_t n_cap, int32_t* tile_rows,
-                                       uint16_t* loc, int32_t* tile_cnt, u3d_stream s) {
-  U3D_REQUIRE(nbr && n_dev && tile_rows && loc && tile_cnt && n_cap > 0 && ld >= n_cap, U3D_ERR_ARG);
+                                       uint16_t* loc, int32_t* tile_cnt, int32_t kvol, u3d_stream s) {
+  U3D_REQUIRE(nbr && n_dev && tile_rows && loc && tile_cnt && n_cap > 0 && ld >= n_cap && kvol >= 1 && kvol <= HL_K, U3D_ERR_ARG);
   const int wpt = u3d_cdiv(u3d_cdiv(n_cap, 32), 256);
   const int lds = wpt * 256 * 6 + 1024;
   if (lds > 160 * 1024) return U3D_ERR_UNSUPPORTED;      // > 869 k rows: the row bitmap does not fit the LDS
   U3D_ALLOW_LDS(k_halo_build, 160 * 1024);                // set once per device: the maximum, the launch asks for what n_cap needs
-  k_halo_build<<<u3d_cdiv(n_cap, HL_T), 256, lds, (hipStream_t)s>>>(nbr, ld, n_dev, n_cap, wpt, tile_rows, loc, tile_cnt);
+  k_halo_build<<<u3d_cdiv(n_cap, HL_T), 256, lds, (hipStream_t)s>>>(nbr, ld, kvol, n_dev, n_cap, wpt, tile_rows, loc, tile_cnt);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
@@ -868,28 +868,29 @@ extern "C" int32_t u3d_subm_halo_wgrad64_bf16(const void* x, const void* dy, con
   return U3D_OK;
 }
 
-extern "C" int32_t u3d_subm_halo_wpack128(const void* w_nmajor, void* w_packed, u3d_stream s) {
-  U3D_REQUIRE(w_nmajor && w_packed, U3D_ERR_ARG);
-  k_halo_wpack128<<<u3d_cdiv(HL_K * 2048, 256), 256, 0, (hipStream_t)s>>>((const u16*)w_nmajor, (u16*)w_packed, nullptr, nullptr);
+extern "C" int32_t u3d_subm_halo_wpack128(const void* w_nmajor, void* w_packed, int32_t kvol, u3d_stream s) {
+  U3D_REQUIRE(w_nmajor && w_packed && kvol >= 1 && kvol <= HL_K, U3D_ERR_ARG);
+  k_halo_wpack128<<<u3d_cdiv(kvol * 2048, 256), 256, 0, (hipStream_t)s>>>((const u16*)w_nmajor, (u16*)w_packed, nullptr, nullptr, kvol);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
-extern "C" int32_t u3d_subm_halo_wpack128_batched(const void* const* srcs_dev, void* const* dsts_dev, int32_t n, u3d_stream s) {
-  U3D_REQUIRE(srcs_dev && dsts_dev && n >= 0, U3D_ERR_ARG);
+extern "C" int32_t u3d_subm_halo_wpack128_batched(const void* const* srcs_dev, void* const* dsts_dev, int32_t n, int32_t kvol, u3d_stream s) {
+  U3D_REQUIRE(srcs_dev && dsts_dev && n >= 0 && kvol >= 1 && kvol <= HL_K, U3D_ERR_ARG);
   if (n == 0) return U3D_OK;
-  k_halo_wpack128<<<dim3(u3d_cdiv(HL_K * 2048, 256), n), 256, 0, (hipStream_t)s>>>(nullptr, nullptr, (const u16* const*)srcs_dev, (u16* const*)dsts_dev);
+  k_halo_wpack128<<<dim3(u3d_cdiv(kvol * 2048, 256), n), 256, 0, (hipStream_t)s>>>(nullptr, nullptr, (const u16* const*)srcs_dev, (u16* const*)dsts_dev, kvol);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
 extern "C" int32_t u3d_subm_halo_conv128_bf16(const void* in, const void* w_packed, const int32_t* tile_rows, const uint16_t* loc,
                                               const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, int32_t krev,
-                                              const void* addend, void* out, double* stats, int32_t max_slots, u3d_stream s) {
-  U3D_REQUIRE(in && w_packed && tile_rows && loc && tile_cnt && n_dev && out && n_cap > 0, U3D_ERR_ARG);
+                                              const void* addend, void* out, double* stats, int32_t max_slots, int32_t kvol,
+                                              u3d_stream s) {
+  U3D_REQUIRE(in && w_packed && tile_rows && loc && tile_cnt && n_dev && out && n_cap > 0 && kvol >= 1 && kvol <= HL_K, U3D_ERR_ARG);
   const int lds = HL_MAXS * HL_RS * 2;
   U3D_ALLOW_LDS(k_subm_halo128, lds);
   k_subm_halo128<<<u3d_cdiv(n_cap, HL_T), 256, lds, (hipStream_t)s>>>((const u16*)in, (const u16*)w_packed, tile_rows, loc, tile_cnt, n_dev, n_cap,
                                                                      krev, (const u16*)addend, (u16*)out, stats,
-                                                                     (max_slots > 0 && max_slots < HL_MAXS) ? max_slots : HL_MAXS);
+                                                                     (max_slots > 0 && max_slots < HL_MAXS) ? max_slots : HL_MAXS, kvol);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

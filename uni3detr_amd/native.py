@@ -109,10 +109,10 @@ _SIGS = {
     "u3d_igemm_dgrad_bnstats_bf16": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "u3d_bn_bwd_finalize_partials": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P]),
     "u3d_subm_halo_sizes": (_I, [_I, _P, _P, _P]),
-    "u3d_subm_halo_build": (_I, [_P, _I, _P, _I, _P, _P, _P, _P]),
-    "u3d_subm_halo_wpack128": (_I, [_P, _P, _P]),
-    "u3d_subm_halo_wpack128_batched": (_I, [_P, _P, _I, _P]),
-    "u3d_subm_halo_conv128_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
+    "u3d_subm_halo_build": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P]),
+    "u3d_subm_halo_wpack128": (_I, [_P, _P, _I, _P]),
+    "u3d_subm_halo_wpack128_batched": (_I, [_P, _P, _I, _I, _P]),
+    "u3d_subm_halo_conv128_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
     "u3d_subm_halo_wgrad64_workspace": (_L, []),
     "u3d_subm_halo_wgrad64_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _P]),
     "u3d_subm_halo_wpack": (_I, [_P, _P, _P]),
@@ -516,11 +516,12 @@ class SubmHalo:
         a, b, t = C.c_int64(0), C.c_int64(0), C.c_int32(0)
         _check(lib().u3d_subm_halo_sizes(n_cap, C.byref(a), C.byref(b), C.byref(t)), "subm_halo_sizes")
         self.tiles, self.n_dev, self.n_cap, self.nbr = t.value, n_dev, n_cap, nbr_fwd
+        self.kvol = nbr_fwd.shape[0]                     # <= 27 offsets (27: sparse SubM levels; 9: the dense stack's (1,3,3) convs)
         self.tile_rows = torch.empty((a.value,), dtype=torch.int32, device=dev)
         self.loc = torch.empty((b.value,), dtype=torch.int16, device=dev)
         self.tile_cnt = torch.empty((t.value,), dtype=torch.int32, device=dev)
         rc = lib().u3d_subm_halo_build(_ptr(nbr_fwd), nbr_fwd.shape[1], _ptr(n_dev), n_cap, _ptr(self.tile_rows), _ptr(self.loc),
-                                       _ptr(self.tile_cnt), _stream())
+                                       _ptr(self.tile_cnt), self.kvol, _stream())
         self.ok = rc != -2              # U3D_ERR_UNSUPPORTED: more rows than the LDS row bitmap holds - the caller keeps the table kernels
         if self.ok:
             _check(rc, "subm_halo_build")
@@ -551,33 +552,40 @@ def subm_halo_wgrad(x, dy, halo, out=None, max_slots=0):
 
 def subm_halo_wpack(w_nmajor, out=None):
     """bf16 [27, 64 (out), 64 (reduction)] -> the MFMA fragment order u3d_subm_halo_conv64_bf16 reads (same shape and size)."""
-    assert w_nmajor.dtype == torch.bfloat16 and tuple(w_nmajor.shape) in ((27, 64, 64), (27, 128, 128)) and w_nmajor.is_contiguous()
+    k, c = w_nmajor.shape[0], w_nmajor.shape[1]
+    assert w_nmajor.dtype == torch.bfloat16 and w_nmajor.is_contiguous() and w_nmajor.shape[2] == c
+    assert (k == 27 and c == 64) or (1 <= k <= 27 and c == 128)
     out = torch.empty_like(w_nmajor) if out is None else out
-    fn = lib().u3d_subm_halo_wpack if w_nmajor.shape[1] == 64 else lib().u3d_subm_halo_wpack128
-    _check(fn(_ptr(w_nmajor), _ptr(out), _stream()), "subm_halo_wpack")
+    if c == 64:
+        _check(lib().u3d_subm_halo_wpack(_ptr(w_nmajor), _ptr(out), _stream()), "subm_halo_wpack")
+    else:
+        _check(lib().u3d_subm_halo_wpack128(_ptr(w_nmajor), _ptr(out), k, _stream()), "subm_halo_wpack128")
     return out
 
 
 def subm_halo_wpack_plan(pairs, device):
     """[(src, dst)] of [27, C, C] bf16 tensors, all with the same C in (64, 128) -> plan for subm_halo_wpack_batched (device pointer
     arrays; the tensors must stay alive)."""
-    c = pairs[0][0].shape[1]
-    assert all(tuple(a.shape) == (27, c, c) for a, _ in pairs) and c in (64, 128)
+    k, c = pairs[0][0].shape[0], pairs[0][0].shape[1]
+    assert all(tuple(a.shape) == (k, c, c) for a, _ in pairs) and ((k == 27 and c == 64) or c == 128)
     src = torch.tensor([a.data_ptr() for a, _ in pairs], dtype=torch.int64, device=device)
     dst = torch.tensor([b.data_ptr() for _, b in pairs], dtype=torch.int64, device=device)
-    return src, dst, len(pairs), pairs, c
+    return src, dst, len(pairs), pairs, c, k
 
 
 def subm_halo_wpack_batched(plan):
-    fn = lib().u3d_subm_halo_wpack_batched if plan[4] == 64 else lib().u3d_subm_halo_wpack128_batched
-    _check(fn(_ptr(plan[0]), _ptr(plan[1]), plan[2], _stream()), "subm_halo_wpack_batched")
+    if plan[4] == 64:
+        _check(lib().u3d_subm_halo_wpack_batched(_ptr(plan[0]), _ptr(plan[1]), plan[2], _stream()), "subm_halo_wpack_batched")
+    else:
+        _check(lib().u3d_subm_halo_wpack128_batched(_ptr(plan[0]), _ptr(plan[1]), plan[2], plan[5], _stream()), "subm_halo_wpack128_batched")
 
 
 def subm_halo_conv(inp, w_packed, halo, krev=False, addend=None, want_stats=False, tag="spconv_fwd", bn_epi=None, max_slots=0):
     """64 -> 64 channel, 27-offset SubM conv out of the tile's staged distinct rows (u3d_subm_halo_conv64_bf16).
     w_packed: subm_halo_wpack of bf16 [27, 64 (out), 64 (reduction)].  -> out, or (out, stats f64 [tiles, 2, 64], 128) with want_stats."""
     c = inp.shape[1]
-    assert inp.dtype == torch.bfloat16 and c in (64, 128) and tuple(w_packed.shape) == (27, c, c) and inp.shape[0] == halo.n_cap
+    assert inp.dtype == torch.bfloat16 and c in (64, 128) and tuple(w_packed.shape) == (halo.kvol, c, c) and inp.shape[0] == halo.n_cap
+    assert c == 128 or halo.kvol == 27
     assert c == 64 or bn_epi is None, "the BatchNorm-backward epilogue exists on the 64-channel kernel only"
     out = torch.empty_like(inp)
     stats = torch.empty((halo.tiles, 2, c), dtype=torch.float64, device=inp.device) if want_stats else None
@@ -591,14 +599,14 @@ def subm_halo_conv(inp, w_packed, halo, krev=False, addend=None, want_stats=Fals
     else:
         _check(lib().u3d_subm_halo_conv128_bf16(_ptr(inp), _ptr(w_packed), _ptr(halo.tile_rows), _ptr(halo.loc), _ptr(halo.tile_cnt),
                                                 _ptr(halo.n_dev), halo.n_cap, int(krev), _ptr(addend), _ptr(out), _ptr(stats),
-                                                int(max_slots), _stream()), "subm_halo_conv128_bf16")
+                                                int(max_slots), halo.kvol, _stream()), "subm_halo_conv128_bf16")
     if t is not None:
         meta = None
         if t.mode == "census":
             n = halo.n_cap
             pairs = int((halo.nbr[:, :n] >= 0).sum().item())
-            meta = dict(kind=CALL_KIND, v2=True, n_in=n, n_out=n, cin=c, cout=c, kvol=27, pairs=pairs,
-                        bytes=n * c * 2 * 2 + 8 * pairs + 27 * c * c * 2, flops=2 * pairs * c * c)
+            meta = dict(kind=CALL_KIND, v2=True, n_in=n, n_out=n, cin=c, cout=c, kvol=halo.kvol, pairs=pairs,
+                        bytes=n * c * 2 * 2 + 8 * pairs + halo.kvol * c * c * 2, flops=2 * pairs * c * c)
         t.end(tag, e0, meta)
     return (out, stats, SubmHalo.TILE) if want_stats else out
 

@@ -102,12 +102,13 @@ class ShadowSet:
         # 64 -> 64 channel, 27-offset weights (the SubM blocks of the stride-4 stage): MFMA-fragment-packed copies of both layouts
         # for the halo kernel (csrc/subm_halo.hip), all of them in ONE launch per refresh
         self._halo_plans = []
-        for c in (64, 128):
+        # (kvol, channels, layout): the sparse encoder's 64- / 128-channel SubM weights and the dense stack's 128-channel (1,3,3) convs
+        for k, c, lay in ((27, 64, "dhwio"), (27, 128, "dhwio"), (9, 128, "oidhw")):
             pairs = []
             for p in self.conv_params:
                 kio, koi = p._u3d_conv_shadow[0], p._u3d_conv_shadow[1]
-                if tuple(kio.shape) == (27, c, c) and conv_layouts[p] == "dhwio":      # (the sparse encoder's weights: the dense stack never takes the halo path)
-                    pk = torch.empty((2, 27, c, c), dtype=torch.bfloat16, device=src.device)
+                if tuple(kio.shape) == (k, c, c) and conv_layouts[p] == lay:
+                    pk = torch.empty((2, k, c, c), dtype=torch.bfloat16, device=src.device)
                     pairs += [(koi, pk[0]), (kio, pk[1])]
                     p._u3d_halo_pack = [pk[0], pk[1], -1]
             if pairs:

@@ -101,6 +101,14 @@ class ConvGeom:
         self.lattice = None         # (batch, (D,H,W), kd) for a stride-1 "same" (kd,3,3) conv on a dense lattice (u3d_igemm_lattice_bf16)
         self.level = None           # SubM convs: the Level (its halo() serves the 64 -> 64 convs, u3d_subm_halo_conv64_bf16)
         self._im2col = None
+        self._halo = None
+
+    def halo(self):
+        """Dense stride-1 convs: distinct-row tables of the (static) forward table, built once per geometry (native.SubmHalo)."""
+        if self._halo is None:
+            h = nv.SubmHalo(self.nbr_fwd, self.n_out_dev, self.n_out) if self.n_out <= nv.SubmHalo.MAX_ROWS else None
+            self._halo = h if (h is not None and h.ok) else False
+        return self._halo or None
 
     def im2col_index(self):
         """int32 [n_out * K]: entry m * K + k = the input row of output row m at offset k (-1: none) - the forward table transposed,
@@ -152,6 +160,10 @@ REV_SUBM_TABLE = os.environ.get("U3D_REV_SUBM_TABLE", "1") == "1"
 SUBM_HALO = os.environ.get("U3D_SUBM_HALO", "1") == "1"       # 64 -> 64 SubM convs out of per-tile staged distinct rows (subm_halo.hip)
 HALO_WGRAD = os.environ.get("U3D_HALO_WGRAD", "1") == "1"     # ... and their weight gradients (k_subm_halo_wgrad64)
 HALO_128 = os.environ.get("U3D_HALO_128", "1") == "1"         # ... and the 128 -> 128 SubM convs (k_subm_halo128: forward / input gradient)
+# ... and the dense stack's stride-1 128 -> 128 (1,3,3) convs (same kernel, 9 offsets, static tables).  Parity-tested; in the captured
+# step it is on par with the LDS-DMA tiled kernel (19.27 vs 19.23 ms, same-box A/B 3 x 100 steps): on a lattice the tiled kernel's
+# operand rows are consecutive, so its row stream is cheap and the weight stream - the same in both - sets the time.  Off.
+HALO_DENSE = os.environ.get("U3D_HALO_DENSE", "0") == "1"
 LATTICE_KERNEL = os.environ.get("U3D_LATTICE_KERNEL", "0") == "1"      # 27-offset dense convs on u3d_igemm_lattice_bf16 (measured on par: off)
 STRIDED_DGRAD_SPLIT = os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
 NMAJOR_FWD = os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
@@ -251,14 +263,20 @@ class _SparseConv(torch.autograd.Function):
         lat = geom.lattice if (LATTICE_KERNEL and nmajor and geom.lattice is not None and geom.lattice[2] == 3) else None
         ctx.halo = (SUBM_HALO and REV_SUBM_TABLE and nmajor and geom.level is not None and kv == 27 and cin == cout
                     and (cin == 64 or (cin == 128 and HALO_128)) and geom.n_out >= 4096 and geom.level.halo() is not None)
+        ctx.halo_tab = geom.level.halo() if ctx.halo else None
+        if (not ctx.halo and HALO_DENSE and nmajor and geom.kind == "dense" and not geom.strided and 1 < kv <= 27 and cin == cout == 128
+                and geom.n_in == geom.n_out and geom.n_out >= 4096 and geom.halo() is not None):
+            # stride-1 "same" conv on a dense lattice, 128 channels (SECOND3D's first branch): the same kernel on static tables; the
+            # transposed table of such a conv is the forward one reversed, as for SubM
+            ctx.halo, ctx.halo_tab = True, geom.halo()
         if ctx.halo:
             pk_fwd, ctx.pk_bwd = halo_packs(weight, kio, koi)
             if want_stats:
-                y, stats, tr = nv.subm_halo_conv(feats, pk_fwd, geom.level.halo(), want_stats=True)
+                y, stats, tr = nv.subm_halo_conv(feats, pk_fwd, ctx.halo_tab, want_stats=True)
                 stats._u3d_tile_rows = tr
                 ctx.mark_non_differentiable(stats)
                 return y, stats
-            return nv.subm_halo_conv(feats, pk_fwd, geom.level.halo())
+            return nv.subm_halo_conv(feats, pk_fwd, ctx.halo_tab)
         if want_stats:
             res = None
             if lat is not None:
@@ -306,7 +324,7 @@ class _SparseConv(torch.autograd.Function):
                 ks = ctx.kio_shape
                 dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol, out_oik=True, out=gv).view(ks[4], ks[3], ks[0], ks[1], ks[2])
             elif ctx.layout == "dhwio" and v2 and ctx.halo and HALO_WGRAD and cin_w == 64:
-                dw = nv.subm_halo_wgrad(feats, dout, g.level.halo(), out=gv).view(ctx.kio_shape)
+                dw = nv.subm_halo_wgrad(feats, dout, ctx.halo_tab, out=gv).view(ctx.kio_shape)
             elif ctx.layout == "dhwio" and v2:
                 dw = nv.spconv_wgrad(feats, dout, nbr, g.n_out_dev, kvol, out=gv).view(ctx.kio_shape)
             else:
@@ -360,11 +378,11 @@ class _SparseConv(torch.autograd.Function):
                     if ctx.halo:
                         pk = ctx.pk_bwd if ctx.pk_bwd is not None else nv.subm_halo_wpack(wc)
                         if bt is not None:
-                            din, st, tr = nv.subm_halo_conv(dout, pk, g.level.halo(), krev=True, addend=add, want_stats=True, tag="spconv_dgrad",
+                            din, st, tr = nv.subm_halo_conv(dout, pk, ctx.halo_tab, krev=True, addend=add, want_stats=True, tag="spconv_dgrad",
                                                             bn_epi=bt.epi)
                             bt.partial = (st, tr)
                         else:
-                            din = nv.subm_halo_conv(dout, pk, g.level.halo(), krev=True, addend=add, tag="spconv_dgrad")
+                            din = nv.subm_halo_conv(dout, pk, ctx.halo_tab, krev=True, addend=add, tag="spconv_dgrad")
                     else:
                         r = nv.spconv_dgrad_bnstats(dout, wc, nbr, g.n_in_dev, g.n_in, cin, add, bt.epi) if (bt is not None and kvol > 1) else None
                         if r is not None:
