@@ -243,6 +243,13 @@ int32_t u3d_subm_halo_wpack128_batched(const void* const* srcs_dev, void* const*
 int32_t u3d_subm_halo_conv128_bf16(const void* in, const void* w_packed, const int32_t* tile_rows, const uint16_t* loc,
                                    const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, int32_t krev,
                                    const void* addend, void* out, double* stats, int32_t max_slots, int32_t kvol, u3d_stream s);
+/* ... and for 32 -> 32 channels (the stride-2 stage): in/out/addend bf16 [n][32], w_packed = u3d_subm_halo_wpack32 of the n-major bf16
+ * weights [27][32][32]; stats f64 [tiles][2][32]. */
+int32_t u3d_subm_halo_wpack32(const void* w_nmajor, void* w_packed, u3d_stream s);
+int32_t u3d_subm_halo_wpack32_batched(const void* const* srcs_dev, void* const* dsts_dev, int32_t n, u3d_stream s);
+int32_t u3d_subm_halo_conv32_bf16(const void* in, const void* w_packed, const int32_t* tile_rows, const uint16_t* loc,
+                                  const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, int32_t krev,
+                                  const void* addend, void* out, double* stats, int32_t max_slots, u3d_stream s);
 /* Weight gradient of the same 64 -> 64 SubM layers from the same tables: dw f32 [27][64][64] (spconv-1.x layout) =
  * sum over rows m of x[nbr_k(m)]^T dy[m]; x / dy bf16 [n][64].  Persistent workgroups, both MFMA operands by transpose reads out of
  * the staged distinct rows / the dy tile, offsets split over four workgroup groups, one f32 partial per workgroup summed in a fixed

@@ -1142,6 +1142,47 @@ def test_subm_halo_128_channel_kernel(cuda, seed, n_pts, dims, cut):
     assert (y[:n].float() - ref).abs().max() / sc < 8e-3
 
 
+@pytest.mark.parametrize("seed,n_pts,dims,cut", [(5, 9000, (16, 40, 36), 0), (11, 60000, (12, 64, 64), 777)])
+def test_subm_halo_32_channel_kernel(cuda, seed, n_pts, dims, cut):
+    """k_subm_halo32 (32 -> 32 SubM convs: the 64-channel scheme at half the width, four workgroups per CU):
+    forward + per-tile statistics, input gradient (offsets reversed) with addend, the global-memory fall-back for rows past the staged
+    slots (max_slots hook), a device-side row count below the capacity with NaN in the dead rows; against the f32 gather-matmul and the
+    LDS-DMA tiled kernel."""
+    import torch
+    from uni3detr_amd import native as nv
+    lvl, nbr = _level(seed=seed, n_pts=n_pts, dims=dims)
+    n_cap = lvl.n
+    n = n_cap - cut
+    cnt = nv.count_tensor(n, "cuda") if cut else lvl.n_dev
+    nb = nbr.clone()
+    if cut:
+        nb[:, :n][nb[:, :n] >= n] = -1
+    halo = nv.SubmHalo(nb, cnt, n_cap)
+    torch.manual_seed(seed)
+    x = torch.randn(n_cap, 32, device="cuda").bfloat16()
+    add = torch.randn(n_cap, 32, device="cuda").bfloat16()
+    if cut:
+        x[n:] = float("nan"); add[n:] = float("nan")
+    w = (torch.randn(27, 32, 32, device="cuda") * 0.15).bfloat16()             # n-major [K][out][reduction]
+    wp = nv.subm_halo_wpack(w)
+    y, stats, tr = nv.subm_halo_conv(x, wp, halo, want_stats=True)
+    exp = _ref_conv(x[:n], w.transpose(1, 2), nb, n)
+    sc = exp.abs().max()
+    assert torch.isfinite(y[:n]).all() and (y[:n].float() - exp).abs().max() / sc < 6e-3
+    assert tr == 128 and stats.shape == (halo.tiles, 2, 32)
+    yf = y[:n].double()
+    assert (stats[:, 0].sum(0) - yf.sum(0)).abs().max() < 1e-3 * yf.abs().sum(0).max()
+    assert (stats[:, 1].sum(0) - (yf * yf).sum(0)).abs().max() < 1e-4 * (yf * yf).sum(0).max()
+    assert torch.equal(nv.subm_halo_conv(x, wp, halo)[:n], y[:n])
+    for ms in (150, 40):
+        assert torch.equal(nv.subm_halo_conv(x, wp, halo, max_slots=ms)[:n], y[:n]), ms
+    g = nv.subm_halo_conv(x, wp, halo, krev=True, addend=add)
+    expg = _ref_conv(x[:n], w.transpose(1, 2), nb.flip(0), n) + add[:n].float()
+    assert (g[:n].float() - expg).abs().max() / expg.abs().max() < 6e-3
+    ref = nv.spconv_fwd(x, w, nb, cnt, n_cap, 32, transpose_w=True)[:n].float()
+    assert (y[:n].float() - ref).abs().max() / sc < 8e-3
+
+
 def test_halo_kernel_on_the_dense_stacks_128_channel_convs(cuda):
     """The stride-1 (1,3,3) 128 -> 128 convs of SECOND3D's first branch run the 128-channel halo kernel on the lattice's STATIC tables
     (9 offsets): forward + statistics against the table kernel, and the input gradient through the reversed forward table against

@@ -22,6 +22,7 @@ TOGGLES = [
     ("uni3detr_amd.sparse", "SUBM_HALO", False),
     ("uni3detr_amd.sparse", "HALO_WGRAD", False),
     ("uni3detr_amd.sparse", "HALO_128", False),
+    ("uni3detr_amd.sparse", "HALO_32", True),
     ("uni3detr_amd.sparse", "HALO_DENSE", True),
     ("uni3detr_amd.sparse", "REV_SUBM_TABLE", False),
     ("uni3detr_amd.sparse", "STRIDED_DGRAD_SPLIT", False),

@@ -96,7 +96,7 @@ def main():
             passes["halo_fwd_stats"] = lambda: nv.subm_halo_conv(x, wpf, halo, want_stats=True)
             passes["halo_dgrad"] = lambda: nv.subm_halo_conv(dy, wpb, halo, krev=True)
             passes["halo_wgrad"] = lambda: nv.subm_halo_wgrad(x, dy, halo)
-        if ci == 128 and co == 128 and g.level is not None and g.level.halo() is not None:
+        if ci == co and ci in (32, 128) and g.level is not None and g.level.halo() is not None:
             halo = g.level.halo()
             wn = w.transpose(1, 2).contiguous()
             wpf, wpb = nv.subm_halo_wpack(wn), nv.subm_halo_wpack(w)

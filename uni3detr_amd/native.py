@@ -110,6 +110,9 @@ _SIGS = {
     "u3d_bn_bwd_finalize_partials": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P]),
     "u3d_subm_halo_sizes": (_I, [_I, _P, _P, _P]),
     "u3d_subm_halo_build": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P]),
+    "u3d_subm_halo_wpack32": (_I, [_P, _P, _P]),
+    "u3d_subm_halo_wpack32_batched": (_I, [_P, _P, _I, _P]),
+    "u3d_subm_halo_conv32_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
     "u3d_subm_halo_wpack128": (_I, [_P, _P, _I, _P]),
     "u3d_subm_halo_wpack128_batched": (_I, [_P, _P, _I, _I, _P]),
     "u3d_subm_halo_conv128_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
@@ -554,9 +557,11 @@ def subm_halo_wpack(w_nmajor, out=None):
     """bf16 [27, 64 (out), 64 (reduction)] -> the MFMA fragment order u3d_subm_halo_conv64_bf16 reads (same shape and size)."""
     k, c = w_nmajor.shape[0], w_nmajor.shape[1]
     assert w_nmajor.dtype == torch.bfloat16 and w_nmajor.is_contiguous() and w_nmajor.shape[2] == c
-    assert (k == 27 and c == 64) or (1 <= k <= 27 and c == 128)
+    assert (k == 27 and c in (32, 64)) or (1 <= k <= 27 and c == 128)
     out = torch.empty_like(w_nmajor) if out is None else out
-    if c == 64:
+    if c == 32:
+        _check(lib().u3d_subm_halo_wpack32(_ptr(w_nmajor), _ptr(out), _stream()), "subm_halo_wpack32")
+    elif c == 64:
         _check(lib().u3d_subm_halo_wpack(_ptr(w_nmajor), _ptr(out), _stream()), "subm_halo_wpack")
     else:
         _check(lib().u3d_subm_halo_wpack128(_ptr(w_nmajor), _ptr(out), k, _stream()), "subm_halo_wpack128")
@@ -567,14 +572,16 @@ def subm_halo_wpack_plan(pairs, device):
     """[(src, dst)] of [27, C, C] bf16 tensors, all with the same C in (64, 128) -> plan for subm_halo_wpack_batched (device pointer
     arrays; the tensors must stay alive)."""
     k, c = pairs[0][0].shape[0], pairs[0][0].shape[1]
-    assert all(tuple(a.shape) == (k, c, c) for a, _ in pairs) and ((k == 27 and c == 64) or c == 128)
+    assert all(tuple(a.shape) == (k, c, c) for a, _ in pairs) and ((k == 27 and c in (32, 64)) or c == 128)
     src = torch.tensor([a.data_ptr() for a, _ in pairs], dtype=torch.int64, device=device)
     dst = torch.tensor([b.data_ptr() for _, b in pairs], dtype=torch.int64, device=device)
     return src, dst, len(pairs), pairs, c, k
 
 
 def subm_halo_wpack_batched(plan):
-    if plan[4] == 64:
+    if plan[4] == 32:
+        _check(lib().u3d_subm_halo_wpack32_batched(_ptr(plan[0]), _ptr(plan[1]), plan[2], _stream()), "subm_halo_wpack32_batched")
+    elif plan[4] == 64:
         _check(lib().u3d_subm_halo_wpack_batched(_ptr(plan[0]), _ptr(plan[1]), plan[2], _stream()), "subm_halo_wpack_batched")
     else:
         _check(lib().u3d_subm_halo_wpack128_batched(_ptr(plan[0]), _ptr(plan[1]), plan[2], plan[5], _stream()), "subm_halo_wpack128_batched")
@@ -584,14 +591,18 @@ def subm_halo_conv(inp, w_packed, halo, krev=False, addend=None, want_stats=Fals
     """64 -> 64 channel, 27-offset SubM conv out of the tile's staged distinct rows (u3d_subm_halo_conv64_bf16).
     w_packed: subm_halo_wpack of bf16 [27, 64 (out), 64 (reduction)].  -> out, or (out, stats f64 [tiles, 2, 64], 128) with want_stats."""
     c = inp.shape[1]
-    assert inp.dtype == torch.bfloat16 and c in (64, 128) and tuple(w_packed.shape) == (halo.kvol, c, c) and inp.shape[0] == halo.n_cap
+    assert inp.dtype == torch.bfloat16 and c in (32, 64, 128) and tuple(w_packed.shape) == (halo.kvol, c, c) and inp.shape[0] == halo.n_cap
     assert c == 128 or halo.kvol == 27
     assert c == 64 or bn_epi is None, "the BatchNorm-backward epilogue exists on the 64-channel kernel only"
     out = torch.empty_like(inp)
     stats = torch.empty((halo.tiles, 2, c), dtype=torch.float64, device=inp.device) if want_stats else None
     t = TIMER
     e0 = t.begin() if t is not None else None
-    if c == 64:
+    if c == 32:
+        _check(lib().u3d_subm_halo_conv32_bf16(_ptr(inp), _ptr(w_packed), _ptr(halo.tile_rows), _ptr(halo.loc), _ptr(halo.tile_cnt),
+                                               _ptr(halo.n_dev), halo.n_cap, int(krev), _ptr(addend), _ptr(out), _ptr(stats),
+                                               int(max_slots), _stream()), "subm_halo_conv32_bf16")
+    elif c == 64:
         _check(lib().u3d_subm_halo_conv64_bf16(_ptr(inp), _ptr(w_packed), _ptr(halo.tile_rows), _ptr(halo.loc), _ptr(halo.tile_cnt),
                                                _ptr(halo.n_dev), halo.n_cap, int(krev), _ptr(addend), _ptr(out), _ptr(stats),
                                                None if bn_epi is None else C.byref(bn_epi), int(max_slots), _stream()),

@@ -103,7 +103,7 @@ class ShadowSet:
         # for the halo kernel (csrc/subm_halo.hip), all of them in ONE launch per refresh
         self._halo_plans = []
         # (kvol, channels, layout): the sparse encoder's 64- / 128-channel SubM weights and the dense stack's 128-channel (1,3,3) convs
-        for k, c, lay in ((27, 64, "dhwio"), (27, 128, "dhwio"), (9, 128, "oidhw")):
+        for k, c, lay in ((27, 32, "dhwio"), (27, 64, "dhwio"), (27, 128, "dhwio"), (9, 128, "oidhw")):
             pairs = []
             for p in self.conv_params:
                 kio, koi = p._u3d_conv_shadow[0], p._u3d_conv_shadow[1]

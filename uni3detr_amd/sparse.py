@@ -164,6 +164,10 @@ HALO_128 = os.environ.get("U3D_HALO_128", "1") == "1"         # ... and the 128 
 # step it is on par with the LDS-DMA tiled kernel (19.27 vs 19.23 ms, same-box A/B 3 x 100 steps): on a lattice the tiled kernel's
 # operand rows are consecutive, so its row stream is cheap and the weight stream - the same in both - sets the time.  Off.
 HALO_DENSE = os.environ.get("U3D_HALO_DENSE", "0") == "1"
+# ... and the 32 -> 32 SubM convs of the stride-2 stage (k_subm_halo32): 37.5 -> 28.7 us per launch in isolation, but the level has
+# 340 k rows - its table build (a 65 KB row bitmap per tile) costs more than the eight launches save: 19.42 -> 19.55 ms per step
+# (same-box A/B, 3 x 100 steps).  Parity-tested, off.
+HALO_32 = os.environ.get("U3D_HALO_32", "0") == "1"
 LATTICE_KERNEL = os.environ.get("U3D_LATTICE_KERNEL", "0") == "1"      # 27-offset dense convs on u3d_igemm_lattice_bf16 (measured on par: off)
 STRIDED_DGRAD_SPLIT = os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
 NMAJOR_FWD = os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
@@ -262,7 +266,8 @@ class _SparseConv(torch.autograd.Function):
         nbr = geom.nbr_fwd if kio.shape[0] > 1 else None
         lat = geom.lattice if (LATTICE_KERNEL and nmajor and geom.lattice is not None and geom.lattice[2] == 3) else None
         ctx.halo = (SUBM_HALO and REV_SUBM_TABLE and nmajor and geom.level is not None and kv == 27 and cin == cout
-                    and (cin == 64 or (cin == 128 and HALO_128)) and geom.n_out >= 4096 and geom.level.halo() is not None)
+                    and (cin == 64 or (cin == 128 and HALO_128) or (cin == 32 and HALO_32)) and geom.n_out >= 4096
+                    and geom.level.halo() is not None)
         ctx.halo_tab = geom.level.halo() if ctx.halo else None
         if (not ctx.halo and HALO_DENSE and nmajor and geom.kind == "dense" and not geom.strided and 1 < kv <= 27 and cin == cout == 128
                 and geom.n_in == geom.n_out and geom.n_out >= 4096 and geom.halo() is not None):
