@@ -1,6 +1,7 @@
 """Benchmark of the Uni3DETR training hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W          (N>1: one rank per GPU - started by torch.distributed.run, or, when
+                                                          run bare, by bench.py itself: uni3detr_amd/launch.py)
 
 One "step" = voxelize -> SparseEncoderHD -> SECOND3D/FPN -> 2xFPS -> decoder/head -> device Hungarian -> losses ->
 backward (RCCL gradient all-reduce overlapped) -> grad-clip -> AdamW, over a batch of B=8 synthetic SUN-RGB-D-shaped
@@ -79,6 +80,12 @@ def make_batch(rank, B, npts, dev, index=0, cfg=None):
     return dict(points=pts, img_metas=None, gt_bboxes_3d=gts, gt_labels_3d=labels)
 
 
+def launch_class(tag, meta):
+    """(arithmetic type of the kernel, direction): bf16 LDS-DMA / direct kernels vs the exact-f32 MFMA kernels (parity mode, and the
+    encoder + backbone of `mixed`); forward and input gradient share a kernel, the weight gradient has its own."""
+    return ("bf16" if meta.get("v2") else "f32", "wgrad" if "wgrad" in tag else "fwd")
+
+
 def cpu_baseline(npts, budget_s=25.0):
     """The oracle restatement (pure torch CPU, fp32) timed fwd+bwd on ONE scene on this host's cores ("port").
     Bounded: iterations stop once `budget_s` seconds of CPU work are spent (at least one iteration is always measured)."""
@@ -117,8 +124,27 @@ def cpu_baseline(npts, budget_s=25.0):
                 sample=f"oracle/model.py fwd+bwd, fp32, 1 scene x {npts} pts, {len(use)} timed iteration(s) of {len(times)} ({t:.2f} s/scene)")
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher (ref: extra_tools/dist_train.sh:7-9): start the N ranks ourselves.
+    Under torch.distributed.run (WORLD_SIZE set) this is skipped and the launcher's ranks are used as they are."""
+    from uni3detr_amd.launch import LaunchError, spawn_ranks
+    try:
+        n_dev = torch.cuda.device_count()
+        worst, codes = spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], n_dev)
+    except LaunchError as e:
+        print(f"[bench] {e}", file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    if worst:
+        print(f"[bench] rank exit codes {codes}", file=sys.stderr, flush=True)
+    raise SystemExit(worst)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     wl = WORKLOADS[args.config]
     args.batch = wl["batch"] if args.batch is None else args.batch
     args.points = wl["points"] if args.points is None else args.points
@@ -129,6 +155,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench: rank {rank} wants GPU {local}, the node exposes {torch.cuda.device_count()}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("U3D_FORCE_DDP") == "1"      # the env flag exercises the RCCL path on one GPU
@@ -178,8 +206,13 @@ def main():
             ts.eager_step()
             torch.cuda.synchronize()
             census = nv.TIMER.census
-            top = max(m["flops"] for _, m in census)
-            mark_targets = [i for i, (_, m) in enumerate(census) if m["flops"] == top]
+            # the heaviest launches (by flops) of EVERY kernel class - (bf16 | f32 kernel) x (forward / input gradient | weight gradient):
+            # whichever class turns out to dominate the step's time is then priced from inside the replayed graph
+            mark_targets = []
+            for key in {launch_class(t, m) for t, m in census}:
+                idx = [i for i, (t, m) in enumerate(census) if launch_class(t, m) == key]
+                top = max(census[i][1]["flops"] for i in idx)
+                mark_targets += [i for i in idx if census[i][1]["flops"] == top]
             marker = nv.TIMER = nv.KernelTimer("mark", mark_targets, per_step=len(census))
         try:
             # exact-size steps over every rotating batch -> capacities -> static-shape warm-up -> hipGraphs
@@ -263,18 +296,24 @@ def main():
     if not np.isfinite(loss_val):
         raise SystemExit(f"bench: training diverged (loss = {loss_val}) — a throughput number for a broken step would be meaningless")
 
+    joined = dist.get_world_size() if (use_dist and dist.is_initialized()) else 1          # ranks that actually joined the job
+    if joined != world:
+        raise SystemExit(f"bench: {joined} rank(s) joined the process group, {world} were launched")
     if rank == 0:
         nq_cfg = int(MODEL_CFG["pts_bbox_head"]["num_query"])
-        scenes = world * args.batch * args.steps
+        scenes = joined * args.batch * args.steps
         out = {
             "metric": ("scenes/sec (fwd+bwd) SUN-RGB-D 20k pts, 300 queries" if args.config == "sunrgbd" else
                        f"scenes/sec (fwd+bwd) {args.config} {args.points} pts, {nq_cfg} queries"), "value": scenes / dt, "unit": "scenes/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "n_gpus": joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "fp32": "f32", "mixed": "f32 encoder+backbone / bf16 neck+head"}[args.precision], "data": "synthetic",
             "config": {"workload": f"{wl['file']} (BASELINE {wl['baseline']}): train step fwd+loss+bwd+clip+AdamW, "
                                    f"{args.batch} scenes/GPU x {args.points} pts, {nq_cfg} queries x 3 groups, random-init weights",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss_val,
+                       "global_batch": joined * args.batch, "parallelism": f"dp{joined}", "rccl_ranks": joined if use_dist else 0,
+                       "launcher": ("self (bench.py --gpus N)" if os.environ.get("U3D_SELF_LAUNCHED") == "1" else
+                                    ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process")),
+                       "final_loss": loss_val,
                        "launch_mode": launch_mode if launch_mode != "hipGraph" else (("hipGraph x4 (fwd+match | loss+bwd head/dense [all-reduce A overlaps] | bwd encoder | clip+AdamW)" if ts.overlap else "hipGraph x3 (fwd+match | loss+bwd | clip+AdamW)") + ", static-shape sparse levels"),
                        "sparse_level_capacities": caps, "rotating_batches": len(rot), "recaptures": int(getattr(ts, "recaptures", 0))},
         }
@@ -310,31 +349,35 @@ def main():
                 for i, ms in mark_ms.items():
                     calls[i]["ms_eager"] = calls[i]["ms"]
                     calls[i]["ms"] = ms
-                # the marked launches are the heaviest shape (equal flops) of TWO kernels: k_igemm_glds (forward / input gradient)
-                # and k_igemm_wgrad_glds.  The dominant kernel is the one with more time per step over all of its launches; it is
-                # priced at the AVERAGE duration of its marked launches (the contract's "average launch duration"); the slowest
-                # marked launch of either kernel is reported beside it
-                def klass(x):
-                    return "wgrad" if "wgrad" in x["tag"] else "fwd"
+                # the marked launches are the heaviest shape of every kernel class (launch_class).  The dominant kernel is the class with
+                # the most time per step over ALL of its launches; it is priced at the AVERAGE duration of its marked launches (the
+                # contract's "average launch duration"); the slowest marked launch of that class is reported beside it
                 tot = {}
                 for x in calls:
-                    if x.get("v2"):
-                        tot[klass(x)] = tot.get(klass(x), 0.0) + x["ms"]
+                    k = launch_class(x["tag"], x)
+                    tot[k] = tot.get(k, 0.0) + x["ms"]
                 dom = max(tot, key=tot.get)
-                mine = [i for i in mark_ms if klass(calls[i]) == dom] or list(mark_ms)
+                mine = [i for i in mark_ms if launch_class(calls[i]["tag"], calls[i]) == dom] or list(mark_ms)
                 j = max(mine, key=lambda i: mark_ms[i])
                 dom_mean_ms = float(np.mean([mark_ms[i] for i in mine]))
+                mark_ms = {i: mark_ms[i] for i in mine}
                 timing = (f"hip event-record nodes inside the replayed hipGraph, mean over the {len(mine)} launches of this shape per step "
                           f"x {MARK_REPLAYS} replays")
             else:
-                j = int(np.argmax([x["ms"] for x in calls]))
+                tot = {}
+                for x in calls:
+                    k = launch_class(x["tag"], x)
+                    tot[k] = tot.get(k, 0.0) + x["ms"]
+                dom = max(tot, key=tot.get)
+                cand = [i for i, x in enumerate(calls) if launch_class(x["tag"], x) == dom]
+                j = max(cand, key=lambda i: calls[i]["flops"])
                 dom_mean_ms = None
             h = dict(calls[j])
             slowest_ms = max(mark_ms.values()) if mark_ms else h["ms"]
             if dom_mean_ms is not None:
                 h["ms"] = dom_mean_ms
             ai = h["flops"] / h["bytes"]
-            peak_tf = MFMA_PEAK_TF["bf16" if args.precision == "bf16" else "f32"]
+            peak_tf = MFMA_PEAK_TF["bf16" if h.get("v2") else "f32"]          # the peak of the type THIS kernel computes in
             if ai > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9):
                 ach, peak, unit, bound = h["flops"] / (h["ms"] * 1e-3) / 1e12, peak_tf, "TFLOP/s", "mfma"
             else:
@@ -368,6 +411,7 @@ def main():
                           f"Cin={h['cin']}, Cout={h['cout']}, K={h['kvol']}, pairs={h['pairs']}]",
                 "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_note,
                 "launch_ms": h["ms"], "launch_timing": timing,
+                "kernel_dtype": "bf16" if h.get("v2") else "f32", "time_per_step_by_kernel_class_ms": {f"{a}/{b}": round(v, 4) for (a, b), v in tot.items()},
                 "frac_slowest_marked_launch": (h["flops"] / (slowest_ms * 1e-3) / 1e12 / peak if bound == "mfma" else None),
                 "frac_mean_of_heaviest_launches": (float(np.mean([h["flops"] / (ms * 1e-3) / 1e12 for ms in mark_ms.values()])) / peak if mark_ms else None),
                 "heaviest_launches_ms": ({calls[i]["tag"] + f"#{i}": round(ms, 4) for i, ms in sorted(mark_ms.items())} if mark_ms else None),
@@ -397,6 +441,16 @@ def main():
                     out["roofline"]["decoder_row_kernels_mfma_util"] = rowk
             if dec_src is None:
                 out["roofline"]["decoder_attention_mfma_util"] = None
+            if pmc is not None:
+                # EVERY kernel source the counter pass recorded is checked against the tree: a stale file is named, and nothing
+                # derived from its kernels is quoted above (igemm_bf16.hip -> traffic, decoder*.hip -> attention utilisation)
+                import hashlib
+                stale = []
+                for f, sha in sorted(pmc.get("source_sha16", {}).items()):
+                    fp = os.path.join(ROOT, "uni3detr_amd", "csrc", f)
+                    if not os.path.exists(fp) or hashlib.sha256(open(fp, "rb").read()).hexdigest()[:16] != sha:
+                        stale.append(f)
+                out["roofline"]["pmc_pass"] = {"tag": pmc.get("tag"), "sources_checked": sorted(pmc.get("source_sha16", {})), "stale_sources": stale}
             if os.environ.get("U3D_BENCH_DUMP_CALLS"):
                 json.dump(calls, open(os.environ["U3D_BENCH_DUMP_CALLS"], "w"))
         if not args.no_cpu_baseline and world == 1 and args.config == "sunrgbd":      # the CPU leg is quoted on the headline workload only

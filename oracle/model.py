@@ -202,7 +202,7 @@ def inverse_sigmoid(x, eps=1e-5):
 
 def sine_embed(pos, num_feats=128, temperature=10000):
     """get_sine_pos_embed (uni3detr_transformer.py:33-65): pos [B,N,3] -> [B,N,384]."""
-    dim_t = torch.arange(num_feats, dtype=torch.float32)
+    dim_t = torch.arange(num_feats, dtype=pos.dtype)
     dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_feats)
     res = []
     for i in range(pos.shape[-1]):
@@ -365,21 +365,23 @@ def assign(cls_pred, bbox_pred, gt, labels, cfg):
     return out
 
 
-def loss_single(cls, box, iou_pred, gts, labels, cfg):
+def loss_single(cls, box, iou_pred, gts, labels, cfg, assigned=None):
     """loss_single (uni3detr_head.py:617-698) for one decoder layer; world size 1.
+    assigned: optional [B,Q] matching to use INSTEAD of running the assigner (checker-only knob: gradient parity of a reduced-precision
+    product run is measured under the product's own discrete matching, so that what is compared is backward arithmetic).
     Target width: 7 columns, or 9 when the box code has 10 entries (nuScenes) - the reference's `[..., :7]` slice (:557) cannot
     feed its own 10-column L1 (:684-687), so uni3detr_nuscenes.py does not train as shipped; this follows the commented-out upstream
     `[..., :9]` line above it, with zero velocities for 7-column GT (same choice as the product: plugin/head.py gt_dim)."""
     B, Q, C = cls.shape
     lab_t = torch.full((B * Q,), C, dtype=torch.long)
     gd = 9 if box.shape[-1] >= 10 else 7
-    gts = [F.pad(g[:, :gd], (0, gd - min(gd, g.shape[1]))) for g in gts]
-    tgt = torch.zeros(B * Q, gd)
-    wgt = torch.zeros(B * Q, box.shape[-1])
+    gts = [F.pad(g[:, :gd], (0, gd - min(gd, g.shape[1]))).to(box.dtype) for g in gts]
+    tgt = torch.zeros(B * Q, gd, dtype=box.dtype)
+    wgt = torch.zeros(B * Q, box.shape[-1], dtype=box.dtype)
     npos = 0
-    assigned = []
+    assigned_in, assigned = assigned, []
     for b in range(B):
-        a = assign(cls[b], box[b], gts[b], labels[b], cfg)
+        a = assign(cls[b], box[b], gts[b], labels[b], cfg) if assigned_in is None else assigned_in[b].long()
         assigned.append(a)
         posm = a > 0
         idx = torch.nonzero(posm).squeeze(-1)
@@ -406,7 +408,7 @@ def loss_single(cls, box, iou_pred, gts, labels, cfg):
     l_cls = (F.binary_cross_entropy_with_logits(cls, ts, reduction="none") * fw).sum() / (cls_avg + torch.finfo(torch.float32).eps)
     l_cls = cfg["cls_w"] * l_cls
     npos_c = max(float(npos), 1.0)
-    cw = torch.tensor(cfg["code_weights"])
+    cw = torch.tensor(cfg["code_weights"], dtype=box.dtype)
     wgt = wgt * cw
     eps32 = torch.finfo(torch.float32).eps
     l_box = cfg["bbox_w"] * ((box - ntgt).abs() * wgt).sum() / (npos_c + eps32)
@@ -415,19 +417,19 @@ def loss_single(cls, box, iou_pred, gts, labels, cfg):
     else:
         l_iou = b3d.sum() * wgt.sum()
     l_iou = l_iou + ((1 - iou_z) * wgt[:, 0]).sum() / npos_c
-    iou_true = ob.bbox_overlaps_3d_aligned(b3d.detach(), tgt[:, :7])
+    iou_true = ob.bbox_overlaps_3d_aligned(b3d.detach(), tgt[:, :7]).to(iou_pred.dtype)
     l_ioup = (F.binary_cross_entropy_with_logits(iou_pred.reshape(-1), iou_true, reduction="none") * wgt[:, 0]).sum() / npos_c * 1.2
     return (l_cls, l_box, l_iou, l_ioup), assigned
 
 
-def head_loss(cls_all, box_all, iou_all, gts_bottom, labels, cfg):
+def head_loss(cls_all, box_all, iou_all, gts_bottom, labels, cfg, assigned=None):
     """Uni3DETRHead.loss (uni3detr_head.py:716-793).  gts_bottom: list of [G,7] with bottom-centre z (box `.tensor`);
     converted to gravity centre as :759-761."""
     gts = [torch.cat([g[:, :2], g[:, 2:3] + g[:, 5:6] * 0.5, g[:, 3:]], 1) for g in gts_bottom]
     L = cls_all.shape[0]
-    out, assigned = {}, []
+    assigned_in, out, assigned = assigned, {}, []
     for l in range(L):
-        (lc, lb, li, lp), a = loss_single(cls_all[l], box_all[l], iou_all[l], gts, labels, cfg)
+        (lc, lb, li, lp), a = loss_single(cls_all[l], box_all[l], iou_all[l], gts, labels, cfg, None if assigned_in is None else assigned_in[l])
         pfx = "" if l == L - 1 else f"d{l}."
         out[pfx + "loss_cls"], out[pfx + "loss_bbox"], out[pfx + "loss_iou"], out[pfx + "loss_iou_pred"] = lc, lb, li, lp
         assigned.append(torch.stack(a))
@@ -461,13 +463,18 @@ def forward_logits(sd, points_list, cfg):
     return dict(cls=cls, box=box, iou=iou, fpsbpts=fpsbpts, feats=x)
 
 
-def forward_train(sd, points_list, gts_bottom, labels, cfg):
+def forward_train(sd, points_list, gts_bottom, labels, cfg, assigned=None):
+    """assigned: optional [L,B,Q] matching override (see loss_single).  The arithmetic runs in the dtype of `sd` (float32 as the
+    reference; float64 = the checker's conditioning yardstick, tests/test_grad_parity_gpu.py): voxelization, VFE means and FPS are
+    float32 either way (they define the integer results) and are cast at the boundary."""
     B = len(points_list)
+    dt = sd["pts_bbox_head.tgt_embed.weight"].dtype
     vox, coors, num = og.voxelize_batch(points_list, cfg["voxel_size"], cfg["pc_range"], cfg["max_points"], cfg["max_voxels"][0])
-    feats = torch.from_numpy(og.vfe_mean(vox, num, cfg["num_features"]))
+    feats = torch.from_numpy(og.vfe_mean(vox, num, cfg["num_features"])).to(dt)
     x = sparse_encoder(sd, "pts_middle_encoder.", feats, coors, B, cfg)
     x = second3dfpn(sd, "pts_neck.", second3d(sd, "pts_backbone.", x, cfg), cfg)
-    fpsbpts = fps_queries(points_list, coors, cfg)
+    fpsbpts = fps_queries(points_list, coors, cfg).to(dt)
+    gts_bottom = [g.to(dt) for g in gts_bottom]
     cls, box, iou = head_forward(sd, "pts_bbox_head.", x, fpsbpts, cfg)
-    losses, assigned = head_loss(cls, box, iou, gts_bottom, labels, cfg)
+    losses, assigned = head_loss(cls, box, iou, gts_bottom, labels, cfg, assigned)
     return losses, dict(cls=cls, box=box, iou=iou, fpsbpts=fpsbpts, feats=x, assigned=assigned)

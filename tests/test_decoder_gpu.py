@@ -365,6 +365,42 @@ def test_head_bf16_fused_path_matches_layerwise_path(cuda):
     assert set(res[True][2]) == set(res[False][2])
 
 
+@pytest.mark.parametrize("spread", [1.0, 0.02], ids=["spread", "clustered"])
+def test_packed_bf16_volume_gradient_scatter_vs_f32_accumulator(cuda, spread):
+    """the trilinear scatter of the value-volume gradient accumulates all 3 layers x 3 query groups in ONE bf16 buffer
+    through global_atomic_pk_add_bf16 (fused_decoder.PK_SCATTER).  Every add rounds to 8 mantissa bits, so the error grows with the
+    number of contributions per cell - bounded here against the f32 accumulator (rounded once) with the queries spread over the volume
+    AND with all 600 FPS queries of a scene inside a 2 % cube (hundreds of contributions per cell)."""
+    from uni3detr_amd.plugin import fused_decoder as fdm
+    head = make_head(cuda, 11)
+    for m in head.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "attn_drop"):
+            m.attn_drop = 0.0
+    g = torch.Generator(device="cpu").manual_seed(5)
+    feats = torch.randn(2, 256, 15, 40, 40, generator=g).clamp_min(0).to(cuda).to(memory_format=torch.channels_last_3d)
+    fps = (0.5 + (torch.rand(2, 600, 3, generator=g) - 0.5) * spread).to(cuda)
+    res = {}
+    old = fdm.PK_SCATTER
+    try:
+        for pk in (True, False):
+            fdm.PK_SCATTER = pk
+            f = feats.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                outs = head(f, None, fps)
+            tot = sum((v.float() ** 2).sum() * w for v, w in zip((outs["all_cls_scores"], outs["all_bbox_preds"], outs["all_iou_preds"]), (1.0, 0.1, 1.0)))
+            head.zero_grad(set_to_none=True)
+            tot.backward()
+            res[pk] = f.grad.float()
+    finally:
+        fdm.PK_SCATTER = old
+    e = rel(res[True], res[False])
+    nz = int((res[False].abs().sum(1) > 0).sum())
+    print(f"\n[pk scatter] spread {spread}: rel L2 {e:.4f} vs f32 accumulator, {nz} touched cells")
+    assert e <= 1e-2, e
+
+
 @pytest.mark.parametrize("lid", [0, 2])
 def test_fused_layer_backward_is_deterministic(cuda, lid):
     """Every gradient slot of the fused backward is bitwise reproducible (NaN-poisoned workspaces: a read-before-write would show).

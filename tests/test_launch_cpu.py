@@ -1,0 +1,59 @@
+"""CPU: `bench.py --gpus N` starts its own ranks (uni3detr_amd/launch.py; ref: extra_tools/dist_train.sh:7-9).
+Argument -> rank fan-out, the environment each rank gets, a real 2-rank gloo rendezvous through it, failure propagation, and the
+loud refusal when the node has fewer GPUs than asked for (this container has none: the CLI itself must exit non-zero)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from uni3detr_amd.launch import LaunchError, rank_envs, spawn_ranks
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rank_envs_are_what_a_launcher_exports():
+    envs = rank_envs(4, base_env={"PATH": os.environ.get("PATH", "")}, port=29999)
+    assert [e["RANK"] for e in envs] == ["0", "1", "2", "3"]
+    assert [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2", "3"]
+    assert all(e["WORLD_SIZE"] == "4" and e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29999" for e in envs)
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)
+
+
+def test_refuses_more_ranks_than_gpus():
+    started = []
+    with pytest.raises(LaunchError, match="exposes 1 GPU"):
+        spawn_ranks(2, ["true"], device_count=1, popen=lambda *a, **k: started.append(a))
+    assert not started                                  # nothing was launched
+
+
+WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+dist.init_process_group("gloo")
+t = torch.tensor([float(dist.get_rank() + 1)])
+dist.all_reduce(t)
+open(os.path.join(sys.argv[1], f"rank{dist.get_rank()}.txt"), "w").write(f"{dist.get_world_size()} {os.environ['LOCAL_RANK']} {t.item()}")
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_rendezvous_over_gloo(tmp_path):
+    worst, codes = spawn_ranks(2, [sys.executable, "-c", WORKER, str(tmp_path)], device_count=2, timeout_s=240)
+    assert worst == 0 and codes == [0, 0]
+    for r in range(2):
+        world, local, total = open(tmp_path / f"rank{r}.txt").read().split()
+        assert (world, local, float(total)) == ("2", str(r), 3.0)
+
+
+def test_failing_rank_takes_the_job_down():
+    code = "import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(120)\n"
+    worst, codes = spawn_ranks(2, [sys.executable, "-c", code], device_count=2, timeout_s=60)
+    assert worst != 0 and codes[1] == 7 and codes[0] not in (None, 0)
+
+
+def test_bench_cli_exits_nonzero_without_enough_gpus():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2, (p.returncode, p.stderr[-400:])
+    assert "GPU(s)" in p.stderr and p.stdout.strip() == ""

@@ -78,6 +78,10 @@ def test_head_forward_and_loss_match_reference():
     assert np.array_equal(assigned.numpy().astype(np.int16), z["assigned"])
     for name, val in zip(z["loss_names"], z["loss_values"]):
         assert abs(float(losses[str(name)]) - val) <= 1e-4 * max(1.0, abs(val)), name
+    # the checker-only `assigned=` override (tests/test_grad_parity_gpu.py): fed the reference's own matching it is the identity
+    with torch.no_grad():
+        l2, a2 = om.head_loss(cls, box, iou, gts, labels, cfg, assigned=torch.from_numpy(z["assigned"].astype(np.int64)))
+    assert torch.equal(a2, assigned) and all(float(l2[k]) == float(losses[k]) for k in losses)
     sum(losses.values()).backward()
     np.testing.assert_allclose(feats.grad.reshape(-1)[::997].numpy(), z["feats_grad_sub"], rtol=2e-3, atol=2e-5)
     assert abs(float(feats.grad.abs().sum()) - float(z["feats_grad_abs_sum"])) <= 1e-3 * float(z["feats_grad_abs_sum"])

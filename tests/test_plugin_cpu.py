@@ -180,6 +180,28 @@ def test_checkpoint_round_trip_incl_spconv2_layout(tmp_path, spconv2):
         load_checkpoint(b, dict(state_dict=bad))
 
 
+class _Evil:
+    """An object whose unpickling would run code (what a hostile checkpoint looks like)."""
+    def __reduce__(self):
+        return (os.path.join, ("a", "b"))
+
+
+def test_checkpoint_with_python_objects_needs_explicit_trust(tmp_path, monkeypatch):
+    """The tensors-only unpickler is the default; a file it rejects is loaded with the full (code-executing) unpickler ONLY on an
+    explicit opt-in, and a missing file is an I/O error, not a reason to try the unsafe path."""
+    from uni3detr_amd.checkpoint import load_checkpoint
+    from uni3detr_amd.configs.sunrgbd import model as MODEL_CFG
+    m = build_model(copy.deepcopy(MODEL_CFG))
+    path = str(tmp_path / "evil.pth")
+    torch.save({"meta": {"obj": _Evil()}, "state_dict": {k: v for k, v in m.state_dict().items()}}, path)
+    monkeypatch.delenv("U3D_TRUST_CHECKPOINTS", raising=False)
+    with pytest.raises(RuntimeError, match="trusted=True"):
+        load_checkpoint(m, path)
+    assert load_checkpoint(m, path, trusted=True)["meta"]["obj"] == os.path.join("a", "b")
+    with pytest.raises(FileNotFoundError):
+        load_checkpoint(m, str(tmp_path / "absent.pth"))
+
+
 def test_unselected_registry_names_match_reference_goldens():
     """RDIoULoss / RDIoUCost / SoftFocalLossCost / get_rdiou (no shipped config selects them) against vectors produced by the reference's
     own files (oracle/make_golden.py gen_extra); AxisAlignedIoU3DCost / RotatedIoU3DCost build from the registry."""

@@ -1,0 +1,87 @@
+"""Wall-time attribution of ONE replayed training step from a rocprofv3 kernel trace (kernel_trace.csv).
+
+Per-kernel duration sums (rocprofv3 --stats) double-count overlapped launches (the three SECOND3D branches, the weight-gradient side
+stream, FPS on its own stream) and hide idle gaps.  This walks the step's timeline instead: at every instant the wall time is shared
+equally among the kernels running then, gaps are booked as 'idle'.  Steps are delimited by `k_adamw_flat` (last kernel of a step).
+
+  python tools/timeline.py <kernel_trace.csv> [out.txt]
+"""
+import collections
+import csv
+import sys
+
+
+def short(name):
+    n = name.split("(")[0]
+    if n.startswith("void "):
+        n = n[5:]
+    return n[:90]
+
+
+def main():
+    path = sys.argv[1]
+    out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
+    rows = []
+    for r in csv.DictReader(open(path)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Grid_Size_X", r.get("Grid_Size", "?")),
+                     r.get("Stream_Id", r.get("Queue_Id", "?"))))
+    rows.sort()
+    ends = [i for i, r in enumerate(rows) if r[2].startswith("k_adamw_flat")]
+    if len(ends) < 3:
+        print("fewer than 3 steps in the trace", file=out)
+        return
+    lo, hi = ends[-3] + 1, ends[-1] + 1                      # the last two full steps
+    nsteps = 2
+    seg = rows[lo:hi]
+    t0, t1 = seg[0][0], max(r[1] for r in seg)
+    ev = []
+    for s, e, n, g, q in seg:
+        ev.append((s, 1, n)); ev.append((e, -1, n))
+    ev.sort(key=lambda x: (x[0], x[1]))
+    running = collections.Counter()
+    attributed = collections.Counter()
+    conc = collections.Counter()
+    idle, last = 0, t0
+    for t, d, n in ev:
+        dt = t - last
+        if dt > 0:
+            k = sum(running.values())
+            if k == 0:
+                idle += dt
+            else:
+                for name, c in running.items():
+                    if c:
+                        attributed[name] += dt * c / k
+            conc[min(k, 4)] += dt
+        last = t
+        running[n] += d
+    wall = (t1 - t0) / nsteps
+    cnt = collections.Counter(n for _, _, n, _, _ in seg)
+    raw = collections.Counter()
+    for s, e, n, g, q in seg:
+        raw[n] += e - s
+    print(f"# step wall {wall / 1e6:.3f} ms ({nsteps} steps averaged), {len(seg) // nsteps} launches/step, idle (no kernel running) {idle / nsteps / 1e6:.3f} ms", file=out)
+    print("# time with k kernels running: " + ", ".join(f"k={k}{'+' if k == 4 else ''}: {v / nsteps / 1e6:.3f} ms" for k, v in sorted(conc.items())), file=out)
+    print(f"# {'attributed_ms':>13s} {'raw_sum_ms':>10s} {'launches':>8s}  kernel", file=out)
+    for n, v in attributed.most_common(60):
+        print(f"  {v / nsteps / 1e6:13.4f} {raw[n] / nsteps / 1e6:10.4f} {cnt[n] / nsteps:8.1f}  {n}", file=out)
+    streams = collections.Counter()
+    for s, e, n, g, q in seg:
+        streams[q] += e - s
+    print("# busy time per stream/queue id: " + ", ".join(f"{q}: {v / nsteps / 1e6:.2f} ms" for q, v in streams.most_common()), file=out)
+    # gaps >= 3 us on the timeline: what ran before / after
+    gaps = []
+    cur_end, prev = seg[0][1], seg[0][2]
+    for s, e, n, g, q in seg[1:]:
+        if s - cur_end >= 3000:
+            gaps.append((s - cur_end, prev, n))
+        if e > cur_end:
+            cur_end, prev = e, n
+    gaps.sort(reverse=True)
+    print(f"# {len(gaps)} gaps >= 3 us in {nsteps} steps, total {sum(g for g, _, _ in gaps) / nsteps / 1e6:.3f} ms/step; largest:", file=out)
+    for g, a, b in gaps[:15]:
+        print(f"    {g / 1e3:8.1f} us  after {a}  before {b}", file=out)
+
+
+if __name__ == "__main__":
+    main()

@@ -31,23 +31,28 @@ def convert_spconv_layout(name, t, want_shape):
     return None
 
 
-def _load_file(path, map_location):
-    """Tensors-only unpickling first (a checkpoint from an untrusted source must not run code); checkpoints whose `meta` holds
-    arbitrary python objects (mmcv stores config text / env info: plain strings, but older runners pickled more) fall back to the
-    full unpickler, as the reference's torch.load does."""
+def _load_file(path, map_location, trusted=False):
+    """Tensors-only unpickling (a checkpoint from an untrusted source must not run code).  Checkpoints whose `meta` holds arbitrary
+    python objects (older mmcv runners pickled more than strings) need the full unpickler, which EXECUTES what the file says: that is
+    an explicit opt-in - `trusted=True` or U3D_TRUST_CHECKPOINTS=1 - never a silent fall-back (a malicious pickle fails the restricted
+    unpickler by construction, so a fall-back would always hand it the full one).  I/O errors propagate as they are."""
+    import os
+    import pickle
     try:
         return torch.load(path, map_location=map_location, weights_only=True)
-    except Exception:                                     # noqa: BLE001 - any failure of the restricted unpickler
-        import warnings
-        warnings.warn(f"{path}: not loadable with weights_only=True; falling back to the full unpickler (trusted files only)")
+    except pickle.UnpicklingError as e:
+        if not (trusted or os.environ.get("U3D_TRUST_CHECKPOINTS") == "1"):
+            raise RuntimeError(f"{path}: holds more than tensors and plain containers ({e}); loading it runs the code it contains. If "
+                               f"you trust the file pass trusted=True to load_checkpoint (or set U3D_TRUST_CHECKPOINTS=1)") from e
         return torch.load(path, map_location=map_location, weights_only=False)
 
 
-def load_checkpoint(model, checkpoint, map_location="cpu", strict=False):
+def load_checkpoint(model, checkpoint, map_location="cpu", strict=False, trusted=False):
     """checkpoint: path | dict.  Returns the checkpoint dict (like mmcv).  strict=False is mmcv.runner.load_checkpoint's default (what
     extra_tools/test.py:197 gets): missing / unexpected keys are REPORTED (meta['missing_keys'], meta['unexpected_keys'] and a
-    warning), not raised; shape mismatches always raise."""
-    ck = _load_file(checkpoint, map_location) if isinstance(checkpoint, (str, bytes)) else checkpoint
+    warning), not raised; shape mismatches always raise.  trusted: allow the full (code-executing) unpickler for files the
+    tensors-only one rejects (see _load_file)."""
+    ck = _load_file(checkpoint, map_location, trusted) if isinstance(checkpoint, (str, bytes)) else checkpoint
     sd = ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck
     own = model.state_dict()
     new, converted, bad_shape = collections.OrderedDict(), [], []

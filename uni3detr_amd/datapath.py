@@ -190,6 +190,11 @@ class ObjectRangeFilter:
         lab = batch.get("gt_labels_3d")
         if lab is not None and lab.dtype != torch.int32:
             lab = batch["gt_labels_3d"] = lab.to(torch.int32)
+        if g.shape[0] == 0:
+            # a batch without a single GT box (plausible for KITTI / nuScenes at 2-4 scenes per GPU): nothing to filter, and an empty
+            # tensor has no device pointer to hand to the kernel
+            batch["gt_count"] = torch.zeros(batch["gt_off"].numel() - 1, dtype=torch.int32, device=batch["gt_off"].device)
+            return batch
         batch["gt_count"] = nv.boxes_range_filter(g, lab, batch["gt_off"], self.bev_range)
         return batch
 

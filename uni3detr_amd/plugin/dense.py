@@ -39,6 +39,7 @@ def _norm(cfg, c):
 
 _BRANCH_STREAMS = []
 PARALLEL_BRANCHES = True      # eager mode: run the independent SECOND3D branches on separate streams
+PARALLEL_CAPTURED = os.environ.get("U3D_PARALLEL_CAPTURED", "0") == "1"      # ... and inside a hipGraph capture too (A/B switch)
 
 
 class Lattice:
@@ -187,7 +188,7 @@ class SECOND3D(nn.Module):
         # 48 000 at B=8 -> 94 / 188 workgroups for 256 CUs), so each branch runs on its own stream and the small ones fill the
         # CUs the large one leaves idle; autograd replays the same fork/join in backward; inside a hipGraph capture the
         # event waits become graph edges.
-        if not PARALLEL_BRANCHES or torch.cuda.is_current_stream_capturing():
+        if not PARALLEL_BRANCHES or (torch.cuda.is_current_stream_capturing() and not PARALLEL_CAPTURED):
             # measured: inside the captured step the fork/join costs more than it gains (56.1 vs 54.4 ms) — the 256x256-tile
             # kernels own a CU's LDS, so branches cannot co-reside; streams only pay off against eager-mode launch gaps
             # the branches' input gradients are summed by the first convs' own backward launches (sp.FanoutToken), not by autograd

@@ -464,7 +464,7 @@ class TrainStep:
                 raise RuntimeError(f"sparse level overflow: {c} active rows > capacity {cap}; re-capture with a larger margin")
         return counts
 
-    def capture(self, warmup=3, keep_state=True, batches=None):
+    def capture(self, warmup=3, keep_state=True, batches=None, remember_batches=True):
         """Measure the sparse-level capacities (over `batches`, a list of (points, gts, labels), when given), warm up, capture.
         keep_state: weights, BatchNorm statistics and optimizer state are restored afterwards - the measuring / warm-up iterations
         are real optimizer steps and must not count as training."""
@@ -472,7 +472,7 @@ class TrainStep:
         if self.dist_on:
             raise RuntimeError("capture() with a live process group: hipGraph capture and RCCL do not mix on this stack (see "
                                "enable_dist); use recapture(), which tears the group down through pg_hooks first")
-        if batches is not None:
+        if batches is not None and remember_batches:
             self._capture_batches = batches
         snap = self.snapshot_full() if keep_state else None
         counts, caps = self.measure_capacities(batches)
@@ -552,7 +552,14 @@ class TrainStep:
         import sys
         print(f"[TrainStep] {held} step(s) held by a sparse-level capacity overflow; re-capturing with margin "
               f"{self.capacity_margin:.2f} (re-capture #{self.recaptures})", file=sys.stderr, flush=True)
-        self.capture(batches=self._capture_batches)
+        # the batch the caller has bound (the one that overflowed, or its successor) is (a) measured together with the capture batches -
+        # capacities must cover what actually ran - and (b) put back into the static input buffers afterwards: measure_capacities()
+        # cycles every capture batch through them, and the replay that follows must train on the caller's batch, not on the last of those
+        cur_pts = dict(self.pts, cat=self.pts["cat"].clone(), scene_off=self.pts["scene_off"].clone())
+        cur_gts = dict(self.gts, gt=self.gts["gt"].clone(), labels=self.gts["labels"].clone(), gt_off=self.gts["gt_off"].clone())
+        bound = (cur_pts, cur_gts, None)
+        self.capture(batches=(list(self._capture_batches) + [bound]) if self._capture_batches else [bound], remember_batches=False)
+        self.set_batch(*bound)
         if self.flat_update:
             self.opt_state[11:13].zero_()
         if was_dist:
@@ -572,6 +579,18 @@ class TrainStep:
         self._steps_since_check += 1
         g1, g2, g2b, g3 = self._graphs
         g1.replay()
+        if not self.flat_update:
+            # torch.optim has no device-side hold flag (u3d_adamw_step_hold is the flat path's): without it a level that outgrew its
+            # captured capacity would be truncated and trained on silently, so this configuration pays one host read per step and
+            # re-captures BEFORE the backward / update of the overflowing batch
+            try:
+                self.check_capacities()
+            except RuntimeError:
+                if self.dist_on:
+                    raise                      # a per-rank decision cannot drive a collective re-capture: flat_update=True does that
+                self.recapture()
+                g1, g2, g2b, g3 = self._graphs
+                g1.replay()
         self._reduce_num_pos()
         g2.replay()
         if g2b is not None:
