@@ -307,14 +307,17 @@ def main():
                        f"scenes/sec (fwd+bwd) {args.config} {args.points} pts, {nq_cfg} queries"), "value": scenes / dt, "unit": "scenes/s",
             "n_gpus": joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "fp32": "f32", "mixed": "f32 encoder+backbone / bf16 neck+head"}[args.precision], "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp32": "f32", "mixed": "f32 encoder+backbone (wide convs as split-bf16: 3 bf16 MFMA products, f32 accumulation) / bf16 neck+head"}[args.precision], "data": "synthetic",
             "config": {"workload": f"{wl['file']} (BASELINE {wl['baseline']}): train step fwd+loss+bwd+clip+AdamW, "
                                    f"{args.batch} scenes/GPU x {args.points} pts, {nq_cfg} queries x 3 groups, random-init weights",
                        "global_batch": joined * args.batch, "parallelism": f"dp{joined}", "rccl_ranks": joined if use_dist else 0,
                        "launcher": ("self (bench.py --gpus N)" if os.environ.get("U3D_SELF_LAUNCHED") == "1" else
                                     ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process")),
                        "final_loss": loss_val,
-                       "launch_mode": launch_mode if launch_mode != "hipGraph" else (("hipGraph x4 (fwd+match | loss+bwd head/dense [all-reduce A overlaps] | bwd encoder | clip+AdamW)" if ts.overlap else "hipGraph x3 (fwd+match | loss+bwd | clip+AdamW)") + ", static-shape sparse levels"),
+                       "launch_mode": launch_mode if launch_mode != "hipGraph" else (
+                           ("hipGraph: " + ("voxelize | FPS on a second stream || encoder + dense stack | head + match" if isinstance((ts._graphs or [None])[0], tuple) else "fwd + match")
+                            + (" | loss + bwd head/dense [all-reduce A overlaps] | bwd encoder | clip + AdamW" if ts.overlap else " | loss + bwd | clip + AdamW"))
+                           + ", static-shape sparse levels"),
                        "sparse_level_capacities": caps, "rotating_batches": len(rot), "recaptures": int(getattr(ts, "recaptures", 0))},
         }
         if timer is not None and census:

@@ -165,14 +165,17 @@ int32_t u3d_igemm_fwd_add_bf16(const void* in, const void* w, const int32_t* nbr
  * models/dense_heads/uni3detr_head.py:365-387.)  U3D_ERR_UNSUPPORTED unless K % 64 == 0 and N % 64 == 0. */
 int32_t u3d_linear_bf16(const void* x, const void* w, const float* bias, int32_t relu, void* out, const int32_t* m_dev,
                         int32_t m_cap, int32_t k, int32_t n, u3d_stream s);
-/* Dense-lattice forward / input gradient of a (kd,3,3) "same"-padded stride-1 convolution (SECOND3D / SECOND3DFPN dense blocks, ref:
- * second_3d.py:52-76, second3d_fpn.py:77-100): rows = batch*D*H*W cells in (b,z,y,x) order, channels-last bf16.  No neighbour table:
- * the nine in-plane offsets of a 256-row tile read ONE LDS window of 256 + 2W + 2 rows per (64-channel slice, z-offset).
- * w n-major [kd*9][Cout][Cin]; transposed != 0 computes the input gradient (pass [K][Cin][Cout]).  stats: NULL or f64
- * [ceil(rows/256)][2][Cout] per-tile BatchNorm sums as u3d_igemm_fwd_stats_bf16.  Returns U3D_ERR_UNSUPPORTED unless
- * kd in {1,3}, Cin % 64 == 0, Cout % 256 == 0, W <= 43. */
-int32_t u3d_igemm_lattice_bf16(const void* in, const void* w, void* out, int32_t batch, int32_t D, int32_t H, int32_t W,
-                               int32_t cin, int32_t cout, int32_t kd, int32_t transposed, double* stats, u3d_stream s);
+/* Split-bf16 convolution: f32-grade products on the bf16 matrix pipe, for the modules the reference keeps in fp32 (ref:
+ * models/pts_encoder/sparse_encoder_hd.py:62-64 fp16_enabled=False, models/detectors/uni3detr.py:150-151; SECOND3D is never wrapped in
+ * auto_fp16).  An f32 row matrix x travels as two bf16 planes (u3d_split_rows_f32: hi = bf16(x), lo = bf16(x - hi), stacked as rows
+ * [hi ; lo] with a plane stride of n_cap rows) and x.w ~ hi.wh + hi.wl + lo.wh with f32 accumulation.  The caller passes the three
+ * products as three sets of offsets: nbr int32 [kvol3][ld] = (nbr, nbr, nbr + n_in_cap), w bf16 [kvol3][Cout][Cin] = (wh, wl, wh),
+ * kvol3 = 3 x offsets.  out is F32 [n_out_cap][Cout]; stats: NULL or f64 [ceil(n_out_cap / u3d_igemm_fwd_stats_rows(.., kvol3))][2][Cout]
+ * per-tile BatchNorm sums of the f32 output.  U3D_ERR_UNSUPPORTED unless Cin % 64 == 0 and Cout % 64 == 0. */
+int32_t u3d_igemm_fwd_split_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, float* out, const int32_t* n_out_dev,
+                                 int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol3, double* stats, u3d_stream s);
+/* dst bf16 [2 * n_cap][c]: rows [0, n) = bf16(x), rows [n_cap, n_cap + n) = bf16(x - hi), n = min(*n_dev, n_cap); c % 4 == 0. */
+int32_t u3d_split_rows_f32(const float* x, const int32_t* n_dev, int32_t n_cap, int32_t c, void* dst, u3d_stream s);
 /* Forward with n-major weights w[K][Cout][Cin] (the layout u3d_igemm_fwd_bf16 takes with transpose_w = 1) that also emits the
  * BatchNorm statistics of its (bf16-rounded) output per row tile: stats f64 [ceil(n_out_cap / T)][2][Cout] with
  * T = u3d_igemm_fwd_stats_tile_rows(...) (0: shape not served - use u3d_igemm_fwd_bf16 + u3d_bn_stats).  Feeds
@@ -243,13 +246,6 @@ int32_t u3d_subm_halo_wpack128_batched(const void* const* srcs_dev, void* const*
 int32_t u3d_subm_halo_conv128_bf16(const void* in, const void* w_packed, const int32_t* tile_rows, const uint16_t* loc,
                                    const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, int32_t krev,
                                    const void* addend, void* out, double* stats, int32_t max_slots, int32_t kvol, u3d_stream s);
-/* ... and for 32 -> 32 channels (the stride-2 stage): in/out/addend bf16 [n][32], w_packed = u3d_subm_halo_wpack32 of the n-major bf16
- * weights [27][32][32]; stats f64 [tiles][2][32]. */
-int32_t u3d_subm_halo_wpack32(const void* w_nmajor, void* w_packed, u3d_stream s);
-int32_t u3d_subm_halo_wpack32_batched(const void* const* srcs_dev, void* const* dsts_dev, int32_t n, u3d_stream s);
-int32_t u3d_subm_halo_conv32_bf16(const void* in, const void* w_packed, const int32_t* tile_rows, const uint16_t* loc,
-                                  const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, int32_t krev,
-                                  const void* addend, void* out, double* stats, int32_t max_slots, u3d_stream s);
 /* Weight gradient of the same 64 -> 64 SubM layers from the same tables: dw f32 [27][64][64] (spconv-1.x layout) =
  * sum over rows m of x[nbr_k(m)]^T dy[m]; x / dy bf16 [n][64].  Persistent workgroups, both MFMA operands by transpose reads out of
  * the staged distinct rows / the dy tile, offsets split over four workgroup groups, one f32 partial per workgroup summed in a fixed

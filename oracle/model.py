@@ -471,10 +471,11 @@ def forward_train(sd, points_list, gts_bottom, labels, cfg, assigned=None):
     dt = sd["pts_bbox_head.tgt_embed.weight"].dtype
     vox, coors, num = og.voxelize_batch(points_list, cfg["voxel_size"], cfg["pc_range"], cfg["max_points"], cfg["max_voxels"][0])
     feats = torch.from_numpy(og.vfe_mean(vox, num, cfg["num_features"])).to(dt)
-    x = sparse_encoder(sd, "pts_middle_encoder.", feats, coors, B, cfg)
-    x = second3dfpn(sd, "pts_neck.", second3d(sd, "pts_backbone.", x, cfg), cfg)
+    enc = sparse_encoder(sd, "pts_middle_encoder.", feats, coors, B, cfg)
+    bb = second3d(sd, "pts_backbone.", enc, cfg)
+    x = second3dfpn(sd, "pts_neck.", bb, cfg)
     fpsbpts = fps_queries(points_list, coors, cfg).to(dt)
     gts_bottom = [g.to(dt) for g in gts_bottom]
     cls, box, iou = head_forward(sd, "pts_bbox_head.", x, fpsbpts, cfg)
     losses, assigned = head_loss(cls, box, iou, gts_bottom, labels, cfg, assigned)
-    return losses, dict(cls=cls, box=box, iou=iou, fpsbpts=fpsbpts, feats=x, assigned=assigned)
+    return losses, dict(cls=cls, box=box, iou=iou, fpsbpts=fpsbpts, feats=x, assigned=assigned, encoder=enc, backbone=bb)

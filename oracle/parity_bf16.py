@@ -46,6 +46,17 @@ def bf16_deviation(device, B=2, npts=20000, seed=11, mode="bf16"):
     labels = [torch.from_numpy(s[2]) for s in scenes]
     with torch.no_grad():
         ref_losses, aux = om.forward_train(sd, [p.numpy() for p in pts], gtb, labels, om.sunrgbd_cfg())
+    extra = {}
+    if mode == "mixed":
+        # the modules the reference keeps in fp32 (encoder + backbone), on their own: f32 rows, wide convs as split-bf16 products
+        with torch.no_grad():
+            from uni3detr_amd import sparse as sp
+            v = model.stage_voxelize([p.to(device) for p in pts])
+            with sp.split_scope(True):
+                enc = model.pts_middle_encoder(v["feats"], v["fcoors"], len(v["lens"]))
+                bb = model.pts_backbone(enc)
+            extra = {"encoder_rel_l2": rel_l2(enc, aux["encoder"]), "backbone_rel_l2": max(rel_l2(a, b) for a, b in zip(bb, aux["backbone"])),
+                     "encoder_dtype": str(enc.dtype)}
     with model.shadow_scope():
         feat, fpsb = model.extract_pts_feat([p.to(device) for p in pts])
         amp = model.amp_dtype
@@ -66,4 +77,5 @@ def bf16_deviation(device, B=2, npts=20000, seed=11, mode="bf16"):
         "loss_total_rel": abs(float(sum(losses.values()).detach()) - float(sum(ref_losses.values()))) / abs(float(sum(ref_losses.values()))),
         "workload": f"{B} scenes x {npts} pts, seeded weights, dropout off", "mode": mode,
     }
+    out.update(extra)
     return out

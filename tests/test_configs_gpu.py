@@ -66,7 +66,9 @@ def test_nuscenes_forward_shapes(cuda):
     sc = [_scene(i, 60000, rng_range, 5) for i in range(2)]
     feat, fps = model.extract_pts_feat([s[0].to(cuda) for s in sc])
     assert tuple(feat.shape) == (2, 256, 5, 180, 180) and tuple(fps.shape) == (2, 1800, 3)
-    outs = model.pts_bbox_head(feat.requires_grad_(True), None, fps)
+    with torch.autocast("cuda", dtype=torch.bfloat16):           # as Uni3DETR.forward_pts_train runs the head in this mode
+        outs = model.pts_bbox_head(feat.requires_grad_(True), None, fps)
+    assert model.pts_bbox_head.transformer.decoder._fused_et == torch.bfloat16      # the fused HIP decoder served it (no ATen fallback)
     assert tuple(outs["all_cls_scores"].shape) == (3, 2, 2700, 10) and tuple(outs["all_bbox_preds"].shape) == (3, 2, 2700, 10)
 
 

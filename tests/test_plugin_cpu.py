@@ -121,7 +121,7 @@ def test_hot_kernels_keep_their_register_budget(tmp_path):
     find = lambda sub: [v for k, v in kernels.items() if sub in k]
     assert len(kernels) > 50
     for sub in ("k_igemm_glds_256x256", "k_igemm_glds_128x128", "k_igemm_glds_128x64", "k_igemm_wgrad_glds_256", "k_igemm_wgrad_glds_128",
-                "k_igemm_lattice_256x256"):
+                "k_igemm_glds8_256x256", "k_igemm_glds8_256x256_f32o", "k_igemm_glds8_256x128_f32o"):
         ks = find(sub)
         assert ks, sub
         assert all(k["scratch"] == 0 for k in ks), (sub, ks)

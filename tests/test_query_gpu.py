@@ -171,28 +171,18 @@ def test_classwise_rotated_nms_matches_sequential_oracle(cuda):
 
 
 @pytest.mark.parametrize("m,k,n,relu", [(7200, 256, 256, True), (7200, 384, 256, False), (1800, 256, 512, True), (333, 512, 256, False)])
-def test_fast_linear_matches_torch(cuda, m, k, n, relu):
-    from uni3detr_amd.plugin.transformer import _LinearFn
+def test_linear_bf16_matches_torch(cuda, m, k, n, relu):
+    """u3d_linear_bf16 (out = act(x W^T + b) on the implicit-GEMM kernels; the strided input gradients' per-offset products run on it,
+    sparse._SparseConv.backward) against F.linear on the same bf16-rounded operands."""
     torch.manual_seed(m + k)
     lin = torch.nn.Linear(k, n).to(cuda)
-    x = torch.randn(4, m // 4 if m % 4 == 0 else m, k, device=cuda)[: 4 if m % 4 == 0 else 1].contiguous()
-    xr = x.detach().bfloat16().float().requires_grad_(True)
-    wr = lin.weight.detach().bfloat16().float().requires_grad_(True)
-    ref = torch.nn.functional.linear(xr, wr, lin.bias)
+    x = torch.randn(m, k, device=cuda).bfloat16()
+    w = lin.weight.detach().bfloat16()
+    ref = torch.nn.functional.linear(x.float(), w.float(), lin.bias)
     ref = torch.relu(ref) if relu else ref
-    gy = torch.randn_like(ref).bfloat16().float()
-    ref.backward(gy)
-    xq = x.detach().bfloat16().requires_grad_(True)
-    w2 = lin.weight.detach().clone().requires_grad_(True)
-    b2 = lin.bias.detach().clone().requires_grad_(True)
-    out = _LinearFn.apply(xq, w2, b2, relu)
+    out = nv.linear_bf16(x, w, lin.bias.detach().float(), relu)
     assert out.dtype == torch.bfloat16 and out.shape == ref.shape
-    assert (out.float() - ref.detach()).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
-    out.backward(gy.bfloat16())
-    assert (xq.grad.float() - xr.grad).abs().max().item() <= 3e-2 * max(1.0, xr.grad.abs().max().item())
-    assert (w2.grad - wr.grad).abs().max().item() <= 2e-2 * max(1.0, wr.grad.abs().max().item())
-    exp_b = (gy * ((ref > 0) if relu else 1)).reshape(-1, n).sum(0)
-    assert (b2.grad - exp_b).abs().max().item() <= 2e-2 * m ** 0.5
+    assert (out.float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("n,c,dtype", [(7200, 256, torch.bfloat16), (21600, 10, torch.float32), (333, 1024, torch.bfloat16), (1, 8, torch.float32),

@@ -589,41 +589,6 @@ def test_full_size_dominant_layer_properties(cuda):
     assert lin.abs().max().item() <= 4e-2 * ys.float().abs().max().item()
 
 
-@pytest.mark.parametrize("kd,dims,cin,cout", [(3, (5, 12, 12), 64, 256), (1, (3, 20, 43), 128, 256), (3, (4, 9, 7), 64, 512)])
-def test_lattice_window_kernel_equals_table_kernel(cuda, kd, dims, cin, cout):
-    """u3d_igemm_lattice_bf16 (dense lattice, no neighbour table: nine in-plane offsets from one LDS window, validity masks from the
-    cell coordinates) == the neighbour-table kernel on the same operands, forward and input gradient, bit for bit (same products,
-    same accumulation order per output), incl. lattice borders, scene borders and a last partial tile; statistics = column sums."""
-    torch.manual_seed(kd * 100 + cin)
-    B = 2
-    n = B * dims[0] * dims[1] * dims[2]
-    ks, pad = (kd, 3, 3), (kd // 2, 1, 1)
-    nbr = nv.dense_nbr_table(B, dims, dims, ks, (1, 1, 1), pad, 0, cuda)
-    nbr_b = nv.dense_nbr_table(B, dims, dims, ks, (1, 1, 1), pad, 1, cuda)
-    nd = nv.count_tensor(n, cuda)
-    x = torch.randn(n, cin, device=cuda).bfloat16()
-    dy = torch.randn(n, cout, device=cuda).bfloat16()
-    kio = (torch.randn(kd * 9, cin, cout, device=cuda) * 0.05).bfloat16()
-    koi = kio.transpose(1, 2).contiguous()
-    ref_f = nv.spconv_fwd(x, koi, nbr, nd, n, cout, transpose_w=True, tag="spconv_fwd")
-    got = nv.lattice_conv(x, koi, B, dims, kd, want_stats=True)
-    assert got is not None
-    got_f, stats = got
-    assert torch.equal(got_f, ref_f)
-    assert torch.allclose(stats[:, 0].sum(0).float(), got_f.float().sum(0), rtol=1e-3, atol=1e-2)
-    # input gradient: N = cin must be a multiple of 256 for this kernel, so use the square case only
-    if cout == cin or cin % 256 == 0:
-        ref_d = nv.spconv_fwd(dy, kio, nbr_b, nd, n, cin, transpose_w=True)
-        got_d = nv.lattice_conv(dy, kio, B, dims, kd, transposed=True)
-        assert got_d is not None and torch.equal(got_d, ref_d)
-    else:
-        w2 = (torch.randn(kd * 9, cout, cout, device=cuda) * 0.05).bfloat16()          # square weights for the transposed pass
-        ref_d = nv.spconv_fwd(dy, w2, nbr_b, nd, n, cout, transpose_w=True)
-        got_d = nv.lattice_conv(dy, w2, B, dims, kd, transposed=True)
-        assert got_d is not None and torch.equal(got_d, ref_d)
-    assert nv.lattice_conv(x[:, :32].contiguous(), koi[:, :, :32].contiguous(), B, dims, kd) is None     # Cin % 64 != 0: not served
-
-
 def test_subm_transposed_table_is_the_reversed_forward_table(cuda):
     """native.RevNbr: the input gradient of a SubM layer reads the forward table with the 27 offsets reversed instead of building
     the transposed table (sparse.Level.subm_tables).  Pinned here against the table the builder produces in transposed mode, on a
@@ -1142,86 +1107,61 @@ def test_subm_halo_128_channel_kernel(cuda, seed, n_pts, dims, cut):
     assert (y[:n].float() - ref).abs().max() / sc < 8e-3
 
 
-@pytest.mark.parametrize("seed,n_pts,dims,cut", [(5, 9000, (16, 40, 36), 0), (11, 60000, (12, 64, 64), 777)])
-def test_subm_halo_32_channel_kernel(cuda, seed, n_pts, dims, cut):
-    """k_subm_halo32 (32 -> 32 SubM convs: the 64-channel scheme at half the width, four workgroups per CU):
-    forward + per-tile statistics, input gradient (offsets reversed) with addend, the global-memory fall-back for rows past the staged
-    slots (max_slots hook), a device-side row count below the capacity with NaN in the dead rows; against the f32 gather-matmul and the
-    LDS-DMA tiled kernel."""
-    import torch
-    from uni3detr_amd import native as nv
-    lvl, nbr = _level(seed=seed, n_pts=n_pts, dims=dims)
-    n_cap = lvl.n
-    n = n_cap - cut
-    cnt = nv.count_tensor(n, "cuda") if cut else lvl.n_dev
-    nb = nbr.clone()
-    if cut:
-        nb[:, :n][nb[:, :n] >= n] = -1
-    halo = nv.SubmHalo(nb, cnt, n_cap)
-    torch.manual_seed(seed)
-    x = torch.randn(n_cap, 32, device="cuda").bfloat16()
-    add = torch.randn(n_cap, 32, device="cuda").bfloat16()
-    if cut:
-        x[n:] = float("nan"); add[n:] = float("nan")
-    w = (torch.randn(27, 32, 32, device="cuda") * 0.15).bfloat16()             # n-major [K][out][reduction]
-    wp = nv.subm_halo_wpack(w)
-    y, stats, tr = nv.subm_halo_conv(x, wp, halo, want_stats=True)
-    exp = _ref_conv(x[:n], w.transpose(1, 2), nb, n)
-    sc = exp.abs().max()
-    assert torch.isfinite(y[:n]).all() and (y[:n].float() - exp).abs().max() / sc < 6e-3
-    assert tr == 128 and stats.shape == (halo.tiles, 2, 32)
-    yf = y[:n].double()
-    assert (stats[:, 0].sum(0) - yf.sum(0)).abs().max() < 1e-3 * yf.abs().sum(0).max()
-    assert (stats[:, 1].sum(0) - (yf * yf).sum(0)).abs().max() < 1e-4 * (yf * yf).sum(0).max()
-    assert torch.equal(nv.subm_halo_conv(x, wp, halo)[:n], y[:n])
-    for ms in (150, 40):
-        assert torch.equal(nv.subm_halo_conv(x, wp, halo, max_slots=ms)[:n], y[:n]), ms
-    g = nv.subm_halo_conv(x, wp, halo, krev=True, addend=add)
-    expg = _ref_conv(x[:n], w.transpose(1, 2), nb.flip(0), n) + add[:n].float()
-    assert (g[:n].float() - expg).abs().max() / expg.abs().max() < 6e-3
-    ref = nv.spconv_fwd(x, w, nb, cnt, n_cap, 32, transpose_w=True)[:n].float()
-    assert (y[:n].float() - ref).abs().max() / sc < 8e-3
+# ---------------------------------------------------------------------------------------------------------------------------
+# split-bf16 convolutions (`mixed` precision: the reference keeps SparseEncoderHD + SECOND3D in fp32, sparse_encoder_hd.py:62-64):
+# f32 rows in and out, three bf16 MFMA products per product on the LDS-DMA kernels (u3d_igemm_fwd_split_bf16, sparse.split_scope)
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_split_rows_is_an_exact_two_term_expansion(cuda):
+    torch.manual_seed(1)
+    x = (torch.randn(1000, 64, device=cuda) * torch.logspace(-6, 6, 64, device=cuda)).contiguous()
+    n_dev = torch.tensor([777], dtype=torch.int32, device=cuda)
+    p = nv.split_rows(x, n_dev)
+    hi, lo = p[:777].float(), p[1000:1777].float()
+    assert torch.equal(p[:777], x[:777].to(torch.bfloat16))
+    assert torch.equal(p[1000:1777], (x[:777] - hi).to(torch.bfloat16))
+    rel = ((hi + lo) - x[:777]).abs() / x[:777].abs().clamp_min(1e-30)
+    assert float(rel.max()) <= 2.0 ** -16          # two bf16 terms carry 16 mantissa bits
 
 
-def test_halo_kernel_on_the_dense_stacks_128_channel_convs(cuda):
-    """The stride-1 (1,3,3) 128 -> 128 convs of SECOND3D's first branch run the 128-channel halo kernel on the lattice's STATIC tables
-    (9 offsets): forward + statistics against the table kernel, and the input gradient through the reversed forward table against
-    the lattice's own transposed table - which it must equal entry for entry."""
-    import torch
-    from uni3detr_amd import native as nv, sparse as sp
-    from uni3detr_amd.plugin.dense import Lattice
-    B, dims = 2, (5, 24, 20)
-    geom, dims_out = Lattice.conv(torch.device("cuda"), B, dims, (1, 3, 3), (1, 1, 1), (0, 1, 1))
-    n = geom.n_out
-    assert dims_out == dims and geom.n_in == n and not geom.strided
-    assert torch.equal(geom.nbr_bwd[:, :n], geom.nbr_fwd.flip(0)[:, :n])        # transposed table == forward table reversed
-    halo = geom.halo()
-    assert halo is not None and halo.kvol == 9
-    torch.manual_seed(0)
-    x = torch.randn(n, 128, device="cuda").bfloat16()
-    w = (torch.randn(9, 128, 128, device="cuda") * 0.1).bfloat16()               # n-major [K][out][reduction]
-    wp = nv.subm_halo_wpack(w)
-    y, stats, tr = nv.subm_halo_conv(x, wp, halo, want_stats=True)
-    ref, rstats, rtr = nv.spconv_fwd_stats(x, w, geom.nbr_fwd, geom.n_out_dev, n, 128)
-    sc = ref.float().abs().max()
-    assert (y.float() - ref.float()).abs().max() / sc < 8e-3
-    assert (stats[:, 0].sum(0) - rstats[:, 0].sum(0)).abs().max() < 2e-2 * rstats[:, 0].sum(0).abs().max() + 1.0
-    g = nv.subm_halo_conv(x, wp, halo, krev=True)
-    gref = nv.spconv_fwd(x, w, geom.nbr_bwd, geom.n_in_dev, n, 128, transpose_w=True)
-    assert (g.float() - gref.float()).abs().max() / gref.float().abs().max() < 8e-3
-    # and through the autograd wrapper: same result and gradients as the table path
-    res = {}
-    w5 = (torch.randn(128, 128, 1, 3, 3, device="cuda") * 0.05)
-    dy = torch.randn(n, 128, device="cuda").bfloat16()
-    for on in (True, False):
-        sp.HALO_DENSE = on
-        try:
-            xi = x.clone().requires_grad_(True)
-            wi = w5.clone().requires_grad_(True)
-            yy, st = sp._SparseConv.apply(xi, wi, geom, "oidhw", True)
-            yy.backward(dy)
-            res[on] = (yy.detach().float(), xi.grad.float(), wi.grad.float())
-        finally:
-            sp.HALO_DENSE = False
-    for a, b, tol in zip(res[True], res[False], (8e-3, 8e-3, 1e-5)):
-        assert (a - b).abs().max() / b.abs().max() < tol
+@pytest.mark.parametrize("cin,cout,kvol,wide_rows", [(64, 64, 27, False), (64, 128, 27, False), (128, 128, 27, False), (128, 256, 1, False),
+                                                     (256, 256, 27, True)])
+def test_split_bf16_conv_forward_backward_match_f32_oracle(cuda, cin, cout, kvol, wide_rows):
+    """_SparseConv inside sparse.split_scope(): forward, input gradient and weight gradient against oracle/geometry.py's f32 conv at
+    5e-5 of the result's scale (bf16 kernels on bf16-rounded operands sit at 1e-2: this is f32-grade), incl. the fused BatchNorm
+    statistics of the f32 output; wide_rows: enough rows for the 256 x 256 eight-phase kernel's f32-output instantiation."""
+    from uni3detr_amd import sparse as sp
+    torch.manual_seed(cin + cout + kvol)
+    B = 3 if wide_rows else 2
+    rc = _level0(cuda, B, 18000 if wide_rows else 2500)          # 3 x 16 000 voxels: 188 row tiles of 256
+    dims = (128, 320, 320)
+    coors = torch.from_numpy(rc).to(cuda)
+    lvl, rank = sp.level_from_coors(coors, B, dims)
+    n = lvl.n
+    if kvol == 27:
+        geom = sp.subm_geom(lvl)
+        ref_nbr = geom.nbr_fwd.cpu().numpy()[:, :n].astype(np.int64)
+        wshape = (3, 3, 3, cin, cout)
+    else:
+        geom = sp.ConvGeom(None, None, n, lvl.n_dev, n, lvl.n_dev)
+        ref_nbr = np.arange(n, dtype=np.int64)[None]
+        wshape = (1, 1, 1, cin, cout)
+    x = torch.randn(n, cin)
+    w = torch.randn(*wshape) * (1.0 / np.sqrt(cin * min(kvol, 9)))
+    gy = torch.randn(n, cout)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = og.sparse_conv(xr, wr.view(kvol, cin, cout), ref_nbr)
+    yr.backward(gy)
+    xd, wd = x.to(cuda).requires_grad_(True), torch.nn.Parameter(w.to(cuda))
+    with sp.split_scope(True):
+        y, stats = sp._SparseConv.apply(xd, wd, geom, "dhwio", True, None, None)
+    assert y.dtype == torch.float32 and stats.numel() > 0            # the split kernels served it, statistics included
+    y.backward(gy.to(cuda))
+    tol = 5e-5
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() <= tol * yr.abs().max().item()
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() <= tol * xr.grad.abs().max().item()
+    assert (wd.grad.cpu() - wr.grad).abs().max().item() <= tol * wr.grad.abs().max().item()
+    tr = stats._u3d_tile_rows
+    s = stats.sum(0).cpu()
+    np.testing.assert_allclose(s[0].numpy(), y.detach().double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4 * float(y.abs().max()) * n ** 0.5)
+    np.testing.assert_allclose(s[1].numpy(), (y.detach().double() ** 2).sum(0).cpu().numpy(), rtol=1e-5)
+    assert stats.shape[0] == (n + tr - 1) // tr

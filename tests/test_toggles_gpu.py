@@ -22,22 +22,18 @@ TOGGLES = [
     ("uni3detr_amd.sparse", "SUBM_HALO", False),
     ("uni3detr_amd.sparse", "HALO_WGRAD", False),
     ("uni3detr_amd.sparse", "HALO_128", False),
-    ("uni3detr_amd.sparse", "HALO_32", True),
-    ("uni3detr_amd.sparse", "HALO_DENSE", True),
     ("uni3detr_amd.sparse", "REV_SUBM_TABLE", False),
     ("uni3detr_amd.sparse", "STRIDED_DGRAD_SPLIT", False),
-    ("uni3detr_amd.sparse", "IM2COL_STRIDED", True),
     ("uni3detr_amd.sparse", "NMAJOR_FWD", False),
     ("uni3detr_amd.sparse", "FUSED_CONV_STATS", False),
     ("uni3detr_amd.sparse", "BN_GRAD_FUSION", True),
     ("uni3detr_amd.sparse", "WGRAD_SIDE", True),
-    ("uni3detr_amd.sparse", "LATTICE_KERNEL", True),
     ("uni3detr_amd.plugin.sparse_encoder", "RESIDUAL_FUSION", False),
     ("uni3detr_amd.plugin.dense", "FANOUT_FUSION", False),
     ("uni3detr_amd.plugin.dense", "FUSED_UPSAMPLE_ORDER", False),
     ("uni3detr_amd.plugin.dense", "FUSED_LEVEL_SUM", False),
     ("uni3detr_amd.plugin.fused_decoder", "ENABLED", False),
-    ("uni3detr_amd.plugin.fused_decoder", "PK_SCATTER", False),
+    ("uni3detr_amd.plugin.fused_decoder", "PK_SCATTER", True),
     ("uni3detr_amd.plugin.head", "FUSED_BOX_DECODE", False),
     ("uni3detr_amd.plugin.head", "FUSED_DET_LOSS", False),
     ("uni3detr_amd.plugin.transformer", "FUSED_LN", False),
@@ -45,7 +41,6 @@ TOGGLES = [
     ("uni3detr_amd.plugin.transformer", "SHARED_VALUE_GRAD", False),
     ("uni3detr_amd.plugin.transformer", "OWN_WGRAD", False),
     ("uni3detr_amd.plugin.transformer", "RELU_EPILOGUE", False),
-    ("uni3detr_amd.plugin.transformer", "FAST_LINEAR", True),
     ("uni3detr_amd.plugin.transformer", "SKINNY_WGRAD", True),
     ("uni3detr_amd.native", "PERMUTE_TILED", False),
 ]

@@ -495,7 +495,7 @@ static int launch_igemm_fwd(const void* in, const void* w, const int32_t* nbr, i
 #endif
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool F32OUT = false>
 __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
                                                 int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
                                                 int cin, int cout, int kvol, const float* __restrict__ bias, int relu,
@@ -781,6 +781,7 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
 #ifndef GLDS8_STAGGER
 #define GLDS8_STAGGER 1     /* 0 (experiment): both wave rows in the same segment at the same time */
 #endif
+template <bool F32OUT = false>
 __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
                                                  int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
                                                  int cin, int cout, int kvol, const float* __restrict__ bias, int relu,
@@ -996,6 +997,11 @@ __global__ __launch_bounds__(512) void k_igemm_glds8_256x256(const u16* in, cons
                                                              const float* bias, int relu, double* stats, BnEpi bn) {
   igemm_glds8_body(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats, bn);
 }
+__global__ __launch_bounds__(512) void k_igemm_glds8_256x256_f32o(const u16* in, const u16* w, const int* nbr, int ld, u16* out,
+                                                                  const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,
+                                                                  const float* bias, int relu, double* stats, BnEpi bn) {
+  igemm_glds8_body<true>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats, bn);
+}
 
 // =============================================================================================
 // 256 x 128 tile on the same idea, for LONG reductions with 128-column output tiles (the 12 000-row 512-channel layers: 72 k-tiles per
@@ -1013,6 +1019,7 @@ __global__ __launch_bounds__(512) void k_igemm_glds8_256x256(const u16* in, cons
 #ifndef IGEMM_GLDS8N
 #define IGEMM_GLDS8N 1
 #endif
+template <bool F32OUT = false>
 __device__ __forceinline__ void igemm_glds8n_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
                                                   int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
                                                   int cin, int cout, int kvol, const float* __restrict__ bias, int relu,
@@ -1209,6 +1216,11 @@ __global__ __launch_bounds__(512) void k_igemm_glds8_256x128(const u16* in, cons
                                                              const float* bias, int relu, double* stats, BnEpi bn) {
   igemm_glds8n_body(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats, bn);
 }
+__global__ __launch_bounds__(512) void k_igemm_glds8_256x128_f32o(const u16* in, const u16* w, const int* nbr, int ld, u16* out,
+                                                                  const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,
+                                                                  const float* bias, int relu, double* stats, BnEpi bn) {
+  igemm_glds8n_body<true>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats, bn);
+}
 // the 256 x 128 eight-phase kernel for the shapes it is dispatched on: long reductions (>= GLDS8N_MIN_KTILES k-tiles), enough
 // workgroups to keep most CUs busy with ONE per CU
 #ifndef GLDS8N_MIN_KTILES
@@ -1220,11 +1232,12 @@ static bool igemm_glds8n_shape(const int32_t* nbr, int n_out_cap, int cin, int c
 }
 static int launch_igemm_glds8n(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev,
                                int n_out_cap, int cin, int cout, int kvol, hipStream_t s, const float* bias = nullptr, int relu = 0,
-                               double* stats = nullptr, const BnEpi bn = BnEpi{}) {
+                               double* stats = nullptr, const BnEpi bn = BnEpi{}, bool f32o = false) {
   constexpr size_t lds = 3 * (size_t)(256 + 128) * 64 * 2;      // 144 KiB
   U3D_ALLOW_LDS(k_igemm_glds8_256x128, lds);
+  U3D_ALLOW_LDS(k_igemm_glds8_256x128_f32o, lds);
   dim3 grid(u3d_cdiv(n_out_cap, 256), cout / 128);
-  hipLaunchKernelGGL(k_igemm_glds8_256x128, grid, dim3(512), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap,
+  hipLaunchKernelGGL(f32o ? k_igemm_glds8_256x128_f32o : k_igemm_glds8_256x128, grid, dim3(512), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap,
                      cin, cout, kvol, bias, relu, stats, bn);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
 }
@@ -1244,192 +1257,36 @@ U3D_GLDS_KERNEL(k_igemm_glds_256x128, 4, 2, 4, 4)
 U3D_GLDS_KERNEL(k_igemm_glds_128x64, 4, 1, 2, 4)
 U3D_GLDS_KERNEL(k_igemm_glds_128x128, 2, 2, 4, 4)      /* 4 waves, 64 KiB LDS: two workgroups per CU run out of phase */
 #undef U3D_GLDS_KERNEL
+// f32-output instantiations of the two small tiles (split-bf16 products, u3d_igemm_fwd_split_bf16)
+#define U3D_GLDS_KERNEL_F32O(NAME, A, B, C, D)                                                                                   \
+  __global__ __launch_bounds__(A* B * 64) void NAME(const u16* in, const u16* w, const int* nbr, int ld, u16* out,               \
+                                                    const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,            \
+                                                    const float* bias, int relu, double* stats, BnEpi bn) {                      \
+    igemm_glds_body<A, B, C, D, true>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats, bn);         \
+  }
+U3D_GLDS_KERNEL_F32O(k_igemm_glds_128x64_f32o, 4, 1, 2, 4)
+U3D_GLDS_KERNEL_F32O(k_igemm_glds_128x128_f32o, 2, 2, 4, 4)
+#undef U3D_GLDS_KERNEL_F32O
 typedef void (*glds_kernel_t)(const u16*, const u16*, const int*, int, u16*, const int*, int, int, int, int, const float*, int, double*, BnEpi);
 
 template <int WAVES_M, int WAVES_N, int WM, int WN>
 static int launch_igemm_glds(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev,
                              int n_out_cap, int cin, int cout, int kvol, hipStream_t s, const float* bias = nullptr, int relu = 0,
-                             double* stats = nullptr, const BnEpi bn = BnEpi{}) {
+                             double* stats = nullptr, const BnEpi bn = BnEpi{}, bool f32o = false) {
   constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
   constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;        // 256 x 256: 128 KiB
   glds_kernel_t kern = (BM == 256 && BN == 256) ? ((IGEMM_GLDS8 && nbr) ? k_igemm_glds8_256x256 : k_igemm_glds_256x256)
                        : (BM == 256 ? k_igemm_glds_256x128 : (BN == 128 ? k_igemm_glds_128x128 : k_igemm_glds_128x64));
+  if (f32o) {      // f32-output instantiations exist for the shapes u3d_igemm_fwd_split_bf16 dispatches: 256 x 256 (eight-phase), 128 x 128, 128 x 64
+    if (BM == 256 && BN == 256 && IGEMM_GLDS8 && nbr) kern = k_igemm_glds8_256x256_f32o;
+    else if (BM == 128 && BN == 128) kern = k_igemm_glds_128x128_f32o;
+    else if (BM == 128 && BN == 64) kern = k_igemm_glds_128x64_f32o;
+    else return U3D_ERR_UNSUPPORTED;
+  }
   if (lds > 64 * 1024) U3D_ALLOW_LDS(kern, lds);      // one call site per template instantiation: per-kernel, per-device
   dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin,
                      cout, kvol, bias, relu, stats, bn);
-  return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
-}
-
-// =============================================================================================
-// Dense-lattice forward / dgrad: 3x3 in-plane kernels on a full [B, D, H, W] lattice (SECOND3D / FPN), stride 1, "same" padding.
-// k_igemm_glds re-loads the 256-row activation tile for every offset: 27 x 32 KiB per 64-channel slice, and the LDS-DMA stream is
-// what that kernel pays for (1150 -> 1550 TF/s without it).  On a lattice the nine in-plane neighbours of rows
-// m0..m0+255 are rows of ONE window [m0 - W - 1, m0 + 255 + W + 1] of the same z-plane: the window (256 + 2W + 2 rows) is loaded once
-// per (channel slice, z-offset) and all nine offsets read their fragments from it at shifted rows; rows whose neighbour falls off
-// the lattice get a zero fragment (27-bit validity mask per row, computed from the cell coordinates).  LDS-DMA bytes per slice:
-// 27 x 32 (weights) + 3 x 43 (windows) = 993 KiB instead of 27 x 64 = 1728 KiB.
-// Same tile / wave layout, weight tiles, swizzle and epilogue as k_igemm_glds_256x256 (8 waves as 2 x 4, 128 x 64 per wave).
-// =============================================================================================
-struct LatGeom { int D, H, W, kd, sign; };     // kd: kernel extent in z (1 or 3); sign +1 forward (gather at +offset), -1 dgrad (transposed table)
-#define LAT_WIN_ROWS 344                        /* 256 + 2*W + 2 rows rounded up to 8, W <= 43 */
-
-template <int WAVES_M, int WAVES_N, int WM, int WN>
-__device__ __forceinline__ void igemm_lattice_body(const u16* __restrict__ in, const u16* __restrict__ w, u16* __restrict__ out,
-                                                   int n_rows, int cin, int cout, LatGeom lg, const float* __restrict__ bias, int relu,
-                                                   double* __restrict__ stats) {
-  const BnEpi bn{};                              // (no BatchNorm-backward epilogue on this kernel: GLDS_EPI_ADDEND 0)
-  constexpr int NW = WAVES_M * WAVES_N;
-  constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16, BK = 64;
-  constexpr int WIN_ELEMS = LAT_WIN_ROWS * BK, W_ELEMS = BN * BK;
-  constexpr int WIN_SEGS = LAT_WIN_ROWS / 8;                       // wave-instructions (8 rows x 128 B) per window
-  constexpr int WIN_PER_WAVE = (WIN_SEGS + NW - 1) / NW;
-  constexpr int SEGS_W = BN / 8 / NW;
-  static_assert(BM == 256 && WIN_PER_WAVE <= 9, "window loads ride on the nine in-plane stages");
-  extern __shared__ __attribute__((aligned(16))) u16 smem[];      // [2 windows][2 weight tiles]
-  u16* const win_base = smem;
-  u16* const wt_base = smem + 2 * WIN_ELEMS;
-
-  const int n_out = n_rows;
-  const int ntile = gridDim.x;
-  const int xq = ntile >> 3, xr = ntile & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
-  const int m0 = tile * BM;
-  if (m0 >= n_out) return;
-  const int col0 = blockIdx.y * BN;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
-  const int kchunks = cin / BK;
-  const int HW = lg.H * lg.W, pz = lg.kd / 2;
-  const int ngroup = kchunks * lg.kd;                             // (channel slice, z-offset) pairs, nine stages each
-  const int nstage = ngroup * 9;
-
-  f32x4 acc[WM][WN];
-#pragma unroll
-  for (int a = 0; a < WM; ++a)
-#pragma unroll
-    for (int b = 0; b < WN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, -1, 0x00020000);
-  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, -1, 0x00020000);
-  const unsigned row_bytes = (unsigned)cin * 2u;
-  const int lrow = lane >> 3, lslot = lane & 7;
-  unsigned w_voff[SEGS_W];
-#pragma unroll
-  for (int u = 0; u < SEGS_W; ++u) {
-    const int r = (wv * SEGS_W + u) * 8 + lrow;
-    const int part = lslot ^ ((r >> 1) & 7);
-    w_voff[u] = (col0 + r < cout) ? (unsigned)((col0 + r) * cin + part * 8) * 2u : 0xFFFFFFFFu;
-  }
-  // one window instruction: window rows seg*8 .. seg*8+7 of group `grp` (channel slice grp / kd, z-offset grp % kd)
-  auto issue_win = [&](int grp, int j) {
-    const int seg = wv + j * NW;
-    if (seg >= WIN_SEGS) return;
-    const int c0 = (grp / lg.kd) * BK, dz = grp % lg.kd - pz;
-    const int wr = seg * 8 + lrow;                                                     // window row
-    const long long row = (long long)m0 + (long long)lg.sign * dz * HW - lg.W - 1 + wr;   // lattice row it holds
-    const int part = lslot ^ ((wr >> 1) & 7);
-    const unsigned voff = (row >= 0 && row < n_out) ? (unsigned)row * row_bytes + (unsigned)part * 16u : 0xFFFFFFFFu;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void_ptr)(win_base + (grp & 1) * WIN_ELEMS + seg * 512), 16, voff, (unsigned)c0 * 2u, 0, 0);
-  };
-  auto issue_w = [&](int st, int u) {
-    const int grp = st / 9, t9 = st - grp * 9;
-    const int c0 = (grp / lg.kd) * BK, kap = (grp % lg.kd) * 9 + t9;
-    u16* Wb = wt_base + (st & 1) * W_ELEMS + wv * (SEGS_W * 512);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_ptr)(Wb + u * 512), 16, w_voff[u], (unsigned)(kap * cin * cout + c0) * 2u, 0, 0);
-  };
-  // validity of the 27 (z, y, x) offsets for this lane's rows (one row per 16-row block a)
-  const int g = lane >> 4, li = lane & 15;
-  unsigned vmask[WM];
-#pragma unroll
-  for (int a = 0; a < WM; ++a) {
-    const int m = m0 + (wm * WM + a) * 16 + li;
-    unsigned bits = 0u;
-    if (m < n_out) {
-      const int x = m % lg.W, t = m / lg.W, y = t % lg.H, z = (t / lg.H) % lg.D;
-      for (int kz = 0; kz < lg.kd; ++kz) {
-        const int zz = z + lg.sign * (kz - pz);
-        for (int ky = 0; ky < 3; ++ky) {
-          const int yy = y + lg.sign * (ky - 1);
-          for (int kx = 0; kx < 3; ++kx) {
-            const int xx = x + lg.sign * (kx - 1);
-            const bool ok = (unsigned)zz < (unsigned)lg.D && (unsigned)yy < (unsigned)lg.H && (unsigned)xx < (unsigned)lg.W;
-            bits |= (ok ? 1u : 0u) << (kz * 9 + ky * 3 + kx);
-          }
-        }
-      }
-    }
-    vmask[a] = bits;
-  }
-  typedef const volatile s16x8 __attribute__((address_space(3))) * lds_vptr;
-  const bf16x8 zero8 = __builtin_bit_cast(bf16x8, (s16x8){0, 0, 0, 0, 0, 0, 0, 0});
-
-  // prologue: window of group 0, weight tile of stage 0
-#pragma unroll
-  for (int j = 0; j < WIN_PER_WAVE; ++j) issue_win(0, j);
-#pragma unroll
-  for (int u = 0; u < SEGS_W; ++u) issue_w(0, u);
-  __syncthreads();
-  for (int st = 0; st < nstage; ++st) {
-    const int grp = st / 9, t9 = st - grp * 9;
-    const int kap = (grp % lg.kd) * 9 + t9;
-    const int nx = st + 1 < nstage ? st + 1 : st;                 // the last stage re-fetches its own weight tile: branch-free body
-    // this offset's fragment rows inside the window: row (m - m0) + W + 1 + sign * ((ky-1) * W + (kx-1))
-    const int shift = lg.W + 1 + lg.sign * ((t9 / 3 - 1) * lg.W + (t9 % 3 - 1));
-    const int r0 = (wm * WM) * 16 + li + shift;
-    const int fsw = (r0 >> 1) & 7;                                // identical for every 16-row block a (a*16 >> 1 is a multiple of 8)
-    const u16* A = win_base + (grp & 1) * WIN_ELEMS + r0 * BK;
-    const u16* Wt = wt_base + (st & 1) * W_ELEMS + (wn * WN * 16 + li) * BK;
-    const int wsw = (lane >> 1) & 7;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int fa = ((ks * 4 + g) ^ fsw) << 3, fw = ((ks * 4 + g) ^ wsw) << 3;
-      bf16x8 af[WM];
-#pragma unroll
-      for (int a = 0; a < WM; ++a) {
-        const s16x8 v = *(lds_vptr)(A + a * 16 * BK + fa);
-        af[a] = ((vmask[a] >> kap) & 1u) ? __builtin_bit_cast(bf16x8, v) : zero8;
-      }
-#pragma unroll
-      for (int b = 0; b < WN; ++b) {
-        const s16x8 wv8 = *(lds_vptr)(Wt + b * 16 * BK + fw);
-        const bf16x8 bfr = __builtin_bit_cast(bf16x8, wv8);
-#pragma unroll
-        for (int a = 0; a < WM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af[a], acc[a][b], 0, 0, 0);
-        if (ks == 0) {                                            // next stage's weight tile (+ a slice of the next window) behind the MFMA groups
-          if (b < SEGS_W) issue_w(nx, b);
-          if (b == WN - 1 && grp + 1 < ngroup && t9 < WIN_PER_WAVE) issue_win(grp + 1, t9);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    __syncthreads();
-  }
-#define GLDS_EPI_ADDEND 0
-#include "glds_epilogue.inc"
-#undef GLDS_EPI_ADDEND
-}
-
-__global__ __launch_bounds__(512) void k_igemm_lattice_256x256(const u16* in, const u16* w, u16* out, int n_rows, int cin, int cout, LatGeom lg,
-                                                               const float* bias, int relu, double* stats) {
-  igemm_lattice_body<2, 4, 8, 4>(in, w, out, n_rows, cin, cout, lg, bias, relu, stats);
-}
-
-// rows = batch * D * H * W lattice cells in (b, z, y, x) order; w n-major [kd*9][Cout][Cin]; transposed != 0: the input gradient
-// (offsets negated; pass the [K][Cin][Cout] weight, i.e. n-major for that product).  stats as u3d_igemm_fwd_stats_bf16 (256-row tiles).
-extern "C" int32_t u3d_igemm_lattice_bf16(const void* in, const void* w, void* out, int32_t batch, int32_t D, int32_t H, int32_t W,
-                                          int32_t cin, int32_t cout, int32_t kd, int32_t transposed, double* stats, u3d_stream s) {
-  U3D_REQUIRE(in && w && out && batch > 0 && D > 0 && H > 0 && W > 0, U3D_ERR_ARG);
-  if ((kd != 1 && kd != 3) || cin % 64 != 0 || cout % 256 != 0 || 256 + 2 * W + 2 > LAT_WIN_ROWS) return U3D_ERR_UNSUPPORTED;
-  const long long n = (long long)batch * D * H * W;
-  if (n >= 0x7fffffffll / (cin > cout ? cin : cout) / 2) return U3D_ERR_UNSUPPORTED;      // 32-bit buffer offsets
-  LatGeom lg = {D, H, W, kd, transposed ? -1 : 1};
-  constexpr size_t lds = (2 * (size_t)LAT_WIN_ROWS * 64 + 2 * (size_t)256 * 64) * 2;      // 150.5 KiB
-  U3D_ALLOW_LDS(k_igemm_lattice_256x256, lds);
-  dim3 grid(u3d_cdiv((int)n, 256), cout / 256);
-  hipLaunchKernelGGL(k_igemm_lattice_256x256, grid, dim3(512), lds, s, (const u16*)in, (const u16*)w, (u16*)out, (int)n, cin, cout, lg,
-                     (const float*)nullptr, 0, stats);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
 }
 
@@ -1501,6 +1358,51 @@ extern "C" int32_t u3d_igemm_fwd_stats_bf16(const void* in, const void* w, const
     return launch_igemm_glds8n(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);
   if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);
   return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, s, nullptr, 0, stats);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 convolution: f32-grade products on the bf16 matrix pipe (the reference keeps SparseEncoderHD and SECOND3D in fp32 - ref:
+// sparse_encoder_hd.py:62-64, uni3detr.py:150-151 - and the exact f32 MFMA runs at 1/16 of the bf16 rate).  An f32 tensor x is held
+// as two bf16 planes, hi = bf16(x) and lo = bf16(x - hi) (16 mantissa bits together), and x.w ~ hi.wh + hi.wl + lo.wh with f32
+// accumulation (the dropped lo.wl term is 2^-16 of a 2^-8 term).  The kernels are the LDS-DMA implicit-GEMM kernels above, UNCHANGED:
+// the three products are three sets of "offsets" - the caller stacks the planes as rows [hi ; lo] of one matrix, triples the
+// neighbour table (nbr, nbr, nbr + plane stride) and the weights (wh, wl, wh) - and this entry only picks the f32-output instantiations.
+//   in   bf16 [2 * n_in_cap][cin] (u3d_split_rows_f32), w bf16 [kvol3][cout][cin] (n-major, kvol3 = 3 * offsets), nbr int32 [kvol3][ld],
+//   out  f32 [n_out_cap][cout]; stats (optional) f64 [ceil(n_out_cap / u3d_igemm_fwd_stats_rows(.., kvol3))][2][cout] of the f32 output
+extern "C" int32_t u3d_igemm_fwd_split_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, float* out,
+                                            const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol3,
+                                            double* stats, u3d_stream s) {
+  U3D_REQUIRE(in && w && out && n_out_dev && nbr && kvol3 > 0, U3D_ERR_ARG);
+  if (!IGEMM_GLDS || cin % 64 != 0 || cout % 64 != 0) return U3D_ERR_UNSUPPORTED;
+  if (n_out_cap <= 0) return U3D_OK;
+  const int tr = u3d_igemm_fwd_stats_tile_rows(n_out_cap, cin, cout);
+  if (tr == 256) return launch_igemm_glds<GLDS256_CFG>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol3, s, nullptr, 0, stats, BnEpi{}, true);
+  if (igemm_glds8n_shape(nbr, n_out_cap, cin, cout, kvol3))
+    return launch_igemm_glds8n(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol3, s, nullptr, 0, stats, BnEpi{}, true);
+  if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol3, s, nullptr, 0, stats, BnEpi{}, true);
+  return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol3, s, nullptr, 0, stats, BnEpi{}, true);
+}
+
+// hi / lo bf16 planes of an f32 row matrix: dst[r] = bf16(x[r]), dst[n_cap + r] = bf16(x[r] - dst[r]) (round to nearest even both)
+__global__ __launch_bounds__(256) void k_split_rows_f32(const float* __restrict__ x, const int* __restrict__ n_dev, int n_cap, int c,
+                                                        u16* __restrict__ dst) {
+  const long long n = (long long)min(*n_dev, n_cap) * c / 4, plane = (long long)n_cap * c;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const f32x4 v = *(const f32x4*)(x + i * 4);
+    const bf16x4 h = __builtin_convertvector(v, bf16x4);
+    const bf16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4);
+    *(bf16x4*)(dst + i * 4) = h;
+    *(bf16x4*)(dst + plane + i * 4) = l;
+  }
+}
+extern "C" int32_t u3d_split_rows_f32(const float* x, const int32_t* n_dev, int32_t n_cap, int32_t c, void* dst, u3d_stream s) {
+  U3D_REQUIRE(x && n_dev && dst && c > 0 && c % 4 == 0, U3D_ERR_ARG);
+  if (n_cap <= 0) return U3D_OK;
+  const long long n4 = (long long)n_cap * c / 4;
+  const int blocks = (int)(n4 / 256 + 1 < 4096 ? n4 / 256 + 1 : 4096);
+  hipLaunchKernelGGL(k_split_rows_f32, dim3(blocks), dim3(256), 0, s, x, n_dev, n_cap, c, (u16*)dst);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
 }
 
 // returns U3D_ERR_UNSUPPORTED when the shape is better served by the first-generation kernel

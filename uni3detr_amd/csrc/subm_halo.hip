@@ -579,179 +579,6 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo128(const u16* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// 32 -> 32 channels (the stride-2 stage's SparseBasicBlocks, ~340 k rows): k_subm_halo64's scheme at half the width
-// ---------------------------------------------------------------------------------------------------------------------------
-// 64-byte rows, 80 B LDS row stride (consecutive slots on distinct 4-bank groups), two 16-column blocks, ONE MFMA k-step: a wave's
-// offset costs 8 ds_read_b128 and 16 MFMAs, the accumulators are 64 registers, the stage buffer 33 KB - four workgroups per CU hide
-// each other's staging latency, which is what this level is made of (its direct-operand kernel issues one 64-byte gather per (row,
-// offset) through the L1 return path: 38 us against ~10 us of HBM time for the 80 MB a launch moves).
-#define H3_C 32
-#define H3_RS 40                 /* LDS row stride in elements (80 B) */
-#define H3_MAXS 416              /* 33 KB: >= the 32 KB of the first reduce-scatter round */
-__global__ __launch_bounds__(256) void k_halo_wpack32(const u16* __restrict__ src, u16* __restrict__ dst, const u16* const* __restrict__ srcs,
-                                                      u16* const* __restrict__ dsts) {
-  if (srcs) { src = srcs[blockIdx.y]; dst = dsts[blockIdx.y]; }
-  const int c = blockIdx.x * 256 + threadIdx.x;   // 16 B chunk of dst: [27][nt 2][lane 64]
-  if (c >= HL_K * 128) return;
-  const int lane = c & 63, nt = (c >> 6) & 1, k = c >> 7;
-  *(u32x4*)(dst + (long long)c * 8) = *(const u32x4*)(src + k * 1024 + (nt * 16 + (lane & 15)) * 32 + (lane >> 4) * 8);
-}
-
-__global__ __launch_bounds__(256, 4) void k_subm_halo32(const u16* __restrict__ in, const u16* __restrict__ wgt,
-                                                        const int32_t* __restrict__ tile_rows, const u16* __restrict__ loc,
-                                                        const int32_t* __restrict__ tile_cnt, const int32_t* __restrict__ n_dev, int n_cap,
-                                                        int krev, const u16* __restrict__ addend, u16* __restrict__ out,
-                                                        double* __restrict__ stats, int maxs) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u16* xs = (u16*)smem;                           // [H3_MAXS][H3_RS]
-  const int tid = threadIdx.x;
-  const int tq = gridDim.x >> 3, trem = gridDim.x & 7, xcd = blockIdx.x & 7;      // XCD-contiguous tile ranges (k_subm_halo64)
-  const int tile = (xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq) + (blockIdx.x >> 3);
-  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r16 = lane & 15, kq = lane >> 4;
-  const int m0 = tile * HL_T;
-  const int n = min(*n_dev, n_cap);
-  if (m0 >= n) {
-    if (stats && tid < 2 * H3_C) stats[(long long)tile * 2 * H3_C + tid] = 0.0;
-    return;
-  }
-  const int32_t* rows_p = tile_rows + (long long)tile * HL_TRC;
-  const int cnt = tile_cnt[tile];
-  const int nl = min(cnt, maxs);
-  {                                               // stage the distinct rows: 4 lanes x 16 B per row, every load of a thread in flight
-    const int part = tid & 3, sb = tid >> 2;
-    for (int base = 0; base < nl; base += 448) {
-      int idx[7];
-      u32x4 v[7];
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int slot = base + sb + 64 * i;
-        idx[i] = (slot > 0 && slot < nl) ? rows_p[slot] : -1;
-      }
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        v[i] = (u32x4){0u, 0u, 0u, 0u};
-        if (idx[i] >= 0) v[i] = *(const u32x4*)(in + (long long)idx[i] * H3_C + part * 8);
-      }
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int slot = base + sb + 64 * i;
-        if (slot < nl) *(u32x4*)(xs + slot * H3_RS + part * 8) = v[i];
-      }
-    }
-  }
-  __syncthreads();
-
-  f32x4 acc[8][2];
-#pragma unroll
-  for (int a = 0; a < 8; ++a) { acc[a][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  const u16* locp = loc + (long long)tile * HL_K * HL_T + r16 * 8;
-  const u16* wl = wgt + lane * 8;                 // fragment-packed (k_halo_wpack32): chunk (k * 2 + nt) * 64 + lane
-  const u16* xl = xs + kq * 8;
-  u16x8 sl = *(const u16x8*)(locp + (krev ? 26 - w : w) * HL_T);
-  bf16x8 wf[2];
-  wf[0] = *(const bf16x8*)(wl + (w * 2 + 0) * 512);
-  wf[1] = *(const bf16x8*)(wl + (w * 2 + 1) * 512);
-#define H3_LOADX(FAST, s, x0)                                                                           \
-  if (FAST || (s) < nl) x0 = *(const bf16x8*)(xl + (s) * H3_RS);                                        \
-  else x0 = *(const bf16x8*)(in + (long long)rows_p[s] * H3_C + kq * 8);
-#define H3_OFFSET_LOOP(FAST)                                                                            \
-  for (int k = w; k < HL_K; k += 4) {                                                                   \
-    const int kn = k + 4 < HL_K ? k + 4 : k;                                                            \
-    const u16x8 sln = *(const u16x8*)(locp + (krev ? 26 - kn : kn) * HL_T);                             \
-    bf16x8 wn[2];                                                                                       \
-    wn[0] = *(const bf16x8*)(wl + (kn * 2 + 0) * 512);                                                  \
-    wn[1] = *(const bf16x8*)(wl + (kn * 2 + 1) * 512);                                                  \
-    bf16x8 x[8];                                                                                        \
-    _Pragma("unroll") for (int a = 0; a < 8; ++a) { H3_LOADX(FAST, (int)sl[a], x[a]) }                   \
-    _Pragma("unroll") for (int a = 0; a < 8; ++a) {                                                      \
-      acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], x[a], acc[a][0], 0, 0, 0);             \
-      acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], x[a], acc[a][1], 0, 0, 0);             \
-    }                                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
-    sl = sln; wf[0] = wn[0]; wf[1] = wn[1];                                                             \
-  }
-  if (cnt <= maxs) { H3_OFFSET_LOOP(1) } else { H3_OFFSET_LOOP(0) }
-#undef H3_LOADX
-#undef H3_OFFSET_LOOP
-
-  // sum the four waves' partial tiles: reduce-scatter in two rounds through the stage buffer (as k_subm_halo64)
-  f32x4* xb = (f32x4*)smem;
-  const bool h = w & 1, q = (w >> 1) & 1;
-  __syncthreads();                                // all waves are done reading the staged rows
-  f32x4 r4[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      xb[(w * 8 + i * 2 + b) * 64 + lane] = hl_sel(h, acc[i][b], acc[4 + i][b]);
-      r4[i][b] = hl_sel(h, acc[4 + i][b], acc[i][b]);
-    }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) r4[i][b] += xb[((w ^ 1) * 8 + i * 2 + b) * 64 + lane];
-  __syncthreads();
-  f32x4 fin[2][2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      xb[(w * 4 + j * 2 + b) * 64 + lane] = hl_sel(q, r4[j][b], r4[2 + j][b]);
-      fin[j][b] = hl_sel(q, r4[2 + j][b], r4[j][b]);
-    }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) fin[j][b] += xb[((w ^ 2) * 4 + j * 2 + b) * 64 + lane];
-
-  // epilogue: this wave owns row blocks mt = 4 h + 2 q + j, both column blocks
-  f32x4 cs[2], cq[2];
-#pragma unroll
-  for (int b = 0; b < 2; ++b) { cs[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; cq[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = m0 + (4 * (int)h + 2 * (int)q + j) * 16 + r16;
-    if (m >= n) continue;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int col = b * 16 + 4 * kq;
-      f32x4 v = fin[j][b];
-      if (addend) v += __builtin_convertvector(*(const bf16x4*)(addend + (long long)m * H3_C + col), f32x4);
-      const bf16x4 o = __builtin_convertvector(v, bf16x4);
-      *(bf16x4*)(out + (long long)m * H3_C + col) = o;
-      const f32x4 vr = __builtin_convertvector(o, f32x4);
-      cs[b] += vr;
-      cq[b] += vr * vr;
-    }
-  }
-  if (stats) {
-    __syncthreads();
-    float* red = (float*)smem;                    // [4 waves][2][32]
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float s1 = hl_row_sum(cs[b][r]), s2 = hl_row_sum(cq[b][r]);
-        if (r16 == 0) {
-          red[(w * 2 + 0) * H3_C + b * 16 + 4 * kq + r] = s1;
-          red[(w * 2 + 1) * H3_C + b * 16 + 4 * kq + r] = s2;
-        }
-      }
-    __syncthreads();
-    if (tid < 2 * H3_C) {
-      const int which = tid >> 5, cl = tid & 31;
-      double a = 0.0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) a += (double)red[(k * 2 + which) * H3_C + cl];
-      stats[((long long)tile * 2 + which) * H3_C + cl] = a;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
 // weight gradient:  dW[k][ci][co] = sum over rows m of  x[nbr_k(m)][ci] * dy[m][co]
 // ---------------------------------------------------------------------------------------------------------------------------
 // The tiled kernel (k_igemm_wgrad_glds_64, 118 us) gathers 27 x 128 row pieces per tile through LDS-DMA like the forward did.  Here
@@ -1068,28 +895,3 @@ extern "C" int32_t u3d_subm_halo_conv128_bf16(const void* in, const void* w_pack
   return U3D_OK;
 }
 
-extern "C" int32_t u3d_subm_halo_wpack32(const void* w_nmajor, void* w_packed, u3d_stream s) {
-  U3D_REQUIRE(w_nmajor && w_packed, U3D_ERR_ARG);
-  k_halo_wpack32<<<u3d_cdiv(HL_K * 128, 256), 256, 0, (hipStream_t)s>>>((const u16*)w_nmajor, (u16*)w_packed, nullptr, nullptr);
-  U3D_CHECK_LAUNCH();
-  return U3D_OK;
-}
-extern "C" int32_t u3d_subm_halo_wpack32_batched(const void* const* srcs_dev, void* const* dsts_dev, int32_t n, u3d_stream s) {
-  U3D_REQUIRE(srcs_dev && dsts_dev && n >= 0, U3D_ERR_ARG);
-  if (n == 0) return U3D_OK;
-  k_halo_wpack32<<<dim3(u3d_cdiv(HL_K * 128, 256), n), 256, 0, (hipStream_t)s>>>(nullptr, nullptr, (const u16* const*)srcs_dev, (u16* const*)dsts_dev);
-  U3D_CHECK_LAUNCH();
-  return U3D_OK;
-}
-extern "C" int32_t u3d_subm_halo_conv32_bf16(const void* in, const void* w_packed, const int32_t* tile_rows, const uint16_t* loc,
-                                             const int32_t* tile_cnt, const int32_t* n_dev, int32_t n_cap, int32_t krev,
-                                             const void* addend, void* out, double* stats, int32_t max_slots, u3d_stream s) {
-  U3D_REQUIRE(in && w_packed && tile_rows && loc && tile_cnt && n_dev && out && n_cap > 0, U3D_ERR_ARG);
-  const int lds = H3_MAXS * H3_RS * 2;
-  static_assert(H3_MAXS * H3_RS * 2 >= 4 * 8 * 64 * 16, "stage buffer holds the first reduce-scatter round");
-  k_subm_halo32<<<u3d_cdiv(n_cap, HL_T), 256, lds, (hipStream_t)s>>>((const u16*)in, (const u16*)w_packed, tile_rows, loc, tile_cnt, n_dev, n_cap,
-                                                                    krev, (const u16*)addend, (u16*)out, stats,
-                                                                    (max_slots > 0 && max_slots < H3_MAXS) ? max_slots : H3_MAXS);
-  U3D_CHECK_LAUNCH();
-  return U3D_OK;
-}

@@ -106,13 +106,12 @@ _SIGS = {
     "u3d_bn_finalize_partials": (_I, [_P, _I, _I, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     "u3d_igemm_fwd_stats_tile_rows": (_I, [_I, _I, _I]),
     "u3d_igemm_fwd_stats_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "u3d_igemm_fwd_split_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "u3d_split_rows_f32": (_I, [_P, _P, _I, _I, _P, _P]),
     "u3d_igemm_dgrad_bnstats_bf16": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "u3d_bn_bwd_finalize_partials": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P]),
     "u3d_subm_halo_sizes": (_I, [_I, _P, _P, _P]),
     "u3d_subm_halo_build": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P]),
-    "u3d_subm_halo_wpack32": (_I, [_P, _P, _P]),
-    "u3d_subm_halo_wpack32_batched": (_I, [_P, _P, _I, _P]),
-    "u3d_subm_halo_conv32_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
     "u3d_subm_halo_wpack128": (_I, [_P, _P, _I, _P]),
     "u3d_subm_halo_wpack128_batched": (_I, [_P, _P, _I, _I, _P]),
     "u3d_subm_halo_conv128_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
@@ -121,7 +120,6 @@ _SIGS = {
     "u3d_subm_halo_wpack": (_I, [_P, _P, _P]),
     "u3d_subm_halo_wpack_batched": (_I, [_P, _P, _I, _P]),
     "u3d_subm_halo_conv64_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P]),
-    "u3d_igemm_lattice_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "u3d_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     "u3d_bn_bwd_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P]),
     "u3d_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
@@ -557,11 +555,9 @@ def subm_halo_wpack(w_nmajor, out=None):
     """bf16 [27, 64 (out), 64 (reduction)] -> the MFMA fragment order u3d_subm_halo_conv64_bf16 reads (same shape and size)."""
     k, c = w_nmajor.shape[0], w_nmajor.shape[1]
     assert w_nmajor.dtype == torch.bfloat16 and w_nmajor.is_contiguous() and w_nmajor.shape[2] == c
-    assert (k == 27 and c in (32, 64)) or (1 <= k <= 27 and c == 128)
+    assert (k == 27 and c == 64) or (1 <= k <= 27 and c == 128)
     out = torch.empty_like(w_nmajor) if out is None else out
-    if c == 32:
-        _check(lib().u3d_subm_halo_wpack32(_ptr(w_nmajor), _ptr(out), _stream()), "subm_halo_wpack32")
-    elif c == 64:
+    if c == 64:
         _check(lib().u3d_subm_halo_wpack(_ptr(w_nmajor), _ptr(out), _stream()), "subm_halo_wpack")
     else:
         _check(lib().u3d_subm_halo_wpack128(_ptr(w_nmajor), _ptr(out), k, _stream()), "subm_halo_wpack128")
@@ -572,16 +568,14 @@ def subm_halo_wpack_plan(pairs, device):
     """[(src, dst)] of [27, C, C] bf16 tensors, all with the same C in (64, 128) -> plan for subm_halo_wpack_batched (device pointer
     arrays; the tensors must stay alive)."""
     k, c = pairs[0][0].shape[0], pairs[0][0].shape[1]
-    assert all(tuple(a.shape) == (k, c, c) for a, _ in pairs) and ((k == 27 and c in (32, 64)) or c == 128)
+    assert all(tuple(a.shape) == (k, c, c) for a, _ in pairs) and ((k == 27 and c == 64) or c == 128)
     src = torch.tensor([a.data_ptr() for a, _ in pairs], dtype=torch.int64, device=device)
     dst = torch.tensor([b.data_ptr() for _, b in pairs], dtype=torch.int64, device=device)
     return src, dst, len(pairs), pairs, c, k
 
 
 def subm_halo_wpack_batched(plan):
-    if plan[4] == 32:
-        _check(lib().u3d_subm_halo_wpack32_batched(_ptr(plan[0]), _ptr(plan[1]), plan[2], _stream()), "subm_halo_wpack32_batched")
-    elif plan[4] == 64:
+    if plan[4] == 64:
         _check(lib().u3d_subm_halo_wpack_batched(_ptr(plan[0]), _ptr(plan[1]), plan[2], _stream()), "subm_halo_wpack_batched")
     else:
         _check(lib().u3d_subm_halo_wpack128_batched(_ptr(plan[0]), _ptr(plan[1]), plan[2], plan[5], _stream()), "subm_halo_wpack128_batched")
@@ -591,18 +585,14 @@ def subm_halo_conv(inp, w_packed, halo, krev=False, addend=None, want_stats=Fals
     """64 -> 64 channel, 27-offset SubM conv out of the tile's staged distinct rows (u3d_subm_halo_conv64_bf16).
     w_packed: subm_halo_wpack of bf16 [27, 64 (out), 64 (reduction)].  -> out, or (out, stats f64 [tiles, 2, 64], 128) with want_stats."""
     c = inp.shape[1]
-    assert inp.dtype == torch.bfloat16 and c in (32, 64, 128) and tuple(w_packed.shape) == (halo.kvol, c, c) and inp.shape[0] == halo.n_cap
+    assert inp.dtype == torch.bfloat16 and c in (64, 128) and tuple(w_packed.shape) == (halo.kvol, c, c) and inp.shape[0] == halo.n_cap
     assert c == 128 or halo.kvol == 27
     assert c == 64 or bn_epi is None, "the BatchNorm-backward epilogue exists on the 64-channel kernel only"
     out = torch.empty_like(inp)
     stats = torch.empty((halo.tiles, 2, c), dtype=torch.float64, device=inp.device) if want_stats else None
     t = TIMER
     e0 = t.begin() if t is not None else None
-    if c == 32:
-        _check(lib().u3d_subm_halo_conv32_bf16(_ptr(inp), _ptr(w_packed), _ptr(halo.tile_rows), _ptr(halo.loc), _ptr(halo.tile_cnt),
-                                               _ptr(halo.n_dev), halo.n_cap, int(krev), _ptr(addend), _ptr(out), _ptr(stats),
-                                               int(max_slots), _stream()), "subm_halo_conv32_bf16")
-    elif c == 64:
+    if c == 64:
         _check(lib().u3d_subm_halo_conv64_bf16(_ptr(inp), _ptr(w_packed), _ptr(halo.tile_rows), _ptr(halo.loc), _ptr(halo.tile_cnt),
                                                _ptr(halo.n_dev), halo.n_cap, int(krev), _ptr(addend), _ptr(out), _ptr(stats),
                                                None if bn_epi is None else C.byref(bn_epi), int(max_slots), _stream()),
@@ -694,6 +684,42 @@ def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False, tag=None,
     if addend is not None:
         out += addend
     return out
+
+
+def split_rows(x, n_dev, n_cap=None):
+    """f32 [n_cap, c] -> bf16 [2 * n_cap, c]: hi plane = bf16(x), lo plane = bf16(x - hi) (u3d_split_rows_f32).  Rows past the
+    device-side count stay unwritten - the tables never name them."""
+    n_cap = x.shape[0] if n_cap is None else n_cap
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty((2 * n_cap, x.shape[1]), dtype=torch.bfloat16, device=x.device)
+    _check(lib().u3d_split_rows_f32(_ptr(x), _ptr(n_dev), n_cap, x.shape[1], _ptr(out), _stream()), "split_rows_f32")
+    return out
+
+
+def spconv_fwd_split(xs, w3, nbr3, n_out_dev, n_out, cout, want_stats=False, tag="spconv_fwd"):
+    """Split-bf16 product (u3d_igemm_fwd_split_bf16): xs bf16 [2 * n_in, cin] planes, w3 bf16 [3K, cout, cin] = (wh, wl, wh), nbr3 int32
+    [3K, ld] = (nbr, nbr, nbr + n_in) -> f32 [n_out, cout] (+ per-tile BatchNorm sums f64 [tiles, 2, cout], rows per tile)."""
+    kvol3, cin = w3.shape[0], xs.shape[1]
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=xs.device)
+    stats, tr = None, 0
+    if want_stats:
+        tr = int(lib().u3d_igemm_fwd_stats_rows(n_out, cin, cout, kvol3))
+        if tr:
+            stats = torch.empty(((n_out + tr - 1) // tr, 2, cout), dtype=torch.float64, device=xs.device)
+    t = TIMER
+    e0 = t.begin() if t is not None else None
+    _check(lib().u3d_igemm_fwd_split_bf16(_ptr(xs), _ptr(w3), _ptr(nbr3), nbr3.shape[1], _ptr(out), _ptr(n_out_dev), n_out, cin, cout, kvol3,
+                                          _ptr(stats), _stream()), "igemm_fwd_split_bf16")
+    if t is not None:
+        meta = None
+        if t.mode == "census":
+            k = kvol3 // 3
+            pairs = int((nbr3[:k, :n_out] >= 0).sum().item())
+            # priced as the f32 convolution it stands for: f32 rows in and out, f32 weights, 2 * pairs * cin * cout flops (the kernel issues 3x)
+            meta = dict(kind=CALL_KIND, v2=True, split=True, n_in=xs.shape[0] // 2, n_out=n_out, cin=cin, cout=cout, kvol=k, pairs=pairs,
+                        bytes=(xs.shape[0] // 2) * cin * 4 + n_out * cout * 4 + 8 * pairs + k * cin * cout * 4, flops=2 * pairs * cin * cout)
+        t.end(tag, e0, meta)
+    return (out, stats, tr) if want_stats else out
 
 
 def spconv_wgrad(inp, dout, nbr, n_out_dev, kvol, out_oik=False, out=None):
@@ -1221,23 +1247,6 @@ def box_decode_bwd(tmp, ref, dout, pc_range, eps=1e-5, want_dref=False):
     _check(lib().u3d_box_decode_bwd(_ptr(tmp), dtype_code(tmp), _ptr(ref), _ptr(dout), n, code, _pc_range6(pc_range), C.c_float(eps),
                                     _ptr(dtmp), _ptr(dref), _stream()), "box_decode_bwd")
     return dtmp, dref
-
-
-def lattice_conv(inp, w_nmajor, batch, dims, kd, transposed=False, want_stats=False):
-    """(kd,3,3) same-padded stride-1 conv on a dense [batch, D, H, W] lattice without a neighbour table (u3d_igemm_lattice_bf16).
-    inp [rows, Cin] bf16, w_nmajor [kd*9, N, K] (forward: [K, Cout, Cin]; transposed: [K, Cin, Cout]).  -> out [rows, N]
-    (+ stats f64 [tiles, 2, N] with 256-row tiles) or None when the shape is not served."""
-    n, cin = inp.shape
-    cout = w_nmajor.shape[1]
-    D, H, W = dims
-    out = torch.empty((n, cout), dtype=inp.dtype, device=inp.device)
-    stats = torch.empty(((n + 255) // 256, 2, cout), dtype=torch.float64, device=inp.device) if want_stats else None
-    rc = lib().u3d_igemm_lattice_bf16(_ptr(inp), _ptr(w_nmajor), _ptr(out), batch, D, H, W, cin, cout, kd, 1 if transposed else 0,
-                                      _ptr(stats), _stream())
-    if rc == -2:
-        return None
-    _check(rc, "igemm_lattice_bf16")
-    return (out, stats) if want_stats else out
 
 
 def sine_embed_fwd(logits, dim_t, out_dtype):

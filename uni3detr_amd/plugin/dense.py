@@ -61,8 +61,6 @@ class Lattice:
             n_in_dev = torch.tensor([n_in], dtype=torch.int32, device=device)
             n_out_dev = torch.tensor([n_out], dtype=torch.int32, device=device)
             g = (sp.ConvGeom(fwd, bwd, n_in, n_in_dev, n_out, n_out_dev, kind="dense", strided=any(s > 1 for s in stride)), dims_out)
-            if (all(s == 1 for s in stride) and tuple(ksize[1:]) == (3, 3) and ksize[0] in (1, 3) and tuple(pad) == (ksize[0] // 2, 1, 1)):
-                g[0].lattice = (batch, tuple(dims_in), int(ksize[0]))
             cls._cache[key] = g
         return g
 

@@ -112,8 +112,10 @@ class Uni3DETR(nn.Module):
         """'fp32': parity mode (exact-f32 MFMA everywhere); 'bf16': throughput mode (BASELINE configs[1]); 'mixed': the REFERENCE's
         recipe - SparseEncoderHD and SECOND3D in fp32 (ref: sparse_encoder_hd.py:62-64 fp16_enabled=False, uni3detr.py:150-151; the
         backbone is not wrapped in auto_fp16), neck + head in 16-bit (second3d_fpn.py:45 auto_fp16, uni3detr_sunrgbd.py:241
-        fp16 loss scaling): fp32-grade features at the price of running 2/3 of the convolution flops on the f32 matrix pipe (1/16
-        of the bf16 rate)."""
+        fp16 loss scaling).  The fp32 modules keep f32 activations, statistics and parameters; their wide convolutions (channels % 64
+        == 0) run as split-bf16 products - hi / lo bf16 planes, three MFMAs per product, f32 accumulation, ~2^-16 relative per product
+        (uni3detr_amd/sparse.py split_scope; U3D_SPLIT_BF16=0 puts them back on the exact f32 MFMA at 1/16 of the bf16 rate) - the
+        narrow sparse levels on the exact f32 kernels."""
         assert mode in ("fp32", "bf16", "mixed")
         self.precision = mode
         self.amp_dtype = None if mode == "fp32" else torch.bfloat16
@@ -191,9 +193,10 @@ class Uni3DETR(nn.Module):
         feats, fcoors = self.pts_voxel_encoder(cat, coors, batch_size=B)
         return coors, feats, fcoors, cat, scene_off, lens
 
-    def shadow_scope(self):
+    def shadow_scope(self, refresh=True):
         """Context for ONE training forward in bf16 mode: refreshes the bf16 parameter shadows with one multi-tensor copy and
-        lets every conv / linear use them instead of casting its own weights."""
+        lets every conv / linear use them instead of casting its own weights.  refresh=False: a later stage of the SAME forward
+        (TrainStep's staged graphs) - the shadows are current, only the scope is entered."""
         import contextlib
         dev = next(self.parameters()).device
         if self.amp_dtype is None or dev.type != "cuda" or not torch.is_grad_enabled():
@@ -212,26 +215,32 @@ class Uni3DETR(nn.Module):
                     if p.dim() == 5:
                         convs[p] = "dhwio"
             self._shadows = ShadowSet(list({id(p): p for p in ps}.values()), self.amp_dtype, convs, flat=getattr(self, "_flat_params", None))
-        return self._shadows.active()
+        return self._shadows.active(refresh)
 
-    def extract_pts_feat(self, pts):
+    # The feature extractor in three stages, so that a captured training step can run stage 2 (the 300 serial FPS rounds, ~1 ms on
+    # 2B CUs) as its OWN graph on a second stream next to stage 3: inside ONE hipGraph every node runs on a single hardware queue on this
+    # stack (a rocprofv3 timeline of the replayed step shows k_fps alone on the device for its whole duration although it was
+    # captured on a forked stream), so fork/join inside a capture buys no overlap.  extract_pts_feat() composes them for eager use.
+    def stage_voxelize(self, pts):
+        """-> dict: table coordinates + mean features (+ what the FPS stage needs)."""
         if self.dynamic_voxelization:
             coors, feats, fcoors, cat, scene_off, lens = self.voxelize_dynamic_batch(pts)
-            x = self.pts_middle_encoder(feats, fcoors, len(lens))
-            voxel_off = scene_off          # the voxel-coordinate FPS runs over the PER-POINT coors incl. -1 rows (ref :166,:183)
-        else:
-            coors, feats, voxel_off, cat, scene_off, lens = self.voxelize_batch(pts)
-        # the 300 serial FPS rounds (~1 ms on 2B CUs) only need points + voxel coords: run them on a side stream underneath the
-        # encoder / dense stack (fork-join, also valid inside a hipGraph capture)
-        cur = torch.cuda.current_stream()
-        if self._fps_stream is None:
-            self._fps_stream = torch.cuda.Stream()
-        side = self._fps_stream
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            fpsbpts = self.fps_queries(cat, scene_off, lens, coors, voxel_off)
-        if not self.dynamic_voxelization:
-            x = self.pts_middle_encoder(feats, coors, len(lens))
+            # the voxel-coordinate FPS runs over the PER-POINT coors incl. -1 rows (ref :166,:183)
+            return dict(coors=coors, feats=feats, fcoors=fcoors, cat=cat, scene_off=scene_off, lens=lens, voxel_off=scene_off)
+        coors, feats, voxel_off, cat, scene_off, lens = self.voxelize_batch(pts)
+        return dict(coors=coors, feats=feats, fcoors=coors, cat=cat, scene_off=scene_off, lens=lens, voxel_off=voxel_off)
+
+    def stage_fps(self, v):
+        return self.fps_queries(v["cat"], v["scene_off"], v["lens"], v["coors"], v["voxel_off"])
+
+    def stage_features(self, v):
+        from .. import sparse as sp
+        # 'mixed': the fp32 modules' wide convs as split-bf16 products (sparse.split_scope) - f32 rows in and out, bf16 matrix pipe
+        with sp.split_scope(getattr(self, "precision", None) == "mixed"):
+            return self._stage_features(v)
+
+    def _stage_features(self, v):
+        x = self.pts_middle_encoder(v["feats"], v["fcoors"], len(v["lens"]))
         self._encoder_out = self._encoder_cut = None
         if getattr(self, "cut_encoder_backward", False) and torch.is_grad_enabled() and x.requires_grad:
             # cut point of TrainStep's two-phase backward: everything above sees a detached leaf; phase B feeds its gradient into x
@@ -245,8 +254,21 @@ class Uni3DETR(nn.Module):
                 if getattr(self, "precision", None) == "mixed":
                     x = tuple(t.to(torch.bfloat16) for t in x) if isinstance(x, (tuple, list)) else x.to(torch.bfloat16)
                 x = self.pts_neck(x)
+        return x
+
+    def extract_pts_feat(self, pts):
+        v = self.stage_voxelize(pts)
+        # the FPS rounds only need points + voxel coords: on a side stream underneath the encoder / dense stack (eager launches overlap)
+        cur = torch.cuda.current_stream()
+        if self._fps_stream is None:
+            self._fps_stream = torch.cuda.Stream()
+        side = self._fps_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            fpsbpts = self.stage_fps(v)
+        x = self.stage_features(v)
         cur.wait_stream(side)
-        for t in (cat, coors, voxel_off, scene_off):
+        for t in (v["cat"], v["coors"], v["voxel_off"], v["scene_off"]):
             t.record_stream(side)
         return x, fpsbpts
 

@@ -24,50 +24,6 @@ def inverse_sigmoid(x, eps=1e-5):
     return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
 
 
-class _LinearFn(torch.autograd.Function):
-    """act(x @ W^T + b) on the HIP implicit-GEMM kernel (u3d_linear_bf16: bias and ReLU fused into the epilogue); backward =
-    the same kernel family (dgrad as a k-major GEMM, wgrad as the row-reduction GEMM).  bf16 operands, f32 accumulation."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, relu):
-        shp = x.shape
-        x2 = x.reshape(-1, shp[-1])
-        x2 = (x2 if x2.dtype == torch.bfloat16 else x2.to(torch.bfloat16)).contiguous()
-        wb = weight.to(torch.bfloat16).contiguous()
-        out = nv.linear_bf16(x2, wb, None if bias is None else bias.float(), relu)
-        ctx.relu, ctx.has_bias = relu, bias is not None
-        ctx.xdtype, ctx.wdtype = x.dtype, weight.dtype
-        ctx.save_for_backward(x2, wb, out if relu else None)
-        ctx.shp = shp
-        return out.view(*shp[:-1], weight.shape[0])
-
-    @staticmethod
-    def backward(ctx, dy):
-        x2, wb, out = ctx.saved_tensors
-        n, k = wb.shape
-        m = x2.shape[0]
-        dy2 = dy.reshape(-1, n)
-        dy2 = dy2 if dy2.dtype == torch.bfloat16 else dy2.to(torch.bfloat16)
-        if ctx.relu:
-            dy2 = dy2 * (out > 0)
-        dy2 = dy2.contiguous()
-        md = nv.count_tensor(m, dy2.device)
-        dx = dw = db = None
-        if LINEAR_BWD_TORCH:
-            if ctx.needs_input_grad[0]:
-                dx = (dy2 @ wb).view(ctx.shp).to(ctx.xdtype)
-            if ctx.needs_input_grad[1]:
-                dw = (dy2.t() @ x2).to(ctx.wdtype)
-        else:
-            if ctx.needs_input_grad[0]:
-                dx = nv.spconv_fwd(dy2, wb.view(1, n, k), None, md, m, k).view(ctx.shp).to(ctx.xdtype)
-            if ctx.needs_input_grad[1]:
-                dw = nv.spconv_wgrad(dy2, x2, None, md, 1).view(n, k).to(ctx.wdtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = nv.colsum(dy2)
-        return dx, dw, db, None
-
-
 _ONES = {}
 
 
@@ -311,9 +267,7 @@ class _InProjFn(torch.autograd.Function):
 
 
 import os as _os
-FAST_LINEAR = _os.environ.get("U3D_FAST_LINEAR", "0") == "1"      # opt-in: measured time-neutral vs hipBLASLt at M = B*900 rows
 SAFE_LINEAR = _os.environ.get("U3D_UNSAFE_LINEAR", "0") != "1"      # test hook: "1" restores torch's own Linear backward
-LINEAR_BWD_TORCH = _os.environ.get("U3D_LINEAR_BWD_TORCH", "0") == "1"
 OWN_WGRAD = _os.environ.get("U3D_OWN_WGRAD", "1") == "1"          # dW of the decoder/head linears on u3d_igemm_wgrad_bf16
 # dW of the <= 16-feature linears on u3d_skinny_wgrad_bf16: correct (tests) but measured SLOWER end to end than hipBLASLt's
 # small products (30.3 vs 29.7 ms per step: 57 workgroups per launch) - opt-in until the kernel splits the wide dimension too
@@ -332,8 +286,6 @@ def fast_linear(x, lin, relu=False, weight=None, bias=None):
     w = lin.weight if weight is None else weight
     b = (lin.bias if lin is not None else None) if bias is None and weight is None else bias
     bf16_mode = x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16))
-    if FAST_LINEAR and bf16_mode and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
-        return _LinearFn.apply(x, w, b, relu)
     if SAFE_LINEAR and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
         if relu and RELU_EPILOGUE:
             return _TorchLinearFn.apply(x, w, b, _autocast_dtype(x), True)
@@ -521,7 +473,7 @@ class MultiheadAttention(nn.Module):
             qk = (x + pos).reshape(-1, group, C)
             xv = x.reshape(-1, group, C)
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
-        if SAFE_LINEAR and not FAST_LINEAR and x.is_cuda and torch.is_grad_enabled() and b is not None:
+        if SAFE_LINEAR and x.is_cuda and torch.is_grad_enabled() and b is not None:
             qk_p, v = _InProjFn.apply(qk, xv, w, b, _autocast_dtype(x))
         else:
             qk_p = fast_linear(qk, None, weight=w[: 2 * C], bias=b[: 2 * C])

@@ -102,8 +102,8 @@ class ShadowSet:
         # 64 -> 64 channel, 27-offset weights (the SubM blocks of the stride-4 stage): MFMA-fragment-packed copies of both layouts
         # for the halo kernel (csrc/subm_halo.hip), all of them in ONE launch per refresh
         self._halo_plans = []
-        # (kvol, channels, layout): the sparse encoder's 64- / 128-channel SubM weights and the dense stack's 128-channel (1,3,3) convs
-        for k, c, lay in ((27, 32, "dhwio"), (27, 64, "dhwio"), (27, 128, "dhwio"), (9, 128, "oidhw")):
+        # (kvol, channels, layout): the sparse encoder's 64- / 128-channel SubM weights
+        for k, c, lay in ((27, 64, "dhwio"), (27, 128, "dhwio")):
             pairs = []
             for p in self.conv_params:
                 kio, koi = p._u3d_conv_shadow[0], p._u3d_conv_shadow[1]
@@ -141,9 +141,10 @@ class ShadowSet:
             p._u3d_conv_shadow[2] = p._version
 
     @contextlib.contextmanager
-    def active(self):
+    def active(self, refresh=True):
         """Refresh, then let compute_copy() / conv_weights() use the shadows for the duration of the block (one training forward)."""
-        self.refresh()
+        if refresh:
+            self.refresh()
         prev = _ACTIVE[0]
         _ACTIVE[0] = True
         try:

@@ -98,24 +98,7 @@ class ConvGeom:
         self.nbr_fwd, self.nbr_bwd = nbr_fwd, nbr_bwd
         self.n_in, self.n_in_dev, self.n_out, self.n_out_dev = n_in, n_in_dev, n_out, n_out_dev
         self.kind = kind            # "sparse" (encoder levels) or "dense" (SECOND3D/FPN lattice): bench.py tags timings with it
-        self.lattice = None         # (batch, (D,H,W), kd) for a stride-1 "same" (kd,3,3) conv on a dense lattice (u3d_igemm_lattice_bf16)
-        self.level = None           # SubM convs: the Level (its halo() serves the 64 -> 64 convs, u3d_subm_halo_conv64_bf16)
-        self._im2col = None
-        self._halo = None
-
-    def halo(self):
-        """Dense stride-1 convs: distinct-row tables of the (static) forward table, built once per geometry (native.SubmHalo)."""
-        if self._halo is None:
-            h = nv.SubmHalo(self.nbr_fwd, self.n_out_dev, self.n_out) if self.n_out <= nv.SubmHalo.MAX_ROWS else None
-            self._halo = h if (h is not None and h.ok) else False
-        return self._halo or None
-
-    def im2col_index(self):
-        """int32 [n_out * K]: entry m * K + k = the input row of output row m at offset k (-1: none) - the forward table transposed,
-        what u3d_gather_rows takes to lay the operand rows of a strided conv out as contiguous rows of K * Cin elements."""
-        if self._im2col is None:
-            self._im2col = self.nbr_fwd[:, :self.n_out].t().contiguous().view(-1)
-        return self._im2col
+        self.level = None           # SubM convs: the Level (its halo() serves the 64 -> 64 / 128 -> 128 convs, subm_halo.hip)
 
 
 def level_from_coors(coors, batch, dims):
@@ -160,24 +143,9 @@ REV_SUBM_TABLE = os.environ.get("U3D_REV_SUBM_TABLE", "1") == "1"
 SUBM_HALO = os.environ.get("U3D_SUBM_HALO", "1") == "1"       # 64 -> 64 SubM convs out of per-tile staged distinct rows (subm_halo.hip)
 HALO_WGRAD = os.environ.get("U3D_HALO_WGRAD", "1") == "1"     # ... and their weight gradients (k_subm_halo_wgrad64)
 HALO_128 = os.environ.get("U3D_HALO_128", "1") == "1"         # ... and the 128 -> 128 SubM convs (k_subm_halo128: forward / input gradient)
-# ... and the dense stack's stride-1 128 -> 128 (1,3,3) convs (same kernel, 9 offsets, static tables).  Parity-tested; in the captured
-# step it is on par with the LDS-DMA tiled kernel (19.27 vs 19.23 ms, same-box A/B 3 x 100 steps): on a lattice the tiled kernel's
-# operand rows are consecutive, so its row stream is cheap and the weight stream - the same in both - sets the time.  Off.
-HALO_DENSE = os.environ.get("U3D_HALO_DENSE", "0") == "1"
-# ... and the 32 -> 32 SubM convs of the stride-2 stage (k_subm_halo32): 37.5 -> 28.7 us per launch in isolation, but the level has
-# 340 k rows - its table build (a 65 KB row bitmap per tile) costs more than the eight launches save: 19.42 -> 19.55 ms per step
-# (same-box A/B, 3 x 100 steps).  Parity-tested, off.
-HALO_32 = os.environ.get("U3D_HALO_32", "0") == "1"
-LATTICE_KERNEL = os.environ.get("U3D_LATTICE_KERNEL", "0") == "1"      # 27-offset dense convs on u3d_igemm_lattice_bf16 (measured on par: off)
 STRIDED_DGRAD_SPLIT = os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
 NMAJOR_FWD = os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
 STRIDED_SPLIT_MIN_RATIO = int(os.environ.get("U3D_STRIDED_SPLIT_MIN_RATIO", "16"))
-# Stride-4 dense convs (SECOND3D's third branch: 192 000 -> 12 000 rows, 9 offsets): forward and weight gradient as im2col (one row
-# gather into contiguous rows of K * Cin) + plain GEMMs.  The table kernels gather cold 512-byte rows one 64-channel slice at a
-# time through LDS-DMA (forward 151 us, weight gradient 142 us in the eager per-launch table); the gathered matrix is 55 MB, and the
-# GEMMs over it take 50 + 52 us in isolation (tools/im2col_probe.py).  At stride 2 the matrix is 221 MB and its gather (110 us) eats
-# the gain.  In the captured step the swap LOSES 0.08 ms (same-box A/B, 3 x 100 steps: 19.32 -> 19.40 ms): off.
-IM2COL_STRIDED = os.environ.get("U3D_IM2COL_STRIDED", "0") == "1"
 STRIDED_SPLIT_SPARSE_RATIO = int(os.environ.get("U3D_STRIDED_SPLIT_SPARSE_RATIO", "16"))      # same threshold for the sparse levels' strided convs
 
 
@@ -215,6 +183,54 @@ def reset_conv_uses():
     _CONV_USES.clear()
 
 
+# ---- split-bf16 convolutions: f32-grade products on the bf16 matrix pipe (csrc/igemm_bf16.hip, u3d_igemm_fwd_split_bf16) -------------
+# `mixed` precision = the REFERENCE's recipe (SparseEncoderHD + SECOND3D in fp32: sparse_encoder_hd.py:62-64, uni3detr.py:150-151).
+# The exact f32 MFMA runs at 1/16 of the bf16 rate; inside split_scope() every f32 conv whose channel counts are multiples of 64 runs
+# instead as three bf16 products (hi.wh + hi.wl + lo.wh, f32 accumulation) on the LDS-DMA kernels the bf16 mode is benchmarked on:
+# activations travel as f32 rows, are split into hi / lo bf16 planes in front of each conv, and the three products are three sets of
+# offsets of ONE launch (tripled neighbour table and weights).  Narrow levels (16 / 32 channels) stay on the exact f32 kernels.
+SPLIT_BF16 = os.environ.get("U3D_SPLIT_BF16", "1") == "1"
+_SPLIT = [False]
+
+
+@contextlib.contextmanager
+def split_scope(on=True):
+    prev = _SPLIT[0]
+    _SPLIT[0] = bool(on) and SPLIT_BF16
+    try:
+        yield
+    finally:
+        _SPLIT[0] = prev
+
+
+def _split_serves(feats, cin, cout):
+    return _SPLIT[0] and feats.is_cuda and feats.dtype == torch.float32 and cin % 64 == 0 and cout % 64 == 0
+
+
+def _split3(w):
+    """f32 [K, A, B] -> bf16 [3K, A, B] = (hi, lo, hi): the weight side of hi.wh + hi.wl + lo.wh."""
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo, hi], 0)
+
+
+def _split_table(geom, which, n_rows, plane):
+    """int32 [3K, ld] = (t, t, t + plane): the table side - the third product reads the lo plane, `plane` rows below the hi plane.
+    which: "fwd" / "bwd" / "wgrad" (the latter [2K, ld] = (t, t + plane): the two products whose second operand is dy's hi plane).
+    Cached on the geometry (static for the dense lattice; the sparse levels' geometries live for one step)."""
+    cache = geom.__dict__.setdefault("_split_tables", {})
+    key = (which, plane)
+    if key not in cache:
+        t = geom.nbr_bwd if which == "bwd" else geom.nbr_fwd
+        if t is None:                                   # 1x1x1: the identity table
+            t = torch.arange(n_rows, dtype=torch.int32, device=geom.n_out_dev.device).view(1, -1)
+        elif isinstance(t, nv.RevNbr):
+            t = t.t.flip(0)
+        lo = torch.where(t >= 0, t + plane, t)
+        cache[key] = torch.cat([t, lo] if which == "wgrad" else [t, t, lo], 0).contiguous()
+    return cache[key]
+
+
 class _SparseConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, weight, geom, layout, want_stats=False, res_token=None, fan_token=None, bn_in=None):
@@ -244,36 +260,31 @@ class _SparseConv(torch.autograd.Function):
         ctx.grad_view = getattr(weight, "_u3d_grad_view", None)
         ctx.kio_shape, ctx.wdtype = kio_shape, weight.dtype
         nv.CALL_KIND = geom.kind
-        ctx.im2col = (IM2COL_STRIDED and nmajor and geom.strided and geom.kind == "dense" and kv > 1 and (kv * cin) % 64 == 0
-                      and geom.n_out * STRIDED_SPLIT_MIN_RATIO <= geom.n_in)
-        ctx.halo = False
-        if ctx.im2col:
-            cols = nv.gather_rows(feats, geom.im2col_index()).view(geom.n_out, kv * cin)
-            w2 = koi.permute(1, 0, 2).reshape(1, cout, kv * cin)                  # [Cout][K][Cin]: n-major for the K * Cin reduction
-            ctx.save_for_backward(cols, kio)          # the weight gradient reads the gathered matrix; the input gradient (split path) needs neither
-            res = nv.spconv_fwd_stats(cols, w2, None, geom.n_out_dev, geom.n_out, cout) if want_stats else None
-            if res is not None:
-                y, stats, tr = res
-                stats._u3d_tile_rows = tr
-            else:
-                y = nv.spconv_fwd(cols, w2, None, geom.n_out_dev, geom.n_out, cout, transpose_w=True, tag="spconv_fwd")
+        ctx.split = _split_serves(feats, cin, cout)
+        if ctx.split:
+            kio, koi = conv_weights(weight, layout, torch.float32, want_koi=True)
+            n_in = feats.shape[0]
+            xs = nv.split_rows(feats.contiguous(), geom.n_in_dev)                        # bf16 [2 * n_in, cin]: hi | lo planes
+            ctx.save_for_backward(xs, kio)                                               # the weight gradient reads the planes
+            ctx.halo = False
+            t3 = _split_table(geom, "fwd", geom.n_out, n_in)
+            res = nv.spconv_fwd_split(xs, _split3(koi), t3, geom.n_out_dev, geom.n_out, cout, want_stats=want_stats)
+            if not want_stats:
+                return res
+            y, stats, tr = res
+            if stats is None:
                 stats = torch.empty(0, dtype=torch.float64, device=feats.device)
-            if want_stats:
-                ctx.mark_non_differentiable(stats)
-                return y, stats
-            return y
+            else:
+                stats._u3d_tile_rows = tr
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        ctx.halo = False
         ctx.save_for_backward(feats, kio)
         nbr = geom.nbr_fwd if kio.shape[0] > 1 else None
-        lat = geom.lattice if (LATTICE_KERNEL and nmajor and geom.lattice is not None and geom.lattice[2] == 3) else None
         ctx.halo = (SUBM_HALO and REV_SUBM_TABLE and nmajor and geom.level is not None and kv == 27 and cin == cout
-                    and (cin == 64 or (cin == 128 and HALO_128) or (cin == 32 and HALO_32)) and geom.n_out >= 4096
+                    and (cin == 64 or (cin == 128 and HALO_128)) and geom.n_out >= 4096
                     and geom.level.halo() is not None)
         ctx.halo_tab = geom.level.halo() if ctx.halo else None
-        if (not ctx.halo and HALO_DENSE and nmajor and geom.kind == "dense" and not geom.strided and 1 < kv <= 27 and cin == cout == 128
-                and geom.n_in == geom.n_out and geom.n_out >= 4096 and geom.halo() is not None):
-            # stride-1 "same" conv on a dense lattice, 128 channels (SECOND3D's first branch): the same kernel on static tables; the
-            # transposed table of such a conv is the forward one reversed, as for SubM
-            ctx.halo, ctx.halo_tab = True, geom.halo()
         if ctx.halo:
             pk_fwd, ctx.pk_bwd = halo_packs(weight, kio, koi)
             if want_stats:
@@ -283,12 +294,7 @@ class _SparseConv(torch.autograd.Function):
                 return y, stats
             return nv.subm_halo_conv(feats, pk_fwd, ctx.halo_tab)
         if want_stats:
-            res = None
-            if lat is not None:
-                r = nv.lattice_conv(feats, koi, lat[0], lat[1], lat[2], want_stats=True)
-                res = None if r is None else (r[0], r[1], 256)
-            if res is None:
-                res = nv.spconv_fwd_stats(feats, koi, nbr, geom.n_out_dev, geom.n_out, cout) if nmajor else None
+            res = nv.spconv_fwd_stats(feats, koi, nbr, geom.n_out_dev, geom.n_out, cout) if nmajor else None
             if res is not None:
                 y, stats, tr = res
                 stats._u3d_tile_rows = tr
@@ -312,11 +318,10 @@ class _SparseConv(torch.autograd.Function):
         kvol = wc.shape[0]
         din = dw = None
         nv.CALL_KIND = g.kind
+        if ctx.split:
+            return _SparseConv._split_backward(ctx, feats, wc, dout)
 
         def weight_grad():
-            if ctx.im2col:      # feats = the gathered matrix [n_out, K * Cin]: dW = cols^T dout, one offset
-                dwp = nv.spconv_wgrad(feats, dout, None, g.n_out_dev, 1).view(ctx.kio_shape).to(ctx.wdtype)
-                return dwp.permute(4, 3, 0, 1, 2) if ctx.layout == "oidhw" else dwp
             nbr = g.nbr_fwd if kvol > 1 else None
             cin_w, cout_w = wc.shape[1], wc.shape[2]
             v2 = feats.dtype == torch.bfloat16 and nv.USE_IGEMM_V2 and cin_w % 16 == 0 and cout_w % 16 == 0 and ctx.wdtype == torch.float32
@@ -361,44 +366,74 @@ class _SparseConv(torch.autograd.Function):
                 if facc is not None and fa is None:
                     din += facc
             else:
-                din = None
-                if LATTICE_KERNEL and g.lattice is not None and g.lattice[2] == 3 and dout.dtype == torch.bfloat16:
-                    din = nv.lattice_conv(dout, wc, g.lattice[0], g.lattice[1], g.lattice[2], transposed=True)
-                    if facc is not None:
-                        din += facc
-                if din is None:
-                    tok = ctx.res_token
-                    add = tok.dres if tok is not None else None
-                    if tok is not None:
-                        tok.dres = None
-                    if add is not None and facc is not None:
-                        add = add + facc
-                    elif facc is not None:
-                        add = facc
-                    bt = ctx.bn_in
-                    if bt is not None and (bt.c != cin or (add is not None and not (add.dtype == torch.bfloat16 and add.is_contiguous()))):
-                        bt = None
-                    if ctx.halo and cin != 64:
-                        bt = None                    # (the 128-channel halo kernel has no BatchNorm-backward epilogue)
-                    if ctx.halo:
-                        pk = ctx.pk_bwd if ctx.pk_bwd is not None else nv.subm_halo_wpack(wc)
-                        if bt is not None:
-                            din, st, tr = nv.subm_halo_conv(dout, pk, ctx.halo_tab, krev=True, addend=add, want_stats=True, tag="spconv_dgrad",
-                                                            bn_epi=bt.epi)
-                            bt.partial = (st, tr)
-                        else:
-                            din = nv.subm_halo_conv(dout, pk, ctx.halo_tab, krev=True, addend=add, tag="spconv_dgrad")
+                tok = ctx.res_token
+                add = tok.dres if tok is not None else None
+                if tok is not None:
+                    tok.dres = None
+                if add is not None and facc is not None:
+                    add = add + facc
+                elif facc is not None:
+                    add = facc
+                bt = ctx.bn_in
+                if bt is not None and (bt.c != cin or (add is not None and not (add.dtype == torch.bfloat16 and add.is_contiguous()))):
+                    bt = None
+                if ctx.halo and cin != 64:
+                    bt = None                    # (the 128-channel halo kernel has no BatchNorm-backward epilogue)
+                if ctx.halo:
+                    pk = ctx.pk_bwd if ctx.pk_bwd is not None else nv.subm_halo_wpack(wc)
+                    if bt is not None:
+                        din, st, tr = nv.subm_halo_conv(dout, pk, ctx.halo_tab, krev=True, addend=add, want_stats=True, tag="spconv_dgrad",
+                                                        bn_epi=bt.epi)
+                        bt.partial = (st, tr)
                     else:
-                        r = nv.spconv_dgrad_bnstats(dout, wc, nbr, g.n_in_dev, g.n_in, cin, add, bt.epi) if (bt is not None and kvol > 1) else None
-                        if r is not None:
-                            din, bt.partial = r[0], (r[1], r[2])
-                        else:
-                            din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True, addend=add)
+                        din = nv.subm_halo_conv(dout, pk, ctx.halo_tab, krev=True, addend=add, tag="spconv_dgrad")
+                else:
+                    r = nv.spconv_dgrad_bnstats(dout, wc, nbr, g.n_in_dev, g.n_in, cin, add, bt.epi) if (bt is not None and kvol > 1) else None
+                    if r is not None:
+                        din, bt.partial = r[0], (r[1], r[2])
+                    else:
+                        din = nv.spconv_fwd(dout, wc, nbr, g.n_in_dev, g.n_in, cin, transpose_w=True, addend=add)
             if fan is not None:
                 din = fan.step(din)
         elif ctx.res_token is not None:
             ctx.res_token.dres = None
         return din, dw, None, None, None, None, None, None
+
+
+def _split_backward_impl(ctx, xs, wc, dout):
+    """Backward of a split-bf16 conv: dy is split into planes once; dx = three products as in the forward (transposed tables /
+    weights); dW = x^T dy ~ xh^T dyh + xl^T dyh + xh^T dyl: two launches of the bf16 weight-gradient kernel (offsets doubled for the
+    two products against dy's hi plane), summed in f32."""
+    g = ctx.geom
+    kvol, cin, cout = wc.shape
+    n_in, n_out = xs.shape[0] // 2, dout.shape[0]
+    dys = nv.split_rows(dout.float() if dout.dtype != torch.float32 else dout, g.n_out_dev)      # bf16 [2 * n_out, cout]
+    din = dw = None
+    if ctx.needs_input_grad[1]:
+        ta = _split_table(g, "wgrad", n_out, n_in)                                         # [2K, ld]: (nbr, nbr + n_in)
+        tb = ta[:kvol]
+        a = nv.spconv_wgrad(xs, dys[:n_out], ta, g.n_out_dev, 2 * kvol)                    # [2K, cin, cout]: xh^T dyh | xl^T dyh
+        b = nv.spconv_wgrad(xs, dys[n_out:], tb, g.n_out_dev, kvol)                        # [K, cin, cout]: xh^T dyl
+        dwk = (a[:kvol] + a[kvol:] + b).reshape(ctx.kio_shape).to(ctx.wdtype)
+        dw = dwk.permute(4, 3, 0, 1, 2) if ctx.layout == "oidhw" else dwk
+    if ctx.needs_input_grad[0]:
+        t3 = _split_table(g, "bwd", g.n_in, n_out)
+        din = nv.spconv_fwd_split(dys, _split3(wc), t3, g.n_in_dev, g.n_in, cin, tag="spconv_dgrad")
+        fan = ctx.fan_token
+        if fan is not None:
+            if fan.acc is not None:
+                din += fan.acc
+            din = fan.step(din)
+        tok = ctx.res_token
+        if tok is not None and tok.dres is not None:
+            din = din + tok.dres
+            tok.dres = None
+    elif ctx.res_token is not None:
+        ctx.res_token.dres = None
+    return din, dw, None, None, None, None, None, None
+
+
+_SparseConv._split_backward = staticmethod(_split_backward_impl)
 
 
 def sparse_conv(feats, weight, geom, layout="dhwio", fan_token=None):
@@ -419,7 +454,7 @@ def conv_bn(feats, weight, geom, bn, n_dev, residual=None, relu=True, layout="dh
             fan_token=None, bn_in=None, bn_out=None):
     """conv -> BatchNorm rows (+ residual) (+ ReLU).  In training the conv's epilogue already reduces the BatchNorm statistics per row
     tile where its kernel supports it (bf16, channels % 64 == 0): the separate statistics pass over the conv output disappears."""
-    if FUSED_CONV_STATS and bn.training and feats.dtype == torch.bfloat16 and feats.is_cuda:
+    if FUSED_CONV_STATS and bn.training and feats.is_cuda and (feats.dtype == torch.bfloat16 or _split_serves(feats, feats.shape[1], bn.num_features)):
         # res_take: this conv's input is the identity of a residual block - its backward sums the token's gradient into the input
         # gradient; res_give: this BatchNorm adds that identity - its backward leaves the identity's gradient in the token
         # fan_token: this conv is one of several that take the same input (FanoutToken)

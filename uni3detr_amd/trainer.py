@@ -34,10 +34,13 @@ EARLY_FLUSH = os.environ.get("U3D_EARLY_FLUSH", "0") == "1"
 class TrainStep:
     def __init__(self, model, points, gt_bboxes_3d, gt_labels_3d, lr=1e-4, weight_decay=0.01, max_norm=10.0, graph=True,
                  capacity_margin=1.25, flat_update=True, overlap_reduce=False, betas=(0.9, 0.999), eps=1e-8, gt_capacity=64,
-                 check_every=50, pg_hooks=None):
+                 check_every=50, pg_hooks=None, fps_graph=None):
         """pg_hooks: (teardown, setup) callables that destroy / re-create the default process group; needed only for a collective
         re-capture after a capacity overflow on a multi-rank run (bench.py passes them)."""
         self.model = model
+        # captured step: the FPS rounds as their own graph on a second stream next to the encoder / dense stack (see capture())
+        self.fps_graph = (os.environ.get("U3D_FPS_GRAPH", "1") == "1") if fps_graph is None else bool(fps_graph)
+        self._fps_stream = None
         self.pg_hooks = pg_hooks
         self._capture_batches = None
         self._msg = None
@@ -173,14 +176,37 @@ class TrainStep:
         _sp.reset_conv_uses()
         with m.shadow_scope():
             feat, fps = m.extract_pts_feat(self.pts)
-            if EARLY_FLUSH and torch.is_tensor(feat) and feat.requires_grad:
-                # the gradient of the head's input exists once every decoder layer has run its backward: that is when the queued
-                # parameter-gradient products of decoder + head (~0.9 ms of small launches) can start - on a side stream, underneath
-                # the dense stack's backward, instead of after it
-                feat.register_hook(self._early_flush)
-            amp = m.amp_dtype
-            with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
-                self._outs = m.pts_bbox_head(feat, None, fps)
+            self._stage1_head(feat, fps)
+
+    # ---- stage 1 in pieces (captured step with fps_graph): voxelize | FPS (own graph, second stream) || features | head + matching ----
+    def _stage1a(self):
+        _T.reset_param_uses()
+        _sp.reset_conv_uses()
+        self._v = self.model.stage_voxelize(self.pts)
+
+    def _stage1_fps(self):
+        self._fps = self.model.stage_fps(self._v)
+
+    def _stage1b(self):
+        m = self.model
+        with m.shadow_scope():
+            self._feat = m.stage_features(self._v)
+
+    def _stage1c(self):
+        with self.model.shadow_scope(refresh=False):
+            self._stage1_head(self._feat, self._fps)
+
+    def _stage1_head(self, feat, fps):
+        """Decoder / head forward, matching and targets (inside the caller's shadow scope)."""
+        m = self.model
+        if EARLY_FLUSH and torch.is_tensor(feat) and feat.requires_grad:
+            # the gradient of the head's input exists once every decoder layer has run its backward: that is when the queued
+            # parameter-gradient products of decoder + head (~0.9 ms of small launches) can start - on a side stream, underneath
+            # the dense stack's backward, instead of after it
+            feat.register_hook(self._early_flush)
+        amp = m.amp_dtype
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            self._outs = m.pts_bbox_head(feat, None, fps)
         self._T = m.pts_bbox_head.loss_targets(self.gts, None, self._outs)
         # the step's collective message: [L positive counts | capacity flag].  The flag (levels over capacity, this rank) is computed on
         # the device from the counts the encoder just produced: no host read
@@ -486,7 +512,7 @@ class TrainStep:
         # drop the eager iteration's activations / autograd graph BEFORE capturing: releasing them from inside a capture
         # (when the attributes are re-assigned) tears down autograd nodes mid-capture and crashes hipStreamEndCapture
         self._outs = self._T = self._num_pos = self._msg = self._losses = self.loss = None
-        self._gx = None
+        self._gx = self._v = self._fps = self._feat = None
         self.model._encoder_out = self.model._encoder_cut = None
         self.model.pts_bbox_head._loss_total = None
         dec = getattr(getattr(self.model.pts_bbox_head, "transformer", None), "decoder", None)
@@ -500,8 +526,28 @@ class TrainStep:
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         g2b = torch.cuda.CUDAGraph() if self.overlap else None
         pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(g1, pool=pool, stream=s, capture_error_mode="thread_local"):
-            self._stage1()
+        self._v = self._fps = self._feat = None
+        if self.fps_graph and not getattr(self.model, "dynamic_voxelization", False):
+            # stage 1 as FOUR graphs: voxelize | FPS || encoder + dense stack | head + matching.  Every node of one hipGraph runs on a
+            # single hardware queue on this stack, so the forked FPS branch of a monolithic stage-1 graph sat alone on the device for
+            # its ~1.1 ms (rocprofv3 timeline, profiles/r04a_timeline.txt); as its own graph, replayed on a second stream, it runs
+            # underneath the encoder.  The FPS graph has its OWN memory pool: it is the one graph that runs concurrently with another,
+            # and graphs sharing a pool may reuse each other's freed blocks.
+            g1a, gf, g1b, g1c = (torch.cuda.CUDAGraph() for _ in range(4))
+            if self._fps_stream is None:
+                self._fps_stream = torch.cuda.Stream()
+            with torch.cuda.graph(g1a, pool=pool, stream=s, capture_error_mode="thread_local"):
+                self._stage1a()
+            with torch.cuda.graph(gf, stream=s, capture_error_mode="thread_local"):
+                self._stage1_fps()
+            with torch.cuda.graph(g1b, pool=pool, stream=s, capture_error_mode="thread_local"):
+                self._stage1b()
+            with torch.cuda.graph(g1c, pool=pool, stream=s, capture_error_mode="thread_local"):
+                self._stage1c()
+            g1 = (g1a, gf, g1b, g1c)
+        else:
+            with torch.cuda.graph(g1, pool=pool, stream=s, capture_error_mode="thread_local"):
+                self._stage1()
         self._reduce_num_pos()
         if self.overlap:
             with torch.cuda.graph(g2, pool=pool, stream=s, capture_error_mode="thread_local"):
@@ -567,6 +613,20 @@ class TrainStep:
             self.dist_on = dist.is_available() and dist.is_initialized()
             self.world = dist.get_world_size() if self.dist_on else 1
 
+    def _replay_stage1(self, g1):
+        if not isinstance(g1, tuple):
+            g1.replay()
+            return
+        g1a, gf, g1b, g1c = g1
+        cur, side = torch.cuda.current_stream(), self._fps_stream
+        g1a.replay()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            gf.replay()                       # the FPS rounds: second stream, underneath ...
+        g1b.replay()                          # ... the sparse encoder and the dense stack
+        cur.wait_stream(side)
+        g1c.replay()
+
     def step(self):
         if self._graphs is None:
             return self.eager_step()
@@ -578,7 +638,7 @@ class TrainStep:
                 self.recapture()
         self._steps_since_check += 1
         g1, g2, g2b, g3 = self._graphs
-        g1.replay()
+        self._replay_stage1(g1)
         if not self.flat_update:
             # torch.optim has no device-side hold flag (u3d_adamw_step_hold is the flat path's): without it a level that outgrew its
             # captured capacity would be truncated and trained on silently, so this configuration pays one host read per step and
@@ -590,7 +650,7 @@ class TrainStep:
                     raise                      # a per-rank decision cannot drive a collective re-capture: flat_update=True does that
                 self.recapture()
                 g1, g2, g2b, g3 = self._graphs
-                g1.replay()
+                self._replay_stage1(g1)
         self._reduce_num_pos()
         g2.replay()
         if g2b is not None:
