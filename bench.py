@@ -318,7 +318,8 @@ def main():
                            ("hipGraph: " + ("voxelize | FPS on a second stream || encoder + dense stack | head + match" if isinstance((ts._graphs or [None])[0], tuple) else "fwd + match")
                             + (" | loss + bwd head/dense [all-reduce A overlaps] | bwd encoder | clip + AdamW" if ts.overlap else " | loss + bwd | clip + AdamW"))
                            + ", static-shape sparse levels"),
-                       "sparse_level_capacities": caps, "rotating_batches": len(rot), "recaptures": int(getattr(ts, "recaptures", 0))},
+                       "sparse_level_capacities": caps, "rotating_batches": len(rot),
+                       "fps_stream_calibration_ms": getattr(ts, "fps_stream_calibration_ms", None), "recaptures": int(getattr(ts, "recaptures", 0))},
         }
         if timer is not None and census:
             durs = timer.durations_ms()

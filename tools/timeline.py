@@ -81,6 +81,21 @@ def main():
     print(f"# {len(gaps)} gaps >= 3 us in {nsteps} steps, total {sum(g for g, _, _ in gaps) / nsteps / 1e6:.3f} ms/step; largest:", file=out)
     for g, a, b in gaps[:15]:
         print(f"    {g / 1e3:8.1f} us  after {a}  before {b}", file=out)
+    # what the other queues do while a long side-stream kernel (k_fps) runs
+    for s0, e0, n0, g0, q0 in seg:
+        if not n0.startswith("k_fps"):
+            continue
+        inside = [(s, e, n, q) for s, e, n, g, q in seg if q != q0 and s < e0 and e > s0]
+        before = [(s, e, n, q) for s, e, n, g, q in seg if q != q0 and e <= s0][-3:]
+        after = [(s, e, n, q) for s, e, n, g, q in seg if q != q0 and s >= e0][:3]
+        print(f"# {n0} on queue {q0}: {(e0 - s0) / 1e3:.1f} us; {len(inside)} kernels of other queues overlap it, covering "
+              f"{sum(min(e, e0) - max(s, s0) for s, e, _, _ in inside) / 1e3:.1f} us", file=out)
+        for s, e, n, q in before:
+            print(f"      before: q{q} {n} ended {(s0 - e) / 1e3:.1f} us before its start", file=out)
+        for s, e, n, q in inside[:6]:
+            print(f"      inside: q{q} {n} start +{(s - s0) / 1e3:.1f} us, {(e - s) / 1e3:.1f} us long", file=out)
+        for s, e, n, q in after:
+            print(f"      after : q{q} {n} started {(s - e0) / 1e3:.1f} us after its end", file=out)
 
 
 if __name__ == "__main__":

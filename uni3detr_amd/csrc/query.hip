@@ -19,26 +19,26 @@ __device__ __forceinline__ bool fps_better(float d, int k, float bd, int bk, uns
   return t1 < t2;
 }
 
-template <bool REG>
-__global__ __launch_bounds__(FPS_THREADS) void k_fps(const float* __restrict__ base, const long long* __restrict__ set_off,
-                                                    const int* __restrict__ set_n, int m, int* __restrict__ out_idx,
-                                                    float* __restrict__ temp, long long temp_stride) {
-  constexpr int NW = FPS_THREADS / 64;
-  __shared__ float s_d[NW];
-  __shared__ int s_k[NW];
-  __shared__ float s_cur[3];
-  const int s = blockIdx.x;
-  const float* p = base + set_off[s];
-  const int n = set_n[s];
-  int* out = out_idx + (long long)s * m;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (n <= 0) { for (int j = tid; j < m; j += FPS_THREADS) out[j] = 0; return; }
-  int T = 1;
-  while ((T << 1) <= n && (T << 1) <= 1024) T <<= 1;
-  const unsigned tmask = (unsigned)T - 1u, un = (unsigned)n;
+// One round = distance update + arg-max.  In the streaming path the winner's COORDINATES travel with (distance, index) through the
+// reductions.  When T == FPS_THREADS (every set with n >= 1024) all points of a thread share k mod T = tid and come in ascending k, so inside a
+// thread the tie rule degenerates to "first maximum wins": a strict compare, no tie keys (-6 VALU per point).
+struct FpsBest { float d; int k; float x, y, z; };
+__device__ __forceinline__ void fps_take(FpsBest& b, bool c, float d, int k, float x, float y, float z) {
+  b.d = c ? d : b.d; b.k = c ? k : b.k; b.x = c ? x : b.x; b.y = c ? y : b.y; b.z = c ? z : b.z;
+}
+__device__ __forceinline__ void fps_merge_shfl(FpsBest& b, int o, unsigned tmask, unsigned n) {
+  const float od = __shfl_xor(b.d, o, 64); const int ok = __shfl_xor(b.k, o, 64);
+  const float ox = __shfl_xor(b.x, o, 64), oy = __shfl_xor(b.y, o, 64), oz = __shfl_xor(b.z, o, 64);
+  fps_take(b, fps_better(od, ok, b.d, b.k, tmask, n), od, ok, ox, oy, oz);
+}
 
+template <bool REG, bool FIRST_WINS>
+__device__ __forceinline__ void fps_rounds(const float* __restrict__ p, int n, int m, int* __restrict__ out, float* __restrict__ tmp,
+                                           unsigned tmask, float* s_d, int* s_k, float* s_x, float* s_y, float* s_z, float* s_cur, int* s_win) {
+  constexpr int NW = FPS_THREADS / 64;
+  const unsigned un = (unsigned)n;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float px[REG ? FPS_MAXJ : 1], py[REG ? FPS_MAXJ : 1], pz[REG ? FPS_MAXJ : 1], md[REG ? FPS_MAXJ : 1];
-  float* tmp = temp + (long long)s * temp_stride;
   if (REG) {
 #pragma unroll
     for (int j = 0; j < FPS_MAXJ; ++j) {
@@ -50,11 +50,12 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps(const float* __restrict__ b
   } else {
     for (int k = tid; k < n; k += FPS_THREADS) tmp[k] = 1e10f;
   }
-  if (tid == 0) { out[0] = 0; s_cur[0] = p[0]; s_cur[1] = p[1]; s_cur[2] = p[2]; }
+  if (tid == 0) { out[0] = 0; s_win[0] = 0; s_x[0] = p[0]; s_y[0] = p[1]; s_z[0] = p[2]; }
   __syncthreads();
   for (int r = 1; r < m; ++r) {
-    const float cx = s_cur[0], cy = s_cur[1], cz = s_cur[2];
-    float bd = -2.f; int bk = 0x7fffffff;
+    const int wprev = s_win[0];                   // the wave whose candidate won the previous round
+    const float cx = s_x[wprev], cy = s_y[wprev], cz = s_z[wprev];
+    FpsBest b = {-2.f, 0x7fffffff, 0.f, 0.f, 0.f};
     int tl = tid;
     asm volatile("" : "+v"(tl));      // launder: stops LICM from hoisting 2 x FPS_MAXJ index/tie registers out of the round loop
     if (REG) {
@@ -65,36 +66,78 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps(const float* __restrict__ b
         float v = fminf(md[j], d);
         md[j] = v;
         int k = tl + j * FPS_THREADS;
-        if (fps_better(v, k, bd, bk, tmask, un)) { bd = v; bk = k; }
-        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound live temporaries: 160 VGPRs hold the points
+        const bool c = FIRST_WINS ? (v > b.d) : fps_better(v, k, b.d, b.k, tmask, un);
+        b.d = c ? v : b.d; b.k = c ? k : b.k;
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound live temporaries: the points stay register-resident
       }
     } else {
       for (int k = tid; k < n; k += FPS_THREADS) {
-        float dx = p[3 * k] - cx, dy = p[3 * k + 1] - cy, dz = p[3 * k + 2] - cz;
+        const float x = p[3 * k], y = p[3 * k + 1], z = p[3 * k + 2];
+        float dx = x - cx, dy = y - cy, dz = z - cz;
         float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
         float v = fminf(tmp[k], d);
         tmp[k] = v;
-        if (fps_better(v, k, bd, bk, tmask, un)) { bd = v; bk = k; }
+        fps_take(b, fps_better(v, k, b.d, b.k, tmask, un), v, k, x, y, z);
       }
     }
+    if (REG) {
+      // wave arg-max of (distance, index) alone: the register-resident path re-reads the winner's coordinates from global memory (L2)
+      // below - every way of taking them out of the owner lane's registers (selects in the point loop, a uniform switch, scalar-
+      // condition selects after the butterfly) tipped the 128-VGPR allocation of this 1024-thread kernel into thousands of spills
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      float od = __shfl_xor(bd, o, 64); int ok = __shfl_xor(bk, o, 64);
-      if (fps_better(od, ok, bd, bk, tmask, un)) { bd = od; bk = ok; }
+      for (int o = 32; o > 0; o >>= 1) {
+        const float od = __shfl_xor(b.d, o, 64); const int ok = __shfl_xor(b.k, o, 64);
+        const bool c = fps_better(od, ok, b.d, b.k, tmask, un);
+        b.d = c ? od : b.d; b.k = c ? ok : b.k;
+      }
+      const int kw = __builtin_amdgcn_readfirstlane(b.k);
+      // every wave's candidate re-reads ITS coordinates from global memory (L2) now: 16 loads in flight underneath the barrier and wave
+      // 0's reduction, instead of one dependent load of the winner after them
+      float wx = 0.f, wy = 0.f, wz = 0.f;
+      if (lane == 0) { wx = p[3 * kw]; wy = p[3 * kw + 1]; wz = p[3 * kw + 2]; s_d[wid] = b.d; s_k[wid] = kw; }
+      __syncthreads();
+      if (lane == 0) { s_x[wid] = wx; s_y[wid] = wy; s_z[wid] = wz; }
+    } else {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) fps_merge_shfl(b, o, tmask, un);
+      if (lane == 0) { s_d[wid] = b.d; s_k[wid] = b.k; }
+      __syncthreads();
+      if (lane == 0) { s_x[wid] = b.x; s_y[wid] = b.y; s_z[wid] = b.z; }      // behind the barrier: a slow wave may still be reading s_x[wprev]
     }
-    if (lane == 0) { s_d[wid] = bd; s_k[wid] = bk; }
-    __syncthreads();
     if (wid == 0) {
-      float d2 = lane < NW ? s_d[lane] : -3.f; int k2 = lane < NW ? s_k[lane] : 0x7fffffff;
+      float d2 = lane < NW ? s_d[lane] : -3.f; int k2 = lane < NW ? s_k[lane] : 0x7fffffff; int w2 = lane;
 #pragma unroll
       for (int o = NW / 2; o > 0; o >>= 1) {
-        float od = __shfl_xor(d2, o, 64); int ok = __shfl_xor(k2, o, 64);
-        if (fps_better(od, ok, d2, k2, tmask, un)) { d2 = od; k2 = ok; }
+        const float od = __shfl_xor(d2, o, 64); const int ok = __shfl_xor(k2, o, 64), ow = __shfl_xor(w2, o, 64);
+        const bool c = fps_better(od, ok, d2, k2, tmask, un);
+        d2 = c ? od : d2; k2 = c ? ok : k2; w2 = c ? ow : w2;
       }
-      if (lane == 0) { out[r] = k2; s_cur[0] = p[3 * k2]; s_cur[1] = p[3 * k2 + 1]; s_cur[2] = p[3 * k2 + 2]; }
+      if (lane == 0) { out[r] = k2; s_win[0] = w2; }
     }
-    __syncthreads();
+    __syncthreads();      // (s_x / s_win are rewritten only behind the NEXT round's first barrier: every thread has read them by then)
   }
+}
+
+template <bool REG>
+__global__ __launch_bounds__(FPS_THREADS) void k_fps(const float* __restrict__ base, const long long* __restrict__ set_off,
+                                                    const int* __restrict__ set_n, int m, int* __restrict__ out_idx,
+                                                    float* __restrict__ temp, long long temp_stride) {
+  constexpr int NW = FPS_THREADS / 64;
+  __shared__ float s_d[NW], s_x[NW], s_y[NW], s_z[NW];
+  __shared__ int s_k[NW], s_win[1];
+  __shared__ float s_cur[3];
+  const int s = blockIdx.x;
+  const float* p = base + set_off[s];
+  const int n = set_n[s];
+  int* out = out_idx + (long long)s * m;
+  if (n <= 0) { for (int j = threadIdx.x; j < m; j += FPS_THREADS) out[j] = 0; return; }
+  int T = 1;
+  while ((T << 1) <= n && (T << 1) <= 1024) T <<= 1;
+  float* tmp = temp + (long long)s * temp_stride;
+  // register-resident points + first-maximum-wins for sets of >= 1024 points; smaller sets (and sets beyond the register budget) stream
+  // their running minima through `temp` with the general tie rule (uniform branch: one path per workgroup)
+  if (REG && T == FPS_THREADS) fps_rounds<true, true>(p, n, m, out, tmp, (unsigned)T - 1u, s_d, s_k, s_x, s_y, s_z, s_cur, s_win);
+  else fps_rounds<false, false>(p, n, m, out, tmp, (unsigned)T - 1u, s_d, s_k, s_x, s_y, s_z, s_cur, s_win);
 }
 
 extern "C" int32_t u3d_fps(const float* base, const int64_t* set_off, const int32_t* set_n, int32_t nsets, int32_t max_n,

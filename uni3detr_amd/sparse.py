@@ -216,13 +216,14 @@ def _split3(w):
 
 def _split_table(geom, which, n_rows, plane):
     """int32 [3K, ld] = (t, t, t + plane): the table side - the third product reads the lo plane, `plane` rows below the hi plane.
-    which: "fwd" / "bwd" / "wgrad" (the latter [2K, ld] = (t, t + plane): the two products whose second operand is dy's hi plane).
+    which: "fwd" / "bwd" / "id" (identity: a plain row product) / "wgrad" ([2K, ld] = (t, t + plane): the two products whose second
+    operand is dy's hi plane).
     Cached on the geometry (static for the dense lattice; the sparse levels' geometries live for one step)."""
     cache = geom.__dict__.setdefault("_split_tables", {})
     key = (which, plane)
     if key not in cache:
-        t = geom.nbr_bwd if which == "bwd" else geom.nbr_fwd
-        if t is None:                                   # 1x1x1: the identity table
+        t = geom.nbr_bwd if which == "bwd" else (None if which == "id" else geom.nbr_fwd)
+        if t is None:                                   # 1x1x1 (or "id": a plain product over n_rows rows): the identity table
             t = torch.arange(n_rows, dtype=torch.int32, device=geom.n_out_dev.device).view(1, -1)
         elif isinstance(t, nv.RevNbr):
             t = t.t.flip(0)
@@ -417,8 +418,17 @@ def _split_backward_impl(ctx, xs, wc, dout):
         dwk = (a[:kvol] + a[kvol:] + b).reshape(ctx.kio_shape).to(ctx.wdtype)
         dw = dwk.permute(4, 3, 0, 1, 2) if ctx.layout == "oidhw" else dwk
     if ctx.needs_input_grad[0]:
-        t3 = _split_table(g, "bwd", g.n_in, n_out)
-        din = nv.spconv_fwd_split(dys, _split3(wc), t3, g.n_in_dev, g.n_in, cin, tag="spconv_dgrad")
+        if (STRIDED_DGRAD_SPLIT and g.strided and kvol > 1 and (kvol * cin) % 64 == 0
+                and n_out * (STRIDED_SPLIT_SPARSE_RATIO if g.kind == "sparse" else STRIDED_SPLIT_MIN_RATIO) <= g.n_in):
+            # strided conv: per-offset products over the (few) OUTPUT rows - one split product with the identity table, [n_out, K * Cin]
+            # f32 - then the gather over the offsets that reach each input row (as the bf16 path, u3d_tap_gather_sum; the
+            # output-stationary form runs all K x 3 products for every input row, 15/16 of them on absent neighbours at stride 4)
+            tid = _split_table(g, "id", n_out, n_out)
+            prod = nv.spconv_fwd_split(dys, _split3(wc.reshape(1, kvol * cin, cout)), tid, g.n_out_dev, n_out, kvol * cin, tag="spconv_dgrad")
+            din = nv.tap_gather_sum(prod, g.nbr_bwd, g.n_in_dev, g.n_in, cin, kvol)
+        else:
+            t3 = _split_table(g, "bwd", g.n_in, n_out)
+            din = nv.spconv_fwd_split(dys, _split3(wc), t3, g.n_in_dev, g.n_in, cin, tag="spconv_dgrad")
         fan = ctx.fan_token
         if fan is not None:
             if fan.acc is not None:
