@@ -174,6 +174,15 @@ int32_t u3d_linear_bf16(const void* x, const void* w, const float* bias, int32_t
  * per-tile BatchNorm sums of the f32 output.  U3D_ERR_UNSUPPORTED unless Cin % 64 == 0 and Cout % 64 == 0. */
 int32_t u3d_igemm_fwd_split_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, float* out, const int32_t* n_out_dev,
                                  int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol3, double* stats, u3d_stream s);
+/* The same product on the NARROW 27-offset sparse levels (cin, cout in {16, 32, 64}, not 64 -> 64; the encoder's stride-1 / stride-2
+ * stages, ref: sparse_encoder_hd.py:140-214): three launches of the direct-operand kernel (igemm_direct.hip) accumulating into one f32
+ * output - no tripled table: in = the bf16 planes [2 * n_in_cap][cin], w3 = (wh, wl, wh) n-major [3 * 27][cout][cin], nbr / ld as
+ * u3d_igemm_fwd_bf16 (ld < 0: the forward table read reversed = the SubM input gradient), out f32 [n_out_cap][cout]. */
+int32_t u3d_igemm_direct_split_bf16(const void* in, const void* w3, const int32_t* nbr, int32_t ld, float* out, const int32_t* n_out_dev,
+                                    int32_t n_out_cap, int32_t n_in_cap, int32_t cin, int32_t cout, u3d_stream s);
+/* The weight side of the same product: dst bf16 [3][k][a][b] = (hi, lo, hi) of the f32 element src[ik * sk + ia * sa + ib * sb]
+ * (element strides: the checkpoint layouts [kD,kH,kW,Cin,Cout] and [Cout,Cin,kD,kH,kW] are read in place). */
+int32_t u3d_split3_weights(const float* src, int64_t sk, int64_t sa, int64_t sb, int32_t k, int32_t a, int32_t b, void* dst, u3d_stream s);
 /* dst bf16 [2 * n_cap][c]: rows [0, n) = bf16(x), rows [n_cap, n_cap + n) = bf16(x - hi), n = min(*n_dev, n_cap); c % 4 == 0. */
 int32_t u3d_split_rows_f32(const float* x, const int32_t* n_dev, int32_t n_cap, int32_t c, void* dst, u3d_stream s);
 /* Forward with n-major weights w[K][Cout][Cin] (the layout u3d_igemm_fwd_bf16 takes with transpose_w = 1) that also emits the

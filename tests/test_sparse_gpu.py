@@ -1124,7 +1124,8 @@ def test_split_rows_is_an_exact_two_term_expansion(cuda):
 
 
 @pytest.mark.parametrize("cin,cout,kvol,wide_rows", [(64, 64, 27, False), (64, 128, 27, False), (128, 128, 27, False), (128, 256, 1, False),
-                                                     (256, 256, 27, True)])
+                                                     (256, 256, 27, True), (16, 16, 27, False), (16, 32, 27, False), (32, 32, 27, False),
+                                                     (32, 64, 27, False), (64, 32, 27, False)])
 def test_split_bf16_conv_forward_backward_match_f32_oracle(cuda, cin, cout, kvol, wide_rows):
     """_SparseConv inside sparse.split_scope(): forward, input gradient and weight gradient against oracle/geometry.py's f32 conv at
     5e-5 of the result's scale (bf16 kernels on bf16-rounded operands sit at 1e-2: this is f32-grade), incl. the fused BatchNorm
@@ -1154,12 +1155,22 @@ def test_split_bf16_conv_forward_backward_match_f32_oracle(cuda, cin, cout, kvol
     xd, wd = x.to(cuda).requires_grad_(True), torch.nn.Parameter(w.to(cuda))
     with sp.split_scope(True):
         y, stats = sp._SparseConv.apply(xd, wd, geom, "dhwio", True, None, None)
-    assert y.dtype == torch.float32 and stats.numel() > 0            # the split kernels served it, statistics included
-    y.backward(gy.to(cuda))
+    narrow = cin % 64 != 0 or cout % 64 != 0                         # the direct-operand kernels: three accumulating launches, no statistics
+    assert y.dtype == torch.float32 and (stats.numel() > 0) == (not narrow)
+    calls = []
+    real = nv.spconv_fwd
+    nv.spconv_fwd = lambda *a, **k: (calls.append(1), real(*a, **k))[1]          # the exact-f32 kernels must not be what served the backward
+    try:
+        y.backward(gy.to(cuda))
+    finally:
+        nv.spconv_fwd = real
+    assert not calls
     tol = 5e-5
     assert (y.detach().cpu() - yr.detach()).abs().max().item() <= tol * yr.abs().max().item()
     assert (xd.grad.cpu() - xr.grad).abs().max().item() <= tol * xr.grad.abs().max().item()
     assert (wd.grad.cpu() - wr.grad).abs().max().item() <= tol * wr.grad.abs().max().item()
+    if narrow:
+        return
     tr = stats._u3d_tile_rows
     s = stats.sum(0).cpu()
     np.testing.assert_allclose(s[0].numpy(), y.detach().double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4 * float(y.abs().max()) * n ** 0.5)

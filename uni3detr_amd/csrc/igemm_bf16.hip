@@ -108,7 +108,7 @@ __device__ __forceinline__ void bn_bwd_tile_sums(const BnEpi bn, u16* smem, int 
 #endif
 int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev, int n_out_cap,
                             int cin, int cout, int kvol, int transpose_w, hipStream_t s, const void* addend = nullptr,
-                            double* stats = nullptr, int* stats_blocks = nullptr);
+                            double* stats = nullptr, int* stats_blocks = nullptr, int f32acc = 0);
 #ifndef IGEMM_SMALL_PF
 #define IGEMM_SMALL_PF 1   /* stages of operand loads in flight in the 16/32-channel kernels (1: the wide layers' one-stage pipeline) */
 #endif
@@ -1401,6 +1401,29 @@ extern "C" int32_t u3d_split_rows_f32(const float* x, const int32_t* n_dev, int3
   const long long n4 = (long long)n_cap * c / 4;
   const int blocks = (int)(n4 / 256 + 1 < 4096 ? n4 / 256 + 1 : 4096);
   hipLaunchKernelGGL(k_split_rows_f32, dim3(blocks), dim3(256), 0, s, x, n_dev, n_cap, c, (u16*)dst);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+// the weight side of a split-bf16 product: dst bf16 [3][K][A][B] = (hi, lo, hi) of src[k * sk + a * sa + b * sb] (f32, any layout:
+// the checkpoint layouts [kD,kH,kW,Cin,Cout] / [Cout,Cin,kD,kH,kW] are read in place, no re-laid-out f32 copy in between)
+__global__ __launch_bounds__(256) void k_split3_weights(const float* __restrict__ src, long long sk, long long sa, long long sb, int K, int A,
+                                                        int B, u16* __restrict__ dst) {
+  const long long n = (long long)K * A * B;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int b = (int)(i % B), a = (int)((i / B) % A), k = (int)(i / ((long long)A * B));
+    const float v = src[k * sk + a * sa + b * sb];
+    const u16 h = f2bf(v);
+    const u16 l = f2bf(v - __uint_as_float((unsigned)h << 16));
+    dst[i] = h; dst[n + i] = l; dst[2 * n + i] = h;
+  }
+}
+extern "C" int32_t u3d_split3_weights(const float* src, int64_t sk, int64_t sa, int64_t sb, int32_t k, int32_t a, int32_t b, void* dst,
+                                      u3d_stream s) {
+  U3D_REQUIRE(src && dst && k > 0 && a > 0 && b > 0, U3D_ERR_ARG);
+  const long long n = (long long)k * a * b;
+  const int blocks = (int)(n / 256 + 1 < 2048 ? n / 256 + 1 : 2048);
+  hipLaunchKernelGGL(k_split3_weights, dim3(blocks), dim3(256), 0, s, src, (long long)sk, (long long)sa, (long long)sb, k, a, b, (u16*)dst);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

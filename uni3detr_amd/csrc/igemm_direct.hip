@@ -65,7 +65,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 //     rows past n_out (and tiles past this wave's slab) get -1 by OR-ing a per-tile lane mask into the index BEFORE it is permuted;
 //   * index loads are buffer loads: per-tile row offset in a VGPR, the offset's table row as the scalar offset;
 //   * weight fragments and permuted indices are requested one offset ahead (LDS round trips are not hidden by two waves per SIMD).
-template <int KS, int WN, bool W_KMAJOR, int NW, int P, bool STATS = false>
+// F32ACC (split-bf16 products of the fp32 modules' narrow levels, u3d_igemm_direct_split_bf16): `out` is an F32 matrix and `addend`
+// is only a FLAG - non-null: the tile is added to what `out` holds (the second and third of the three products hi.wh + hi.wl + lo.wh).
+template <int KS, int WN, bool W_KMAJOR, int NW, int P, bool STATS = false, bool F32ACC = false>
 __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr, int ld,
                                                   u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap, int cin, int cout,
                                                   int co0, const u16* __restrict__ addend, double* __restrict__ stats) {
@@ -261,6 +263,14 @@ __device__ __forceinline__ void igemm_direct_body(const u16* __restrict__ in, co
 #pragma unroll
           for (int b = 0; b < WN; ++b) {
 #if !(defined(DIR_EXP) && (DIR_EXP & 8))                        /* timing experiment (wrong results): nothing stored except by the last tile */
+            if constexpr (F32ACC) {
+              if (m < n_out) {
+                float* of = (float*)out + (long long)m * cout + co0 + b * 16 + g * 4;
+                f32x4 v = acc[a][b];
+                if (addend) v += *(const f32x4*)of;
+                *(f32x4*)of = v;
+              }
+            } else
             if (m < n_out) {
               f32x4 v = acc[a][b];
               // addend (nullable): a bf16 tensor of out's shape summed in before the rounding (the residual branch's gradient)
@@ -348,12 +358,24 @@ U3D_DIRECT_KERNEL_S(k_igemm_direct_32x32_ns, 1, 2, DIR_NW_A, DIR_P1)
 U3D_DIRECT_KERNEL_S(k_igemm_direct_64x16_ns, 2, 1, DIR_NW_A, DIR_P2)
 U3D_DIRECT_KERNEL_S(k_igemm_direct_64x32_ns, 2, 2, DIR_NW_B, DIR_P2)
 
+#define U3D_DIRECT_KERNEL_F(NAME, KS, WN, NW, P)                                                                                     \
+  __global__ __launch_bounds__(NW * 64, DIR_WAVES_PER_SIMD) void NAME(const u16* in, const u16* w, const int* nbr, int ld, u16* out, const int* n_out_dev, \
+                                                  int n_out_cap, int cin, int cout, int co0, const u16* addend, double* stats) {   \
+    igemm_direct_body<KS, WN, false, NW, P, false, true>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, co0, addend, stats);       \
+  }
+U3D_DIRECT_KERNEL_F(k_igemm_direct_32x16_nf, 1, 1, DIR_NW_A, DIR_P1)
+U3D_DIRECT_KERNEL_F(k_igemm_direct_32x32_nf, 1, 2, DIR_NW_A, DIR_P1)
+U3D_DIRECT_KERNEL_F(k_igemm_direct_32x64_nf, 1, 4, DIR_NW_B, DIR_P1)
+U3D_DIRECT_KERNEL_F(k_igemm_direct_64x16_nf, 2, 1, DIR_NW_A, DIR_P2)
+U3D_DIRECT_KERNEL_F(k_igemm_direct_64x32_nf, 2, 2, DIR_NW_B, DIR_P2)
+
 typedef void (*direct_kernel_t)(const u16*, const u16*, const int*, int, u16*, const int*, int, int, int, int, const u16*, double*);
 
 // 0 = launched, U3D_ERR_UNSUPPORTED = shape not served here (caller falls through to the tiled kernels)
 int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, int ld, void* out, const int32_t* n_out_dev, int n_out_cap,
                             int cin, int cout, int kvol, int transpose_w, hipStream_t s, const void* addend, double* stats,
-                            int* stats_blocks) {
+                            int* stats_blocks, int f32acc) {
+  // f32acc: 0 = bf16 output (+ bf16 addend); 1 / 2 = F32 output of an n-major launch, written (1) or accumulated into (2)
   // stats_blocks != nullptr: a QUERY - nothing is launched, *stats_blocks = number of per-wave statistics partials a launch writes
   if (kvol != DIR_K || !nbr || (cin != 16 && cin != 32 && cin != 64) || (cout != 16 && cout != 32 && cout != 64))
     return U3D_ERR_UNSUPPORTED;
@@ -381,6 +403,15 @@ int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, i
   DIR_PICK(2, 32, k_igemm_direct_64x32_k, k_igemm_direct_64x32_n, DIR_NW_B)
 #undef DIR_PICK
   if (!kern) return U3D_ERR_UNSUPPORTED;
+  if (f32acc) {
+    if (!transpose_w || stats || stats_blocks || halves == 2) return U3D_ERR_UNSUPPORTED;
+    if (ks == 1 && cout == 16) { kern = k_igemm_direct_32x16_nf; U3D_ALLOW_LDS(k_igemm_direct_32x16_nf, lds); }
+    if (ks == 1 && cout == 32) { kern = k_igemm_direct_32x32_nf; U3D_ALLOW_LDS(k_igemm_direct_32x32_nf, lds); }
+    if (ks == 1 && cout == 64) { kern = k_igemm_direct_32x64_nf; U3D_ALLOW_LDS(k_igemm_direct_32x64_nf, lds); }
+    if (ks == 2 && cout == 16) { kern = k_igemm_direct_64x16_nf; U3D_ALLOW_LDS(k_igemm_direct_64x16_nf, lds); }
+    if (ks == 2 && cout == 32) { kern = k_igemm_direct_64x32_nf; U3D_ALLOW_LDS(k_igemm_direct_64x32_nf, lds); }
+    addend = f32acc == 2 ? out : nullptr;                        // the F32ACC kernels read `addend` as the accumulate flag
+  }
   if (stats || stats_blocks) {                                   // statistics epilogue: n-major kernels with <= 32 output columns
     if (halves == 2 || !transpose_w || cout > 32) return U3D_ERR_UNSUPPORTED;
     if (ks == 1 && cout == 16) { kern = k_igemm_direct_32x16_ns; U3D_ALLOW_LDS(k_igemm_direct_32x16_ns, lds); }
@@ -413,4 +444,23 @@ int u3d_launch_igemm_direct(const void* in, const void* w, const int32_t* nbr, i
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin,
                        cout_total, h * 32, (const u16*)addend, stats);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
+}
+
+// Split-bf16 product on the narrow 27-offset levels (cin, cout in {16, 32, 64}, not 64 -> 64): the three products hi.wh + hi.wl +
+// lo.wh as three launches of the direct-operand kernel accumulating into ONE f32 output.  in: bf16 planes [2 * n_in_cap][cin]
+// (u3d_split_rows_f32), w3: bf16 [3 * 27][cout][cin] = (wh, wl, wh) n-major (u3d_split3_weights), nbr / ld as u3d_igemm_fwd_bf16
+// (ld < 0: reversed table), out f32 [n_out_cap][cout].
+extern "C" int32_t u3d_igemm_direct_split_bf16(const void* in, const void* w3, const int32_t* nbr, int32_t ld, float* out,
+                                               const int32_t* n_out_dev, int32_t n_out_cap, int32_t n_in_cap, int32_t cin, int32_t cout,
+                                               u3d_stream s) {
+  U3D_REQUIRE(in && w3 && nbr && out && n_out_dev && n_in_cap >= 0, U3D_ERR_ARG);
+  const u16* hi = (const u16*)in;
+  const u16* lo = hi + (long long)n_in_cap * cin;
+  const u16* wh = (const u16*)w3;
+  const u16* wl = wh + (long long)DIR_K * cout * cin;
+  int rc = u3d_launch_igemm_direct(hi, wh, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, DIR_K, 1, (hipStream_t)s, nullptr, nullptr, nullptr, 1);
+  if (rc != U3D_OK) return rc;
+  rc = u3d_launch_igemm_direct(hi, wl, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, DIR_K, 1, (hipStream_t)s, nullptr, nullptr, nullptr, 2);
+  if (rc != U3D_OK) return rc;
+  return u3d_launch_igemm_direct(lo, wh, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, DIR_K, 1, (hipStream_t)s, nullptr, nullptr, nullptr, 2);
 }

@@ -108,6 +108,8 @@ _SIGS = {
     "u3d_igemm_fwd_stats_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
     "u3d_igemm_fwd_split_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
     "u3d_split_rows_f32": (_I, [_P, _P, _I, _I, _P, _P]),
+    "u3d_split3_weights": (_I, [_P, C.c_int64, C.c_int64, C.c_int64, _I, _I, _I, _P, _P]),
+    "u3d_igemm_direct_split_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "u3d_igemm_dgrad_bnstats_bf16": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "u3d_bn_bwd_finalize_partials": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P]),
     "u3d_subm_halo_sizes": (_I, [_I, _P, _P, _P]),
@@ -693,6 +695,46 @@ def split_rows(x, n_dev, n_cap=None):
     assert x.dtype == torch.float32 and x.is_contiguous()
     out = torch.empty((2 * n_cap, x.shape[1]), dtype=torch.bfloat16, device=x.device)
     _check(lib().u3d_split_rows_f32(_ptr(x), _ptr(n_dev), n_cap, x.shape[1], _ptr(out), _stream()), "split_rows_f32")
+    return out
+
+
+def spconv_fwd_split_direct(xs, w3, nbr, n_out_dev, n_out, cout, tag="spconv_fwd"):
+    """Split-bf16 product on a narrow 27-offset level (u3d_igemm_direct_split_bf16): xs bf16 planes [2 * n_in, cin], w3 bf16
+    [81, cout, cin] = (wh, wl, wh), nbr the PLAIN table (or a RevNbr) -> f32 [n_out, cout]."""
+    cin, n_in = xs.shape[1], xs.shape[0] // 2
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=xs.device)
+    nbr_p, ld = _nbr_ptr_ld(nbr)
+    t = TIMER
+    e0 = t.begin() if t is not None else None
+    _check(lib().u3d_igemm_direct_split_bf16(_ptr(xs), _ptr(w3), nbr_p, ld, _ptr(out), _ptr(n_out_dev), n_out, n_in, cin, cout, _stream()),
+           "igemm_direct_split_bf16")
+    if t is not None:
+        meta = None
+        if t.mode == "census":
+            tab = nbr.t.flip(0) if isinstance(nbr, RevNbr) else nbr
+            pairs = int((tab[:, :n_out] >= 0).sum().item())
+            meta = dict(kind=CALL_KIND, v2=True, split=True, n_in=n_in, n_out=n_out, cin=cin, cout=cout, kvol=27, pairs=pairs,
+                        bytes=n_in * cin * 4 + n_out * cout * 4 + 8 * pairs + 27 * cin * cout * 4, flops=2 * pairs * cin * cout)
+        t.end(tag, e0, meta)
+    return out
+
+
+def split3_weights(weight, layout, nmajor):
+    """Conv PARAMETER (f32, checkpoint layout "dhwio" [kD,kH,kW,Cin,Cout] or "oidhw" [Cout,Cin,kD,kH,kW]) -> bf16 [3K, A, B] = (hi, lo, hi)
+    of its [K, Cout, Cin] (nmajor) or [K, Cin, Cout] view, read in place through element strides (u3d_split3_weights)."""
+    w = weight.detach()
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 5
+    if layout == "dhwio":
+        kd, kh, kw, cin, cout = w.shape
+        k = kd * kh * kw
+        sk, s_ci, s_co = cin * cout, cout, 1
+    else:
+        cout, cin, kd, kh, kw = w.shape
+        k = kd * kh * kw
+        sk, s_ci, s_co = 1, k, cin * k
+    a, b, sa, sb = (cout, cin, s_co, s_ci) if nmajor else (cin, cout, s_ci, s_co)
+    out = torch.empty((3 * k, a, b), dtype=torch.bfloat16, device=w.device)
+    _check(lib().u3d_split3_weights(_ptr(w), sk, sa, sb, k, a, b, _ptr(out), _stream()), "split3_weights")
     return out
 
 

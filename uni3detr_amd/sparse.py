@@ -203,15 +203,16 @@ def split_scope(on=True):
         _SPLIT[0] = prev
 
 
-def _split_serves(feats, cin, cout):
-    return _SPLIT[0] and feats.is_cuda and feats.dtype == torch.float32 and cin % 64 == 0 and cout % 64 == 0
-
-
-def _split3(w):
-    """f32 [K, A, B] -> bf16 [3K, A, B] = (hi, lo, hi): the weight side of hi.wh + hi.wl + lo.wh."""
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
-    return torch.cat([hi, lo, hi], 0)
+def _split_serves(feats, cin, cout, kvol=None):
+    """"wide": channels % 64 == 0 - the LDS-DMA kernels with tripled offsets; "narrow": the 27-offset 16 / 32 / 64-channel levels - three
+    accumulating launches of the direct-operand kernel (kvol=None: the caller only asks about "wide"); None: the exact f32 kernels."""
+    if not (_SPLIT[0] and feats.is_cuda and feats.dtype == torch.float32):
+        return None
+    if cin % 64 == 0 and cout % 64 == 0:
+        return "wide"
+    if kvol == 27 and cin in (16, 32, 64) and cout in (16, 32, 64):
+        return "narrow"
+    return None
 
 
 def _split_table(geom, which, n_rows, plane):
@@ -219,7 +220,8 @@ def _split_table(geom, which, n_rows, plane):
     which: "fwd" / "bwd" / "id" (identity: a plain row product) / "wgrad" ([2K, ld] = (t, t + plane): the two products whose second
     operand is dy's hi plane).
     Cached on the geometry (static for the dense lattice; the sparse levels' geometries live for one step)."""
-    cache = geom.__dict__.setdefault("_split_tables", {})
+    owner = geom.level if (getattr(geom, "level", None) is not None and which != "id") else geom      # SubM: one set per Level, not per conv
+    cache = owner.__dict__.setdefault("_split_tables", {})
     key = (which, plane)
     if key not in cache:
         t = geom.nbr_bwd if which == "bwd" else (None if which == "id" else geom.nbr_fwd)
@@ -249,7 +251,10 @@ class _SparseConv(torch.autograd.Function):
         kv = kio_shape[0] * kio_shape[1] * kio_shape[2]
         narrow = kv == 27 and cin in (16, 32, 64) and cout in (16, 32, 64) and not (cin == 64 and cout == 64)
         nmajor = NMAJOR_FWD and bf16 and ((cin % 64 == 0 and cout % 64 == 0) or narrow)
-        kio, koi = conv_weights(weight, layout, feats.dtype, want_koi=nmajor)
+        split = _split_serves(feats, cin, cout, kv)
+        if split == "narrow" and geom.nbr_fwd is None:
+            split = None
+        kio, koi = (None, None) if split else conv_weights(weight, layout, feats.dtype, want_koi=nmajor)
         ctx.geom, ctx.layout = geom, layout
         ctx.res_token = res_token
         ctx.fan_token = fan_token if (fan_token is not None and feats.requires_grad) else None
@@ -261,17 +266,23 @@ class _SparseConv(torch.autograd.Function):
         ctx.grad_view = getattr(weight, "_u3d_grad_view", None)
         ctx.kio_shape, ctx.wdtype = kio_shape, weight.dtype
         nv.CALL_KIND = geom.kind
-        ctx.split = _split_serves(feats, cin, cout)
+        ctx.split = split
         if ctx.split:
-            kio, koi = conv_weights(weight, layout, torch.float32, want_koi=True)
             n_in = feats.shape[0]
             xs = nv.split_rows(feats.contiguous(), geom.n_in_dev)                        # bf16 [2 * n_in, cin]: hi | lo planes
-            ctx.save_for_backward(xs, kio)                                               # the weight gradient reads the planes
+            ctx.save_for_backward(xs, weight)                                            # the weight gradient reads the planes
             ctx.halo = False
-            t3 = _split_table(geom, "fwd", geom.n_out, n_in)
-            res = nv.spconv_fwd_split(xs, _split3(koi), t3, geom.n_out_dev, geom.n_out, cout, want_stats=want_stats)
+            w3 = nv.split3_weights(weight, layout, nmajor=True)                          # [3K, cout, cin], straight from the parameter
+            if split == "narrow":
+                y = nv.spconv_fwd_split_direct(xs, w3, geom.nbr_fwd, geom.n_out_dev, geom.n_out, cout)
+                res = (y, None, 0)
+            else:
+                t3 = _split_table(geom, "fwd", geom.n_out, n_in)
+                res = nv.spconv_fwd_split(xs, w3, t3, geom.n_out_dev, geom.n_out, cout, want_stats=want_stats)
+                if not want_stats:
+                    return res
             if not want_stats:
-                return res
+                return res[0]
             y, stats, tr = res
             if stats is None:
                 stats = torch.empty(0, dtype=torch.float64, device=feats.device)
@@ -406,10 +417,32 @@ def _split_backward_impl(ctx, xs, wc, dout):
     weights); dW = x^T dy ~ xh^T dyh + xl^T dyh + xh^T dyl: two launches of the bf16 weight-gradient kernel (offsets doubled for the
     two products against dy's hi plane), summed in f32."""
     g = ctx.geom
-    kvol, cin, cout = wc.shape
+    ks = ctx.kio_shape
+    kvol, cin, cout = ks[0] * ks[1] * ks[2], ks[3], ks[4]
     n_in, n_out = xs.shape[0] // 2, dout.shape[0]
     dys = nv.split_rows(dout.float() if dout.dtype != torch.float32 else dout, g.n_out_dev)      # bf16 [2 * n_out, cout]
     din = dw = None
+    if ctx.split == "narrow":
+        if ctx.needs_input_grad[1]:
+            # three launches of the narrow weight-gradient kernels on plane views (the table indexes rows of a plane): no doubled table
+            xh, xl, dyh, dyl = xs[:n_in], xs[n_in:], dys[:n_out], dys[n_out:]
+            dwk = nv.spconv_wgrad(xh, dyh, g.nbr_fwd, g.n_out_dev, kvol) + nv.spconv_wgrad(xl, dyh, g.nbr_fwd, g.n_out_dev, kvol)
+            dwk = (dwk + nv.spconv_wgrad(xh, dyl, g.nbr_fwd, g.n_out_dev, kvol)).reshape(ctx.kio_shape).to(ctx.wdtype)
+            dw = dwk.permute(4, 3, 0, 1, 2) if ctx.layout == "oidhw" else dwk
+        if ctx.needs_input_grad[0]:
+            din = nv.spconv_fwd_split_direct(dys, nv.split3_weights(wc, ctx.layout, nmajor=False), g.nbr_bwd, g.n_in_dev, g.n_in, cin,
+                                             tag="spconv_dgrad")
+            fan, tok = ctx.fan_token, ctx.res_token
+            if fan is not None:
+                if fan.acc is not None:
+                    din += fan.acc
+                din = fan.step(din)
+            if tok is not None and tok.dres is not None:
+                din = din + tok.dres
+                tok.dres = None
+        elif ctx.res_token is not None:
+            ctx.res_token.dres = None
+        return din, dw, None, None, None, None, None, None
     if ctx.needs_input_grad[1]:
         ta = _split_table(g, "wgrad", n_out, n_in)                                         # [2K, ld]: (nbr, nbr + n_in)
         tb = ta[:kvol]
@@ -424,11 +457,12 @@ def _split_backward_impl(ctx, xs, wc, dout):
             # f32 - then the gather over the offsets that reach each input row (as the bf16 path, u3d_tap_gather_sum; the
             # output-stationary form runs all K x 3 products for every input row, 15/16 of them on absent neighbours at stride 4)
             tid = _split_table(g, "id", n_out, n_out)
-            prod = nv.spconv_fwd_split(dys, _split3(wc.reshape(1, kvol * cin, cout)), tid, g.n_out_dev, n_out, kvol * cin, tag="spconv_dgrad")
+            wt3 = nv.split3_weights(wc, ctx.layout, nmajor=False).view(3, kvol * cin, cout)      # [K, Cin, Cout] as ONE [K * Cin, Cout] matrix
+            prod = nv.spconv_fwd_split(dys, wt3, tid, g.n_out_dev, n_out, kvol * cin, tag="spconv_dgrad")
             din = nv.tap_gather_sum(prod, g.nbr_bwd, g.n_in_dev, g.n_in, cin, kvol)
         else:
             t3 = _split_table(g, "bwd", g.n_in, n_out)
-            din = nv.spconv_fwd_split(dys, _split3(wc), t3, g.n_in_dev, g.n_in, cin, tag="spconv_dgrad")
+            din = nv.spconv_fwd_split(dys, nv.split3_weights(wc, ctx.layout, nmajor=False), t3, g.n_in_dev, g.n_in, cin, tag="spconv_dgrad")
         fan = ctx.fan_token
         if fan is not None:
             if fan.acc is not None:
@@ -464,7 +498,7 @@ def conv_bn(feats, weight, geom, bn, n_dev, residual=None, relu=True, layout="dh
             fan_token=None, bn_in=None, bn_out=None):
     """conv -> BatchNorm rows (+ residual) (+ ReLU).  In training the conv's epilogue already reduces the BatchNorm statistics per row
     tile where its kernel supports it (bf16, channels % 64 == 0): the separate statistics pass over the conv output disappears."""
-    if FUSED_CONV_STATS and bn.training and feats.is_cuda and (feats.dtype == torch.bfloat16 or _split_serves(feats, feats.shape[1], bn.num_features)):
+    if FUSED_CONV_STATS and bn.training and feats.is_cuda and (feats.dtype == torch.bfloat16 or _split_serves(feats, feats.shape[1], bn.num_features) == "wide"):
         # res_take: this conv's input is the identity of a residual block - its backward sums the token's gradient into the input
         # gradient; res_give: this BatchNorm adds that identity - its backward leaves the identity's gradient in the token
         # fan_token: this conv is one of several that take the same input (FanoutToken)
