@@ -273,3 +273,33 @@ def test_bf16_fused_backward_equals_unfused_composition_and_tracks_the_oracle(cu
     loose = ("pts_bbox_head.reg_branches", "pts_bbox_head.refpoint_embed", "pts_bbox_head.tgt_embed")
     near = [(k, e) for k, (e, _) in dev_f.items() if k.startswith(NEAR) and not e <= (BF16_REG_TOL if k.startswith(loose) else BF16_NEAR_TOL)]
     assert not near, f"bf16 gradients next to the loss off the oracle: {near[:8]}"
+
+
+def test_mixed_recipe_gradients_are_closer_to_fp32_than_bf16_mode(cuda):
+    """`mixed` (the reference's recipe: fp32 encoder + backbone - here as split-bf16 products -, 16-bit neck + head) against the float64
+    oracle under its own matching, next to the all-bf16 mode: the fp32 modules stop injecting rounding noise of their own, what is
+    left is the 16-bit neck's noise amplified on the way down.  Gates: every gradient finite and present, the neck / head tensors within
+    the bf16 gates, and the median deviation of the encoder's and the backbone's gradients below the all-bf16 mode's."""
+    model, sd = _model(cuda, "mixed")
+    names = {n for n, p in model.named_parameters() if p.requires_grad}
+    saved = []
+    for module, attr, value in AS_CAPTURED:
+        mod = importlib.import_module(module)
+        saved.append((mod, attr, getattr(mod, attr)))
+        setattr(mod, attr, value)
+    try:
+        got_m, loss_m, asg_m = _train_step_grads(model, cuda, overlap=True)
+    finally:
+        for mod, attr, old in saved:
+            setattr(mod, attr, old)
+    got_b, loss_b, asg_b, _, _ = _bf16_run(cuda, AS_CAPTURED)
+    dev_m = _deviations(got_m, _oracle_grads(sd, names, torch.float64, assigned=asg_m)[0], "mixed vs float64 oracle", 1e-4)
+    dev_b = _deviations(got_b, _oracle_grads(sd, names, torch.float64, assigned=asg_b)[0], "bf16 vs float64 oracle", 1e-4)
+    _report("mixed vs float64 oracle", dev_m)
+    gm, gb = _groups(dev_m), _groups(dev_b)
+    print(f"\n[grad parity mixed] per module (median, max, n): {gm}\n   all-bf16 mode: {gb}")
+    for mod in ("pts_middle_encoder", "pts_backbone"):
+        assert gm[mod][0] <= gb[mod][0], (mod, gm[mod], gb[mod])
+    loose = ("pts_bbox_head.reg_branches", "pts_bbox_head.refpoint_embed", "pts_bbox_head.tgt_embed")
+    near = [(k, e) for k, (e, _) in dev_m.items() if k.startswith(NEAR) and not e <= (BF16_REG_TOL if k.startswith(loose) else BF16_NEAR_TOL)]
+    assert not near, near[:8]
