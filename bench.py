@@ -460,11 +460,11 @@ def main():
         if not args.no_cpu_baseline and world == 1 and args.config == "sunrgbd":      # the CPU leg is quoted on the headline workload only
             faulthandler.cancel_dump_traceback_later()       # CPU leg: no GPU work can hang here
             out["cpu_baseline"] = cpu_baseline(args.points)
-            if args.precision == "bf16":
-                # checker leg: deviation of the benched (bf16) mode from the fp32 CPU oracle on the same workload shape, 2 scenes;
+            if args.precision in ("bf16", "mixed"):
+                # checker leg: deviation of the benched mode from the fp32 CPU oracle on the same workload shape, 2 scenes;
                 # gated by tests/test_bf16_parity_gpu.py (tolerances stated there)
                 from oracle.parity_bf16 import bf16_deviation
-                out["bf16_vs_fp32_oracle"] = bf16_deviation(dev, B=2, npts=args.points)
+                out[f"{args.precision}_vs_fp32_oracle"] = bf16_deviation(dev, B=2, npts=args.points, mode=args.precision)
         result_line = json.dumps(out)
     else:
         result_line = None

@@ -193,14 +193,34 @@ SPLIT_BF16 = os.environ.get("U3D_SPLIT_BF16", "1") == "1"
 _SPLIT = [False]
 
 
+# hi / lo planes that already exist for an f32 row matrix: an earlier conv split the same rows (SECOND3D's three branches read one
+# input; a residual block's input feeds its first conv once).  Keyed by the rows' address; the entry holds the row tensor itself, so
+# the address cannot be handed to another tensor while the entry lives.  (Writing the planes from the BatchNorm apply that produces
+# the rows - one pass less per layer - was built and measured time-neutral, 216.0 vs 217.2 scenes/s: the extra 4 B / element of stores
+# cost what the saved read gains; removed.)
+_PLANES = {}
+
+
+def _planes_of(feats, n_dev):
+    ent = _PLANES.get(feats.data_ptr())
+    if ent is not None and ent[0].shape == feats.shape and ent[0].dtype == feats.dtype and ent[0]._version == ent[2] == feats._version:
+        return ent[1]
+    xs = nv.split_rows(feats.contiguous(), n_dev)
+    if feats.is_contiguous():
+        _PLANES[feats.data_ptr()] = (feats, xs, feats._version)
+    return xs
+
+
 @contextlib.contextmanager
 def split_scope(on=True):
     prev = _SPLIT[0]
     _SPLIT[0] = bool(on) and SPLIT_BF16
+    _PLANES.clear()
     try:
         yield
     finally:
         _SPLIT[0] = prev
+        _PLANES.clear()
 
 
 def _split_serves(feats, cin, cout, kvol=None):
@@ -269,7 +289,7 @@ class _SparseConv(torch.autograd.Function):
         ctx.split = split
         if ctx.split:
             n_in = feats.shape[0]
-            xs = nv.split_rows(feats.contiguous(), geom.n_in_dev)                        # bf16 [2 * n_in, cin]: hi | lo planes
+            xs = _planes_of(feats, geom.n_in_dev)                                        # bf16 [2 * n_in, cin]: hi | lo planes
             ctx.save_for_backward(xs, weight)                                            # the weight gradient reads the planes
             ctx.halo = False
             w3 = nv.split3_weights(weight, layout, nmajor=True)                          # [3K, cout, cin], straight from the parameter
