@@ -32,6 +32,25 @@ def test_fps_matches_oracle_packed_and_voxel(cuda):
         assert np.array_equal(idx[s], ref), s
 
 
+def test_fps_small_and_mixed_sets_in_one_launch(cuda):
+    """One launch over sets of very different sizes: below 1024 points the upstream tie rule's T is smaller than the workgroup (general
+    two-key compare), from 1024 on it degenerates to first-maximum-wins inside a thread (k_fps' two round loops); integer-lattice points
+    make ties the rule; an empty set yields zeros; fewer points than samples repeats as the reference does."""
+    rng = np.random.default_rng(4)
+    ns = [1, 37, 300, 1023, 1024, 1025, 5000, 0]
+    sets = [rng.integers(0, 6, (n, 3)).astype(np.float32) for n in ns]
+    offs, o = [], 0
+    for p in sets:
+        offs.append(o); o += p.size
+    base = torch.from_numpy(np.concatenate([p.reshape(-1) for p in sets] + [np.zeros(3, np.float32)])).to(cuda)
+    idx = nv.fps(base, torch.tensor(offs, dtype=torch.int64, device=cuda), torch.tensor(ns, dtype=torch.int32, device=cuda), max(ns), 64).cpu().numpy()
+    for s, n in enumerate(ns):
+        if n == 0:
+            assert not idx[s].any()
+        else:
+            assert np.array_equal(idx[s], om.fps_packed(sets[s].reshape(-1), n, 64)), (s, n)
+
+
 def test_fps_large_set_streaming_path(cuda):
     p = np.random.default_rng(0).random((50000, 3)).astype(np.float32)
     base = torch.from_numpy(p.reshape(-1)).to(cuda)

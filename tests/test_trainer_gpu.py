@@ -57,6 +57,26 @@ def test_graph_step_matches_eager_step(cuda):
     assert le[-1] < le[0]                         # and it trains
 
 
+def test_mixed_precision_graph_step_matches_eager_and_trains(cuda):
+    """`mixed` (fp32 encoder + backbone as split-bf16 products, 16-bit neck + head): the captured step - staged stage-1 graphs, FPS graph
+    on its second stream - follows the eager step's loss trajectory from the same weights, and the loss goes down."""
+    pts, gts, labels = _data(cuda)
+    ref = _model(cuda).set_precision("mixed")
+    sd = copy.deepcopy(ref.state_dict())
+    eager = TrainStep(ref, pts, gts, labels, graph=False)
+    le = [float(eager.step()) for _ in range(4)]
+    m2 = _model(cuda, sd).set_precision("mixed")
+    ts = TrainStep(m2, pts, gts, labels, graph=True)
+    snap = ts.snapshot()
+    ts.capture()
+    ts.restore(snap)
+    assert isinstance(ts._graphs[0], tuple) and len(ts.fps_stream_calibration_ms) == 8       # voxelize | FPS | features | head graphs
+    lg = [float(ts.step()) for _ in range(4)]
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-2 * abs(a), (le, lg)
+    assert le[-1] < le[0] and lg[-1] < lg[0]
+
+
 def test_capacity_overflow_is_reported(cuda):
     pts, gts, labels = _data(cuda, n=6000)
     m = _model(cuda)

@@ -34,7 +34,7 @@ __device__ __forceinline__ void fps_merge_shfl(FpsBest& b, int o, unsigned tmask
 
 template <bool REG, bool FIRST_WINS>
 __device__ __forceinline__ void fps_rounds(const float* __restrict__ p, int n, int m, int* __restrict__ out, float* __restrict__ tmp,
-                                           unsigned tmask, float* s_d, int* s_k, float* s_x, float* s_y, float* s_z, float* s_cur, int* s_win) {
+                                           unsigned tmask, float* s_d, int* s_k, float* s_x, float* s_y, float* s_z, int* s_win) {
   constexpr int NW = FPS_THREADS / 64;
   const unsigned un = (unsigned)n;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -125,7 +125,6 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps(const float* __restrict__ b
   constexpr int NW = FPS_THREADS / 64;
   __shared__ float s_d[NW], s_x[NW], s_y[NW], s_z[NW];
   __shared__ int s_k[NW], s_win[1];
-  __shared__ float s_cur[3];
   const int s = blockIdx.x;
   const float* p = base + set_off[s];
   const int n = set_n[s];
@@ -134,10 +133,10 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps(const float* __restrict__ b
   int T = 1;
   while ((T << 1) <= n && (T << 1) <= 1024) T <<= 1;
   float* tmp = temp + (long long)s * temp_stride;
-  // register-resident points + first-maximum-wins for sets of >= 1024 points; smaller sets (and sets beyond the register budget) stream
-  // their running minima through `temp` with the general tie rule (uniform branch: one path per workgroup)
-  if (REG && T == FPS_THREADS) fps_rounds<true, true>(p, n, m, out, tmp, (unsigned)T - 1u, s_d, s_k, s_x, s_y, s_z, s_cur, s_win);
-  else fps_rounds<false, false>(p, n, m, out, tmp, (unsigned)T - 1u, s_d, s_k, s_x, s_y, s_z, s_cur, s_win);
+  // first-maximum-wins for sets of >= 1024 points, the general tie rule for smaller ones (uniform branch: one path per workgroup); both
+  // register-resident in the REG kernel (`temp` may be null there), both streaming through `temp` in the other
+  if (REG && T == FPS_THREADS) fps_rounds<true, true>(p, n, m, out, tmp, (unsigned)T - 1u, s_d, s_k, s_x, s_y, s_z, s_win);
+  else fps_rounds<REG, false>(p, n, m, out, tmp, (unsigned)T - 1u, s_d, s_k, s_x, s_y, s_z, s_win);
 }
 
 extern "C" int32_t u3d_fps(const float* base, const int64_t* set_off, const int32_t* set_n, int32_t nsets, int32_t max_n,
