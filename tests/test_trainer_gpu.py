@@ -77,6 +77,59 @@ def test_mixed_precision_graph_step_matches_eager_and_trains(cuda):
     assert le[-1] < le[0] and lg[-1] < lg[0]
 
 
+def test_dynamic_voxelization_step_is_captured(cuda):
+    """ScanNet-large style configuration (dynamic voxelization + DynamicSimpleVFE, ref: uni3detr.py:155-171,
+    uni3detr_scannet_large.py:28-31): the voxel list is capacity-sized with its count on the device, so the whole step captures
+    (no host read of the voxel count) and follows the eager step; a batch that outgrows the list is reported by check_capacities."""
+    from uni3detr_amd.configs import variants
+    from uni3detr_amd.synth import room_scene
+    cfg = copy.deepcopy(variants.scannet_large)
+    rng_range = tuple(cfg["pts_voxel_layer"]["point_cloud_range"])
+    ncls = cfg["pts_bbox_head"]["num_classes"]
+
+    def data(seed0, n):
+        pts, gts, labels = [], [], []
+        for i in range(2):
+            p, g, l = room_scene(seed0 + i, n, pc_range=rng_range)
+            gb = torch.from_numpy(g).clone()
+            gb[:, 2] -= gb[:, 5] / 2
+            pts.append(torch.from_numpy(p).to(cuda)); gts.append(Boxes3D(gb).to(cuda)); labels.append((torch.from_numpy(l) % ncls).to(cuda))
+        return pts, gts, labels
+
+    def model(sd=None):
+        torch.manual_seed(5)
+        m = build_model(copy.deepcopy(cfg))
+        if sd is not None:
+            m.load_state_dict(sd)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if hasattr(mod, "attn_drop"):
+                mod.attn_drop = 0.0
+        return m.to(cuda).train().set_precision("bf16")
+
+    pts, gts, labels = data(0, 30000)
+    ref = model()
+    assert ref.dynamic_voxelization
+    sd = copy.deepcopy(ref.state_dict())
+    eager = TrainStep(ref, pts, gts, labels, graph=False)
+    le = [float(eager.step()) for _ in range(3)]
+    m2 = model(sd)
+    ts = TrainStep(m2, pts, gts, labels, graph=True)
+    snap = ts.snapshot()
+    ts.capture()
+    ts.restore(snap)
+    assert ts._graphs is not None and m2.pts_voxel_encoder.capacity is not None
+    lg = [float(ts.step()) for _ in range(3)]
+    ts.check_capacities()
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-2 * abs(a), (le, lg)
+    m2.pts_voxel_encoder.capacity = 256                         # a voxel list that is too short: reported, not silently truncated
+    ts.eager_step()
+    with pytest.raises(RuntimeError, match="overflow"):
+        ts.check_capacities()
+
+
 def test_capacity_overflow_is_reported(cuda):
     pts, gts, labels = _data(cuda, n=6000)
     m = _model(cuda)

@@ -42,6 +42,10 @@ class DynamicSimpleVFE(nn.Module):
         super().__init__()
         self.voxel_size, self.point_cloud_range = list(voxel_size), list(point_cloud_range)
         self.fp16_enabled = False
+        # static-shape mode (hipGraph capture, set by TrainStep.measure_capacities): the voxel list has `capacity` rows, the real count
+        # stays on the device (last_count_dev); None: exact size, one host read (as upstream's torch.unique)
+        self.capacity = None
+        self.last_count_dev = None
 
     def grid_dims(self):
         vs, pr = self.voxel_size, self.point_cloud_range
@@ -57,7 +61,14 @@ class DynamicSimpleVFE(nn.Module):
         g = nv.BitGrid(batch_size, self.grid_dims(), features.device, linear=True)
         g.mark(coors)
         g.scan()
-        n_vox = int(g.count_dev.item())
+        self.last_count_dev = g.count_dev
+        if self.capacity is None or not self.training:
+            n_vox = int(g.count_dev.item())
+        else:
+            # no host read: capacity-sized list, ranks past it come back as -1 (their points are dropped; the step's capacity flag
+            # reports it and the update is held - TrainStep), rows past the count stay (-1, ...) and zero
+            n_vox = int(self.capacity)
+            g.set_row_capacity(n_vox)
         rank = g.rank(coors)
         feats, _ = nv.scatter_mean(features.float().contiguous(), rank, n_vox)
         return feats, g.coords(n_vox)

@@ -218,7 +218,11 @@ class TrainStep:
         enc = getattr(m, "pts_middle_encoder", None)
         caps = getattr(enc, "level_capacities", None) if enc is not None else None
         if caps is not None and m.static_shapes:
-            nv.capacity_flag(list(enc.last_level_counts[1:1 + len(caps)]), caps, self._msg[L:])
+            cnts, cps = list(enc.last_level_counts[1:1 + len(caps)]), list(caps)
+            vfe = getattr(m, "pts_voxel_encoder", None)
+            if getattr(vfe, "capacity", None) is not None and vfe.last_count_dev is not None:      # dynamic voxelization: the voxel list too
+                cnts, cps = [vfe.last_count_dev] + cnts, [int(vfe.capacity)] + cps
+            nv.capacity_flag(cnts, cps, self._msg[L:])
         else:
             self._msg[L:].zero_()
         self._num_pos = self._msg[:L]
@@ -471,6 +475,9 @@ class TrainStep:
         m = self.model
         m.static_shapes = False
         m.pts_middle_encoder.level_capacities = None
+        vfe = getattr(m, "pts_voxel_encoder", None) if getattr(m, "dynamic_voxelization", False) else None
+        if vfe is not None:
+            vfe.capacity = None
         counts = None
         for b in (batches if batches else [None]):
             if b is not None:
@@ -480,6 +487,9 @@ class TrainStep:
             counts = c if counts is None else [max(a, b_) for a, b_ in zip(counts, c)]
         caps = [((int(c * self.capacity_margin) + 255) // 256) * 256 for c in counts[1:]]
         m.pts_middle_encoder.level_capacities = caps
+        if vfe is not None:
+            # dynamic voxelization: the voxel list itself (level 0) is capacity-sized too, with the count kept on the device
+            vfe.capacity = ((int(counts[0] * self.capacity_margin) + 255) // 256) * 256
         m.static_shapes = True
         return counts, caps
 
@@ -489,6 +499,11 @@ class TrainStep:
         for c, cap in zip(counts[1:], enc.level_capacities):
             if c > cap:
                 raise RuntimeError(f"sparse level overflow: {c} active rows > capacity {cap}; re-capture with a larger margin")
+        vfe = getattr(self.model, "pts_voxel_encoder", None)
+        if getattr(vfe, "capacity", None) is not None and vfe.last_count_dev is not None:
+            c = int(vfe.last_count_dev.item())
+            if c > int(vfe.capacity):
+                raise RuntimeError(f"sparse level overflow: {c} voxels > capacity {vfe.capacity} of the dynamic voxel list; re-capture with a larger margin")
         return counts
 
     def capture(self, warmup=3, keep_state=True, batches=None, remember_batches=True):
