@@ -270,3 +270,17 @@ def test_object_range_filter_on_device_and_all_shipped_pipelines_build(cuda):
         for key in ("train_pipeline", "test_pipeline"):
             pipe = dp.DevicePipeline(cfg[key])
             assert pipe.transforms or key == "test_pipeline", (name, key)
+
+
+def test_object_range_filter_on_a_batch_without_any_box(cuda):
+    """a batch whose scenes hold no GT box at all (plausible for KITTI / nuScenes at 2-4 scenes per GPU after filtering) must
+    pass through ObjectRangeFilter: zero live boxes per scene, nothing raised (an empty tensor has no device pointer to hand over)."""
+    from uni3detr_amd import datapath as dp
+    rng = np.random.default_rng(3)
+    pts = _scenes(rng, [100, 50])
+    batch = dp.pack_batch([torch.from_numpy(p).cuda() for p in pts], [torch.zeros((0, 7)).cuda(), torch.zeros((0, 7)).cuda()], box_type_3d="LiDAR",
+                          gt_labels_3d=[torch.zeros((0,), dtype=torch.int64).cuda(), torch.zeros((0,), dtype=torch.int64).cuda()])
+    batch = dp.ObjectRangeFilter([0, -40, -3, 70.4, 40, 1])(batch)
+    assert batch["gt_count"].tolist() == [0, 0]
+    _, gb, gl = dp.unpack_batch(batch)
+    assert all(b.tensor.shape[0] == 0 for b in gb) and all(l.numel() == 0 for l in gl)

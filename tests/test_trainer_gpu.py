@@ -379,6 +379,32 @@ def test_capacity_overflow_holds_the_update_and_recaptures_collectively(cuda):
             dist.destroy_process_group()
 
 
+def test_overflow_without_flat_update_recaptures_and_keeps_the_bound_batch(cuda):
+    """graph=True with flat_update=False has no device-side hold flag (torch.optim): step() must notice a level that
+    outgrew its captured capacity on the host BEFORE the backward / update, re-capture, and then train on the batch the caller had
+    bound - not on the last of the capture batches that recapture() cycles through the static buffers."""
+    pts, gts, labels = _data(cuda)
+    ctr = torch.tensor([0.0, 3.0, -0.7, 0.0], device=cuda)
+    small = [(p - ctr) * torch.tensor([0.2, 0.2, 0.2, 1.0], device=cuda) + ctr for p in pts]
+    m = _model(cuda)
+    ts = TrainStep(m, small, gts, labels, graph=True, flat_update=False, capacity_margin=1.0)
+    ts.capture(batches=[(small, gts, labels)])
+    ts.step()
+    assert ts.recaptures == 0
+    ts.set_batch(pts, gts, labels)                         # the real scenes overflow the squeezed scenes' capacities
+    bound = ts.pts["cat"].clone()
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    loss = float(ts.step())
+    assert ts.recaptures == 1 and torch.isfinite(torch.tensor(loss))
+    assert torch.equal(ts.pts["cat"], bound)               # the static input buffers hold the caller's batch again
+    ts.check_capacities()                                  # and the new capacities cover it
+    # the step that ran was a step on `pts` from the weights it started with (the re-capture's own warm-up steps were rolled back):
+    # its loss is the eager loss on that batch from those weights
+    eager = TrainStep(_model(cuda, before), pts, gts, labels, graph=False, flat_update=False, lr=0.0)
+    l_eager = float(eager.step())
+    assert abs(l_eager - loss) <= 2e-2 * abs(loss), (l_eager, loss)
+
+
 def test_optimizer_state_round_trip(cuda):
     """resume_from (ref: extra_tools/train.py:141-142): flat AdamW moments / step count exported and re-imported bit for bit."""
     pts, gts, labels = _data(cuda)
