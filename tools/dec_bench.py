@@ -21,6 +21,9 @@ def main():
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     head = build_model(MODEL_CFG).pts_bbox_head.to(dev).train()
+    eval_mode = os.environ.get("U3D_DEC_EVAL") == "1"          # no dropout, forward only: the attention kernel without its hash / mask VALU work
+    if eval_mode:
+        head = head.eval()
     dec = head.transformer.decoder
     fd = fdm.FusedDecoder(dec, head.reg_branches, head.cls_branches, head.iou_branches)
     B, G, nq, D, H, W = 8, 3, 300, 15, 40, 40
@@ -35,6 +38,10 @@ def main():
     plist = fdm.tensor_list(sp)
 
     def once():
+        if eval_mode:
+            with torch.no_grad():
+                fdm.FusedLayerFn.apply(x, None, ref, rows, meta, *plist)
+            return
         outs = fdm.FusedLayerFn.apply(x, None, ref, rows, meta, *plist)
         loss = outs[0].sum() + outs[2].sum() + outs[3].sum() + outs[4].sum()
         loss.backward()
