@@ -191,8 +191,10 @@ def main():
     # a sparse level outgrowing its captured capacity on ANY rank holds the step on all ranks (the flag rides the positive-count
     # all-reduce) and re-captures collectively: the process group is torn down for the capture and re-created afterwards
     pg_hooks = ((lambda: dist.destroy_process_group()), init_pg) if use_dist else None
+    # U3D_GRAD_COMM=bf16: exchange the gradient in bf16 (half the xGMI bytes; the f32 exchange is the default and what the parity tests pin)
+    comm_dt = torch.bfloat16 if os.environ.get("U3D_GRAD_COMM", "fp32") == "bf16" else torch.float32
     ts = TrainStep(model, data["points"], data["gt_bboxes_3d"], data["gt_labels_3d"], graph=not args.no_graph, overlap_reduce=overlap,
-                   pg_hooks=pg_hooks)
+                   pg_hooks=pg_hooks, grad_comm_dtype=comm_dt)
     caps = None
     launch_mode = "eager" if args.no_graph else "hipGraph"
     census, marker, mark_targets = None, None, []
@@ -310,7 +312,7 @@ def main():
             "dtype": {"bf16": "bf16", "fp32": "f32", "mixed": "f32 encoder+backbone (wide convs as split-bf16: 3 bf16 MFMA products, f32 accumulation) / bf16 neck+head"}[args.precision], "data": "synthetic",
             "config": {"workload": f"{wl['file']} (BASELINE {wl['baseline']}): train step fwd+loss+bwd+clip+AdamW, "
                                    f"{args.batch} scenes/GPU x {args.points} pts, {nq_cfg} queries x 3 groups, random-init weights",
-                       "global_batch": joined * args.batch, "parallelism": f"dp{joined}", "rccl_ranks": joined if use_dist else 0,
+                       "global_batch": joined * args.batch, "parallelism": f"dp{joined}", "rccl_ranks": joined if use_dist else 0, "gradient_exchange_dtype": str(comm_dt).replace("torch.", ""),
                        "launcher": ("self (bench.py --gpus N)" if os.environ.get("U3D_SELF_LAUNCHED") == "1" else
                                     ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process")),
                        "final_loss": loss_val,

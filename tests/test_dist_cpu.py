@@ -45,15 +45,28 @@ def _worker(rank, world, port, q):
         from uni3detr_amd.trainer import TrainStep
         g = torch.Generator().manual_seed(7)
         local = [torch.randn(1000, generator=g) * (r + 1) for r in range(world)]
-        st = SimpleNamespace(dist_on=True, world=world, flat_grad=local[rank].clone(), enc_end=384, _work=None,
+        class _Stub(SimpleNamespace):                      # the reductions call each other through self
+            _comm_view = TrainStep._comm_view
+            _all_reduce_slice = TrainStep._all_reduce_slice
+        st = _Stub(dist_on=True, world=world, flat_grad=local[rank].clone(), enc_end=384, _work=None, grad_comm_dtype=torch.float32, _comm=None,
                              _msg=torch.tensor([30.0, 20.0, 10.0, 1.0 if rank == 1 else 0.0]) * torch.tensor([rank + 1.0] * 3 + [1.0]))
         TrainStep._reduce_grads_a(st)
         assert st._work is not None
         TrainStep._reduce_grads_b(st)
         assert st._work is None and torch.allclose(st.flat_grad, sum(local) / world, atol=1e-6)
-        st2 = SimpleNamespace(dist_on=True, world=world, flat_grad=local[rank].clone())
+        st2 = _Stub(dist_on=True, world=world, flat_grad=local[rank].clone(), grad_comm_dtype=torch.float32, _comm=None)
         TrainStep._reduce_grads(st2)
         assert torch.allclose(st2.flat_grad, st.flat_grad, atol=1e-6)
+        # (3b) the bf16 exchange option: same buckets, staged through a bf16 buffer - the mean to bf16 precision, identical on all ranks
+        st3 = _Stub(dist_on=True, world=world, flat_grad=local[rank].clone(), enc_end=384, _work=None, _work_buf=None, _comm=None)
+        st3.grad_comm_dtype = torch.bfloat16
+        TrainStep._reduce_grads_a(st3)
+        TrainStep._reduce_grads_b(st3)
+        exact = sum(local) / world
+        assert st3._work is None and float((st3.flat_grad - exact).abs().max()) <= 2.0 ** -7 * float(exact.abs().max())
+        gathered = [torch.empty_like(st3.flat_grad) for _ in range(world)]
+        dist.all_gather(gathered, st3.flat_grad)
+        assert all(torch.equal(gathered[0], t) for t in gathered)
         TrainStep._reduce_num_pos(st)
         assert torch.allclose(st._msg[:3], torch.tensor([45.0, 30.0, 15.0])) and float(st._msg[3]) > 0.0      # rank 1's overflow holds rank 0 too
         q.put((rank, "ok"))

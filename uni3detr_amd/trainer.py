@@ -35,10 +35,16 @@ FPS_LAUNCH_ORDER = os.environ.get("U3D_FPS_ORDER", "early")      # A/B: which of
 class TrainStep:
     def __init__(self, model, points, gt_bboxes_3d, gt_labels_3d, lr=1e-4, weight_decay=0.01, max_norm=10.0, graph=True,
                  capacity_margin=1.25, flat_update=True, overlap_reduce=False, betas=(0.9, 0.999), eps=1e-8, gt_capacity=64,
-                 check_every=50, pg_hooks=None, fps_graph=None):
+                 check_every=50, pg_hooks=None, fps_graph=None, grad_comm_dtype=torch.float32):
         """pg_hooks: (teardown, setup) callables that destroy / re-create the default process group; needed only for a collective
         re-capture after a capacity overflow on a multi-rank run (bench.py passes them)."""
         self.model = model
+        # gradient exchange dtype (N > 1): float32 (default: the all-reduced gradient is the exact mean) or bfloat16 - half the xGMI
+        # bytes (63 instead of 127 MB per step), the mean rounded to 8 mantissa bits per hop of the ring (what torch's bf16 DDP
+        # compression hook trades too); the master gradient / moments stay f32 either way
+        assert grad_comm_dtype in (torch.float32, torch.bfloat16)
+        self.grad_comm_dtype = grad_comm_dtype
+        self._comm = None
         # captured step: the FPS rounds as their own graph on a second stream next to the encoder / dense stack (see capture())
         self.fps_graph = (os.environ.get("U3D_FPS_GRAPH", "1") == "1") if fps_graph is None else bool(fps_graph)
         self._fps_stream = None
@@ -84,7 +90,7 @@ class TrainStep:
         model.cut_encoder_backward = self.overlap
         self.n_enc = n_enc
         self.enc_end = self.offsets[n_enc] if self.overlap else 0          # flat offset where phase A's slice starts
-        self._work = None
+        self._work = self._work_buf = None
         if flat_update:
             # parameters re-homed into ONE flat buffer (each p.data becomes a view; names/shapes/state_dict unchanged), moments flat:
             # clip + AdamW is u3d_adamw_step - three launches that stream the 7 arrays once (torch: ~30 multi-tensor launches)
@@ -345,25 +351,43 @@ class TrainStep:
         self._gx = None
         self.model._encoder_out = self.model._encoder_cut = None
 
+    def _comm_view(self, lo, hi):
+        """bf16 staging slice for flat_grad[lo:hi] (allocated once: static addresses, one cast launch each way)."""
+        if self._comm is None or self._comm.numel() != self.flat_grad.numel():
+            self._comm = torch.empty(self.flat_grad.numel(), dtype=torch.bfloat16, device=self.flat_grad.device)
+        return self._comm[lo:hi]
+
+    def _all_reduce_slice(self, lo, hi, async_op=False):
+        """Mean over ranks of flat_grad[lo:hi], in place; -> (work or None, staging slice or None)."""
+        a = self.flat_grad[lo:hi]
+        a.div_(self.world)
+        if self.grad_comm_dtype == torch.float32:
+            return dist.all_reduce(a, async_op=async_op), None
+        buf = self._comm_view(lo, hi)
+        buf.copy_(a)
+        w = dist.all_reduce(buf, async_op=async_op)
+        if not async_op:
+            a.copy_(buf)
+            return w, None
+        return w, buf
+
     def _reduce_grads_a(self):
         if self.dist_on:
-            a = self.flat_grad[self.enc_end:]
-            a.div_(self.world)
-            self._work = dist.all_reduce(a, async_op=True)          # in flight underneath phase B
+            n = self.flat_grad.numel()
+            self._work, self._work_buf = self._all_reduce_slice(self.enc_end, n, async_op=True)          # in flight underneath phase B
 
     def _reduce_grads_b(self):
         if self.dist_on:
             if self._work is not None:
                 self._work.wait()
-                self._work = None
-            b = self.flat_grad[:self.enc_end]
-            b.div_(self.world)
-            dist.all_reduce(b)
+                if getattr(self, "_work_buf", None) is not None:
+                    self.flat_grad[self.enc_end:].copy_(self._work_buf)
+                self._work = self._work_buf = None
+            self._all_reduce_slice(0, self.enc_end)
 
     def _reduce_grads(self):
         if self.dist_on:
-            self.flat_grad.div_(self.world)
-            dist.all_reduce(self.flat_grad)
+            self._all_reduce_slice(0, self.flat_grad.numel())
 
     def _stage3(self):
         if self.flat_update:
@@ -605,7 +629,7 @@ class TrainStep:
                 raise RuntimeError("sparse level overflow on a multi-rank run and no pg_hooks=(teardown, setup) to re-capture with: "
                                    "capture with a larger capacity_margin or more representative `batches`")
             if self._work is not None:
-                self._work.wait(); self._work = None
+                self._work.wait(); self._work = self._work_buf = None
             torch.cuda.synchronize()
             dist.barrier()
             self.pg_hooks[0]()
