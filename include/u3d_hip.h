@@ -374,6 +374,30 @@ int32_t u3d_scatter_rows(const void* in, const int32_t* idx, int32_t n, int32_t 
  * ---------------------------------------------------------------------------------------------- */
 int32_t u3d_fps(const float* base, const int64_t* set_off, const int32_t* set_n, int32_t nsets, int32_t max_n,
                 int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, u3d_stream s);
+/* the same over two buffers: sets [0, split) are offsets into base, sets [split, nsets) into base2 */
+int32_t u3d_fps2(const float* base, const float* base2, int32_t split, const int64_t* set_off, const int32_t* set_n,
+                 int32_t nsets, int32_t max_n, int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, u3d_stream s);
+/* The detector's glue around its two FPS passes (ref: models/detectors/uni3detr.py:178-189), one launch each side.
+ *   u3d_fps_prep: vox f32 [v_rows,3] = float (z,y,x) of coors int32 [v_rows,4] (b,z,y,x); set descriptors for u3d_fps2 with
+ *     split = batch: sets 0..B-1 = the packed-triple view of the [N,nfeat] point buffer from row scene_off[b] (offset
+ *     scene_off[b]*nfeat, n = scene_off[b+1]-scene_off[b]); sets B..2B-1 = the voxel rows voxel_off[b]..voxel_off[b+1]
+ *     (offset voxel_off[b]*3 into vox).  set_off int64 [2B], set_n int32 [2B].
+ *   u3d_fps_points: idx int32 [2B,m] (u3d_fps2's output) -> out f32 [B,2m,3]: rows 0..m-1 = the sampled points' (x,y,z),
+ *     rows m..2m-1 = the sampled voxel coordinates as (x,y,z), each group mapped to the unit cube by its per-scene
+ *     min / max over the m samples (shift_scale_points, ref :18-46: (x - lo) / (hi - lo)). */
+int32_t u3d_fps_prep(const int32_t* coors, int32_t v_rows, const int32_t* scene_off, const int32_t* voxel_off, int32_t batch,
+                     int32_t nfeat, float* vox, int64_t* set_off, int32_t* set_n, u3d_stream s);
+int32_t u3d_fps_points(const float* pts, int32_t nfeat, const float* vox, const int32_t* idx, const int32_t* scene_off,
+                       const int32_t* voxel_off, int32_t batch, int32_t m, float* out, u3d_stream s);
+/* Query assembly of Uni3DETRHead.forward (ref: dense_heads/uni3detr_head.py:436-455) in one launch: `groups` query groups of nq
+ * queries; group 0 = (tgt[:nq], anchor), group g >= 1 = (tgt[nq:], inverse_sigmoid(points of group g)) with the points of
+ * groups 1, 2 in fps f32 [B,2nq,3] and of group 3 (eval layout) in rnd f32 [B,nq,3].  tgt f32 [2nq,c], anchor f32 [nq,3].
+ * Outputs: query_embeds f32 [B,G*nq,c+3] and its two column blocks as contiguous tensors, query [B,G*nq,c], ref [B,G*nq,3].
+ * _bwd: d_tgt [2nq,c], d_anchor [nq,3] = sums over scenes (and sharing groups) of the output gradients (each may be null). */
+int32_t u3d_query_embed_fwd(const float* tgt, const float* anchor, const float* fps, const float* rnd, int32_t batch, int32_t nq,
+                            int32_t groups, int32_t c, float* query_embeds, float* query, float* ref, u3d_stream s);
+int32_t u3d_query_embed_bwd(const float* d_query_embeds, const float* d_query, const float* d_ref, int32_t batch, int32_t nq,
+                            int32_t groups, int32_t c, float* d_tgt, float* d_anchor, u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * Matching (ref: core/bbox/assigners/hungarian_assigner_3d.py:53-151; match_costs/match_cost.py:19-30,91-97; upstream

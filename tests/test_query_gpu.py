@@ -59,6 +59,52 @@ def test_fps_large_set_streaming_path(cuda):
     assert np.array_equal(idx[0], om.fps_packed(p.reshape(-1), 50000, 64))
 
 
+def test_fused_fps_queries_match_oracle_bit_exact(cuda):
+    """u3d_fps_prep | u3d_fps2 | u3d_fps_points (the detector's three-launch form of uni3detr.py:178-189) against the oracle's
+    fps_queries: sampled indices identical, unit-cube points bit-identical (one subtraction and one correctly rounded division each)."""
+    pl = [room_scene(i, 20000 - 3000 * i)[0] for i in range(3)]
+    _, rc, _ = og.voxelize_batch(pl, SUNRGBD_VOXEL, SUNRGBD_RANGE, 5, 16000)
+    ref = om.fps_queries(pl, rc, dict(num_query=300, fps_packed_quirk=True)).numpy()
+    cat = torch.from_numpy(np.concatenate(pl)).to(cuda)
+    lens = [p.shape[0] for p in pl]
+    scene_off = torch.tensor(np.cumsum([0] + lens), dtype=torch.int32, device=cuda)
+    vlens = [int((rc[:, 0] == b).sum()) for b in range(3)]
+    voxel_off = torch.tensor(np.cumsum([0] + vlens), dtype=torch.int32, device=cuda)
+    coors = torch.from_numpy(np.concatenate([rc, -np.ones((100, 4), rc.dtype)])).int().to(cuda)      # capacity rows past the count: (-1, ...)
+    out, idx = nv.fps_queries(cat, coors, scene_off, voxel_off, 3, max(max(lens), 16000), 300)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    for b in range(3):
+        assert np.array_equal(idx[b].cpu().numpy(), om.fps_packed(pl[b].reshape(-1), lens[b], 300))
+
+
+@pytest.mark.parametrize("groups", [3, 4])
+def test_fused_query_embed_matches_torch_formulation(cuda, groups):
+    """u3d_query_embed_fwd / _bwd against the cat / expand / inverse_sigmoid formulation of uni3detr_head.py:436-455 (train: 3 groups,
+    eval: 4 with a random-point group), forward bit-exact up to the log, gradients of both embeddings to f32 summation order."""
+    from uni3detr_amd.plugin.head import _QueryEmbed
+    from uni3detr_amd.plugin.transformer import inverse_sigmoid
+    torch.manual_seed(0)
+    B, nq, c = 4, 300, 256
+    tgt = torch.randn(2 * nq, c, device=cuda, requires_grad=True)
+    anchor = torch.randn(nq, 3, device=cuda, requires_grad=True)
+    fps = torch.rand(B, 2 * nq, 3, device=cuda)
+    fps[0, 0] = torch.tensor([0.0, 1.0, 1e-7], device=cuda)                                # the clamps' corner cases
+    rnd = torch.rand(B, nq, 3, device=cuda) if groups == 4 else None
+    qe, q, r = _QueryEmbed.apply(tgt, anchor, fps, rnd, groups)
+    refs = [anchor.unsqueeze(0).expand(B, -1, -1), inverse_sigmoid(fps)] + ([inverse_sigmoid(rnd)] if groups == 4 else [])
+    tgts = [tgt[:nq]] + [tgt[nq:]] * (groups - 1)
+    exp = torch.cat([torch.cat(tgts).unsqueeze(0).expand(B, -1, -1), torch.cat(refs, 1)], -1)
+    assert torch.allclose(qe, exp, rtol=1e-6, atol=1e-6)
+    assert torch.equal(q, qe[..., :c]) and torch.equal(r, qe[..., c:])
+    w1, w2, w3 = torch.randn_like(qe), torch.randn_like(q), torch.randn_like(r)
+    g = torch.autograd.grad((qe * w1).sum() + (q * w2).sum() + (r * w3).sum(), [tgt, anchor])
+    ge = torch.autograd.grad((exp * w1).sum() + (exp[..., :c] * w2).sum() + (exp[..., c:] * w3).sum(), [tgt, anchor])
+    for a, b_ in zip(g, ge):
+        assert torch.allclose(a, b_, rtol=1e-5, atol=1e-5)
+    g2 = torch.autograd.grad((q * w2).sum(), [tgt, anchor], allow_unused=True)             # only one output used: the others' gradients are None
+    assert torch.allclose(g2[0], torch.autograd.grad((exp[..., :c] * w2).sum(), tgt)[0], rtol=1e-5, atol=1e-5)
+
+
 def _fixture():
     z = np.load(os.path.join(G, "head_train_b2.npz"))
     gts, labels, o = [], [], 0

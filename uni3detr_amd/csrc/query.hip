@@ -119,14 +119,15 @@ __device__ __forceinline__ void fps_rounds(const float* __restrict__ p, int n, i
 }
 
 template <bool REG>
-__global__ __launch_bounds__(FPS_THREADS) void k_fps(const float* __restrict__ base, const long long* __restrict__ set_off,
+__global__ __launch_bounds__(FPS_THREADS) void k_fps(const float* __restrict__ base, const float* __restrict__ base2, int split,
+                                                    const long long* __restrict__ set_off,
                                                     const int* __restrict__ set_n, int m, int* __restrict__ out_idx,
                                                     float* __restrict__ temp, long long temp_stride) {
   constexpr int NW = FPS_THREADS / 64;
   __shared__ float s_d[NW], s_x[NW], s_y[NW], s_z[NW];
   __shared__ int s_k[NW], s_win[1];
   const int s = blockIdx.x;
-  const float* p = base + set_off[s];
+  const float* p = (s < split ? base : base2) + set_off[s];      // sets [split, nsets) live in a second buffer (u3d_fps2)
   const int n = set_n[s];
   int* out = out_idx + (long long)s * m;
   if (n <= 0) { for (int j = threadIdx.x; j < m; j += FPS_THREADS) out[j] = 0; return; }
@@ -139,15 +140,190 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps(const float* __restrict__ b
   else fps_rounds<REG, false>(p, n, m, out, tmp, (unsigned)T - 1u, s_d, s_k, s_x, s_y, s_z, s_win);
 }
 
-extern "C" int32_t u3d_fps(const float* base, const int64_t* set_off, const int32_t* set_n, int32_t nsets, int32_t max_n,
-                           int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, u3d_stream s) {
-  U3D_REQUIRE(base && set_off && set_n && out_idx && nsets > 0 && m > 0, U3D_ERR_ARG);
+static int fps_launch(const float* base, const float* base2, int split, const int64_t* set_off, const int32_t* set_n, int32_t nsets,
+                      int32_t max_n, int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, hipStream_t s) {
+  U3D_REQUIRE(base && base2 && set_off && set_n && out_idx && nsets > 0 && m > 0, U3D_ERR_ARG);
   if (max_n <= FPS_THREADS * FPS_MAXJ) {
-    hipLaunchKernelGGL(k_fps<true>, dim3(nsets), dim3(FPS_THREADS), 0, s, base, (const long long*)set_off, set_n, m, out_idx, temp, (long long)temp_stride);
+    hipLaunchKernelGGL(k_fps<true>, dim3(nsets), dim3(FPS_THREADS), 0, s, base, base2, split, (const long long*)set_off, set_n, m, out_idx, temp, (long long)temp_stride);
   } else {
     U3D_REQUIRE(temp && temp_stride >= max_n, U3D_ERR_WORKSPACE);
-    hipLaunchKernelGGL(k_fps<false>, dim3(nsets), dim3(FPS_THREADS), 0, s, base, (const long long*)set_off, set_n, m, out_idx, temp, (long long)temp_stride);
+    hipLaunchKernelGGL(k_fps<false>, dim3(nsets), dim3(FPS_THREADS), 0, s, base, base2, split, (const long long*)set_off, set_n, m, out_idx, temp, (long long)temp_stride);
   }
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+extern "C" int32_t u3d_fps(const float* base, const int64_t* set_off, const int32_t* set_n, int32_t nsets, int32_t max_n,
+                           int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, u3d_stream s) {
+  return fps_launch(base, base, nsets, set_off, set_n, nsets, max_n, m, out_idx, temp, temp_stride, (hipStream_t)s);
+}
+// the same over TWO buffers: sets [0, split) are offsets into `base`, sets [split, nsets) into `base2` (the detector's raw-point sets
+// and voxel-coordinate sets without a concatenated copy of both)
+extern "C" int32_t u3d_fps2(const float* base, const float* base2, int32_t split, const int64_t* set_off, const int32_t* set_n,
+                            int32_t nsets, int32_t max_n, int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, u3d_stream s) {
+  U3D_REQUIRE(split >= 0 && split <= nsets, U3D_ERR_ARG);
+  return fps_launch(base, base2, split, set_off, set_n, nsets, max_n, m, out_idx, temp, temp_stride, (hipStream_t)s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The detector's glue around the two FPS passes of a batch (ref: models/detectors/uni3detr.py:178-189), one launch each side:
+//   k_fps_prep:   float-cast (z,y,x) voxel coordinates + the 2B set descriptors (B raw-point sets in the packed-triple view of the
+//                 [N,F] point buffer, B voxel-coordinate sets)
+//   k_fps_points: gather the sampled raw points (x,y,z) / voxel coordinates ((z,y,x) -> (x,y,z)), per-scene min / max over the m
+//                 samples, affine map to the unit cube (shift_scale_points, ref :18-46), both groups concatenated: out [B, 2m, 3]
+// ---------------------------------------------------------------------------------------------
+__global__ void k_fps_prep(const int* __restrict__ coors, int v_rows, const int* __restrict__ scene_off, const int* __restrict__ voxel_off,
+                           int B, int F, float* __restrict__ vox, long long* __restrict__ set_off, int* __restrict__ set_n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < v_rows) {
+    const int4 c = ((const int4*)coors)[i];
+    vox[3 * i] = (float)c.y; vox[3 * i + 1] = (float)c.z; vox[3 * i + 2] = (float)c.w;
+  }
+  if (i < B) {
+    set_off[i] = (long long)scene_off[i] * F;
+    set_n[i] = scene_off[i + 1] - scene_off[i];
+    set_off[B + i] = (long long)voxel_off[i] * 3;
+    set_n[B + i] = voxel_off[i + 1] - voxel_off[i];
+  }
+}
+extern "C" int32_t u3d_fps_prep(const int32_t* coors, int32_t v_rows, const int32_t* scene_off, const int32_t* voxel_off, int32_t batch,
+                                int32_t nfeat, float* vox, int64_t* set_off, int32_t* set_n, u3d_stream s) {
+  U3D_REQUIRE(scene_off && voxel_off && vox && set_off && set_n && batch > 0 && nfeat >= 3 && v_rows >= 0 && (coors || v_rows == 0), U3D_ERR_ARG);
+  const int n = v_rows > batch ? v_rows : batch;
+  hipLaunchKernelGGL(k_fps_prep, dim3(u3d_cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, coors, v_rows, scene_off, voxel_off, batch, nfeat, vox,
+                     (long long*)set_off, set_n);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+__global__ __launch_bounds__(256) void k_fps_points(const float* __restrict__ pts, int F, const float* __restrict__ vox,
+                                                    const int* __restrict__ idx, const int* __restrict__ scene_off,
+                                                    const int* __restrict__ voxel_off, int B, int m, float* __restrict__ out) {
+  __shared__ float s_lo[4][3], s_hi[4][3];
+  const int b = blockIdx.x, which = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int* ix = idx + ((long long)which * B + b) * m;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  auto fetch = [&](int j, float* v) {
+    if (which == 0) {
+      const float* p = pts + ((long long)scene_off[b] + ix[j]) * F;
+      v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+    } else {
+      const float* p = vox + ((long long)voxel_off[b] + ix[j]) * 3;
+      v[0] = p[2]; v[1] = p[1]; v[2] = p[0];                        // (z,y,x) voxel coordinates -> (x,y,z)
+    }
+  };
+  for (int j = tid; j < m; j += 256) {
+    float v[3];
+    fetch(j, v);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], v[c]); hi[c] = fmaxf(hi[c], v[c]); }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o, 64)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o, 64)); }
+    if (lane == 0) { s_lo[wid][c] = lo[c]; s_hi[wid][c] = hi[c]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    lo[c] = fminf(fminf(s_lo[0][c], s_lo[1][c]), fminf(s_lo[2][c], s_lo[3][c]));
+    hi[c] = fmaxf(fmaxf(s_hi[0][c], s_hi[1][c]), fmaxf(s_hi[2][c], s_hi[3][c]));
+  }
+  float* o = out + ((long long)b * 2 * m + (long long)which * m) * 3;
+  for (int j = tid; j < m; j += 256) {
+    float v[3];
+    fetch(j, v);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[3 * j + c] = __fdiv_rn(__fsub_rn(v[c], lo[c]), __fsub_rn(hi[c], lo[c]));      // ((x - lo) * (1 - 0)) / (hi - lo) + 0
+  }
+}
+extern "C" int32_t u3d_fps_points(const float* pts, int32_t nfeat, const float* vox, const int32_t* idx, const int32_t* scene_off,
+                                  const int32_t* voxel_off, int32_t batch, int32_t m, float* out, u3d_stream s) {
+  U3D_REQUIRE(pts && vox && idx && scene_off && voxel_off && out && batch > 0 && m > 0 && nfeat >= 3, U3D_ERR_ARG);
+  hipLaunchKernelGGL(k_fps_points, dim3(batch, 2), dim3(256), 0, (hipStream_t)s, pts, nfeat, vox, idx, scene_off, voxel_off, batch, m, out);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Query assembly of Uni3DETRHead.forward (ref: dense_heads/uni3detr_head.py:436-455): G query groups of nq queries each,
+//   group 0: (tgt_embed[:nq], refpoint_embed), groups g >= 1: (tgt_embed[nq:], inverse_sigmoid(points of group g)) -
+//   query [B, G*nq, 256] | ref_logits [B, G*nq, 3] and their concatenation query_embeds [B, G*nq, 259] in ONE launch (the reference:
+//   3 cats, 2 expands, an inverse_sigmoid of 6 element-wise ops); backward: the batch / group sums of the two embeddings' gradients.
+//   points: fps [B, 2*nq, 3] (groups 1, 2) and, in the 4-group eval layout, rand [B, nq, 3] (group 3)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float inv_sigmoid_ref(float x) {      // torch: x.clamp(0, 1); log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+  const float eps = 1e-5f;
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  return logf(__fdiv_rn(fmaxf(x, eps), fmaxf(__fsub_rn(1.f, x), eps)));
+}
+__global__ __launch_bounds__(256) void k_query_embed(const float* __restrict__ tgt, const float* __restrict__ anchor,
+                                                     const float* __restrict__ fps, const float* __restrict__ rnd, int B, int nq, int G,
+                                                     int C, float* __restrict__ qe, float* __restrict__ query, float* __restrict__ ref) {
+  const long long row = blockIdx.x;                        // b * G*nq + g * nq + j
+  const int N = G * nq, b = (int)(row / N), r = (int)(row % N), g = r / nq, j = r % nq;
+  const float* t = tgt + (long long)(g == 0 ? j : nq + j) * C;
+  float* qrow = qe + row * (C + 3);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float v = t[c];
+    qrow[c] = v;
+    query[row * C + c] = v;
+  }
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    float v;
+    if (g == 0) v = anchor[j * 3 + c];
+    else if (g <= 2) v = inv_sigmoid_ref(fps[((long long)b * 2 * nq + (long long)(g - 1) * nq + j) * 3 + c]);
+    else v = inv_sigmoid_ref(rnd[((long long)b * nq + j) * 3 + c]);
+    qrow[C + c] = v;
+    ref[row * 3 + c] = v;
+  }
+}
+extern "C" int32_t u3d_query_embed_fwd(const float* tgt, const float* anchor, const float* fps, const float* rnd, int32_t batch,
+                                       int32_t nq, int32_t groups, int32_t c, float* query_embeds, float* query, float* ref, u3d_stream s) {
+  U3D_REQUIRE(tgt && anchor && fps && query_embeds && query && ref && batch > 0 && nq > 0 && groups >= 1 && groups <= 4 && c > 0, U3D_ERR_ARG);
+  U3D_REQUIRE(groups <= 3 || rnd, U3D_ERR_ARG);
+  hipLaunchKernelGGL(k_query_embed, dim3((unsigned)((long long)batch * groups * nq)), dim3(256), 0, (hipStream_t)s, tgt, anchor, fps, rnd, batch, nq,
+                     groups, c, query_embeds, query, ref);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+// d_tgt [2*nq, C], d_anchor [nq, 3] from the gradients of the three outputs (any of them may be null): sums over scenes (and, for
+// tgt_embed[nq:], over the groups that share it) in a fixed order
+__global__ __launch_bounds__(256) void k_query_embed_bwd(const float* __restrict__ dqe, const float* __restrict__ dquery,
+                                                         const float* __restrict__ dref, int B, int nq, int G, int C,
+                                                         float* __restrict__ dtgt, float* __restrict__ danchor) {
+  const int N = G * nq;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long nt = (long long)2 * nq * C;
+  if (i < nt) {
+    const int tr = (int)(i / C), c = (int)(i % C);
+    const int j = tr < nq ? tr : tr - nq, g0 = tr < nq ? 0 : 1, g1 = tr < nq ? 1 : G;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b)
+      for (int g = g0; g < g1; ++g) {
+        const long long row = (long long)b * N + (long long)g * nq + j;
+        if (dquery) a += dquery[row * C + c];
+        if (dqe) a += dqe[row * (C + 3) + c];
+      }
+    dtgt[i] = a;
+  } else if (i < nt + (long long)nq * 3) {
+    const int k = (int)(i - nt), j = k / 3, c = k % 3;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const long long row = (long long)b * N + j;
+      if (dref) a += dref[row * 3 + c];
+      if (dqe) a += dqe[row * (C + 3) + C + c];
+    }
+    danchor[k] = a;
+  }
+}
+extern "C" int32_t u3d_query_embed_bwd(const float* d_query_embeds, const float* d_query, const float* d_ref, int32_t batch, int32_t nq,
+                                       int32_t groups, int32_t c, float* d_tgt, float* d_anchor, u3d_stream s) {
+  U3D_REQUIRE(d_tgt && d_anchor && batch > 0 && nq > 0 && groups >= 1 && c > 0, U3D_ERR_ARG);
+  const long long n = (long long)2 * nq * c + (long long)nq * 3;
+  hipLaunchKernelGGL(k_query_embed_bwd, dim3((unsigned)u3d_cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, d_query_embeds, d_query, d_ref, batch, nq,
+                     groups, c, d_tgt, d_anchor);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

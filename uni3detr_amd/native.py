@@ -128,6 +128,11 @@ _SIGS = {
     "u3d_to_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     "u3d_from_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     "u3d_fps": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _L, _P]),
+    "u3d_fps2": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _L, _P]),
+    "u3d_fps_prep": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "u3d_fps_points": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "u3d_query_embed_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "u3d_query_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "u3d_match_cost": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "u3d_lsa": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "u3d_trilinear_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
@@ -945,6 +950,50 @@ def fps(base, set_off, set_n, max_n, m):
         stride = max_n
     _check(lib().u3d_fps(_ptr(base), _ptr(set_off), _ptr(set_n), nsets, max_n, m, _ptr(out), _ptr(temp), stride, _stream()), "fps")
     return out
+
+
+def fps_queries(points, coors, scene_off, voxel_off, batch, max_n, m):
+    """The detector's two FPS passes + their glue in three launches (u3d_fps_prep | u3d_fps2 | u3d_fps_points).
+    points f32 [N,F] (packed-triple view: the reference hands the whole [N,F] buffer to the sampler), coors int32 [V,4] (b,z,y,x),
+    scene_off / voxel_off int32 [B+1] -> fpsbpts f32 [B, 2m, 3] in the unit cube (ref: uni3detr.py:178-189)."""
+    dev = points.device
+    F_ = points.shape[1]
+    V = coors.shape[0]
+    vox = torch.empty((max(V, 1), 3), dtype=torch.float32, device=dev)
+    set_off = torch.empty((2 * batch,), dtype=torch.int64, device=dev)
+    set_n = torch.empty((2 * batch,), dtype=torch.int32, device=dev)
+    _check(lib().u3d_fps_prep(_ptr(coors), V, _ptr(scene_off), _ptr(voxel_off), batch, F_, _ptr(vox), _ptr(set_off), _ptr(set_n), _stream()),
+           "fps_prep")
+    idx = torch.empty((2 * batch, m), dtype=torch.int32, device=dev)
+    temp, stride = None, 0
+    if max_n > FPS_REG_MAX:
+        temp = torch.empty((2 * batch, max_n), dtype=torch.float32, device=dev)
+        stride = max_n
+    _check(lib().u3d_fps2(_ptr(points), _ptr(vox), batch, _ptr(set_off), _ptr(set_n), 2 * batch, max_n, m, _ptr(idx), _ptr(temp), stride,
+                          _stream()), "fps2")
+    out = torch.empty((batch, 2 * m, 3), dtype=torch.float32, device=dev)
+    _check(lib().u3d_fps_points(_ptr(points), F_, _ptr(vox), _ptr(idx), _ptr(scene_off), _ptr(voxel_off), batch, m, _ptr(out), _stream()),
+           "fps_points")
+    return out, idx
+
+
+def query_embed_fwd(tgt, anchor, fps, rnd, groups):
+    """-> (query_embeds [B,G*nq,c+3], query [B,G*nq,c], ref_logits [B,G*nq,3]) f32 (u3d_query_embed_fwd)."""
+    B, nq, c = fps.shape[0], anchor.shape[0], tgt.shape[1]
+    dev = tgt.device
+    qe = torch.empty((B, groups * nq, c + 3), dtype=torch.float32, device=dev)
+    q = torch.empty((B, groups * nq, c), dtype=torch.float32, device=dev)
+    r = torch.empty((B, groups * nq, 3), dtype=torch.float32, device=dev)
+    _check(lib().u3d_query_embed_fwd(_ptr(tgt), _ptr(anchor), _ptr(fps), _ptr(rnd), B, nq, groups, c, _ptr(qe), _ptr(q), _ptr(r), _stream()),
+           "query_embed_fwd")
+    return qe, q, r
+
+
+def query_embed_bwd(dqe, dq, dr, B, nq, groups, c, device):
+    dt = torch.empty((2 * nq, c), dtype=torch.float32, device=device)
+    da = torch.empty((nq, 3), dtype=torch.float32, device=device)
+    _check(lib().u3d_query_embed_bwd(_ptr(dqe), _ptr(dq), _ptr(dr), B, nq, groups, c, _ptr(dt), _ptr(da), _stream()), "query_embed_bwd")
+    return dt, da
 
 
 def match_cost(cls, box, gt, labels, gt_off, gmax, w_cls, w_reg, w_iou, alpha=0.25, gamma=2.0):

@@ -1,5 +1,6 @@
 """Uni3DETR detector behind the reference's registry name / constructor / method signatures (ref:
 projects/mmdet3d_plugin/models/detectors/uni3detr.py:113-357; upstream MVXTwoStageDetector)."""
+import os
 from collections import OrderedDict
 
 import torch
@@ -72,6 +73,9 @@ class DynamicSimpleVFE(nn.Module):
         rank = g.rank(coors)
         feats, _ = nv.scatter_mean(features.float().contiguous(), rank, n_vox)
         return feats, g.coords(n_vox)
+
+
+FUSED_FPS_GLUE = os.environ.get("U3D_FUSED_FPS_GLUE", "1") == "1"      # 0: the ATen formulation of the glue around the FPS launch (A/B, parity tests)
 
 
 def shift_scale_points(pred_xyz, src_range, dst_range=None):
@@ -177,6 +181,12 @@ class Uni3DETR(nn.Module):
         m = self.num_fps
         F_ = cat.shape[1]
         dev = cat.device
+        max_n = max(max(lens), int(self.pts_voxel_layer.max_voxels[0 if self.training else 1]) if not self.dynamic_voxelization else 0)
+        if (FUSED_FPS_GLUE and self.fps_packed_view and cat.is_cuda and cat.dtype == torch.float32 and cat.is_contiguous()
+                and coors.dtype == torch.int32 and coors.is_contiguous() and coors.shape[1] == 4
+                and scene_off.dtype == torch.int32 and voxel_off.dtype == torch.int32):
+            # set descriptors + float voxel coordinates | the FPS rounds | gather + unit-cube map + concat: three launches
+            return nv.fps_queries(cat, coors, scene_off, voxel_off, B, max_n, m)[0]
         vox = coors[:, 1:].float().contiguous()                                           # [V,3] (z,y,x)
         if self.fps_packed_view:
             raw, raw_off = cat.reshape(-1), scene_off[:-1].long() * F_
@@ -185,7 +195,6 @@ class Uni3DETR(nn.Module):
         base = torch.cat([raw, vox.reshape(-1)])
         set_off = torch.cat([raw_off, raw.numel() + voxel_off[:-1].long() * 3])
         set_n = torch.cat([scene_off[1:] - scene_off[:-1], voxel_off[1:] - voxel_off[:-1]]).int()
-        max_n = max(max(lens), int(self.pts_voxel_layer.max_voxels[0 if self.training else 1]) if not self.dynamic_voxelization else 0)
         idx = nv.fps(base, set_off.contiguous(), set_n.contiguous(), max_n, m).long()     # [2B, m]
         p_idx = idx[:B] + scene_off[:-1].long()[:, None]
         v_idx = idx[B:] + voxel_off[:-1].long()[:, None]

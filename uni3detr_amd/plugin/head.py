@@ -57,6 +57,33 @@ class _DetLoss(torch.autograd.Function):
         return (dcls, dbox, diou) + (None,) * 11
 
 
+FUSED_QUERY_EMBED = _os.environ.get("U3D_FUSED_QUERY_EMBED", "1") == "1"
+
+
+class _QueryEmbed(torch.autograd.Function):
+    """Query assembly (ref: uni3detr_head.py:436-455) in one launch each way (u3d_query_embed_fwd / _bwd): the G groups' content
+    embeddings and reference logits - group 0 = (tgt_embed[:nq], refpoint_embed), groups g >= 1 = (tgt_embed[nq:],
+    inverse_sigmoid(sampled points)) - as query_embeds [B, G*nq, 259] AND as its two column blocks (what the transformer slices out
+    of it again: the slices' backward would be two zero-fills and a full-tensor add)."""
+
+    @staticmethod
+    def forward(ctx, tgt, anchor, fps, rnd, groups):
+        qe, q, r = nv.query_embed_fwd(tgt.contiguous(), anchor.contiguous(), fps.contiguous(), None if rnd is None else rnd.contiguous(), groups)
+        ctx.dims = (fps.shape[0], anchor.shape[0], groups, tgt.shape[1])
+        ctx.set_materialize_grads(False)          # unused outputs arrive as None, not as zero-filled tensors
+        return qe, q, r
+
+    @staticmethod
+    def backward(ctx, dqe, dq, dr):
+        B, nq, G, c = ctx.dims
+        f = lambda t: None if t is None else t.contiguous().float()
+        if dqe is None and dq is None and dr is None:
+            return None, None, None, None, None
+        dev = next(t for t in (dqe, dq, dr) if t is not None).device
+        dt, da = nv.query_embed_bwd(f(dqe), f(dq), f(dr), B, nq, G, c, dev)
+        return dt, da, None, None, None
+
+
 class _BoxDecode(torch.autograd.Function):
     """Regression-branch output + reference point -> normalised box code in ONE launch each way (u3d_box_decode_fwd/_bwd; ref:
     uni3detr_head.py:475-490).  tmp [..., code] f32|bf16, ref [..., 3] sigmoid space."""
@@ -158,15 +185,22 @@ class Uni3DETRHead(nn.Module):
         nq = self.num_query
         tgt, anchor = self.tgt_embed.weight, self.refpoint_embed.weight
         B = fpsbpts.shape[0]
-        refs = [anchor.unsqueeze(0).expand(B, -1, -1), inverse_sigmoid(fpsbpts)]
-        tgts = [tgt[:nq], tgt[nq:], tgt[nq:]]
-        if not pts_feats.requires_grad:
-            if rand_points is None:
-                rand_points = torch.rand(fpsbpts.shape, device=fpsbpts.device)[:, :nq, :]
-            refs.append(inverse_sigmoid(rand_points))
-            tgts.append(tgt[nq:])
-        tgt_all = torch.cat(tgts)
-        query_embeds = torch.cat([tgt_all.unsqueeze(0).expand(B, -1, -1), torch.cat(refs, 1).to(tgt_all.dtype)], -1)
+        if not pts_feats.requires_grad and rand_points is None:
+            rand_points = torch.rand(fpsbpts.shape, device=fpsbpts.device)[:, :nq, :]
+        if (FUSED_QUERY_EMBED and tgt.is_cuda and tgt.dtype == torch.float32 and anchor.dtype == torch.float32 and fpsbpts.dtype == torch.float32
+                and tuple(fpsbpts.shape[1:]) == (2 * nq, 3) and tgt.shape[0] == 2 * nq and anchor.shape == (nq, 3)
+                and (pts_feats.requires_grad or (rand_points.dtype == torch.float32 and tuple(rand_points.shape) == (B, nq, 3)))):
+            query_embeds, q_part, r_part = _QueryEmbed.apply(tgt, anchor, fpsbpts, None if pts_feats.requires_grad else rand_points,
+                                                             3 if pts_feats.requires_grad else 4)
+            query_embeds._u3d_parts = (q_part, r_part)          # Uni3DETRTransformer.forward takes these instead of slicing
+        else:
+            refs = [anchor.unsqueeze(0).expand(B, -1, -1), inverse_sigmoid(fpsbpts)]
+            tgts = [tgt[:nq], tgt[nq:], tgt[nq:]]
+            if not pts_feats.requires_grad:
+                refs.append(inverse_sigmoid(rand_points))
+                tgts.append(tgt[nq:])
+            tgt_all = torch.cat(tgts)
+            query_embeds = torch.cat([tgt_all.unsqueeze(0).expand(B, -1, -1), torch.cat(refs, 1).to(tgt_all.dtype)], -1)
         dec = self.transformer.decoder
         if self.with_box_refine and hasattr(dec, "forward_bf"):
             object.__setattr__(dec, "_head_branches", (self.cls_branches, self.iou_branches))     # the fused bf16 path runs them per layer

@@ -752,8 +752,12 @@ class Uni3DETRTransformer(nn.Module):
         assert query_embed is not None
         if pts_value.dim() == 6:
             pts_value = pts_value.flatten(0, 1) if pts_value.shape[1] == 1 else pts_value[:, 0]
-        ref_logits = query_embed[..., self.d_model:]
-        query = query_embed[..., : self.d_model]
+        parts = getattr(query_embed, "_u3d_parts", None)       # the head's fused query assembly leaves the two column blocks beside the cat
+        if parts is not None and parts[0].shape[-1] == self.d_model:
+            query, ref_logits = parts
+        else:
+            ref_logits = query_embed[..., self.d_model:]
+            query = query_embed[..., : self.d_model]
         states, refs = self.decoder.forward_bf(query, ref_logits, pts_value, reg_branches, num_query)
         if not self.decoder.return_intermediate:
             states, refs = states[None], refs[None]
