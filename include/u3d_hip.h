@@ -82,7 +82,7 @@ int32_t u3d_bitgrid_scan(const u3d_bitgrid* g, void* scratch, u3d_stream s);
 /* rank[i] = row index of coors[i] in g (or -1). */
 int32_t u3d_bitgrid_rank(const u3d_bitgrid* g, const int32_t* coors, int32_t n, int32_t* rank, u3d_stream s);
 
-/* Enumerate occupied cells in rank order: coors_out int32 [count,4] (b,z,y,x); cap = rows available. */
+/* Enumerate occupied cells in rank order: coors_out int32 [cap,4] (b,z,y,x); cap = rows available; rows [count, cap) = (-1,-1,-1,-1). */
 int32_t u3d_bitgrid_coords(const u3d_bitgrid* g, int32_t* coors_out, int32_t cap, u3d_stream s);
 
 /* Neighbour table ("rulebook") nbr[kappa][ld] int32, kappa = (kz*k1 + ky)*k2 + kx, -1 = no partner.
@@ -477,6 +477,13 @@ int32_t u3d_det_loss_bwd(const float* cls, const float* box, const float* iou_lo
                          const float* w, const float* iou_true, const float* cls_avg, const float* npos, const float* code_w,
                          const float* gout, int32_t L, int32_t m, int32_t c, int32_t code, int32_t tdim, float alpha, float w_cls,
                          float w_box, float w_iou, float eps, float* dcls, float* dbox, float* diou, u3d_stream s);
+/* Target construction behind the assignment (ref: dense_heads/uni3detr_head.py:510-570), all layers and scenes in one launch:
+ * asg int32 [L,B,Q] (u3d_lsa: 0 background, else 1-based GT of the scene), gt f32 [sumG,gd], labels int32 [sumG], gt_off int32 [B+1] ->
+ * asg64 int64 [L,B,Q], w f32 [L,B,Q] (1 on matched queries), tgt f32 [L,B,Q,gd] (matched GT row, zeros for background),
+ * lab int64 [L,B,Q] (GT label, ncls for background), num_pos f32 [L] (matched queries per layer). */
+int32_t u3d_loss_targets(const int32_t* asg, const float* gt, const int32_t* labels, const int32_t* gt_off, int32_t L, int32_t B,
+                         int32_t Q, int32_t gd, int32_t ncls, int64_t* asg64, float* w, float* tgt, int64_t* lab, float* num_pos,
+                         u3d_stream s);
 /* codes [n, code] -> boxes [n, 7] (cx, cy, cz, dx, dy, dz, yaw) (ref: core/bbox/util.py denormalize_bbox). */
 int32_t u3d_denormalize_boxes(const float* codes, int32_t n, int32_t code, float* boxes, u3d_stream s);
 /* Box decode of the head (ref: dense_heads/uni3detr_head.py:475-490): out = tmp with columns 0,1,4 replaced by

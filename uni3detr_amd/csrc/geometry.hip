@@ -248,6 +248,12 @@ extern "C" int32_t u3d_bitgrid_rank(const u3d_bitgrid* g, const int32_t* coors, 
 
 __global__ void k_bitgrid_coords(BitGridDev g, long long nwords, int4* __restrict__ out, int cap) {
   long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // rows past the occupied count (capacity-sized lists of a captured step): (-1, -1, -1, -1), written here instead of by a fill launch
+  {
+    const int count = g.prefix[nwords];
+    for (long long i = w; i < cap; i += (long long)gridDim.x * blockDim.x)
+      if (i >= count) out[i] = make_int4(-1, -1, -1, -1);
+  }
   if (w >= nwords) return;
   unsigned long long bits = g.words[w];
   if (!bits) return;

@@ -212,6 +212,50 @@ extern "C" int32_t u3d_det_loss_bwd(const float* cls, const float* box, const fl
   return U3D_OK;
 }
 
+// Target construction behind the assignment (ref: dense_heads/uni3detr_head.py:510-570 _get_target_single / get_targets), all layers
+// and scenes in one launch: asg int32 [L,B,Q] (0 = background, else 1-based GT of the scene) ->
+//   asg64 (the same as int64), w f32 [L,B,Q] (1 on matched queries), tgt f32 [L,B,Q,gd] (the matched GT row, zeros for background),
+//   lab int64 [L,B,Q] (the GT's label, num_classes for background), num_pos f32 [L] (matched queries per layer: exact integer sums).
+// One workgroup per layer.
+__global__ __launch_bounds__(1024) void k_loss_targets(const int* __restrict__ asg, const float* __restrict__ gt, const int* __restrict__ labels,
+                                                       const int* __restrict__ gt_off, int B, int Q, int gd, int ncls,
+                                                       long long* __restrict__ asg64, float* __restrict__ w, float* __restrict__ tgt,
+                                                       long long* __restrict__ lab, float* __restrict__ num_pos) {
+  __shared__ int s_cnt[16];
+  const int l = blockIdx.x, tid = threadIdx.x;
+  const long long base = (long long)l * B * Q;
+  int cnt = 0;
+  for (int i = tid; i < B * Q; i += 1024) {
+    const int b = i / Q, a = asg[base + i];
+    const bool pos = a > 0;
+    asg64[base + i] = a;
+    w[base + i] = pos ? 1.f : 0.f;
+    const int gi = gt_off[b] + (pos ? a - 1 : 0);
+    lab[base + i] = pos ? (long long)labels[gi] : (long long)ncls;
+    float* t = tgt + (base + i) * gd;
+    for (int c = 0; c < gd; ++c) t[c] = pos ? gt[(long long)gi * gd + c] : 0.f;
+    cnt += pos;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    int a = 0;
+    for (int k = 0; k < 16; ++k) a += s_cnt[k];
+    num_pos[l] = (float)a;
+  }
+}
+extern "C" int32_t u3d_loss_targets(const int32_t* asg, const float* gt, const int32_t* labels, const int32_t* gt_off, int32_t L, int32_t B,
+                                    int32_t Q, int32_t gd, int32_t ncls, int64_t* asg64, float* w, float* tgt, int64_t* lab, float* num_pos,
+                                    u3d_stream s) {
+  U3D_REQUIRE(asg && gt && labels && gt_off && asg64 && w && tgt && lab && num_pos && L > 0 && B > 0 && Q > 0 && gd > 0, U3D_ERR_ARG);
+  hipLaunchKernelGGL(k_loss_targets, dim3(L), dim3(1024), 0, (hipStream_t)s, asg, gt, labels, gt_off, B, Q, gd, ncls, (long long*)asg64, w, tgt,
+                     (long long*)lab, num_pos);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
 // codes [n, code] -> boxes [n, 7] (cx, cy, cz, dx, dy, dz, yaw): denormalize_bbox without the velocity columns (what the rotated
 // IoU target of the IoU-prediction branch is evaluated on)
 __global__ void k_denorm_boxes(const float* __restrict__ codes, int n, int code, float* __restrict__ boxes) {

@@ -128,6 +128,7 @@ _SIGS = {
     "u3d_to_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     "u3d_from_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     "u3d_fps": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _L, _P]),
+    "u3d_loss_targets": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "u3d_fps2": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _L, _P]),
     "u3d_fps_prep": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P]),
     "u3d_fps_points": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
@@ -274,7 +275,7 @@ class BitGrid:
         return out
 
     def coords(self, n):
-        out = torch.full((n, 4), -1, dtype=torch.int32, device=self.words.device)
+        out = torch.empty((n, 4), dtype=torch.int32, device=self.words.device)      # (rows past the count: -1, written by the kernel)
         _check(lib().u3d_bitgrid_coords(C.byref(self.c), _ptr(out), n, _stream()), "bitgrid_coords")
         return out
 
@@ -975,6 +976,21 @@ def fps_queries(points, coors, scene_off, voxel_off, batch, max_n, m):
     _check(lib().u3d_fps_points(_ptr(points), F_, _ptr(vox), _ptr(idx), _ptr(scene_off), _ptr(voxel_off), batch, m, _ptr(out), _stream()),
            "fps_points")
     return out, idx
+
+
+def loss_targets(asg, gt, labels, gt_off, ncls):
+    """asg int32 [L,B,Q], gt f32 [sumG,gd], labels int32 [sumG] -> (asg int64, w f32 [L,B,Q], tgt f32 [L,B,Q,gd], lab int64, num_pos f32 [L])."""
+    L, B, Q = asg.shape
+    gd = gt.shape[1]
+    dev = asg.device
+    a64 = torch.empty((L, B, Q), dtype=torch.int64, device=dev)
+    w = torch.empty((L, B, Q), dtype=torch.float32, device=dev)
+    tgt = torch.empty((L, B, Q, gd), dtype=torch.float32, device=dev)
+    lab = torch.empty((L, B, Q), dtype=torch.int64, device=dev)
+    npos = torch.empty((L,), dtype=torch.float32, device=dev)
+    _check(lib().u3d_loss_targets(_ptr(asg), _ptr(gt), _ptr(labels), _ptr(gt_off), L, B, Q, gd, ncls, _ptr(a64), _ptr(w), _ptr(tgt), _ptr(lab),
+                                  _ptr(npos), _stream()), "loss_targets")
+    return a64, w, tgt, lab, npos
 
 
 def query_embed_fwd(tgt, anchor, fps, rnd, groups):

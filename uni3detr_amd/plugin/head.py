@@ -57,6 +57,7 @@ class _DetLoss(torch.autograd.Function):
         return (dcls, dbox, diou) + (None,) * 11
 
 
+FUSED_LOSS_TARGETS = _os.environ.get("U3D_FUSED_LOSS_TARGETS", "1") == "1"
 FUSED_QUERY_EMBED = _os.environ.get("U3D_FUSED_QUERY_EMBED", "1") == "1"
 
 
@@ -291,7 +292,12 @@ class Uni3DETRHead(nn.Module):
         dev = cls_all.device
         gt, labels, gt_off, gmax = self._pack_gts(gt_bboxes_list, gt_labels_list, dev)
         gt7 = gt if gt.shape[1] == 7 else gt[:, :7].contiguous()          # matching sees the 7 geometric columns (ref: match_cost.py:19-30, 91-97)
-        asg = self.assigner.assign_batched(cls_all, box_all, gt7, labels, gt_off, gmax, self.num_query).long()   # [L,B,Q]
+        asg = self.assigner.assign_batched(cls_all, box_all, gt7, labels, gt_off, gmax, self.num_query)          # int32 [L,B,Q]
+        if (FUSED_LOSS_TARGETS and asg.is_cuda and gt.shape[0] and gt.dtype == torch.float32 and gt.is_contiguous()
+                and labels.dtype == torch.int32 and gt_off.dtype == torch.int32):
+            a64, w, tgt, lab, npos = nv.loss_targets(asg.contiguous(), gt, labels.contiguous(), gt_off, C)       # one launch (u3d_loss_targets)
+            return dict(asg=a64, w=w, tgt=tgt, lab=lab, num_pos=npos)
+        asg = asg.long()
         pos = asg > 0
         w = pos.to(torch.float32)
         if gt.shape[0]:
