@@ -286,7 +286,9 @@ int32_t u3d_colsum(const void* x, int32_t n, int32_t c, int32_t dtype, float* ou
 
 /* Batched forms for the parameter gradients of the decoder / head linears (one shape per call, count <= 48 / 64): all weight
  * gradients dW_b = in_b^T @ dout_b (bf16 [n_rows, cin] x [n_rows, cout] -> f32 [cin, cout]) in two launches, all bias gradients
- * in two launches; pointer arrays are HOST arrays of device pointers (they travel in the kernel arguments). */
+ * in two launches; pointer arrays are HOST arrays of device pointers (they travel in the kernel arguments).  CONSECUTIVE batch
+ * slots that name the same output are SUMMED into it in a fixed order (a linear shared by several decoder layers: ref
+ * models/utils/uni3detr_transformer.py:276-283 ref_point_head / query_scale) - no separate accumulate launches. */
 int64_t u3d_wgrad_batched_workspace(int32_t count, int32_t n_rows, int32_t cin, int32_t cout);
 int32_t u3d_wgrad_batched_bf16(const void* const* in, const void* const* dout, float* const* dw, int32_t count,
                                const int32_t* n_dev, int32_t n_rows, int32_t cin, int32_t cout, void* workspace,

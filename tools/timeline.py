@@ -22,7 +22,9 @@ def main():
     path = sys.argv[1]
     out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
     rows = []
+    full = {}
     for r in csv.DictReader(open(path)):
+        full[(int(r["Start_Timestamp"]), int(r["End_Timestamp"]))] = r["Kernel_Name"]
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Grid_Size_X", r.get("Grid_Size", "?")),
                      r.get("Stream_Id", r.get("Queue_Id", "?"))))
     rows.sort()
@@ -65,6 +67,14 @@ def main():
     print(f"# {'attributed_ms':>13s} {'raw_sum_ms':>10s} {'launches':>8s}  kernel", file=out)
     for n, v in attributed.most_common(60):
         print(f"  {v / nsteps / 1e6:13.4f} {raw[n] / nsteps / 1e6:10.4f} {cnt[n] / nsteps:8.1f}  {n}", file=out)
+    # launches that are not this library's kernels (ATen element-wise / copies / fills, rocBLAS): one step's list in launch order
+    one = rows[ends[-2] + 1:ends[-1] + 1]
+    other = [(i, r) for i, r in enumerate(one) if not r[2].startswith("k_")]
+    print(f"# {len(other)} launches per step that are not k_* kernels, {sum(r[1] - r[0] for _, r in other) / 1e6:.3f} ms:", file=out)
+    for i, (s, e, n, g, q) in other:
+        prev_k = next((one[j][2] for j in range(i - 1, -1, -1) if one[j][2].startswith("k_")), "-")
+        nm = full.get((s, e), n).replace("at::native::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+        print(f"    {(e - s) / 1e3:7.1f} us  grid {g:>9s}  after {prev_k[:28]:28s} {nm[:150]}", file=out)
     streams = collections.Counter()
     for s, e, n, g, q in seg:
         streams[q] += e - s

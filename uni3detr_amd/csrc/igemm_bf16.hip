@@ -2348,11 +2348,17 @@ __device__ __forceinline__ f32x4 wgrad_sum_splits(const float* __restrict__ p, l
   return (a + b) + (c + d);
 }
 
-__global__ void k_wgrad_batch_reduce(WgradBatch bt, const float* __restrict__ partial, long long n, int nsplit, long long partial_stride) {
+// Products that name the SAME output in consecutive batch slots (a weight shared by several decoder layers: dW = sum over its uses)
+// are summed here: the group's first slot reduces the nsplit partials of all its members (contiguous in the workspace), the others
+// have no output (mult 0).  One fixed order, no separate accumulate launches.
+struct WgradGroups { unsigned char mult[U3D_WGRAD_BATCH_MAX]; };
+__global__ void k_wgrad_batch_reduce(WgradBatch bt, WgradGroups gr, const float* __restrict__ partial, long long n, int nsplit,
+                                     long long partial_stride) {
   const int b = blockIdx.y;
+  const int g = gr.mult[b];
   long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= n) return;
-  *(f32x4*)(bt.dw[b] + i) = wgrad_sum_splits(partial + (long long)b * partial_stride + i, n, nsplit);
+  if (i >= n || g == 0) return;
+  *(f32x4*)(bt.dw[b] + i) = wgrad_sum_splits(partial + (long long)b * partial_stride + i, n, nsplit * g);
 }
 
 typedef void (*wgrad_glds_kernel_t)(const u16*, const u16*, const int*, int, float*, const int*, int, int, int, int, int);
@@ -2582,7 +2588,12 @@ extern "C" int32_t u3d_wgrad_batched_bf16(const void* const* in, const void* con
   } else {
     hipLaunchKernelGGL(k_wgrad_batch_64, grid, dim3(256), lds, s, bt, (float*)workspace, n_dev, n_rows, cin, cout, p.co_blocks, stride);
   }
-  hipLaunchKernelGGL(k_wgrad_batch_reduce, dim3(u3d_cdiv(n / 4, 256), count), dim3(256), 0, s, bt, (const float*)workspace, n, p.nsplit, stride);
+  WgradGroups gr;
+  for (int i = 0; i < U3D_WGRAD_BATCH_MAX; ++i) gr.mult[i] = 0;
+  for (int i = 0, lead = 0; i < count; ++i) {
+    if (i > 0 && dw[i] == dw[i - 1]) { gr.mult[lead]++; } else { lead = i; gr.mult[i] = 1; }
+  }
+  hipLaunchKernelGGL(k_wgrad_batch_reduce, dim3(u3d_cdiv(n / 4, 256), count), dim3(256), 0, s, bt, gr, (const float*)workspace, n, p.nsplit, stride);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

@@ -371,6 +371,9 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
 }
 #define U3D_COLSUM_BATCH_MAX 64
 struct ColsumBatch { const void* x[U3D_COLSUM_BATCH_MAX]; float* out[U3D_COLSUM_BATCH_MAX]; };
+// consecutive batch slots naming the SAME output are summed into it by the group's first slot (mult = group size; 0 = no output of its
+// own): the bias of a linear shared by several decoder layers
+struct ColsumGroups { unsigned char mult[U3D_COLSUM_BATCH_MAX]; };
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_colsum_partial_b(ColsumBatch bt, int n, int c, float* __restrict__ partial, long long pstride) {
   // same body as k_colsum_partial, batch index = blockIdx.y
@@ -411,10 +414,13 @@ __global__ __launch_bounds__(256) void k_colsum_partial_b(ColsumBatch bt, int n,
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(256) void k_colsum_final_b(ColsumBatch bt, const float* __restrict__ partial, int nb, int c, long long pstride) {
+__global__ __launch_bounds__(256) void k_colsum_final_b(ColsumBatch bt, ColsumGroups gr, const float* __restrict__ partial, int nb, int c,
+                                                        long long pstride) {
   int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (col >= c) return;
-  const float* p = partial + (long long)blockIdx.y * pstride;
+  const int g = gr.mult[blockIdx.y];
+  if (col >= c || g == 0) return;
+  const float* p = partial + (long long)blockIdx.y * pstride;      // (pstride = nb * c: the members' partial rows follow each other)
+  nb *= g;
   float s = 0.f;
   for (int b = lane; b < nb; b += 64) s += p[(long long)b * c + col];
   s = u3d_wave_sum(s);
@@ -441,7 +447,12 @@ extern "C" int32_t u3d_colsum_batched(const void* const* x, float* const* out, i
     if (c % 8 == 0) hipLaunchKernelGGL((k_colsum_partial_b<u16, 8>), grid, dim3(256), 0, s, bt, n, c, ws, pstride);
     else hipLaunchKernelGGL((k_colsum_partial_b<u16, 1>), grid, dim3(256), 0, s, bt, n, c, ws, pstride);
   } else return U3D_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_colsum_final_b, dim3(u3d_cdiv(c, 4), count), dim3(256), 0, s, bt, (const float*)ws, nb, c, pstride);
+  ColsumGroups gr;
+  for (int i = 0; i < U3D_COLSUM_BATCH_MAX; ++i) gr.mult[i] = 0;
+  for (int i = 0, lead = 0; i < count; ++i) {
+    if (i > 0 && out[i] == out[i - 1]) { gr.mult[lead]++; } else { lead = i; gr.mult[i] = 1; }
+  }
+  hipLaunchKernelGGL(k_colsum_final_b, dim3(u3d_cdiv(c, 4), count), dim3(256), 0, s, bt, gr, (const float*)ws, nb, c, pstride);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

@@ -1178,14 +1178,28 @@ def _ptr_array(tensors):
     return arr
 
 
+def _batch_chunks(outs, maxb):
+    """(start, end) slices of at most maxb batch slots that never split a run of slots naming the same output tensor."""
+    o, n = 0, len(outs)
+    while o < n:
+        e = min(n, o + maxb)
+        while e < n and e > o + 1 and outs[e].data_ptr() == outs[e - 1].data_ptr():
+            e -= 1
+        if e < n and outs[e].data_ptr() == outs[e - 1].data_ptr():
+            raise U3DError("a group of batch slots with one output is larger than the batch limit")
+        yield o, e
+        o = e
+
+
 def wgrad_batched(ins, douts, dws):
-    """dws[b] <- ins[b]^T @ douts[b] for same-shape bf16 [M,Cin] / [M,Cout] pairs (f32 [Cin,Cout] outputs, preallocated)."""
+    """dws[b] <- ins[b]^T @ douts[b] for same-shape bf16 [M,Cin] / [M,Cout] pairs (f32 [Cin,Cout] outputs, preallocated).
+    CONSECUTIVE slots that name the same output are summed into it (a weight used by several layers)."""
     m, cin = ins[0].shape
     cout = douts[0].shape[1]
     dev = ins[0].device
     MAXB = 48
-    for o in range(0, len(ins), MAXB):
-        a, b, c = ins[o:o + MAXB], douts[o:o + MAXB], dws[o:o + MAXB]
+    for o, e in _batch_chunks(dws, MAXB):
+        a, b, c = ins[o:e], douts[o:e], dws[o:e]
         wsb = int(lib().u3d_wgrad_batched_workspace(len(a), m, cin, cout))
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         _check(lib().u3d_wgrad_batched_bf16(_ptr_array(a), _ptr_array(b), _ptr_array(c), len(a), _ptr(count_tensor(m, dev)), m, cin, cout,
@@ -1193,12 +1207,13 @@ def wgrad_batched(ins, douts, dws):
 
 
 def colsum_batched(xs, outs):
-    """outs[b] <- column sums of xs[b] (same-shape [n, C] matrices, f32 [C] outputs, preallocated)."""
+    """outs[b] <- column sums of xs[b] (same-shape [n, C] matrices, f32 [C] outputs, preallocated).  CONSECUTIVE slots that name the
+    same output are summed into it."""
     n, c = xs[0].shape
     dev = xs[0].device
     MAXB = 64
-    for o in range(0, len(xs), MAXB):
-        a, b = xs[o:o + MAXB], outs[o:o + MAXB]
+    for o, e in _batch_chunks(outs, MAXB):
+        a, b = xs[o:e], outs[o:e]
         wsb = int(lib().u3d_colsum_batched_workspace(len(a), n, c))
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         _check(lib().u3d_colsum_batched(_ptr_array(a), _ptr_array(b), len(a), n, c, dtype_code(a[0]), _ptr(ws), ws.numel(), _stream()),

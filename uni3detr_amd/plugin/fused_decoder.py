@@ -26,6 +26,7 @@ ENABLED = os.environ.get("U3D_FUSED_DECODER", "1") == "1"
 # volume to zero and cast: -0.07 ms per step).  OPT-IN: every add rounds to 8 mantissa bits, and all 3 layers x 3 query groups land in one
 # buffer - with queries clustered on objects a cell collects hundreds of contributions and the result drifts 9 % from the f32
 # accumulator (tests/test_decoder_gpu.py::test_packed_bf16_volume_gradient_scatter_vs_f32_accumulator; 0.7 % with spread queries).
+SHARED_DEFER = os.environ.get("U3D_SHARED_DEFER", "1") == "1"     # shared linears' gradients summed by the deferred flush (0: autograd adds)
 PK_SCATTER = os.environ.get("U3D_PK_SCATTER", "0") == "1"
 POISON = os.environ.get("U3D_DEC_POISON", "0") == "1"      # debugging: NaN-fill the workspaces (read-before-write shows up as NaN)
 DEBUG_KEEP = None          # tests: a list that receives every backward call's gradient workspace
@@ -259,6 +260,7 @@ class FusedLayerFn(torch.autograd.Function):
         for w, r0, rows_, b in sp.lin:
             if r0 == 0:
                 _Deferred.uses[id(w)] = _Deferred.uses.get(id(w), 0) + 1
+                _Deferred.fused_uses[id(w)] = _Deferred.fused_uses.get(id(w), 0) + 1
                 _Deferred.params[id(w)] = (w, b)
         for t in (sp.attw.weight, sp.pe0.weight):
             _Deferred.uses[id(t)] = _Deferred.uses.get(id(t), 0) + 1
@@ -365,6 +367,20 @@ class FusedLayerFn(torch.autograd.Function):
                 dfr = deferred_ok and _Deferred.uses.get(id(w), 0) == 1
                 dw, db = slot(w, dfr), slot(b, dfr)
             single = _Deferred.uses.get(id(w), 0) == 1
+            # a linear SHARED by several layers (ref_point_head, query_scale) whose every use is a fused layer: all its (dY, X) pairs are
+            # queued and the flush sums them into ONE gradient (consecutive batch slots with one output, u3d_wgrad_batched_bf16) - the
+            # first backward to get here hands autograd the placeholder, the others contribute None instead of a tensor to be added
+            shared = (SHARED_DEFER and deferred_ok and not single and i not in _NARROW and i not in (nv.DL_INQK, nv.DL_INV)
+                      and _Deferred.fused_uses.get(id(w), 0) == _Deferred.uses.get(id(w), 0))
+            if shared:
+                if id(w) in _Deferred.shared_seen:
+                    dw = db = None
+                else:
+                    _Deferred.shared_seen.add(id(w))
+                    dw, db = slot(w, True), slot(b, True)
+                _Deferred.items.append((dy, xin, id(w), r0, r0 + rows_, True))
+                grads += [dw, db]
+                continue
             if i in _NARROW:
                 if deferred_ok and single:
                     _Deferred.skinny.append((dy, xin, w))        # the product itself waits for the flush: one launch for all layers

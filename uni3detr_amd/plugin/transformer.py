@@ -72,11 +72,13 @@ class _Deferred:
     sum_items = []      # (matrix [rows, C] f32, parameter): parameter.grad <- column sums
     skinny = []         # (dy2 [M,n], x2 [M,k], weight) with min(n, k) <= 16: all products of a step in one launch per skinny side
     uses = {}           # id(weight) -> number of forward uses in this step
+    fused_uses = {}     # id(weight) -> how many of those were fused decoder layers (plugin/fused_decoder.py)
+    shared_seen = set() # weights with several uses whose gradient placeholder has been handed to autograd in this backward
     params = {}         # id(weight) -> (weight, bias)
 
 
 def reset_param_uses():
-    _Deferred.uses, _Deferred.params = {}, {}
+    _Deferred.uses, _Deferred.params, _Deferred.fused_uses, _Deferred.shared_seen = {}, {}, {}, set()
 
 
 def flush_deferred():
@@ -107,10 +109,14 @@ def flush_deferred():
             if b.grad is None or b.grad.dtype != torch.float32:
                 raise RuntimeError("deferred bias gradient: no f32 .grad to write into")
             bgroups.setdefault((dy2.shape[0], dy2.shape[1]), []).append((dy2, b.grad[r0:r1]))
+    # products / sums with one output tensor (a linear shared by several layers) in consecutive batch slots: the launch sums them
     for g in groups.values():
+        g.sort(key=lambda t: t[2].data_ptr())
         nv.wgrad_batched([a for a, _, _ in g], [b for _, b, _ in g], [c for _, _, c in g])
     for g in bgroups.values():
+        g.sort(key=lambda t: t[1].data_ptr())
         nv.colsum_batched([a for a, _ in g], [b for _, b in g])
+    _Deferred.shared_seen = set()
     return keep
 
 
@@ -121,6 +127,7 @@ import contextlib as _contextlib
 def deferred_param_grads():
     prev = _Deferred.active
     _Deferred.active, _Deferred.items, _Deferred.sum_items, _Deferred.skinny = True, [], [], []
+    _Deferred.shared_seen = set()
     try:
         yield
         flush_deferred()
