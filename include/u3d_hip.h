@@ -394,12 +394,15 @@ int32_t u3d_fps_points(const float* pts, int32_t nfeat, const float* vox, const 
 /* Query assembly of Uni3DETRHead.forward (ref: dense_heads/uni3detr_head.py:436-455) in one launch: `groups` query groups of nq
  * queries; group 0 = (tgt[:nq], anchor), group g >= 1 = (tgt[nq:], inverse_sigmoid(points of group g)) with the points of
  * groups 1, 2 in fps f32 [B,2nq,3] and of group 3 (eval layout) in rnd f32 [B,nq,3].  tgt f32 [2nq,c], anchor f32 [nq,3].
- * Outputs: query_embeds f32 [B,G*nq,c+3] and its two column blocks as contiguous tensors, query [B,G*nq,c], ref [B,G*nq,3].
- * _bwd: d_tgt [2nq,c], d_anchor [nq,3] = sums over scenes (and sharing groups) of the output gradients (each may be null). */
+ * Outputs: query_embeds f32 [B,G*nq,c+3] and its two column blocks as contiguous tensors, query [B,G*nq,c], ref [B,G*nq,3];
+ * ref_sig (nullable) [B,G*nq,3] = sigmoid(ref), the transformer's init_reference.
+ * _bwd: d_tgt [2nq,c], d_anchor [nq,3] = sums over scenes (and sharing groups) of the output gradients (each may be null;
+ *   d_ref_sig reaches the anchor through the sigmoid, which is why `anchor` is passed). */
 int32_t u3d_query_embed_fwd(const float* tgt, const float* anchor, const float* fps, const float* rnd, int32_t batch, int32_t nq,
-                            int32_t groups, int32_t c, float* query_embeds, float* query, float* ref, u3d_stream s);
-int32_t u3d_query_embed_bwd(const float* d_query_embeds, const float* d_query, const float* d_ref, int32_t batch, int32_t nq,
-                            int32_t groups, int32_t c, float* d_tgt, float* d_anchor, u3d_stream s);
+                            int32_t groups, int32_t c, float* query_embeds, float* query, float* ref, float* ref_sig, u3d_stream s);
+int32_t u3d_query_embed_bwd(const float* d_query_embeds, const float* d_query, const float* d_ref, const float* d_ref_sig,
+                            const float* anchor, int32_t batch, int32_t nq, int32_t groups, int32_t c, float* d_tgt, float* d_anchor,
+                            u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * Matching (ref: core/bbox/assigners/hungarian_assigner_3d.py:53-151; match_costs/match_cost.py:19-30,91-97; upstream
@@ -496,6 +499,12 @@ int32_t u3d_box_decode_fwd(const void* tmp, int32_t dtype, const float* ref, int
                            float eps, float* out, u3d_stream s);
 int32_t u3d_box_decode_bwd(const void* tmp, int32_t dtype, const float* ref, const float* dout, int32_t n, int32_t code,
                            const float* pc_range, float eps, void* dtmp, float* dref, u3d_stream s);
+/* Reference-point refinement + box decode of one decoder layer in one launch (ref: models/utils/uni3detr_transformer.py:194-202,
+ * dense_heads/uni3detr_head.py:463-490): tmp f32 [n,code] (regression branch), ref_in f32 [n,3] (the layer's input reference
+ * logits), ref_s f32 [n,3] (the same in sigmoid space) -> out [n,code] (= u3d_box_decode_fwd(tmp, ref_s)), ref_out [n,3] =
+ * ref_in + tmp[:,(0,1,4)], ref_sig [n,3] = sigmoid(ref_out).  Backward w.r.t. tmp: u3d_box_decode_bwd(tmp, ref_s, dout). */
+int32_t u3d_refine_decode_fwd(const float* tmp, const float* ref_in, const float* ref_s, int32_t n, int32_t code,
+                              const float* pc_range, float eps, float* out, float* ref_out, float* ref_sig, u3d_stream s);
 /* Sine position embedding of the decoder's reference points (ref: models/utils/uni3detr_transformer.py:33-65,181):
  * out[n][j*nfeat + f] = (f even ? sin : cos)(sigmoid(logits[n][j]) * 2*pi / dim_t[f]); logits f32 [n, nc], dim_t f32 [nfeat] (host
  * table T^(2*(f/2)/nfeat)), out f32 or bf16 [n, nc*nfeat].  Backward: dlogits f32 [n, nc] from dout (f32 or bf16). */

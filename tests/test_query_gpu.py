@@ -90,15 +90,17 @@ def test_fused_query_embed_matches_torch_formulation(cuda, groups):
     fps = torch.rand(B, 2 * nq, 3, device=cuda)
     fps[0, 0] = torch.tensor([0.0, 1.0, 1e-7], device=cuda)                                # the clamps' corner cases
     rnd = torch.rand(B, nq, 3, device=cuda) if groups == 4 else None
-    qe, q, r = _QueryEmbed.apply(tgt, anchor, fps, rnd, groups)
+    qe, q, r, rs = _QueryEmbed.apply(tgt, anchor, fps, rnd, groups)
     refs = [anchor.unsqueeze(0).expand(B, -1, -1), inverse_sigmoid(fps)] + ([inverse_sigmoid(rnd)] if groups == 4 else [])
     tgts = [tgt[:nq]] + [tgt[nq:]] * (groups - 1)
     exp = torch.cat([torch.cat(tgts).unsqueeze(0).expand(B, -1, -1), torch.cat(refs, 1)], -1)
     assert torch.allclose(qe, exp, rtol=1e-6, atol=1e-6)
     assert torch.equal(q, qe[..., :c]) and torch.equal(r, qe[..., c:])
-    w1, w2, w3 = torch.randn_like(qe), torch.randn_like(q), torch.randn_like(r)
-    g = torch.autograd.grad((qe * w1).sum() + (q * w2).sum() + (r * w3).sum(), [tgt, anchor])
-    ge = torch.autograd.grad((exp * w1).sum() + (exp[..., :c] * w2).sum() + (exp[..., c:] * w3).sum(), [tgt, anchor])
+    assert torch.allclose(rs, exp[..., c:].sigmoid(), rtol=1e-6, atol=1e-7)                # init_reference
+    w1, w2, w3, w4 = torch.randn_like(qe), torch.randn_like(q), torch.randn_like(r), torch.randn_like(r)
+    g = torch.autograd.grad((qe * w1).sum() + (q * w2).sum() + (r * w3).sum() + (rs * w4).sum(), [tgt, anchor], retain_graph=True)
+    ge = torch.autograd.grad((exp * w1).sum() + (exp[..., :c] * w2).sum() + (exp[..., c:] * w3).sum() + (exp[..., c:].sigmoid() * w4).sum(),
+                             [tgt, anchor])
     for a, b_ in zip(g, ge):
         assert torch.allclose(a, b_, rtol=1e-5, atol=1e-5)
     g2 = torch.autograd.grad((q * w2).sum(), [tgt, anchor], allow_unused=True)             # only one output used: the others' gradients are None

@@ -355,6 +355,41 @@ extern "C" int32_t u3d_box_decode_fwd(const void* tmp, int32_t dtype, const floa
   return U3D_OK;
 }
 
+// The per-layer tail of the decoder loop and the head's box decode in ONE launch (ref: models/utils/uni3detr_transformer.py:194-202
+// reference-point refinement, dense_heads/uni3detr_head.py:463-490 box decode): from the regression branch's raw code `tmp` [n, code]
+// (f32), the layer's INPUT reference point as logits `ref_in` [n, 3] and in sigmoid space `ref_s` [n, 3]:
+//   out      [n, code] = the box decode of k_box_decode_fwd (same arithmetic, same operands)
+//   ref_out  [n, 3]    = ref_in + tmp[:, (0, 1, 4)]        (the next layer's reference logits, detached in the reference)
+//   ref_sig  [n, 3]    = sigmoid(ref_out)                  (inter_references of the transformer's return value)
+// In torch: index_select + add per layer, a stack and a sigmoid behind the loop, and the decode launch.  Backward = k_box_decode_bwd.
+__global__ void k_refine_decode_fwd(const float* __restrict__ tmp, const float* __restrict__ ref_in, const float* __restrict__ ref_s, int n,
+                                    int code, BoxRange pr, float eps, float* __restrict__ out, float* __restrict__ ref_out,
+                                    float* __restrict__ ref_sig) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int col[3] = {0, 1, 4};
+  float* o = out + (long long)i * code;
+  for (int c = 0; c < code; ++c) o[c] = tmp[(long long)i * code + c];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float t = o[col[j]];
+    const float r = __fadd_rn(ref_in[(long long)i * 3 + j], t);
+    ref_out[(long long)i * 3 + j] = r;
+    ref_sig[(long long)i * 3 + j] = 1.f / (1.f + expf(-r));
+    const float v = t + bd_inv_sigmoid(ref_s[(long long)i * 3 + j], eps);
+    o[col[j]] = (1.f / (1.f + expf(-v))) * pr.span[j] + pr.lo[j];
+  }
+}
+extern "C" int32_t u3d_refine_decode_fwd(const float* tmp, const float* ref_in, const float* ref_s, int32_t n, int32_t code,
+                                         const float* pc_range, float eps, float* out, float* ref_out, float* ref_sig, u3d_stream s) {
+  U3D_REQUIRE(tmp && ref_in && ref_s && out && ref_out && ref_sig && pc_range && n >= 0 && code >= 5 && code <= 16, U3D_ERR_ARG);
+  if (n == 0) return U3D_OK;
+  hipLaunchKernelGGL(k_refine_decode_fwd, dim3(u3d_cdiv(n, 128)), dim3(128), 0, (hipStream_t)s, tmp, ref_in, ref_s, n, code, box_range(pc_range), eps, out,
+                     ref_out, ref_sig);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
 extern "C" int32_t u3d_box_decode_bwd(const void* tmp, int32_t dtype, const float* ref, const float* dout, int32_t n, int32_t code,
                                       const float* pc_range, float eps, void* dtmp, float* dref, u3d_stream s) {
   U3D_REQUIRE(tmp && ref && dout && dtmp && pc_range && n >= 0 && code >= 5 && code <= 16, U3D_ERR_ARG);

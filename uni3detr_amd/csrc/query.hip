@@ -259,7 +259,8 @@ __device__ __forceinline__ float inv_sigmoid_ref(float x) {      // torch: x.cla
 }
 __global__ __launch_bounds__(256) void k_query_embed(const float* __restrict__ tgt, const float* __restrict__ anchor,
                                                      const float* __restrict__ fps, const float* __restrict__ rnd, int B, int nq, int G,
-                                                     int C, float* __restrict__ qe, float* __restrict__ query, float* __restrict__ ref) {
+                                                     int C, float* __restrict__ qe, float* __restrict__ query, float* __restrict__ ref,
+                                                     float* __restrict__ ref_sig) {
   const long long row = blockIdx.x;                        // b * G*nq + g * nq + j
   const int N = G * nq, b = (int)(row / N), r = (int)(row % N), g = r / nq, j = r % nq;
   const float* t = tgt + (long long)(g == 0 ? j : nq + j) * C;
@@ -277,21 +278,23 @@ __global__ __launch_bounds__(256) void k_query_embed(const float* __restrict__ t
     else v = inv_sigmoid_ref(rnd[((long long)b * nq + j) * 3 + c]);
     qrow[C + c] = v;
     ref[row * 3 + c] = v;
+    if (ref_sig) ref_sig[row * 3 + c] = 1.f / (1.f + expf(-v));      // init_reference of the transformer's return value
   }
 }
 extern "C" int32_t u3d_query_embed_fwd(const float* tgt, const float* anchor, const float* fps, const float* rnd, int32_t batch,
-                                       int32_t nq, int32_t groups, int32_t c, float* query_embeds, float* query, float* ref, u3d_stream s) {
+                                       int32_t nq, int32_t groups, int32_t c, float* query_embeds, float* query, float* ref, float* ref_sig, u3d_stream s) {
   U3D_REQUIRE(tgt && anchor && fps && query_embeds && query && ref && batch > 0 && nq > 0 && groups >= 1 && groups <= 4 && c > 0, U3D_ERR_ARG);
   U3D_REQUIRE(groups <= 3 || rnd, U3D_ERR_ARG);
   hipLaunchKernelGGL(k_query_embed, dim3((unsigned)((long long)batch * groups * nq)), dim3(256), 0, (hipStream_t)s, tgt, anchor, fps, rnd, batch, nq,
-                     groups, c, query_embeds, query, ref);
+                     groups, c, query_embeds, query, ref, ref_sig);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
 // d_tgt [2*nq, C], d_anchor [nq, 3] from the gradients of the three outputs (any of them may be null): sums over scenes (and, for
 // tgt_embed[nq:], over the groups that share it) in a fixed order
 __global__ __launch_bounds__(256) void k_query_embed_bwd(const float* __restrict__ dqe, const float* __restrict__ dquery,
-                                                         const float* __restrict__ dref, int B, int nq, int G, int C,
+                                                         const float* __restrict__ dref, const float* __restrict__ dref_sig,
+                                                         const float* __restrict__ anchor, int B, int nq, int G, int C,
                                                          float* __restrict__ dtgt, float* __restrict__ danchor) {
   const int N = G * nq;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -309,21 +312,27 @@ __global__ __launch_bounds__(256) void k_query_embed_bwd(const float* __restrict
     dtgt[i] = a;
   } else if (i < nt + (long long)nq * 3) {
     const int k = (int)(i - nt), j = k / 3, c = k % 3;
-    float a = 0.f;
+    float a = 0.f, as = 0.f;
     for (int b = 0; b < B; ++b) {
       const long long row = (long long)b * N + j;
       if (dref) a += dref[row * 3 + c];
       if (dqe) a += dqe[row * (C + 3) + C + c];
+      if (dref_sig) as += dref_sig[row * 3 + c];
+    }
+    if (dref_sig) {                                        // through ref_sig = sigmoid(anchor) (the first layer's box decode reads it)
+      const float sg = 1.f / (1.f + expf(-anchor[k]));
+      a += as * sg * (1.f - sg);
     }
     danchor[k] = a;
   }
 }
-extern "C" int32_t u3d_query_embed_bwd(const float* d_query_embeds, const float* d_query, const float* d_ref, int32_t batch, int32_t nq,
-                                       int32_t groups, int32_t c, float* d_tgt, float* d_anchor, u3d_stream s) {
-  U3D_REQUIRE(d_tgt && d_anchor && batch > 0 && nq > 0 && groups >= 1 && c > 0, U3D_ERR_ARG);
+extern "C" int32_t u3d_query_embed_bwd(const float* d_query_embeds, const float* d_query, const float* d_ref, const float* d_ref_sig,
+                                       const float* anchor, int32_t batch, int32_t nq, int32_t groups, int32_t c, float* d_tgt,
+                                       float* d_anchor, u3d_stream s) {
+  U3D_REQUIRE(d_tgt && d_anchor && batch > 0 && nq > 0 && groups >= 1 && c > 0 && (!d_ref_sig || anchor), U3D_ERR_ARG);
   const long long n = (long long)2 * nq * c + (long long)nq * 3;
-  hipLaunchKernelGGL(k_query_embed_bwd, dim3((unsigned)u3d_cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, d_query_embeds, d_query, d_ref, batch, nq,
-                     groups, c, d_tgt, d_anchor);
+  hipLaunchKernelGGL(k_query_embed_bwd, dim3((unsigned)u3d_cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, d_query_embeds, d_query, d_ref, d_ref_sig, anchor,
+                     batch, nq, groups, c, d_tgt, d_anchor);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

@@ -128,12 +128,13 @@ _SIGS = {
     "u3d_to_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     "u3d_from_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     "u3d_fps": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _L, _P]),
+    "u3d_refine_decode_fwd": (_I, [_P, _P, _P, _I, _I, _P, C.c_float, _P, _P, _P, _P]),
     "u3d_loss_targets": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "u3d_fps2": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _L, _P]),
     "u3d_fps_prep": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P]),
     "u3d_fps_points": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
-    "u3d_query_embed_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
-    "u3d_query_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "u3d_query_embed_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "u3d_query_embed_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "u3d_match_cost": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "u3d_lsa": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "u3d_trilinear_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
@@ -994,21 +995,23 @@ def loss_targets(asg, gt, labels, gt_off, ncls):
 
 
 def query_embed_fwd(tgt, anchor, fps, rnd, groups):
-    """-> (query_embeds [B,G*nq,c+3], query [B,G*nq,c], ref_logits [B,G*nq,3]) f32 (u3d_query_embed_fwd)."""
+    """-> (query_embeds [B,G*nq,c+3], query [B,G*nq,c], ref_logits [B,G*nq,3], sigmoid(ref_logits)) f32 (u3d_query_embed_fwd)."""
     B, nq, c = fps.shape[0], anchor.shape[0], tgt.shape[1]
     dev = tgt.device
     qe = torch.empty((B, groups * nq, c + 3), dtype=torch.float32, device=dev)
     q = torch.empty((B, groups * nq, c), dtype=torch.float32, device=dev)
     r = torch.empty((B, groups * nq, 3), dtype=torch.float32, device=dev)
-    _check(lib().u3d_query_embed_fwd(_ptr(tgt), _ptr(anchor), _ptr(fps), _ptr(rnd), B, nq, groups, c, _ptr(qe), _ptr(q), _ptr(r), _stream()),
-           "query_embed_fwd")
-    return qe, q, r
+    rs = torch.empty((B, groups * nq, 3), dtype=torch.float32, device=dev)
+    _check(lib().u3d_query_embed_fwd(_ptr(tgt), _ptr(anchor), _ptr(fps), _ptr(rnd), B, nq, groups, c, _ptr(qe), _ptr(q), _ptr(r), _ptr(rs),
+                                     _stream()), "query_embed_fwd")
+    return qe, q, r, rs
 
 
-def query_embed_bwd(dqe, dq, dr, B, nq, groups, c, device):
+def query_embed_bwd(dqe, dq, dr, drs, anchor, B, nq, groups, c, device):
     dt = torch.empty((2 * nq, c), dtype=torch.float32, device=device)
     da = torch.empty((nq, 3), dtype=torch.float32, device=device)
-    _check(lib().u3d_query_embed_bwd(_ptr(dqe), _ptr(dq), _ptr(dr), B, nq, groups, c, _ptr(dt), _ptr(da), _stream()), "query_embed_bwd")
+    _check(lib().u3d_query_embed_bwd(_ptr(dqe), _ptr(dq), _ptr(dr), _ptr(drs), _ptr(anchor), B, nq, groups, c, _ptr(dt), _ptr(da), _stream()),
+           "query_embed_bwd")
     return dt, da
 
 
@@ -1359,6 +1362,15 @@ def box_decode_fwd(tmp, ref, pc_range, eps=1e-5):
     out = torch.empty((n, code), dtype=torch.float32, device=tmp.device)
     _check(lib().u3d_box_decode_fwd(_ptr(tmp), dtype_code(tmp), _ptr(ref), n, code, _pc_range6(pc_range), C.c_float(eps), _ptr(out), _stream()),
            "box_decode_fwd")
+    return out
+
+
+def refine_decode_fwd(tmp, ref_in, ref_s, pc_range, ref_out, ref_sig, eps=1e-5):
+    """tmp f32 [n,code], ref_in / ref_s f32 [n,3]; ref_out / ref_sig: preallocated f32 [n,3] views -> decoded codes f32 [n,code]."""
+    n, code = tmp.shape
+    out = torch.empty((n, code), dtype=torch.float32, device=tmp.device)
+    _check(lib().u3d_refine_decode_fwd(_ptr(tmp), _ptr(ref_in), _ptr(ref_s), n, code, _pc_range6(pc_range), C.c_float(eps), _ptr(out),
+                                       _ptr(ref_out), _ptr(ref_sig), _stream()), "refine_decode_fwd")
     return out
 
 

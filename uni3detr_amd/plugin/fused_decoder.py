@@ -463,9 +463,35 @@ def tensor_list(sp):
     return out
 
 
-def run(fd, query, ref_logits, value, group, et=torch.bfloat16):
+FUSED_REFINE_DECODE = os.environ.get("U3D_FUSED_REFINE_DECODE", "1") == "1"
+
+
+class _RefineDecode(torch.autograd.Function):
+    """The decoder loop's reference-point refinement and the head's box decode of one layer in one launch (u3d_refine_decode_fwd;
+    ref: uni3detr_transformer.py:194-202, uni3detr_head.py:463-490).  reg f32 [M,code], ref_in f32 [M,3] logits (detached), ref_s
+    [M,3] = the same point in sigmoid space (differentiable for the first layer: init_reference = sigmoid(refpoint_embed));
+    ref_out / ref_sig: [M,3] slices of the stacked per-layer buffers the launch writes.  -> decoded box codes f32 [M,code]."""
+
+    @staticmethod
+    def forward(ctx, reg, ref_in, ref_s, pc_range, ref_out, ref_sig):
+        reg, ref_s = reg.contiguous(), ref_s.contiguous()
+        ctx.save_for_backward(reg, ref_s)
+        ctx.pc_range = pc_range
+        return nv.refine_decode_fwd(reg, ref_in.contiguous(), ref_s, pc_range, ref_out, ref_sig)
+
+    @staticmethod
+    def backward(ctx, dout):
+        reg, ref_s = ctx.saved_tensors
+        dtmp, dref = nv.box_decode_bwd(reg, ref_s, dout.contiguous().float(), ctx.pc_range, want_dref=ctx.needs_input_grad[2])
+        return dtmp, None, dref, None, None, None
+
+
+def run(fd, query, ref_logits, value, group, et=torch.bfloat16, pc_range=None, ref_sig=None):
     """query [B,N,256] f32, ref_logits [B,N,3], value [B,256,D,H,W] -> per-layer lists (states [B,N,256] f32, refs, reg, cls, iou).
-    et: element type of the kernels (bf16: throughput mode; f32: parity mode)."""
+    et: element type of the kernels (bf16: throughput mode; f32: parity mode).
+    With pc_range (the head's point-cloud range) and ref_sig (sigmoid(ref_logits), the transformer's init_reference) the layer tail runs
+    as ONE launch (_RefineDecode) and three more results come back: the decoded box codes per layer and the stacked reference points
+    after each layer as logits / in sigmoid space ([L,B,N,3] buffers the launches wrote into)."""
     from .transformer import ValueGradAccum
     B, N, Cc = query.shape
     _, _, D, H, W = value.shape
@@ -483,16 +509,28 @@ def run(fd, query, ref_logits, value, group, et=torch.bfloat16):
     ref = ref_logits.reshape(B * N, 3).float()
     states, refs, regs, clss, ious = [], [], [], [], []
     cols = None
+    fused_tail = FUSED_REFINE_DECODE and pc_range is not None and ref_sig is not None and ref_sig.dtype == torch.float32
+    if fused_tail:
+        refs_buf = torch.empty((L, B * N, 3), dtype=torch.float32, device=dev)
+        sig_buf = torch.empty((L, B * N, 3), dtype=torch.float32, device=dev)
+        rs = ref_sig.reshape(B * N, 3)
+        coords = []
     for lid in range(L):
         sp = fd.specs[lid]
         meta = (fd, lid, (B, N, group, D, H, W), accum, et)
         x, xc, reg, cls, iou = FusedLayerFn.apply(x, xc, ref, rows, meta, *tensor_list(sp))
-        if cols is None:
-            cols = fd.xyz_cols(dev)
-        ref = (ref.detach() + reg.detach().index_select(-1, cols)).detach()
+        if fused_tail:
+            coords.append(_RefineDecode.apply(reg, ref.detach(), rs, pc_range, refs_buf[lid], sig_buf[lid]).view(B, N, -1))
+            ref, rs = refs_buf[lid], sig_buf[lid]
+        else:
+            if cols is None:
+                cols = fd.xyz_cols(dev)
+            ref = (ref.detach() + reg.detach().index_select(-1, cols)).detach()
         states.append(x.view(B, N, Cc))
         refs.append(ref.view(B, N, 3))
         regs.append(reg.view(B, N, -1))
         clss.append(cls.view(B, N, -1))
         ious.append(iou.view(B, N, 1))
+    if fused_tail:
+        return states, refs, regs, clss, ious, coords, refs_buf.view(L, B, N, 3), sig_buf.view(L, B, N, 3)
     return states, refs, regs, clss, ious

@@ -69,19 +69,22 @@ class _QueryEmbed(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, tgt, anchor, fps, rnd, groups):
-        qe, q, r = nv.query_embed_fwd(tgt.contiguous(), anchor.contiguous(), fps.contiguous(), None if rnd is None else rnd.contiguous(), groups)
+        anchor = anchor.contiguous()
+        qe, q, r, rs = nv.query_embed_fwd(tgt.contiguous(), anchor, fps.contiguous(), None if rnd is None else rnd.contiguous(), groups)
         ctx.dims = (fps.shape[0], anchor.shape[0], groups, tgt.shape[1])
         ctx.set_materialize_grads(False)          # unused outputs arrive as None, not as zero-filled tensors
-        return qe, q, r
+        ctx.save_for_backward(anchor)             # rs = sigmoid(ref) is differentiable: the first layer's box decode reads the anchors through it
+        return qe, q, r, rs
 
     @staticmethod
-    def backward(ctx, dqe, dq, dr):
+    def backward(ctx, dqe, dq, dr, drs):
         B, nq, G, c = ctx.dims
+        (anchor,) = ctx.saved_tensors
         f = lambda t: None if t is None else t.contiguous().float()
-        if dqe is None and dq is None and dr is None:
+        if dqe is None and dq is None and dr is None and drs is None:
             return None, None, None, None, None
-        dev = next(t for t in (dqe, dq, dr) if t is not None).device
-        dt, da = nv.query_embed_bwd(f(dqe), f(dq), f(dr), B, nq, G, c, dev)
+        dev = next(t for t in (dqe, dq, dr, drs) if t is not None).device
+        dt, da = nv.query_embed_bwd(f(dqe), f(dq), f(dr), f(drs), anchor, B, nq, G, c, dev)
         return dt, da, None, None, None
 
 
@@ -191,9 +194,9 @@ class Uni3DETRHead(nn.Module):
         if (FUSED_QUERY_EMBED and tgt.is_cuda and tgt.dtype == torch.float32 and anchor.dtype == torch.float32 and fpsbpts.dtype == torch.float32
                 and tuple(fpsbpts.shape[1:]) == (2 * nq, 3) and tgt.shape[0] == 2 * nq and anchor.shape == (nq, 3)
                 and (pts_feats.requires_grad or (rand_points.dtype == torch.float32 and tuple(rand_points.shape) == (B, nq, 3)))):
-            query_embeds, q_part, r_part = _QueryEmbed.apply(tgt, anchor, fpsbpts, None if pts_feats.requires_grad else rand_points,
-                                                             3 if pts_feats.requires_grad else 4)
-            query_embeds._u3d_parts = (q_part, r_part)          # Uni3DETRTransformer.forward takes these instead of slicing
+            query_embeds, q_part, r_part, r_sig = _QueryEmbed.apply(tgt, anchor, fpsbpts, None if pts_feats.requires_grad else rand_points,
+                                                                    3 if pts_feats.requires_grad else 4)
+            query_embeds._u3d_parts = (q_part, r_part, r_sig)   # Uni3DETRTransformer.forward takes these instead of slicing
         else:
             refs = [anchor.unsqueeze(0).expand(B, -1, -1), inverse_sigmoid(fpsbpts)]
             tgts = [tgt[:nq], tgt[nq:], tgt[nq:]]
@@ -205,6 +208,7 @@ class Uni3DETRHead(nn.Module):
         dec = self.transformer.decoder
         if self.with_box_refine and hasattr(dec, "forward_bf"):
             object.__setattr__(dec, "_head_branches", (self.cls_branches, self.iou_branches))     # the fused bf16 path runs them per layer
+            object.__setattr__(dec, "_pc_range", tuple(float(v) for v in self.pc_range) if FUSED_BOX_DECODE else None)      # ... and the box decode
         hs, init_reference, inter_references = self.transformer(
             pts_feats, query_embeds, nq, reg_branches=self.reg_branches if self.with_box_refine else None, img_metas=img_metas)
         hs = hs.permute(0, 2, 1, 3)                                                   # [L,B,N,C]
@@ -222,7 +226,10 @@ class Uni3DETRHead(nn.Module):
             else:
                 tmp = run_sequential(self.reg_branches[lvl], h)
             assert ref_s.shape[-1] == 3
-            if FUSED_BOX_DECODE and tmp.is_cuda and tmp.dtype in (torch.float32, torch.bfloat16) and tmp.shape[-1] <= 16:
+            co = getattr(dec, "_coord_outputs", None)
+            if co is not None and len(co) == hs.shape[0] and self.with_box_refine:
+                coords.append(co[lvl])         # decoded by the decoder layer's own tail launch (fused_decoder._RefineDecode)
+            elif FUSED_BOX_DECODE and tmp.is_cuda and tmp.dtype in (torch.float32, torch.bfloat16) and tmp.shape[-1] <= 16:
                 coords.append(_BoxDecode.apply(tmp, ref_s, tuple(float(v) for v in pr)))
             else:
                 reference = inverse_sigmoid(ref_s)

@@ -13,6 +13,7 @@ import math
 import torch
 import torch.nn.functional as F
 from torch import nn
+import os
 
 from .. import native as nv
 from ..shadow import compute_copy
@@ -690,16 +691,23 @@ class Uni3DETRTransformerDecoder(nn.Module):
                                f"back to vendor GEMM / SDPA kernels silently. Set U3D_ALLOW_ATEN_DECODER=1 to run the layer-by-layer path.")
         return None
 
-    def forward_bf(self, query, ref_logits, value, reg_branches, group):
-        """query [B,N,C], ref_logits [B,N,3] -> (states [L,B,N,C], refs [L,B,N,3] logits after each layer's refinement)."""
-        self._cls_outputs = self._iou_outputs = None
+    def forward_bf(self, query, ref_logits, value, reg_branches, group, ref_sig=None):
+        """query [B,N,C], ref_logits [B,N,3] -> (states [L,B,N,C], refs [L,B,N,3] logits after each layer's refinement).
+        ref_sig: sigmoid(ref_logits) when the caller already has it (the head's fused query assembly)."""
+        self._cls_outputs = self._iou_outputs = self._coord_outputs = self._refs_sig = None
         fd = self._fused_decoder(query, value, reg_branches)
         if fd is not None:
             # every layer is one fused HIP call each way (plugin/fused_decoder.py; u3d_decoder_layer_fwd/_bwd): the bf16 instantiation
             # under bf16 autocast (throughput mode), the exact-f32 instantiation of the same kernels for f32 tensors (parity mode)
             from . import fused_decoder as _fdm
-            states, refs, regs, clss, ious = _fdm.run(fd, query, ref_logits, value, group, self._fused_et)
+            res = _fdm.run(fd, query, ref_logits, value, group, self._fused_et, getattr(self, "_pc_range", None), ref_sig)
+            states, refs, regs, clss, ious = res[:5]
             self._reg_outputs, self._cls_outputs, self._iou_outputs, self._states_c = regs, clss, ious, None
+            if len(res) > 5:             # the layer tails ran as one launch each: decoded boxes + the stacked reference points came with them
+                self._coord_outputs, refs_stacked, self._refs_sig = res[5], res[6], res[7]
+                if self.return_intermediate:
+                    return torch.stack(states), refs_stacked
+                return states[-1], refs[-1]
             if self.return_intermediate:
                 return torch.stack(states), torch.stack(refs)
             return states[-1], refs[-1]
@@ -760,12 +768,16 @@ class Uni3DETRTransformer(nn.Module):
         if pts_value.dim() == 6:
             pts_value = pts_value.flatten(0, 1) if pts_value.shape[1] == 1 else pts_value[:, 0]
         parts = getattr(query_embed, "_u3d_parts", None)       # the head's fused query assembly leaves the two column blocks beside the cat
+        init_sig = None
         if parts is not None and parts[0].shape[-1] == self.d_model:
-            query, ref_logits = parts
+            query, ref_logits, init_sig = parts                # (+ sigmoid(ref_logits): init_reference)
         else:
             ref_logits = query_embed[..., self.d_model:]
             query = query_embed[..., : self.d_model]
-        states, refs = self.decoder.forward_bf(query, ref_logits, pts_value, reg_branches, num_query)
+        states, refs = self.decoder.forward_bf(query, ref_logits, pts_value, reg_branches, num_query, ref_sig=init_sig)
         if not self.decoder.return_intermediate:
             states, refs = states[None], refs[None]
-        return states.permute(0, 2, 1, 3), ref_logits.sigmoid(), refs.sigmoid()
+        refs_sig = getattr(self.decoder, "_refs_sig", None)     # written by the fused layer tails (plugin/fused_decoder._RefineDecode)
+        if refs_sig is None or refs_sig.shape != refs.shape:
+            refs_sig = refs.sigmoid()
+        return states.permute(0, 2, 1, 3), (ref_logits.sigmoid() if init_sig is None else init_sig), refs_sig

@@ -560,6 +560,7 @@ class TrainStep:
             dec._reg_outputs = None
             dec._states_c = None
             dec._cls_outputs = dec._iou_outputs = None
+            dec._coord_outputs = dec._refs_sig = None
         import gc
         gc.collect()
         torch.cuda.synchronize()
