@@ -321,7 +321,8 @@ def main():
                             + (" | loss + bwd head/dense [all-reduce A overlaps] | bwd encoder | clip + AdamW" if ts.overlap else " | loss + bwd | clip + AdamW"))
                            + ", static-shape sparse levels"),
                        "sparse_level_capacities": caps, "rotating_batches": len(rot),
-                       "fps_stream_calibration_ms": getattr(ts, "fps_stream_calibration_ms", None), "recaptures": int(getattr(ts, "recaptures", 0))},
+                       "fps_stream_calibration_ms": getattr(ts, "fps_stream_calibration_ms", None),
+                       "fps_overlap_reference_ms": getattr(ts, "fps_overlap_reference_ms", None), "recaptures": int(getattr(ts, "recaptures", 0))},
         }
         if timer is not None and census:
             durs = timer.durations_ms()

@@ -37,7 +37,7 @@ struct BnEpi {
 template <int BM, int BN, int NT>
 __device__ __forceinline__ void bn_bwd_tile_sums(const BnEpi bn, u16* smem, int m0, int col0, int n_out, int cout, int tile,
                                               double* __restrict__ stats, int tid) {
-  constexpr int CPR = BN / 8, SWZ = (CPR - 1) & 15, R = NT / CPR, ROWS = BM / R, BATCH = ROWS < 8 ? ROWS : 8;
+  constexpr int CPR = BN / 8, SWZ = (CPR - 1) & 15, R = NT / CPR, ROWS = BM / R, BATCH = ROWS < 8 ? ROWS : (ROWS % 8 == 0 ? 8 : (ROWS % 6 == 0 ? 6 : 4));
   static_assert(NT % CPR == 0 && BM % R == 0 && ROWS % BATCH == 0, "tile / thread mismatch");
   const int cc = tid % CPR, r0 = tid / CPR;
   const int col = col0 + cc * 8;
@@ -781,13 +781,17 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
 #ifndef GLDS8_STAGGER
 #define GLDS8_STAGGER 1     /* 0 (experiment): both wave rows in the same segment at the same time */
 #endif
-template <bool F32OUT = false>
+// RB = 16-row blocks per wave and row half: 4 = the 256-row tile; 3 = a 192-row tile in the SAME LDS image and schedule (the last
+// 16 rows of every 64-row piece quarter are dead: never requested - their LDS-DMA lanes carry the "no row" offset -, never read,
+// never multiplied).  For row counts where 256-row tiles leave a quarter of the CUs without a workgroup (48 000 rows x 256 columns:
+// 188 tiles for 256 CUs; 192-row tiles: 250) - see igemm_rows192().
+template <bool F32OUT = false, int RB = 4>
 __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
                                                  int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
                                                  int cin, int cout, int kvol, const float* __restrict__ bias, int relu,
                                                  double* __restrict__ stats, const BnEpi bn) {
-  constexpr int WAVES_M = 2, WAVES_N = 4, WM = 8, WN = 4, NW = 8;
-  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int WAVES_M = 2, WAVES_N = 4, WM = 2 * RB, WN = 4, NW = 8;
+  constexpr int BM = 64 * RB, BN = 256, BK = 64;
   constexpr int PIECE = 128 * BK;                         // elements of one piece (16 KiB)
   constexpr int STAGE_ELEMS = 4 * PIECE;                  // A0 | A1 | B0 | B1
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
@@ -816,14 +820,14 @@ __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, con
   // loader role: LDS-DMA instruction u (0 / 1) of this wave fills piece rows (wv*2+u)*8 .. +7; lane = (row in group, 16-byte slot)
   const int lrow = lane >> 3, lslot = lane & 7;
   unsigned a_part16[2], w_voff[2][2];                     // [u], [piece t][u]
-  int arow[2][2];                                         // tile row of (piece s, u)
+  int arow[2][2];                                         // tile row of (piece s, u); -1: a dead row of the 192-row tile
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int r = (wv * 2 + u) * 8 + lrow;                // piece row 0..127
     a_part16[u] = (unsigned)(lslot ^ ((r >> 1) & 7)) * 16u;
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
-      arow[sp][u] = (r < 64) ? sp * 64 + r : 128 + sp * 64 + (r - 64);
+      arow[sp][u] = ((r & 63) < 16 * RB) ? (r >> 6) * (32 * RB) + sp * (16 * RB) + (r & 63) : -1;
       const int tc = (r >> 5) * 64 + sp * 32 + (r & 31);  // piece B_sp row r = tile column tc
       w_voff[sp][u] = (col0 + tc < cout) ? (unsigned)((col0 + tc) * cin + (lslot ^ ((r >> 1) & 7)) * 8) * 2u : 0xFFFFFFFFu;
     }
@@ -835,7 +839,7 @@ __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, con
   for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int m = m0 + arow[sp][u];
+      const int m = m0 + (arow[sp][u] < 0 ? 0 : arow[sp][u]);
       mcl[sp][u] = m < n_out ? m : n_out - 1;
       idx_nxt[sp][u] = mcl[sp][u];
     }
@@ -855,7 +859,7 @@ __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, con
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) idx_cur[sp][u] = (m0 + arow[sp][u] < n_out) ? idx_nxt[sp][u] : -1;
+      for (int u = 0; u < 2; ++u) idx_cur[sp][u] = (arow[sp][u] >= 0 && m0 + arow[sp][u] < n_out) ? idx_nxt[sp][u] : -1;
   };
   auto issue_a = [&](int st, int buf, int sp) {           // piece A_sp of k-tile st
     const unsigned soff = (unsigned)((st / kvol) * BK) * 2u;
@@ -883,16 +887,16 @@ __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, con
     return __builtin_bit_cast(bf16x8, v);
   };
 #if GLDS8_BALANCE
-  bf16x8 af2[2][4][2], bf[2][2][2];                       // A: [half][row block][k-step]; B: [half][col block][k-step]
+  bf16x8 af2[2][RB][2], bf[2][2][2];                      // A: [half][row block][k-step]; B: [half][col block][k-step]
 #define G8_AF(SP) af2[SP]
 #else
-  bf16x8 af1[4][2], bf[2][2][2];                          // A: [row block][k-step] of the current half; B: [half][col block][k-step]
+  bf16x8 af1[RB][2], bf[2][2][2];                         // A: [row block][k-step] of the current half; B: [half][col block][k-step]
 #define G8_AF(SP) af1
 #endif
 #define G8_READ_A(BUF, SP)                                                                                   \
   {                                                                                                          \
     const u16* A_ = smem + (BUF) * STAGE_ELEMS + (SP) * PIECE + (wm * 64 + li) * BK;                         \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                          \
+    _Pragma("unroll") for (int a = 0; a < RB; ++a) {                                                         \
       G8_AF(SP)[a][0] = frag(A_ + a * 16 * BK, 0);                                                           \
       G8_AF(SP)[a][1] = frag(A_ + a * 16 * BK, 1);                                                           \
     }                                                                                                        \
@@ -910,9 +914,9 @@ __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, con
     __builtin_amdgcn_s_setprio(GLDS8_PRIO);                                                                  \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
       _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                          \
-        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                        \
-          acc[(SA) * 4 + a][(SB) * 2 + b] =                                                                  \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[SB][b][ks], G8_AF(SA)[a][ks], acc[(SA) * 4 + a][(SB) * 2 + b], 0, 0, 0); \
+        _Pragma("unroll") for (int a = 0; a < RB; ++a)                                                       \
+          acc[(SA) * RB + a][(SB) * 2 + b] =                                                                 \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[SB][b][ks], G8_AF(SA)[a][ks], acc[(SA) * RB + a][(SB) * 2 + b], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                           \
   }
 #define G8_BAR()                                  \
@@ -1002,6 +1006,27 @@ __global__ __launch_bounds__(512) void k_igemm_glds8_256x256_f32o(const u16* in,
                                                                   const float* bias, int relu, double* stats, BnEpi bn) {
   igemm_glds8_body<true>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats, bn);
 }
+__global__ __launch_bounds__(512) void k_igemm_glds8_192x256(const u16* in, const u16* w, const int* nbr, int ld, u16* out,
+                                                             const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,
+                                                             const float* bias, int relu, double* stats, BnEpi bn) {
+  igemm_glds8_body<false, 3>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats, bn);
+}
+__global__ __launch_bounds__(512) void k_igemm_glds8_192x256_f32o(const u16* in, const u16* w, const int* nbr, int ld, u16* out,
+                                                                  const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,
+                                                                  const float* bias, int relu, double* stats, BnEpi bn) {
+  igemm_glds8_body<true, 3>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats, bn);
+}
+// 192-row tiles instead of 256-row ones when they finish sooner on 256 CUs with one workgroup each (time ~ rounds x tile rows): the
+// mid-size layers of the dense stack (48 000 rows x 256 columns: 188 -> 250 workgroups, 12 000 rows x 512 columns in 128-column
+// tiles: 188 -> 252).  Convolutions with a neighbour table and more than one offset only (the plain-GEMM callers stay on 256 rows).
+#ifndef IGEMM_ROWS192
+#define IGEMM_ROWS192 1
+#endif
+static inline bool igemm_rows192(const int32_t* nbr, int n_out_cap, int col_blocks, int kvol) {
+  if (!IGEMM_ROWS192 || !nbr || kvol <= 1) return false;
+  const long long w256 = (long long)u3d_cdiv(n_out_cap, 256) * col_blocks, w192 = (long long)u3d_cdiv(n_out_cap, 192) * col_blocks;
+  return (double)u3d_cdiv(w192, 256) * 192.0 * 1.05 < (double)u3d_cdiv(w256, 256) * 256.0;
+}
 
 // =============================================================================================
 // 256 x 128 tile on the same idea, for LONG reductions with 128-column output tiles (the 12 000-row 512-channel layers: 72 k-tiles per
@@ -1019,13 +1044,13 @@ __global__ __launch_bounds__(512) void k_igemm_glds8_256x256_f32o(const u16* in,
 #ifndef IGEMM_GLDS8N
 #define IGEMM_GLDS8N 1
 #endif
-template <bool F32OUT = false>
+template <bool F32OUT = false, int RB = 4>      // RB = 3: 192-row tiles (48 live rows per wave), see igemm_glds8_body
 __device__ __forceinline__ void igemm_glds8n_body(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr,
                                                   int ld, u16* __restrict__ out, const int* __restrict__ n_out_dev, int n_out_cap,
                                                   int cin, int cout, int kvol, const float* __restrict__ bias, int relu,
                                                   double* __restrict__ stats, const BnEpi bn) {
-  constexpr int WAVES_M = 4, WAVES_N = 2, WM = 4, WN = 4, NW = 8;
-  constexpr int BM = 256, BN = 128, BK = 64;
+  constexpr int WAVES_M = 4, WAVES_N = 2, WM = RB, WN = 4, NW = 8;
+  constexpr int BM = 64 * RB, BN = 128, BK = 64;
   constexpr int APIECE = 128 * BK, BPIECE = 64 * BK;
   constexpr int STAGE_ELEMS = 2 * APIECE + 2 * BPIECE;    // A0 | A1 | B0 | B1 = 48 KiB
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
@@ -1061,7 +1086,7 @@ __device__ __forceinline__ void igemm_glds8n_body(const u16* __restrict__ in, co
     const int r = (wv * 2 + u) * 8 + lrow;
     a_part16[u] = (unsigned)(lslot ^ ((r >> 1) & 7)) * 16u;
 #pragma unroll
-    for (int gp = 0; gp < 2; ++gp) arow[gp][u] = gp * 128 + r;
+    for (int gp = 0; gp < 2; ++gp) arow[gp][u] = ((r & 63) < 16 * RB) ? gp * (32 * RB) + (r >> 6) * (16 * RB) + (r & 63) : -1;
   }
   {
     const int r = wv * 8 + lrow;
@@ -1076,7 +1101,7 @@ __device__ __forceinline__ void igemm_glds8n_body(const u16* __restrict__ in, co
   for (int gp = 0; gp < 2; ++gp)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int m = m0 + arow[gp][u];
+      const int m = m0 + (arow[gp][u] < 0 ? 0 : arow[gp][u]);
       mcl[gp][u] = m < n_out ? m : n_out - 1;
       idx_nxt[gp][u] = mcl[gp][u];
     }
@@ -1091,7 +1116,7 @@ __device__ __forceinline__ void igemm_glds8n_body(const u16* __restrict__ in, co
 #pragma unroll
     for (int gp = 0; gp < 2; ++gp)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) idx_cur[gp][u] = (m0 + arow[gp][u] < n_out) ? idx_nxt[gp][u] : -1;
+      for (int u = 0; u < 2; ++u) idx_cur[gp][u] = (arow[gp][u] >= 0 && m0 + arow[gp][u] < n_out) ? idx_nxt[gp][u] : -1;
   };
   auto issue_a = [&](int st, int sl) {                    // both A pieces of k-tile st into stage slot sl (rows idx_cur describes)
     const unsigned soff = (unsigned)((st / kvol) * BK) * 2u;
@@ -1122,11 +1147,11 @@ __device__ __forceinline__ void igemm_glds8n_body(const u16* __restrict__ in, co
     s16x8 v = *(lds_vptr)(rowp + foff[ks]);
     return __builtin_bit_cast(bf16x8, v);
   };
-  bf16x8 af[2][4][2], bf[2][2][2];                        // A: [register set][row block][k-step]; B: [column half][col block][k-step]
+  bf16x8 af[2][RB][2], bf[2][2][2];                       // A: [register set][row block][k-step]; B: [column half][col block][k-step]
 #define N8_READ_A(SL, SET)                                                                                   \
   {                                                                                                          \
     const u16* A_ = smem + (SL) * STAGE_ELEMS + grp * APIECE + (((wv >> 1) & 1) * 64 + li) * BK;             \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                          \
+    _Pragma("unroll") for (int a = 0; a < RB; ++a) {                                                         \
       af[SET][a][0] = frag(A_ + a * 16 * BK, 0);                                                             \
       af[SET][a][1] = frag(A_ + a * 16 * BK, 1);                                                             \
     }                                                                                                        \
@@ -1146,7 +1171,7 @@ __device__ __forceinline__ void igemm_glds8n_body(const u16* __restrict__ in, co
     __builtin_amdgcn_s_setprio(1);                                                                           \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
       _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                          \
-        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                        \
+        _Pragma("unroll") for (int a = 0; a < RB; ++a)                                                       \
           acc[a][(T) * 2 + b] =                                                                              \
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[T][b][ks], af[SET][a][ks], acc[a][(T) * 2 + b], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                           \
@@ -1221,6 +1246,16 @@ __global__ __launch_bounds__(512) void k_igemm_glds8_256x128_f32o(const u16* in,
                                                                   const float* bias, int relu, double* stats, BnEpi bn) {
   igemm_glds8n_body<true>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats, bn);
 }
+__global__ __launch_bounds__(512) void k_igemm_glds8_192x128(const u16* in, const u16* w, const int* nbr, int ld, u16* out,
+                                                             const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,
+                                                             const float* bias, int relu, double* stats, BnEpi bn) {
+  igemm_glds8n_body<false, 3>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats, bn);
+}
+__global__ __launch_bounds__(512) void k_igemm_glds8_192x128_f32o(const u16* in, const u16* w, const int* nbr, int ld, u16* out,
+                                                                  const int* n_out_dev, int n_out_cap, int cin, int cout, int kvol,
+                                                                  const float* bias, int relu, double* stats, BnEpi bn) {
+  igemm_glds8n_body<true, 3>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol, bias, relu, stats, bn);
+}
 // the 256 x 128 eight-phase kernel for the shapes it is dispatched on: long reductions (>= GLDS8N_MIN_KTILES k-tiles), enough
 // workgroups to keep most CUs busy with ONE per CU
 #ifndef GLDS8N_MIN_KTILES
@@ -1236,8 +1271,12 @@ static int launch_igemm_glds8n(const void* in, const void* w, const int32_t* nbr
   constexpr size_t lds = 3 * (size_t)(256 + 128) * 64 * 2;      // 144 KiB
   U3D_ALLOW_LDS(k_igemm_glds8_256x128, lds);
   U3D_ALLOW_LDS(k_igemm_glds8_256x128_f32o, lds);
-  dim3 grid(u3d_cdiv(n_out_cap, 256), cout / 128);
-  hipLaunchKernelGGL(f32o ? k_igemm_glds8_256x128_f32o : k_igemm_glds8_256x128, grid, dim3(512), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap,
+  U3D_ALLOW_LDS(k_igemm_glds8_192x128, lds);
+  U3D_ALLOW_LDS(k_igemm_glds8_192x128_f32o, lds);
+  const bool r192 = igemm_rows192(nbr, n_out_cap, cout / 128, kvol);
+  dim3 grid(u3d_cdiv(n_out_cap, r192 ? 192 : 256), cout / 128);
+  hipLaunchKernelGGL(r192 ? (f32o ? k_igemm_glds8_192x128_f32o : k_igemm_glds8_192x128) : (f32o ? k_igemm_glds8_256x128_f32o : k_igemm_glds8_256x128),
+                     grid, dim3(512), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap,
                      cin, cout, kvol, bias, relu, stats, bn);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
 }
@@ -1283,8 +1322,13 @@ static int launch_igemm_glds(const void* in, const void* w, const int32_t* nbr, 
     else if (BM == 128 && BN == 64) kern = k_igemm_glds_128x64_f32o;
     else return U3D_ERR_UNSUPPORTED;
   }
+  int rows = BM;
+  if (BM == 256 && BN == 256 && IGEMM_GLDS8 && nbr && igemm_rows192(nbr, n_out_cap, u3d_cdiv(cout, BN), kvol)) {
+    kern = f32o ? k_igemm_glds8_192x256_f32o : k_igemm_glds8_192x256;      // same LDS image, 192 live rows (igemm_glds8_body<., 3>)
+    rows = 192;
+  }
   if (lds > 64 * 1024) U3D_ALLOW_LDS(kern, lds);      // one call site per template instantiation: per-kernel, per-device
-  dim3 grid(u3d_cdiv(n_out_cap, BM), u3d_cdiv(cout, BN));
+  dim3 grid(u3d_cdiv(n_out_cap, rows), u3d_cdiv(cout, BN));
   hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, (const u16*)in, (const u16*)w, nbr, ld, (u16*)out, n_out_dev, n_out_cap, cin,
                      cout, kvol, bias, relu, stats, bn);
   return hipGetLastError() == hipSuccess ? U3D_OK : U3D_ERR_LAUNCH;
@@ -1324,8 +1368,11 @@ extern "C" int32_t u3d_igemm_fwd_stats_tile_rows(int32_t n_out_cap, int32_t cin,
 // u3d_bn_finalize_partials takes as rows_per_block): the LDS-DMA kernels' row-tile height - which depends on kvol where the
 // 256 x 128 eight-phase kernel serves long reductions -, 0 for the per-wave partials of the direct-operand kernels / unserved shapes
 extern "C" int32_t u3d_igemm_fwd_stats_rows(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol) {
-  if (igemm_glds8n_shape((const int32_t*)16, n_out_cap, cin, cout, kvol)) return 256;
-  return u3d_igemm_fwd_stats_tile_rows(n_out_cap, cin, cout);
+  const int32_t* some = (const int32_t*)16;      // "there is a neighbour table"
+  if (igemm_glds8n_shape(some, n_out_cap, cin, cout, kvol)) return igemm_rows192(some, n_out_cap, cout / 128, kvol) ? 192 : 256;
+  const int tr = u3d_igemm_fwd_stats_tile_rows(n_out_cap, cin, cout);
+  if (tr == 256 && IGEMM_GLDS8 && igemm_rows192(some, n_out_cap, cout / 256, kvol)) return 192;      // (launch_igemm_glds's choice)
+  return tr;
 }
 #ifndef DIRECT_STATS
 #define DIRECT_STATS 1

@@ -529,7 +529,7 @@ def conv_bn(feats, weight, geom, bn, n_dev, residual=None, relu=True, layout="dh
             tr = getattr(stats, "_u3d_tile_rows", None)
             if tr is None:                      # attribute lost on the way through autograd: recover it from the shape
                 nb = stats.shape[0]
-                tr = 128 if (y.shape[0] + 127) // 128 == nb else (256 if (y.shape[0] + 255) // 256 == nb else 0)
+                tr = next((t for t in (128, 256, 192) if (y.shape[0] + t - 1) // t == nb), 0)
             return _BNRows.apply(y, bn.weight, bn.bias, residual, n_dev, bn, relu, True, stats, tr, None, post_add, res_give, bn_out)
         return _BNRows.apply(y, bn.weight, bn.bias, residual, n_dev, bn, relu, bn.training, None, 0, None, post_add, res_give, bn_out)
     return bn_rows(sparse_conv(feats, weight, geom, layout, fan_token), bn, n_dev, residual, relu, None, post_add)

@@ -684,6 +684,24 @@ class TrainStep:
                 best, best_t = side, t
         self._fps_stream = best
         self.fps_stream_calibration_ms = seen          # stage-1 wall time per candidate (bench.py reports it)
+        # two reference points for the numbers above: stage 1 with the FPS graph on the MAIN stream (no overlap possible) and without
+        # the FPS graph at all (what full overlap would give; g1c then reads the previous replay's samples - timing only)
+        g1a, gf, g1b, g1c = g1
+
+        def wall2(with_fps):
+            def once():
+                g1a.replay()
+                if with_fps:
+                    gf.replay()
+                g1b.replay(); g1c.replay()
+            once()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                once()
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - t0) / reps * 1e3, 3)
+        self.fps_overlap_reference_ms = {"serial": wall2(True), "without_fps": wall2(False), "chosen": round(best_t * 1e3, 3)}
 
     def _replay_stage1(self, g1):
         if not isinstance(g1, tuple):
