@@ -474,7 +474,11 @@ def test_strided_dgrad_split_path_matches_conv3d(cuda, stride, cout):
 
 @pytest.mark.parametrize("cin,cout,B,dims", [(64, 64, 2, (5, 12, 10)), (128, 256, 3, (4, 11, 9)), (256, 256, 8, (15, 40, 40)),
                                              (32, 32, 3, (7, 13, 11)), (16, 32, 2, (5, 12, 10)), (64, 32, 2, (6, 9, 14)), (32, 16, 4, (9, 20, 17)),
-                                             (64, 16, 1, (3, 5, 4)), (512, 512, 8, (15, 10, 10))])
+                                             (64, 16, 1, (3, 5, 4)), (512, 512, 8, (15, 10, 10)),
+                                             # 192-row tiles of the eight-phase kernels: a partial last tile; and a shape BOTH wide-tile rules accept, where
+                                             # the 256-column kernel (dispatched) and the 128-column one would choose different tile heights - the
+                                             # statistics buffer must be sized by the dispatched kernel's (u3d_igemm_fwd_stats_rows)
+                                             (256, 256, 3, (15, 32, 31)), (512, 512, 10, (10, 20, 20))])
 def test_conv_epilogue_bn_statistics_match_separate_pass(cuda, cin, cout, B, dims):
     """conv -> BatchNorm with the statistics reduced in the conv epilogue (u3d_igemm_fwd_stats_bf16 + u3d_bn_finalize_partials) equals
     the conv followed by the stand-alone statistics pass: outputs, running statistics, and the backward through both."""

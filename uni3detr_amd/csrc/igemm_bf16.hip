@@ -1368,10 +1368,11 @@ extern "C" int32_t u3d_igemm_fwd_stats_tile_rows(int32_t n_out_cap, int32_t cin,
 // u3d_bn_finalize_partials takes as rows_per_block): the LDS-DMA kernels' row-tile height - which depends on kvol where the
 // 256 x 128 eight-phase kernel serves long reductions -, 0 for the per-wave partials of the direct-operand kernels / unserved shapes
 extern "C" int32_t u3d_igemm_fwd_stats_rows(int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol) {
+  // the dispatch order of u3d_igemm_fwd_stats_bf16 / _dgrad_bnstats: 256-column tiles first, then the 256 x 128 eight-phase kernel
   const int32_t* some = (const int32_t*)16;      // "there is a neighbour table"
-  if (igemm_glds8n_shape(some, n_out_cap, cin, cout, kvol)) return igemm_rows192(some, n_out_cap, cout / 128, kvol) ? 192 : 256;
   const int tr = u3d_igemm_fwd_stats_tile_rows(n_out_cap, cin, cout);
-  if (tr == 256 && IGEMM_GLDS8 && igemm_rows192(some, n_out_cap, cout / 256, kvol)) return 192;      // (launch_igemm_glds's choice)
+  if (tr == 256) return (IGEMM_GLDS8 && igemm_rows192(some, n_out_cap, cout / 256, kvol)) ? 192 : 256;      // (launch_igemm_glds's choice)
+  if (igemm_glds8n_shape(some, n_out_cap, cin, cout, kvol)) return igemm_rows192(some, n_out_cap, cout / 128, kvol) ? 192 : 256;
   return tr;
 }
 #ifndef DIRECT_STATS
