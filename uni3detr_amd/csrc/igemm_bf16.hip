@@ -198,11 +198,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_igemm_fwd(const u16* 
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule; used for speed only).  Every XCD gets one
   // CONTIGUOUS slab of row tiles, so the halo rows a tile re-gathers for its 27 offsets are shared through that XCD's L2
   // instead of being pulled into all eight L2s.  (Measured: time-neutral on the 3x3x3 layers — they are MFMA-pipeline bound.)
-  const int ntile = gridDim.x;
-  const int xq = ntile >> 3, xr = ntile & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+  const int tile = u3d_xcd_tile(blockIdx.x, (n_out + BM - 1) / BM);      // XCD-contiguous ranges of the LIVE tiles (capacity-sized grids)
+  if (tile < 0) return;
   const int m0 = tile * BM;
-  if (m0 >= n_out) return;
   const int col0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv / WAVES_N, wn = wv % WAVES_N;
@@ -509,11 +507,9 @@ __device__ __forceinline__ void igemm_glds_body(const u16* __restrict__ in, cons
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
 
   const int n_out = min(*n_out_dev, n_out_cap);
-  const int ntile = gridDim.x;
-  const int xq = ntile >> 3, xr = ntile & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+  const int tile = u3d_xcd_tile(blockIdx.x, (n_out + BM - 1) / BM);      // XCD-contiguous ranges of the LIVE tiles (capacity-sized grids)
+  if (tile < 0) return;
   const int m0 = tile * BM;
-  if (m0 >= n_out) return;
   const int col0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -797,11 +793,9 @@ __device__ __forceinline__ void igemm_glds8_body(const u16* __restrict__ in, con
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
 
   const int n_out = min(*n_out_dev, n_out_cap);
-  const int ntile = gridDim.x;
-  const int xq = ntile >> 3, xr = ntile & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+  const int tile = u3d_xcd_tile(blockIdx.x, (n_out + BM - 1) / BM);      // XCD-contiguous ranges of the LIVE tiles (capacity-sized grids)
+  if (tile < 0) return;
   const int m0 = tile * BM;
-  if (m0 >= n_out) return;
   const int col0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1056,11 +1050,9 @@ __device__ __forceinline__ void igemm_glds8n_body(const u16* __restrict__ in, co
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
 
   const int n_out = min(*n_out_dev, n_out_cap);
-  const int ntile = gridDim.x;
-  const int xq = ntile >> 3, xr = ntile & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+  const int tile = u3d_xcd_tile(blockIdx.x, (n_out + BM - 1) / BM);      // XCD-contiguous ranges of the LIVE tiles (capacity-sized grids)
+  if (tile < 0) return;
   const int m0 = tile * BM;
-  if (m0 >= n_out) return;
   const int col0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -187,23 +187,22 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo64(const u16* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u16* xs = (u16*)smem;                           // [HL_MAXS][HL_RS]
   const int tid = threadIdx.x;
+  // workgroups go round-robin over the 8 XCDs: give each XCD a CONTIGUOUS range of the LIVE tiles - neighbouring tiles share most of
+  // their halo rows, which then hit that XCD's L2 instead of being fetched once per XCD (u3d_xcd_tile: the grid is capacity-sized)
+  const int n = min(*n_dev, n_cap);
+  const int live = (n + HL_T - 1) / HL_T;
+  if (stats && live + (int)blockIdx.x < (int)gridDim.x && tid < 2 * HL_C)      // statistics rows of the tiles past the count: zeros
+    stats[(long long)(live + blockIdx.x) * 2 * HL_C + tid] = 0.0;
 #ifdef HL_NO_XCD_MAP
-  const int tile = blockIdx.x;
+  const int tile = (int)blockIdx.x < live ? (int)blockIdx.x : -1;
 #else
-  // workgroups go round-robin over the 8 XCDs: give each XCD a CONTIGUOUS range of tiles - neighbouring tiles share most of their
-  // halo rows, which then hit that XCD's L2 instead of being fetched once per XCD
-  const int tq = gridDim.x >> 3, trem = gridDim.x & 7, xcd = blockIdx.x & 7;
-  const int tile = (xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq) + (blockIdx.x >> 3);
+  const int tile = u3d_xcd_tile(blockIdx.x, live);
 #endif
+  if (tile < 0) return;
   const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kq = lane >> 4;
   const int m0 = tile * HL_T;
   HL_MARK(0);
-  const int n = min(*n_dev, n_cap);
-  if (m0 >= n) {
-    if (stats && tid < 2 * HL_C) stats[(long long)tile * 2 * HL_C + tid] = 0.0;
-    return;
-  }
   const int32_t* rows_p = tile_rows + (long long)tile * HL_TRC;
   const int nl = min(tile_cnt[tile], maxs);      // staged slots (maxs <= HL_MAXS: the stage buffer; lower only as a test hook)
   // stage the distinct rows: 8 lanes x 16 B per row.  All of a thread's row indices are requested at once, then all of its rows:
@@ -446,16 +445,15 @@ __global__ __launch_bounds__(256, 2) void k_subm_halo128(const u16* __restrict__
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u16* xs = (u16*)smem;                           // [HL_MAXS][HL_RS]: one 64-channel half of the distinct rows
   const int tid = threadIdx.x;
-  const int tq = gridDim.x >> 3, trem = gridDim.x & 7, xcd = blockIdx.x & 7;      // XCD-contiguous tile ranges (k_subm_halo64)
-  const int tile = (xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq) + (blockIdx.x >> 3);
+  const int n = min(*n_dev, n_cap);
+  const int live = (n + HL_T - 1) / HL_T;
+  if (stats && live + (int)blockIdx.x < (int)gridDim.x && tid < 2 * HL_C2)     // statistics rows of the tiles past the count: zeros
+    stats[(long long)(live + blockIdx.x) * 2 * HL_C2 + tid] = 0.0;
+  const int tile = u3d_xcd_tile(blockIdx.x, live);      // XCD-contiguous ranges of the live tiles (k_subm_halo64)
+  if (tile < 0) return;
   const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kq = lane >> 4;
   const int m0 = tile * HL_T;
-  const int n = min(*n_dev, n_cap);
-  if (m0 >= n) {
-    if (stats && tid < 2 * HL_C2) stats[(long long)tile * 2 * HL_C2 + tid] = 0.0;
-    return;
-  }
   const int32_t* rows_p = tile_rows + (long long)tile * HL_TRC;
   const int cnt = tile_cnt[tile];
   const int nl = min(cnt, maxs);
