@@ -21,6 +21,9 @@ LAYERS = {
     "dense32to64": (8, (30, 60, 24), 32, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     "dense16to32": (8, (20, 40, 20), 16, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     "dense16": (8, (20, 40, 20), 16, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    # SECOND3D's strided first convs (branches 1 and 2 read the 192 000-row volume with stride 2 / 4)
+    "stride2_256": (8, (15, 40, 40), 256, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    "stride4_512": (8, (15, 40, 40), 256, 512, (1, 3, 3), (1, 4, 4), (0, 1, 1)),
 }
 
 
@@ -46,14 +49,17 @@ def main():
     for name, (B, dims, cin, cout, ks, st, pad) in LAYERS.items():
         if a.only and a.only not in name:
             continue
-        n = B * dims[0] * dims[1] * dims[2]
+        dims_out = tuple((d + 2 * p_ - k_) // s_ + 1 for d, k_, s_, p_ in zip(dims, ks, st, pad))
+        n_in = B * dims[0] * dims[1] * dims[2]
+        n = B * dims_out[0] * dims_out[1] * dims_out[2]
         kvol = ks[0] * ks[1] * ks[2]
-        nbr = nv.dense_nbr_table(B, dims, dims, ks, st, pad, 0, dev)
-        nbr_b = nv.dense_nbr_table(B, dims, dims, ks, st, pad, 1, dev)
+        nbr = nv.dense_nbr_table(B, dims_out, dims, ks, st, pad, 0, dev)
+        nbr_b = nv.dense_nbr_table(B, dims, dims_out, ks, st, pad, 1, dev)
         nd = nv.count_tensor(n, dev)
+        nd_in = nv.count_tensor(n_in, dev)
         torch.manual_seed(0)
-        def gen(c):
-            t = torch.randn(n, c, device=dev)
+        def gen(c, rows=None):
+            t = torch.randn(n if rows is None else rows, c, device=dev)
             if a.data == "relu":
                 t = torch.relu(t)
             elif a.data == "small":
@@ -63,7 +69,7 @@ def main():
             elif a.data == "bn":
                 t = torch.relu(t * 0.7 + 0.1)
             return t.bfloat16()
-        xs = [gen(cin) for _ in range(a.rotate)]
+        xs = [gen(cin, n_in) for _ in range(a.rotate)]
         dys = [gen(cout) for _ in range(a.rotate)]
         x, dy = xs[0], dys[0]
         ctr = [0]
@@ -79,7 +85,7 @@ def main():
         passes = {
             "fwd": lambda: nv.spconv_fwd(nxt()[0], koi, nbr, nd, n, cout, transpose_w=True, tag="spconv_fwd"),
             "fwd_k": lambda: nv.spconv_fwd(nxt()[0], w, nbr, nd, n, cout),         # k-major weights: the inference / first-generation path
-            "dgrad": lambda: nv.spconv_fwd(nxt()[1], w, nbr_b, nd, n, cin, transpose_w=True),
+            "dgrad": lambda: nv.spconv_fwd(nxt()[1], w, nbr_b, nd_in, n_in, cin, transpose_w=True),
             "wgrad": lambda: nv.spconv_wgrad(*nxt(), nbr, nd, kvol),
         }
         for pname, fn in passes.items():
