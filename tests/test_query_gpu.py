@@ -59,6 +59,41 @@ def test_fps_large_set_streaming_path(cuda):
     assert np.array_equal(idx[0], om.fps_packed(p.reshape(-1), 50000, 64))
 
 
+def test_fps_large_sets_split_over_workgroups(cuda):
+    """Sets above 20 480 points run on several resident workgroups that exchange their round winners (k_fps_multi): one launch over
+    large and small sets (slice boundaries at 20 480 / 20 481 points, an empty set, a small set with the general tie rule), integer-
+    lattice points so that ties across slices and workgroups are the rule - indices identical to the oracle's sequential FPS."""
+    rng = np.random.default_rng(7)
+    ns = [50000, 20480, 20481, 1000, 0, 70000, 300]
+    sets = [rng.integers(0, 40, (n, 3)).astype(np.float32) for n in ns]
+    offs, o = [], 0
+    for p in sets:
+        offs.append(o); o += p.size
+    base = torch.from_numpy(np.concatenate([p.reshape(-1) for p in sets] + [np.zeros(3, np.float32)])).to(cuda)
+    idx = nv.fps(base, torch.tensor(offs, dtype=torch.int64, device=cuda), torch.tensor(ns, dtype=torch.int32, device=cuda), max(ns), 96).cpu().numpy()
+    for s, n in enumerate(ns):
+        if n == 0:
+            assert not idx[s].any()
+        else:
+            assert np.array_equal(idx[s], om.fps_packed(sets[s].reshape(-1), n, 96)), (s, n)
+    # random (tie-free) coordinates, twice in a row on the same workspace-sized problem: the round tags of the first launch must not leak
+    p = rng.random((120000, 3)).astype(np.float32)
+    b2 = torch.from_numpy(p.reshape(-1)).to(cuda)
+    ref = om.fps_packed(p.reshape(-1), 120000, 48)
+    for _ in range(2):
+        got = nv.fps(b2, torch.tensor([0], dtype=torch.int64, device=cuda), torch.tensor([120000], dtype=torch.int32, device=cuda), 120000, 48).cpu().numpy()
+        assert np.array_equal(got[0], ref)
+
+
+def test_fps_streaming_path_for_sets_beyond_the_split_limit(cuda):
+    """More than 16 x 20 480 points: the single-workgroup streaming kernel (min-distances through the workspace)."""
+    p = np.random.default_rng(1).random((350000, 3)).astype(np.float32)
+    base = torch.from_numpy(p.reshape(-1)).to(cuda)
+    idx = nv.fps(base, torch.tensor([0], dtype=torch.int64, device=cuda), torch.tensor([350000], dtype=torch.int32, device=cuda),
+                 350000, 12).cpu().numpy()
+    assert np.array_equal(idx[0], om.fps_packed(p.reshape(-1), 350000, 12))
+
+
 def test_fused_fps_queries_match_oracle_bit_exact(cuda):
     """u3d_fps_prep | u3d_fps2 | u3d_fps_points (the detector's three-launch form of uni3detr.py:178-189) against the oracle's
     fps_queries: sampled indices identical, unit-cube points bit-identical (one subtraction and one correctly rounded division each)."""

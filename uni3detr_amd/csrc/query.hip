@@ -140,11 +140,153 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps(const float* __restrict__ b
   else fps_rounds<REG, false>(p, n, m, out, tmp, (unsigned)T - 1u, s_d, s_k, s_x, s_y, s_z, s_win);
 }
 
+// --------------------------------------------------------------------------------------------
+// Sets of more than FPS_THREADS * FPS_MAXJ = 20 480 points (nuScenes: 250 000 raw points / up to 90 000 voxels per scene, 900 samples;
+// ScanNet-large: 100 000): the streaming path above walks such a set with ONE workgroup - 72 us per round, 65 ms of the 85 ms nuScenes
+// step.  Here a set is split over W = ceil(n / 20 480) workgroups (<= FPS_MULTI_MAXW), each keeps its 20 480-point slice REGISTER-resident
+// exactly like the single-workgroup kernel (point k of slice w: k = w * 20 480 + tid + j * 1024, so k mod T = tid as before and the
+// in-thread "first maximum wins" rule holds), and the W local winners meet once per round through data-tagged 8-byte granules
+// ({value, round} written by ONE agent-scope store, polled with agent-scope loads: no fence, no counter; MI355X_MICROARCH.md
+// "handoff-1to1"): slots[round & 1][w] = {distance bits | round} {index | round}.  Two slot sets by round parity: a workgroup can be at
+// most one round ahead of the slowest one (it needs everybody's round-r candidate before it can produce round r + 1).  Every
+// workgroup reduces the W candidates with the same total order (fps_better) and fetches the winner's coordinates from the (read-only)
+// input itself.  All W * nsets workgroups must be resident together: the launcher refuses grids above the CU count, and every poll loop
+// is bounded (error flag instead of a hang).
+// --------------------------------------------------------------------------------------------
+#ifndef FPS_MULTI
+#define FPS_MULTI 1
+#endif
+#define FPS_MULTI_MAX_GRID 192      /* workgroups that must be resident together (one per CU, 256 CUs; room for the other stream's kernels) */
+#define FPS_MULTI_MAXW 16
+#define FPS_CHUNK (FPS_THREADS * FPS_MAXJ)
+#define FPS_POLL_LIMIT (1 << 24)
+__device__ __forceinline__ void fps_rounds_multi(const float* __restrict__ p, int n, int m, int* __restrict__ out, int w, int W,
+                                                 unsigned long long* __restrict__ slots, int* __restrict__ err, float* s_d, int* s_k,
+                                                 float* s_x, float* s_y, float* s_z) {
+  constexpr int NW = FPS_THREADS / 64;
+  const unsigned un = (unsigned)n, tmask = FPS_THREADS - 1u;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int kbase = w * FPS_CHUNK;
+  float px[FPS_MAXJ], py[FPS_MAXJ], pz[FPS_MAXJ], md[FPS_MAXJ];
+#pragma unroll
+  for (int j = 0; j < FPS_MAXJ; ++j) {
+    const int k = kbase + tid + j * FPS_THREADS;
+    px[j] = py[j] = pz[j] = 0.f;
+    if (k < n) { px[j] = p[3 * (long long)k]; py[j] = p[3 * (long long)k + 1]; pz[j] = p[3 * (long long)k + 2]; }
+    md[j] = k < n ? 1e10f : -1.f;
+  }
+  if (w == 0 && tid == 0) out[0] = 0;
+  if (tid == 0) { s_x[0] = p[0]; s_y[0] = p[1]; s_z[0] = p[2]; }
+  __syncthreads();
+  for (int r = 1; r < m; ++r) {
+    const float cx = s_x[0], cy = s_y[0], cz = s_z[0];
+    float bd = -2.f; int bk = 0x7fffffff;
+    int tl = kbase + tid;
+    asm volatile("" : "+v"(tl));
+#pragma unroll
+    for (int j = 0; j < FPS_MAXJ; ++j) {
+      float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+      float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      float v = fminf(md[j], d);
+      md[j] = v;
+      const bool c = v > bd;                                  // first maximum wins inside a thread (ascending k, one k mod T)
+      bd = c ? v : bd; bk = c ? tl + j * FPS_THREADS : bk;
+      if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float od = __shfl_xor(bd, o, 64); const int ok = __shfl_xor(bk, o, 64);
+      const bool c = fps_better(od, ok, bd, bk, tmask, un);
+      bd = c ? od : bd; bk = c ? ok : bk;
+    }
+    if (lane == 0) { s_d[wid] = bd; s_k[wid] = bk; }
+    __syncthreads();                                          // (everybody has read s_x[0] of the previous round by now)
+    if (wid == 0) {
+      float d2 = lane < NW ? s_d[lane] : -3.f; int k2 = lane < NW ? s_k[lane] : 0x7fffffff;
+#pragma unroll
+      for (int o = NW / 2; o > 0; o >>= 1) {
+        const float od = __shfl_xor(d2, o, 64); const int ok = __shfl_xor(k2, o, 64);
+        const bool c = fps_better(od, ok, d2, k2, tmask, un);
+        d2 = c ? od : d2; k2 = c ? ok : k2;
+      }
+      d2 = __shfl(d2, 0, 64); k2 = __shfl(k2, 0, 64);         // this workgroup's candidate of round r
+      unsigned long long* sl = slots + (size_t)(r & 1) * FPS_MULTI_MAXW * 2;
+      const unsigned long long tag = (unsigned long long)(unsigned)r << 32;
+      if (lane == 0) {
+        __hip_atomic_store(sl + w * 2, tag | (unsigned long long)__float_as_uint(d2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sl + w * 2 + 1, tag | (unsigned long long)(unsigned)k2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // lane l < W collects workgroup l's candidate (its own included: one code path)
+      float dd = -3.f; int kk = 0x7fffffff;
+      bool ready = lane >= W;
+      int polls = 0;
+      while (!__all(ready)) {
+        if (!ready) {
+          const unsigned long long g0 = __hip_atomic_load(sl + lane * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long g1 = __hip_atomic_load(sl + lane * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((g0 >> 32) == (unsigned)r && (g1 >> 32) == (unsigned)r) {
+            dd = __uint_as_float((unsigned)g0); kk = (int)(unsigned)g1; ready = true;
+          }
+        }
+        if (++polls > FPS_POLL_LIMIT) { if (lane == 0) atomicExch(err, 1); break; }      // a sibling never arrived: flag it, do not hang
+        if (!__all(ready)) __builtin_amdgcn_s_sleep(2);
+      }
+#pragma unroll
+      for (int o = FPS_MULTI_MAXW / 2; o > 0; o >>= 1) {
+        const float od = __shfl_xor(dd, o, 64); const int ok = __shfl_xor(kk, o, 64);
+        const bool c = fps_better(od, ok, dd, kk, tmask, un);
+        dd = c ? od : dd; kk = c ? ok : kk;
+      }
+      kk = __shfl(kk, 0, 64);
+      if (lane == 0) {
+        const int kw = ((unsigned)kk < un) ? kk : 0;             // (only after a time-out)
+        s_x[0] = p[3 * (long long)kw]; s_y[0] = p[3 * (long long)kw + 1]; s_z[0] = p[3 * (long long)kw + 2];
+        if (w == 0) out[r] = kw;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(FPS_THREADS) void k_fps_multi(const float* __restrict__ base, const float* __restrict__ base2, int split,
+                                                          const long long* __restrict__ set_off, const int* __restrict__ set_n, int m,
+                                                          int* __restrict__ out_idx, unsigned long long* __restrict__ slots,
+                                                          int* __restrict__ err) {
+  constexpr int NW = FPS_THREADS / 64;
+  __shared__ float s_d[NW], s_x[NW], s_y[NW], s_z[NW];
+  __shared__ int s_k[NW], s_win[1];
+  const int s = blockIdx.y, w = blockIdx.x;
+  const float* p = (s < split ? base : base2) + set_off[s];
+  const int n = set_n[s];
+  int* out = out_idx + (long long)s * m;
+  const int W = n > 0 ? (n + FPS_CHUNK - 1) / FPS_CHUNK : 1;
+  if (w >= W) return;
+  if (n <= 0) { for (int j = threadIdx.x; j < m; j += FPS_THREADS) out[j] = 0; return; }
+  if (W == 1) {                                     // a small set next to large ones: the single-workgroup rounds, no exchange
+    int T = 1;
+    while ((T << 1) <= n && (T << 1) <= 1024) T <<= 1;
+    if (T == FPS_THREADS) fps_rounds<true, true>(p, n, m, out, nullptr, (unsigned)T - 1u, s_d, s_k, s_x, s_y, s_z, s_win);
+    else fps_rounds<true, false>(p, n, m, out, nullptr, (unsigned)T - 1u, s_d, s_k, s_x, s_y, s_z, s_win);
+    return;
+  }
+  fps_rounds_multi(p, n, m, out, w, W, slots + (size_t)s * 2 * FPS_MULTI_MAXW * 2, err, s_d, s_k, s_x, s_y, s_z);
+}
+
 static int fps_launch(const float* base, const float* base2, int split, const int64_t* set_off, const int32_t* set_n, int32_t nsets,
                       int32_t max_n, int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, hipStream_t s) {
   U3D_REQUIRE(base && base2 && set_off && set_n && out_idx && nsets > 0 && m > 0, U3D_ERR_ARG);
   if (max_n <= FPS_THREADS * FPS_MAXJ) {
     hipLaunchKernelGGL(k_fps<true>, dim3(nsets), dim3(FPS_THREADS), 0, s, base, base2, split, (const long long*)set_off, set_n, m, out_idx, temp, (long long)temp_stride);
+  } else if (FPS_MULTI && u3d_cdiv(max_n, FPS_CHUNK) <= FPS_MULTI_MAXW && (long long)u3d_cdiv(max_n, FPS_CHUNK) * nsets <= FPS_MULTI_MAX_GRID) {
+    // large sets split over several resident workgroups (k_fps_multi); the head of `temp` carries the per-set candidate slots + the
+    // error flag (zeroed here: round tags start at 1), so the workspace contract of the streaming path covers it
+    U3D_REQUIRE(temp && temp_stride >= max_n, U3D_ERR_WORKSPACE);
+    const int W = u3d_cdiv(max_n, FPS_CHUNK);
+    const size_t slot_bytes = (size_t)nsets * 2 * FPS_MULTI_MAXW * 2 * 8;
+    U3D_REQUIRE((size_t)nsets * (size_t)temp_stride * 4 >= slot_bytes + 64, U3D_ERR_WORKSPACE);
+    if (hipMemsetAsync(temp, 0, slot_bytes + 64, s) != hipSuccess) return U3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_fps_multi, dim3(W, nsets), dim3(FPS_THREADS), 0, s, base, base2, split, (const long long*)set_off, set_n, m, out_idx,
+                       (unsigned long long*)temp, (int*)((char*)temp + slot_bytes));
   } else {
     U3D_REQUIRE(temp && temp_stride >= max_n, U3D_ERR_WORKSPACE);
     hipLaunchKernelGGL(k_fps<false>, dim3(nsets), dim3(FPS_THREADS), 0, s, base, base2, split, (const long long*)set_off, set_n, m, out_idx, temp, (long long)temp_stride);
