@@ -371,8 +371,10 @@ int32_t u3d_scatter_rows(const void* in, const int32_t* idx, int32_t n, int32_t 
  * SURVEY.md App. A5).  nsets independent point sets; point k of set s is the float triple base[set_off[s]+3k..+2]
  * (the packed-triple view the upstream kernel takes of whatever buffer it is handed).  idx[0]=0; squared-L2 running
  * minimum; arg-max ties resolved as the upstream 2^k-thread block reduction does: smallest (k mod T, k),
- * T = min(1024, 2^floor(log2 n)).  out_idx int32 [nsets, m].  temp: f32 [nsets, temp_stride] only needed when
- * max_n > 20480.
+ * T = min(1024, 2^floor(log2 n)).  out_idx int32 [nsets, m].  temp: f32 [nsets, temp_stride >= max_n] workspace, only needed
+ * when max_n > 20480: such sets run either on ceil(n / 20480) <= 16 resident workgroups per set that exchange their round
+ * winners through the head of temp (when ceil(max_n / 20480) * nsets <= 192), or on one workgroup streaming the running
+ * minima through temp.  Same indices either way.
  * ---------------------------------------------------------------------------------------------- */
 int32_t u3d_fps(const float* base, const int64_t* set_off, const int32_t* set_n, int32_t nsets, int32_t max_n,
                 int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, u3d_stream s);
