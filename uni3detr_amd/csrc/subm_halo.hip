@@ -58,15 +58,17 @@ extern "C" int32_t u3d_debug_halo_wgrad_times(uint64_t* out) { return hipMemcpyF
 // order, and an entry's slot is prefix[word] + popcount(bits below) + 1 - two LDS reads.  (A hash set + bitonic sort of the keys
 // took 44 us per level, a sort of the raw 27 x 128 entries 180 us; sorted slots keep the neighbours of consecutive rows on
 // consecutive LDS rows - conflict-free fragment reads in k_subm_halo64.)
-// dynamic LDS: bitmap u32 [W] | word prefix u16 [W] | part int [256], W = words rounded up to a multiple of 256
+// dynamic LDS: bitmap u32 [W] | prefix u16 [W / 4] (one per GROUP of four words = 128 rows) | part int [256], W = words rounded up to a
+// multiple of 1024.  (A prefix per word cost 6 B per 32 rows and capped a level at 869 k rows - ScanNet-large's 64-channel level has a
+// capacity of 960 k; per group it is 4.5 B per 32 rows = 1.15 M rows, for up to three more popcounts per lookup.)
 __global__ __launch_bounds__(256) void k_halo_build(const int32_t* __restrict__ nbr, int ld, int kvol, const int32_t* __restrict__ n_dev,
                                                     int n_cap, int wpt, int32_t* __restrict__ tile_rows, u16* __restrict__ loc,
                                                     int32_t* __restrict__ tile_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int W = wpt * 256;
+  const int W = wpt * 256;                        // wpt % 4 == 0: a thread owns whole groups
   unsigned* bits = (unsigned*)smem;
-  u16* wpre = (u16*)(bits + W);
-  int* part = (int*)(wpre + W);
+  u16* gpre = (u16*)(bits + W);                   // [W / 4]
+  int* part = (int*)(gpre + W / 4);
   const int tid = threadIdx.x, tile = blockIdx.x;
   const int m0 = tile * HL_T;
   const int n = min(*n_dev, n_cap);
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void k_halo_build(const int32_t* __restrict__ 
     if (gs[i] >= 0) atomicOr(&bits[gs[i] >> 5], 1u << (gs[i] & 31));
   __syncthreads();
   HB_MARK(2);
-  // thread t owns words [t * wpt, (t + 1) * wpt): popcount, block scan, per-word exclusive prefix
+  // thread t owns words [t * wpt, (t + 1) * wpt): popcount, block scan, per-group exclusive prefix
   int c = 0;
   for (int j = 0; j < wpt; ++j) c += __popc(bits[tid * wpt + j]);
   part[tid] = c;
@@ -103,28 +105,36 @@ __global__ __launch_bounds__(256) void k_halo_build(const int32_t* __restrict__ 
   int32_t* tr = tile_rows + (long long)tile * HL_TRC;
   if (tid == 0) { tile_cnt[tile] = total + 1; tr[0] = -1; }
   int p = part[tid] - c;
-  for (int j = 0; j < wpt; ++j) {
+  for (int j = 0; j < wpt; j += 4) {
     const int wd = tid * wpt + j;
-    wpre[wd] = (u16)p;
-    p += __popc(bits[wd]);
+    gpre[wd >> 2] = (u16)p;
+    p += __popc(bits[wd]) + __popc(bits[wd + 1]) + __popc(bits[wd + 2]) + __popc(bits[wd + 3]);
   }
   __syncthreads();
-  // slot-parallel: the i-th set bit = (last word whose prefix is <= i - a non-empty word is the last of its run of equal
-  // prefixes -, bit of rank i - prefix in it).  A word-parallel loop over set bits ran 26 words x up to 32 bits with one lane live.
+  // slot-parallel: the i-th set bit = (last group whose prefix is <= i - a non-empty group is the last of its run of equal
+  // prefixes -, then the word inside it, then the bit of that rank).  A word-parallel loop over set bits ran 26 words x up to 32 bits
+  // with one lane live.
+  const int NG = W >> 2;
   for (int i = tid; i < total; i += 256) {
-    int lo = 0, hi = W;                           // wpre[lo] <= i < wpre[hi] (wpre[W] = total)
+    int lo = 0, hi = NG;                          // gpre[lo] <= i < gpre[hi] (gpre[NG] = total)
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if ((int)wpre[mid] <= i) lo = mid; else hi = mid;
+      if ((int)gpre[mid] <= i) lo = mid; else hi = mid;
     }
-    unsigned v = bits[lo];
-    int k = i - (int)wpre[lo], pos = 0;
+    int k = i - (int)gpre[lo], wd = lo << 2;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {                 // the word of the group that holds rank k
+      const int cw = __popc(bits[wd]);
+      if (k >= cw) { k -= cw; ++wd; }
+    }
+    unsigned v = bits[wd];
+    int pos = 0;
 #pragma unroll
     for (int sh = 16; sh >= 1; sh >>= 1) {
       const int cnt = __popc(v & ((1u << sh) - 1u));
       if (k >= cnt) { k -= cnt; pos += sh; v >>= sh; }
     }
-    tr[1 + i] = lo * 32 + pos;
+    tr[1 + i] = wd * 32 + pos;
   }
   __syncthreads();
   HB_MARK(4);
@@ -134,7 +144,13 @@ __global__ __launch_bounds__(256) void k_halo_build(const int32_t* __restrict__ 
     const int e = tid + i * 256;
     const int g = gs[i];
     int slot = 0;
-    if (g >= 0) slot = wpre[g >> 5] + __popc(bits[g >> 5] & ((1u << (g & 31)) - 1u)) + 1;
+    if (g >= 0) {
+      const int wd = g >> 5, w0 = wd & ~3;
+      slot = gpre[wd >> 2] + __popc(bits[wd] & ((1u << (g & 31)) - 1u)) + 1;
+      if (wd > w0) slot += __popc(bits[w0]);
+      if (wd > w0 + 1) slot += __popc(bits[w0 + 1]);
+      if (wd > w0 + 2) slot += __popc(bits[w0 + 2]);
+    }
     if (e < HL_K * HL_T) lp[e] = (u16)slot;      // entry (r % 16) * 8 + r / 16 of (tile, k): a lane's 8 row blocks in one 16 B word
   }
   HB_MARK(5);
@@ -803,9 +819,9 @@ extern "C" int32_t u3d_subm_halo_sizes(int32_t n_cap, int64_t* tile_rows_elems, 
 extern "C" int32_t u3d_subm_halo_build(const int32_t* nbr, int32_t ld, const int32_t* n_dev, int32_t n_cap, int32_t* tile_rows,
                                        uint16_t* loc, int32_t* tile_cnt, int32_t kvol, u3d_stream s) {
   U3D_REQUIRE(nbr && n_dev && tile_rows && loc && tile_cnt && n_cap > 0 && ld >= n_cap && kvol >= 1 && kvol <= HL_K, U3D_ERR_ARG);
-  const int wpt = u3d_cdiv(u3d_cdiv(n_cap, 32), 256);
-  const int lds = wpt * 256 * 6 + 1024;
-  if (lds > 160 * 1024) return U3D_ERR_UNSUPPORTED;      // > 869 k rows: the row bitmap does not fit the LDS
+  const int wpt = u3d_cdiv(u3d_cdiv(n_cap, 32), 1024) * 4;      // words per thread, a multiple of 4 (whole prefix groups)
+  const int lds = wpt * 256 * 4 + wpt * 64 * 2 + 1024;
+  if (lds > 160 * 1024) return U3D_ERR_UNSUPPORTED;      // > 1.15 M rows: the row bitmap does not fit the LDS
   U3D_ALLOW_LDS(k_halo_build, 160 * 1024);                // set once per device: the maximum, the launch asks for what n_cap needs
   k_halo_build<<<u3d_cdiv(n_cap, HL_T), 256, lds, (hipStream_t)s>>>(nbr, ld, kvol, n_dev, n_cap, wpt, tile_rows, loc, tile_cnt);
   U3D_CHECK_LAUNCH();

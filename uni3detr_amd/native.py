@@ -519,7 +519,7 @@ class SubmHalo:
     the forward neighbour table, shared by all of the level's 64 -> 64 convs and (offsets reversed) their input gradients."""
     TILE = 128
 
-    MAX_ROWS = 106 * 256 * 32       # u3d_subm_halo_build's LDS row bitmap: 6 B per 32 rows + 1 KiB within 160 KiB
+    MAX_ROWS = 140 * 256 * 32       # u3d_subm_halo_build's LDS row bitmap: 4.5 B per 32 rows + 1 KiB within 160 KiB (the C side decides)
 
     def __init__(self, nbr_fwd, n_dev, n_cap):
         dev = nbr_fwd.device
