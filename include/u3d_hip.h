@@ -171,9 +171,11 @@ int32_t u3d_linear_bf16(const void* x, const void* w, const float* bias, int32_t
  * [hi ; lo] with a plane stride of n_cap rows) and x.w ~ hi.wh + hi.wl + lo.wh with f32 accumulation.  The caller passes the three
  * products as three sets of offsets: nbr int32 [kvol3][ld] = (nbr, nbr, nbr + n_in_cap), w bf16 [kvol3][Cout][Cin] = (wh, wl, wh),
  * kvol3 = 3 x offsets.  out is F32 [n_out_cap][Cout]; stats: NULL or f64 [ceil(n_out_cap / u3d_igemm_fwd_stats_rows(.., kvol3))][2][Cout]
- * per-tile BatchNorm sums of the f32 output.  U3D_ERR_UNSUPPORTED unless Cin % 64 == 0 and Cout % 64 == 0. */
+ * per-tile BatchNorm sums of the f32 output; addend: NULL or f32 [n_out_cap][Cout] summed into the result in the epilogue (the
+ * residual / fan-out gradient sums of the input gradients, as u3d_igemm_fwd_add_bf16).  U3D_ERR_UNSUPPORTED unless Cin % 64 == 0 and
+ * Cout % 64 == 0. */
 int32_t u3d_igemm_fwd_split_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, float* out, const int32_t* n_out_dev,
-                                 int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol3, double* stats, u3d_stream s);
+                                 int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol3, double* stats, const float* addend, u3d_stream s);
 /* The same product on the NARROW 27-offset sparse levels (cin, cout in {16, 32, 64}, not 64 -> 64; the encoder's stride-1 / stride-2
  * stages, ref: sparse_encoder_hd.py:140-214): three launches of the direct-operand kernel (igemm_direct.hip) accumulating into one f32
  * output - no tripled table: in = the bf16 planes [2 * n_in_cap][cin], w3 = (wh, wl, wh) n-major [3 * 27][cout][cin], nbr / ld as

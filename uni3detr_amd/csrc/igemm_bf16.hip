@@ -1411,16 +1411,17 @@ extern "C" int32_t u3d_igemm_fwd_stats_bf16(const void* in, const void* w, const
 //   out  f32 [n_out_cap][cout]; stats (optional) f64 [ceil(n_out_cap / u3d_igemm_fwd_stats_rows(.., kvol3))][2][cout] of the f32 output
 extern "C" int32_t u3d_igemm_fwd_split_bf16(const void* in, const void* w, const int32_t* nbr, int32_t ld, float* out,
                                             const int32_t* n_out_dev, int32_t n_out_cap, int32_t cin, int32_t cout, int32_t kvol3,
-                                            double* stats, u3d_stream s) {
+                                            double* stats, const float* addend, u3d_stream s) {
   U3D_REQUIRE(in && w && out && n_out_dev && nbr && kvol3 > 0, U3D_ERR_ARG);
   if (!IGEMM_GLDS || cin % 64 != 0 || cout % 64 != 0) return U3D_ERR_UNSUPPORTED;
   if (n_out_cap <= 0) return U3D_OK;
   const int tr = u3d_igemm_fwd_stats_tile_rows(n_out_cap, cin, cout);
-  if (tr == 256) return launch_igemm_glds<GLDS256_CFG>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol3, s, nullptr, 0, stats, BnEpi{}, true);
+  if (tr == 256 && addend && !(IGEMM_GLDS8 && nbr)) return U3D_ERR_UNSUPPORTED;      // (the two-phase 256 x 256 kernel has no addend epilogue)
+  if (tr == 256) return launch_igemm_glds<GLDS256_CFG>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol3, s, addend, addend ? 2 : 0, stats, BnEpi{}, true);
   if (igemm_glds8n_shape(nbr, n_out_cap, cin, cout, kvol3))
-    return launch_igemm_glds8n(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol3, s, nullptr, 0, stats, BnEpi{}, true);
-  if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol3, s, nullptr, 0, stats, BnEpi{}, true);
-  return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol3, s, nullptr, 0, stats, BnEpi{}, true);
+    return launch_igemm_glds8n(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol3, s, addend, addend ? 2 : 0, stats, BnEpi{}, true);
+  if (cout % 128 == 0) return launch_igemm_glds<2, 2, 4, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol3, s, addend, addend ? 2 : 0, stats, BnEpi{}, true);
+  return launch_igemm_glds<4, 1, 2, 4>(in, w, nbr, ld, out, n_out_dev, n_out_cap, cin, cout, kvol3, s, addend, addend ? 2 : 0, stats, BnEpi{}, true);
 }
 
 // hi / lo bf16 planes of an f32 row matrix: dst[r] = bf16(x[r]), dst[n_cap + r] = bf16(x[r] - dst[r]) (round to nearest even both)

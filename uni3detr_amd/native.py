@@ -106,7 +106,7 @@ _SIGS = {
     "u3d_bn_finalize_partials": (_I, [_P, _I, _I, _P, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     "u3d_igemm_fwd_stats_tile_rows": (_I, [_I, _I, _I]),
     "u3d_igemm_fwd_stats_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
-    "u3d_igemm_fwd_split_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "u3d_igemm_fwd_split_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "u3d_split_rows_f32": (_I, [_P, _P, _I, _I, _P, _P]),
     "u3d_split3_weights": (_I, [_P, C.c_int64, C.c_int64, C.c_int64, _I, _I, _I, _P, _P]),
     "u3d_igemm_direct_split_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
@@ -745,7 +745,7 @@ def split3_weights(weight, layout, nmajor):
     return out
 
 
-def spconv_fwd_split(xs, w3, nbr3, n_out_dev, n_out, cout, want_stats=False, tag="spconv_fwd"):
+def spconv_fwd_split(xs, w3, nbr3, n_out_dev, n_out, cout, want_stats=False, tag="spconv_fwd", addend=None):
     """Split-bf16 product (u3d_igemm_fwd_split_bf16): xs bf16 [2 * n_in, cin] planes, w3 bf16 [3K, cout, cin] = (wh, wl, wh), nbr3 int32
     [3K, ld] = (nbr, nbr, nbr + n_in) -> f32 [n_out, cout] (+ per-tile BatchNorm sums f64 [tiles, 2, cout], rows per tile)."""
     kvol3, cin = w3.shape[0], xs.shape[1]
@@ -757,8 +757,9 @@ def spconv_fwd_split(xs, w3, nbr3, n_out_dev, n_out, cout, want_stats=False, tag
             stats = torch.empty(((n_out + tr - 1) // tr, 2, cout), dtype=torch.float64, device=xs.device)
     t = TIMER
     e0 = t.begin() if t is not None else None
+    assert addend is None or (addend.dtype == torch.float32 and tuple(addend.shape) == (n_out, cout))
     _check(lib().u3d_igemm_fwd_split_bf16(_ptr(xs), _ptr(w3), _ptr(nbr3), nbr3.shape[1], _ptr(out), _ptr(n_out_dev), n_out, cin, cout, kvol3,
-                                          _ptr(stats), _stream()), "igemm_fwd_split_bf16")
+                                          _ptr(stats), _ptr(addend), _stream()), "igemm_fwd_split_bf16")
     if t is not None:
         meta = None
         if t.mode == "census":

@@ -190,6 +190,7 @@ def reset_conv_uses():
 # activations travel as f32 rows, are split into hi / lo bf16 planes in front of each conv, and the three products are three sets of
 # offsets of ONE launch (tripled neighbour table and weights).  Narrow levels (16 / 32 channels) stay on the exact f32 kernels.
 SPLIT_BF16 = os.environ.get("U3D_SPLIT_BF16", "1") == "1"
+SPLIT_FUSED_ADD = os.environ.get("U3D_SPLIT_FUSED_ADD", "1") == "1"      # residual / fan-out gradient sums in the split input gradient's epilogue
 _SPLIT = [False]
 
 
@@ -480,18 +481,35 @@ def _split_backward_impl(ctx, xs, wc, dout):
             wt3 = nv.split3_weights(wc, ctx.layout, nmajor=False).view(3, kvol * cin, cout)      # [K, Cin, Cout] as ONE [K * Cin, Cout] matrix
             prod = nv.spconv_fwd_split(dys, wt3, tid, g.n_out_dev, n_out, kvol * cin, tag="spconv_dgrad")
             din = nv.tap_gather_sum(prod, g.nbr_bwd, g.n_in_dev, g.n_in, cin, kvol)
+            fused_add = False
         else:
+            # the residual branch's / the other fan-out branches' gradient rides the launch's epilogue (f32 addend), as in bf16 mode
+            fan, tok = ctx.fan_token, ctx.res_token
+            add = tok.dres if (tok is not None and tok.dres is not None) else None
+            facc = fan.acc if fan is not None else None
+            if add is not None and facc is not None:
+                add = add + facc
+            elif facc is not None:
+                add = facc
+            fused_add = SPLIT_FUSED_ADD and (add is None or (add.dtype == torch.float32 and add.is_contiguous() and tuple(add.shape) == (g.n_in, cin)))
             t3 = _split_table(g, "bwd", g.n_in, n_out)
-            din = nv.spconv_fwd_split(dys, nv.split3_weights(wc, ctx.layout, nmajor=False), t3, g.n_in_dev, g.n_in, cin, tag="spconv_dgrad")
+            din = nv.spconv_fwd_split(dys, nv.split3_weights(wc, ctx.layout, nmajor=False), t3, g.n_in_dev, g.n_in, cin, tag="spconv_dgrad",
+                                      addend=add if fused_add else None)
         fan = ctx.fan_token
-        if fan is not None:
-            if fan.acc is not None:
-                din += fan.acc
-            din = fan.step(din)
         tok = ctx.res_token
-        if tok is not None and tok.dres is not None:
-            din = din + tok.dres
-            tok.dres = None
+        if fused_add:
+            if tok is not None:
+                tok.dres = None
+            if fan is not None:
+                din = fan.step(din)
+        else:
+            if fan is not None:
+                if fan.acc is not None:
+                    din += fan.acc
+                din = fan.step(din)
+            if tok is not None and tok.dres is not None:
+                din = din + tok.dres
+                tok.dres = None
     elif ctx.res_token is not None:
         ctx.res_token.dres = None
     return din, dw, None, None, None, None, None, None
