@@ -375,8 +375,8 @@ int32_t u3d_scatter_rows(const void* in, const int32_t* idx, int32_t n, int32_t 
  * minimum; arg-max ties resolved as the upstream 2^k-thread block reduction does: smallest (k mod T, k),
  * T = min(1024, 2^floor(log2 n)).  out_idx int32 [nsets, m].  temp: f32 [nsets, temp_stride >= max_n] workspace, only needed
  * when max_n > 20480: such sets run either on ceil(n / 20480) <= 16 resident workgroups per set that exchange their round
- * winners through the head of temp (when ceil(max_n / 20480) * nsets <= 192), or on one workgroup streaming the running
- * minima through temp.  Same indices either way.
+ * winners through the head of temp (sets go out in launches of at most 192 workgroups), or - beyond 16 x 20480 points - on one
+ * workgroup streaming the running minima through temp.  Same indices either way.
  * ---------------------------------------------------------------------------------------------- */
 int32_t u3d_fps(const float* base, const int64_t* set_off, const int32_t* set_n, int32_t nsets, int32_t max_n,
                 int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, u3d_stream s);

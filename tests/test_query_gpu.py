@@ -85,6 +85,21 @@ def test_fps_large_sets_split_over_workgroups(cuda):
         assert np.array_equal(got[0], ref)
 
 
+def test_fps_many_large_sets_go_out_in_groups(cuda):
+    """More large sets than fit the chip at once (80 sets x 3 workgroups > 192): several launches of k_fps_multi, one result."""
+    rng = np.random.default_rng(9)
+    ns = [45000 + 13 * i for i in range(80)]
+    pts = [rng.integers(0, 64, (n, 3)).astype(np.float32) for n in ns[:3]]
+    sets = [pts[i % 3][: ns[i]] if ns[i] <= pts[i % 3].shape[0] else np.concatenate([pts[i % 3], pts[(i + 1) % 3]])[: ns[i]] for i in range(80)]
+    offs, o = [], 0
+    for p in sets:
+        offs.append(o); o += p.size
+    base = torch.from_numpy(np.concatenate([p.reshape(-1) for p in sets])).to(cuda)
+    idx = nv.fps(base, torch.tensor(offs, dtype=torch.int64, device=cuda), torch.tensor(ns, dtype=torch.int32, device=cuda), max(ns), 24).cpu().numpy()
+    for s in (0, 1, 40, 63, 64, 65, 79):
+        assert np.array_equal(idx[s], om.fps_packed(sets[s].reshape(-1), ns[s], 24)), s
+
+
 def test_fps_streaming_path_for_sets_beyond_the_split_limit(cuda):
     """More than 16 x 20 480 points: the single-workgroup streaming kernel (min-distances through the workspace)."""
     p = np.random.default_rng(1).random((350000, 3)).astype(np.float32)

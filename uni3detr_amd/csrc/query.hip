@@ -150,8 +150,8 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps(const float* __restrict__ b
 // "handoff-1to1"): slots[round & 1][w] = {distance bits | round} {index | round}.  Two slot sets by round parity: a workgroup can be at
 // most one round ahead of the slowest one (it needs everybody's round-r candidate before it can produce round r + 1).  Every
 // workgroup reduces the W candidates with the same total order (fps_better) and fetches the winner's coordinates from the (read-only)
-// input itself.  All W * nsets workgroups must be resident together: the launcher refuses grids above the CU count, and every poll loop
-// is bounded (error flag instead of a hang).
+// input itself.  All workgroups of a launch must be resident together: the launcher sends the sets out in groups of at most
+// FPS_MULTI_MAX_GRID workgroups, and every poll loop is bounded (error flag instead of a hang).
 // --------------------------------------------------------------------------------------------
 #ifndef FPS_MULTI
 #define FPS_MULTI 1
@@ -251,11 +251,11 @@ __device__ __forceinline__ void fps_rounds_multi(const float* __restrict__ p, in
 __global__ __launch_bounds__(FPS_THREADS) void k_fps_multi(const float* __restrict__ base, const float* __restrict__ base2, int split,
                                                           const long long* __restrict__ set_off, const int* __restrict__ set_n, int m,
                                                           int* __restrict__ out_idx, unsigned long long* __restrict__ slots,
-                                                          int* __restrict__ err) {
+                                                          int* __restrict__ err, int s0) {
   constexpr int NW = FPS_THREADS / 64;
   __shared__ float s_d[NW], s_x[NW], s_y[NW], s_z[NW];
   __shared__ int s_k[NW], s_win[1];
-  const int s = blockIdx.y, w = blockIdx.x;
+  const int s = s0 + blockIdx.y, w = blockIdx.x;      // (s0: first set of this launch - many sets go out in groups that fit the chip)
   const float* p = (s < split ? base : base2) + set_off[s];
   const int n = set_n[s];
   int* out = out_idx + (long long)s * m;
@@ -277,7 +277,7 @@ static int fps_launch(const float* base, const float* base2, int split, const in
   U3D_REQUIRE(base && base2 && set_off && set_n && out_idx && nsets > 0 && m > 0, U3D_ERR_ARG);
   if (max_n <= FPS_THREADS * FPS_MAXJ) {
     hipLaunchKernelGGL(k_fps<true>, dim3(nsets), dim3(FPS_THREADS), 0, s, base, base2, split, (const long long*)set_off, set_n, m, out_idx, temp, (long long)temp_stride);
-  } else if (FPS_MULTI && u3d_cdiv(max_n, FPS_CHUNK) <= FPS_MULTI_MAXW && (long long)u3d_cdiv(max_n, FPS_CHUNK) * nsets <= FPS_MULTI_MAX_GRID) {
+  } else if (FPS_MULTI && u3d_cdiv(max_n, FPS_CHUNK) <= FPS_MULTI_MAXW) {
     // large sets split over several resident workgroups (k_fps_multi); the head of `temp` carries the per-set candidate slots + the
     // error flag (zeroed here: round tags start at 1), so the workspace contract of the streaming path covers it
     U3D_REQUIRE(temp && temp_stride >= max_n, U3D_ERR_WORKSPACE);
@@ -285,8 +285,12 @@ static int fps_launch(const float* base, const float* base2, int split, const in
     const size_t slot_bytes = (size_t)nsets * 2 * FPS_MULTI_MAXW * 2 * 8;
     U3D_REQUIRE((size_t)nsets * (size_t)temp_stride * 4 >= slot_bytes + 64, U3D_ERR_WORKSPACE);
     if (hipMemsetAsync(temp, 0, slot_bytes + 64, s) != hipSuccess) return U3D_ERR_LAUNCH;
-    hipLaunchKernelGGL(k_fps_multi, dim3(W, nsets), dim3(FPS_THREADS), 0, s, base, base2, split, (const long long*)set_off, set_n, m, out_idx,
-                       (unsigned long long*)temp, (int*)((char*)temp + slot_bytes));
+    const int per = FPS_MULTI_MAX_GRID / W;            // sets per launch: all their workgroups must be resident together
+    for (int s0 = 0; s0 < nsets; s0 += per) {
+      const int ns = nsets - s0 < per ? nsets - s0 : per;
+      hipLaunchKernelGGL(k_fps_multi, dim3(W, ns), dim3(FPS_THREADS), 0, s, base, base2, split, (const long long*)set_off, set_n, m, out_idx,
+                         (unsigned long long*)temp, (int*)((char*)temp + slot_bytes), s0);
+    }
   } else {
     U3D_REQUIRE(temp && temp_stride >= max_n, U3D_ERR_WORKSPACE);
     hipLaunchKernelGGL(k_fps<false>, dim3(nsets), dim3(FPS_THREADS), 0, s, base, base2, split, (const long long*)set_off, set_n, m, out_idx, temp, (long long)temp_stride);
