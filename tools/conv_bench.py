@@ -21,6 +21,10 @@ LAYERS = {
     "dense32to64": (8, (30, 60, 24), 32, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     "dense16to32": (8, (20, 40, 20), 16, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     "dense16": (8, (20, 40, 20), 16, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    # the same 128-channel layer at other heights (KITTI: 704 000 rows): how the two-phase tile's efficiency depends on the launch size
+    "rows96k_128k9": (4, (15, 40, 40), 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    "rows384k_128k9": (16, (15, 40, 40), 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    "rows704k_128k9": (4, (5, 200, 176), 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     # SECOND3D's strided first convs (branches 1 and 2 read the 192 000-row volume with stride 2 / 4)
     "stride2_256": (8, (15, 40, 40), 256, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
     "stride4_512": (8, (15, 40, 40), 256, 512, (1, 3, 3), (1, 4, 4), (0, 1, 1)),
