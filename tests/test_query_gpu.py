@@ -83,6 +83,7 @@ def test_fps_large_sets_split_over_workgroups(cuda):
     for _ in range(2):
         got = nv.fps(b2, torch.tensor([0], dtype=torch.int64, device=cuda), torch.tensor([120000], dtype=torch.int32, device=cuda), 120000, 48).cpu().numpy()
         assert np.array_equal(got[0], ref)
+    assert not nv.fps_multi_error()                      # no workgroup gave up waiting for a sibling
 
 
 def test_fps_many_large_sets_go_out_in_groups(cuda):

@@ -943,6 +943,26 @@ def scatter_rows(inp, idx, n_out):
 FPS_REG_MAX = 20480
 
 
+# workspace of the last FPS launch over sets above FPS_REG_MAX points (k_fps_multi keeps its candidate slots and a time-out flag at its
+# head: include/u3d_hip.h u3d_fps): fps_multi_error() reads the flag - a host synchronisation, so callers poll it rarely
+_FPS_MULTI_WS = [None, 0]
+
+
+def _note_fps_ws(temp, nsets, max_n):
+    if temp is not None and -(-max_n // FPS_REG_MAX) <= 16:
+        _FPS_MULTI_WS[0], _FPS_MULTI_WS[1] = temp, nsets * 2 * 16 * 2 * 8
+
+
+def fps_multi_error():
+    """True when a workgroup of the last multi-workgroup FPS launch gave up waiting for its siblings (their round candidates never
+    arrived within the poll limit: the sampled indices of that launch are not to be trusted).  Synchronises with the device.  Valid
+    for an EAGER call (the workspace of a call made during a hipGraph capture is the graph's to reuse: tests and one-off launches only)."""
+    ws, off = _FPS_MULTI_WS
+    if ws is None:
+        return False
+    return bool(int(ws.view(torch.uint8).reshape(-1)[off:off + 4].view(torch.int32).item()))
+
+
 def fps(base, set_off, set_n, max_n, m):
     """base: f32 device buffer; set_off int64 [S] element offsets; set_n int32 [S]; -> idx int32 [S, m]."""
     nsets = set_off.shape[0]
@@ -952,6 +972,7 @@ def fps(base, set_off, set_n, max_n, m):
         temp = torch.empty((nsets, max_n), dtype=torch.float32, device=base.device)
         stride = max_n
     _check(lib().u3d_fps(_ptr(base), _ptr(set_off), _ptr(set_n), nsets, max_n, m, _ptr(out), _ptr(temp), stride, _stream()), "fps")
+    _note_fps_ws(temp, nsets, max_n)
     return out
 
 
@@ -974,6 +995,7 @@ def fps_queries(points, coors, scene_off, voxel_off, batch, max_n, m):
         stride = max_n
     _check(lib().u3d_fps2(_ptr(points), _ptr(vox), batch, _ptr(set_off), _ptr(set_n), 2 * batch, max_n, m, _ptr(idx), _ptr(temp), stride,
                           _stream()), "fps2")
+    _note_fps_ws(temp, 2 * batch, max_n)
     out = torch.empty((batch, 2 * m, 3), dtype=torch.float32, device=dev)
     _check(lib().u3d_fps_points(_ptr(points), F_, _ptr(vox), _ptr(idx), _ptr(scene_off), _ptr(voxel_off), batch, m, _ptr(out), _stream()),
            "fps_points")
