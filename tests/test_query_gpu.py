@@ -86,6 +86,34 @@ def test_fps_large_sets_split_over_workgroups(cuda):
     assert not nv.fps_multi_error()                      # no workgroup gave up waiting for a sibling
 
 
+def test_fps_large_sets_replayed_from_a_graph(cuda):
+    """The multi-workgroup FPS inside a captured hipGraph, replayed on changing data: the candidate slots are cleared by a kernel of the
+    graph (a memset NODE does not leave zeros on replay on this stack: HISTORY.md), so no round tag of the previous replay survives."""
+    rng = np.random.default_rng(11)
+    n, m = 60000, 40
+    data = [rng.integers(0, 50, (n, 3)).astype(np.float32) for _ in range(3)]
+    base = torch.zeros(n * 3, device=cuda)
+    off = torch.tensor([0], dtype=torch.int64, device=cuda)
+    cnt = torch.tensor([n], dtype=torch.int32, device=cuda)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        base.copy_(torch.from_numpy(data[0].reshape(-1)))
+        nv.fps(base, off, cnt, n, m)                     # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        idx = nv.fps(base, off, cnt, n, m)
+    for d in data:
+        base.copy_(torch.from_numpy(d.reshape(-1)))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(idx[0].cpu().numpy(), om.fps_packed(d.reshape(-1), n, m))
+        assert not nv.fps_multi_error()
+
+
 def test_fps_many_large_sets_go_out_in_groups(cuda):
     """More large sets than fit the chip at once (80 sets x 3 workgroups > 192): several launches of k_fps_multi, one result."""
     rng = np.random.default_rng(9)

@@ -248,6 +248,10 @@ __device__ __forceinline__ void fps_rounds_multi(const float* __restrict__ p, in
   }
 }
 
+__global__ void k_fps_zero(unsigned long long* __restrict__ p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0ull;
+}
+
 __global__ __launch_bounds__(FPS_THREADS) void k_fps_multi(const float* __restrict__ base, const float* __restrict__ base2, int split,
                                                           const long long* __restrict__ set_off, const int* __restrict__ set_n, int m,
                                                           int* __restrict__ out_idx, unsigned long long* __restrict__ slots,
@@ -284,7 +288,9 @@ static int fps_launch(const float* base, const float* base2, int split, const in
     const int W = u3d_cdiv(max_n, FPS_CHUNK);
     const size_t slot_bytes = (size_t)nsets * 2 * FPS_MULTI_MAXW * 2 * 8;
     U3D_REQUIRE((size_t)nsets * (size_t)temp_stride * 4 >= slot_bytes + 64, U3D_ERR_WORKSPACE);
-    if (hipMemsetAsync(temp, 0, slot_bytes + 64, s) != hipSuccess) return U3D_ERR_LAUNCH;
+    // (a kernel, not hipMemsetAsync: the memset NODE of a captured graph left a repeating 16-byte pattern of two device pointers
+    //  in this range on replay instead of zeros - ROCm 7.2, tools/fps_ws_probe.py; stale round tags of the previous replay must go)
+    hipLaunchKernelGGL(k_fps_zero, dim3(1), dim3(256), 0, s, (unsigned long long*)temp, (int)((slot_bytes + 64) / 8));
     const int per = FPS_MULTI_MAX_GRID / W;            // sets per launch: all their workgroups must be resident together
     for (int s0 = 0; s0 < nsets; s0 += per) {
       const int ns = nsets - s0 < per ? nsets - s0 : per;

@@ -955,8 +955,8 @@ def _note_fps_ws(temp, nsets, max_n):
 
 def fps_multi_error():
     """True when a workgroup of the last multi-workgroup FPS launch gave up waiting for its siblings (their round candidates never
-    arrived within the poll limit: the sampled indices of that launch are not to be trusted).  Synchronises with the device.  Valid
-    for an EAGER call (the workspace of a call made during a hipGraph capture is the graph's to reuse: tests and one-off launches only)."""
+    arrived within the poll limit: the sampled indices of that launch are not to be trusted).  Synchronises with the device.  For a
+    captured launch it reads the flag the last REPLAY left (the workspace tensor of the capture stays referenced here)."""
     ws, off = _FPS_MULTI_WS
     if ws is None:
         return False

@@ -615,6 +615,8 @@ class TrainStep:
     def held_steps(self):
         """Steps whose update was held because a sparse level overflowed somewhere in the job (one small device-to-host read;
         identical on every rank: the flag is all-reduced before the update)."""
+        if nv.fps_multi_error():             # (the same rare host read: large point sets sampled by several workgroups, native.fps_multi_error)
+            raise RuntimeError("FPS over several workgroups timed out waiting for a sibling workgroup: sampled query points are invalid")
         if not self.flat_update:
             return 0
         return int(self.opt_state[12].item())
