@@ -52,7 +52,7 @@ def parse():
                     help="shipped configuration to run (BASELINE.json configs[1..4]); the headline metric is quoted on sunrgbd")
     ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (default: the workload's)")
     ap.add_argument("--points", type=int, default=None, help="points per scene (default: the workload's)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "mixed"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "mixed", "parity"],
                     help="bf16: BASELINE configs[1]; mixed: the reference's recipe (fp32 encoder + backbone, 16-bit neck + head); fp32: parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -309,7 +309,8 @@ def main():
                        f"scenes/sec (fwd+bwd) {args.config} {args.points} pts, {nq_cfg} queries"), "value": scenes / dt, "unit": "scenes/s",
             "n_gpus": joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "fp32": "f32", "mixed": "f32 encoder+backbone (wide convs as split-bf16: 3 bf16 MFMA products, f32 accumulation) / bf16 neck+head"}[args.precision], "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp32": "f32", "mixed": "f32 encoder+backbone (convs as split-bf16: 3 bf16 MFMA products, f32 accumulation) / bf16 neck+head",
+                      "parity": "f32 storage everywhere; convs as split-bf16 (3 bf16 MFMA products, f32 accumulation), decoder+head exact-f32 MFMA"}[args.precision], "data": "synthetic",
             "config": {"workload": f"{wl['file']} (BASELINE {wl['baseline']}): train step fwd+loss+bwd+clip+AdamW, "
                                    f"{args.batch} scenes/GPU x {args.points} pts, {nq_cfg} queries x 3 groups, random-init weights",
                        "global_batch": joined * args.batch, "parallelism": f"dp{joined}", "rccl_ranks": joined if use_dist else 0, "gradient_exchange_dtype": str(comm_dt).replace("torch.", ""),
@@ -463,7 +464,7 @@ def main():
         if not args.no_cpu_baseline and world == 1 and args.config == "sunrgbd":      # the CPU leg is quoted on the headline workload only
             faulthandler.cancel_dump_traceback_later()       # CPU leg: no GPU work can hang here
             out["cpu_baseline"] = cpu_baseline(args.points)
-            if args.precision in ("bf16", "mixed"):
+            if args.precision in ("bf16", "mixed", "parity"):
                 # checker leg: deviation of the benched mode from the fp32 CPU oracle on the same workload shape, 2 scenes;
                 # gated by tests/test_bf16_parity_gpu.py (tolerances stated there)
                 from oracle.parity_bf16 import bf16_deviation

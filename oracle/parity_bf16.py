@@ -16,7 +16,8 @@ def rel_l2(a, b):
 
 
 def bf16_deviation(device, B=2, npts=20000, seed=11, mode="bf16"):
-    """mode: "bf16" (throughput mode) or "mixed" (the reference's recipe: fp32 encoder + backbone, 16-bit neck + head).
+    """mode: "bf16" (throughput mode), "mixed" (the reference's recipe: fp32 encoder + backbone, 16-bit neck + head), "parity"
+    (f32 storage everywhere, convolutions as split-bf16 products, exact-f32 decoder) or "fp32" (exact-f32 MFMA everywhere).
     Returns dict: feature / logit relative L2 deviations, share of identical Hungarian assignments, worst relative loss deviation."""
     import projects.mmdet3d_plugin  # noqa: F401
     from oracle import model as om
@@ -47,7 +48,7 @@ def bf16_deviation(device, B=2, npts=20000, seed=11, mode="bf16"):
     with torch.no_grad():
         ref_losses, aux = om.forward_train(sd, [p.numpy() for p in pts], gtb, labels, om.sunrgbd_cfg())
     extra = {}
-    if mode == "mixed":
+    if mode in ("mixed", "parity"):
         # the modules the reference keeps in fp32 (encoder + backbone), on their own: f32 rows, wide convs as split-bf16 products
         with torch.no_grad():
             from uni3detr_amd import sparse as sp
