@@ -375,14 +375,21 @@ int32_t u3d_scatter_rows(const void* in, const int32_t* idx, int32_t n, int32_t 
  * minimum; arg-max ties resolved as the upstream 2^k-thread block reduction does: smallest (k mod T, k),
  * T = min(1024, 2^floor(log2 n)).  out_idx int32 [nsets, m].  temp: f32 [nsets, temp_stride >= max_n] workspace, only needed
  * when max_n > 20480: such sets run either on ceil(n / 20480) <= 16 resident workgroups per set that exchange their round
- * winners through the head of temp (sets go out in launches of at most 192 workgroups), or - beyond 16 x 20480 points - on one
- * workgroup streaming the running minima through temp.  Same indices either way.
+ * winners through the head of temp (sets go out in launches of at most max_wg workgroups; max_wg = 0: 3/4 of the device's CUs,
+ * hipDeviceAttributeMultiprocessorCount), or - beyond 16 x 20480 points, or when one set needs more than max_wg workgroups
+ * (max_wg = 1: always) - on one workgroup streaming the running minima through temp.  Same indices either way.
+ * err: int32 [2], device; REQUIRED for the several-workgroup form, optional otherwise.  err[0] is written by the call: 0, or 1
+ * when a workgroup waited longer than poll_ticks (100 MHz ticks of the constant clock; 0 = 0.5 s) for a sibling's round winner -
+ * then every workgroup of the call leaves at once, unfinished rounds hold index 0 and the samples of this call MUST NOT be
+ * used (the training step ORs err[0] into its collective hold flag).  err[1] += 1 per call that timed out (the caller clears it).
  * ---------------------------------------------------------------------------------------------- */
 int32_t u3d_fps(const float* base, const int64_t* set_off, const int32_t* set_n, int32_t nsets, int32_t max_n,
-                int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, u3d_stream s);
+                int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, int32_t* err, int64_t poll_ticks, int32_t max_wg,
+                u3d_stream s);
 /* the same over two buffers: sets [0, split) are offsets into base, sets [split, nsets) into base2 */
 int32_t u3d_fps2(const float* base, const float* base2, int32_t split, const int64_t* set_off, const int32_t* set_n,
-                 int32_t nsets, int32_t max_n, int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, u3d_stream s);
+                 int32_t nsets, int32_t max_n, int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, int32_t* err,
+                 int64_t poll_ticks, int32_t max_wg, u3d_stream s);
 /* The detector's glue around its two FPS passes (ref: models/detectors/uni3detr.py:178-189), one launch each side.
  *   u3d_fps_prep: vox f32 [v_rows,3] = float (z,y,x) of coors int32 [v_rows,4] (b,z,y,x); set descriptors for u3d_fps2 with
  *     split = batch: sets 0..B-1 = the packed-triple view of the [N,nfeat] point buffer from row scene_off[b] (offset

@@ -80,10 +80,44 @@ def test_fps_large_sets_split_over_workgroups(cuda):
     p = rng.random((120000, 3)).astype(np.float32)
     b2 = torch.from_numpy(p.reshape(-1)).to(cuda)
     ref = om.fps_packed(p.reshape(-1), 120000, 48)
+    err = nv.fps_err_buffer(cuda)
     for _ in range(2):
-        got = nv.fps(b2, torch.tensor([0], dtype=torch.int64, device=cuda), torch.tensor([120000], dtype=torch.int32, device=cuda), 120000, 48).cpu().numpy()
+        got = nv.fps(b2, torch.tensor([0], dtype=torch.int64, device=cuda), torch.tensor([120000], dtype=torch.int32, device=cuda), 120000, 48, err=err).cpu().numpy()
         assert np.array_equal(got[0], ref)
-    assert not nv.fps_multi_error()                      # no workgroup gave up waiting for a sibling
+    assert err.tolist() == [0, 0]                        # no workgroup gave up waiting for a sibling
+    # the resident-workgroup budget: max_wg below the 6 workgroups this set needs -> the single-workgroup streaming kernel, same indices
+    got = nv.fps(b2, torch.tensor([0], dtype=torch.int64, device=cuda), torch.tensor([120000], dtype=torch.int32, device=cuda), 120000, 48, max_wg=4).cpu().numpy()
+    assert np.array_equal(got[0], ref)
+
+
+def test_fps_time_out_is_flagged_and_every_workgroup_leaves(cuda):
+    """poll_ticks = 1 (10 ns): the first workgroup to publish its round winner cannot see its siblings' in time -> err[0] = 1, err[1]
+    counts the call, ALL workgroups of the call return promptly (no per-round wait: the whole call finishes in well under the 0.5 s
+    default limit), indices stay valid point indices; the next call with the default limit clears err[0] and is index-identical to
+    the oracle again."""
+    import time
+    rng = np.random.default_rng(3)
+    n, m = 100000, 64
+    p = rng.random((n, 3)).astype(np.float32)
+    base = torch.from_numpy(p.reshape(-1)).to(cuda)
+    off = torch.tensor([0, 0], dtype=torch.int64, device=cuda)
+    cnt = torch.tensor([n, n], dtype=torch.int32, device=cuda)
+    err = nv.fps_err_buffer(cuda)
+    nv.fps(base, off, cnt, n, m, err=err)
+    torch.cuda.synchronize()
+    assert err.tolist() == [0, 0]
+    t0 = time.perf_counter()
+    idx = nv.fps(base, off, cnt, n, m, err=err, poll_ticks=1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert err.tolist() == [1, 1], err.tolist()
+    assert dt < 0.25, dt
+    got = idx.cpu().numpy()
+    assert got.min() >= 0 and got.max() < n
+    idx = nv.fps(base, off, cnt, n, m, err=err)
+    assert err.tolist() == [0, 1]
+    ref = om.fps_packed(p.reshape(-1), n, m)
+    assert np.array_equal(idx[0].cpu().numpy(), ref) and np.array_equal(idx[1].cpu().numpy(), ref)
 
 
 def test_fps_large_sets_replayed_from_a_graph(cuda):
@@ -103,15 +137,16 @@ def test_fps_large_sets_replayed_from_a_graph(cuda):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
+    err = nv.fps_err_buffer(cuda)
     with torch.cuda.graph(g, stream=side):
-        idx = nv.fps(base, off, cnt, n, m)
+        idx = nv.fps(base, off, cnt, n, m, err=err)
     for d in data:
         base.copy_(torch.from_numpy(d.reshape(-1)))
         torch.cuda.synchronize()
         g.replay()
         torch.cuda.synchronize()
         assert np.array_equal(idx[0].cpu().numpy(), om.fps_packed(d.reshape(-1), n, m))
-        assert not nv.fps_multi_error()
+        assert err.tolist() == [0, 0]
 
 
 def test_fps_many_large_sets_go_out_in_groups(cuda):

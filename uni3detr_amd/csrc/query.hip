@@ -150,19 +150,24 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps(const float* __restrict__ b
 // "handoff-1to1"): slots[round & 1][w] = {distance bits | round} {index | round}.  Two slot sets by round parity: a workgroup can be at
 // most one round ahead of the slowest one (it needs everybody's round-r candidate before it can produce round r + 1).  Every
 // workgroup reduces the W candidates with the same total order (fps_better) and fetches the winner's coordinates from the (read-only)
-// input itself.  All workgroups of a launch must be resident together: the launcher sends the sets out in groups of at most
-// FPS_MULTI_MAX_GRID workgroups, and every poll loop is bounded (error flag instead of a hang).
+// input itself.  All workgroups of a launch must be resident together (one 1024-thread workgroup owns a CU): the launcher sends the sets
+// out in groups of at most 3/4 of the DEVICE's CUs (hipDeviceAttributeMultiprocessorCount; the rest is room for the kernels of another
+// stream) and takes the single-workgroup streaming kernel when one set alone would need more.
+// Time-out: the wait for the siblings is bounded in WALL TIME (s_memrealtime, 100 MHz; FPS_POLL_TICKS = 0.5 s unless the caller passes
+// its own limit).  The first workgroup that gives up sets err[0] = 1 (and counts the call in err[1]); every poll loop also watches
+// err[0], so all other workgroups of the call leave within one poll instead of waiting out their own limit round after round; rounds
+// that did not complete write index 0 (a valid point).  The caller must not use the samples of a call that left err[0] != 0: the
+// training step feeds err[0] into its collective HOLD flag (uni3detr_amd/trainer.py), so no rank applies an update computed from them.
 // --------------------------------------------------------------------------------------------
 #ifndef FPS_MULTI
 #define FPS_MULTI 1
 #endif
-#define FPS_MULTI_MAX_GRID 192      /* workgroups that must be resident together (one per CU, 256 CUs; room for the other stream's kernels) */
 #define FPS_MULTI_MAXW 16
 #define FPS_CHUNK (FPS_THREADS * FPS_MAXJ)
-#define FPS_POLL_LIMIT (1 << 24)
+#define FPS_POLL_TICKS 50000000ll      /* 0.5 s of the 100 MHz constant clock */
 __device__ __forceinline__ void fps_rounds_multi(const float* __restrict__ p, int n, int m, int* __restrict__ out, int w, int W,
-                                                 unsigned long long* __restrict__ slots, int* __restrict__ err, float* s_d, int* s_k,
-                                                 float* s_x, float* s_y, float* s_z) {
+                                                 unsigned long long* __restrict__ slots, int* __restrict__ err, long long poll_ticks,
+                                                 float* s_d, int* s_k, float* s_x, float* s_y, float* s_z, int* s_abort) {
   constexpr int NW = FPS_THREADS / 64;
   const unsigned un = (unsigned)n, tmask = FPS_THREADS - 1u;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -176,9 +181,13 @@ __device__ __forceinline__ void fps_rounds_multi(const float* __restrict__ p, in
     md[j] = k < n ? 1e10f : -1.f;
   }
   if (w == 0 && tid == 0) out[0] = 0;
-  if (tid == 0) { s_x[0] = p[0]; s_y[0] = p[1]; s_z[0] = p[2]; }
+  if (tid == 0) { s_x[0] = p[0]; s_y[0] = p[1]; s_z[0] = p[2]; s_abort[0] = 0; }
   __syncthreads();
   for (int r = 1; r < m; ++r) {
+    if (s_abort[0]) {                                         // a workgroup of this call timed out (uniform: written before the round's last barrier)
+      if (w == 0) for (int j = r + tid; j < m; j += FPS_THREADS) out[j] = 0;
+      return;
+    }
     const float cx = s_x[0], cy = s_y[0], cz = s_z[0];
     float bd = -2.f; int bk = 0x7fffffff;
     int tl = kbase + tid;
@@ -219,7 +228,8 @@ __device__ __forceinline__ void fps_rounds_multi(const float* __restrict__ p, in
       // lane l < W collects workgroup l's candidate (its own included: one code path)
       float dd = -3.f; int kk = 0x7fffffff;
       bool ready = lane >= W;
-      int polls = 0;
+      bool failed = false;
+      const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
       while (!__all(ready)) {
         if (!ready) {
           const unsigned long long g0 = __hip_atomic_load(sl + lane * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -228,8 +238,18 @@ __device__ __forceinline__ void fps_rounds_multi(const float* __restrict__ p, in
             dd = __uint_as_float((unsigned)g0); kk = (int)(unsigned)g1; ready = true;
           }
         }
-        if (++polls > FPS_POLL_LIMIT) { if (lane == 0) atomicExch(err, 1); break; }      // a sibling never arrived: flag it, do not hang
-        if (!__all(ready)) __builtin_amdgcn_s_sleep(2);
+        if (__all(ready)) break;
+        // somebody else of this call gave up (leave with them), or a sibling has not arrived within the wall-time limit (flag it)
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { failed = true; break; }
+        if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > poll_ticks) {
+          if (lane == 0 && atomicExch(err, 1) == 0) atomicAdd(err + 1, 1);
+          failed = true; break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (failed) {
+        if (lane == 0) { s_abort[0] = 1; if (w == 0) out[r] = 0; }
+        dd = -3.f; kk = 0;
       }
 #pragma unroll
       for (int o = FPS_MULTI_MAXW / 2; o > 0; o >>= 1) {
@@ -239,7 +259,7 @@ __device__ __forceinline__ void fps_rounds_multi(const float* __restrict__ p, in
       }
       kk = __shfl(kk, 0, 64);
       if (lane == 0) {
-        const int kw = ((unsigned)kk < un) ? kk : 0;             // (only after a time-out)
+        const int kw = ((unsigned)kk < un && !failed) ? kk : 0;
         s_x[0] = p[3 * (long long)kw]; s_y[0] = p[3 * (long long)kw + 1]; s_z[0] = p[3 * (long long)kw + 2];
         if (w == 0) out[r] = kw;
       }
@@ -248,17 +268,18 @@ __device__ __forceinline__ void fps_rounds_multi(const float* __restrict__ p, in
   }
 }
 
-__global__ void k_fps_zero(unsigned long long* __restrict__ p, int n) {
+__global__ void k_fps_zero(unsigned long long* __restrict__ p, int n, int* __restrict__ err) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0ull;
+  if (threadIdx.x == 0 && err) err[0] = 0;                  // err[1] (calls that timed out so far) is the caller's to clear
 }
 
 __global__ __launch_bounds__(FPS_THREADS) void k_fps_multi(const float* __restrict__ base, const float* __restrict__ base2, int split,
                                                           const long long* __restrict__ set_off, const int* __restrict__ set_n, int m,
                                                           int* __restrict__ out_idx, unsigned long long* __restrict__ slots,
-                                                          int* __restrict__ err, int s0) {
+                                                          int* __restrict__ err, long long poll_ticks, int s0) {
   constexpr int NW = FPS_THREADS / 64;
   __shared__ float s_d[NW], s_x[NW], s_y[NW], s_z[NW];
-  __shared__ int s_k[NW], s_win[1];
+  __shared__ int s_k[NW], s_win[1], s_abort[1];
   const int s = s0 + blockIdx.y, w = blockIdx.x;      // (s0: first set of this launch - many sets go out in groups that fit the chip)
   const float* p = (s < split ? base : base2) + set_off[s];
   const int n = set_n[s];
@@ -273,47 +294,60 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_multi(const float* __restri
     else fps_rounds<true, false>(p, n, m, out, nullptr, (unsigned)T - 1u, s_d, s_k, s_x, s_y, s_z, s_win);
     return;
   }
-  fps_rounds_multi(p, n, m, out, w, W, slots + (size_t)s * 2 * FPS_MULTI_MAXW * 2, err, s_d, s_k, s_x, s_y, s_z);
+  fps_rounds_multi(p, n, m, out, w, W, slots + (size_t)s * 2 * FPS_MULTI_MAXW * 2, err, poll_ticks, s_d, s_k, s_x, s_y, s_z, s_abort);
 }
 
 static int fps_launch(const float* base, const float* base2, int split, const int64_t* set_off, const int32_t* set_n, int32_t nsets,
-                      int32_t max_n, int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, hipStream_t s) {
-  U3D_REQUIRE(base && base2 && set_off && set_n && out_idx && nsets > 0 && m > 0, U3D_ERR_ARG);
-  if (max_n <= FPS_THREADS * FPS_MAXJ) {
+                      int32_t max_n, int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, int32_t* err, int64_t poll_ticks,
+                      int32_t max_wg, hipStream_t s) {
+  U3D_REQUIRE(base && base2 && set_off && set_n && out_idx && nsets > 0 && m > 0 && poll_ticks >= 0 && max_wg >= 0, U3D_ERR_ARG);
+  const int W = u3d_cdiv(max_n, FPS_CHUNK);
+  int budget = max_wg;                                 // workgroups that may be asked to be resident together
+  if (FPS_MULTI && W > 1 && W <= FPS_MULTI_MAXW && budget == 0) {
+    // one 1024-thread workgroup of k_fps_multi owns a CU: 3/4 of THIS device's CUs, the rest is room for another stream's kernels
+    int dev = 0, cus = 0;
+    U3D_REQUIRE(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess,
+                U3D_ERR_LAUNCH);
+    budget = cus * 3 / 4;
+  }
+  if (max_n <= FPS_CHUNK) {
     hipLaunchKernelGGL(k_fps<true>, dim3(nsets), dim3(FPS_THREADS), 0, s, base, base2, split, (const long long*)set_off, set_n, m, out_idx, temp, (long long)temp_stride);
-  } else if (FPS_MULTI && u3d_cdiv(max_n, FPS_CHUNK) <= FPS_MULTI_MAXW) {
-    // large sets split over several resident workgroups (k_fps_multi); the head of `temp` carries the per-set candidate slots + the
-    // error flag (zeroed here: round tags start at 1), so the workspace contract of the streaming path covers it
-    U3D_REQUIRE(temp && temp_stride >= max_n, U3D_ERR_WORKSPACE);
-    const int W = u3d_cdiv(max_n, FPS_CHUNK);
+    if (err) hipLaunchKernelGGL(k_fps_zero, dim3(1), dim3(64), 0, s, (unsigned long long*)nullptr, 0, err);
+  } else if (FPS_MULTI && W <= FPS_MULTI_MAXW && W <= budget) {
+    // large sets split over several resident workgroups (k_fps_multi); the head of `temp` carries the per-set candidate slots
+    // (zeroed here: round tags start at 1), so the workspace contract of the streaming path covers it; err is the caller's buffer
+    U3D_REQUIRE(temp && temp_stride >= max_n && err, U3D_ERR_WORKSPACE);
     const size_t slot_bytes = (size_t)nsets * 2 * FPS_MULTI_MAXW * 2 * 8;
-    U3D_REQUIRE((size_t)nsets * (size_t)temp_stride * 4 >= slot_bytes + 64, U3D_ERR_WORKSPACE);
+    U3D_REQUIRE((size_t)nsets * (size_t)temp_stride * 4 >= slot_bytes, U3D_ERR_WORKSPACE);
     // (a kernel, not hipMemsetAsync: the memset NODE of a captured graph left a repeating 16-byte pattern of two device pointers
-    //  in this range on replay instead of zeros - ROCm 7.2, tools/fps_ws_probe.py; stale round tags of the previous replay must go)
-    hipLaunchKernelGGL(k_fps_zero, dim3(1), dim3(256), 0, s, (unsigned long long*)temp, (int)((slot_bytes + 64) / 8));
-    const int per = FPS_MULTI_MAX_GRID / W;            // sets per launch: all their workgroups must be resident together
+    //  in this range on replay instead of zeros - ROCm 7.2, HISTORY.md; stale round tags of the previous replay must go)
+    hipLaunchKernelGGL(k_fps_zero, dim3(1), dim3(256), 0, s, (unsigned long long*)temp, (int)(slot_bytes / 8), err);
+    const int per = budget / W;                        // sets per launch: all their workgroups must be resident together
     for (int s0 = 0; s0 < nsets; s0 += per) {
       const int ns = nsets - s0 < per ? nsets - s0 : per;
       hipLaunchKernelGGL(k_fps_multi, dim3(W, ns), dim3(FPS_THREADS), 0, s, base, base2, split, (const long long*)set_off, set_n, m, out_idx,
-                         (unsigned long long*)temp, (int*)((char*)temp + slot_bytes), s0);
+                         (unsigned long long*)temp, err, (long long)(poll_ticks > 0 ? poll_ticks : FPS_POLL_TICKS), s0);
     }
   } else {
     U3D_REQUIRE(temp && temp_stride >= max_n, U3D_ERR_WORKSPACE);
     hipLaunchKernelGGL(k_fps<false>, dim3(nsets), dim3(FPS_THREADS), 0, s, base, base2, split, (const long long*)set_off, set_n, m, out_idx, temp, (long long)temp_stride);
+    if (err) hipLaunchKernelGGL(k_fps_zero, dim3(1), dim3(64), 0, s, (unsigned long long*)nullptr, 0, err);
   }
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }
 extern "C" int32_t u3d_fps(const float* base, const int64_t* set_off, const int32_t* set_n, int32_t nsets, int32_t max_n,
-                           int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, u3d_stream s) {
-  return fps_launch(base, base, nsets, set_off, set_n, nsets, max_n, m, out_idx, temp, temp_stride, (hipStream_t)s);
+                           int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, int32_t* err, int64_t poll_ticks,
+                           int32_t max_wg, u3d_stream s) {
+  return fps_launch(base, base, nsets, set_off, set_n, nsets, max_n, m, out_idx, temp, temp_stride, err, poll_ticks, max_wg, (hipStream_t)s);
 }
 // the same over TWO buffers: sets [0, split) are offsets into `base`, sets [split, nsets) into `base2` (the detector's raw-point sets
 // and voxel-coordinate sets without a concatenated copy of both)
 extern "C" int32_t u3d_fps2(const float* base, const float* base2, int32_t split, const int64_t* set_off, const int32_t* set_n,
-                            int32_t nsets, int32_t max_n, int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, u3d_stream s) {
+                            int32_t nsets, int32_t max_n, int32_t m, int32_t* out_idx, float* temp, int64_t temp_stride, int32_t* err,
+                            int64_t poll_ticks, int32_t max_wg, u3d_stream s) {
   U3D_REQUIRE(split >= 0 && split <= nsets, U3D_ERR_ARG);
-  return fps_launch(base, base2, split, set_off, set_n, nsets, max_n, m, out_idx, temp, temp_stride, (hipStream_t)s);
+  return fps_launch(base, base2, split, set_off, set_n, nsets, max_n, m, out_idx, temp, temp_stride, err, poll_ticks, max_wg, (hipStream_t)s);
 }
 
 // ---------------------------------------------------------------------------------------------

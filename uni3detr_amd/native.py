@@ -127,10 +127,10 @@ _SIGS = {
     "u3d_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
     "u3d_to_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     "u3d_from_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
-    "u3d_fps": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _L, _P]),
+    "u3d_fps": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _L, _I, _P]),
     "u3d_refine_decode_fwd": (_I, [_P, _P, _P, _I, _I, _P, C.c_float, _P, _P, _P, _P]),
     "u3d_loss_targets": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
-    "u3d_fps2": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _L, _P]),
+    "u3d_fps2": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _L, _P, _L, _I, _P]),
     "u3d_fps_prep": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P]),
     "u3d_fps_points": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
     "u3d_query_embed_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
@@ -943,43 +943,42 @@ def scatter_rows(inp, idx, n_out):
 FPS_REG_MAX = 20480
 
 
-# workspace of the last FPS launch over sets above FPS_REG_MAX points (k_fps_multi keeps its candidate slots and a time-out flag at its
-# head: include/u3d_hip.h u3d_fps): fps_multi_error() reads the flag - a host synchronisation, so callers poll it rarely
-_FPS_MULTI_WS = [None, 0]
+def fps_err_buffer(device):
+    """int32 [2] time-out record of FPS calls over sets above FPS_REG_MAX points (include/u3d_hip.h u3d_fps): [0] = this call timed
+    out (its samples must not be used), [1] = calls that timed out so far.  Owned by the caller (TrainStep keeps one and feeds [0]
+    into the step's collective hold flag); reading it synchronises with the device."""
+    return torch.zeros(2, dtype=torch.int32, device=device)
 
 
-def _note_fps_ws(temp, nsets, max_n):
-    if temp is not None and -(-max_n // FPS_REG_MAX) <= 16:
-        _FPS_MULTI_WS[0], _FPS_MULTI_WS[1] = temp, nsets * 2 * 16 * 2 * 8
+def _fps_err_arg(err, max_n, device):
+    """The several-workgroup form REQUIRES the record; smaller sets never write it (and a captured step saves the clearing launch)."""
+    if max_n <= FPS_REG_MAX:
+        return None
+    return fps_err_buffer(device) if err is None else err
 
 
-def fps_multi_error():
-    """True when a workgroup of the last multi-workgroup FPS launch gave up waiting for its siblings (their round candidates never
-    arrived within the poll limit: the sampled indices of that launch are not to be trusted).  Synchronises with the device.  For a
-    captured launch it reads the flag the last REPLAY left (the workspace tensor of the capture stays referenced here)."""
-    ws, off = _FPS_MULTI_WS
-    if ws is None:
-        return False
-    return bool(int(ws.view(torch.uint8).reshape(-1)[off:off + 4].view(torch.int32).item()))
-
-
-def fps(base, set_off, set_n, max_n, m):
-    """base: f32 device buffer; set_off int64 [S] element offsets; set_n int32 [S]; -> idx int32 [S, m]."""
+def fps(base, set_off, set_n, max_n, m, err=None, poll_ticks=0, max_wg=0):
+    """base: f32 device buffer; set_off int64 [S] element offsets; set_n int32 [S]; -> idx int32 [S, m].
+    err: int32 [2] from fps_err_buffer() (None: a private one, reachable as `idx._u3d_fps_err`); poll_ticks / max_wg: the C ABI's
+    time-out limit (100 MHz ticks, 0 = 0.5 s) and resident-workgroup budget (0 = 3/4 of the device's CUs, 1 = streaming kernel)."""
     nsets = set_off.shape[0]
     out = torch.empty((nsets, m), dtype=torch.int32, device=base.device)
     temp, stride = None, 0
     if max_n > FPS_REG_MAX:
         temp = torch.empty((nsets, max_n), dtype=torch.float32, device=base.device)
         stride = max_n
-    _check(lib().u3d_fps(_ptr(base), _ptr(set_off), _ptr(set_n), nsets, max_n, m, _ptr(out), _ptr(temp), stride, _stream()), "fps")
-    _note_fps_ws(temp, nsets, max_n)
+    err = _fps_err_arg(err, max_n, base.device)
+    _check(lib().u3d_fps(_ptr(base), _ptr(set_off), _ptr(set_n), nsets, max_n, m, _ptr(out), _ptr(temp), stride, _ptr(err), int(poll_ticks),
+                         int(max_wg), _stream()), "fps")
+    out._u3d_fps_err = err
     return out
 
 
-def fps_queries(points, coors, scene_off, voxel_off, batch, max_n, m):
+def fps_queries(points, coors, scene_off, voxel_off, batch, max_n, m, err=None, poll_ticks=0, max_wg=0):
     """The detector's two FPS passes + their glue in three launches (u3d_fps_prep | u3d_fps2 | u3d_fps_points).
     points f32 [N,F] (packed-triple view: the reference hands the whole [N,F] buffer to the sampler), coors int32 [V,4] (b,z,y,x),
-    scene_off / voxel_off int32 [B+1] -> fpsbpts f32 [B, 2m, 3] in the unit cube (ref: uni3detr.py:178-189)."""
+    scene_off / voxel_off int32 [B+1] -> fpsbpts f32 [B, 2m, 3] in the unit cube (ref: uni3detr.py:178-189).  err / poll_ticks /
+    max_wg: as fps()."""
     dev = points.device
     F_ = points.shape[1]
     V = coors.shape[0]
@@ -993,9 +992,10 @@ def fps_queries(points, coors, scene_off, voxel_off, batch, max_n, m):
     if max_n > FPS_REG_MAX:
         temp = torch.empty((2 * batch, max_n), dtype=torch.float32, device=dev)
         stride = max_n
+    err = _fps_err_arg(err, max_n, dev)
     _check(lib().u3d_fps2(_ptr(points), _ptr(vox), batch, _ptr(set_off), _ptr(set_n), 2 * batch, max_n, m, _ptr(idx), _ptr(temp), stride,
-                          _stream()), "fps2")
-    _note_fps_ws(temp, 2 * batch, max_n)
+                          _ptr(err), int(poll_ticks), int(max_wg), _stream()), "fps2")
+    idx._u3d_fps_err = err
     out = torch.empty((batch, 2 * m, 3), dtype=torch.float32, device=dev)
     _check(lib().u3d_fps_points(_ptr(points), F_, _ptr(vox), _ptr(idx), _ptr(scene_off), _ptr(voxel_off), batch, m, _ptr(out), _stream()),
            "fps_points")

@@ -114,6 +114,9 @@ class Uni3DETR(nn.Module):
         self.fps_packed_view = True
         self.amp_dtype = None           # torch.bfloat16 -> throughput mode (sparse encoder bf16 MFMA, dense + decoder autocast)
         self._fps_stream = None
+        # FPS over sets above 20 480 points (several workgroups per set, native.fps): the caller's time-out record (int32 [2]; TrainStep
+        # installs one and ORs [0] into the step's collective hold flag), the wait limit and the resident-workgroup budget
+        self.fps_err, self.fps_poll_ticks, self.fps_max_wg = None, 0, 0
         self._shadows = None            # bf16 shadow set of the conv / linear parameters (uni3detr_amd/shadow.py)
         self.static_shapes = False      # True: capacity-sized tensors + device-side counts, no host reads (hipGraph capturable)
 
@@ -191,7 +194,8 @@ class Uni3DETR(nn.Module):
                 and coors.dtype == torch.int32 and coors.is_contiguous() and coors.shape[1] == 4
                 and scene_off.dtype == torch.int32 and voxel_off.dtype == torch.int32):
             # set descriptors + float voxel coordinates | the FPS rounds | gather + unit-cube map + concat: three launches
-            return nv.fps_queries(cat, coors, scene_off, voxel_off, B, max_n, m)[0]
+            return nv.fps_queries(cat, coors, scene_off, voxel_off, B, max_n, m, err=self.fps_err, poll_ticks=self.fps_poll_ticks,
+                                  max_wg=self.fps_max_wg)[0]
         vox = coors[:, 1:].float().contiguous()                                           # [V,3] (z,y,x)
         if self.fps_packed_view:
             raw, raw_off = cat.reshape(-1), scene_off[:-1].long() * F_
@@ -200,7 +204,8 @@ class Uni3DETR(nn.Module):
         base = torch.cat([raw, vox.reshape(-1)])
         set_off = torch.cat([raw_off, raw.numel() + voxel_off[:-1].long() * 3])
         set_n = torch.cat([scene_off[1:] - scene_off[:-1], voxel_off[1:] - voxel_off[:-1]]).int()
-        idx = nv.fps(base, set_off.contiguous(), set_n.contiguous(), max_n, m).long()     # [2B, m]
+        idx = nv.fps(base, set_off.contiguous(), set_n.contiguous(), max_n, m, err=self.fps_err, poll_ticks=self.fps_poll_ticks,
+                     max_wg=self.fps_max_wg).long()                                       # [2B, m]
         p_idx = idx[:B] + scene_off[:-1].long()[:, None]
         v_idx = idx[B:] + voxel_off[:-1].long()[:, None]
         a = cat[:, :3][p_idx]                                                             # [B,m,3] xyz

@@ -48,11 +48,16 @@ class TrainStep:
         # captured step: the FPS rounds as their own graph on a second stream next to the encoder / dense stack (see capture())
         self.fps_graph = (os.environ.get("U3D_FPS_GRAPH", "1") == "1") if fps_graph is None else bool(fps_graph)
         self._fps_stream = None
+        self.fps_timeouts_seen = 0
         self.pg_hooks = pg_hooks
         self._capture_batches = None
         self._msg = None
         self._flush_stream, self._flush_keep = None, None
         self.dev = next(model.parameters()).device
+        # time-out record of the several-workgroup FPS (sets above 20 480 points; native.fps_err_buffer): [0] = this step's launch gave
+        # up waiting for a sibling workgroup - ORed into the step's collective HOLD flag (_stage1_head), so NO rank applies an update
+        # computed from such samples; [1] = how often that happened, read with the held-step counter (held_steps / step)
+        model.fps_err = nv.fps_err_buffer(self.dev)
         self.dist_on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.dist_on else 1
         self.max_norm = max_norm
@@ -223,15 +228,28 @@ class TrainStep:
         self._msg[:L].copy_(npos)
         enc = getattr(m, "pts_middle_encoder", None)
         caps = getattr(enc, "level_capacities", None) if enc is not None else None
+        cnts, cps = [], []
         if caps is not None and m.static_shapes:
             cnts, cps = list(enc.last_level_counts[1:1 + len(caps)]), list(caps)
             vfe = getattr(m, "pts_voxel_encoder", None)
             if getattr(vfe, "capacity", None) is not None and vfe.last_count_dev is not None:      # dynamic voxelization: the voxel list too
                 cnts, cps = [vfe.last_count_dev] + cnts, [int(vfe.capacity)] + cps
+        if self._fps_can_time_out():
+            cnts, cps = cnts + [m.fps_err[:1]], cps + [0]        # the FPS time-out flag of this step's launch as a "count" with capacity 0
+        if cnts:
             nv.capacity_flag(cnts, cps, self._msg[L:])
         else:
             self._msg[L:].zero_()
         self._num_pos = self._msg[:L]
+
+    def _fps_can_time_out(self):
+        """Only FPS over sets above native.FPS_REG_MAX points runs on several workgroups that wait for each other."""
+        m = self.model
+        if getattr(m, "fps_err", None) is None or getattr(m, "fps_max_wg", 0) == 1:
+            return False
+        vl = getattr(m, "pts_voxel_layer", None)
+        mv = 0 if (vl is None or m.dynamic_voxelization) else int(vl.max_voxels[0 if m.training else 1])
+        return max(max(self.pts["lens"]), mv) > nv.FPS_REG_MAX
 
     def _early_flush(self, grad):
         if _T._Deferred.active and (_T._Deferred.items or _T._Deferred.sum_items or _T._Deferred.skinny):
@@ -613,13 +631,16 @@ class TrainStep:
         return counts, caps
 
     def held_steps(self):
-        """Steps whose update was held because a sparse level overflowed somewhere in the job (one small device-to-host read;
-        identical on every rank: the flag is all-reduced before the update)."""
-        if nv.fps_multi_error():             # (the same rare host read: large point sets sampled by several workgroups, native.fps_multi_error)
-            raise RuntimeError("FPS over several workgroups timed out waiting for a sibling workgroup: sampled query points are invalid")
+        """Steps whose update was held because a sparse level overflowed - or the several-workgroup FPS timed out - somewhere in the job
+        (one small device-to-host read; identical on every rank: the flag is all-reduced before the update)."""
         if not self.flat_update:
             return 0
         return int(self.opt_state[12].item())
+
+    def fps_timeouts(self):
+        """FPS launches of THIS rank that timed out since the last check (host read of model.fps_err[1])."""
+        e = getattr(self.model, "fps_err", None)
+        return int(e[1].item()) if e is not None else 0
 
     def recapture(self):
         """Collective re-capture with more room (every rank calls it at the same step: the decision comes from the all-reduced
@@ -637,12 +658,25 @@ class TrainStep:
             dist.barrier()
             self.pg_hooks[0]()
             self.dist_on = False
-        self.capacity_margin *= 1.5
-        self.recaptures += 1
         held = self.held_steps()
+        # WHY steps were held is a per-rank fact, what to change must be a job-wide decision: step() exchanged the maximum over ranks
+        # before the group was torn down (_job_fps_timeouts); a direct caller on one rank falls back to its own count
+        n_to = max(self.fps_timeouts(), getattr(self, "_job_fps_timeouts", 0))
+        self._job_fps_timeouts = 0
+        self.recaptures += 1
         import sys
-        print(f"[TrainStep] {held} step(s) held by a sparse-level capacity overflow; re-capturing with margin "
-              f"{self.capacity_margin:.2f} (re-capture #{self.recaptures})", file=sys.stderr, flush=True)
+        if n_to > 0:
+            # the several-workgroup FPS needs all its workgroups resident together and waited in vain: from here on every rank samples
+            # with the single-workgroup streaming kernel (slower rounds, no cross-workgroup wait) - same indices
+            self.fps_timeouts_seen += n_to
+            self.model.fps_max_wg = 1
+            self.model.fps_err.zero_()
+            print(f"[TrainStep] {held} step(s) held, {n_to} FPS launch(es) timed out waiting for a sibling workgroup; re-capturing with the "
+                  f"single-workgroup FPS (re-capture #{self.recaptures})", file=sys.stderr, flush=True)
+        else:
+            self.capacity_margin *= 1.5
+            print(f"[TrainStep] {held} step(s) held by a sparse-level capacity overflow; re-capturing with margin "
+                  f"{self.capacity_margin:.2f} (re-capture #{self.recaptures})", file=sys.stderr, flush=True)
         # the batch the caller has bound (the one that overflowed, or its successor) is (a) measured together with the capture batches -
         # capacities must cover what actually ran - and (b) put back into the static input buffers afterwards: measure_capacities()
         # cycles every capture batch through them, and the replay that follows must train on the caller's batch, not on the last of those
@@ -735,6 +769,12 @@ class TrainStep:
             # one small device-to-host read every `check_every` steps, then a collective re-capture with room to spare
             self._steps_since_check = 0
             if self.held_steps() > 0:
+                # the reason (level overflow vs FPS time-out) is per rank; the decision what to change must not be: job-wide maximum
+                self._job_fps_timeouts = self.fps_timeouts()
+                if self.dist_on:
+                    t = torch.tensor([float(self._job_fps_timeouts)], device=self.dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    self._job_fps_timeouts = int(t.item())
                 self.recapture()
         self._steps_since_check += 1
         g1, g2, g2b, g3 = self._graphs
