@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--allow-eager", action="store_true", help="if the hipGraph capture fails, fall back to eager launches instead of exiting non-zero")
+    ap.add_argument("--no-modes", action="store_true", help="skip the `modes` block (mixed / parity throughput + logits deviation beside the bf16 headline)")
     return ap.parse_args()
 
 
@@ -86,9 +88,10 @@ def launch_class(tag, meta):
     return ("bf16" if meta.get("v2") else "f32", "wgrad" if "wgrad" in tag else "fwd")
 
 
-def cpu_baseline(npts, budget_s=25.0):
-    """The oracle restatement (pure torch CPU, fp32) timed fwd+bwd on ONE scene on this host's cores ("port").
-    Bounded: iterations stop once `budget_s` seconds of CPU work are spent (at least one iteration is always measured)."""
+def cpu_baseline(npts, budget_s=40.0, warmups=2, timed=5):
+    """The oracle restatement (pure torch CPU, fp32) timed fwd+bwd on ONE scene on this host's cores ("port"), SURVEY.md 8(d)'s protocol:
+    2 warm-up iterations, then the median of 5 timed ones.  Bounded: the loop stops early once `budget_s` seconds of CPU work are spent
+    (at least one timed iteration is always measured; the sample string says what ran)."""
     from oracle import model as om
     from uni3detr_amd.configs.sunrgbd import model as MODEL_CFG
     from uni3detr_amd.registry import build_model
@@ -96,7 +99,7 @@ def cpu_baseline(npts, budget_s=25.0):
     host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # cores this process may run on
     # threads actually used: this fp32 workload (many small sparse gathers + 256-channel 3-D convolutions on ONE scene) stops scaling
     # near 32 threads, and with one thread per core of a 256-core host it ran 350x SLOWER (1790 s vs 5 s per scene: oversubscribed
-    # intra-op pools) - `cores` reports the threads used, `host_cores` what the box offers
+    # intra-op pools; HISTORY.md round 2) - `cores` reports the threads used, `host_cores` what the box offers
     cores = min(host_cores, 32)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
@@ -109,19 +112,58 @@ def cpu_baseline(npts, budget_s=25.0):
     cfg = om.sunrgbd_cfg()
     times = []
     t_start = time.perf_counter()
-    while True:
+    while len(times) < warmups + timed:
         t0 = time.perf_counter()
         losses, _ = om.forward_train(sd, [p], [gb], [torch.from_numpy(l)], cfg)
         sum(losses.values()).backward()
         times.append(time.perf_counter() - t0)
         for v in sd.values():
             v.grad = None
-        if time.perf_counter() - t_start > budget_s or len(times) >= 4:
+        if time.perf_counter() - t_start > budget_s and len(times) > 1:
             break
-    use = times[1:] if len(times) > 1 else times          # first iteration = warm-up when there was time for more
+    n_warm = min(warmups, len(times) - 1)
+    use = times[n_warm:]
     t = float(np.median(use))
     return dict(value=1.0 / t, unit="scenes/s", cores=cores, host_cores=host_cores, kind="port",
-                sample=f"oracle/model.py fwd+bwd, fp32, 1 scene x {npts} pts, {len(use)} timed iteration(s) of {len(times)} ({t:.2f} s/scene)")
+                thread_note="32 of the host's cores: the oracle's small gathers + one-scene 3-D convolutions stop scaling there; one thread per core of a 256-core host measured 350x slower (oversubscribed intra-op pools)",
+                sample=f"oracle/model.py fwd+bwd, fp32, 1 scene x {npts} pts, {n_warm} warm-up + {len(use)} timed iteration(s), median ({t:.2f} s/scene)")
+
+
+def time_mode(precision, args, dev, rot, cfg):
+    """Throughput of ONE more precision mode on the benched workload, same protocol as the headline (capture over all rotating batches,
+    `--warmup` untimed steps, `--steps` timed steps between synchronisations, rotating batches, loss checked finite).  N = 1 only."""
+    from uni3detr_amd.registry import build_model
+    from uni3detr_amd.trainer import TrainStep
+    torch.manual_seed(1234)
+    model = build_model(cfg).to(dev).train()
+    model.set_precision(precision)
+    d0 = rot[0]
+    ts = TrainStep(model, d0["points"], d0["gt_bboxes_3d"], d0["gt_labels_3d"], graph=True, overlap_reduce=os.environ.get("U3D_OVERLAP_REDUCE", "1") == "1")
+    snap = ts.snapshot()
+    ts.capture(batches=[(d["points"], d["gt_bboxes_3d"], d["gt_labels_3d"]) for d in rot])
+    ts.restore(snap)
+    packed = [(model.pack_points(d["points"]), model.pts_bbox_head.pack_gts(d["gt_bboxes_3d"], d["gt_labels_3d"], dev), None) for d in rot]
+    it = 0
+    for _ in range(args.warmup):
+        ts.set_batch(*packed[it % len(packed)]); it += 1
+        ts.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        ts.set_batch(*packed[it % len(packed)]); it += 1
+        last = ts.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ts.check_capacities()
+    loss_val = float(last.detach())
+    if not np.isfinite(loss_val):
+        raise SystemExit(f"bench: {precision} training diverged (loss = {loss_val})")
+    res = dict(value=args.batch * args.steps / dt, unit="scenes/s", ms_per_step=1000.0 * dt / args.steps, steps=args.steps, warmup=args.warmup,
+               final_loss=loss_val, launch_mode="hipGraph", recaptures=int(ts.recaptures))
+    del ts, model, packed
+    torch.cuda.empty_cache()
+    return res
 
 
 def self_launch(args):
@@ -219,9 +261,14 @@ def main():
         try:
             # exact-size steps over every rotating batch -> capacities -> static-shape warm-up -> hipGraphs
             counts, caps = ts.capture(batches=[(d["points"], d["gt_bboxes_3d"], d["gt_labels_3d"]) for d in rot])
-        except Exception as e:                          # safety net: a failed capture must not cost the run its number
+        except Exception as e:
+            # a number measured on eager launches is NOT the headline configuration: without --allow-eager a failed capture fails the run
+            if not args.allow_eager:
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); refusing to report an eager-mode number "
+                      f"(--allow-eager to fall back)", file=sys.stderr, flush=True)
+                raise SystemExit(3)
             nv.TIMER = marker = None
-            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr, flush=True)
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches (--allow-eager)", file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             ts._graphs = None
             ts.graph = False
@@ -464,11 +511,26 @@ def main():
         if not args.no_cpu_baseline and world == 1 and args.config == "sunrgbd":      # the CPU leg is quoted on the headline workload only
             faulthandler.cancel_dump_traceback_later()       # CPU leg: no GPU work can hang here
             out["cpu_baseline"] = cpu_baseline(args.points)
+            # checker leg: deviation of each mode from the fp32 CPU oracle on the same workload shape (2 scenes, seeded weights, dropout
+            # off; the oracle's forward runs ONCE); gated by tests/test_bf16_parity_gpu.py (tolerances stated there)
+            from oracle.parity_bf16 import bf16_deviation, oracle_reference
+            oref = oracle_reference(B=2, npts=args.points)
             if args.precision in ("bf16", "mixed", "parity"):
-                # checker leg: deviation of the benched mode from the fp32 CPU oracle on the same workload shape, 2 scenes;
-                # gated by tests/test_bf16_parity_gpu.py (tolerances stated there)
-                from oracle.parity_bf16 import bf16_deviation
-                out[f"{args.precision}_vs_fp32_oracle"] = bf16_deviation(dev, B=2, npts=args.points, mode=args.precision)
+                out[f"{args.precision}_vs_fp32_oracle"] = bf16_deviation(dev, B=2, npts=args.points, mode=args.precision, ref=oref)
+            if args.precision == "bf16" and not args.no_modes and not args.no_graph:
+                # the OTHER precision modes beside the headline: `mixed` = the reference's own recipe (fp32 encoder +
+                # backbone, 16-bit neck + head), `parity` = f32-grade everywhere (the mode that holds logits within 1e-3) - throughput
+                # under the headline's protocol and the measured deviation on the benched shape, both from THIS run
+                out["modes"] = {}
+                for mode in ("mixed", "parity"):
+                    faulthandler.dump_traceback_later(int(os.environ.get("U3D_WATCHDOG_S", "900")), exit=True)
+                    r = time_mode(mode, args, dev, rot, MODEL_CFG)
+                    faulthandler.cancel_dump_traceback_later()
+                    dv = bf16_deviation(dev, B=2, npts=args.points, mode=mode, ref=oref)
+                    r["vs_fp32_oracle"] = dv
+                    r["cls_logit_rel_l2"], r["box_rel_l2"], r["cls_logit_max_abs"] = dv["cls_logit_rel_l2"], dv["box_rel_l2"], dv["cls_logit_max_abs"]
+                    r["logits_within_1e-3"] = bool(dv["cls_logit_rel_l2"] <= 1e-3 and dv["box_rel_l2"] <= 1e-3 and dv["iou_logit_rel_l2"] <= 1e-3)
+                    out["modes"][mode] = r
         result_line = json.dumps(out)
     else:
         result_line = None

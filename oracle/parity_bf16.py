@@ -15,18 +15,48 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
-def bf16_deviation(device, B=2, npts=20000, seed=11, mode="bf16"):
+def _scenes(B, npts):
+    from uni3detr_amd.synth import room_scene
+    scenes = [room_scene(i, npts - 2500 * i) for i in range(B)]
+    pts = [torch.from_numpy(s[0]) for s in scenes]
+    gtb = []
+    for s in scenes:
+        g = torch.from_numpy(s[1]).clone()
+        g[:, 2] -= g[:, 5] / 2
+        gtb.append(g)
+    return pts, gtb, [torch.from_numpy(s[2]) for s in scenes]
+
+
+def oracle_reference(B=2, npts=20000, seed=11):
+    """The fp32 CPU oracle's training forward on the deviation workload: (losses, aux) - computed once, shared by every mode."""
+    import projects.mmdet3d_plugin  # noqa: F401
+    from oracle import model as om
+    from oracle.weights import seeded_tensor
+    from uni3detr_amd.configs.sunrgbd import model as MODEL_CFG
+    from uni3detr_amd.registry import build_model
+    sd = {k: seeded_tensor(k, tuple(v.shape), seed) for k, v in build_model(MODEL_CFG).state_dict().items()}
+    pts, gtb, labels = _scenes(B, npts)
+    with torch.no_grad():
+        ref_losses, aux = om.forward_train(sd, [p.numpy() for p in pts], gtb, labels, om.sunrgbd_cfg())
+    return dict(losses=ref_losses, aux=aux, B=B, npts=npts, seed=seed)
+
+
+def bf16_deviation(device, B=2, npts=20000, seed=11, mode="bf16", ref=None):
     """mode: "bf16" (throughput mode), "mixed" (the reference's recipe: fp32 encoder + backbone, 16-bit neck + head), "parity"
     (f32 storage everywhere, convolutions as split-bf16 products, exact-f32 decoder) or "fp32" (exact-f32 MFMA everywhere).
-    Returns dict: feature / logit relative L2 deviations, share of identical Hungarian assignments, worst relative loss deviation."""
+    Returns dict: feature / logit relative L2 deviations, share of identical Hungarian assignments, worst relative loss deviation.
+    ref: oracle_reference(...) of the same (B, npts, seed) - computed here when absent."""
     import projects.mmdet3d_plugin  # noqa: F401
     from oracle import model as om
     from oracle.weights import seeded_tensor
     from uni3detr_amd.configs.sunrgbd import model as MODEL_CFG
     from uni3detr_amd.plugin.structures import Boxes3D
     from uni3detr_amd.registry import build_model
-    from uni3detr_amd.synth import room_scene
 
+    if ref is None:
+        ref = oracle_reference(B, npts, seed)
+    assert (ref["B"], ref["npts"], ref["seed"]) == (B, npts, seed)
+    ref_losses, aux = ref["losses"], ref["aux"]
     model = build_model(MODEL_CFG)
     sd = {k: seeded_tensor(k, tuple(v.shape), seed) for k, v in model.state_dict().items()}
     model.load_state_dict(sd)
@@ -37,16 +67,7 @@ def bf16_deviation(device, B=2, npts=20000, seed=11, mode="bf16"):
             m.attn_drop = 0.0
     model = model.to(device).train()
     model.set_precision(mode)
-    scenes = [room_scene(i, npts - 2500 * i) for i in range(B)]
-    pts = [torch.from_numpy(s[0]) for s in scenes]
-    gtb = []
-    for s in scenes:
-        g = torch.from_numpy(s[1]).clone()
-        g[:, 2] -= g[:, 5] / 2
-        gtb.append(g)
-    labels = [torch.from_numpy(s[2]) for s in scenes]
-    with torch.no_grad():
-        ref_losses, aux = om.forward_train(sd, [p.numpy() for p in pts], gtb, labels, om.sunrgbd_cfg())
+    pts, gtb, labels = _scenes(B, npts)
     extra = {}
     if mode in ("mixed", "parity"):
         # the modules the reference keeps in fp32 (encoder + backbone), on their own: f32 rows, wide convs as split-bf16 products

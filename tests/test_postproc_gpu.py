@@ -114,3 +114,47 @@ def test_reloaded_checkpoint_gives_identical_detections(cuda, tmp_path):
         ta = ta.tensor if hasattr(ta, "tensor") else ta
         tb = tb.tensor if hasattr(tb, "tensor") else tb
         assert torch.equal(ta, tb), k
+
+
+def test_nms_free_coder_decode_matches_reference_golden_on_device(cuda):
+    """f-1 on the GPU: NMSFreeCoder.decode over device tensors against the REFERENCE file's own output
+    (tests/golden/coder_decode.npz from core/bbox/coders/nms_free_coder.py:42-136, all three coder settings): labels and ORDER exactly,
+    boxes / scores / ious 1e-6; plus the tie rule the upstream top-k leaves open, pinned here: equal scores come out by ascending
+    (query, class) index, identically on the host and on the device."""
+    import os
+    from uni3detr_amd.plugin.bbox import NMSFreeCoder
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "coder_decode.npz"))
+    preds = dict(all_cls_scores=torch.from_numpy(z["cls"]).to(cuda), all_bbox_preds=torch.from_numpy(z["box"]).to(cuda),
+                 all_iou_preds=torch.from_numpy(z["iou"]).to(cuda))
+    si = 0
+    while f"s{si}_cfg" in z:
+        c = z[f"s{si}_cfg"]
+        coder = NMSFreeCoder(pc_range=list(z["pc_range"]), voxel_size=[0.02] * 3, post_center_range=[float(v) for v in c[3:9]], max_num=int(c[2]),
+                             score_threshold=None if c[1] < 0 else float(c[1]), alpha=float(c[0]), num_classes=10)
+        res = coder.decode(preds)
+        for b, r in enumerate(res):
+            assert r["labels"].is_cuda
+            assert r["labels"].cpu().numpy().tolist() == z[f"s{si}_b{b}_labels"].tolist(), (si, b)
+            for k in ("bboxes", "scores", "ious"):
+                ref = z[f"s{si}_b{b}_{k}"]
+                got = r[k].cpu().numpy()
+                assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (si, b, k)
+        si += 1
+    assert si == 3
+    # ties: every query carries the same logits -> 40 x 10 scores in 10 distinct values, 40-way ties each
+    L, B, Q, Cn = 3, 1, 40, 10
+    cls = torch.linspace(-2, 2, Cn).view(1, 1, 1, Cn).expand(L, B, Q, Cn).contiguous()
+    box = torch.zeros(L, B, Q, 8)
+    box[..., 0] = torch.arange(Q).float() * 0.01          # the query index is readable from the decoded centre
+    iou = torch.zeros(L, B, Q, 1)
+    coder = NMSFreeCoder(pc_range=[-4.0, -4.0, -4.0, 4.0, 4.0, 4.0], post_center_range=[-100.0] * 3 + [100.0] * 3, max_num=100, alpha=1.0, num_classes=Cn)
+    outs = []
+    for dev in ("cpu", cuda):
+        r = coder.decode(dict(all_cls_scores=cls.to(dev), all_bbox_preds=box.to(dev), all_iou_preds=iou.to(dev)))[0]
+        outs.append((r["labels"].cpu(), r["bboxes"].cpu(), r["scores"].cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1][:, 0], outs[1][1][:, 0])        # labels and query order: exactly
+    assert torch.allclose(outs[0][1], outs[1][1], atol=1e-6) and torch.allclose(outs[0][2], outs[1][2], atol=1e-6)
+    lab = outs[1][0].tolist()
+    assert lab[:40] == [Cn - 1] * 40 and lab[40:80] == [Cn - 2] * 40           # best class first, 40-way ties inside
+    xq = outs[1][1][:, 0]
+    assert torch.all(xq[1:40] > xq[:39]) and torch.all(xq[41:80] > xq[40:79])  # ... resolved by ascending query index

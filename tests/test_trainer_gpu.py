@@ -57,15 +57,17 @@ def test_graph_step_matches_eager_step(cuda):
     assert le[-1] < le[0]                         # and it trains
 
 
-def test_mixed_precision_graph_step_matches_eager_and_trains(cuda):
-    """`mixed` (fp32 encoder + backbone as split-bf16 products, 16-bit neck + head): the captured step - staged stage-1 graphs, FPS graph
-    on its second stream - follows the eager step's loss trajectory from the same weights, and the loss goes down."""
+@pytest.mark.parametrize("mode", ["mixed", "parity"])
+def test_mixed_precision_graph_step_matches_eager_and_trains(cuda, mode):
+    """`mixed` (fp32 encoder + backbone as split-bf16 products, 16-bit neck + head) and `parity` (f32 storage everywhere, all convolutions
+    as split-bf16 products, exact-f32 decoder): the captured step - staged stage-1 graphs, FPS graph on its second stream - follows the
+    eager step's loss trajectory from the same weights, and the loss goes down."""
     pts, gts, labels = _data(cuda)
-    ref = _model(cuda).set_precision("mixed")
+    ref = _model(cuda).set_precision(mode)
     sd = copy.deepcopy(ref.state_dict())
     eager = TrainStep(ref, pts, gts, labels, graph=False)
     le = [float(eager.step()) for _ in range(4)]
-    m2 = _model(cuda, sd).set_precision("mixed")
+    m2 = _model(cuda, sd).set_precision(mode)
     ts = TrainStep(m2, pts, gts, labels, graph=True)
     snap = ts.snapshot()
     ts.capture()

@@ -163,7 +163,10 @@ class NMSFreeCoder:
         if self.post_center_range is None:
             raise NotImplementedError("only post_center_range is not None is supported (as in the reference)")
         cls_scores = cls_scores.sigmoid()
-        scores, idx = cls_scores.view(-1).topk(self.max_num)
+        # top-k with a PINNED tie order: descending score, equal scores by ascending (query, class) index - a stable descending sort keeps
+        # equal elements in input order by contract on every device (the upstream `topk` leaves ties to the backend: ref :70)
+        scores, idx = cls_scores.view(-1).sort(descending=True, stable=True)
+        scores, idx = scores[: self.max_num], idx[: self.max_num]
         labels = idx % self.num_classes
         bidx = torch.div(idx, self.num_classes, rounding_mode="floor")
         boxes = denormalize_bbox(bbox_preds[bidx], self.pc_range)
