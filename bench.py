@@ -201,6 +201,10 @@ def main():
         raise SystemExit(f"bench: rank {rank} wants GPU {local}, the node exposes {torch.cuda.device_count()}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    numa = None
+    if world > 1 and os.environ.get("U3D_NUMA_BIND", "1") == "1":
+        from uni3detr_amd.launch import bind_to_gpu_numa
+        numa = bind_to_gpu_numa(local)                    # host threads of this rank next to its GPU (None: topology unknown)
     use_dist = world > 1 or os.environ.get("U3D_FORCE_DDP") == "1"      # the env flag exercises the RCCL path on one GPU
 
     def init_pg():
@@ -291,6 +295,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    ts.comm_diag = use_dist                               # event pairs around the gradient waits (three event records per step)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -302,6 +307,9 @@ def main():
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
+    comm = ts.comm_exposed_ms() if use_dist else None
+    ts.comm_diag = False
     if not args.no_graph:
         ts.check_capacities()
     # ---- roofline: per-launch HIP-event timing needs individually launched kernels, so it runs on eager instrumented steps
@@ -338,8 +346,27 @@ def main():
         torch.cuda.synchronize()
         nv.TIMER = None
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    multi = None
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        # N > 1 diagnostics (the first multi-GPU run must explain itself): every rank's own wall time, its exposed gradient waits,
+        # its re-captures and held steps, its NUMA placement
+        mine = torch.tensor([dt_local * 1e3 / args.steps, (comm or {}).get("reduce_a_exposed_ms", 0.0), (comm or {}).get("reduce_b_exposed_ms", 0.0),
+                             float(getattr(ts, "recaptures", 0)), float(ts.held_steps()), float(-1 if numa is None else numa["node"])],
+                            device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allr, mine)
+        rows = torch.stack(allr).cpu().numpy()
+        multi = {"per_rank_ms_per_step": [round(float(v), 4) for v in rows[:, 0]],
+                 "ms_per_step_min": float(rows[:, 0].min()), "ms_per_step_max": float(rows[:, 0].max()),
+                 "reduce_a_exposed_ms": float(rows[:, 1].max()), "reduce_b_exposed_ms": float(rows[:, 2].max()),
+                 "reduce_a_exposed_ms_per_rank": [round(float(v), 4) for v in rows[:, 1]],
+                 "reduce_b_exposed_ms_per_rank": [round(float(v), 4) for v in rows[:, 2]],
+                 "recaptures_per_rank": [int(v) for v in rows[:, 3]], "held_steps_per_rank": [int(v) for v in rows[:, 4]],
+                 "numa_node_per_rank": [int(v) for v in rows[:, 5]],
+                 "bucket_a_MB": (comm or {}).get("bucket_a_MB"), "bucket_b_MB": (comm or {}).get("bucket_b_MB"),
+                 "overlap_reduce": bool(ts.overlap),
+                 "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None}
     dt = float(tt.item())
     loss_val = float(last.detach())
     if not np.isfinite(loss_val):
@@ -372,6 +399,8 @@ def main():
                        "fps_stream_calibration_ms": getattr(ts, "fps_stream_calibration_ms", None),
                        "fps_overlap_reference_ms": getattr(ts, "fps_overlap_reference_ms", None), "recaptures": int(getattr(ts, "recaptures", 0))},
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
         if timer is not None and census:
             durs = timer.durations_ms()
             per_step = len(census)

@@ -57,3 +57,27 @@ def test_bench_cli_exits_nonzero_without_enough_gpus():
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 2, (p.returncode, p.stderr[-400:])
     assert "GPU(s)" in p.stderr and p.stdout.strip() == ""
+
+
+def test_numa_binding_reads_the_gpus_node_from_sysfs(tmp_path):
+    """launch.bind_to_gpu_numa: PCI address of the rank's GPU -> numa_node -> that node's cpulist -> sched_setaffinity.
+    Driven against a fake sysfs tree; unknown topology (numa_node = -1, missing files) leaves the process alone."""
+    from types import SimpleNamespace
+    from uni3detr_amd import launch as L
+    assert L.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    allowed = sorted(os.sched_getaffinity(0))
+    (node / "cpulist").write_text(f"{allowed[0]},{allowed[-1]},100000\n")
+    seen = []
+    props = SimpleNamespace(pci_domain_id=0, pci_bus_id=0xC1, pci_device_id=0)
+    r = L.bind_to_gpu_numa(0, sysfs=str(tmp_path), props=props, setaffinity=lambda pid, cpus: seen.append((pid, list(cpus))))
+    assert r == dict(node=1, cpus=len({allowed[0], allowed[-1]}), pci="0000:c1:00.0")
+    assert seen == [(0, sorted({allowed[0], allowed[-1]}))]
+    (dev / "numa_node").write_text("-1\n")
+    assert L.bind_to_gpu_numa(0, sysfs=str(tmp_path), props=props, setaffinity=lambda *a: seen.append(a)) is None
+    assert L.bind_to_gpu_numa(0, sysfs=str(tmp_path / "nope"), props=props, setaffinity=lambda *a: seen.append(a)) is None
+    assert len(seen) == 1

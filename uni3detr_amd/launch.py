@@ -73,3 +73,51 @@ def spawn_ranks(n, argv, device_count, popen=subprocess.Popen, poll_s=0.2, timeo
         raise
     worst = max((abs(c) for c in codes if c is not None), default=1)
     return worst, codes
+
+
+# ---- NUMA placement of a rank: the host threads of rank r (launch loop, RCCL proxy threads, the data path's staging copies) next to GPU r --
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0,1,2,3,8,10,11] (the kernel's cpulist format)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def numa_cpus_for_pci(bdf, sysfs="/sys"):
+    """CPUs of the NUMA node the PCI device `bdf` ('0000:c1:00.0') hangs off, or None when the platform does not say (single-node hosts
+    report numa_node = -1)."""
+    try:
+        node = int(open(os.path.join(sysfs, "bus", "pci", "devices", bdf, "numa_node")).read().strip())
+        if node < 0:
+            return None
+        cpus = parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")).read())
+        return (node, cpus) if cpus else None
+    except (OSError, ValueError):
+        return None
+
+
+def bind_to_gpu_numa(device_index, sysfs="/sys", props=None, setaffinity=None):
+    """Pin THIS process to the CPUs of the NUMA node of GPU `device_index` (first-touch then places its host allocations there too).
+    Intersects with the CPUs the process may already run on; leaves everything alone when the topology is unknown or the intersection
+    is empty.  -> dict(node=, cpus=) describing what was done, or None."""
+    if props is None:
+        import torch
+        props = torch.cuda.get_device_properties(device_index)
+    try:
+        bdf = f"{int(getattr(props, 'pci_domain_id', 0)):04x}:{int(props.pci_bus_id):02x}:{int(props.pci_device_id):02x}.0"
+    except (AttributeError, TypeError, ValueError):
+        return None
+    found = numa_cpus_for_pci(bdf, sysfs)
+    if found is None:
+        return None
+    node, cpus = found
+    allowed = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set(cpus)
+    use = sorted(allowed & set(cpus))
+    if not use:
+        return None
+    (setaffinity or os.sched_setaffinity)(0, use)
+    return dict(node=node, cpus=len(use), pci=bdf)

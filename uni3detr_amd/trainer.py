@@ -96,6 +96,7 @@ class TrainStep:
         self.n_enc = n_enc
         self.enc_end = self.offsets[n_enc] if self.overlap else 0          # flat offset where phase A's slice starts
         self._work = self._work_buf = None
+        self.comm_diag, self._comm_events = False, []
         if flat_update:
             # parameters re-homed into ONE flat buffer (each p.data becomes a view; names/shapes/state_dict unchanged), moments flat:
             # clip + AdamW is u3d_adamw_step - three launches that stream the 7 arrays once (torch: ~30 multi-tensor launches)
@@ -396,12 +397,35 @@ class TrainStep:
 
     def _reduce_grads_b(self):
         if self.dist_on:
+            # comm_diag: event pairs around the two waits of the compute stream - how much of bucket A's all-reduce is NOT hidden under
+            # the encoder's backward (the stream stalls in work.wait()) and what bucket B (never overlapped) costs; read by comm_exposed_ms()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.comm_diag else None
+            if ev:
+                ev[0].record()
             if self._work is not None:
                 self._work.wait()
                 if getattr(self, "_work_buf", None) is not None:
                     self.flat_grad[self.enc_end:].copy_(self._work_buf)
                 self._work = self._work_buf = None
+            if ev:
+                ev[1].record()
             self._all_reduce_slice(0, self.enc_end)
+            if ev:
+                ev[2].record()
+                self._comm_events.append(ev)
+                del self._comm_events[:-256]
+
+    def comm_exposed_ms(self):
+        """Mean stall of the compute stream in the two gradient waits over the steps recorded since comm_diag was switched on:
+        dict(reduce_a_exposed_ms, reduce_b_exposed_ms, steps) - synchronises with the device."""
+        if not self._comm_events:
+            return None
+        torch.cuda.synchronize()
+        a = [e[0].elapsed_time(e[1]) for e in self._comm_events]
+        b = [e[1].elapsed_time(e[2]) for e in self._comm_events]
+        return dict(reduce_a_exposed_ms=sum(a) / len(a), reduce_b_exposed_ms=sum(b) / len(b), steps=len(a),
+                    bucket_a_MB=(self.flat_grad.numel() - self.enc_end) * (4 if self.grad_comm_dtype == torch.float32 else 2) / 1e6,
+                    bucket_b_MB=self.enc_end * (4 if self.grad_comm_dtype == torch.float32 else 2) / 1e6)
 
     def _reduce_grads(self):
         if self.dist_on:
