@@ -656,7 +656,10 @@ enum {
   U3D_DS_SINE, U3D_DS_RPH1, U3D_DS_RPH2, U3D_DS_RAW, U3D_DS_QS1, U3D_DS_QS2, U3D_DS_QS, U3D_DS_POS, U3D_DS_QKIN,
   U3D_DS_QK, U3D_DS_V, U3D_DS_LSE, U3D_DS_O, U3D_DS_U1, U3D_DS_MR, U3D_DS_QP, U3D_DS_SAMP, U3D_DS_GATED, U3D_DS_PEH0,
   U3D_DS_UPE1, U3D_DS_U2, U3D_DS_X2C, U3D_DS_FFH, U3D_DS_U3, U3D_DS_R1, U3D_DS_R2, U3D_DS_I1, U3D_DS_I2, U3D_DS_UC1,
-  U3D_DS_C1, U3D_DS_UC2, U3D_DS_C2, U3D_DS_COUNT
+  U3D_DS_C1, U3D_DS_UC2, U3D_DS_C2,
+  U3D_DS_AMASK,   /* uint32 [m*8][10]: attention-dropout keep bits, row (group*8 + head)*nq + query, bit b of word w = key 32w + b; written by the
+                     fused in-projection + attention launch (bf16, nq <= 320, p_attn > 0), read by the layer's backward */
+  U3D_DS_COUNT
 };
 /* backward-workspace slots: dY of every linear (bf16), LayerNorm partials, intermediate f32 gradients */
 enum {

@@ -73,6 +73,14 @@ def main():
         tot = t[-1] - t[0]
         print(f"-- {sym}: {tot} shader clocks in the marked workgroup")
         full = list(buf)
+        if sym == "u3d_debug_fwd_times" and full[41] > full[32] > 0:
+            mp = full[32:42]
+            names_mp = ["issue row loads + weight copy", "barrier (weights landed)", "in-projection: 3 row blocks", "barrier (images complete)",
+                        "slot stores (q, k, v)", "query block 0", "query block 1", "query block 2", "tail"]
+            print(f"-- k_mha_proj_fwd, workgroup 7 wave 0: {mp[9] - mp[0]} shader clocks")
+            for i, n in enumerate(names_mp):
+                if mp[i + 1] >= mp[i] > 0:
+                    print(f"   {n:50s} {mp[i + 1] - mp[i]:8d} clk")
         if sym == "u3d_debug_fwd_times" and full[23] > full[20] > 0:
             print(f"   [reg0 linear taken apart] burst+MFMA {full[21] - full[20]}  epilogue {full[22] - full[21]}  barrier {full[23] - full[22]} clk")
         for i, n in enumerate(names):

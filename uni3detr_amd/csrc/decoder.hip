@@ -13,8 +13,10 @@
 __device__ unsigned long long dc_dbg_fwd[64];
 #define DC_MARK(id) do { if (blockIdx.x == 7 && threadIdx.x == 0) dc_dbg_fwd[id] = __builtin_readcyclecounter(); } while (0)
 extern "C" int32_t u3d_debug_fwd_times(uint64_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dc_dbg_fwd), 64 * 8) == hipSuccess ? 0 : -1; }
+#define MP_MARK(id) do { if (blockIdx.x == 7 && threadIdx.x == 0) dc_dbg_fwd[32 + (id)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DC_MARK(id)
+#define MP_MARK(id)
 #endif
 
 template <typename E>
@@ -29,6 +31,7 @@ struct DcPtrs {            // forward-save slot pointers (device), resolved on t
   T *x2c, *ffh;
   float* u3;
   T *r1, *r2, *i1, *i2, *uc1, *c1, *uc2, *c2;
+  unsigned* amask;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -38,7 +41,8 @@ static const int kSaveCols[U3D_DS_COUNT][2] = {   // (columns, bytes per element
     {384, 2}, {256, 2}, {256, 2}, {256, 2}, {256, 2}, {256, 2}, {256, 2}, {256, 2}, {256, 2},   // SINE RPH1 RPH2 RAW QS1 QS2 QS POS QKIN
     {512, 2}, {256, 2}, {8, 4}, {256, 2}, {256, 4}, {16, 4}, {256, 2}, {256, 2}, {256, 2}, {256, 2},   // QK V LSE O U1 MR QP SAMP GATED PEH0
     {256, 2}, {256, 4}, {256, 2}, {512, 2}, {256, 4}, {256, 2}, {256, 2}, {256, 2}, {256, 2}, {256, 2},   // UPE1 U2 X2C FFH U3 R1 R2 I1 I2 UC1
-    {256, 2}, {256, 2}, {256, 2}};                                                                        // C1 UC2 C2
+    {256, 2}, {256, 2}, {256, 2},                                                                         // C1 UC2 C2
+    {80, 4}};                                                                                             // AMASK (8 heads x 10 words per query row)
 
 extern "C" int32_t u3d_decoder_layer_blocks_dt(int32_t m, int32_t dtype) { return u3d_cdiv(m > 0 ? m : 1, dc_bm(dtype)); }
 extern "C" int32_t u3d_decoder_layer_blocks(int32_t m) { return u3d_decoder_layer_blocks_dt(m, U3D_BF16); }
@@ -101,6 +105,7 @@ static DcPtrs<E> dc_resolve(void* save, int m) {
   p.r1 = (T*)(b + off[U3D_DS_R1]); p.r2 = (T*)(b + off[U3D_DS_R2]); p.i1 = (T*)(b + off[U3D_DS_I1]);
   p.i2 = (T*)(b + off[U3D_DS_I2]); p.uc1 = (T*)(b + off[U3D_DS_UC1]); p.c1 = (T*)(b + off[U3D_DS_C1]);
   p.uc2 = (T*)(b + off[U3D_DS_UC2]); p.c2 = (T*)(b + off[U3D_DS_C2]);
+  p.amask = (unsigned*)(b + off[U3D_DS_AMASK]);
   return p;
 }
 
@@ -175,7 +180,7 @@ extern "C" int32_t u3d_dropout_mask(const uint64_t* rng, int32_t layer, int32_t 
 // ---------------------------------------------------------------------------------------------------------------------------
 template <typename E>
 __global__ __launch_bounds__(DC_THREADS) void k_dec_pre(u3d_declayer_params P, u3d_declayer_dims dm, const typename E::T* __restrict__ xc,
-                                                        const float* __restrict__ ref, DcPtrs<E> S) {
+                                                        const float* __restrict__ ref, DcPtrs<E> S, int skip_inproj) {
   typedef typename E::T T;
   typedef typename E::V4 V4;
   typedef typename E::VC VC;
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_pre(u3d_declayer_params P, u
   }
   __syncthreads();
   dc_store_a<E, 256>(A1b, S.qkin, DC_C, row0, tid);
+  if (skip_inproj) return;                               // (uniform) the attention launch projects its own head: k_mha_proj_fwd
   // in-projection: q = A1b . Wq^T + b -> A1, k -> A2 (pos is saved), v = A0 . Wv^T + b -> A1b; each block leaves for HBM from its tile
   // (the attention kernel regroups rows by (group, head))
   dc_linear<E, 256, 4>(A1b, (const T*)P.w[U3D_DL_INQK], wv * 64, lane, lin_to(A1, P.b[U3D_DL_INQK]));
@@ -276,6 +282,76 @@ __global__ __launch_bounds__(DC_THREADS) void k_dec_pre(u3d_declayer_params P, u
   dc_linear<E, 256, 4>(A0, (const T*)P.w[U3D_DL_INV], wv * 64, lane, lin_to(A1b, P.b[U3D_DL_INV]));
   __syncthreads();
   dc_store_a<E, 256>(A1b, S.v, DC_C, row0, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// One staged chunk of keys / values against the 16 queries of a wave (lane: query column r16, keys kq*4 .. +3 of every 16-key tile):
+// scores, running-maximum rescale, exponentials, dropout, P.V.  Shared by k_mha_fwd and k_mha_proj_fwd.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename E>
+__device__ __forceinline__ void mha_chunk(const typename E::T* Ks, const typename E::T* Vs, const typename E::T* Vt, int kc0, int nkeys,
+                                          const typename Mha<E>::RowFrag& qf, unsigned row, unsigned nq_pad, DcRng rg, unsigned key_site,
+                                          unsigned thresh, float inv_keep, float scale_log2, int r16, int kq, float& m_run, float& l_run,
+                                          f32x4 (&oacc)[2], const unsigned* __restrict__ keep_bits = nullptr) {
+  // keep_bits (nullable, uniform): the query's keep-mask words of this chunk, bit b of word tp = key kc0 + 32 tp + b - the SAME
+  // decisions as the hash below (it made them), read instead of recomputed
+  typedef Mha<E> H;
+  constexpr int KC = H::KC;
+  const int ntile = (nkeys + 15) >> 4;
+  f32x4 s[KC / 16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < KC / 16; ++t) {
+    s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (t < ntile) {
+      f32x4 a = H::scores(Ks, t * 16, r16, kq, qf);
+      if (t == ntile - 1) {                          // only the last tile can hold keys past the group (zero rows in the image)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = t * 16 + kq * 4 + r < nkeys ? a[r] : -INFINITY;
+      }
+      mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
+      s[t] = a;
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float m_new = fmaxf(m_run, mx);
+  const float corr = E::exp2((m_run - m_new) * scale_log2);            // first chunk: exp2(-inf) = 0
+  const float neg_m = -m_new * scale_log2;
+  l_run *= corr;
+  oacc[0] *= corr; oacc[1] *= corr;
+  m_run = m_new;
+#pragma unroll
+  for (int tp = 0; tp < KC / 32; ++tp) {
+    if (tp * 2 < ntile) {
+      f32x4 p0, p1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p0[r] = E::exp2(fmaf(s[2 * tp][r], scale_log2, neg_m));
+        p1[r] = E::exp2(fmaf(s[2 * tp + 1][r], scale_log2, neg_m));
+        l_run += p0[r] + p1[r];
+      }
+      if (thresh && keep_bits) {
+        // bit -> all-ones / zero word in one v_bfe_i32, applied to the (non-negative) probability's bits; 1 / (1 - p) multiplies
+        const int w = (int)keep_bits[tp];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p0[r] = __int_as_float(__float_as_int(p0[r] * inv_keep) & __builtin_amdgcn_sbfe(w, kq * 4 + r, 1));
+          p1[r] = __int_as_float(__float_as_int(p1[r] * inv_keep) & __builtin_amdgcn_sbfe(w, 16 + kq * 4 + r, 1));
+        }
+      } else if (thresh) {
+        bool k0[4], k1[4];
+        dc_keep4(rg, key_site, dc_att_idx(row, (unsigned)(kc0 + (2 * tp) * 16 + kq * 4), nq_pad), thresh, k0);
+        dc_keep4(rg, key_site, dc_att_idx(row, (unsigned)(kc0 + (2 * tp + 1) * 16 + kq * 4), nq_pad), thresh, k1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p0[r] *= k0[r] ? inv_keep : 0.f;
+          p1[r] *= k1[r] ? inv_keep : 0.f;
+        }
+      }
+      H::pv(Vs, Vt, tp, r16, kq, p0, p1, oacc);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -320,54 +396,7 @@ __global__ __launch_bounds__(256, 2) void k_mha_fwd(const typename E::T* __restr
         H::stage(vv + h * DC_HD, 256, base, kc0, nq, H::TR ? Vs : nullptr, Vt, tid);
         __syncthreads();
       }
-      const int nkeys = min(KC, nq - kc0);
-      const int ntile = (nkeys + 15) >> 4;
-      f32x4 s[KC / 16];
-      float mx = -INFINITY;
-#pragma unroll
-      for (int t = 0; t < KC / 16; ++t) {
-        s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        if (t < ntile) {
-          f32x4 a = H::scores(Ks, t * 16, r16, kq, qf);
-          if (t == ntile - 1) {                          // only the last tile can hold keys past the group (zero rows in the image)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = t * 16 + kq * 4 + r < nkeys ? a[r] : -INFINITY;
-          }
-          mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
-          s[t] = a;
-        }
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float corr = E::exp2((m_run - m_new) * scale_log2);            // first chunk: exp2(-inf) = 0
-      const float neg_m = -m_new * scale_log2;
-      l_run *= corr;
-      oacc[0] *= corr; oacc[1] *= corr;
-      m_run = m_new;
-#pragma unroll
-      for (int tp = 0; tp < KC / 32; ++tp) {
-        if (tp * 2 < ntile) {
-          f32x4 p0, p1;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            p0[r] = E::exp2(fmaf(s[2 * tp][r], scale_log2, neg_m));
-            p1[r] = E::exp2(fmaf(s[2 * tp + 1][r], scale_log2, neg_m));
-            l_run += p0[r] + p1[r];
-          }
-          if (thresh) {
-            bool k0[4], k1[4];
-            dc_keep4(rg, key_site, dc_att_idx(row, (unsigned)(kc0 + (2 * tp) * 16 + kq * 4), nq_pad), thresh, k0);
-            dc_keep4(rg, key_site, dc_att_idx(row, (unsigned)(kc0 + (2 * tp + 1) * 16 + kq * 4), nq_pad), thresh, k1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              p0[r] *= k0[r] ? inv_keep : 0.f;
-              p1[r] *= k1[r] ? inv_keep : 0.f;
-            }
-          }
-          H::pv(Vs, Vt, tp, r16, kq, p0, p1, oacc);
-        }
-      }
+      mha_chunk<E>(Ks, Vs, Vt, kc0, min(KC, nq - kc0), qf, row, nq_pad, rg, key_site, thresh, inv_keep, scale_log2, r16, kq, m_run, l_run, oacc);
     }
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
@@ -402,6 +431,192 @@ extern "C" int32_t u3d_mha_fwd_dt(const void* qk, const void* v, int32_t m, int3
 extern "C" int32_t u3d_mha_fwd(const void* qk, const void* v, int32_t m, int32_t nq, float p_attn, int32_t layer, const uint64_t* rng,
                                void* o, float* lse, u3d_stream s) {
   return u3d_mha_fwd_dt(qk, v, m, nq, p_attn, layer, rng, o, lse, U3D_BF16, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_mha_proj_fwd (bf16, groups of at most KC = 320 queries): the in-projection AND the attention of ONE (group, head) per workgroup
+// (ref: mmcv MultiheadAttention = nn.MultiheadAttention(q = k = x + pos, v = x), uni3detr_sunrgbd.py:79-83).  The three launches of a
+// layer were k_dec_pre (... -> in-projection -> qk / v slots) | k_mha_fwd | k_dec_post; a (group, head) workgroup of k_mha_fwd then
+// spent a launch, a staging round and a softmax on 11.5 MFLOP of MFMA work.  Here the workgroup also computes its head's
+// q / k / v = [x + pos | x] . W_h^T + b (14.7 MFLOP; 96 of the 768 in-projection rows: 48 KiB of fragment-packed weights, staged in
+// LDS once and read as a-operands, activation rows straight from L2 as b-operands, a row block ahead), writes them into the LDS
+// images the attention reads (and to the qk / v slots the backward reads), and walks ALL query tiles of the group over them:
+// 8 waves, wave w takes the 16-query blocks w, w + 8, w + 16.  k_dec_pre stops after the x + pos slot.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define MHA_PROJ_THREADS 512
+struct MhaProjLds {
+  static constexpr int IMG = Mha<EB>::KC * Mha<EB>::RS;          // elements of one row-major image (q, k, v)
+  static constexpr int WT = 6 * (DC_C / 32) * 512;               // six 16-row weight tiles x 8 k-steps x (64 lanes x 8 elements)
+  static constexpr int MW = Mha<EB>::KC / 32;                    // dropout keep-mask words per query row (one bit per key)
+  static constexpr int MASK = Mha<EB>::KC * MW;                  // 32-bit words
+  static constexpr int BYTES = (3 * IMG + WT) * 2 + MASK * 4;
+};
+static_assert(MhaProjLds::BYTES <= 160 * 1024, "q / k / v images + the head's weight tiles must fit the CU's LDS");
+static_assert(Mha<EB>::KC / 16 <= 3 * (MHA_PROJ_THREADS / 64), "three row blocks per wave cover a chunk");
+__global__ __launch_bounds__(MHA_PROJ_THREADS) void k_mha_proj_fwd(const u16* __restrict__ qkin, const u16* __restrict__ xc,
+                                                                   const u16* __restrict__ wqk, const float* __restrict__ bqk,
+                                                                   const u16* __restrict__ wv, const float* __restrict__ bv, int nq,
+                                                                   float scale_log2, unsigned thresh, float inv_keep, int layer,
+                                                                   const unsigned long long* __restrict__ rng, u16* __restrict__ qk_out,
+                                                                   u16* __restrict__ v_out, u16* __restrict__ o, float* __restrict__ lse,
+                                                                   unsigned* __restrict__ amask) {
+  typedef Mha<EB> H;
+  typedef u16x8 VC;
+  typedef u16x4 V4;
+  constexpr int KC = H::KC, RS = H::RS, KS = DC_C / 32, WBLK = 512, NW = MHA_PROJ_THREADS / 64;
+  extern __shared__ __attribute__((aligned(16))) u16 sm_[];
+  u16* Qs = sm_;
+  u16* Ks = Qs + MhaProjLds::IMG;
+  u16* Vs = Ks + MhaProjLds::IMG;
+  u16* Ws = Vs + MhaProjLds::IMG;
+  unsigned* Ms = (unsigned*)(Ws + MhaProjLds::WT);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, kq = lane >> 4;
+  // workgroups are dealt to the 8 XCDs round-robin by their linear id: the eight HEADS of a group read the same 2 x nq activation
+  // rows, so they are given ids that are congruent mod 8 (one XCD, one L2 fill per row) - head-major inside blocks of 64 ids
+  int bh = blockIdx.x;
+  {
+    const int ngrp = gridDim.x >> 3, blk = bh >> 6, in = bh & 63, g_ = blk * 8 + (in & 7);
+    if ((blk + 1) * 8 <= ngrp) bh = g_ * 8 + (in >> 3);     // whole blocks of 8 groups; a ragged tail keeps the plain order
+  }
+  const int g = bh >> 3, h = bh & 7;
+  const long long base = (long long)g * nq;
+  const int nrb = (nq + 15) >> 4;                          // 16-row blocks of the group (<= KC / 16 = 20)
+
+  // ---- phase A: q | k | v of this head for all rows of the group -------------------------------------------------------------
+  // every request of the phase goes out first, in the order it is needed (vmcnt retires in order): the head's six weight tiles
+  // (fragment-packed: copied as they are), the six bias quads, then the b-operands (x + pos | x) of ALL of this wave's row blocks
+  constexpr int RBW = 3;                                   // row blocks per wave: ceil(20 / 8)
+  VC wt[6];
+  {
+    const u16* src[6] = {wqk + (size_t)(2 * h) * KS * WBLK,      wqk + (size_t)(2 * h + 1) * KS * WBLK,
+                         wqk + (size_t)(16 + 2 * h) * KS * WBLK, wqk + (size_t)(17 + 2 * h) * KS * WBLK,
+                         wv + (size_t)(2 * h) * KS * WBLK,       wv + (size_t)(2 * h + 1) * KS * WBLK};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) wt[t] = *(const VC*)(src[t] + tid * 8);
+  }
+  const int bcol = h * DC_HD + kq * 4;
+  f32x4 bias[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) bias[t] = *(const f32x4*)((t < 2 ? bqk : (t < 4 ? bqk + 256 : bv)) + bcol + (t & 1) * 16);
+  VC a1[2][KS], a2[2][KS];                                 // two row blocks in flight; the third takes the first one's registers
+  auto load_rows = [&](int rb, VC (&p1)[KS], VC (&p2)[KS]) {
+    const int row = min(rb * 16 + r16, nq - 1);
+    const u16* s1 = qkin + (base + row) * DC_C + kq * 8;
+    const u16* s2 = xc + (base + row) * DC_C + kq * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      p1[ks] = *(const VC*)(s1 + ks * 32);
+      p2[ks] = *(const VC*)(s2 + ks * 32);
+    }
+  };
+  MP_MARK(0);
+  if (wave < nrb) load_rows(wave, a1[0], a2[0]);           // wave-uniform
+  if (wave + NW < nrb) load_rows(wave + NW, a1[1], a2[1]);
+  const unsigned nq_pad = (unsigned)(nq + 1) & ~1u;
+  const DcRng rg = dc_rng_load(rng);
+  const unsigned key_site = dc_site_key(layer, 4);
+  __builtin_amdgcn_sched_barrier(0);                       // every request above is issued before the first hash instruction
+  if (thresh) {
+    // the (group, head)'s dropout keep-mask, one bit per (query, key), hashed HERE - underneath the requests above, whose data takes
+    // ~20 k clocks to arrive while the vector ALU idles - instead of on the score path, where the hash was a third of the softmax
+    constexpr int MW = MhaProjLds::MW;
+    const int words = nrb * 16 * MW, iters = (words + MHA_PROJ_THREADS - 1) / MHA_PROJ_THREADS;
+    for (int it = 0; it < iters; ++it) {
+      const int wd = it * MHA_PROJ_THREADS + tid;
+      if (wd < words) {
+        const int q = wd / MW, tp = wd - q * MW;
+        const unsigned idx0 = dc_att_idx((unsigned)(bh * nq + q), (unsigned)(tp * 32), nq_pad);      // even: whole hash pairs
+        unsigned bits = 0u;
+#pragma unroll
+        for (int pr = 0; pr < 16; ++pr) {
+          const unsigned hw = dc_hash_pair(rg, key_site, (idx0 >> 1) + pr);
+          bits |= (dc_keep_half(hw, 0u, thresh) ? 1u : 0u) << (2 * pr);
+          bits |= (dc_keep_half(hw, 1u, thresh) ? 1u : 0u) << (2 * pr + 1);
+        }
+        Ms[wd] = bits;
+      }
+    }
+  }
+  {
+#pragma unroll
+    for (int t = 0; t < 6; ++t) *(VC*)(Ws + t * KS * WBLK + tid * 8) = wt[t];
+    // value rows past the last row block that the paired P.V tiles still touch: zero (an odd number of row blocks)
+    const int z0 = nrb * 16 * RS, zn = (KC * RS - z0) / 8;
+    for (int c = tid; c < zn; c += MHA_PROJ_THREADS) *(VC*)(Vs + z0 + c * 8) = (VC){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  MP_MARK(1);
+  __syncthreads();
+  MP_MARK(2);
+#pragma unroll
+  for (int i = 0; i < RBW; ++i) {
+    const int rb = wave + NW * i;                          // wave-uniform
+    if (rb < nrb) {
+      f32x4 acc[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int t = 0; t < 6; ++t) EB::mma(*(const VC*)(Ws + (t * KS + ks) * WBLK + lane * 8), t < 4 ? a1[i & 1][ks] : a2[i & 1][ks], acc[t]);
+      if (i == 0 && rb + 2 * NW < nrb) load_rows(rb + 2 * NW, a1[0], a2[0]);
+      const int row = rb * 16 + r16;
+      const bool valid = row < nq;                         // rows past the group: zero rows in all three images
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        u16* img = t < 2 ? Qs : (t < 4 ? Ks : Vs);
+        const V4 pk = EB::pack4(acc[t] + bias[t]);
+        *(V4*)(img + row * RS + (t & 1) * 16 + kq * 4) = valid ? pk : (V4){0, 0, 0, 0};
+      }
+    }
+  }
+  MP_MARK(3);
+  __syncthreads();
+  MP_MARK(4);
+  // the slots the backward reads (and the unfused attention entry points): 16 bytes per lane out of the images
+  {
+    const int per = nq * 4, total = 3 * per, iters = (total + MHA_PROJ_THREADS - 1) / MHA_PROJ_THREADS;
+    for (int it = 0; it < iters; ++it) {
+      const int c = it * MHA_PROJ_THREADS + tid;
+      if (c < total) {
+        const int which = c / per, rem = c - which * per, row = rem >> 2, part = rem & 3;
+        const VC v = *(const VC*)((which == 0 ? Qs : (which == 1 ? Ks : Vs)) + row * RS + part * 8);
+        u16* dst = which == 2 ? v_out + (base + row) * DC_C + h * DC_HD + part * 8
+                              : qk_out + (base + row) * 512 + which * 256 + h * DC_HD + part * 8;
+        *(VC*)dst = v;
+      }
+    }
+    if (thresh) {                                          // the keep bits, for the backward kernels (same decisions, no second hash)
+      const int words = nq * MhaProjLds::MW, wit = (words + MHA_PROJ_THREADS - 1) / MHA_PROJ_THREADS;
+      for (int it = 0; it < wit; ++it) {
+        const int wd = it * MHA_PROJ_THREADS + tid;
+        if (wd < words) amask[(size_t)bh * words + wd] = Ms[wd];
+      }
+    }
+  }
+  MP_MARK(5);
+  // ---- phase B: softmax(q k^T / sqrt(32)) v for every query block of the group (one chunk: no running-maximum rescale) ----
+  for (int qb = wave; qb < nrb; qb += NW) {
+    const int q = qb * 16 + r16;
+    H::RowFrag qf;
+    qf.c[0] = *(const VC*)(Qs + q * RS + kq * 8);
+    f32x4 oacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float m_run = -INFINITY, l_run = 0.f;
+    const unsigned row = (unsigned)(bh * nq + q);
+    unsigned kb[MhaProjLds::MW];
+#pragma unroll
+    for (int j = 0; j < MhaProjLds::MW; ++j) kb[j] = Ms[q * MhaProjLds::MW + j];
+    mha_chunk<EB>(Ks, Vs, nullptr, 0, nq, qf, row, nq_pad, rg, key_site, thresh, inv_keep, scale_log2, r16, kq, m_run, l_run, oacc, kb);
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (q < nq) {
+      const float inv = 1.f / l_run;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) *(V4*)(o + (base + q) * DC_C + h * DC_HD + dt * 16 + kq * 4) = EB::pack4(oacc[dt] * inv);
+      if (kq == 0) lse[(base + q) * DC_NHEAD + h] = m_run * scale_log2 + log2f(l_run);
+    }
+    MP_MARK(6 + (qb >> 3));
+  }
+  MP_MARK(9);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -676,9 +891,20 @@ static int32_t dc_layer_fwd(const u3d_declayer_params* p, const u3d_declayer_dim
   const int nb = u3d_decoder_layer_blocks_dt(d->m, E::DT);
   U3D_ALLOW_LDS(k_dec_pre<E>, DcLds<E>::BYTES);
   U3D_ALLOW_LDS(k_dec_post<E>, DcLds<E>::BYTES);
-  hipLaunchKernelGGL(k_dec_pre<E>, dim3(nb), dim3(DC_THREADS), DcLds<E>::BYTES, s, *p, *d, (const T*)xc, ref, S);
-  int32_t rc = u3d_mha_fwd_dt(S.qk, S.v, d->m, d->nq, d->p_attn, d->layer, rng, S.o, S.lse, E::DT, s);
-  if (rc != U3D_OK) return rc;
+  // bf16, groups of at most one LDS chunk of queries: in-projection + attention in ONE launch per layer (k_mha_proj_fwd)
+  const bool fused = mha_fused_inproj(E::DT, d->nq);
+  hipLaunchKernelGGL(k_dec_pre<E>, dim3(nb), dim3(DC_THREADS), DcLds<E>::BYTES, s, *p, *d, (const T*)xc, ref, S, fused ? 1 : 0);
+  if (fused) {
+    U3D_ALLOW_LDS(k_mha_proj_fwd, MhaProjLds::BYTES);
+    const float scale_log2 = 1.4426950408889634f / sqrtf((float)DC_HD);
+    hipLaunchKernelGGL(k_mha_proj_fwd, dim3((d->m / d->nq) * DC_NHEAD), dim3(MHA_PROJ_THREADS), MhaProjLds::BYTES, s, (const u16*)S.qkin,
+                       (const u16*)xc, (const u16*)p->w[U3D_DL_INQK], p->b[U3D_DL_INQK], (const u16*)p->w[U3D_DL_INV], p->b[U3D_DL_INV],
+                       d->nq, scale_log2, dc_thresh(d->p_attn), dc_inv_keep(d->p_attn), d->layer, (const unsigned long long*)rng,
+                       (u16*)S.qk, (u16*)S.v, (u16*)S.o, S.lse, S.amask);
+  } else {
+    int32_t rc = u3d_mha_fwd_dt(S.qk, S.v, d->m, d->nq, d->p_attn, d->layer, rng, S.o, S.lse, E::DT, s);
+    if (rc != U3D_OK) return rc;
+  }
   hipLaunchKernelGGL(k_dec_post<E>, dim3(nb), dim3(DC_THREADS), DcLds<E>::BYTES, s, *p, *d, x, ref, (const T*)value,
                      (const unsigned long long*)rng, S, x_out, (T*)xc_out, reg_out, cls_out, iou_out);
   U3D_CHECK_LAUNCH();

@@ -29,6 +29,7 @@ struct DcSave {            // forward-save slots (read-only here)
   const T *x2c, *ffh;
   const float* u3;
   const T *r1, *r2, *i1, *i2, *uc1, *c1, *uc2, *c2;
+  const unsigned* amask;
 };
 template <typename E>
 struct DcGrad {            // gradient-workspace slots
@@ -61,6 +62,7 @@ static DcSave<E> dcb_resolve_save(const void* save, int m) {
   p.r1 = (const T*)(b + off[U3D_DS_R1]); p.r2 = (const T*)(b + off[U3D_DS_R2]); p.i1 = (const T*)(b + off[U3D_DS_I1]);
   p.i2 = (const T*)(b + off[U3D_DS_I2]); p.uc1 = (const T*)(b + off[U3D_DS_UC1]); p.c1 = (const T*)(b + off[U3D_DS_C1]);
   p.uc2 = (const T*)(b + off[U3D_DS_UC2]); p.c2 = (const T*)(b + off[U3D_DS_C2]);
+  p.amask = (const unsigned*)(b + off[U3D_DS_AMASK]);
   return p;
 }
 template <typename E>
@@ -506,11 +508,12 @@ __global__ __launch_bounds__(256, 2) void k_mha_bwd_dq(const typename E::T* __re
                                                        const typename E::T* __restrict__ o, const typename E::T* __restrict__ d_o,
                                                        const float* __restrict__ lse, int nq, int qt_per_wg, float scale_log2, float scale,
                                                        unsigned thresh, float inv_keep, int layer, const unsigned long long* __restrict__ rng,
-                                                       typename E::T* __restrict__ dqk) {
+                                                       typename E::T* __restrict__ dqk, const unsigned* __restrict__ amask) {
+  // amask (nullable, uniform): the keep bits the forward launch published (U3D_DS_AMASK; one chunk: nq <= KC) - read instead of hashed
   typedef typename E::T T;
   typedef typename E::V4 V4;
   typedef Mha<E> H;
-  constexpr int KC = H::KC;
+  constexpr int KC = H::KC, MW = KC / 32;
   __shared__ __attribute__((aligned(16))) T Ks[H::RM_ELEMS];
   __shared__ __attribute__((aligned(16))) T Vs[H::RM_ELEMS];
   __shared__ __attribute__((aligned(16))) T Kt[H::TP_ELEMS];
@@ -538,6 +541,9 @@ __global__ __launch_bounds__(256, 2) void k_mha_bwd_dq(const typename E::T* __re
     Dq += __shfl_xor(Dq, 32, 64);
     f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const unsigned row = (unsigned)(bh * nq + q);
+    unsigned kb[MW];
+#pragma unroll
+    for (int j = 0; j < MW; ++j) kb[j] = (amask && qok) ? amask[(size_t)row * MW + j] : 0u;
     for (int kc0 = 0; kc0 < nq; kc0 += KC) {
       if (qt == 0 || !one_chunk) {
         __syncthreads();
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void k_mha_bwd_dq(const typename E::T* __re
       }
       const int nkeys = min(KC, nq - kc0);
       const int ntile = (nkeys + 15) >> 4;
-#pragma unroll 2
+#pragma unroll
       for (int tp = 0; tp < KC / 32; ++tp) {
         if (tp * 2 < ntile) {
           f32x4 dsv[2];
@@ -563,7 +569,11 @@ __global__ __launch_bounds__(256, 2) void k_mha_bwd_dq(const typename E::T* __re
 #pragma unroll
               for (int r = 0; r < 4; ++r) p[r] = t * 16 + kq * 4 + r < nkeys ? p[r] : 0.f;
             }
-            if (thresh) {
+            if (thresh && amask) {
+              const int w = (int)kb[tp];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) dp[r] = __int_as_float(__float_as_int(dp[r] * inv_keep) & __builtin_amdgcn_sbfe(w, u * 16 + kq * 4 + r, 1));
+            } else if (thresh) {
               bool keep[4];
               dc_keep4(rg, key_site, dc_att_idx(row, (unsigned)(kc0 + t * 16 + kq * 4), nq_pad), thresh, keep);
 #pragma unroll
@@ -590,12 +600,16 @@ __global__ __launch_bounds__(256, 2) void k_mha_bwd_dkv(const typename E::T* __r
                                                         const typename E::T* __restrict__ o, const typename E::T* __restrict__ d_o,
                                                         const float* __restrict__ lse, int nq, int kt_per_wg, float scale_log2, float scale,
                                                         unsigned thresh, float inv_keep, int layer, const unsigned long long* __restrict__ rng,
-                                                        typename E::T* __restrict__ dqk, typename E::T* __restrict__ dv) {
+                                                        typename E::T* __restrict__ dqk, typename E::T* __restrict__ dv,
+                                                        const unsigned* __restrict__ amask) {
+  // amask (nullable, uniform; EB only): the forward's keep bits - the (group, head)'s words are staged in LDS with the query chunk,
+  // a lane reads the word holding ITS key of four consecutive query rows per tile (this kernel hashed every element on its own)
   typedef typename E::T T;
   typedef typename E::V4 V4;
   typedef typename E::VC VC;
   typedef Mha<E> H;
-  constexpr int KC = H::KC, NP = H::NP;
+  constexpr int KC = H::KC, NP = H::NP, MW = KC / 32;
+  __shared__ unsigned Ms[H::TR ? KC * MW : 4];
   __shared__ __attribute__((aligned(16))) T Qs[H::RM_ELEMS];
   __shared__ __attribute__((aligned(16))) T Os[H::RM_ELEMS];        // dO rows
   __shared__ __attribute__((aligned(16))) T Qt[H::TP_ELEMS];
@@ -640,6 +654,11 @@ __global__ __launch_bounds__(256, 2) void k_mha_bwd_dkv(const typename E::T* __r
             lse_s[qq] = qc0 + qq < nq ? lse[(base + qc0 + qq) * DC_NHEAD + h] : INFINITY;
           }
         }
+        if constexpr (H::TR) {
+          if (amask) {
+            DC_FOR_TID(c, KC * MW) Ms[c] = c < nq * MW ? amask[(size_t)bh * nq * MW + c] : 0u;
+          }
+        }
         __syncthreads();
       }
       const int nqs = min(KC, nq - qc0);
@@ -658,7 +677,9 @@ __global__ __launch_bounds__(256, 2) void k_mha_bwd_dkv(const typename E::T* __r
             for (int r = 0; r < 4; ++r) {
               const float p = E::exp2(fmaf(s[r], scale_log2, -l4[r]));
               float keepf = 1.f;
-              if (thresh) keepf = dc_keep(rg, key_site, dc_att_idx((unsigned)(bh * nq + qc0 + t * 16 + kq * 4 + r), (unsigned)key, nq_pad), thresh) ? inv_keep : 0.f;
+              if (H::TR && thresh && amask)
+                keepf = __int_as_float(__float_as_int(inv_keep) & __builtin_amdgcn_sbfe((int)Ms[(t * 16 + kq * 4 + r) * MW + (key >> 5)], key & 31, 1));
+              else if (thresh) keepf = dc_keep(rg, key_site, dc_att_idx((unsigned)(bh * nq + qc0 + t * 16 + kq * 4 + r), (unsigned)key, nq_pad), thresh) ? inv_keep : 0.f;
               pd[u][r] = p * keepf;
               dsv[u][r] = p * (dp[r] * keepf - D4[r]) * scale;
             }
@@ -680,15 +701,16 @@ __global__ __launch_bounds__(256, 2) void k_mha_bwd_dkv(const typename E::T* __r
 
 template <typename E>
 static void mha_bwd_launch(const void* qk, const void* v, const void* o, const void* d_o, const float* lse, int32_t m, int32_t nq,
-                           float p_attn, int32_t layer, const uint64_t* rng, void* dqk, void* dv, u3d_stream s) {
+                           float p_attn, int32_t layer, const uint64_t* rng, void* dqk, void* dv, u3d_stream s, const unsigned* amask = nullptr) {
   typedef typename E::T T;
+  if (nq > Mha<E>::KC || E::DT != U3D_BF16) amask = nullptr;      // the published bits cover one-chunk bf16 groups only
   const float scale = 1.f / sqrtf((float)DC_HD), scale_log2 = 1.4426950408889634f * scale;
   const int qt = mha_tiles_per_wg<E>(nq);
   const dim3 grid(u3d_cdiv(nq, 64 * qt), (m / nq) * DC_NHEAD);
   hipLaunchKernelGGL(k_mha_bwd_dq<E>, grid, dim3(256), 0, s, (const T*)qk, (const T*)v, (const T*)o, (const T*)d_o, lse, nq, qt, scale_log2,
-                     scale, dc_thresh(p_attn), dc_inv_keep(p_attn), layer, (const unsigned long long*)rng, (T*)dqk);
+                     scale, dc_thresh(p_attn), dc_inv_keep(p_attn), layer, (const unsigned long long*)rng, (T*)dqk, amask);
   hipLaunchKernelGGL(k_mha_bwd_dkv<E>, grid, dim3(256), 0, s, (const T*)qk, (const T*)v, (const T*)o, (const T*)d_o, lse, nq, qt, scale_log2,
-                     scale, dc_thresh(p_attn), dc_inv_keep(p_attn), layer, (const unsigned long long*)rng, (T*)dqk, (T*)dv);
+                     scale, dc_thresh(p_attn), dc_inv_keep(p_attn), layer, (const unsigned long long*)rng, (T*)dqk, (T*)dv, amask);
 }
 extern "C" int32_t u3d_mha_bwd_dt(const void* qk, const void* v, const void* o, const void* d_o, const float* lse, int32_t m, int32_t nq,
                                   float p_attn, int32_t layer, const uint64_t* rng, void* dqk, void* dv, int32_t dtype, u3d_stream s) {
@@ -828,8 +850,14 @@ static int32_t dcb_layer_bwd(const u3d_declayer_params* p, const u3d_declayer_di
   U3D_ALLOW_LDS(k_dec_pre_bwd<E>, DcLds<E>::BYTES);
   hipLaunchKernelGGL(k_dec_post_bwd<E>, dim3(G.nb), dim3(DC_THREADS), DcLds<E>::BYTES, s, *p, *d, ref, (const T*)value,
                      (const unsigned long long*)rng, S, G, dx_out, dreg, dcls, diou, dvalue, dref);
-  int32_t rc = u3d_mha_bwd_dt(S.qk, S.v, S.o, G.d_o, S.lse, d->m, d->nq, d->p_attn, d->layer, rng, G.dqk, G.dv, E::DT, s);
-  if (rc != U3D_OK) return rc;
+  if (mha_fused_inproj(E::DT, d->nq) && d->p_attn > 0.f) {
+    // the forward launch of this layer published its keep bits: the same decisions, read instead of hashed
+    U3D_REQUIRE((long long)(d->m / d->nq) * DC_NHEAD * d->nq * (d->nq + 1) < (1ll << 32), U3D_ERR_UNSUPPORTED);
+    mha_bwd_launch<E>(S.qk, S.v, S.o, G.d_o, S.lse, d->m, d->nq, d->p_attn, d->layer, rng, G.dqk, G.dv, s, S.amask);
+  } else {
+    int32_t rc = u3d_mha_bwd_dt(S.qk, S.v, S.o, G.d_o, S.lse, d->m, d->nq, d->p_attn, d->layer, rng, G.dqk, G.dv, E::DT, s);
+    if (rc != U3D_OK) return rc;
+  }
   hipLaunchKernelGGL(k_dec_pre_bwd<E>, dim3(G.nb), dim3(DC_THREADS), DcLds<E>::BYTES, s, *p, *d, S, G, dx);
   U3D_CHECK_LAUNCH();
   return U3D_OK;

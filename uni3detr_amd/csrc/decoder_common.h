@@ -547,4 +547,10 @@ struct Mha {
 // workgroups of 3 + 2 tiles, every workgroup resident in one round), else one (chunks are re-staged per tile)
 template <typename E>
 static inline int mha_tiles_per_wg(int nq) { return nq <= Mha<E>::KC ? 3 : 1; }
+// bf16 layers whose attention groups fit one LDS chunk run in-projection + attention as ONE launch (k_mha_proj_fwd, decoder.hip), which
+// also publishes the attention-dropout keep bits (U3D_DS_AMASK) that the layer's backward then reads instead of hashing again
+#ifndef MHA_FUSED_INPROJ
+#define MHA_FUSED_INPROJ 1
+#endif
+static inline bool mha_fused_inproj(int dtype, int nq) { return MHA_FUSED_INPROJ && dtype == U3D_BF16 && nq <= Mha<EB>::KC; }
 

@@ -28,7 +28,7 @@ DL_NLIN, DL_NLN = 22, 7
  DL_REG2, DL_CLS0, DL_CLS1, DL_CLS2, DL_IOU0, DL_IOU1, DL_IOU2) = range(DL_NLIN)
 (DLN_1, DLN_2, DLN_3, DLN_PE0, DLN_PE1, DLN_C1, DLN_C2) = range(DL_NLN)
 DS_NAMES = ("SINE RPH1 RPH2 RAW QS1 QS2 QS POS QKIN QK V LSE O U1 MR QP SAMP GATED PEH0 UPE1 U2 X2C FFH U3 R1 R2 I1 I2 UC1 C1 UC2 "
-            "C2").split()
+            "C2 AMASK").split()
 DG_NAMES = ("CLSO C2U C1U IOUO I2 I1 REGO R2 R1 F FFH OUT UPE1 P0 WL O2 DO DQK DV QS QS2 QS1 RAW RPH2 RPH1 LNP DU1 DPOSA "
             "SINE").split()
 
