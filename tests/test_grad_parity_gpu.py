@@ -179,7 +179,9 @@ def _train_step_grads(model, dev, overlap):
     return got, float(ts.loss), model.pts_bbox_head._last_assigned.clone()
 
 
-def _fp32_check(got, sd, names, what):
+def _fp32_check(got, sd, names, what, floor=None, factor=None, raw_cap=None):
+    FP32_TOL, NOISE_FACTOR = (globals()["FP32_TOL"] if floor is None else floor), (globals()["NOISE_FACTOR"] if factor is None else factor)
+    RAW_CAP = globals()["RAW_CAP"] if raw_cap is None else raw_cap
     ref64, losses64, asg64 = _oracle_grads(sd, names, torch.float64)
     ref32, _, asg32 = _oracle_grads(sd, names, torch.float32)
     assert torch.equal(asg32, asg64)
@@ -224,6 +226,23 @@ def test_fp32_every_parameter_gradient_matches_oracle_train_step(cuda, overlap):
     names = {n for n, p in model.named_parameters() if p.requires_grad}
     got, loss, asg = _train_step_grads(model, cuda, overlap)
     _, ref_losses, ref_asg = _fp32_check(got, sd, names, f"fp32 TrainStep {'two' if overlap else 'one'}-phase backward")
+    assert torch.equal(asg.cpu(), ref_asg)
+    assert abs(loss - sum(ref_losses.values())) <= 1e-3 * abs(sum(ref_losses.values()))
+
+
+def test_parity_mode_every_parameter_gradient_matches_oracle_train_step(cuda):
+    """`parity` precision (f32 storage, every convolution AND the decoder's parameter gradients as split-bf16 products, exact-f32 fused
+    decoder forward / input gradients): all 293 parameter gradients against the float64 oracle, identical Hungarian assignments, the loss
+    within 1e-3.  The FORWARD of this mode sits at 1e-5 ... 1e-4 of the oracle (tests/test_bf16_parity_gpu.py); its gradients carry the
+    16-mantissa-bit products' 2^-16 through the same ~1.4x-per-layer amplification as everything else in this random network
+    (module docstring): measured head 1.4e-5 median / 2.1e-3 max, decoder 3e-4 / 1.4e-3 (dY^T X sums cancel ~20 : 1), neck 5e-3 / 1.2e-2,
+    backbone 1.7e-2 / 2.1e-2, encoder 2.2e-2 / 4.7e-2 - between the exact-f32 mode (encoder 6e-3 / 1.1e-2) and the 16-bit modes (`mixed`
+    encoder ~0.3, bf16 0.4-0.9).  Gate: max(3e-3, 16 x the float32 oracle's own deviation from float64) per tensor."""
+    model, sd = _model(cuda, "parity")
+    names = {n for n, p in model.named_parameters() if p.requires_grad}
+    got, loss, asg = _train_step_grads(model, cuda, True)
+    assert model.pts_bbox_head.transformer.decoder.split_f32_wgrad
+    _, ref_losses, ref_asg = _fp32_check(got, sd, names, "parity mode TrainStep two-phase backward", floor=3e-3, factor=16.0, raw_cap=8e-2)
     assert torch.equal(asg.cpu(), ref_asg)
     assert abs(loss - sum(ref_losses.values())) <= 1e-3 * abs(sum(ref_losses.values()))
 

@@ -27,7 +27,6 @@ TOGGLES = [
     ("uni3detr_amd.sparse", "NMAJOR_FWD", False),
     ("uni3detr_amd.sparse", "FUSED_CONV_STATS", False),
     ("uni3detr_amd.sparse", "BN_GRAD_FUSION", True),
-    ("uni3detr_amd.sparse", "WGRAD_SIDE", True),
     ("uni3detr_amd.plugin.sparse_encoder", "RESIDUAL_FUSION", False),
     ("uni3detr_amd.plugin.dense", "FANOUT_FUSION", False),
     ("uni3detr_amd.plugin.dense", "FUSED_UPSAMPLE_ORDER", False),

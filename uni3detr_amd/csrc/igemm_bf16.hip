@@ -1427,9 +1427,11 @@ extern "C" int32_t u3d_igemm_fwd_split_bf16(const void* in, const void* w, const
 // hi / lo bf16 planes of an f32 row matrix: dst[r] = bf16(x[r]), dst[n_cap + r] = bf16(x[r] - dst[r]) (round to nearest even both)
 __global__ __launch_bounds__(256) void k_split_rows_f32(const float* __restrict__ x, const int* __restrict__ n_dev, int n_cap, int c,
                                                         u16* __restrict__ dst) {
-  const long long n = (long long)min(*n_dev, n_cap) * c / 4, plane = (long long)n_cap * c;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const f32x4 v = *(const f32x4*)(x + i * 4);
+  // rows past the device-side count (capacity padding of a captured step) become ZERO rows of both planes: a table entry can then
+  // never pick up a stale NaN pattern, whatever it names
+  const long long n = (long long)min(*n_dev, n_cap) * c / 4, plane = (long long)n_cap * c, ncap = plane / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ncap; i += (long long)gridDim.x * 256) {
+    const f32x4 v = i < n ? *(const f32x4*)(x + i * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     const bf16x4 h = __builtin_convertvector(v, bf16x4);
     const bf16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4);
     *(bf16x4*)(dst + i * 4) = h;

@@ -1338,7 +1338,7 @@ PERMUTE_DESC_DTYPE = [("src_off", "<i8"), ("dst_off", "<i8"), ("n", "<i4"), ("ro
                       ("stride_k", "<i8"), ("stride_r", "<i8"), ("stride_c", "<i8")]          # = struct u3d_permute_desc
 
 
-PERMUTE_TILED = os.environ.get("U3D_PERMUTE_TILED", "1") == "1"
+PERMUTE_TILED = True
 
 
 def permute_plan(descs, device):

@@ -8,7 +8,6 @@ kernels as the sparse encoder, over channels-last rows [B*D*H*W, C] with a stati
 The nn.Conv3d / nn.BatchNorm3d modules are kept as parameter holders so that state_dict names and shapes are the
 reference checkpoints' (`blocks.{i}.{3j}.weight` [Cout,Cin,kd,kh,kw], `deblocks.{i}.0.weight`, `extra_blocks.{3j}.weight`).
 """
-import os
 
 import numpy as np
 import torch
@@ -39,7 +38,6 @@ def _norm(cfg, c):
 
 _BRANCH_STREAMS = []
 PARALLEL_BRANCHES = True      # eager mode: run the independent SECOND3D branches on separate streams
-PARALLEL_CAPTURED = os.environ.get("U3D_PARALLEL_CAPTURED", "0") == "1"      # ... and inside a hipGraph capture too (A/B switch)
 
 
 class Lattice:
@@ -85,8 +83,8 @@ class Lattice:
         return v
 
 
-FUSED_LEVEL_SUM = os.environ.get("U3D_FUSED_LEVEL_SUM", "1") == "1"
-FUSED_UPSAMPLE_ORDER = os.environ.get("U3D_FUSED_UPSAMPLE", "1") == "1"
+FUSED_LEVEL_SUM = True
+FUSED_UPSAMPLE_ORDER = True
 
 
 class _GatherBijection(torch.autograd.Function):
@@ -138,7 +136,7 @@ def deconv_bn_relu(rows, B, dims, deconv, bn, post_add=None):
     return sp.bn_rows(y, bn, n_dev, None, True, post_add=post_add), dims_out
 
 
-FANOUT_FUSION = os.environ.get("U3D_FANOUT_FUSION", "1") == "1"
+FANOUT_FUSION = True
 
 
 @BACKBONES.register_module()
@@ -186,7 +184,7 @@ class SECOND3D(nn.Module):
         # 48 000 at B=8 -> 94 / 188 workgroups for 256 CUs), so each branch runs on its own stream and the small ones fill the
         # CUs the large one leaves idle; autograd replays the same fork/join in backward; inside a hipGraph capture the
         # event waits become graph edges.
-        if not PARALLEL_BRANCHES or (torch.cuda.is_current_stream_capturing() and not PARALLEL_CAPTURED):
+        if not PARALLEL_BRANCHES or torch.cuda.is_current_stream_capturing():
             # measured: inside the captured step the fork/join costs more than it gains (56.1 vs 54.4 ms) — the 256x256-tile
             # kernels own a CU's LDS, so branches cannot co-reside; streams only pay off against eager-mode launch gaps
             # the branches' input gradients are summed by the first convs' own backward launches (sp.FanoutToken), not by autograd

@@ -1,6 +1,5 @@
 """Uni3DETR detector behind the reference's registry name / constructor / method signatures (ref:
 projects/mmdet3d_plugin/models/detectors/uni3detr.py:113-357; upstream MVXTwoStageDetector)."""
-import os
 from collections import OrderedDict
 
 import torch
@@ -75,7 +74,7 @@ class DynamicSimpleVFE(nn.Module):
         return feats, g.coords(n_vox)
 
 
-FUSED_FPS_GLUE = os.environ.get("U3D_FUSED_FPS_GLUE", "1") == "1"      # 0: the ATen formulation of the glue around the FPS launch (A/B, parity tests)
+FUSED_FPS_GLUE = True      # 0: the ATen formulation of the glue around the FPS launch (A/B, parity tests)
 
 
 def shift_scale_points(pred_xyz, src_range, dst_range=None):
@@ -144,6 +143,9 @@ class Uni3DETR(nn.Module):
         self.amp_dtype = None if mode in ("fp32", "parity") else torch.bfloat16
         if self.pts_middle_encoder is not None:
             self.pts_middle_encoder.compute_dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+        dec = getattr(getattr(getattr(self, "pts_bbox_head", None), "transformer", None), "decoder", None)
+        if dec is not None:
+            dec.split_f32_wgrad = mode == "parity"      # the f32 decoder's parameter gradients as split-bf16 products (fused_decoder.py)
         return self
 
     # ------------------------------------------------------------------------------------------

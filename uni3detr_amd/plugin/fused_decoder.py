@@ -13,7 +13,6 @@ The module layout is the registry's (plugin/transformer.py, plugin/head.py): thi
 copies of the weights (one refresh launch per step: u3d_wpack_bf16) and turns the kernels' gradient slots into parameter
 gradients through the same deferred / batched mechanism the layer-by-layer path uses (plugin/transformer.py `_Deferred`).
 """
-import ctypes as C
 import os
 
 import torch
@@ -26,7 +25,7 @@ ENABLED = os.environ.get("U3D_FUSED_DECODER", "1") == "1"
 # volume to zero and cast: -0.07 ms per step).  OPT-IN: every add rounds to 8 mantissa bits, and all 3 layers x 3 query groups land in one
 # buffer - with queries clustered on objects a cell collects hundreds of contributions and the result drifts 9 % from the f32
 # accumulator (tests/test_decoder_gpu.py::test_packed_bf16_volume_gradient_scatter_vs_f32_accumulator; 0.7 % with spread queries).
-SHARED_DEFER = os.environ.get("U3D_SHARED_DEFER", "1") == "1"     # shared linears' gradients summed by the deferred flush (0: autograd adds)
+SHARED_DEFER = True     # shared linears' gradients summed by the deferred flush (0: autograd adds)
 PK_SCATTER = os.environ.get("U3D_PK_SCATTER", "0") == "1"
 POISON = os.environ.get("U3D_DEC_POISON", "0") == "1"      # debugging: NaN-fill the workspaces (read-before-write shows up as NaN)
 DEBUG_KEEP = None          # tests: a list that receives every backward call's gradient workspace
@@ -332,6 +331,20 @@ class FusedLayerFn(torch.autograd.Function):
         # the deferred / batched parameter-gradient launches are bf16 kernels; parity mode computes every product right here on the
         # exact-f32 weight-gradient kernel (u3d_spconv_wgrad, one offset)
         deferred_ok = _Deferred.active and et == torch.bfloat16
+        # `parity` precision (f32 layer, split-bf16 products elsewhere in the model): the wide dY^T X products as THREE bf16 products of
+        # hi / lo planes (dyh.xh + dyl.xh + dyh.xl, f32 accumulation, ~2^-16 relative) in the batched bf16 weight-gradient launch -
+        # consecutive batch slots with one output are summed by the kernel.  54 launches of the exact-f32 kernel (2.7 ms per step: it
+        # walks 7 200 rows on one offset) become one launch per shape.
+        split_wg = et == torch.float32 and getattr(fd.decoder, "split_f32_wgrad", False)
+        planes = {}
+
+        def hi_lo(t):
+            key = id(t)
+            if key not in planes:
+                t2 = t.contiguous()
+                pl = nv.split_rows(t2, nv.count_tensor(t2.shape[0], dev))
+                planes[key] = (t, pl[:t2.shape[0]], pl[t2.shape[0]:])
+            return planes[key][1], planes[key][2]
         grads = []
         wgrad_now = {}              # (n, k) -> list of (dy, x, out)
         sums_now = []               # (matrix, out vector)
@@ -392,6 +405,10 @@ class FusedLayerFn(torch.autograd.Function):
                 _Deferred.items.append((dy, xin, id(w), r0, r0 + rows_, True))
             elif et == torch.bfloat16:
                 wgrad_now.setdefault((n, k), []).append((dy, xin, dw))
+                sums_now.append((dy, db))
+            elif split_wg and n % 64 == 0 and k % 64 == 0:
+                (dyh, dyl), (xh, xl) = hi_lo(dy), hi_lo(xin)
+                wgrad_now.setdefault((n, k), []).extend([(dyh, xh, dw), (dyl, xh, dw), (dyh, xl, dw)])
                 sums_now.append((dy, db))
             else:
                 dw.copy_(_wgrad_f32(dy, xin))
@@ -463,7 +480,7 @@ def tensor_list(sp):
     return out
 
 
-FUSED_REFINE_DECODE = os.environ.get("U3D_FUSED_REFINE_DECODE", "1") == "1"
+FUSED_REFINE_DECODE = True
 
 
 class _RefineDecode(torch.autograd.Function):

@@ -27,9 +27,8 @@ def reduce_mean_(t):
     return t
 
 
-import os as _os
-FUSED_BOX_DECODE = _os.environ.get("U3D_FUSED_BOX_DECODE", "1") == "1"
-FUSED_DET_LOSS = _os.environ.get("U3D_FUSED_DET_LOSS", "1") == "1"
+FUSED_BOX_DECODE = True
+FUSED_DET_LOSS = True
 
 
 class _DetLoss(torch.autograd.Function):
@@ -57,8 +56,8 @@ class _DetLoss(torch.autograd.Function):
         return (dcls, dbox, diou) + (None,) * 11
 
 
-FUSED_LOSS_TARGETS = _os.environ.get("U3D_FUSED_LOSS_TARGETS", "1") == "1"
-FUSED_QUERY_EMBED = _os.environ.get("U3D_FUSED_QUERY_EMBED", "1") == "1"
+FUSED_LOSS_TARGETS = True
+FUSED_QUERY_EMBED = True
 
 
 class _QueryEmbed(torch.autograd.Function):

@@ -7,7 +7,6 @@ Parameter names follow the reference checkpoints: `conv_i
 """
 import math
 
-import os
 
 import torch
 from torch import nn
@@ -60,7 +59,7 @@ class SparseBasicBlock(nn.Module):
         self.bn2 = _bn(norm_cfg, planes)
 
 
-RESIDUAL_FUSION = os.environ.get("U3D_RESIDUAL_FUSION", "1") == "1"
+RESIDUAL_FUSION = True
 
 
 @MIDDLE_ENCODERS.register_module()

@@ -13,7 +13,6 @@ import math
 import torch
 import torch.nn.functional as F
 from torch import nn
-import os
 
 from .. import native as nv
 from ..shadow import compute_copy
@@ -276,11 +275,11 @@ class _InProjFn(torch.autograd.Function):
 
 import os as _os
 SAFE_LINEAR = _os.environ.get("U3D_UNSAFE_LINEAR", "0") != "1"      # test hook: "1" restores torch's own Linear backward
-OWN_WGRAD = _os.environ.get("U3D_OWN_WGRAD", "1") == "1"          # dW of the decoder/head linears on u3d_igemm_wgrad_bf16
+OWN_WGRAD = True          # dW of the decoder/head linears on u3d_igemm_wgrad_bf16
 # dW of the <= 16-feature linears on u3d_skinny_wgrad_bf16: correct (tests) but measured SLOWER end to end than hipBLASLt's
 # small products (30.3 vs 29.7 ms per step: 57 workgroups per launch) - opt-in until the kernel splits the wide dimension too
-RELU_EPILOGUE = _os.environ.get("U3D_RELU_EPILOGUE", "1") == "1"   # Linear+ReLU: activation in the GEMM epilogue (torch._addmm_activation)
-SKINNY_WGRAD = _os.environ.get("U3D_SKINNY_WGRAD", "0") == "1"
+RELU_EPILOGUE = True   # Linear+ReLU: activation in the GEMM epilogue (torch._addmm_activation)
+SKINNY_WGRAD = False
 # the layer-by-layer decoder on vendor kernels (F.linear / SDPA) for calls the fused HIP decoder does not cover: explicit opt-in only
 ALLOW_ATEN_DECODER = _os.environ.get("U3D_ALLOW_ATEN_DECODER", "0") == "1"
 
@@ -337,8 +336,8 @@ class _FusedLN(torch.autograd.Function):
         return dx.view(ctx.shp), dg, db, None, None, None
 
 
-FUSED_LN = _os.environ.get("U3D_FUSED_LN", "1") == "1"
-SHARED_VALUE_GRAD = _os.environ.get("U3D_SHARED_VALUE_GRAD", "1") == "1"
+FUSED_LN = True
+SHARED_VALUE_GRAD = True
 
 
 def fused_layer_norm(x, ln, relu=False, out_dtype=None):
@@ -433,7 +432,7 @@ class _SineEmbed(torch.autograd.Function):
         return nv.sine_embed_bwd(l2, dim_t, d2).view(ctx.shape).to(ctx.in_dtype), None, None
 
 
-FUSED_SINE_EMBED = _os.environ.get("U3D_FUSED_SINE_EMBED", "1") == "1"
+FUSED_SINE_EMBED = True
 
 
 def sine_embed_of_logits(ref_logits, out_dtype, num_pos_feats=128, temperature=10000):

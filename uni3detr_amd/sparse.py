@@ -139,41 +139,14 @@ def strided_level(lvl, ksize, stride, pad, capacity=None):
     return out, ConvGeom(fwd, bwd, lvl.n, lvl.n_dev, n_out, out.n_dev, strided=True)
 
 
-REV_SUBM_TABLE = os.environ.get("U3D_REV_SUBM_TABLE", "1") == "1"
+REV_SUBM_TABLE = True
 SUBM_HALO = os.environ.get("U3D_SUBM_HALO", "1") == "1"       # 64 -> 64 SubM convs out of per-tile staged distinct rows (subm_halo.hip)
-HALO_WGRAD = os.environ.get("U3D_HALO_WGRAD", "1") == "1"     # ... and their weight gradients (k_subm_halo_wgrad64)
-HALO_128 = os.environ.get("U3D_HALO_128", "1") == "1"         # ... and the 128 -> 128 SubM convs (k_subm_halo128: forward / input gradient)
-STRIDED_DGRAD_SPLIT = os.environ.get("U3D_STRIDED_DGRAD_SPLIT", "1") == "1"
-NMAJOR_FWD = os.environ.get("U3D_NMAJOR_FWD", "1") == "1"
-STRIDED_SPLIT_MIN_RATIO = int(os.environ.get("U3D_STRIDED_SPLIT_MIN_RATIO", "16"))
-STRIDED_SPLIT_SPARSE_RATIO = int(os.environ.get("U3D_STRIDED_SPLIT_SPARSE_RATIO", "16"))      # same threshold for the sparse levels' strided convs
-
-
-# Weight gradients on a side stream (opt-in, see wgrad_side_stream()): dW of a conv is off the backward's critical chain
-# (dy -> BN backward -> dgrad -> ...), so it can run next to the HBM-bound BatchNorm kernels of the layers below instead of in front
-# of them.  Operands are kept alive until the join (no allocator reuse while the side stream still reads them).
-# Measured in the captured step: 27.0 vs 26.45 ms - the two MFMA kernels running side by side cost more than the BatchNorm overlap
-# gains (as with the parallel SECOND3D branches, plugin/dense.py) -> off by default.
-WGRAD_SIDE = os.environ.get("U3D_WGRAD_SIDE", "0") == "1"
-_WG = {"active": False, "stream": None, "pending": []}
-
-
-@contextlib.contextmanager
-def wgrad_side_stream():
-    """Backward passes inside this block launch conv weight gradients on a side stream; the block joins it before returning
-    (the gradients are valid on the current stream afterwards)."""
-    if not (WGRAD_SIDE and torch.cuda.is_available()):
-        yield
-        return
-    if _WG["stream"] is None:
-        _WG["stream"] = torch.cuda.Stream()
-    _WG["active"] = True
-    try:
-        yield
-    finally:
-        _WG["active"] = False
-        torch.cuda.current_stream().wait_stream(_WG["stream"])
-        _WG["pending"].clear()
+HALO_WGRAD = True     # ... and their weight gradients (k_subm_halo_wgrad64)
+HALO_128 = True         # ... and the 128 -> 128 SubM convs (k_subm_halo128: forward / input gradient)
+STRIDED_DGRAD_SPLIT = True
+NMAJOR_FWD = True
+STRIDED_SPLIT_MIN_RATIO = 16
+STRIDED_SPLIT_SPARSE_RATIO = 16      # same threshold for the sparse levels' strided convs
 
 
 _CONV_USES = {}          # id(conv weight) -> forward uses since reset_conv_uses() (TrainStep resets it at the top of every step)
@@ -190,25 +163,25 @@ def reset_conv_uses():
 # activations travel as f32 rows, are split into hi / lo bf16 planes in front of each conv, and the three products are three sets of
 # offsets of ONE launch (tripled neighbour table and weights).  Narrow levels (16 / 32 channels) stay on the exact f32 kernels.
 SPLIT_BF16 = os.environ.get("U3D_SPLIT_BF16", "1") == "1"
-SPLIT_FUSED_ADD = os.environ.get("U3D_SPLIT_FUSED_ADD", "1") == "1"      # residual / fan-out gradient sums in the split input gradient's epilogue
+SPLIT_FUSED_ADD = True      # residual / fan-out gradient sums in the split input gradient's epilogue
 _SPLIT = [False]
 
 
 # hi / lo planes that already exist for an f32 row matrix: an earlier conv split the same rows (SECOND3D's three branches read one
-# input; a residual block's input feeds its first conv once).  Keyed by the rows' address; the entry holds the row tensor itself, so
-# the address cannot be handed to another tensor while the entry lives.  (Writing the planes from the BatchNorm apply that produces
-# the rows - one pass less per layer - was built and measured time-neutral, 216.0 vs 217.2 scenes/s: the extra 4 B / element of stores
-# cost what the saved read gains; removed.)
+# input; a residual block's input feeds its first conv once).  Keyed by the tensor OBJECT (an entry holds the tensor, so the id
+# cannot be reused while it lives) and its autograd version; the scope clears the table on entry and on exit, so an entry never
+# outlives the forward that made it.  (Writing the planes from the BatchNorm apply that produces the rows - one pass less per layer -
+# was built and measured time-neutral, 216.0 vs 217.2 scenes/s: the extra 4 B / element of stores cost what the saved read gains.)
 _PLANES = {}
 
 
 def _planes_of(feats, n_dev):
-    ent = _PLANES.get(feats.data_ptr())
-    if ent is not None and ent[0].shape == feats.shape and ent[0].dtype == feats.dtype and ent[0]._version == ent[2] == feats._version:
+    ent = _PLANES.get(id(feats))
+    if ent is not None and ent[0] is feats and ent[2] == feats._version:
         return ent[1]
     xs = nv.split_rows(feats.contiguous(), n_dev)
     if feats.is_contiguous():
-        _PLANES[feats.data_ptr()] = (feats, xs, feats._version)
+        _PLANES[id(feats)] = (feats, xs, feats._version)
     return xs
 
 
@@ -377,14 +350,7 @@ class _SparseConv(torch.autograd.Function):
             return dw
 
         if ctx.needs_input_grad[1]:
-            if _WG["active"] and dout.is_cuda:
-                side = _WG["stream"]
-                side.wait_stream(torch.cuda.current_stream())          # dout is ready on the current stream
-                with torch.cuda.stream(side):
-                    dw = weight_grad()
-                _WG["pending"].append((feats, dout, dw))
-            else:
-                dw = weight_grad()
+            dw = weight_grad()
         if ctx.needs_input_grad[0]:
             nbr = g.nbr_bwd if kvol > 1 else None
             cin, cout = wc.shape[1], wc.shape[2]
@@ -528,8 +494,8 @@ def sparse_conv(feats, weight, geom, layout="dhwio", fan_token=None):
 # take them over grow by +0.44 ms (per-tile sums in a tail that runs at one or two workgroups per CU: its x loads and ~8 VALU ops per
 # element are exposed, where the separate pass streams at full occupancy), and k_bn_bwd_apply loses the L2 hits the statistics pass
 # left behind (+0.05 ms): 19.77 -> 19.85 ms per step.  Kept (parity-tested) but off.
-BN_GRAD_FUSION = os.environ.get("U3D_BN_GRAD_FUSION", "0") == "1"
-FUSED_CONV_STATS = os.environ.get("U3D_FUSED_CONV_STATS", "1") == "1"
+BN_GRAD_FUSION = False
+FUSED_CONV_STATS = True
 
 
 def conv_bn(feats, weight, geom, bn, n_dev, residual=None, relu=True, layout="dhwio", post_add=None, res_take=None, res_give=None,

@@ -28,8 +28,6 @@ from .plugin import transformer as _T
 
 # decoder / head parameter-gradient launches on a side stream underneath the dense stack's backward: opt-in, measured time-neutral
 # (same-box A/B 22.11 / 22.04 vs 22.01 / 22.32 ms per step: the MFMA kernels of the dense stack leave no idle units to fill)
-EARLY_FLUSH = os.environ.get("U3D_EARLY_FLUSH", "0") == "1"
-FPS_LAUNCH_ORDER = os.environ.get("U3D_FPS_ORDER", "early")      # A/B: which of the two concurrent stage-1 graphs is launched first
 
 
 class TrainStep:
@@ -52,7 +50,6 @@ class TrainStep:
         self.pg_hooks = pg_hooks
         self._capture_batches = None
         self._msg = None
-        self._flush_stream, self._flush_keep = None, None
         self.dev = next(model.parameters()).device
         # time-out record of the several-workgroup FPS (sets above 20 480 points; native.fps_err_buffer): [0] = this step's launch gave
         # up waiting for a sibling workgroup - ORed into the step's collective HOLD flag (_stage1_head), so NO rank applies an update
@@ -212,11 +209,6 @@ class TrainStep:
     def _stage1_head(self, feat, fps):
         """Decoder / head forward, matching and targets (inside the caller's shadow scope)."""
         m = self.model
-        if EARLY_FLUSH and torch.is_tensor(feat) and feat.requires_grad:
-            # the gradient of the head's input exists once every decoder layer has run its backward: that is when the queued
-            # parameter-gradient products of decoder + head (~0.9 ms of small launches) can start - on a side stream, underneath
-            # the dense stack's backward, instead of after it
-            feat.register_hook(self._early_flush)
         amp = m.amp_dtype
         with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
             self._outs = m.pts_bbox_head(feat, None, fps)
@@ -252,21 +244,6 @@ class TrainStep:
         mv = 0 if (vl is None or m.dynamic_voxelization) else int(vl.max_voxels[0 if m.training else 1])
         return max(max(self.pts["lens"]), mv) > nv.FPS_REG_MAX
 
-    def _early_flush(self, grad):
-        if _T._Deferred.active and (_T._Deferred.items or _T._Deferred.sum_items or _T._Deferred.skinny):
-            if self._flush_stream is None:
-                self._flush_stream = torch.cuda.Stream()
-            cur, side = torch.cuda.current_stream(), self._flush_stream
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                self._flush_keep = _T.flush_deferred()          # operands stay referenced until the join
-        return None
-
-    def _join_flush(self):
-        if self._flush_keep is not None:
-            torch.cuda.current_stream().wait_stream(self._flush_stream)
-            self._flush_keep = None
-
     def _reduce_num_pos(self):
         """ONE small all-reduce per step: the mean positive counts (ref: reduce_mean in uni3detr_head.py:658-664, 680-681) and, in the
         same message, the job-wide capacity flag (> 0 on every rank iff any rank overflowed)."""
@@ -285,9 +262,8 @@ class TrainStep:
         if loss is None or not all("loss" in k for k in losses):
             loss = sum(v for k, v in losses.items() if "loss" in k)
         self.model.pts_bbox_head._loss_total = None
-        with _sp.wgrad_side_stream(), _T.deferred_param_grads():      # dW / db of the decoder + head linears: queued, then one batched launch per shape
+        with _T.deferred_param_grads():      # dW / db of the decoder + head linears: queued, then one batched launch per shape
             loss.backward()
-        self._join_flush()
         self.loss = loss.detach()
         dst, src, missing = [], [], []
         for i, (p, v) in enumerate(zip(self.params, self.views)):
@@ -353,9 +329,8 @@ class TrainStep:
         self.model.pts_bbox_head._loss_total = None
         cut = self.model._encoder_cut                # detached leaf the dense stack / head were fed with (detector.extract_pts_feat)
         cut.grad = None
-        with _sp.wgrad_side_stream(), _T.deferred_param_grads():
+        with _T.deferred_param_grads():
             loss.backward()
-        self._join_flush()
         self.loss = loss.detach()
         self._pack(self.n_enc, len(self.params))
         self._gx = cut.grad
@@ -364,8 +339,7 @@ class TrainStep:
     def _stage2b(self):
         """Phase B: the sparse encoder's backward from the gradient of its output."""
         x = self.model._encoder_out
-        with _sp.wgrad_side_stream():
-            x.backward(self._gx)
+        x.backward(self._gx)
         self._pack(0, self.n_enc)
         self._gx = None
         self.model._encoder_out = self.model._encoder_cut = None
@@ -399,7 +373,7 @@ class TrainStep:
         if self.dist_on:
             # comm_diag: event pairs around the two waits of the compute stream - how much of bucket A's all-reduce is NOT hidden under
             # the encoder's backward (the stream stalls in work.wait()) and what bucket B (never overlapped) costs; read by comm_exposed_ms()
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.comm_diag else None
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if getattr(self, "comm_diag", False) else None
             if ev:
                 ev[0].record()
             if self._work is not None:
@@ -647,8 +621,14 @@ class TrainStep:
             self._stage3()
         torch.cuda.synchronize()
         self._graphs = (g1, g2, g2b, g3)
-        if isinstance(g1, tuple):
+        if isinstance(g1, tuple) and getattr(self, "fps_stream_calibration_ms", None) is None:
+            # once per TrainStep: a re-capture keeps the stream the first capture chose (every rank then keeps ITS choice for the
+            # whole job, and a re-capture costs no calibration replays)
+            bufs = [(b, b.clone()) for b in self.model.buffers()]
             self._pick_fps_stream(g1)
+            with torch.no_grad():
+                for b, v in bufs:                    # the ~40 calibration replays ran BatchNorm in training mode on one batch
+                    b.copy_(v)
         if snap is not None:
             self.restore_full(snap)
         self._steps_since_check = 0
@@ -770,18 +750,10 @@ class TrainStep:
         g1a, gf, g1b, g1c = g1
         cur, side = torch.cuda.current_stream(), self._fps_stream
         g1a.replay()
-        if FPS_LAUNCH_ORDER == "late":
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            g1b.replay()                      # the sparse encoder and the dense stack are queued first ...
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                gf.replay()                   # ... the FPS rounds (which only need stage 1a) second, on the other stream
-        else:
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                gf.replay()                   # the FPS rounds: second stream, underneath ...
-            g1b.replay()                      # ... the sparse encoder and the dense stack
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            gf.replay()                       # the FPS rounds: second stream, underneath ...
+        g1b.replay()                          # ... the sparse encoder and the dense stack
         cur.wait_stream(side)
         g1c.replay()
 
