@@ -119,5 +119,8 @@ def bind_to_gpu_numa(device_index, sysfs="/sys", props=None, setaffinity=None):
     use = sorted(allowed & set(cpus))
     if not use:
         return None
-    (setaffinity or os.sched_setaffinity)(0, use)
+    try:
+        (setaffinity or os.sched_setaffinity)(0, use)
+    except OSError:                                         # a container that does not allow it: placement is an optimisation, never an error
+        return None
     return dict(node=node, cpus=len(use), pci=bdf)
