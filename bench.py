@@ -552,14 +552,19 @@ def main():
                 # under the headline's protocol and the measured deviation on the benched shape, both from THIS run
                 out["modes"] = {}
                 for mode in ("mixed", "parity"):
-                    faulthandler.dump_traceback_later(int(os.environ.get("U3D_WATCHDOG_S", "900")), exit=True)
-                    r = time_mode(mode, args, dev, rot, MODEL_CFG)
-                    faulthandler.cancel_dump_traceback_later()
-                    dv = bf16_deviation(dev, B=2, npts=args.points, mode=mode, ref=oref)
-                    r["vs_fp32_oracle"] = dv
-                    r["cls_logit_rel_l2"], r["box_rel_l2"], r["cls_logit_max_abs"] = dv["cls_logit_rel_l2"], dv["box_rel_l2"], dv["cls_logit_max_abs"]
-                    r["logits_within_1e-3"] = bool(dv["cls_logit_rel_l2"] <= 1e-3 and dv["box_rel_l2"] <= 1e-3 and dv["iou_logit_rel_l2"] <= 1e-3)
-                    out["modes"][mode] = r
+                    try:                                 # a failing extra mode must not cost the run its headline line: recorded, not raised
+                        faulthandler.dump_traceback_later(int(os.environ.get("U3D_WATCHDOG_S", "900")), exit=True)
+                        r = time_mode(mode, args, dev, rot, MODEL_CFG)
+                        faulthandler.cancel_dump_traceback_later()
+                        dv = bf16_deviation(dev, B=2, npts=args.points, mode=mode, ref=oref)
+                        r["vs_fp32_oracle"] = dv
+                        r["cls_logit_rel_l2"], r["box_rel_l2"], r["cls_logit_max_abs"] = dv["cls_logit_rel_l2"], dv["box_rel_l2"], dv["cls_logit_max_abs"]
+                        r["logits_within_1e-3"] = bool(dv["cls_logit_rel_l2"] <= 1e-3 and dv["box_rel_l2"] <= 1e-3 and dv["iou_logit_rel_l2"] <= 1e-3)
+                        out["modes"][mode] = r
+                    except (Exception, SystemExit) as e:
+                        faulthandler.cancel_dump_traceback_later()
+                        print(f"[bench] modes.{mode} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                        out["modes"][mode] = {"error": f"{type(e).__name__}: {e}"}
         result_line = json.dumps(out)
     else:
         result_line = None
