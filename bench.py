@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--allow-eager", action="store_true", help="if the hipGraph capture fails, fall back to eager launches instead of exiting non-zero")
     ap.add_argument("--no-modes", action="store_true", help="skip the `modes` block (mixed / parity throughput + logits deviation beside the bf16 headline)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` block (BASELINE.json configs[2..4] beside the headline)")
+    ap.add_argument("--workload-steps", type=int, default=30, help="timed steps of each entry of the `workloads` block (5 warm-up steps, 4 rotating batches)")
     return ap.parse_args()
 
 
@@ -164,6 +166,22 @@ def time_mode(precision, args, dev, rot, cfg):
     del ts, model, packed
     torch.cuda.empty_cache()
     return res
+
+
+def time_workload(name, args, dev, rank=0):
+    """One more shipped configuration (BASELINE.json configs[2..4]) under the headline's protocol - bf16, hipGraph replay, capture over
+    the rotating batches, untimed warm-up, timed steps between synchronisations, loss checked finite - at that configuration's own
+    batch / cloud size.  N = 1, rank 0; fewer steps and rotating batches than the headline so the default run stays within minutes."""
+    import types
+    wl = WORKLOADS[name]
+    cfg = workload_cfg(name)
+    a = types.SimpleNamespace(batch=wl["batch"], points=wl["points"], steps=args.workload_steps, warmup=5)
+    rot = [make_batch(rank, a.batch, a.points, dev, index=j, cfg=cfg) for j in range(4)]
+    r = time_mode("bf16", a, dev, rot, cfg)
+    r.update(workload=f"{wl['file']} (BASELINE {wl['baseline']})", batch=a.batch, points=a.points, precision="bf16")
+    del rot
+    torch.cuda.empty_cache()
+    return r
 
 
 def self_launch(args):
@@ -565,6 +583,19 @@ def main():
                         faulthandler.cancel_dump_traceback_later()
                         print(f"[bench] modes.{mode} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
                         out["modes"][mode] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and args.config == "sunrgbd" and args.precision == "bf16" and not args.no_workloads and not args.no_graph:
+            # the other shipped configurations (ScanNet-large, KITTI, nuScenes were builder-run lines only): same
+            # protocol, each at its own batch / cloud size; a failure is recorded, never raised
+            out["workloads"] = {}
+            for name in ("scannet_large", "kitti_3classes", "nuscenes"):
+                try:
+                    faulthandler.dump_traceback_later(int(os.environ.get("U3D_WATCHDOG_S", "900")), exit=True)
+                    out["workloads"][name] = time_workload(name, args, dev, rank)
+                    faulthandler.cancel_dump_traceback_later()
+                except (Exception, SystemExit) as e:
+                    faulthandler.cancel_dump_traceback_later()
+                    print(f"[bench] workloads.{name} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                    out["workloads"][name] = {"error": f"{type(e).__name__}: {e}"}
         result_line = json.dumps(out)
     else:
         result_line = None

@@ -5,9 +5,11 @@ voxelize -> VFE -> SparseEncoderHD -> SECOND3D -> SECOND3DFPN -> 2x FPS -> Uni3D
 HungarianAssigner3D -> losses.  Parameters come in as a flat state_dict with the reference's key names
 (SURVEY.md Appendix C).  Every function cites the reference file:line it follows.
 
-Pinning: the decoder/head/matcher/loss half is checked against golden vectors generated from the reference's own
-files (oracle/make_golden.py -> tests/golden/*.npz; tests/test_oracle_cpu.py).  The voxelize / sparse-conv / FPS
-half restates un-vendored upstream ops: PARITY UNPINNED there (property tests only).
+Pinning: everything the reference itself implements is checked against golden vectors generated from the reference's own
+files (oracle/make_golden.py -> tests/golden/*.npz; tests/test_oracle_cpu.py): decoder / head / matcher / losses / coder, and
+(round 6) SECOND3D + SECOND3DFPN (dense_stack.npz), SparseEncoderHD's layer wiring (encoder_wiring.npz) and
+shift_scale_points (detector_glue.npz).  The voxelize / sparse-conv arithmetic / BN1d / FPS / IoU pieces restate un-vendored
+upstream ops (mmcv, mmdet3d, spconv): PARITY UNPINNED there (property tests only).
 """
 import math
 
@@ -169,10 +171,22 @@ def fps_packed(flat, n, m):
     return idx
 
 
+def shift_scale_points(x, src_lo, src_hi, dst_lo=None, dst_hi=None):
+    """models/detectors/uni3detr.py:18-46: affine map of x [B,N,3] (or [B,M,N,3]: ranges gain an axis, :31-33) from the per-scene box
+    [src_lo, src_hi] ([B,3]) onto [dst_lo, dst_hi] (default the unit cube, :24-28): ((x - src_lo) * dst_diff) / src_diff + dst_lo, in
+    that operation order (:42-45).  Pinned by tests/golden/detector_glue.npz."""
+    if dst_lo is None:
+        dst_lo, dst_hi = torch.zeros_like(src_lo), torch.ones_like(src_lo)
+    if x.dim() == 4:
+        src_lo, src_hi, dst_lo, dst_hi = (t[:, None] for t in (src_lo, src_hi, dst_lo, dst_hi))
+    src_diff = src_hi[:, None, :] - src_lo[:, None, :]
+    dst_diff = dst_hi[:, None, :] - dst_lo[:, None, :]
+    return ((x - src_lo[:, None, :]) * dst_diff) / src_diff + dst_lo[:, None, :]
+
+
 def shift_scale_unit(x):
     """shift_scale_points(x, src=[min,max]) with dst=[0,1] (uni3detr.py:18-46,:181)."""
-    lo, hi = x.min(dim=1)[0], x.max(dim=1)[0]
-    return ((x - lo[:, None, :]) * 1.0) / (hi - lo)[:, None, :] + 0.0
+    return shift_scale_points(x, x.min(dim=1)[0], x.max(dim=1)[0])
 
 
 def fps_queries(points_list, coors, cfg):

@@ -74,10 +74,29 @@ def test_numa_binding_reads_the_gpus_node_from_sysfs(tmp_path):
     (node / "cpulist").write_text(f"{allowed[0]},{allowed[-1]},100000\n")
     seen = []
     props = SimpleNamespace(pci_domain_id=0, pci_bus_id=0xC1, pci_device_id=0)
-    r = L.bind_to_gpu_numa(0, sysfs=str(tmp_path), props=props, setaffinity=lambda pid, cpus: seen.append((pid, list(cpus))))
-    assert r == dict(node=1, cpus=len({allowed[0], allowed[-1]}), pci="0000:c1:00.0")
-    assert seen == [(0, sorted({allowed[0], allowed[-1]}))]
+    # every thread of the process is pinned (sched_setaffinity(0, ...) moves only the caller; the HIP runtime's and torch's
+    # worker threads exist by the time a rank knows its GPU): a fake /proc/self/task with three thread ids
+    tasks = tmp_path / "task"
+    for tid in (4242, 4243, 4250):
+        (tasks / str(tid)).mkdir(parents=True)
+    r = L.bind_to_gpu_numa(0, sysfs=str(tmp_path), props=props, setaffinity=lambda pid, cpus: seen.append((pid, list(cpus))),
+                           task_dir=str(tasks))
+    want = sorted({allowed[0], allowed[-1]})
+    assert r == dict(node=1, cpus=len(want), pci="0000:c1:00.0", threads=3)
+    assert seen == [(4242, want), (4243, want), (4250, want)]
+
+    def flaky(pid, cpus):                 # a thread that exited between the listing and the call is skipped, not an error
+        if pid == 4243:
+            raise ProcessLookupError(pid)
+        seen.append((pid, list(cpus)))
+    del seen[:]
+    assert L.bind_to_gpu_numa(0, sysfs=str(tmp_path), props=props, setaffinity=flaky, task_dir=str(tasks))["threads"] == 2
+    # no readable task list: the calling thread alone
+    del seen[:]
+    assert L.bind_to_gpu_numa(0, sysfs=str(tmp_path), props=props, setaffinity=lambda pid, cpus: seen.append(pid),
+                              task_dir=str(tmp_path / "no_such_dir"))["threads"] == 1 and seen == [0]
+    n = len(seen)
     (dev / "numa_node").write_text("-1\n")
     assert L.bind_to_gpu_numa(0, sysfs=str(tmp_path), props=props, setaffinity=lambda *a: seen.append(a)) is None
     assert L.bind_to_gpu_numa(0, sysfs=str(tmp_path / "nope"), props=props, setaffinity=lambda *a: seen.append(a)) is None
-    assert len(seen) == 1
+    assert len(seen) == n

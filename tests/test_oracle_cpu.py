@@ -319,3 +319,185 @@ def test_datapath_oracle_filter_and_sample():
     assert s.shape == (5, 4) and set(idx) <= {0, 1}                         # n < num_points: with replacement
     s, idx = od.point_sample(np.arange(40, dtype=np.float32).reshape(10, 4), 6, rng)
     assert len(set(idx)) == 6                                               # n >= num_points: without replacement
+
+
+# ==================================================================================================
+# round 6: the reference-held math that was restated but not pinned (SECOND3D / SECOND3DFPN, SparseEncoderHD wiring,
+# shift_scale_points) against goldens produced by the reference's own files (oracle/make_golden.py gen_dense_stack /
+# gen_encoder_wiring / gen_detector_glue)
+# ==================================================================================================
+ORACLE_CFG = {"sunrgbd": om.sunrgbd_cfg, "kitti_3classes": om.kitti_cfg, "scannet_large": om.scannet_large_cfg, "nuscenes": om.nuscenes_cfg}
+
+
+def _seeded_sd(prefix, keys, shapes, seed):
+    """The generator seeds each reference module's tensors by its OWN (unprefixed) key."""
+    return {prefix + str(k): seeded_tensor(str(k), eval(str(s)), seed) for k, s in zip(keys, shapes)}     # noqa: S307 (repr of an int tuple)
+
+
+def dense_stack_fixture(name):
+    z = np.load(os.path.join(G, "dense_stack.npz"), allow_pickle=False)
+    seed = int(z["seed"])
+    sd = _seeded_sd("pts_backbone.", z[f"{name}.backbone_keys"], z[f"{name}.backbone_shapes"], seed)
+    sd.update(_seeded_sd("pts_neck.", z[f"{name}.neck_keys"], z[f"{name}.neck_shapes"], seed))
+    return z, sd
+
+
+@pytest.mark.parametrize("name", ["sunrgbd", "scannet_large"])
+def test_dense_stack_oracle_matches_reference_golden(name):
+    """ref models/backbones/second_3d.py:52-76,89-114 + models/necks/second3d_fpn.py:48-104,112-143, training-mode BatchNorm."""
+    z, sd = dense_stack_fixture(name)
+    cfg = ORACLE_CFG[name]()
+    leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    x = torch.from_numpy(z[f"{name}.x"]).requires_grad_(True)
+    outs = om.second3d(leaf, "pts_backbone.", x, cfg)
+    y = om.second3dfpn(leaf, "pts_neck.", outs, cfg)
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.detach().numpy(), z[f"{name}.backbone{i}"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(y.detach().numpy(), z[f"{name}.neck"], rtol=1e-5, atol=1e-6)
+    (y * torch.from_numpy(z[f"{name}.cot"])).sum().backward()
+    scale = float(np.abs(z[f"{name}.dx"]).max())
+    np.testing.assert_allclose(x.grad.numpy(), z[f"{name}.dx"], rtol=1e-4, atol=1e-5 * scale)
+    got = np.concatenate([leaf[str(k)].grad.numpy().reshape(-1) for k in z[f"{name}.bn_grad_keys"]])
+    np.testing.assert_allclose(got, z[f"{name}.bn_grads"], rtol=1e-4, atol=1e-5 * float(np.abs(z[f"{name}.bn_grads"]).max()))
+    w0 = leaf["pts_backbone.blocks.0.0.weight"].grad[:8].numpy()
+    np.testing.assert_allclose(w0, z[f"{name}.wgrad_first_8"], rtol=1e-4, atol=1e-5 * float(np.abs(w0).max()))
+    wd = leaf["pts_neck.deblocks.2.0.weight"].grad[:, :4].numpy()
+    np.testing.assert_allclose(wd, z[f"{name}.wgrad_deconv2_4"], rtol=1e-4, atol=1e-5 * float(np.abs(wd).max()))
+
+
+def test_dense_stack_aliases_and_state_dict_names():
+    """KITTI / nuScenes ship the SAME pts_backbone / pts_neck dicts as SUN RGB-D (recorded by the generator, mirrored by the oracle's
+    configs); the product's modules carry the reference's parameter names and shapes."""
+    z = np.load(os.path.join(G, "dense_stack.npz"), allow_pickle=False)
+    keys = ("bb_in", "bb_out", "bb_layers", "bb_strides", "bb_kernel", "fpn_in", "fpn_out", "fpn_strides", "fpn_extra", "bn_eps")
+    for alias in ("kitti_3classes", "nuscenes"):
+        assert str(z[f"{alias}.same_as"]) == "sunrgbd"
+        assert all(ORACLE_CFG[alias]()[k] == om.sunrgbd_cfg()[k] for k in keys)
+    import projects.mmdet3d_plugin  # noqa: F401
+    from uni3detr_amd.configs.sunrgbd import model as mine
+    from uni3detr_amd.registry import build_model
+    m = build_model(mine)
+    for mod, pre in ((m.pts_backbone, "backbone"), (m.pts_neck, "neck")):
+        ref = {str(k): eval(str(s)) for k, s in zip(z[f"sunrgbd.{pre}_keys"], z[f"sunrgbd.{pre}_shapes"])}     # noqa: S307
+        assert {k: tuple(v.shape) for k, v in mod.state_dict().items()} == ref
+
+
+def _expected_trace(cfg, shape):
+    """The sparse-conv call sequence oracle.model.sparse_encoder performs, from its config numbers (the restatement's wiring)."""
+    k3 = (3, 3, 3)
+    rows = [("SubMConv3d", cfg["enc_in"], cfg["enc_base"], k3, (1, 1, 1))]
+    c = cfg["enc_base"]
+    last = len(cfg["encoder_channels"]) - 1
+    for i, blocks in enumerate(cfg["encoder_channels"]):
+        for j, oc in enumerate(blocks):
+            if j == len(blocks) - 1 and i != last:
+                s = (cfg["encoder_strides"][i],) * 3
+                rows.append(("SparseConv3d", c, oc, k3, s))
+            else:
+                rows += [("SubMConv3d", oc, oc, k3, (1, 1, 1))] * 2
+            c = oc
+    rows.append(("SparseConv3d", c, cfg["enc_out"], (1, 1, 1), (1, 1, 1)))
+    return rows
+
+
+@pytest.mark.parametrize("name", ["sunrgbd", "kitti_3classes", "scannet_large", "nuscenes"])
+def test_encoder_wiring_oracle_matches_reference_golden(name):
+    """ref models/pts_encoder/sparse_encoder_hd.py:36-138 (constructor + forward) and :140-214 (make_encoder_layers), built from the
+    shipped config over stand-in sparse layers that evaluate conv3d on the densified tensor: the oracle performs the same sequence of
+    sparse convolutions (kind, channels, kernel, stride, padding), meets the same active-set sizes at every level (its rulebook code
+    against the dense-mask definition) and produces the same dense volume."""
+    z = np.load(os.path.join(G, "encoder_wiring.npz"), allow_pickle=False)
+    seed, shape = int(z["seed"]), tuple(int(v) for v in z["sparse_shape"])
+    cfg = dict(ORACLE_CFG[name](), sparse_shape=shape)
+    sd = _seeded_sd("pts_middle_encoder.", z[f"{name}.keys"], z[f"{name}.shapes"], seed)
+    feats, coors = torch.from_numpy(z[f"{name}.feats"]), z[f"{name}.coors"]
+    B = int(coors[:, 0].max()) + 1
+    y = om.sparse_encoder(sd, "pts_middle_encoder.", feats, coors, B, cfg)
+    ref = z[f"{name}.dense"]
+    assert tuple(y.shape) == ref.shape
+    np.testing.assert_allclose(y.numpy(), ref, rtol=2e-4, atol=2e-5 * float(np.abs(ref).max()))
+    assert np.array_equal(y.numpy() != 0, ref != 0) or float(np.mean((y.numpy() != 0) != (ref != 0))) < 1e-3     # same active cells (ReLU zeros aside)
+    # the call sequence
+    num = z[f"{name}.trace_num"]
+    exp = _expected_trace(cfg, shape)
+    assert len(exp) == num.shape[0] == 21
+    for row, kind, (ek, ecin, ecout, ekern, estride) in zip(num, z[f"{name}.trace_kind"], exp):
+        assert (str(kind), int(row[0]), int(row[1]), tuple(row[2:5]), tuple(row[5:8])) == (ek, ecin, ecout, ekern, estride)
+    # active-set sizes level by level: oracle/geometry.py's strided rule against the dense-mask definition the stand-ins evaluate
+    c, dims, pads = coors, shape, []
+    strided = [r for r, k in zip(num, z[f"{name}.trace_kind"]) if str(k) == "SparseConv3d" and tuple(r[2:5]) == (3, 3, 3)]
+    for r in strided:
+        pad = tuple(int(v) for v in r[8:11])
+        oc, odims = og.strided_out_coords(c, dims, (3, 3, 3), tuple(int(v) for v in r[5:8]), pad)
+        assert (int(r[11]), int(r[12])) == (c.shape[0], oc.shape[0]) and tuple(int(v) for v in r[16:19]) == tuple(odims)
+        c, dims = oc, odims
+        pads.append(pad)
+    assert pads == [(1, 1, 1), (1, 1, 1), (0, 1, 1)]                # encoder_paddings' last entries (cfg :39), as make_encoder_layers reads them
+    # indice keys as the reference assigns them (:79,:88,:103,:189): SparseBasicBlock convs carry none (=> rulebooks rebuilt per conv upstream)
+    keys = [str(k) for k in z[f"{name}.trace_key"]]
+    assert keys[0] == "subm1" and keys[-1] == "spconv_down2" and [k for k in keys if k.startswith("spconv") and k != "spconv_down2"] == ["spconv1", "spconv2", "spconv3"]
+    assert sum(k == "" for k in keys) == 16
+
+
+def test_encoder_state_dict_names_match_reference():
+    z = np.load(os.path.join(G, "encoder_wiring.npz"), allow_pickle=False)
+    import projects.mmdet3d_plugin  # noqa: F401
+    from uni3detr_amd.configs.sunrgbd import model as mine
+    from uni3detr_amd.registry import build_model
+    m = build_model(mine)
+    ref = {str(k): eval(str(s)) for k, s in zip(z["sunrgbd.keys"], z["sunrgbd.shapes"])}     # noqa: S307
+    assert {k: tuple(v.shape) for k, v in m.pts_middle_encoder.state_dict().items()} == ref
+
+
+def test_shift_scale_points_matches_reference_golden():
+    """ref models/detectors/uni3detr.py:18-46."""
+    z = np.load(os.path.join(G, "detector_glue.npz"), allow_pickle=False)
+    x3 = torch.from_numpy(z["x3"])
+    lo, hi = x3.min(dim=1)[0], x3.max(dim=1)[0]
+    assert np.array_equal(om.shift_scale_unit(x3).numpy(), z["y_unit"])
+    assert np.array_equal(om.shift_scale_points(x3, lo, hi, torch.from_numpy(z["dst_lo"]), torch.from_numpy(z["dst_hi"])).numpy(), z["y_dst"])
+    ints = torch.from_numpy(z["ints"])
+    assert np.array_equal(om.shift_scale_unit(ints).numpy(), z["y_int"])
+    x4 = torch.from_numpy(z["x4"])
+    f = x4.reshape(x4.shape[0], -1, 3)
+    assert np.array_equal(om.shift_scale_points(x4, f.min(dim=1)[0], f.max(dim=1)[0]).numpy(), z["y4"])
+    # the product's host-side form of the same function (plugin/detector.py) on the same vectors
+    from uni3detr_amd.plugin.detector import shift_scale_points as prod
+    assert np.array_equal(prod(x3, [lo, hi]).numpy(), z["y_unit"])
+    assert np.array_equal(prod(ints, [ints.min(dim=1)[0], ints.max(dim=1)[0]]).numpy(), z["y_int"])
+
+
+def test_dense_stack_gradient_conditioning():
+    """The yardstick for every gradient tolerance over the dense stack (tests/test_reference_golden_gpu.py): in
+    float64, perturb every convolution output of the restated SECOND3D + SECOND3DFPN by a relative 3e-6 (gaussian).  The forward
+    moves by ~2e-5 - and the gradients by ~1.5e-2, three orders of magnitude more: ReLU decisions next to zero flip, each flip moves
+    a whole row of the gradient in front of it and the BatchNorm means behind it.  A correct backward whose FORWARD deviates by 2e-5
+    (the `parity` mode's split-bf16 products) therefore shows gradient deviations of 1-2e-2 on this network."""
+    import torch.nn.functional as F
+    name = "sunrgbd"
+    z, sd = dense_stack_fixture(name)
+    cfg = om.sunrgbd_cfg()
+
+    def run(noise):
+        g = torch.Generator().manual_seed(1)
+        leaf = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+        x = torch.from_numpy(z[f"{name}.x"]).double().requires_grad_(True)
+        orig = F.conv3d
+
+        def noisy(*a, **k):
+            y = orig(*a, **k)
+            return y * (1 + noise * torch.randn(y.shape, generator=g, dtype=y.dtype)) if noise else y
+        F.conv3d = noisy
+        try:
+            y = om.second3dfpn(leaf, "pts_neck.", om.second3d(leaf, "pts_backbone.", x, cfg), cfg)
+        finally:
+            F.conv3d = orig
+        (y * torch.from_numpy(z[f"{name}.cot"]).double()).sum().backward()
+        return y.detach(), x.grad, leaf["pts_backbone.blocks.0.1.bias"].grad
+
+    rel = lambda a, b: float((a - b).norm() / b.norm())      # noqa: E731
+    clean, pert = run(0.0), run(3e-6)
+    fwd, dx, db = (rel(a, b) for a, b in zip(pert, clean))
+    assert 5e-6 < fwd < 1e-4, fwd
+    assert 3e-3 < dx < 5e-2 and 3e-3 < db < 6e-2, (dx, db)
+    assert dx > 100 * fwd                                       # the amplification itself

@@ -100,7 +100,7 @@ def numa_cpus_for_pci(bdf, sysfs="/sys"):
         return None
 
 
-def bind_to_gpu_numa(device_index, sysfs="/sys", props=None, setaffinity=None):
+def bind_to_gpu_numa(device_index, sysfs="/sys", props=None, setaffinity=None, task_dir="/proc/self/task"):
     """Pin THIS process to the CPUs of the NUMA node of GPU `device_index` (first-touch then places its host allocations there too).
     Intersects with the CPUs the process may already run on; leaves everything alone when the topology is unknown or the intersection
     is empty.  -> dict(node=, cpus=) describing what was done, or None."""
@@ -119,8 +119,21 @@ def bind_to_gpu_numa(device_index, sysfs="/sys", props=None, setaffinity=None):
     use = sorted(allowed & set(cpus))
     if not use:
         return None
+    # sched_setaffinity(0, ...) pins only the CALLING thread: by the time a rank knows its GPU the HIP runtime and torch's intra-op
+    # pool have already started threads with the old mask -> every thread of the process (/proc/self/task) gets the new one.
+    # (Pages those threads touched earlier stay where they are; bench.py therefore binds before it allocates its host buffers.)
+    setaff = setaffinity or os.sched_setaffinity
     try:
-        (setaffinity or os.sched_setaffinity)(0, use)
-    except OSError:                                         # a container that does not allow it: placement is an optimisation, never an error
+        tids = sorted(int(t) for t in os.listdir(task_dir))
+    except OSError:
+        tids = [0]
+    done = 0
+    for tid in (tids or [0]):
+        try:
+            setaff(tid, use)
+            done += 1
+        except OSError:                                     # a thread that exited meanwhile, or a container that does not allow it:
+            continue                                        # placement is an optimisation, never an error
+    if done == 0:
         return None
-    return dict(node=node, cpus=len(use), pci=bdf)
+    return dict(node=node, cpus=len(use), pci=bdf, threads=done)

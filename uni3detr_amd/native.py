@@ -696,8 +696,9 @@ def spconv_fwd(inp, w, nbr, n_out_dev, n_out, cout, transpose_w=False, tag=None,
 
 
 def split_rows(x, n_dev, n_cap=None):
-    """f32 [n_cap, c] -> bf16 [2 * n_cap, c]: hi plane = bf16(x), lo plane = bf16(x - hi) (u3d_split_rows_f32).  Rows past the
-    device-side count stay unwritten - the tables never name them."""
+    """f32 [n_cap, c] -> bf16 [2 * n_cap, c]: hi plane = bf16(x), lo plane = bf16(x - hi) (u3d_split_rows_f32).  Rows between the
+    device-side count and n_cap are written as ZEROS in both planes (the kernel zero-fills up to the capacity: the LDS-DMA kernels stage
+    whole tiles, and a NaN bit pattern in a never-named padding row would still poison a BatchNorm statistic through 0 * NaN)."""
     n_cap = x.shape[0] if n_cap is None else n_cap
     assert x.dtype == torch.float32 and x.is_contiguous()
     out = torch.empty((2 * n_cap, x.shape[1]), dtype=torch.bfloat16, device=x.device)

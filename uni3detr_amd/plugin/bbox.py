@@ -165,8 +165,14 @@ class NMSFreeCoder:
         cls_scores = cls_scores.sigmoid()
         # top-k with a PINNED tie order: descending score, equal scores by ascending (query, class) index - a stable descending sort keeps
         # equal elements in input order by contract on every device (the upstream `topk` leaves ties to the backend: ref :70)
-        scores, idx = cls_scores.view(-1).sort(descending=True, stable=True)
-        scores, idx = scores[: self.max_num], idx[: self.max_num]
+        # Cost: a top-k for the cut, then the stable sort over the SELECTED elements only (everything >= the k-th score: k of them unless
+        # the k-th score is tied) - not over all num_query x num_classes scores (nuScenes: 27 000 per scene)
+        flat = cls_scores.reshape(-1)
+        k = min(int(self.max_num), flat.numel())
+        kth = flat.topk(k).values[-1]
+        cand = (flat >= kth).nonzero().view(-1)                       # ascending (query, class) index
+        scores, order = flat[cand].sort(descending=True, stable=True)
+        scores, idx = scores[:k], cand[order][:k]
         labels = idx % self.num_classes
         bidx = torch.div(idx, self.num_classes, rounding_mode="floor")
         boxes = denormalize_bbox(bbox_preds[bidx], self.pc_range)

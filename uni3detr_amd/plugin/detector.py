@@ -74,7 +74,8 @@ class DynamicSimpleVFE(nn.Module):
         return feats, g.coords(n_vox)
 
 
-FUSED_FPS_GLUE = True      # 0: the ATen formulation of the glue around the FPS launch (A/B, parity tests)
+FUSED_FPS_GLUE = True      # test-only module attribute: tests/test_toggles_gpu.py sets it False to run the tensor-op formulation of the
+                           # glue around the FPS launch against the fused one (no environment switch reads it)
 
 
 def shift_scale_points(pred_xyz, src_range, dst_range=None):

@@ -273,15 +273,16 @@ class _InProjFn(torch.autograd.Function):
         return (None if dq_in is None else dq_in.view(qc.shape)), (None if dv_in is None else dv_in.view(vc.shape)), dw, db, None
 
 
-import os as _os
-SAFE_LINEAR = _os.environ.get("U3D_UNSAFE_LINEAR", "0") != "1"      # test hook: "1" restores torch's own Linear backward
+SAFE_LINEAR = True        # test-only module attribute (tests/test_toggles_gpu.py): False restores torch's own Linear backward
 OWN_WGRAD = True          # dW of the decoder/head linears on u3d_igemm_wgrad_bf16
 # dW of the <= 16-feature linears on u3d_skinny_wgrad_bf16: correct (tests) but measured SLOWER end to end than hipBLASLt's
 # small products (30.3 vs 29.7 ms per step: 57 workgroups per launch) - opt-in until the kernel splits the wide dimension too
 RELU_EPILOGUE = True   # Linear+ReLU: activation in the GEMM epilogue (torch._addmm_activation)
 SKINNY_WGRAD = False
-# the layer-by-layer decoder on vendor kernels (F.linear / SDPA) for calls the fused HIP decoder does not cover: explicit opt-in only
-ALLOW_ATEN_DECODER = _os.environ.get("U3D_ALLOW_ATEN_DECODER", "0") == "1"
+# The layer-by-layer formulation of the decoder further down (nn.Linear / SDPA through ATen) is what runs on CPU tensors (the
+# registry / config tests of this container) and what the GPU tests compare the fused HIP decoder with by setting
+# fused_decoder.ENABLED = False themselves.  No environment variable selects it: on a CUDA tensor a call the fused kernels do not cover
+# raises (Uni3DETRTransformerDecoder._fused_decoder).
 
 
 def _autocast_dtype(x):
@@ -682,12 +683,12 @@ class Uni3DETRTransformerDecoder(nn.Module):
             if cached[1] is not None:
                 return cached[1]
             why = cached[2]
-        # not covered.  On the GPU the layer-by-layer formulation below runs on vendor kernels (F.linear -> hipBLASLt, SDPA): that is a
-        # different product, so it is never entered silently - only through an explicit switch (fused_decoder.ENABLED = False /
-        # U3D_FUSED_DECODER=0: the A/B formulation the tests compare against, or U3D_ALLOW_ATEN_DECODER=1)
-        if query.is_cuda and _fdm.ENABLED and not ALLOW_ATEN_DECODER:
-            raise RuntimeError(f"Uni3DETRTransformerDecoder: the fused HIP decoder does not cover this call ({why}); refusing to fall "
-                               f"back to vendor GEMM / SDPA kernels silently. Set U3D_ALLOW_ATEN_DECODER=1 to run the layer-by-layer path.")
+        # not covered.  On the GPU the layer-by-layer formulation below would run on vendor kernels (F.linear -> hipBLASLt, SDPA): a
+        # different product, so the call fails instead - there is no switch a user can set (the tests that compare the two
+        # formulations flip fused_decoder.ENABLED in-process)
+        if query.is_cuda and _fdm.ENABLED:
+            raise RuntimeError(f"Uni3DETRTransformerDecoder: the fused HIP decoder does not cover this call ({why}); there is no vendor-kernel "
+                               f"fallback in this package")
         return None
 
     def forward_bf(self, query, ref_logits, value, reg_branches, group, ref_sig=None):

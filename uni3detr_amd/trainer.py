@@ -26,8 +26,9 @@ from . import native as nv
 from . import sparse as _sp
 from .plugin import transformer as _T
 
-# decoder / head parameter-gradient launches on a side stream underneath the dense stack's backward: opt-in, measured time-neutral
-# (same-box A/B 22.11 / 22.04 vs 22.01 / 22.32 ms per step: the MFMA kernels of the dense stack leave no idle units to fill)
+
+class FpsTimeout(RuntimeError):
+    """check_capacities(): the step's FPS launch did not finish (the caller re-captures with the single-workgroup FPS)."""
 
 
 class TrainStep:
@@ -447,8 +448,10 @@ class TrainStep:
             self._skip_known = True
         self.set_hyper()
 
-    def eager_step(self):
-        self._stage1(); self._reduce_num_pos()
+    def eager_step(self, stage1_done=False):
+        if not stage1_done:
+            self._stage1()
+        self._reduce_num_pos()
         if self.overlap:
             self._stage2a(); self._reduce_grads_a(); self._stage2b(); self._reduce_grads_b()
         else:
@@ -544,6 +547,11 @@ class TrainStep:
             c = int(vfe.last_count_dev.item())
             if c > int(vfe.capacity):
                 raise RuntimeError(f"sparse level overflow: {c} voxels > capacity {vfe.capacity} of the dynamic voxel list; re-capture with a larger margin")
+        # the several-workgroup FPS's time-out record: [0] != 0 = THIS step's launch gave up waiting for a sibling workgroup, i.e. the
+        # samples behind the decoder's queries are invalid (index 0 for the unfinished rounds) - as fatal for the step as a truncated level
+        e = getattr(self.model, "fps_err", None)
+        if e is not None and getattr(self.model, "fps_max_wg", 0) != 1 and int(e[0].item()) != 0:
+            raise FpsTimeout("several-workgroup FPS timed out waiting for a sibling workgroup: this step's query samples are invalid")
         return counts
 
     def capture(self, warmup=3, keep_state=True, batches=None, remember_batches=True):
@@ -757,8 +765,40 @@ class TrainStep:
         cur.wait_stream(side)
         g1c.replay()
 
+    def _eager_check(self):
+        """Eager mode has no graph to re-capture, but the device-side HOLD still skips updates (level overflow cannot happen without
+        captured capacities; a persistent FPS time-out can): every `check_every` steps read the counters and, on a time-out, fall back
+        to the single-workgroup FPS - otherwise every step would be a silent no-op that still returns a finite loss."""
+        self._steps_since_check = 0
+        held, n_to = self.held_steps(), self.fps_timeouts()
+        if n_to > 0:
+            import sys
+            self.fps_timeouts_seen += n_to
+            self.model.fps_max_wg = 1
+            self.model.fps_err.zero_()
+            if self.flat_update:
+                self.opt_state[11:13].zero_()
+            print(f"[TrainStep] eager mode: {held} step(s) held, {n_to} FPS launch(es) timed out waiting for a sibling workgroup; "
+                  "continuing with the single-workgroup FPS", file=sys.stderr, flush=True)
+
     def step(self):
         if self._graphs is None:
+            if self.check_every and self._steps_since_check >= self.check_every:
+                self._eager_check()
+            self._steps_since_check += 1
+            if not self.flat_update and getattr(self.model, "fps_err", None) is not None and getattr(self.model, "fps_max_wg", 0) != 1:
+                # torch.optim path: no device-side hold -> the time-out is caught on the host (one small read per step) between the
+                # forward and the backward; the forward is repeated with the single-workgroup FPS, nothing trains on invalid samples
+                self._stage1()
+                if int(self.model.fps_err[0].item()) != 0:
+                    import sys
+                    self.fps_timeouts_seen += 1
+                    self.model.fps_max_wg = 1
+                    self.model.fps_err.zero_()
+                    print("[TrainStep] eager mode: the several-workgroup FPS timed out; repeating the forward with the single-workgroup "
+                          "FPS", file=sys.stderr, flush=True)
+                    self._stage1()
+                return self.eager_step(stage1_done=True)
             return self.eager_step()
         if self.check_every and self._steps_since_check >= self.check_every:
             # held steps = a level outgrew its capacity on some rank (the device already refused to train on it, on every rank):
@@ -780,10 +820,12 @@ class TrainStep:
             # captured capacity would be truncated and trained on silently, so this configuration pays one host read per step and
             # re-captures BEFORE the backward / update of the overflowing batch
             try:
-                self.check_capacities()
-            except RuntimeError:
+                self.check_capacities()        # (also reads the FPS time-out flag: this path has no device-side hold to catch it)
+            except RuntimeError as e:
                 if self.dist_on:
                     raise                      # a per-rank decision cannot drive a collective re-capture: flat_update=True does that
+                if isinstance(e, FpsTimeout):
+                    self._job_fps_timeouts = max(1, self.fps_timeouts())       # recapture() switches to the single-workgroup FPS
                 self.recapture()
                 g1, g2, g2b, g3 = self._graphs
                 self._replay_stage1(g1)
