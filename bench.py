@@ -370,7 +370,8 @@ def main():
         # N > 1 diagnostics (the first multi-GPU run must explain itself): every rank's own wall time, its exposed gradient waits,
         # its re-captures and held steps, its NUMA placement
         mine = torch.tensor([dt_local * 1e3 / args.steps, (comm or {}).get("reduce_a_exposed_ms", 0.0), (comm or {}).get("reduce_b_exposed_ms", 0.0),
-                             float(getattr(ts, "recaptures", 0)), float(ts.held_steps()), float(-1 if numa is None else numa["node"])],
+                             float(getattr(ts, "recaptures", 0)), float(ts.held_steps()), float(-1 if numa is None else numa["node"]),
+                             (comm or {}).get("reduce_m_exposed_ms", 0.0)],
                             device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(allr, mine)
@@ -382,7 +383,11 @@ def main():
                  "reduce_b_exposed_ms_per_rank": [round(float(v), 4) for v in rows[:, 2]],
                  "recaptures_per_rank": [int(v) for v in rows[:, 3]], "held_steps_per_rank": [int(v) for v in rows[:, 4]],
                  "numa_node_per_rank": [int(v) for v in rows[:, 5]],
-                 "bucket_a_MB": (comm or {}).get("bucket_a_MB"), "bucket_b_MB": (comm or {}).get("bucket_b_MB"),
+                 # three buckets in reverse layer order: a = neck + head + decoder, in flight under SECOND3D's backward;
+                 # m = SECOND3D, in flight under the sparse encoder's backward; b = the encoder, never overlapped (U3D_REDUCE_BUCKETS=2: a = a + m)
+                 "reduce_m_exposed_ms": float(rows[:, 6].max()), "reduce_m_exposed_ms_per_rank": [round(float(v), 4) for v in rows[:, 6]],
+                 "buckets": (comm or {}).get("buckets"),
+                 "bucket_a_MB": (comm or {}).get("bucket_a_MB"), "bucket_m_MB": (comm or {}).get("bucket_m_MB"), "bucket_b_MB": (comm or {}).get("bucket_b_MB"),
                  "overlap_reduce": bool(ts.overlap),
                  "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None}
     dt = float(tt.item())

@@ -571,3 +571,23 @@ def test_fused_layer_f32_gradients_match_f32_restatement(cuda, exact, lid, p_on)
             bad.append((n, e, float(b.norm())))
     print(f"f32 fused layer {lid} dropout={p_on}: worst relative gradient error {worst:.2e}")
     assert not bad, bad
+
+
+def test_uncovered_decoder_call_raises_instead_of_running_vendor_kernels(cuda):
+    """there is no vendor-kernel (F.linear / SDPA) decoder a user can switch on.  A CUDA call in a layout the fused HIP
+    decoder does not cover (here: float16 autocast) fails loudly; the layer-by-layer formulation is only reachable when a test flips
+    fused_decoder.ENABLED in-process (the A/B comparisons above), and no environment variable selects it."""
+    import os
+    from uni3detr_amd.plugin import fused_decoder as fdm
+    from uni3detr_amd.plugin import transformer as T
+    assert fdm.ENABLED is True and not hasattr(T, "ALLOW_ATEN_DECODER")
+    for name in ("U3D_ALLOW_ATEN_DECODER", "U3D_FUSED_DECODER", "U3D_UNSAFE_LINEAR"):
+        src = open(T.__file__).read() + open(fdm.__file__).read()
+        assert f'"{name}"' not in src and f"'{name}'" not in src, name
+    head = make_head(cuda, 11)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    feats = torch.randn(1, 256, 15, 40, 40, generator=g).clamp_min(0).to(cuda).to(memory_format=torch.channels_last_3d).requires_grad_(True)
+    fps = torch.rand(1, 600, 3, generator=g).to(cuda)
+    with pytest.raises(RuntimeError, match="no vendor-kernel"):
+        with torch.autocast("cuda", dtype=torch.float16):
+            head(feats, None, fps)

@@ -1,6 +1,7 @@
 """CPU, world size 2, gloo: the N>1 specific host logic - the fused scalar all-reduces of the loss / log-vars, and the reductions of
-uni3detr_amd.trainer.TrainStep as bench.py runs them for N > 1 (flat gradient buffer averaged in two buckets, the first one in
-flight under the second half of the backward; ONE small message per step carrying the positive counts and the capacity flag),
+uni3detr_amd.trainer.TrainStep as bench.py runs them for N > 1 (flat gradient buffer averaged in THREE buckets in reverse layer
+order - neck + head, SECOND3D, sparse encoder - the first two asynchronously, each in flight under the backward phase that follows it
+(the two-bucket plan of rounds 3-5 is still covered); ONE small message per step carrying the positive counts and the capacity flag),
 called as unbound methods on a CPU stand-in that holds the attributes they touch."""
 import os
 import socket
@@ -48,22 +49,36 @@ def _worker(rank, world, port, q):
         class _Stub(SimpleNamespace):                      # the reductions call each other through self
             _comm_view = TrainStep._comm_view
             _all_reduce_slice = TrainStep._all_reduce_slice
-        st = _Stub(dist_on=True, world=world, flat_grad=local[rank].clone(), enc_end=384, _work=None, grad_comm_dtype=torch.float32, _comm=None,
-                             _msg=torch.tensor([30.0, 20.0, 10.0, 1.0 if rank == 1 else 0.0]) * torch.tensor([rank + 1.0] * 3 + [1.0]))
+            _launch_bucket = TrainStep._launch_bucket
+        st = _Stub(dist_on=True, world=world, flat_grad=local[rank].clone(), enc_end=384, bb_end=384, three_phase=False, grad_comm_dtype=torch.float32,
+                   _comm=None, _msg=torch.tensor([30.0, 20.0, 10.0, 1.0 if rank == 1 else 0.0]) * torch.tensor([rank + 1.0] * 3 + [1.0]))
+        st._works = []
         TrainStep._reduce_grads_a(st)
-        assert st._work is not None
+        assert len(st._works) == 1 and st._works[0][2:] == (384, 1000)
         TrainStep._reduce_grads_b(st)
-        assert st._work is None and torch.allclose(st.flat_grad, sum(local) / world, atol=1e-6)
+        assert not st._works and torch.allclose(st.flat_grad, sum(local) / world, atol=1e-6)
+        # (3a) the three-bucket plan (round 6): [bb_end:) after the head / FPN backward, [enc_end:bb_end) after SECOND3D's, [:enc_end) last;
+        #      two reductions in flight at once; element for element the mean of the local gradients, identical to the single-bucket result
+        s3 = _Stub(dist_on=True, world=world, flat_grad=local[rank].clone(), enc_end=100, bb_end=640, three_phase=True, grad_comm_dtype=torch.float32,
+                   _comm=None, comm_diag=False)
+        s3._works = []
+        TrainStep._reduce_grads_a(s3)
+        TrainStep._reduce_grads_m(s3)
+        assert [w[2:] for w in s3._works] == [(640, 1000), (100, 640)]
+        TrainStep._reduce_grads_b(s3)
+        assert not s3._works and torch.equal(s3.flat_grad, st.flat_grad)
         st2 = _Stub(dist_on=True, world=world, flat_grad=local[rank].clone(), grad_comm_dtype=torch.float32, _comm=None)
         TrainStep._reduce_grads(st2)
         assert torch.allclose(st2.flat_grad, st.flat_grad, atol=1e-6)
         # (3b) the bf16 exchange option: same buckets, staged through a bf16 buffer - the mean to bf16 precision, identical on all ranks
-        st3 = _Stub(dist_on=True, world=world, flat_grad=local[rank].clone(), enc_end=384, _work=None, _work_buf=None, _comm=None)
+        st3 = _Stub(dist_on=True, world=world, flat_grad=local[rank].clone(), enc_end=384, bb_end=700, three_phase=True, _comm=None)
         st3.grad_comm_dtype = torch.bfloat16
+        st3._works = []
         TrainStep._reduce_grads_a(st3)
+        TrainStep._reduce_grads_m(st3)
         TrainStep._reduce_grads_b(st3)
         exact = sum(local) / world
-        assert st3._work is None and float((st3.flat_grad - exact).abs().max()) <= 2.0 ** -7 * float(exact.abs().max())
+        assert not st3._works and float((st3.flat_grad - exact).abs().max()) <= 2.0 ** -7 * float(exact.abs().max())
         gathered = [torch.empty_like(st3.flat_grad) for _ in range(world)]
         dist.all_gather(gathered, st3.flat_grad)
         assert all(torch.equal(gathered[0], t) for t in gathered)

@@ -67,7 +67,7 @@ def _mean_worker(rank, world, port, q, overlap):
             local_np.append(ts._msg[:L].clone())
             ts._msg[:L].copy_(mean_np)
         ts._reduce_num_pos = fake_reduce
-        ts._reduce_grads = ts._reduce_grads_a = ts._reduce_grads_b = lambda: None
+        ts._reduce_grads = ts._reduce_grads_a = ts._reduce_grads_m = ts._reduce_grads_b = lambda: None      # (all three buckets)
         ts.step()
         torch.cuda.synchronize()
         g_loc = ts.flat_grad.clone()

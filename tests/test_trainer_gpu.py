@@ -286,11 +286,13 @@ def test_flat_parameter_shadows_equal_per_tensor_casts(cuda):
     assert sh._plan[4] > 0 and sh._plan[2] > 0
 
 
+@pytest.mark.parametrize("buckets", [2, 3])
 @pytest.mark.parametrize("graph", [False, True])
-def test_two_phase_backward_matches_single_backward(cuda, graph):
+def test_two_phase_backward_matches_single_backward(cuda, graph, buckets):
     """overlap_reduce=True: backward cut at the sparse encoder's dense() output (phase A: losses/head/decoder/dense stack, phase B: the
-    encoder) must leave the same flat gradient as the single backward, eager and captured; the encoder's parameters are the prefix
-    of the flat buffer that is reduced last."""
+    encoder) - and, with three buckets (the default since round 6), also at SECOND3D's outputs (phase A: losses/head/decoder/FPN, phase
+    M: SECOND3D) - must leave the same flat gradient as the single backward, eager and captured; the flat buffer is
+    [encoder | SECOND3D | neck + head], reduced last to first."""
     pts, gts, labels = _data(cuda)
     ref = _model(cuda)
     sd = copy.deepcopy(ref.state_dict())
@@ -298,9 +300,14 @@ def test_two_phase_backward_matches_single_backward(cuda, graph):
     a.step()
     ga = a.flat_grad.clone()
     m2 = _model(cuda, sd)
-    b = TrainStep(m2, pts, gts, labels, graph=graph, lr=0.0, overlap_reduce=True)
+    b = TrainStep(m2, pts, gts, labels, graph=graph, lr=0.0, overlap_reduce=True, reduce_buckets=buckets)
     assert b.overlap and 0 < b.n_enc < len(b.params) and b.enc_end == b.offsets[b.n_enc]
     assert all(n.startswith("pts_middle_encoder.") for n, _ in list(m2.named_parameters())[:b.n_enc])
+    assert b.three_phase == (buckets == 3)
+    if b.three_phase:
+        assert b.enc_end < b.bb_end < b.flat_grad.numel() and b.bb_end == b.offsets[b.n_bb_end]
+        assert all(n.startswith("pts_backbone.") for n, _ in list(m2.named_parameters())[b.n_enc:b.n_bb_end])
+        assert list(m2.named_parameters())[b.n_bb_end][0].startswith("pts_neck.")
     if graph:
         snap = b.snapshot()
         b.capture()
@@ -315,6 +322,10 @@ def test_two_phase_backward_matches_single_backward(cuda, graph):
     assert rel <= (5e-2 if graph else 5e-3), rel
     enc = slice(0, b.enc_end)
     assert gb[enc].abs().sum() > 0 and gb[b.enc_end:].abs().sum() > 0
+    if b.three_phase:                      # every bucket on its own, so a bucket packed into the wrong slice cannot hide in the total
+        for lo, hi in ((b.enc_end, b.bb_end), (b.bb_end, gb.numel())):
+            r = (ga[lo:hi] - gb[lo:hi]).norm().item() / ga[lo:hi].norm().item()
+            assert r <= (5e-2 if graph else 5e-3), (lo, hi, r)
 
 
 def test_adamw_state_entry_follows_hyper_parameters_and_skip_mask(cuda):

@@ -283,6 +283,13 @@ class Uni3DETR(nn.Module):
         with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
             if self.with_pts_backbone:
                 x = self.pts_backbone(x)              # follows the dtype of its input rows: fp32 in 'mixed' mode (the encoder's dense())
+                self._backbone_out = self._backbone_cut = None
+                if getattr(self, "cut_backbone_backward", False) and torch.is_grad_enabled() and isinstance(x, (tuple, list)) \
+                        and all(t.requires_grad for t in x):
+                    # second cut point of TrainStep's phased backward (SECOND3D outputs): the neck + head backward ends at these leaves,
+                    # their gradient bucket is on the wire while the backbone's backward runs
+                    self._backbone_out = tuple(x)
+                    x = self._backbone_cut = tuple(t.detach().requires_grad_(True) for t in x)
             if self.with_pts_neck:
                 if getattr(self, "precision", None) == "mixed":
                     x = tuple(t.to(torch.bfloat16) for t in x) if isinstance(x, (tuple, list)) else x.to(torch.bfloat16)

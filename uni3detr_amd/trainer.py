@@ -6,8 +6,10 @@ step consists of (host enqueue time ≈ GPU time in eager mode):
         [eager] all-reduce of the per-layer positive counts (3 floats; skipped for world size 1)
     G2  losses + backward into ONE flat gradient buffer
         [eager] all-reduce of the flat gradient buffer over RCCL/xGMI (world size > 1)
-        (overlap_reduce=True: G2a = losses + backward of head / decoder / dense stack, asynchronous all-reduce of their slice,
-         G2b = the sparse encoder's backward underneath it, then the all-reduce of the encoder's small slice)
+        (overlap_reduce=True: the backward is cut at SECOND3D's outputs and at the sparse encoder's dense() output - THREE graphs and
+         three gradient buckets in reverse layer order: G2a = losses + head / decoder / FPN backward -> asynchronous
+         all-reduce of the neck + head slice; G2m = SECOND3D's backward underneath it -> asynchronous all-reduce of the backbone
+         slice; G2b = the sparse encoder's backward underneath both; then the all-reduce of the encoder's small slice)
     G3  gradient clipping + fused AdamW
 The sparse levels run in static-shape mode (capacity-sized tensors, device-side row counts; uni3detr_amd/sparse.py), so the
 captured launches are valid for any batch whose level sizes fit the capacities.  A batch that does NOT fit is handled on the device and
@@ -34,7 +36,7 @@ class FpsTimeout(RuntimeError):
 class TrainStep:
     def __init__(self, model, points, gt_bboxes_3d, gt_labels_3d, lr=1e-4, weight_decay=0.01, max_norm=10.0, graph=True,
                  capacity_margin=1.25, flat_update=True, overlap_reduce=False, betas=(0.9, 0.999), eps=1e-8, gt_capacity=64,
-                 check_every=50, pg_hooks=None, fps_graph=None, grad_comm_dtype=torch.float32):
+                 check_every=50, pg_hooks=None, fps_graph=None, grad_comm_dtype=torch.float32, reduce_buckets=None):
         """pg_hooks: (teardown, setup) callables that destroy / re-create the default process group; needed only for a collective
         re-capture after a capacity overflow on a multi-rank run (bench.py passes them)."""
         self.model = model
@@ -93,7 +95,19 @@ class TrainStep:
         model.cut_encoder_backward = self.overlap
         self.n_enc = n_enc
         self.enc_end = self.offsets[n_enc] if self.overlap else 0          # flat offset where phase A's slice starts
-        self._work = self._work_buf = None
+        # second cut (round 6): SECOND3D's parameters follow the encoder's in the flat buffer (module order of the detector); the phase
+        # between the two cuts is the backbone's backward, and the slice behind it (neck, head, decoder) leaves first
+        bb = getattr(model, "pts_backbone", None)
+        bb_ids = {id(p) for p in bb.parameters()} if bb is not None else set()
+        n_bb = sum(1 for p in self.params if id(p) in bb_ids)
+        mid = (self.overlap and n_bb > 0 and all(id(p) in bb_ids for p in self.params[n_enc:n_enc + n_bb]) and n_enc + n_bb < len(self.params)
+               and getattr(model, "pts_neck", None) is not None
+               and int(reduce_buckets if reduce_buckets is not None else os.environ.get("U3D_REDUCE_BUCKETS", "3")) >= 3)
+        self.three_phase = bool(mid)
+        model.cut_backbone_backward = self.three_phase
+        self.n_bb_end = n_enc + n_bb if self.three_phase else n_enc
+        self.bb_end = self.offsets[self.n_bb_end] if self.three_phase else self.enc_end
+        self._works = []                                                   # asynchronous bucket reductions in flight: (work, staging, lo, hi)
         self.comm_diag, self._comm_events = False, []
         if flat_update:
             # parameters re-homed into ONE flat buffer (each p.data becomes a view; names/shapes/state_dict unchanged), moments flat:
@@ -330,12 +344,37 @@ class TrainStep:
         self.model.pts_bbox_head._loss_total = None
         cut = self.model._encoder_cut                # detached leaf the dense stack / head were fed with (detector.extract_pts_feat)
         cut.grad = None
+        bcut = self.model._backbone_cut if self.three_phase else None
+        if bcut is not None:
+            for t in bcut:
+                t.grad = None
         with _T.deferred_param_grads():
             loss.backward()
         self.loss = loss.detach()
+        if bcut is not None:                         # the backward stopped at SECOND3D's outputs: phase M continues from their gradients
+            self._pack(self.n_bb_end, len(self.params))
+            self._gbb = [t.grad for t in bcut]
+            for t in bcut:
+                t.grad = None
+            return
         self._pack(self.n_enc, len(self.params))
         self._gx = cut.grad
         cut.grad = None
+
+    def _stage2m(self):
+        """Phase M (three-phase backward): SECOND3D's backward from the gradients of its three outputs down to the encoder cut."""
+        m = self.model
+        cut = m._encoder_cut
+        outs, gs = [], []
+        for o, g in zip(m._backbone_out, self._gbb):
+            if g is not None:
+                outs.append(o); gs.append(g)
+        torch.autograd.backward(outs, gs)
+        self._pack(self.n_enc, self.n_bb_end)
+        self._gx = cut.grad
+        cut.grad = None
+        self._gbb = None
+        m._backbone_out = m._backbone_cut = None
 
     def _stage2b(self):
         """Phase B: the sparse encoder's backward from the gradient of its output."""
@@ -365,42 +404,61 @@ class TrainStep:
             return w, None
         return w, buf
 
+    def _launch_bucket(self, lo, hi):
+        """Asynchronous mean over ranks of flat_grad[lo:hi]; collected by _reduce_grads_b()."""
+        if self.dist_on and hi > lo:
+            w, buf = self._all_reduce_slice(lo, hi, async_op=True)
+            self._works.append((w, buf, lo, hi))
+
     def _reduce_grads_a(self):
-        if self.dist_on:
-            n = self.flat_grad.numel()
-            self._work, self._work_buf = self._all_reduce_slice(self.enc_end, n, async_op=True)          # in flight underneath phase B
+        """First bucket on the wire: neck + head + decoder (three-phase) or everything behind the encoder (two-phase)."""
+        self._launch_bucket(self.bb_end if getattr(self, "three_phase", False) else self.enc_end, self.flat_grad.numel())
+
+    def _reduce_grads_m(self):
+        """Second bucket (three-phase): SECOND3D's slice, in flight underneath the encoder's backward."""
+        self._launch_bucket(self.enc_end, self.bb_end)
 
     def _reduce_grads_b(self):
         if self.dist_on:
-            # comm_diag: event pairs around the two waits of the compute stream - how much of bucket A's all-reduce is NOT hidden under
-            # the encoder's backward (the stream stalls in work.wait()) and what bucket B (never overlapped) costs; read by comm_exposed_ms()
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if getattr(self, "comm_diag", False) else None
-            if ev:
-                ev[0].record()
-            if self._work is not None:
-                self._work.wait()
-                if getattr(self, "_work_buf", None) is not None:
-                    self.flat_grad[self.enc_end:].copy_(self._work_buf)
-                self._work = self._work_buf = None
-            if ev:
-                ev[1].record()
+            # comm_diag: event pairs around the waits of the compute stream - how much of each asynchronous bucket is NOT hidden under
+            # the backward that follows it (the stream stalls in work.wait()) and what the encoder's bucket (never overlapped) costs;
+            # read by comm_exposed_ms()
+            diag = getattr(self, "comm_diag", False)
+            ev = []
+            if diag:
+                ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
+            for w, buf, lo, hi in self._works:
+                w.wait()
+                if buf is not None:
+                    self.flat_grad[lo:hi].copy_(buf)
+                if diag:
+                    ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
+            n_async = len(self._works)
+            del self._works[:]
             self._all_reduce_slice(0, self.enc_end)
-            if ev:
-                ev[2].record()
-                self._comm_events.append(ev)
+            if diag:
+                ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
+                self._comm_events.append((n_async, ev))
                 del self._comm_events[:-256]
 
     def comm_exposed_ms(self):
-        """Mean stall of the compute stream in the two gradient waits over the steps recorded since comm_diag was switched on:
-        dict(reduce_a_exposed_ms, reduce_b_exposed_ms, steps) - synchronises with the device."""
+        """Mean stall of the compute stream in the gradient waits over the steps recorded since comm_diag was switched on:
+        reduce_a_exposed_ms (first asynchronous bucket: neck + head, or everything behind the encoder in the two-phase plan),
+        reduce_m_exposed_ms (the backbone's bucket, three-phase only), reduce_b_exposed_ms (the encoder's bucket, never overlapped),
+        bucket sizes, steps - synchronises with the device."""
         if not self._comm_events:
             return None
         torch.cuda.synchronize()
-        a = [e[0].elapsed_time(e[1]) for e in self._comm_events]
-        b = [e[1].elapsed_time(e[2]) for e in self._comm_events]
-        return dict(reduce_a_exposed_ms=sum(a) / len(a), reduce_b_exposed_ms=sum(b) / len(b), steps=len(a),
-                    bucket_a_MB=(self.flat_grad.numel() - self.enc_end) * (4 if self.grad_comm_dtype == torch.float32 else 2) / 1e6,
-                    bucket_b_MB=self.enc_end * (4 if self.grad_comm_dtype == torch.float32 else 2) / 1e6)
+        three = bool(getattr(self, "three_phase", False))
+        rows = [[e[i].elapsed_time(e[i + 1]) for i in range(len(e) - 1)] for _, e in self._comm_events]
+        mean = lambda k: sum(r[k] for r in rows if len(r) > k) / max(1, sum(1 for r in rows if len(r) > k))      # noqa: E731
+        bpe = 4 if self.grad_comm_dtype == torch.float32 else 2
+        n = self.flat_grad.numel()
+        out = dict(reduce_a_exposed_ms=mean(0), reduce_b_exposed_ms=mean(2 if three else 1), steps=len(rows), buckets=3 if three else 2,
+                   bucket_a_MB=(n - (self.bb_end if three else self.enc_end)) * bpe / 1e6, bucket_b_MB=self.enc_end * bpe / 1e6)
+        if three:
+            out.update(reduce_m_exposed_ms=mean(1), bucket_m_MB=(self.bb_end - self.enc_end) * bpe / 1e6)
+        return out
 
     def _reduce_grads(self):
         if self.dist_on:
@@ -453,7 +511,10 @@ class TrainStep:
             self._stage1()
         self._reduce_num_pos()
         if self.overlap:
-            self._stage2a(); self._reduce_grads_a(); self._stage2b(); self._reduce_grads_b()
+            self._stage2a(); self._reduce_grads_a()
+            if self.three_phase:
+                self._stage2m(); self._reduce_grads_m()
+            self._stage2b(); self._reduce_grads_b()
         else:
             self._stage2(); self._reduce_grads()
         self._stage3()
@@ -590,6 +651,7 @@ class TrainStep:
         torch.cuda.synchronize()
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         g2b = torch.cuda.CUDAGraph() if self.overlap else None
+        g2m = torch.cuda.CUDAGraph() if (self.overlap and self.three_phase) else None
         pool = torch.cuda.graph_pool_handle()
         self._v = self._fps = self._feat = None
         if self.fps_graph and not getattr(self.model, "dynamic_voxelization", False):
@@ -618,6 +680,10 @@ class TrainStep:
             with torch.cuda.graph(g2, pool=pool, stream=s, capture_error_mode="thread_local"):
                 self._stage2a()
             self._reduce_grads_a()
+            if g2m is not None:
+                with torch.cuda.graph(g2m, pool=pool, stream=s, capture_error_mode="thread_local"):
+                    self._stage2m()
+                self._reduce_grads_m()
             with torch.cuda.graph(g2b, pool=pool, stream=s, capture_error_mode="thread_local"):
                 self._stage2b()
             self._reduce_grads_b()
@@ -629,6 +695,7 @@ class TrainStep:
             self._stage3()
         torch.cuda.synchronize()
         self._graphs = (g1, g2, g2b, g3)
+        self._g2m = g2m
         if isinstance(g1, tuple) and getattr(self, "fps_stream_calibration_ms", None) is None:
             # once per TrainStep: a re-capture keeps the stream the first capture chose (every rank then keeps ITS choice for the
             # whole job, and a re-capture costs no calibration replays)
@@ -664,8 +731,9 @@ class TrainStep:
             if self.pg_hooks is None:
                 raise RuntimeError("sparse level overflow on a multi-rank run and no pg_hooks=(teardown, setup) to re-capture with: "
                                    "capture with a larger capacity_margin or more representative `batches`")
-            if self._work is not None:
-                self._work.wait(); self._work = self._work_buf = None
+            for w, _buf, _lo, _hi in self._works:
+                w.wait()
+            del self._works[:]
             torch.cuda.synchronize()
             dist.barrier()
             self.pg_hooks[0]()
@@ -833,6 +901,9 @@ class TrainStep:
         g2.replay()
         if g2b is not None:
             self._reduce_grads_a()
+            if getattr(self, "_g2m", None) is not None:
+                self._g2m.replay()
+                self._reduce_grads_m()
             g2b.replay()
             self._reduce_grads_b()
         else:
