@@ -185,6 +185,12 @@ int32_t u3d_igemm_direct_split_bf16(const void* in, const void* w3, const int32_
 /* The weight side of the same product: dst bf16 [3][k][a][b] = (hi, lo, hi) of the f32 element src[ik * sk + ia * sa + ib * sb]
  * (element strides: the checkpoint layouts [kD,kH,kW,Cin,Cout] and [Cout,Cin,kD,kH,kW] are read in place). */
 int32_t u3d_split3_weights(const float* src, int64_t sk, int64_t sa, int64_t sb, int32_t k, int32_t a, int32_t b, void* dst, u3d_stream s);
+/* The same for every convolution weight of a step in ONE launch.  jobs: device array of njobs records of u3d_split3_job_bytes() bytes,
+ * natural C layout { const float* src; void* dst; int64_t sk, sa, sb; int32_t k, a, b, first_block; }, first_block = sum of
+ * u3d_split3_job_blocks(k, a, b) over the jobs before this one; total_blocks = that sum over all jobs. */
+int64_t u3d_split3_job_bytes(void);
+int32_t u3d_split3_job_blocks(int32_t k, int32_t a, int32_t b);
+int32_t u3d_split3_weights_batch(const void* jobs, int32_t njobs, int32_t total_blocks, u3d_stream s);
 /* dst bf16 [2 * n_cap][c]: rows [0, n) = bf16(x), rows [n_cap, n_cap + n) = bf16(x - hi), n = min(*n_dev, n_cap); c % 4 == 0. */
 int32_t u3d_split_rows_f32(const float* x, const int32_t* n_dev, int32_t n_cap, int32_t c, void* dst, u3d_stream s);
 /* Forward with n-major weights w[K][Cout][Cin] (the layout u3d_igemm_fwd_bf16 takes with transpose_w = 1) that also emits the
@@ -353,6 +359,17 @@ int32_t u3d_bn_bwd_stats(const void* dy, const void* y, const void* x, const flo
 int32_t u3d_bn_bwd_apply(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, const double* sums, int32_t relu, void* dx, void* dres,
                          const int32_t* n_dev, int32_t n_cap, int32_t c, int32_t dtype, const int32_t* row_map, u3d_stream s);
+/* The same two passes over F32 rows that ALSO leave their output as the hi / lo bf16 planes of a split-bf16 product (planes: bf16
+ * [2 * n_cap][C] in the output's row order, rows n .. n_cap of both planes zero - exactly what u3d_split_rows_f32 of the output would
+ * hold): the BatchNorm of the fp32 modules (ref: sparse_encoder_hd.py:62-64, second_3d.py:52-76 - kept in fp32 by the reference)
+ * hands its consumer convolution the planes without a further pass over the tensor; the backward hands the producer convolution the
+ * planes of dy.  U3D_ERR_UNSUPPORTED when C does not fit the vector kernels (C % 4, (C / 4) | 256): run the plain pass + the split. */
+int32_t u3d_bn_apply_planes(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                            const float* residual, int32_t relu, float* y, void* planes, const int32_t* n_dev, int32_t n_cap,
+                            int32_t c, const int32_t* row_map, const float* post_add, u3d_stream s);
+int32_t u3d_bn_bwd_apply_planes(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, const double* sums, int32_t relu, float* dx, float* dres,
+                                void* planes, const int32_t* n_dev, int32_t n_cap, int32_t c, const int32_t* row_map, u3d_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * SparseConvTensor.dense() (ref: sparse_encoder_hd.py:133): rows -> channels-last dense volume

@@ -1180,3 +1180,129 @@ def test_split_bf16_conv_forward_backward_match_f32_oracle(cuda, cin, cout, kvol
     np.testing.assert_allclose(s[0].numpy(), y.detach().double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4 * float(y.abs().max()) * n ** 0.5)
     np.testing.assert_allclose(s[1].numpy(), (y.detach().double() ** 2).sum(0).cpu().numpy(), rtol=1e-5)
     assert stats.shape[0] == (n + tr - 1) // tr
+
+
+@pytest.mark.parametrize("c,res,rowmap", [(16, False, False), (64, True, False), (256, False, True), (512, False, False), (128, False, False)])
+def test_bn_passes_write_the_planes_a_split_product_reads(cuda, c, res, rowmap):
+    """u3d_bn_apply_planes / u3d_bn_bwd_apply_planes (round 6): the BatchNorm apply pass of the fp32 modules also leaves its output as the
+    hi / lo bf16 planes of a split-bf16 product, the backward pass the planes of dx - bit for bit what u3d_split_rows_f32 of the same
+    tensor holds (padding rows of a capacity-sized tensor: zeros), and y / dx themselves unchanged."""
+    torch.manual_seed(c)
+    n_cap, n = 3000, 2777
+    x = (torch.randn(n_cap, c, device=cuda) * 2 + 0.5).contiguous()
+    x[n:] = float("nan")                                   # capacity padding holds garbage
+    r = torch.randn(n_cap, c, device=cuda) if res else None
+    gamma, beta = torch.rand(c, device=cuda) + 0.5, torch.randn(c, device=cuda) * 0.1
+    nd = torch.tensor([n], dtype=torch.int32, device=cuda)
+    mean, invstd = nv.bn_forward_stats(x, nd, 1e-3, 0.1)
+    rm = None
+    if rowmap:
+        perm = torch.randperm(n, device=cuda)
+        rm = torch.cat([perm, torch.arange(n, n_cap, device=cuda)]).int()
+    y0 = nv.bn_apply(x, mean, invstd, gamma, beta, r, True, nd, rm)
+    y1, pl = nv.bn_apply(x, mean, invstd, gamma, beta, r, True, nd, rm, want_planes=True)
+    assert pl is not None and pl.shape == (2 * n_cap, c) and pl.dtype == torch.bfloat16
+    live = rm[:n].long() if rowmap else torch.arange(n, device=cuda)
+    assert torch.equal(y0[live], y1[live])
+    y1c = y1.clone()
+    y1c[n:] = 0                                            # rows past the count: unwritten in y, zero in the planes
+    ref = nv.split_rows(y1c, nd)
+    assert torch.equal(pl, ref)
+    assert not bool(torch.isnan(pl.float()).any())
+    # backward
+    dy = torch.randn(n_cap, c, device=cuda)
+    sums = nv.bn_bwd_stats(dy, None if not res else y1, x, mean, invstd, True, nd, gamma, beta, rm)
+    dx0, dres0 = nv.bn_bwd_apply(dy, None if not res else y1, x, mean, invstd, gamma, sums, True, nd, res, beta, rm)
+    dx1, dres1, dpl = nv.bn_bwd_apply(dy, None if not res else y1, x, mean, invstd, gamma, sums, True, nd, res, beta, rm, want_planes=True)
+    assert dpl is not None and torch.equal(dx0[:n], dx1[:n]) and (not res or torch.equal(dres0[:n], dres1[:n]))
+    d = dx1.clone()
+    d[n:] = 0
+    assert torch.equal(dpl, nv.split_rows(d, nd))
+
+
+def test_split_convs_pick_up_the_planes_their_batchnorm_wrote(cuda):
+    """A conv -> BN -> ReLU -> conv -> BN chain inside split_scope: with sparse.BN_PLANES the second convolution's input planes and the first
+    convolution's output-gradient planes come from the BatchNorm passes - same bits as with separate u3d_split_rows_f32 launches, and
+    the separate launches are gone (counted through native.split_rows)."""
+    import torch.nn as nn
+    from uni3detr_amd import sparse as sp
+    from uni3detr_amd.plugin import dense as D
+    torch.manual_seed(3)
+    B, dims, C = 2, (3, 12, 12), 64
+    convs = [nn.Conv3d(C, C, (1, 3, 3), padding=(0, 1, 1), bias=False).to(cuda) for _ in range(2)]
+    bns = [nn.BatchNorm3d(C, eps=1e-3, momentum=0.01).to(cuda).train() for _ in range(2)]
+    x0 = torch.randn(B, C, *dims, device=cuda).clamp_min(0).contiguous(memory_format=torch.channels_last_3d)
+    res, calls = {}, {}
+    orig = nv.split_rows
+    for on in (True, False):
+        sp.BN_PLANES = on
+        cnt = [0]
+
+        def counting(*a, **k):
+            cnt[0] += 1
+            return orig(*a, **k)
+        nv.split_rows = counting
+        try:
+            x = x0.clone().requires_grad_(True)
+            for m in convs + bns:
+                m.zero_grad(set_to_none=True)
+            with sp.split_scope(True):
+                rows, Bb, dd = D.to_rows(x)
+                for cv, bn in zip(convs, bns):
+                    rows, dd = D.conv_bn_relu(rows, Bb, dd, cv, bn)
+                y = D.to_volume(rows, Bb, dd)
+            (y * y).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            nv.split_rows = orig
+            sp.BN_PLANES = True
+        res[on] = (y.detach().clone(), x.grad.clone(), [c.weight.grad.clone() for c in convs])
+        calls[on] = cnt[0]
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert all(torch.equal(a, b) for a, b in zip(res[True][2], res[False][2]))
+    # separate passes: 2 inputs + 2 output gradients; with the planes from the BatchNorm passes only the very first input is split on its own
+    assert calls[False] == 4 and calls[True] == 1, calls
+
+
+def test_weight_splits_of_a_step_in_one_launch(cuda):
+    """native.Split3Set (u3d_split3_weights_batch): the (hi, lo, hi) bf16 planes of every convolution weight a split scope asks for are
+    refreshed by ONE launch at the top of the next scope - bit-identical to the per-request launches, recomputed after the parameters
+    change (in-place torch update: version check; raw-pointer update + refresh: TrainStep's flat AdamW), entries of dead parameters pruned."""
+    import gc
+    import torch.nn as nn
+    from uni3detr_amd import sparse as sp
+    torch.manual_seed(5)
+    ws = [nn.Parameter(torch.randn(3, 3, 3, 16, 32, device=cuda)), nn.Parameter(torch.randn(64, 128, 1, 3, 3, device=cuda)),
+          nn.Parameter(torch.randn(1, 1, 1, 128, 256, device=cuda))]
+    lay = ["dhwio", "oidhw", "dhwio"]
+    ref = lambda w, l, nm: (nv.SPLIT3_BATCH, setattr(nv, "SPLIT3_BATCH", False), nv.split3_weights(w, l, nm), setattr(nv, "SPLIT3_BATCH", True))[2]      # noqa: E731
+    own = nv.Split3Set()
+    with sp.split_scope(True, own):                                    # first scope: per-request launches, the set fills up
+        first = [(nv.split3_weights(w, l, True), nv.split3_weights(w, l, False)) for w, l in zip(ws, lay)]
+    assert len(own.entries) == 6 and not own.fresh
+    calls = [0]
+    orig = nv.lib().u3d_split3_weights
+    with sp.split_scope(True, own):                                    # second scope: one batched launch, every request served from it
+        assert own.fresh and own.njobs == 6
+        got = [(nv.split3_weights(w, l, True), nv.split3_weights(w, l, False)) for w, l in zip(ws, lay)]
+        for (a, b), (fa, fb) in zip(got, first):
+            assert a.data_ptr() == fa.data_ptr() and b.data_ptr() == fb.data_ptr()          # the cached buffers
+    for (a, b), w, l in zip(got, ws, lay):
+        assert torch.equal(a, ref(w, l, True)) and torch.equal(b, ref(w, l, False))
+    # parameters change: (1) in-place torch update inside a scope -> the version check refuses the cached planes
+    with sp.split_scope(True, own):
+        with torch.no_grad():
+            ws[0].mul_(1.5)
+        a = nv.split3_weights(ws[0], lay[0], True)
+        assert torch.equal(a, ref(ws[0], lay[0], True))
+    # (2) a raw update (no version bump) followed by the next scope's refresh
+    with torch.no_grad():
+        ws[1].data.view(-1)[:1000] += 1.0
+    with sp.split_scope(True, own):
+        assert torch.equal(nv.split3_weights(ws[1], lay[1], False), ref(ws[1], lay[1], False))
+    # (3) a parameter dies: its jobs leave the table at the next refresh (nothing reads freed memory)
+    del ws[2], got, first, a, w, l
+    gc.collect()
+    with sp.split_scope(True, own):
+        assert len(own.entries) == 4 and own.njobs == 4
+    torch.cuda.synchronize()

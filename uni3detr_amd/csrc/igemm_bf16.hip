@@ -1471,6 +1471,41 @@ extern "C" int32_t u3d_split3_weights(const float* src, int64_t sk, int64_t sa, 
   return U3D_OK;
 }
 
+// All weight splits of a step in ONE launch (a `parity` step made 88 launches of k_split3_weights, ~6.6 us each whatever the size):
+// jobs[j] describes one (parameter, layout) pair, blocks [first_block[j], first_block[j + 1]) of the grid work on it.
+struct U3dSplit3Job { const float* src; u16* dst; long long sk, sa, sb; int K, A, B, first_block; };
+#define SPLIT3_EPB 2048          /* elements per block */
+__global__ __launch_bounds__(256) void k_split3_weights_batch(const U3dSplit3Job* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs;                               // the job this block belongs to: last j with first_block[j] <= blockIdx.x
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const U3dSplit3Job jb = jobs[lo];
+  const long long n = (long long)jb.K * jb.A * jb.B;
+  const long long i0 = (long long)((int)blockIdx.x - jb.first_block) * SPLIT3_EPB;
+  for (long long i = i0 + threadIdx.x; i < i0 + SPLIT3_EPB && i < n; i += 256) {
+    const int b = (int)(i % jb.B), a = (int)((i / jb.B) % jb.A), k = (int)(i / ((long long)jb.A * jb.B));
+    const float v = jb.src[k * jb.sk + a * jb.sa + b * jb.sb];
+    const u16 h = f2bf(v);
+    const u16 l = f2bf(v - __uint_as_float((unsigned)h << 16));
+    jb.dst[i] = h; jb.dst[n + i] = l; jb.dst[2 * n + i] = h;
+  }
+}
+extern "C" int64_t u3d_split3_job_bytes(void) { return (int64_t)sizeof(U3dSplit3Job); }
+extern "C" int32_t u3d_split3_job_blocks(int32_t k, int32_t a, int32_t b) {
+  const long long n = (long long)k * a * b;
+  return (int32_t)((n + SPLIT3_EPB - 1) / SPLIT3_EPB);
+}
+// jobs: DEVICE array of njobs records {src, dst, sk, sa, sb (element strides, int64), K, A, B, first_block (int32)} of u3d_split3_job_bytes()
+// bytes each (natural C layout), first_block ascending from 0; total_blocks = sum of u3d_split3_job_blocks over the jobs
+extern "C" int32_t u3d_split3_weights_batch(const void* jobs, int32_t njobs, int32_t total_blocks, u3d_stream s) {
+  U3D_REQUIRE(jobs && njobs > 0 && total_blocks > 0, U3D_ERR_ARG);
+  hipLaunchKernelGGL(k_split3_weights_batch, dim3(total_blocks), dim3(256), 0, s, (const U3dSplit3Job*)jobs, njobs);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
 // returns U3D_ERR_UNSUPPORTED when the shape is better served by the first-generation kernel
 
 // =============================================================================================

@@ -629,13 +629,27 @@ __device__ __forceinline__ void store_vec<u16>(u16* p, const float* v) {
   *(bf16x8_t*)p = __builtin_convertvector(f, bf16x8_t);        // 4 x v_cvt_pk_bf16_f32 (round to nearest even), one 16-byte store
 }
 
-template <typename T>
+// hi / lo bf16 planes of four f32 values (u3d_split_rows_f32's arithmetic): p[0..3] = bf16(v), p[plane + 0..3] = bf16(v - hi)
+__device__ __forceinline__ void store_planes4(u16* p, long long plane, const float* v) {
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  const f32x4_t f = {v[0], v[1], v[2], v[3]};
+  const bf16x4_t h = __builtin_convertvector(f, bf16x4_t);
+  const bf16x4_t l = __builtin_convertvector(f - __builtin_convertvector(h, f32x4_t), bf16x4_t);
+  *(bf16x4_t*)p = h;
+  *(bf16x4_t*)(p + plane) = l;
+}
+// PLANES (f32 rows only, u3d_bn_apply_planes / u3d_bn_bwd_apply_planes): the kernel ALSO leaves its output as the two bf16 planes a
+// split-bf16 convolution reads ([2 * n_cap][c]: hi | lo, padding rows n .. n_cap zero) - the separate u3d_split_rows_f32 pass over the
+// tensor (one more read + write of every element, 186 launches per `parity` step) disappears for every tensor a BatchNorm produces
+template <typename T, bool PLANES = false>
 __global__ __launch_bounds__(256) void k_bn_apply_vec(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const T* __restrict__ res, int relu, T* __restrict__ y,
                                                       const int* __restrict__ n_dev, int n_cap, int c, const int* __restrict__ row_map,
-                                                      const T* __restrict__ post_add) {
+                                                      const T* __restrict__ post_add, u16* __restrict__ planes = nullptr) {
   constexpr int V = VecOf<T>::N;
+  static_assert(!PLANES || V == 4, "planes are an f32 feature");
   const int n = min(*n_dev, n_cap), cv = c / V, rpb = 256 / cv;
   const int vc = threadIdx.x % cv, rl = threadIdx.x / cv;
   float mu[V], is[V], ga[V], be[V];
@@ -660,17 +674,24 @@ __global__ __launch_bounds__(256) void k_bn_apply_vec(const T* __restrict__ x, c
       for (int e = 0; e < V; ++e) out[e] += pv[e];
     }
     store_vec<T>(y + oy, out);
+    if constexpr (PLANES) store_planes4(planes + oy, (long long)n_cap * c, out);
+  }
+  if constexpr (PLANES) {                             // capacity padding: zero rows of both planes (never a stale NaN pattern)
+    const float z[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = n + blockIdx.x * rpb + rl; r < n_cap; r += gridDim.x * rpb)
+      store_planes4(planes + (long long)r * c + (long long)vc * V, (long long)n_cap * c, z);
   }
 }
 
-template <typename T>
+template <typename T, bool PLANES = false>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply_vec(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const double* __restrict__ sums, int relu, T* __restrict__ dx,
                                                           T* __restrict__ dres, const int* __restrict__ n_dev, int n_cap, int c,
-                                                          const int* __restrict__ row_map) {
+                                                          const int* __restrict__ row_map, u16* __restrict__ planes = nullptr) {
   constexpr int V = VecOf<T>::N;
+  static_assert(!PLANES || V == 4, "planes are an f32 feature");
   const int n = min(*n_dev, n_cap), cv = c / V, rpb = 256 / cv;
   const int vc = threadIdx.x % cv, rl = threadIdx.x / cv;
   const float inv_n = n > 0 ? 1.f / (float)n : 0.f;               // f32: a per-thread f64 divide + 16 f64 multiplies cost as much as the stream
@@ -702,7 +723,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_vec(const T* __restrict__ 
       gv[e] = g;
     }
     store_vec<T>(dx + o, dxv);
+    if constexpr (PLANES) store_planes4(planes + o, (long long)n_cap * c, dxv);      // the planes of dx: what the conv in front reads as dy
     if (dres) store_vec<T>(dres + o, gv);
+  }
+  if constexpr (PLANES) {
+    const float z[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = n + blockIdx.x * rpb + rl; r < n_cap; r += gridDim.x * rpb)
+      store_planes4(planes + (long long)r * c + (long long)vc * V, (long long)n_cap * c, z);
   }
 }
 
@@ -759,6 +786,31 @@ extern "C" int32_t u3d_bn_bwd_apply(const void* dy, const void* y, const void* x
   else if (dtype == U3D_BF16)
     hipLaunchKernelGGL(k_bn_bwd_apply<u16>, dim3(g), dim3(256), 0, s, (const u16*)dy, (const u16*)y, (const u16*)x, mean, invstd, gamma, beta, sums, relu, (u16*)dx, (u16*)dres, n_dev, n_cap, c);
   else return U3D_ERR_UNSUPPORTED;
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+
+// f32 rows only: y (dx) AND its hi / lo bf16 planes [2 * n_cap][c] in one pass (see k_bn_apply_vec<., PLANES>).  U3D_ERR_UNSUPPORTED for
+// shapes the vector kernels do not take (the caller then runs u3d_bn_apply + u3d_split_rows_f32).
+extern "C" int32_t u3d_bn_apply_planes(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                       const float* residual, int32_t relu, float* y, void* planes, const int32_t* n_dev, int32_t n_cap,
+                                       int32_t c, const int32_t* row_map, const float* post_add, u3d_stream s) {
+  U3D_REQUIRE(x && mean && invstd && gamma && beta && y && planes && n_dev && c > 0, U3D_ERR_ARG);
+  if (!bn_vec_ok(c, 4) || !(al16(mean) && al16(invstd) && al16(gamma) && al16(beta)) || (row_map && residual)) return U3D_ERR_UNSUPPORTED;
+  if (n_cap <= 0) return U3D_OK;
+  hipLaunchKernelGGL((k_bn_apply_vec<float, true>), dim3(bn_vec_grid(n_cap, c, 4)), dim3(256), 0, s, x, mean, invstd, gamma, beta, residual, relu, y,
+                     n_dev, n_cap, c, row_map, post_add, (u16*)planes);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+extern "C" int32_t u3d_bn_bwd_apply_planes(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                                           const float* gamma, const float* beta, const double* sums, int32_t relu, float* dx, float* dres,
+                                           void* planes, const int32_t* n_dev, int32_t n_cap, int32_t c, const int32_t* row_map, u3d_stream s) {
+  U3D_REQUIRE(dy && x && mean && invstd && gamma && sums && dx && planes && n_dev && c > 0 && (!relu || y || beta), U3D_ERR_ARG);
+  if (!bn_vec_ok(c, 4) || !(al16(mean) && al16(invstd) && al16(gamma) && al16(beta) && al16(sums)) || (row_map && dres)) return U3D_ERR_UNSUPPORTED;
+  if (n_cap <= 0) return U3D_OK;
+  hipLaunchKernelGGL((k_bn_bwd_apply_vec<float, true>), dim3(bn_vec_grid(n_cap, c, 4)), dim3(256), 0, s, dy, y, x, mean, invstd, gamma, beta, sums, relu,
+                     dx, dres, n_dev, n_cap, c, row_map, (u16*)planes);
   U3D_CHECK_LAUNCH();
   return U3D_OK;
 }

@@ -109,6 +109,9 @@ _SIGS = {
     "u3d_igemm_fwd_split_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "u3d_split_rows_f32": (_I, [_P, _P, _I, _I, _P, _P]),
     "u3d_split3_weights": (_I, [_P, C.c_int64, C.c_int64, C.c_int64, _I, _I, _I, _P, _P]),
+    "u3d_split3_job_bytes": (C.c_int64, []),
+    "u3d_split3_job_blocks": (_I, [_I, _I, _I]),
+    "u3d_split3_weights_batch": (_I, [_P, _I, _I, _P]),
     "u3d_igemm_direct_split_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "u3d_igemm_dgrad_bnstats_bf16": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "u3d_bn_bwd_finalize_partials": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P]),
@@ -125,6 +128,8 @@ _SIGS = {
     "u3d_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     "u3d_bn_bwd_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P]),
     "u3d_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "u3d_bn_apply_planes": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "u3d_bn_bwd_apply_planes": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
     "u3d_to_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     "u3d_from_dense": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     "u3d_fps": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _L, _I, _P]),
@@ -727,11 +732,8 @@ def spconv_fwd_split_direct(xs, w3, nbr, n_out_dev, n_out, cout, tag="spconv_fwd
     return out
 
 
-def split3_weights(weight, layout, nmajor):
-    """Conv PARAMETER (f32, checkpoint layout "dhwio" [kD,kH,kW,Cin,Cout] or "oidhw" [Cout,Cin,kD,kH,kW]) -> bf16 [3K, A, B] = (hi, lo, hi)
-    of its [K, Cout, Cin] (nmajor) or [K, Cin, Cout] view, read in place through element strides (u3d_split3_weights)."""
-    w = weight.detach()
-    assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 5
+def _split3_geometry(w, layout, nmajor):
+    """(k, a, b, sk, sa, sb): the [K, A, B] view of a conv parameter in its checkpoint layout, as element strides."""
     if layout == "dhwio":
         kd, kh, kw, cin, cout = w.shape
         k = kd * kh * kw
@@ -741,8 +743,110 @@ def split3_weights(weight, layout, nmajor):
         k = kd * kh * kw
         sk, s_ci, s_co = 1, k, cin * k
     a, b, sa, sb = (cout, cin, s_co, s_ci) if nmajor else (cin, cout, s_ci, s_co)
+    return k, a, b, sk, sa, sb
+
+
+class Split3Set:
+    """Every (conv parameter, layout, n-major?) triple a step asks for, refreshed by ONE launch at the top of the step
+    (u3d_split3_weights_batch).  A request the set has not seen yet is served by its own launch and joins the set; entries whose
+    parameter died or moved (TrainStep re-homes parameters into its flat buffer) are dropped / re-described at the next refresh."""
+
+    class _Job(C.Structure):
+        _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("sk", C.c_int64), ("sa", C.c_int64), ("sb", C.c_int64),
+                    ("K", C.c_int32), ("A", C.c_int32), ("B", C.c_int32), ("first_block", C.c_int32)]
+
+    def __init__(self):
+        self.entries = {}            # (data_ptr, nmajor) -> [weakref, layout, nmajor, dst, data_ptr, in the job table?, version, shape]
+        self.jobs_dev = None
+        self._keep = []              # every job table ever uploaded: a captured graph may still read an older one
+        self.total_blocks = 0
+        self.dirty = True
+        self.fresh = False           # the dst tensors hold the split of the CURRENT parameter values
+
+    def get(self, weight, layout, nmajor):
+        """Keyed by the parameter's MEMORY (the backward sees the saved tensor, not necessarily the Parameter object)."""
+        e = self.entries.get((weight.data_ptr(), bool(nmajor)))
+        if e is not None and e[0]() is not None and e[1] == layout and e[7] == tuple(weight.shape):
+            # served only when THIS step's refresh computed it from the parameter's current values (in-place torch updates bump the
+            # version; TrainStep's flat AdamW does not, but every step of it starts with a refresh)
+            if self.fresh and e[5] and e[6] == weight._version:
+                return e[3]
+        return None
+
+    def add(self, weight, layout, nmajor, dst):
+        import weakref
+        key = (weight.data_ptr(), bool(nmajor))
+        old = self.entries.get(key)
+        if old is not None and old[0]() is not None and old[1] == layout and old[7] == tuple(weight.shape) and old[5]:
+            return                    # already in the job table (asked for before this step's refresh could serve it)
+        self.entries[key] = [weakref.ref(weight), layout, bool(nmajor), dst, weight.data_ptr(), False, -1, tuple(weight.shape)]
+        self.dirty = True
+
+    def refresh(self):
+        """One launch over every live entry (called at the top of a step's forward, inside the captured graph too - the job table is
+        rebuilt on the host only OUTSIDE a capture; a table that went stale during one falls back to per-request launches)."""
+        dead = [k for k, e in self.entries.items() if e[0]() is None]
+        for k in dead:
+            del self.entries[k]
+            self.dirty = True
+        moved = [k for k, e in self.entries.items() if e[0]().data_ptr() != e[4]]      # re-homed parameters (TrainStep's flat buffer): asked for again
+        for k in moved:
+            del self.entries[k]
+            self.dirty = True
+        if not self.entries:
+            self.fresh = False
+            return
+        if self.dirty:
+            if torch.cuda.is_current_stream_capturing():
+                self.fresh = False
+                return
+            assert int(lib().u3d_split3_job_bytes()) == C.sizeof(Split3Set._Job)
+            jobs = (Split3Set._Job * len(self.entries))()
+            fb = 0
+            for j, e in enumerate(self.entries.values()):
+                w = e[0]().detach()
+                k, a, b, sk, sa, sb = _split3_geometry(w, e[1], e[2])
+                jobs[j].src, jobs[j].dst = w.data_ptr(), e[3].data_ptr()
+                jobs[j].sk, jobs[j].sa, jobs[j].sb = sk, sa, sb
+                jobs[j].K, jobs[j].A, jobs[j].B, jobs[j].first_block = k, a, b, fb
+                fb += int(lib().u3d_split3_job_blocks(k, a, b))
+                e[5] = True
+            raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
+            dev = next(iter(self.entries.values()))[3].device
+            self.jobs_dev = raw.to(dev)
+            self._keep.append(self.jobs_dev)
+            self.total_blocks, self.njobs, self.dirty = fb, len(self.entries), False
+        _check(lib().u3d_split3_weights_batch(_ptr(self.jobs_dev), self.njobs, self.total_blocks, _stream()), "split3_weights_batch")
+        for e in self.entries.values():
+            e[6] = e[0]()._version
+        self.fresh = True
+
+
+SPLIT3_DEFAULT = Split3Set()   # scopes without an owner (ad-hoc calls, tests); a detector brings its own set (detector.stage_features)
+SPLIT3_ACTIVE = None           # the set of the split scope being executed (sparse.split_scope), None outside
+SPLIT3_BATCH = True            # test-only module attribute: False = one u3d_split3_weights launch per request (the A/B formulation)
+
+
+def split3_weights(weight, layout, nmajor, cache=None):
+    """Conv PARAMETER (f32, checkpoint layout "dhwio" [kD,kH,kW,Cin,Cout] or "oidhw" [Cout,Cin,kD,kH,kW]) -> bf16 [3K, A, B] = (hi, lo, hi)
+    of its [K, Cout, Cin] (nmajor) or [K, Cin, Cout] view, read in place through element strides (u3d_split3_weights) - or, when the
+    step's batched refresh (Split3Set) already produced it, the cached tensor."""
+    cache = cache if cache is not None else SPLIT3_ACTIVE
+    if not (SPLIT3_BATCH and weight.is_cuda):
+        cache = None
+    if cache is not None:
+        hit = cache.get(weight, layout, nmajor)
+        if hit is not None:
+            return hit
+    w = weight.detach()
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 5
+    k, a, b, sk, sa, sb = _split3_geometry(w, layout, nmajor)
     out = torch.empty((3 * k, a, b), dtype=torch.bfloat16, device=w.device)
     _check(lib().u3d_split3_weights(_ptr(w), sk, sa, sb, k, a, b, _ptr(out), _stream()), "split3_weights")
+    # only PARAMETERS join the set: a temporary (the FPN's transposed-conv weights reach here as a re-laid-out copy made each step) has
+    # new memory every time - its entry would be pruned and re-added at every refresh and keep the job table dirty for ever
+    if cache is not None and isinstance(weight, torch.nn.Parameter) and not torch.cuda.is_current_stream_capturing():
+        cache.add(weight, layout, nmajor, out)
     return out
 
 
@@ -874,10 +978,26 @@ def bn_forward_stats(x, n_dev, eps, momentum, running_mean=None, running_var=Non
     return mean, invstd
 
 
-def bn_apply(x, mean, invstd, gamma, beta, residual, relu, n_dev, row_map=None, post_add=None):
-    """row_map (int32 [n], a bijection): row r of x lands in row row_map[r] of y (see include/u3d_hip.h)."""
+def bn_apply(x, mean, invstd, gamma, beta, residual, relu, n_dev, row_map=None, post_add=None, want_planes=False):
+    """row_map (int32 [n], a bijection): row r of x lands in row row_map[r] of y (see include/u3d_hip.h).
+    want_planes (f32 rows): -> (y, planes) with planes bf16 [2 * n, c] = split_rows(y) written by the same pass (u3d_bn_apply_planes), or
+    (y, None) for a shape the fused pass does not take."""
     n, c = x.shape
     y = torch.empty_like(x)
+    if want_planes:
+        planes = None
+        if x.dtype == torch.float32 and x.is_cuda:
+            planes = torch.empty((2 * n, c), dtype=torch.bfloat16, device=x.device)
+            rc = lib().u3d_bn_apply_planes(_ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(residual), int(relu), _ptr(y),
+                                           _ptr(planes), _ptr(n_dev), n, c, _ptr(row_map), _ptr(post_add), _stream())
+            if rc == 0:
+                return y, planes
+            if rc != -2:
+                _check(rc, "bn_apply_planes")
+            planes = None
+        _check(lib().u3d_bn_apply(_ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(residual), int(relu),
+                                  _ptr(y), _ptr(n_dev), n, c, dtype_code(x), _ptr(row_map), _ptr(post_add), _stream()), "bn_apply")
+        return y, None
     _check(lib().u3d_bn_apply(_ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(residual), int(relu),
                               _ptr(y), _ptr(n_dev), n, c, dtype_code(x), _ptr(row_map), _ptr(post_add), _stream()), "bn_apply")
     return y
@@ -895,10 +1015,23 @@ def bn_bwd_stats(dy, y, x, mean, invstd, relu, n_dev, gamma=None, beta=None, row
     return (sums, s32) if want_f32 else sums
 
 
-def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, relu, n_dev, want_dres, beta=None, row_map=None):
+def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, relu, n_dev, want_dres, beta=None, row_map=None, want_planes=False):
+    """want_planes (f32 rows): -> (dx, dres, planes of dx or None) - u3d_bn_bwd_apply_planes."""
     n, c = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
+    if want_planes:
+        if x.dtype == torch.float32 and x.is_cuda:
+            planes = torch.empty((2 * n, c), dtype=torch.bfloat16, device=x.device)
+            rc = lib().u3d_bn_bwd_apply_planes(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(sums), int(relu),
+                                               _ptr(dx), _ptr(dres), _ptr(planes), _ptr(n_dev), n, c, _ptr(row_map), _stream())
+            if rc == 0:
+                return dx, dres, planes
+            if rc != -2:
+                _check(rc, "bn_bwd_apply_planes")
+        _check(lib().u3d_bn_bwd_apply(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(sums), int(relu),
+                                      _ptr(dx), _ptr(dres), _ptr(n_dev), n, c, dtype_code(x), _ptr(row_map), _stream()), "bn_bwd_apply")
+        return dx, dres, None
     _check(lib().u3d_bn_bwd_apply(_ptr(dy), _ptr(y), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(sums), int(relu),
                                   _ptr(dx), _ptr(dres), _ptr(n_dev), n, c, dtype_code(x), _ptr(row_map), _stream()), "bn_bwd_apply")
     return dx, dres

@@ -269,7 +269,11 @@ class Uni3DETR(nn.Module):
     def stage_features(self, v):
         from .. import sparse as sp
         # 'mixed': the fp32 modules' wide convs as split-bf16 products (sparse.split_scope) - f32 rows in and out, bf16 matrix pipe
-        with sp.split_scope(getattr(self, "precision", None) in ("mixed", "parity")):
+        on = getattr(self, "precision", None) in ("mixed", "parity")
+        if on and getattr(self, "_split3", None) is None:
+            from .. import native as nv
+            self._split3 = nv.Split3Set()        # this model's weight planes + job table: one refresh launch per step (native.Split3Set)
+        with sp.split_scope(on, getattr(self, "_split3", None)):
             return self._stage_features(v)
 
     def _stage_features(self, v):

@@ -154,6 +154,7 @@ _CONV_USES = {}          # id(conv weight) -> forward uses since reset_conv_uses
 
 def reset_conv_uses():
     _CONV_USES.clear()
+    _PLANES_BWD.clear()       # (gradient planes nobody picked up in the previous step: the 4 -> 16 input conv runs on the exact f32 kernel)
 
 
 # ---- split-bf16 convolutions: f32-grade products on the bf16 matrix pipe (csrc/igemm_bf16.hip, u3d_igemm_fwd_split_bf16) -------------
@@ -173,6 +174,8 @@ _SPLIT = [False]
 # outlives the forward that made it.  (Writing the planes from the BatchNorm apply that produces the rows - one pass less per layer -
 # was built and measured time-neutral, 216.0 vs 217.2 scenes/s: the extra 4 B / element of stores cost what the saved read gains.)
 _PLANES = {}
+_PLANES_BWD = {}          # planes of a gradient tensor produced together with it (u3d_bn_bwd_apply_planes); popped by their one consumer
+BN_PLANES = True          # test-only module attribute: False = every tensor is split by its own u3d_split_rows_f32 pass (the A/B formulation)
 
 
 def _planes_of(feats, n_dev):
@@ -180,20 +183,51 @@ def _planes_of(feats, n_dev):
     if ent is not None and ent[0] is feats and ent[2] == feats._version:
         return ent[1]
     xs = nv.split_rows(feats.contiguous(), n_dev)
-    if feats.is_contiguous():
+    if _SPLIT[0]:
         _PLANES[id(feats)] = (feats, xs, feats._version)
     return xs
 
 
+def _give_planes(t, planes):
+    """The BatchNorm apply pass wrote `planes` = split_rows(t) along with t: the convolution that consumes t finds them here."""
+    if planes is not None and _SPLIT[0]:
+        _PLANES[id(t)] = (t, planes, t._version)
+
+
+def _give_bwd_planes(t, planes):
+    if planes is not None:
+        _PLANES_BWD[t.data_ptr()] = (t, planes, t._version)
+
+
+def _bwd_planes_of(dout, n_dev):
+    """bf16 planes of a convolution's output gradient: handed over by the BatchNorm backward that produced it (same storage, same
+    version: the entry keeps the tensor alive, so the address cannot have been recycled), else split here."""
+    ent = _PLANES_BWD.pop(dout.data_ptr(), None)
+    if (ent is not None and ent[0].numel() == dout.numel() and ent[0].dtype == dout.dtype and ent[2] == ent[0]._version
+            and dout.dim() == 2 and dout.is_contiguous() and ent[0].is_contiguous()):
+        # (a reshaped view of the same rows - the FPN's transposed convolutions see [n, taps * C] where their BatchNorm saw
+        #  [n * taps, C] - has the same planes: both are the tensor's elements in memory order, hi plane then lo plane)
+        return ent[1].view(2 * dout.shape[0], dout.shape[1])
+    return nv.split_rows(dout.float() if dout.dtype != torch.float32 else dout, n_dev)
+
+
 @contextlib.contextmanager
-def split_scope(on=True):
-    prev = _SPLIT[0]
+def split_scope(on=True, split3=None):
+    """split3: the native.Split3Set that owns the weight planes of the convolutions run inside (a detector passes its own: the job
+    table and plane buffers a captured graph reads then live as long as the model); None: the module-wide default set."""
+    prev, prev3 = _SPLIT[0], nv.SPLIT3_ACTIVE
     _SPLIT[0] = bool(on) and SPLIT_BF16
     _PLANES.clear()
+    _PLANES_BWD.clear()
+    if _SPLIT[0]:
+        nv.SPLIT3_ACTIVE = split3 if split3 is not None else nv.SPLIT3_DEFAULT
+        if nv.SPLIT3_BATCH:
+            nv.SPLIT3_ACTIVE.refresh()          # every weight split of the step in one launch (the sets fill up during the first step)
     try:
         yield
     finally:
         _SPLIT[0] = prev
+        nv.SPLIT3_ACTIVE = prev3
         _PLANES.clear()
 
 
@@ -266,6 +300,7 @@ class _SparseConv(torch.autograd.Function):
             xs = _planes_of(feats, geom.n_in_dev)                                        # bf16 [2 * n_in, cin]: hi | lo planes
             ctx.save_for_backward(xs, weight)                                            # the weight gradient reads the planes
             ctx.halo = False
+            ctx.split3 = nv.SPLIT3_ACTIVE                                                # the backward runs outside the scope: same set
             w3 = nv.split3_weights(weight, layout, nmajor=True)                          # [3K, cout, cin], straight from the parameter
             if split == "narrow":
                 y = nv.spconv_fwd_split_direct(xs, w3, geom.nbr_fwd, geom.n_out_dev, geom.n_out, cout)
@@ -407,7 +442,7 @@ def _split_backward_impl(ctx, xs, wc, dout):
     ks = ctx.kio_shape
     kvol, cin, cout = ks[0] * ks[1] * ks[2], ks[3], ks[4]
     n_in, n_out = xs.shape[0] // 2, dout.shape[0]
-    dys = nv.split_rows(dout.float() if dout.dtype != torch.float32 else dout, g.n_out_dev)      # bf16 [2 * n_out, cout]
+    dys = _bwd_planes_of(dout, g.n_out_dev)                                              # bf16 [2 * n_out, cout]
     din = dw = None
     if ctx.split == "narrow":
         if ctx.needs_input_grad[1]:
@@ -417,7 +452,7 @@ def _split_backward_impl(ctx, xs, wc, dout):
             dwk = (dwk + nv.spconv_wgrad(xh, dyl, g.nbr_fwd, g.n_out_dev, kvol)).reshape(ctx.kio_shape).to(ctx.wdtype)
             dw = dwk.permute(4, 3, 0, 1, 2) if ctx.layout == "oidhw" else dwk
         if ctx.needs_input_grad[0]:
-            din = nv.spconv_fwd_split_direct(dys, nv.split3_weights(wc, ctx.layout, nmajor=False), g.nbr_bwd, g.n_in_dev, g.n_in, cin,
+            din = nv.spconv_fwd_split_direct(dys, nv.split3_weights(wc, ctx.layout, nmajor=False, cache=getattr(ctx, "split3", None)), g.nbr_bwd, g.n_in_dev, g.n_in, cin,
                                              tag="spconv_dgrad")
             fan, tok = ctx.fan_token, ctx.res_token
             if fan is not None:
@@ -444,7 +479,7 @@ def _split_backward_impl(ctx, xs, wc, dout):
             # f32 - then the gather over the offsets that reach each input row (as the bf16 path, u3d_tap_gather_sum; the
             # output-stationary form runs all K x 3 products for every input row, 15/16 of them on absent neighbours at stride 4)
             tid = _split_table(g, "id", n_out, n_out)
-            wt3 = nv.split3_weights(wc, ctx.layout, nmajor=False).view(3, kvol * cin, cout)      # [K, Cin, Cout] as ONE [K * Cin, Cout] matrix
+            wt3 = nv.split3_weights(wc, ctx.layout, nmajor=False, cache=getattr(ctx, "split3", None)).view(3, kvol * cin, cout)      # [K, Cin, Cout] as ONE [K * Cin, Cout] matrix
             prod = nv.spconv_fwd_split(dys, wt3, tid, g.n_out_dev, n_out, kvol * cin, tag="spconv_dgrad")
             din = nv.tap_gather_sum(prod, g.nbr_bwd, g.n_in_dev, g.n_in, cin, kvol)
             fused_add = False
@@ -459,7 +494,7 @@ def _split_backward_impl(ctx, xs, wc, dout):
                 add = facc
             fused_add = SPLIT_FUSED_ADD and (add is None or (add.dtype == torch.float32 and add.is_contiguous() and tuple(add.shape) == (g.n_in, cin)))
             t3 = _split_table(g, "bwd", g.n_in, n_out)
-            din = nv.spconv_fwd_split(dys, nv.split3_weights(wc, ctx.layout, nmajor=False), t3, g.n_in_dev, g.n_in, cin, tag="spconv_dgrad",
+            din = nv.spconv_fwd_split(dys, nv.split3_weights(wc, ctx.layout, nmajor=False, cache=getattr(ctx, "split3", None)), t3, g.n_in_dev, g.n_in, cin, tag="spconv_dgrad",
                                       addend=add if fused_add else None)
         fan = ctx.fan_token
         tok = ctx.res_token
@@ -539,7 +574,14 @@ class _BNRows(torch.autograd.Function):
         if post_add is not None:
             assert relu and residual is None and post_add.shape == x.shape and post_add.dtype == x.dtype
             post_add = post_add.contiguous()
-        y = nv.bn_apply(x, mean, invstd, g32, b32, residual, relu, n_dev, row_map, post_add)
+        # split-bf16 scope, f32 rows: the pass also writes y's hi / lo bf16 planes for the convolution that reads y next, and the backward
+        # will write the planes of dx for the convolution that produced x (u3d_bn_apply_planes / u3d_bn_bwd_apply_planes)
+        ctx.planes = bool(BN_PLANES and _SPLIT[0] and x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 16 == 0)
+        if ctx.planes:
+            y, ypl = nv.bn_apply(x, mean, invstd, g32, b32, residual, relu, n_dev, row_map, post_add, want_planes=True)
+            _give_planes(y, ypl)
+        else:
+            y = nv.bn_apply(x, mean, invstd, g32, b32, residual, relu, n_dev, row_map, post_add)
         # ReLU without residual: the backward recomputes the mask from x (same expression) instead of streaming y again
         ctx.remask = bool(relu and residual is None)
         ctx.save_for_backward(x, None if ctx.remask else y, mean, invstd, g32, b32)
@@ -566,12 +608,12 @@ class _BNRows(torch.autograd.Function):
             sums, s32 = nv.bn_bwd_finalize_partials(part[0], part[1], ctx.n_dev, x.shape[0])
         else:
             sums, s32 = nv.bn_bwd_stats(dy, y, x, mean, invstd, ctx.relu, ctx.n_dev, gamma, beta, ctx.row_map, want_f32=True)
-        if not ctx.training:
-            # eval statistics are constants: dx = gamma*invstd*g
-            zero = torch.zeros_like(sums)
-            dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, zero, ctx.relu, ctx.n_dev, ctx.has_res, beta, ctx.row_map)
+        use = sums if ctx.training else torch.zeros_like(sums)       # eval statistics are constants: dx = gamma*invstd*g
+        if getattr(ctx, "planes", False):
+            dx, dres, dpl = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, use, ctx.relu, ctx.n_dev, ctx.has_res, beta, ctx.row_map, want_planes=True)
+            _give_bwd_planes(dx, dpl)
         else:
-            dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, ctx.relu, ctx.n_dev, ctx.has_res, beta, ctx.row_map)
+            dx, dres = nv.bn_bwd_apply(dy, y, x, mean, invstd, gamma, use, ctx.relu, ctx.n_dev, ctx.has_res, beta, ctx.row_map)
         if ctx.pdtype != torch.float32:
             s32 = s32.to(ctx.pdtype)
         if ctx.res_token is not None and dres is not None:
