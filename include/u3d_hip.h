@@ -188,6 +188,18 @@ int32_t u3d_split3_weights(const float* src, int64_t sk, int64_t sa, int64_t sb,
 /* The same for every convolution weight of a step in ONE launch.  jobs: device array of njobs records of u3d_split3_job_bytes() bytes,
  * natural C layout { const float* src; void* dst; int64_t sk, sa, sb; int32_t k, a, b, first_block; }, first_block = sum of
  * u3d_split3_job_blocks(k, a, b) over the jobs before this one; total_blocks = that sum over all jobs. */
+/* hi / lo bf16 planes (as u3d_split_rows_f32, all rows live) of up to 32 strided f32 row matrices in one launch; `jobs` is a HOST
+ * structure (its contents travel in the kernel arguments; first_block is filled by the call). */
+typedef struct U3dSplitRowsJobs {
+  const float* src[32];
+  void* dst[32];
+  int32_t ld[32], rows[32], cols[32];
+  int32_t first_block[33];
+  int32_t njobs;
+} U3dSplitRowsJobs;
+int32_t u3d_split_rows_batch(const U3dSplitRowsJobs* jobs, u3d_stream s);
+/* out = (a + b) + c over n f32 elements (n % 4 == 0, 16-byte aligned): the three partial weight gradients of a split-bf16 product. */
+int32_t u3d_sum3_f32(const float* a, const float* b, const float* c, float* out, int64_t n, u3d_stream s);
 int64_t u3d_split3_job_bytes(void);
 int32_t u3d_split3_job_blocks(int32_t k, int32_t a, int32_t b);
 int32_t u3d_split3_weights_batch(const void* jobs, int32_t njobs, int32_t total_blocks, u3d_stream s);

@@ -1306,3 +1306,20 @@ def test_weight_splits_of_a_step_in_one_launch(cuda):
     with sp.split_scope(True, own):
         assert len(own.entries) == 4 and own.njobs == 4
     torch.cuda.synchronize()
+
+
+def test_batched_row_split_and_three_way_sum(cuda):
+    """u3d_split_rows_batch (several strided f32 row matrices -> hi / lo planes in one launch; > 32 jobs = several launches) against
+    u3d_split_rows_f32 on contiguous copies; u3d_sum3_f32 against (a + b) + c."""
+    torch.manual_seed(2)
+    big = torch.randn(700, 1024, device=cuda) * torch.logspace(-4, 4, 1024, device=cuda)
+    views = [big[:, o:o + w] for o, w in ((0, 256), (256, 512), (768, 4), (772, 12), (784, 240))] + [torch.randn(33, 64, device=cuda)]
+    views = views * 7                                       # 42 jobs: two launches
+    got = nv.split_rows_batch(views)
+    for v, g in zip(views, got):
+        nd = torch.tensor([v.shape[0]], dtype=torch.int32, device=cuda)
+        assert torch.equal(g, nv.split_rows(v.contiguous(), nd))
+    a, b, c = (torch.randn(27, 64, 128, device=cuda) for _ in range(3))
+    assert torch.equal(nv.sum3(a, b, c), (a + b) + c)
+    two = torch.randn(54, 64, 128, device=cuda)
+    assert torch.equal(nv.sum3(two[:27], two[27:], c), (two[:27] + two[27:]) + c)

@@ -1492,6 +1492,57 @@ __global__ __launch_bounds__(256) void k_split3_weights_batch(const U3dSplit3Job
     jb.dst[i] = h; jb.dst[n + i] = l; jb.dst[2 * n + i] = h;
   }
 }
+// hi / lo planes of up to 32 (possibly strided) f32 row matrices in ONE launch (the decoder's parameter-gradient operands in `parity`
+// mode: ~30 tensors of 7 200 rows per layer, each of which was a copy + a u3d_split_rows_f32 launch of ~6 us).  The job list travels
+// BY VALUE in the kernel arguments: the sources are slots of per-step workspaces, so nothing about it can be uploaded ahead of time.
+// (U3dSplitRowsJobs: include/u3d_hip.h - row r of job j starts at src[j] + r * ld[j]; dst[j] bf16 [2 * rows[j]][cols[j]], hi plane then lo
+//  plane; blocks [first_block[j], first_block[j + 1]) work on job j, 1024 elements per block)
+__global__ __launch_bounds__(256) void k_split_rows_batch(const U3dSplitRowsJobs jb) {
+  int j = 0;
+  while (j + 1 < jb.njobs && jb.first_block[j + 1] <= (int)blockIdx.x) ++j;
+  const int cols = jb.cols[j], c4 = cols >> 2;
+  const long long n4 = (long long)jb.rows[j] * c4, plane = (long long)jb.rows[j] * cols;
+  const long long i = (long long)((int)blockIdx.x - jb.first_block[j]) * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int r = (int)(i / c4), c = (int)(i % c4) * 4;
+  const f32x4 v = *(const f32x4*)(jb.src[j] + (long long)r * jb.ld[j] + c);
+  const bf16x4 h = __builtin_convertvector(v, bf16x4);
+  const bf16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4);
+  u16* d = (u16*)jb.dst[j] + (long long)r * cols + c;
+  *(bf16x4*)d = h;
+  *(bf16x4*)(d + plane) = l;
+}
+// jobs->first_block is filled here (cols % 4 == 0, 16-byte aligned rows); njobs <= 32
+extern "C" int32_t u3d_split_rows_batch(const U3dSplitRowsJobs* jobs, u3d_stream s) {
+  U3D_REQUIRE(jobs && jobs->njobs > 0 && jobs->njobs <= 32, U3D_ERR_ARG);
+  U3dSplitRowsJobs jb = *jobs;
+  int fb = 0;
+  for (int j = 0; j < jb.njobs; ++j) {
+    U3D_REQUIRE(jb.src[j] && jb.dst[j] && jb.cols[j] > 0 && jb.cols[j] % 4 == 0 && jb.ld[j] % 4 == 0 && jb.rows[j] >= 0, U3D_ERR_ARG);
+    jb.first_block[j] = fb;
+    fb += (int)(((long long)jb.rows[j] * (jb.cols[j] / 4) + 255) / 256);
+  }
+  jb.first_block[jb.njobs] = fb;
+  if (fb == 0) return U3D_OK;
+  hipLaunchKernelGGL(k_split_rows_batch, dim3(fb), dim3(256), 0, s, jb);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
+// dW of a split-bf16 product = the sum of its three bf16 products' f32 weight gradients (x^T dy ~ xh^T dyh + xl^T dyh + xh^T dyl):
+// one pass instead of two element-wise additions
+__global__ __launch_bounds__(256) void k_sum3_f32(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                  float* __restrict__ out, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+    *(f32x4*)(out + i * 4) = (*(const f32x4*)(a + i * 4) + *(const f32x4*)(b + i * 4)) + *(const f32x4*)(c + i * 4);
+}
+extern "C" int32_t u3d_sum3_f32(const float* a, const float* b, const float* c, float* out, int64_t n, u3d_stream s) {
+  U3D_REQUIRE(a && b && c && out && n >= 0 && n % 4 == 0, U3D_ERR_ARG);
+  if (n == 0) return U3D_OK;
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(k_sum3_f32, dim3((int)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048)), dim3(256), 0, s, a, b, c, out, n4);
+  U3D_CHECK_LAUNCH();
+  return U3D_OK;
+}
 extern "C" int64_t u3d_split3_job_bytes(void) { return (int64_t)sizeof(U3dSplit3Job); }
 extern "C" int32_t u3d_split3_job_blocks(int32_t k, int32_t a, int32_t b) {
   const long long n = (long long)k * a * b;

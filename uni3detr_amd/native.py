@@ -109,6 +109,8 @@ _SIGS = {
     "u3d_igemm_fwd_split_bf16": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "u3d_split_rows_f32": (_I, [_P, _P, _I, _I, _P, _P]),
     "u3d_split3_weights": (_I, [_P, C.c_int64, C.c_int64, C.c_int64, _I, _I, _I, _P, _P]),
+    "u3d_sum3_f32": (_I, [_P, _P, _P, _P, C.c_int64, _P]),
+    "u3d_split_rows_batch": (_I, [_P, _P]),
     "u3d_split3_job_bytes": (C.c_int64, []),
     "u3d_split3_job_blocks": (_I, [_I, _I, _I]),
     "u3d_split3_weights_batch": (_I, [_P, _I, _I, _P]),
@@ -729,6 +731,43 @@ def spconv_fwd_split_direct(xs, w3, nbr, n_out_dev, n_out, cout, tag="spconv_fwd
             meta = dict(kind=CALL_KIND, v2=True, split=True, n_in=n_in, n_out=n_out, cin=cin, cout=cout, kvol=27, pairs=pairs,
                         bytes=n_in * cin * 4 + n_out * cout * 4 + 8 * pairs + 27 * cin * cout * 4, flops=2 * pairs * cin * cout)
         t.end(tag, e0, meta)
+    return out
+
+
+class _SplitRowsJobs(C.Structure):
+    _fields_ = [("src", C.c_void_p * 32), ("dst", C.c_void_p * 32), ("ld", C.c_int32 * 32), ("rows", C.c_int32 * 32), ("cols", C.c_int32 * 32),
+                ("first_block", C.c_int32 * 33), ("njobs", C.c_int32)]
+
+
+def split_rows_batch_into(tensors, outs):
+    """hi / lo bf16 planes of several f32 row matrices (2-D, unit column stride, any row stride) in one launch per 32 of them
+    (u3d_split_rows_batch); outs[i]: bf16 [2 * rows, cols] (hi plane, then lo plane), written here."""
+    for i in range(0, len(tensors), 32):
+        jobs = _SplitRowsJobs()
+        chunk = list(zip(tensors[i:i + 32], outs[i:i + 32]))
+        jobs.njobs = len(chunk)
+        for j, (t, o) in enumerate(chunk):
+            assert t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[1] % 4 == 0 and t.stride(0) % 4 == 0
+            assert o.dtype == torch.bfloat16 and o.is_contiguous() and tuple(o.shape) == (2 * t.shape[0], t.shape[1])
+            jobs.src[j], jobs.dst[j] = t.data_ptr(), o.data_ptr()
+            jobs.ld[j], jobs.rows[j], jobs.cols[j] = t.stride(0), t.shape[0], t.shape[1]
+        _check(lib().u3d_split_rows_batch(C.byref(jobs), _stream()), "split_rows_batch")
+
+
+def split_rows_batch(tensors):
+    outs = [torch.empty((2 * t.shape[0], t.shape[1]), dtype=torch.bfloat16, device=t.device) for t in tensors]
+    split_rows_batch_into(tensors, outs)
+    return outs
+
+
+def sum3(a, b, c):
+    """(a + b) + c for three contiguous f32 tensors of one shape, one launch (u3d_sum3_f32)."""
+    assert a.shape == b.shape == c.shape and a.dtype == b.dtype == c.dtype == torch.float32
+    a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
+    if a.numel() % 4 != 0 or not a.is_cuda:
+        return a + b + c
+    out = torch.empty_like(a)
+    _check(lib().u3d_sum3_f32(_ptr(a), _ptr(b), _ptr(c), _ptr(out), a.numel(), _stream()), "sum3_f32")
     return out
 
 

@@ -337,12 +337,17 @@ class FusedLayerFn(torch.autograd.Function):
         # walks 7 200 rows on one offset) become one launch per shape.
         split_wg = et == torch.float32 and getattr(fd.decoder, "split_f32_wgrad", False)
         planes = {}
+        # every tensor that needs planes is split by ONE launch (u3d_split_rows_batch, strided slot views read in place) right before the
+        # batched weight-gradient launch that consumes them: a copy + a u3d_split_rows_f32 launch per tensor was ~90 launches per step
+        to_split = []
+        ok = lambda t: t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.shape[1] % 4 == 0 and t.data_ptr() % 16 == 0      # noqa: E731
 
         def hi_lo(t):
             key = id(t)
             if key not in planes:
-                t2 = t.contiguous()
-                pl = nv.split_rows(t2, nv.count_tensor(t2.shape[0], dev))
+                t2 = t if ok(t) else t.contiguous()
+                pl = torch.empty((2 * t2.shape[0], t2.shape[1]), dtype=torch.bfloat16, device=dev)
+                to_split.append((t2, pl))
                 planes[key] = (t, pl[:t2.shape[0]], pl[t2.shape[0]:])
             return planes[key][1], planes[key][2]
         grads = []
@@ -442,6 +447,8 @@ class FusedLayerFn(torch.autograd.Function):
                 skinny_now(dy, xin.contiguous(), dw)
                 sums_now.append((dy, db))
             grads += [dw, db]
+        if to_split:
+            nv.split_rows_batch_into([a for a, _ in to_split], [b_ for _, b_ in to_split])
         for (n, k), lst in wgrad_now.items():
             nv.wgrad_batched([a for a, _, _ in lst], [b_ for _, b_, _ in lst], [c for _, _, c in lst])
         groups = {}

@@ -448,8 +448,8 @@ def _split_backward_impl(ctx, xs, wc, dout):
         if ctx.needs_input_grad[1]:
             # three launches of the narrow weight-gradient kernels on plane views (the table indexes rows of a plane): no doubled table
             xh, xl, dyh, dyl = xs[:n_in], xs[n_in:], dys[:n_out], dys[n_out:]
-            dwk = nv.spconv_wgrad(xh, dyh, g.nbr_fwd, g.n_out_dev, kvol) + nv.spconv_wgrad(xl, dyh, g.nbr_fwd, g.n_out_dev, kvol)
-            dwk = (dwk + nv.spconv_wgrad(xh, dyl, g.nbr_fwd, g.n_out_dev, kvol)).reshape(ctx.kio_shape).to(ctx.wdtype)
+            dwk = nv.sum3(nv.spconv_wgrad(xh, dyh, g.nbr_fwd, g.n_out_dev, kvol), nv.spconv_wgrad(xl, dyh, g.nbr_fwd, g.n_out_dev, kvol),
+                          nv.spconv_wgrad(xh, dyl, g.nbr_fwd, g.n_out_dev, kvol)).reshape(ctx.kio_shape).to(ctx.wdtype)
             dw = dwk.permute(4, 3, 0, 1, 2) if ctx.layout == "oidhw" else dwk
         if ctx.needs_input_grad[0]:
             din = nv.spconv_fwd_split_direct(dys, nv.split3_weights(wc, ctx.layout, nmajor=False, cache=getattr(ctx, "split3", None)), g.nbr_bwd, g.n_in_dev, g.n_in, cin,
@@ -470,7 +470,7 @@ def _split_backward_impl(ctx, xs, wc, dout):
         tb = ta[:kvol]
         a = nv.spconv_wgrad(xs, dys[:n_out], ta, g.n_out_dev, 2 * kvol)                    # [2K, cin, cout]: xh^T dyh | xl^T dyh
         b = nv.spconv_wgrad(xs, dys[n_out:], tb, g.n_out_dev, kvol)                        # [K, cin, cout]: xh^T dyl
-        dwk = (a[:kvol] + a[kvol:] + b).reshape(ctx.kio_shape).to(ctx.wdtype)
+        dwk = nv.sum3(a[:kvol], a[kvol:], b).reshape(ctx.kio_shape).to(ctx.wdtype)
         dw = dwk.permute(4, 3, 0, 1, 2) if ctx.layout == "oidhw" else dwk
     if ctx.needs_input_grad[0]:
         if (STRIDED_DGRAD_SPLIT and g.strided and kvol > 1 and (kvol * cin) % 64 == 0
