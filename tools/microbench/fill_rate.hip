@@ -11,7 +11,8 @@
 //   run:   tools/microbench/fill_rate [iters]          (prints one table; gpurun_out/ copy -> profiles/r06_fill_rate.txt)
 //
 // Variants (template parameters):
-//   SRC    0 LDS-DMA (raw_ptr_buffer_load_lds, 16 B / lane), 1 global_load_dwordx4 into registers (no LDS write), 2 no loads
+//   SRC    0 LDS-DMA (raw_ptr_buffer_load_lds, 16 B / lane), 1 global_load_dwordx4 into registers (no LDS write), 2 no loads,
+//          3 activations by LDS-DMA, WEIGHTS by global loads straight into the MFMA operand registers (fragment-packed: no LDS traffic for B)
 //   WIN    activation rows folded into a 1024-row window (L2-resident: 512 KiB) instead of the layer's real stream (98 MB)
 //   READS  the 24 ds_read_b128 fragment reads per wave and k-tile of the real loop
 //   MFMA   0 none, 1: 64 x v_mfma_f32_16x16x32_bf16 per wave and k-tile, 2: 32 x v_mfma_f32_32x32x16_bf16 (same flops)
@@ -108,13 +109,23 @@ __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const 
     for (int u = 0; u < 2; ++u) {
       const int iv = idx_cur[sp][u];
       const unsigned voff = iv >= 0 ? (unsigned)(WIN ? (iv & 1023) : iv) * row_bytes + a_part16[u] : 0xFFFFFFFFu;
-      if constexpr (SRC == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void_ptr)(dst + u * 512), 16, voff, soff, 0, 0);
+      if constexpr (SRC == 0 || SRC == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void_ptr)(dst + u * 512), 16, voff, soff, 0, 0);
       else if constexpr (SRC == 1) {
         hold[buf][sp * 2 + u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rs, voff, soff, 0));
       }
     }
   };
   auto issue_b = [&](int st, int buf, int sp) {
+    if constexpr (SRC == 3) {
+      // B operand straight into registers: fragment-packed weights, this wave's 64 columns x 64 k of the k-tile = 8 blocks of 1 KiB
+      // (wave columns share their blocks through L1 / L2; the two calls per k-tile fetch four blocks each)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned off = (unsigned)((((st * 4 + wn) * 8) + sp * 4 + j) * 1024 + lane * 16);
+        hold[buf][sp * 4 + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, off, 0, 0));
+      }
+      return;
+    }
     const unsigned soff = (unsigned)((st % kvol) * cin * cout + (st / kvol) * BK) * 2u;
     u16* dst = smem + buf * STAGE_ELEMS + (2 + sp) * PIECE + wv * 1024;
 #pragma unroll
@@ -191,7 +202,10 @@ __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const 
 #pragma unroll
           for (int a = 0; a < 8; ++a) af[a] = frag(A + (a >> 2) * PIECE + (a & 3) * 16 * BK, ks);
 #pragma unroll
-          for (int b = 0; b < 4; ++b) bfr[b] = frag(B + (b >> 1) * PIECE + (b & 1) * 16 * BK, ks);
+          for (int b = 0; b < 4; ++b) {
+            if constexpr (SRC == 3) bfr[b] = __builtin_bit_cast(bf16x8, hold[buf][ks * 4 + b]);
+            else bfr[b] = frag(B + (b >> 1) * PIECE + (b & 1) * 16 * BK, ks);
+          }
         } else {
 #pragma unroll
           for (int a = 0; a < 8; ++a) af[a] = ra[a];
@@ -223,7 +237,8 @@ __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const 
     if (SRC != 2) {
       __builtin_amdgcn_sched_barrier(0);
       advance_idx();                                        // (hipcc waits for the indices here: vmcnt(8))
-      __builtin_amdgcn_s_waitcnt(0x0F78);                   // k-tile st and the index set requested this trip have landed; k-tile st + 1 stays in flight
+      if constexpr (SRC == 3) __builtin_amdgcn_s_waitcnt(0x0F7C);      // vmcnt(12): 4 LDS-DMA + 8 register loads of k-tile st + 1 stay in flight
+      else __builtin_amdgcn_s_waitcnt(0x0F78);              // k-tile st and the index set requested this trip have landed; k-tile st + 1 stays in flight
       if constexpr (SRC == 1) {                             // consume k-tile st (requested one trip ago): k-tile st + 1 stays in flight
 #pragma unroll
         for (int j = 0; j < 8; ++j) junk += hold[buf][j];
@@ -606,6 +621,8 @@ int main(int argc, char** argv) {
       {"dma_stream + reads + mfma16   (= the product loop, unscheduled)", k_fill<0, false, true, 1>, true, true},
       {"dma_stream + reads + mfma32", k_fill<0, false, true, 2>, true, true},
       {"dma_window + reads + mfma16", k_fill<0, true, true, 1>, true, true},
+      {"B FROM REGISTERS: A by LDS-DMA, B by global loads, A reads + mfma16", k_fill<3, false, true, 1>, true, true},
+      {"B FROM REGISTERS, no MFMA (A dma + B loads + A reads)", k_fill<3, false, true, 0>, true, false},
       {"ROLES: 4 waves MFMA only | 4 waves idle", k_roles<false, true, false>, false, true},
       {"ROLES: 4 waves MFMA | 4 waves DMA", k_roles<false, true, true>, true, true},
       {"ROLES: 4 waves MFMA | 4 waves DMA + all frag reads", k_roles<true, true, true>, true, true},
