@@ -39,7 +39,7 @@ __device__ __forceinline__ int xcd_tile(int block, int live_tiles) {       // = 
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-template <int SRC, bool WIN, bool READS, int MFMA>
+template <int SRC, bool WIN, bool READS, int MFMA, int SPREAD = 0>
 __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr, int ld,
                                               int n_out, int cin, int cout, int kvol, float* __restrict__ sink,
                                               unsigned long long* __restrict__ clk) {
@@ -136,6 +136,18 @@ __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const 
       }
     }
   };
+  auto issue_a1 = [&](int st, int buf, int sp, int u) {
+    const unsigned soff = (unsigned)((st / kvol) * BK) * 2u;
+    u16* dst = smem + buf * STAGE_ELEMS + sp * PIECE + wv * 1024;
+    const int iv = idx_cur[sp][u];
+    const unsigned voff = iv >= 0 ? (unsigned)(WIN ? (iv & 1023) : iv) * row_bytes + a_part16[u] : 0xFFFFFFFFu;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void_ptr)(dst + u * 512), 16, voff, soff, 0, 0);
+  };
+  auto issue_b1 = [&](int st, int buf, int sp, int u) {
+    const unsigned soff = (unsigned)((st % kvol) * cin * cout + (st / kvol) * BK) * 2u;
+    u16* dst = smem + buf * STAGE_ELEMS + (2 + sp) * PIECE + wv * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_void_ptr)(dst + u * 512), 16, w_voff[sp][u], soff, 0, 0);
+  };
   const int g = lane >> 4, li = lane & 15, fsw = (lane >> 1) & 7;
   int foff[2];
 #pragma unroll
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const 
   };
   f32x4 acc[8][4];
   f32x16 acc2[4][2];
-  if constexpr (MFMA == 1) {
+  if constexpr (MFMA == 1 || MFMA == 3) {
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
@@ -190,8 +202,53 @@ __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const 
     if (SRC != 2) {
       load_idx_next(st + 2 < nstage ? st + 2 : nstage - 1);
       __builtin_amdgcn_sched_barrier(0);
-      issue_a(nx, buf ^ 1, 0); issue_b(nx, buf ^ 1, 0); issue_b(nx, buf ^ 1, 1); issue_a(nx, buf ^ 1, 1);
+      if constexpr (SPREAD == 0) { issue_a(nx, buf ^ 1, 0); issue_b(nx, buf ^ 1, 0); issue_b(nx, buf ^ 1, 1); issue_a(nx, buf ^ 1, 1); }
     }
+    if constexpr (MFMA == 3) {
+      // software-pipelined fragment reads (hipcc's own order for the plain loop is read -> s_waitcnt lgkmcnt(0) -> 8 MFMAs, i.e. every
+      // group of 8 MFMAs waits out an LDS round trip): the B fragment of group g + 1 and, in the last groups of a k-step, the A fragments
+      // of the next k-step are requested BEFORE the MFMAs of group g, pinned by scheduling barriers
+      const u16* A = smem + buf * STAGE_ELEMS + (wm * 64 + li) * BK;
+      const u16* B = smem + buf * STAGE_ELEMS + 2 * PIECE + (wn * 32 + li) * BK;
+      bf16x8 afp[2][8], bcur, bnxt;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) afp[0][a] = frag(A + (a >> 2) * PIECE + (a & 3) * 16 * BK, 0);
+      bcur = frag(B, 0);
+#pragma unroll
+      for (int g8 = 0; g8 < 8; ++g8) {                      // group = (k-step, column block)
+        const int ks = g8 >> 2, b = g8 & 3;
+        if (g8 + 1 < 8) {
+          const int ks1 = (g8 + 1) >> 2, b1 = (g8 + 1) & 3;
+          bnxt = frag(B + (b1 >> 1) * PIECE + (b1 & 1) * 16 * BK, ks1);
+        }
+        if (ks == 0) {                                      // two A fragments of k-step 1 per group of k-step 0
+          afp[1][2 * b] = frag(A + ((2 * b) >> 2) * PIECE + ((2 * b) & 3) * 16 * BK, 1);
+          afp[1][2 * b + 1] = frag(A + ((2 * b + 1) >> 2) * PIECE + ((2 * b + 1) & 3) * 16 * BK, 1);
+        }
+        if constexpr (SPREAD != 0 && SRC == 0) {
+          // the next k-tile's 8 LDS-DMA requests dealt out behind the MFMA groups instead of one burst at the top of the trip (a wave that
+          // issues a request is blocked ~100 clocks; in a burst both waves of a SIMD are blocked together and the matrix pipe idles):
+          // 1: one per group; 2: two per group in the first four groups; 3: as 2, the second wave row two groups later
+          const int slot = SPREAD == 1 ? g8 : (SPREAD == 2 ? (g8 < 4 ? g8 : -1) : ((g8 - 2 * wm >= 0 && g8 - 2 * wm < 4) ? g8 - 2 * wm : -1));
+          if (SPREAD == 1) {
+            if (slot == 0) issue_a1(nx, buf ^ 1, 0, 0); if (slot == 1) issue_a1(nx, buf ^ 1, 0, 1);
+            if (slot == 2) issue_b1(nx, buf ^ 1, 0, 0); if (slot == 3) issue_b1(nx, buf ^ 1, 0, 1);
+            if (slot == 4) issue_b1(nx, buf ^ 1, 1, 0); if (slot == 5) issue_b1(nx, buf ^ 1, 1, 1);
+            if (slot == 6) issue_a1(nx, buf ^ 1, 1, 0); if (slot == 7) issue_a1(nx, buf ^ 1, 1, 1);
+          } else {
+            if (slot == 0) issue_a(nx, buf ^ 1, 0);
+            if (slot == 1) issue_b(nx, buf ^ 1, 0);
+            if (slot == 2) issue_b(nx, buf ^ 1, 1);
+            if (slot == 3) issue_a(nx, buf ^ 1, 1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur, afp[ks][a], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bcur = bnxt;
+      }
+    } else
     if constexpr (READS || MFMA) {
       const u16* A = smem + buf * STAGE_ELEMS + (wm * 64 + li) * BK;
       const u16* B = smem + buf * STAGE_ELEMS + 2 * PIECE + (wn * 32 + li) * BK;
@@ -237,7 +294,8 @@ __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const 
     if (SRC != 2) {
       __builtin_amdgcn_sched_barrier(0);
       advance_idx();                                        // (hipcc waits for the indices here: vmcnt(8))
-      if constexpr (SRC == 3) __builtin_amdgcn_s_waitcnt(0x0F7C);      // vmcnt(12): 4 LDS-DMA + 8 register loads of k-tile st + 1 stay in flight
+      if constexpr (SPREAD != 0) __builtin_amdgcn_s_waitcnt(0x0F70);      // spread requests: k-tile st + 1 was requested DURING this trip and is read right after the barrier
+      else if constexpr (SRC == 3) __builtin_amdgcn_s_waitcnt(0x0F7C);      // vmcnt(12): 4 LDS-DMA + 8 register loads of k-tile st + 1 stay in flight
       else __builtin_amdgcn_s_waitcnt(0x0F78);              // k-tile st and the index set requested this trip have landed; k-tile st + 1 stays in flight
       if constexpr (SRC == 1) {                             // consume k-tile st (requested one trip ago): k-tile st + 1 stays in flight
 #pragma unroll
@@ -252,7 +310,7 @@ __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const 
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   float s = junk[0] + junk[1] + junk[2] + junk[3];
-  if constexpr (MFMA == 1) {
+  if constexpr (MFMA == 1 || MFMA == 3) {
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
@@ -621,6 +679,11 @@ int main(int argc, char** argv) {
       {"dma_stream + reads + mfma16   (= the product loop, unscheduled)", k_fill<0, false, true, 1>, true, true},
       {"dma_stream + reads + mfma32", k_fill<0, false, true, 2>, true, true},
       {"dma_window + reads + mfma16", k_fill<0, true, true, 1>, true, true},
+      {"dma_stream + PIPELINED reads + mfma16 (fragments one group ahead)", k_fill<0, false, true, 3>, true, true},
+      {"PIPELINED reads + mfma16 (no loads)", k_fill<2, false, true, 3>, false, true},
+      {"PIPELINED + LDS-DMA spread: one request per MFMA group", k_fill<0, false, true, 3, 1>, true, true},
+      {"PIPELINED + LDS-DMA spread: two per group, first four groups", k_fill<0, false, true, 3, 2>, true, true},
+      {"PIPELINED + LDS-DMA spread: two per group, wave rows two groups apart", k_fill<0, false, true, 3, 3>, true, true},
       {"B FROM REGISTERS: A by LDS-DMA, B by global loads, A reads + mfma16", k_fill<3, false, true, 1>, true, true},
       {"B FROM REGISTERS, no MFMA (A dma + B loads + A reads)", k_fill<3, false, true, 0>, true, false},
       {"ROLES: 4 waves MFMA only | 4 waves idle", k_roles<false, true, false>, false, true},

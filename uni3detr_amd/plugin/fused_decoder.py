@@ -25,7 +25,7 @@ ENABLED = True         # test-only module attribute: the GPU tests set it False 
 # volume to zero and cast: -0.07 ms per step).  OPT-IN: every add rounds to 8 mantissa bits, and all 3 layers x 3 query groups land in one
 # buffer - with queries clustered on objects a cell collects hundreds of contributions and the result drifts 9 % from the f32
 # accumulator (tests/test_decoder_gpu.py::test_packed_bf16_volume_gradient_scatter_vs_f32_accumulator; 0.7 % with spread queries).
-SHARED_DEFER = True     # shared linears' gradients summed by the deferred flush (0: autograd adds)
+SHARED_DEFER = True     # test-only module attribute: shared linears' gradients summed by the deferred flush (False: autograd adds them)
 PK_SCATTER = os.environ.get("U3D_PK_SCATTER", "0") == "1"
 POISON = os.environ.get("U3D_DEC_POISON", "0") == "1"      # debugging: NaN-fill the workspaces (read-before-write shows up as NaN)
 DEBUG_KEEP = None          # tests: a list that receives every backward call's gradient workspace
