@@ -39,7 +39,7 @@ __device__ __forceinline__ int xcd_tile(int block, int live_tiles) {       // = 
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-template <int SRC, bool WIN, bool READS, int MFMA, int SPREAD = 0>
+template <int SRC, bool WIN, bool READS, int MFMA, int SPREAD = 0, bool DEEP = false>
 __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const u16* __restrict__ w, const int* __restrict__ nbr, int ld,
                                               int n_out, int cin, int cout, int kvol, float* __restrict__ sink,
                                               unsigned long long* __restrict__ clk) {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const 
     if (SRC != 2) {
       load_idx_next(st + 2 < nstage ? st + 2 : nstage - 1);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SPREAD == 0) { issue_a(nx, buf ^ 1, 0); issue_b(nx, buf ^ 1, 0); issue_b(nx, buf ^ 1, 1); issue_a(nx, buf ^ 1, 1); }
+      if constexpr (SPREAD == 0 || SPREAD >= 4) { issue_a(nx, buf ^ 1, 0); issue_b(nx, buf ^ 1, 0); issue_b(nx, buf ^ 1, 1); issue_a(nx, buf ^ 1, 1); }
     }
     if constexpr (MFMA == 3) {
       // software-pipelined fragment reads (hipcc's own order for the plain loop is read -> s_waitcnt lgkmcnt(0) -> 8 MFMAs, i.e. every
@@ -210,13 +210,20 @@ __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const 
       // of the next k-step are requested BEFORE the MFMAs of group g, pinned by scheduling barriers
       const u16* A = smem + buf * STAGE_ELEMS + (wm * 64 + li) * BK;
       const u16* B = smem + buf * STAGE_ELEMS + 2 * PIECE + (wn * 32 + li) * BK;
-      bf16x8 afp[2][8], bcur, bnxt;
+      bf16x8 afp[2][8], bcur, bnxt, bnn;
 #pragma unroll
       for (int a = 0; a < 8; ++a) afp[0][a] = frag(A + (a >> 2) * PIECE + (a & 3) * 16 * BK, 0);
       bcur = frag(B, 0);
+      if constexpr (SPREAD == 5) bnxt = frag(B + 16 * BK, 0);
 #pragma unroll
       for (int g8 = 0; g8 < 8; ++g8) {                      // group = (k-step, column block)
         const int ks = g8 >> 2, b = g8 & 3;
+        if constexpr (SPREAD == 5) {                        // B fragments TWO groups ahead
+          if (g8 + 2 < 8) {
+            const int ks1 = (g8 + 2) >> 2, b1 = (g8 + 2) & 3;
+            bnn = frag(B + (b1 >> 1) * PIECE + (b1 & 1) * 16 * BK, ks1);
+          }
+        } else
         if (g8 + 1 < 8) {
           const int ks1 = (g8 + 1) >> 2, b1 = (g8 + 1) & 3;
           bnxt = frag(B + (b1 >> 1) * PIECE + (b1 & 1) * 16 * BK, ks1);
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const 
           afp[1][2 * b] = frag(A + ((2 * b) >> 2) * PIECE + ((2 * b) & 3) * 16 * BK, 1);
           afp[1][2 * b + 1] = frag(A + ((2 * b + 1) >> 2) * PIECE + ((2 * b + 1) & 3) * 16 * BK, 1);
         }
-        if constexpr (SPREAD != 0 && SRC == 0) {
+        if constexpr (SPREAD != 0 && SPREAD < 4 && SRC == 0) {
           // the next k-tile's 8 LDS-DMA requests dealt out behind the MFMA groups instead of one burst at the top of the trip (a wave that
           // issues a request is blocked ~100 clocks; in a burst both waves of a SIMD are blocked together and the matrix pipe idles):
           // 1: one per group; 2: two per group in the first four groups; 3: as 2, the second wave row two groups later
@@ -243,10 +250,13 @@ __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const 
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SPREAD == 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int a = 0; a < 8; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur, afp[ks][a], acc[a][b], 0, 0, 0);
+        if constexpr (SPREAD == 4) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         bcur = bnxt;
+        if constexpr (SPREAD == 5) bnxt = bnn;
       }
     } else
     if constexpr (READS || MFMA) {
@@ -294,9 +304,12 @@ __global__ __launch_bounds__(512) void k_fill(const u16* __restrict__ in, const 
     if (SRC != 2) {
       __builtin_amdgcn_sched_barrier(0);
       advance_idx();                                        // (hipcc waits for the indices here: vmcnt(8))
-      if constexpr (SPREAD != 0) __builtin_amdgcn_s_waitcnt(0x0F70);      // spread requests: k-tile st + 1 was requested DURING this trip and is read right after the barrier
+      // k-tile st + 1 was requested during THIS trip and is read right after the barrier: with two stage buffers nothing may stay in
+      // flight across it (the first version of this program waited vmcnt(8) here - one k-tile too few: timing-only, but a trip more of
+      // latency tolerance than a correct kernel has; the DEEP variants keep that discipline on purpose to price it)
+      if constexpr (SRC == 0 && !DEEP) __builtin_amdgcn_s_waitcnt(0x0F70);
       else if constexpr (SRC == 3) __builtin_amdgcn_s_waitcnt(0x0F7C);      // vmcnt(12): 4 LDS-DMA + 8 register loads of k-tile st + 1 stay in flight
-      else __builtin_amdgcn_s_waitcnt(0x0F78);              // k-tile st and the index set requested this trip have landed; k-tile st + 1 stays in flight
+      else __builtin_amdgcn_s_waitcnt(0x0F78);
       if constexpr (SRC == 1) {                             // consume k-tile st (requested one trip ago): k-tile st + 1 stays in flight
 #pragma unroll
         for (int j = 0; j < 8; ++j) junk += hold[buf][j];
@@ -683,7 +696,10 @@ int main(int argc, char** argv) {
       {"PIPELINED reads + mfma16 (no loads)", k_fill<2, false, true, 3>, false, true},
       {"PIPELINED + LDS-DMA spread: one request per MFMA group", k_fill<0, false, true, 3, 1>, true, true},
       {"PIPELINED + LDS-DMA spread: two per group, first four groups", k_fill<0, false, true, 3, 2>, true, true},
-      {"PIPELINED + LDS-DMA spread: two per group, wave rows two groups apart", k_fill<0, false, true, 3, 3>, true, true},
+      {"PIPELINED, one k-tile MORE in flight than two buffers allow (timing only)", k_fill<0, false, true, 3, 0, true>, true, true},
+      {"unscheduled loop, one k-tile more in flight (timing only)", k_fill<0, false, true, 1, 0, true>, true, true},
+      {"PIPELINED + s_setprio(1) around the MFMA groups", k_fill<0, false, true, 3, 4>, true, true},
+      {"PIPELINED, B fragments two groups ahead", k_fill<0, false, true, 3, 5>, true, true},
       {"B FROM REGISTERS: A by LDS-DMA, B by global loads, A reads + mfma16", k_fill<3, false, true, 1>, true, true},
       {"B FROM REGISTERS, no MFMA (A dma + B loads + A reads)", k_fill<3, false, true, 0>, true, false},
       {"ROLES: 4 waves MFMA only | 4 waves idle", k_roles<false, true, false>, false, true},
