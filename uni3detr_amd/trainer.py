@@ -351,6 +351,7 @@ class TrainStep:
         with _T.deferred_param_grads():
             loss.backward()
         self.loss = loss.detach()
+        self._gbb = None
         if bcut is not None:                         # the backward stopped at SECOND3D's outputs: phase M continues from their gradients
             self._pack(self.n_bb_end, len(self.params))
             self._gbb = [t.grad for t in bcut]
@@ -364,6 +365,8 @@ class TrainStep:
     def _stage2m(self):
         """Phase M (three-phase backward): SECOND3D's backward from the gradients of its three outputs down to the encoder cut."""
         m = self.model
+        if getattr(self, "_gbb", None) is None or m._backbone_out is None:
+            return                       # the forward made no second cut (nothing behind SECOND3D required a gradient): phase A did it all
         cut = m._encoder_cut
         outs, gs = [], []
         for o, g in zip(m._backbone_out, self._gbb):
