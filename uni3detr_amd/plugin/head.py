@@ -322,8 +322,8 @@ class Uni3DETRHead(nn.Module):
         iou_all = preds_dicts["all_iou_preds"].float()
         L, B, Q, C = cls_all.shape
         w, tgt, lab = T["w"], T["tgt"], T["lab"]
-        cls_avg = num_pos.clamp(min=1) if self.sync_cls_avg_factor else T["num_pos"].clamp(min=1)
         npos = num_pos.clamp(min=1)
+        cls_avg = npos if self.sync_cls_avg_factor else T["num_pos"].clamp(min=1)      # (one launch, not two, in the usual synced case)
         from .losses import IoU3DLoss, L1Loss, SoftFocalLoss, _EPS32
         if (FUSED_DET_LOSS and cls_all.is_cuda and type(self.loss_cls) is SoftFocalLoss and type(self.loss_bbox) is L1Loss
                 and type(self.loss_iou) is IoU3DLoss and self.loss_cls.reduction == self.loss_bbox.reduction == self.loss_iou.reduction == "mean"
