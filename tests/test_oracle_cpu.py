@@ -504,22 +504,26 @@ def test_dense_stack_gradient_conditioning():
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/projects/mmdet3d_plugin"), reason="the reference tree only exists in the build container")
-def test_round6_goldens_regenerate_bit_identically_from_the_reference(tmp_path):
-    """The pin itself: oracle/make_golden.py, run HERE against the reference's own files (second_3d.py, second3d_fpn.py,
-    sparse_encoder_hd.py, detectors/uni3detr.py, loaded where they lie through oracle/refshim.py), reproduces the committed
-    dense_stack / encoder_wiring / detector_glue fixtures bit for bit - array by array, names included."""
+def test_every_golden_regenerates_bit_identically_from_the_reference(tmp_path):
+    """The pin itself: oracle/make_golden.py, run HERE against the reference's own files (loaded where they lie through
+    oracle/refshim.py), reproduces every committed fixture bit for bit - array by array, names and dtypes included: the head / decoder /
+    matcher / loss / coder / cost fixtures of rounds 1-5 and the dense-stack / encoder-wiring / detector-glue fixtures of round 6."""
     import oracle.make_golden as mg
     from oracle import refshim as rs
-    nd = rs.load_dense_path()
     old = mg.OUT
     mg.OUT = str(tmp_path)
     try:
-        mg.gen_dense_stack(nd)
-        mg.gen_encoder_wiring(nd)
-        mg.gen_detector_glue(nd)
+        ns = rs.load_hot_path()
+        for gen in (mg.gen_small, mg.gen_head_train, mg.gen_head_eval, mg.gen_decode, mg.gen_head_variants, mg.gen_extra):
+            gen(ns)
+        nd = rs.load_dense_path()
+        for gen in (mg.gen_dense_stack, mg.gen_encoder_wiring, mg.gen_detector_glue):
+            gen(nd)
     finally:
         mg.OUT = old
-    for name in ("dense_stack.npz", "encoder_wiring.npz", "detector_glue.npz"):
+    names = sorted(f for f in os.listdir(G) if f.endswith(".npz"))
+    assert names == sorted(f for f in os.listdir(str(tmp_path)) if f.endswith(".npz")) and len(names) == 9
+    for name in names:
         a = np.load(os.path.join(G, name), allow_pickle=False)
         b = np.load(os.path.join(str(tmp_path), name), allow_pickle=False)
         assert sorted(a.files) == sorted(b.files), name
